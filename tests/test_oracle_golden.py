@@ -1,0 +1,285 @@
+"""Pin the CPU oracle (oracle/proxgrad_oracle.py) against the reference's own known answers.
+
+Mirrors: test/problems/test_lasso_small.jl, test_lasso_small_strongly_convex.jl,
+test/accel/test_lbfgs.jl, test/accel/test_nesterov.jl, test/utilities/test_fb_tools.jl,
+test/problems/test_equivalence.jl:51-84, test/problems/test_nonconvex_qp.jl:33-34 and the
+stored optima of benchmark/data/lasso_*.jld2.
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import reference_vectors as rv
+from oracle import proxgrad_oracle as o
+
+GOLDEN = os.path.dirname(os.path.abspath(rv.__file__))
+
+
+def lasso_small(dtype):
+    A = np.asfortranarray(rv.LASSO_SMALL_A.astype(dtype))
+    b = rv.LASSO_SMALL_B.astype(dtype)
+    R = np.dtype(dtype).type
+    lam = R(0.1) * R(np.max(np.abs(A.T @ b)))
+    Lf = R(np.linalg.norm(A, 2) ** 2)
+    return A, b, lam, Lf
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+class TestLassoSmall:
+    """test/problems/test_lasso_small.jl:46-135"""
+
+    def check(self, dtype, x, it, bound, x0):
+        assert x.dtype == dtype
+        assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+        assert it < bound
+        assert np.all(x0 == 0)
+
+    def test_fb_fixed(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.forward_backward(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=Lf)
+        self.check(dtype, x, it, rv.LASSO_SMALL_BOUNDS["fb_fixed"], x0)
+
+    def test_fb_adaptive(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.forward_backward(tol=rv.LASSO_SMALL_TOL, adaptive=True, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        self.check(dtype, x, it, rv.LASSO_SMALL_BOUNDS["fb_adaptive"], x0)
+
+    def test_fb_adaptive_regret(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.forward_backward(tol=rv.LASSO_SMALL_TOL, adaptive=True, increase_gamma=1.01, x0=x0,
+                                   f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        self.check(dtype, x, it, rv.LASSO_SMALL_BOUNDS["fb_adaptive_regret"], x0)
+
+    def test_ffb_fixed(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.fast_forward_backward(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=Lf)
+        self.check(dtype, x, it, rv.LASSO_SMALL_BOUNDS["ffb_fixed"], x0)
+
+    def test_ffb_adaptive(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.fast_forward_backward(tol=rv.LASSO_SMALL_TOL, adaptive=True, x0=x0, f=o.LeastSquares(A, b),
+                                        g=o.NormL1(lam))
+        self.check(dtype, x, it, rv.LASSO_SMALL_BOUNDS["ffb_adaptive"], x0)
+
+    def test_ffb_adaptive_regret(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.fast_forward_backward(tol=rv.LASSO_SMALL_TOL, adaptive=True, increase_gamma=1.01, x0=x0,
+                                        f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        self.check(dtype, x, it, rv.LASSO_SMALL_BOUNDS["ffb_adaptive_regret"], x0)
+
+    def test_ffb_custom_sequence(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.fast_forward_backward(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=Lf,
+                                        extrapolation_sequence=o.fixed_nesterov_sequence(dtype))
+        self.check(dtype, x, it, rv.LASSO_SMALL_BOUNDS["ffb_fixed_custom_seq"], x0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+class TestLassoStronglyConvex:
+    """test/problems/test_lasso_small_strongly_convex.jl:65-144"""
+
+    def setup_problem(self, dtype):
+        A, b, lam, x0 = rv.strongly_convex_problem(dtype)
+        return A, b, lam, x0, x0.copy()
+
+    def check(self, dtype, y, it, bound, x0, x0_backup):
+        assert y.dtype == dtype
+        assert np.max(np.abs(y - rv.SC_XSTAR.astype(dtype))) <= rv.SC_TOL
+        assert it < bound
+        assert np.array_equal(x0, x0_backup)
+
+    def test_fb(self, dtype):
+        A, b, lam, x0, bk = self.setup_problem(dtype)
+        y, it = o.forward_backward(tol=rv.SC_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=dtype(rv.SC_LF))
+        self.check(dtype, y, it, rv.SC_BOUNDS["fb_fixed"], x0, bk)
+
+    def test_fb_adaptive(self, dtype):
+        A, b, lam, x0, bk = self.setup_problem(dtype)
+        y, it = o.forward_backward(tol=rv.SC_TOL, adaptive=True, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        self.check(dtype, y, it, rv.SC_BOUNDS["fb_adaptive"], x0, bk)
+
+    def test_fb_adaptive_regret(self, dtype):
+        A, b, lam, x0, bk = self.setup_problem(dtype)
+        y, it = o.forward_backward(tol=rv.SC_TOL, adaptive=True, increase_gamma=1.01, x0=x0, f=o.LeastSquares(A, b),
+                                   g=o.NormL1(lam))
+        self.check(dtype, y, it, rv.SC_BOUNDS["fb_adaptive_regret"], x0, bk)
+
+    def test_ffb_mf(self, dtype):
+        A, b, lam, x0, bk = self.setup_problem(dtype)
+        y, it = o.fast_forward_backward(tol=rv.SC_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam),
+                                        Lf=dtype(rv.SC_LF), mf=dtype(rv.SC_MF))
+        self.check(dtype, y, it, rv.SC_BOUNDS["ffb_fixed_mf"], x0, bk)
+
+    def test_ffb_adaptive(self, dtype):
+        A, b, lam, x0, bk = self.setup_problem(dtype)
+        y, it = o.fast_forward_backward(tol=rv.SC_TOL, adaptive=True, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        self.check(dtype, y, it, rv.SC_BOUNDS["ffb_adaptive"], x0, bk)
+
+    def test_ffb_adaptive_regret(self, dtype):
+        A, b, lam, x0, bk = self.setup_problem(dtype)
+        y, it = o.fast_forward_backward(tol=rv.SC_TOL, adaptive=True, increase_gamma=1.01, x0=x0,
+                                        f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        self.check(dtype, y, it, rv.SC_BOUNDS["ffb_adaptive_regret"], x0, bk)
+
+    def test_ffb_constant_sequence(self, dtype):
+        A, b, lam, x0, bk = self.setup_problem(dtype)
+        mf, Lf = dtype(rv.SC_MF), dtype(rv.SC_LF)
+        y, it = o.fast_forward_backward(tol=rv.SC_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam),
+                                        gamma=dtype(1) / Lf, mf=mf,
+                                        extrapolation_sequence=o.constant_nesterov_sequence(mf, dtype(1) / Lf))
+        self.check(dtype, y, it, rv.SC_BOUNDS["ffb_constant_seq"], x0, bk)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lbfgs_golden_directions(dtype):
+    """test/accel/test_lbfgs.jl:103-133"""
+    Q, q = rv.LBFGS_Q.astype(dtype), rv.LBFGS_q.astype(dtype)
+    xs = rv.LBFGS_XS.astype(dtype)
+    H = o.LBFGSOperator(rv.LBFGS_MEM, np.zeros(10, dtype))
+    x = xs[0]
+    grad = Q @ x + q
+    d = -(H * grad)
+    rtol = 1e-4 if dtype == np.float32 else 1e-8  # Julia isapprox default rtol = sqrt(eps)
+    np.testing.assert_allclose(d, rv.LBFGS_DIRS_REF[0], rtol=rtol, atol=rtol * np.linalg.norm(rv.LBFGS_DIRS_REF[0]))
+    for i in range(1, 5):
+        x_prev, grad_prev = x, grad
+        x = xs[i]
+        grad = Q @ x + q
+        H.update(x - x_prev, grad - grad_prev)
+        H.mul(d, -grad)
+        ref = rv.LBFGS_DIRS_REF[i]
+        assert np.linalg.norm(d - ref) <= np.sqrt(np.finfo(dtype).eps) * max(np.linalg.norm(d), np.linalg.norm(ref))
+    H.reset()
+    assert np.array_equal(H * x, x)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("seq", ["simple", "fixed"])
+def test_nesterov_beck_teboulle_bound(dtype, seq):
+    """test/accel/test_nesterov.jl:12-61"""
+    R = np.dtype(dtype).type
+    Hm, l = rv.NESTEROV_H.astype(dtype), rv.NESTEROV_l.astype(dtype)
+    f = lambda x: np.dot(x, Hm @ x) / 2 + np.dot(x, l)
+    x_star = -np.linalg.solve(Hm, l)
+    f_star = f(x_star)
+    gamma = R(1) / R(np.linalg.norm(Hm, 2))
+    x = np.zeros(5, dtype)
+    y = x
+    err0 = np.linalg.norm(x_star - x)
+    gen = o.simple_nesterov_sequence(dtype) if seq == "simple" else o.fixed_nesterov_sequence(dtype)
+    for it, coeff in enumerate(itertools.islice(gen, 100), start=1):
+        assert coeff.dtype == dtype
+        if it == 1:
+            assert coeff == 0
+        g = Hm @ y + l
+        x_prev = x
+        x = y - gamma * g
+        y = x + coeff * (x - x_prev)
+        assert f(x) - f_star <= 2 / (gamma * (it + 1) ** 2) * err0**2
+
+
+def test_nesterov_adaptive_identities():
+    """test/accel/test_nesterov.jl:63-81"""
+    R = np.float64
+    g = R(rv.NESTEROV_FIXED_GAMMA)
+    ad = o.AdaptiveNesterovSequence(R(0))
+    for el in itertools.islice(o.fixed_nesterov_sequence(R), 20):
+        assert np.isclose(el, ad.next(g), rtol=1e-8)
+    m = R(1)
+    ad = o.AdaptiveNesterovSequence(m)
+    for _ in range(20):
+        assert np.isclose((1 - np.sqrt(m * g)) / (1 + np.sqrt(m * g)), ad.next(g), rtol=1e-8)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fb_tools_properties(dtype):
+    """test/utilities/test_fb_tools.jl:7-48"""
+    rng = np.random.default_rng(0)
+    sv = np.array([0.01, 1.0, 1.0, 1.0, 100.0], dtype)
+    U, _ = np.linalg.qr(rng.standard_normal((5, 5)).astype(dtype))
+    Q = ((U * sv[None, :]) @ U.T).astype(dtype)
+    q = rng.standard_normal(5).astype(dtype)
+    f = o.Quadratic(Q, q)
+    Lf = sv.max()
+    for _ in range(100):
+        x = rng.standard_normal(5).astype(dtype)
+        Lest = o.lower_bound_smoothness_constant(f, x)
+        assert Lest.dtype == dtype
+        assert Lest <= Lf * (1 + 8 * np.finfo(dtype).eps)
+    x = rng.standard_normal(5).astype(dtype)
+    Lest = o.lower_bound_smoothness_constant(f, x)
+    gamma_init = dtype(10) / Lest
+    gamma = gamma_init
+    g = o.Zero()
+    for _ in range(100):
+        x = rng.standard_normal(5).astype(dtype)
+        # allocating variant fb_tools.jl:65-98 with A = I
+        f_x, grad = f.value_and_gradient(x)
+        y = x - gamma * grad
+        z, g_z = g.prox(y, gamma)
+        new_gamma, *_ = o.backtrack_stepsize(gamma, f, g, x, f_x, grad, y, z, g_z, x - z, alpha=0.5)
+        assert new_gamma <= gamma
+        gamma = new_gamma
+    assert gamma < gamma_init
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fb_iterate_sequence_pin(dtype):
+    """test/problems/test_equivalence.jl:51-84 pins FB's z-sequence (gamma = 0.95/||A||^2) against
+    PANOC(no acceleration, 1 backtrack).  PANOC is not on the hot path; what the identity says for
+    FB is that z_{k+1} = prox_{gamma g}(z_k - gamma grad f(z_k)) -- checked here directly."""
+    A, b, lam, Lf = lasso_small(dtype)
+    R = np.dtype(dtype).type
+    gamma = R(0.95) / Lf
+    it = o.ForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(5, dtype), gamma=gamma)
+    z_prev = None
+    for k, s in enumerate(itertools.islice(it, 10)):
+        if z_prev is not None:
+            _, grad = o.LeastSquares(A, b).value_and_gradient(z_prev)
+            z_exp, _ = o.NormL1(lam).prox(z_prev - gamma * grad, gamma)
+            np.testing.assert_allclose(s.z, z_exp, rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-7)
+        z_prev = s.z.copy()
+
+
+def test_indbox_prox_is_clamp():
+    """test/problems/test_nonconvex_qp.jl:33: z = min.(upp, max.(low, .))"""
+    x = np.array([-3.0, -1.0, -0.2, 0.0, 0.7, 1.0, 5.0])
+    y, v = o.IndBox(rv.NCQP_LOW, rv.NCQP_UPP).prox(x, 0.3)
+    assert np.array_equal(y, np.minimum(rv.NCQP_UPP, np.maximum(rv.NCQP_LOW, x)))
+    assert v == 0
+
+
+@pytest.mark.parametrize("name,ffb_tol", [("lasso_tiny", 2e-4), ("lasso_small", 1e-6), ("lasso_medium", 1e-6)])
+def test_shipped_benchmark_instances(name, ffb_tol):
+    """benchmark/benchmarks.jl:47-61 settings (tol=1e-6, x0=0, adaptive) on the shipped data; the
+    stored xstar is the pin."""
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    A, b, xstar, lam = d["A"], d["b"], d["xstar"], float(d["lam"])
+    x0 = np.zeros(A.shape[1])
+    z, k = o.fast_forward_backward(tol=1e-6, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
+    assert k < 10_000
+    assert np.max(np.abs(z - xstar)) <= ffb_tol
+    if name != "lasso_tiny":
+        z, k = o.forward_backward(tol=1e-6, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        assert k < 10_000
+        assert np.max(np.abs(z - xstar)) <= 1e-6
+
+
+def test_synthetic_generator_reproducible_and_shardable():
+    A = o.synthetic_matrix(64, 48, seed=3)
+    A2 = o.synthetic_matrix(64, 48, seed=3)
+    assert np.array_equal(A, A2)
+    top = o.synthetic_matrix(32, 48, seed=3, row_offset=0, m_global=64)
+    bot = o.synthetic_matrix(32, 48, seed=3, row_offset=32, m_global=64)
+    assert np.array_equal(np.vstack([top, bot]), A)
+    big = o.synthetic_matrix(512, 512, seed=0)
+    assert abs(big.std() * np.sqrt(512) - 1) < 0.01 and abs(big.mean()) < 1e-3
