@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- FastForwardBackward iterations/sec on synthetic LASSO (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE FastForwardBackward iteration (fast_forward_backward.jl:106-145) of the fused HIP engine on
+the headline workload  m = 16384, n = 2^20, Float32, fixed step gamma = 1/Lf  (BASELINE.json north_star).
+A (64 GiB) is generated on the device and is resident in HBM before the timed region.  For N > 1 the driver
+launches one process per GPU with torch.distributed.run; rows of A are sharded over the N ranks (STRONG
+scaling: the global problem is fixed) and each gradient evaluation ends with one RCCL all-reduce of n+1
+floats.  Rank 0 prints ONE JSON line.
+
+Extra legs in the same line:
+  roofline      HBM roofline of the dominant kernel (the slower of the two GEMV passes over A), timed live with
+                HIP event pairs on the launch stream (pg_ctx_profile_*), algorithmic bytes = one full read of the
+                local A block + its vectors.
+  cpu_baseline  the CPU restatement (oracle/, numpy + OpenBLAS, same unfused op order as the reference) timed on
+                this host on a bounded sample (same m, fewer columns), scaled to it/s of the full workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (m, n)            BASELINE.json
+    "headline": (16384, 1 << 20),  # north_star target; configs[4] is its 8-GPU weak-scaled twin
+    "config2": (8192, 262144),  # configs[1]
+    "small": (2048, 16384),  # quick functional check
+}
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", choices=sorted(WORKLOADS), default="headline")
+    p.add_argument("--m", type=int, default=None, help="override rows (global)")
+    p.add_argument("--n", type=int, default=None, help="override columns")
+    p.add_argument("--mode", choices=["fixed", "adaptive"], default="fixed")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-cols", type=int, default=16384)
+    p.add_argument("--cpu-steps", type=int, default=10)
+    return p.parse_args()
+
+
+def cpu_baseline(m, n, sample_cols, steps, seed):
+    """Reference op sequence on the host cores (oracle = numpy/OpenBLAS restatement), bounded sample."""
+    import numpy as np
+
+    from oracle import proxgrad_oracle as o
+
+    ns = min(n, sample_cols)
+    rng = np.random.default_rng(seed)
+    A = np.asfortranarray(rng.standard_normal((m, ns), dtype=np.float32) / np.float32(math.sqrt(m)))
+    xt = np.zeros(ns, np.float32)
+    k = max(1, ns // 1000)
+    xt[rng.choice(ns, k, replace=False)] = rng.standard_normal(k).astype(np.float32)
+    b = A @ xt + np.float32(0.01) * rng.standard_normal(m).astype(np.float32)
+    lam = np.float32(0.1) * np.float32(np.max(np.abs(A.T @ b)))
+    v = np.ones(ns, np.float32) / np.float32(math.sqrt(ns))
+    for _ in range(10):
+        v = A.T @ (A @ v)
+        v /= np.linalg.norm(v)
+    Lf = np.float32(1.1 * np.linalg.norm(A @ v) ** 2)
+    it = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(ns, np.float32), Lf=Lf))
+    next(it)
+    next(it)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        next(it)
+    dt = time.perf_counter() - t0
+    its_sample = steps / dt
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {
+        "value": its_sample * ns / n,
+        "unit": "it/s",
+        "cores": int(cores),
+        "kind": "port",
+        "sample": f"oracle FFB fixed-step, m={m} n={ns} f32 ({steps} it, {dt:.2f} s, {its_sample:.2f} it/s on the sample; "
+                  f"scaled linearly in n to n={n})",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import proximalalgorithms.jl_amd as pa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    m_glob, n = WORKLOADS[args.workload]
+    m_glob = args.m or m_glob
+    n = args.n or n
+    dtype = np.float32
+    ctx = pa.get_context(local_rank)
+    row_off, m_loc = pa.shard_rows(m_glob, world, rank)
+
+    # ---------------- problem setup (untimed): A resident in HBM, b, lam, Lf ----------------
+    t_setup = time.perf_counter()
+    A = pa.HIPMatrix.synthetic(m_loc, n, dtype, seed=args.seed, row_offset=row_off, m_global=m_glob, ctx=ctx)
+    rng = np.random.default_rng(args.seed + 12345)
+    k = max(1, n // 1000)
+    x_true = np.zeros(n, dtype)
+    x_true[rng.choice(n, size=k, replace=False)] = rng.standard_normal(k).astype(dtype)
+    noise = np.random.default_rng(args.seed + 54321).standard_normal(m_glob).astype(dtype)[row_off:row_off + m_loc]
+    b = A.mul(pa.HIPVector.from_numpy(x_true, ctx))  # rows are independent: no collective
+    b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
+    comm = pa.TorchDistributedComm() if world > 1 else None
+    f = pa.LeastSquares(A, b, comm=comm)
+    zero_n = pa.HIPVector.zeros(n, dtype, ctx)
+    _, g0 = f.value_and_gradient(zero_n)  # = -A'b (all-reduced over the shards)
+    lam = dtype(0.1) * g0.norm_inf()  # test_lasso_small.jl:29
+    Lf = None
+    if args.mode == "fixed":
+        f0 = pa.LeastSquares(A, pa.HIPVector.zeros(m_loc, dtype, ctx), comm=comm)  # x -> A'A x
+        v = pa.HIPVector.zeros(n, dtype, ctx).fill_(1.0 / math.sqrt(n))
+        w = v.similar()
+        nrm = dtype(1)
+        for _ in range(30):
+            f0.value_and_gradient(v, out=w)
+            nrm = w.norm()
+            v.axpby_(1.0 / float(nrm), w)
+        Lf = dtype(1.1) * nrm  # ||A||^2 estimate (+10 % margin: power iteration under-estimates)
+        del f0
+    ctx.sync()
+    t_setup = time.perf_counter() - t_setup
+
+    iteration = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=zero_n, Lf=Lf)
+    it = iter(iteration)
+    state = next(it)  # init (k = 1)
+    stop_rule = lambda s: float(s.res_inf) / float(s.gamma) <= 1e-6  # benchmarks.jl:57 (evaluated, not acted on)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        state = next(it)
+        stop_rule(state)
+    passes0 = iteration.counters.get("a_passes", 0)
+    ctx.profile(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state = next(it)
+        stop_rule(state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    a_passes = iteration.counters.get("a_passes", 0) - passes0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    its = args.steps / elapsed
+    es = 4
+    bytes_iter_local = a_passes / max(args.steps, 1) * m_loc * n * es + 10 * n * es + 3 * m_loc * es
+    # dominant kernel = the slower GEMV pass; algorithmic bytes of one launch = the local A block + vectors
+    kern = {}
+    for name, vec_bytes in (("gemv_n_partial", n * es), ("gemv_t", m_loc * es + n * es)):
+        cnt, ms = prof[name]
+        if cnt:
+            avg_ms = ms / cnt
+            kern[name] = {"launches": cnt, "avg_ms": avg_ms,
+                          "GBps": (m_loc * n * es + vec_bytes) / (avg_ms * 1e-3) / 1e9}
+    dom = max(kern, key=lambda k_: kern[k_]["avg_ms"]) if kern else None
+    roofline = None
+    if dom:
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(kern[dom]["GBps"], 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(kern[dom]["avg_ms"], 4), "launches": kern[dom]["launches"],
+                    "algorithmic_bytes_per_launch": m_loc * n * es + (n * es if dom == "gemv_n_partial" else (m_loc + n) * es),
+                    "per_kernel": {k_: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1), "launches": v["launches"]}
+                                   for k_, v in kern.items()},
+                    "whole_iteration": {"algorithmic_bytes_per_gpu": int(bytes_iter_local),
+                                        "GBps_per_gpu": round(bytes_iter_local * its / 1e9, 1),
+                                        "frac": round(bytes_iter_local * its / 1e9 / HBM_PEAK_GBS, 4)}}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(m_glob, n, args.cpu_sample_cols, args.cpu_steps, args.seed)
+        line = {
+            "metric": "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, f32)" % (m_glob, n),
+            "value": round(its, 4),
+            "unit": "it/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "FFB LASSO m=%d n=%d Float32, %s step, rows of A sharded over %d GPU(s)"
+                                   % (m_glob, n, args.mode, world),
+                       "m": m_glob, "n": n, "mode": args.mode, "row_shards": world, "m_per_gpu": m_loc,
+                       "lambda": float(lam), "Lf": float(Lf) if Lf is not None else None, "seed": args.seed,
+                       "a_passes_per_step": a_passes / max(args.steps, 1), "setup_s": round(t_setup, 2),
+                       "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
+                                 "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,254 @@
+/*
+ * proxgrad_hip.h -- C ABI of libproxgrad_hip.so: an MI355X (gfx950) native engine for the
+ * ForwardBackward / FastForwardBackward inner iteration of ProximalAlgorithms.jl.
+ *
+ * This header is the drop-in boundary.  Each entry point cites the
+ * reference interface it replaces (paths relative to the ProximalAlgorithms.jl checkout).
+ * The reference host language is Julia; `ccall` binds these symbols directly (see
+ * INTEGRATION.md for the Julia-side glue).  A Python/ctypes host with the same operator
+ * and iterator surface lives in `proximalalgorithms.jl_amd/`.
+ *
+ * Conventions
+ *  - plain C, `extern "C"`, opaque handles, plain pointers and sizes; no C++/torch types.
+ *  - every function returns a pg_status (0 = ok, negative = error); pg_last_error() gives the
+ *    message of the last failure on the calling thread.
+ *  - `dtype`: PG_F32 (Float32) or PG_F64 (Float64) -- the reference's `real(eltype(x0))`.
+ *  - vectors are raw DEVICE pointers to `n` (or `m`) contiguous elements of `dtype`, owned by
+ *    the caller (pg_malloc/pg_free are provided for hosts without a HIP allocator).
+ *  - the matrix A is a library-owned object (pg_mat): dense column-major like a Julia
+ *    `Matrix{T}`, stored with the leading dimension padded to 1 KiB so that every column is
+ *    16-byte aligned for the streaming kernels.
+ *  - all work is enqueued on the context's HIP stream; an entry point that returns a scalar
+ *    through a HOST pointer synchronises that stream before returning, the others are
+ *    asynchronous.  One host thread per context at a time.
+ *  - scalars cross the ABI as double; kernels compute in `dtype` with fp64 final reductions.
+ *  - multi-GPU: rows of A are sharded one shard per process/GPU.  Register a SUM all-reduce
+ *    with pg_ctx_set_allreduce(); pg_ls_* then reduce [grad ; f] (n+1 elements) once per
+ *    gradient evaluation and 1 element per f-only evaluation.
+ */
+#ifndef PROXGRAD_HIP_H
+#define PROXGRAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+typedef int32_t pg_status;
+enum {
+  PG_OK = 0,
+  PG_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, unknown enum)        */
+  PG_ERR_HIP = -2,       /* a HIP runtime call failed; see pg_last_error()                   */
+  PG_ERR_ALLOC = -3,     /* device allocation failed                                         */
+  PG_ERR_UNSUPPORTED = -4,
+  PG_ERR_COLLECTIVE = -5 /* the registered all-reduce callback reported a failure           */
+};
+
+enum { PG_F32 = 0, PG_F64 = 1 };
+
+/* proximable term g -- ProximalOperators.{NormL1, IndBox}, ProximalCore.Zero               */
+enum { PG_G_ZERO = 0, PG_G_NORML1 = 1, PG_G_INDBOX = 2 };
+
+/* extrapolation sequences -- src/accel/nesterov.jl                                          */
+enum {
+  PG_SEQ_ADAPTIVE = 0, /* AdaptiveNesterovSequence(mf)   nesterov.jl:56-103 (FFB default)   */
+  PG_SEQ_FIXED = 1,    /* FixedNesterovSequence          nesterov.jl:14-17                   */
+  PG_SEQ_SIMPLE = 2,   /* SimpleNesterovSequence         nesterov.jl:36                      */
+  PG_SEQ_CONSTANT = 3, /* ConstantNesterovSequence(m, s) nesterov.jl:51-54                   */
+  PG_SEQ_HOST = 4      /* coefficient supplied by the host each step (custom iterators)      */
+};
+
+/* flags reported in pg_iter_scalars.flags */
+enum { PG_FLAG_GAMMA_TOO_SMALL = 1 /* fb_tools.jl:59-61 (@warn, not an error) */ };
+
+typedef struct pg_ctx pg_ctx;
+typedef struct pg_mat pg_mat;
+typedef struct pg_ls pg_ls;
+typedef struct pg_iter pg_iter;
+typedef struct pg_lbfgs pg_lbfgs;
+
+/* SUM all-reduce over the row shards, in place on a device buffer, ordered on `stream`.
+ * Returns 0 on success. */
+typedef int (*pg_allreduce_fn)(void* user, void* dev_buf, int64_t count, int32_t dtype, void* stream);
+
+typedef struct pg_device_info {
+  int32_t device;
+  int32_t compute_units;
+  int32_t wavefront_size;
+  int32_t lds_bytes_per_cu;
+  int64_t global_mem_bytes;
+  int32_t clock_khz;
+  char arch[64];
+  char name[128];
+} pg_device_info;
+
+/* ------------------------------------------------------------------ context / memory ---- */
+int32_t pg_abi_version(void);
+const char* pg_last_error(void);
+/* `stream` is a hipStream_t (NULL = the device's default stream); it is borrowed, not owned. */
+pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out);
+pg_status pg_ctx_destroy(pg_ctx* ctx);
+pg_status pg_ctx_set_stream(pg_ctx* ctx, void* stream);
+pg_status pg_ctx_set_allreduce(pg_ctx* ctx, pg_allreduce_fn fn, void* user);
+pg_status pg_ctx_sync(pg_ctx* ctx);
+pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
+/* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every
+ * launch of the kernels below is bracketed by an event pair; pg_ctx_profile_read synchronises the stream and
+ * returns the launch count and summed duration since the last reset. */
+enum { PG_K_GEMV_N = 0, PG_K_GEMV_N_FINISH = 1, PG_K_GEMV_T = 2, PG_K_EPILOGUE = 3, PG_K_EXTRAPOLATE = 4, PG_K_COUNT = 5 };
+pg_status pg_ctx_profile_enable(pg_ctx* ctx, int32_t enable);
+pg_status pg_ctx_profile_reset(pg_ctx* ctx);
+pg_status pg_ctx_profile_read(pg_ctx* ctx, int32_t kernel, int64_t* launches, double* total_ms);
+
+/* Julia `Array` alloc/copy idioms (copy, similar, zero, copyto!) */
+pg_status pg_malloc(pg_ctx* ctx, size_t bytes, void** dptr);
+pg_status pg_free(pg_ctx* ctx, void* dptr);
+pg_status pg_memcpy_h2d(pg_ctx* ctx, void* dst, const void* src, size_t bytes);
+pg_status pg_memcpy_d2h(pg_ctx* ctx, void* dst, const void* src, size_t bytes); /* syncs */
+pg_status pg_memcpy_d2d(pg_ctx* ctx, void* dst, const void* src, size_t bytes);
+pg_status pg_memset_zero(pg_ctx* ctx, void* dst, size_t bytes);
+
+/* ------------------------------------------------------------------ matrix A ------------ */
+/* Julia `Matrix{T}` (m x n, column-major) held by `LeastSquares(A, b)`:
+ * benchmark/benchmarks.jl:41-52 ; test/problems/test_lasso_small.jl:17-23,37 */
+pg_status pg_mat_create(pg_ctx* ctx, int32_t dtype, int64_t m, int64_t n, pg_mat** out);
+pg_status pg_mat_destroy(pg_mat* A);
+pg_status pg_mat_upload(pg_mat* A, const void* host_colmajor, int64_t ld_host);
+pg_status pg_mat_set_from_device(pg_mat* A, const void* dev_colmajor, int64_t ld_dev);
+pg_status pg_mat_download(pg_mat* A, void* host_colmajor, int64_t ld_host); /* syncs */
+/* synthetic instance of SURVEY 8(d): A[i,j] = ih8(seed, row_offset+i, j) * scale, identical
+ * bit-for-bit to oracle/proxgrad_oracle.py::synthetic_matrix for every row shard */
+pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double scale);
+pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int32_t* dtype, void** dptr);
+/* y = A x  (mul!(y, A, x)) and g = A' r  (mul!(g, A', r)) -- the two GEMV orientations on the
+ * column-major store; used by LeastSquares and (later) PANOC's `mul!` with A: panoc.jl:150-190 */
+pg_status pg_mat_mul(pg_mat* A, const void* x, void* y);
+pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
+
+/* ------------------------------------------------------------------ LeastSquares -------- */
+/* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the
+ * value_and_gradient method of benchmark/benchmarks.jl:11-17.  `b` is a device m-vector
+ * borrowed for the lifetime of the object. */
+pg_status pg_ls_create(pg_ctx* ctx, pg_mat* A, const void* b, double lam, pg_ls** out);
+pg_status pg_ls_destroy(pg_ls* f);
+/* (f(x), grad f(x)) = (||A x - b||^2 / 2, A'(A x - b))   benchmarks.jl:15-16 ; called from
+ * forward_backward.jl:67,113 ; fast_forward_backward.jl:75,138 ; fb_tools.jl:10,44,53 */
+pg_status pg_ls_value_and_gradient(pg_ls* f, const void* x, void* grad_out, double* f_out);
+/* f(x) only (the line search discards the gradient in FFB: fast_forward_backward.jl:110-129) */
+pg_status pg_ls_value(pg_ls* f, const void* x, double* f_out);
+/* ProximalCore.gradient!(y, f, x) -> f(x)  (ProximalCore <= 0.1 callers; same arithmetic) */
+pg_status pg_ls_gradient(pg_ls* f, void* grad_out, const void* x, double* f_out);
+/* r = A x - b of the last evaluation (device m-vector, library-owned; valid until next call) */
+pg_status pg_ls_residual_ptr(pg_ls* f, const void** r_out);
+
+/* ------------------------------------------------------------------ prox operators ------ */
+/* ProximalCore.prox!(y, g::NormL1, x, gamma) -> g(y) : y_i = sign(x_i) max(|x_i| - gamma lam, 0),
+ * returns lam ||y||_1.  Call sites forward_backward.jl:72,118 ; fast_forward_backward.jl:80,141 ;
+ * fb_tools.jl:49.  y may alias x.  gy_out may be NULL (no sync, value skipped). */
+pg_status pg_prox_norml1(pg_ctx* ctx, int32_t dtype, int64_t n, void* y, const void* x, double lam,
+                         double gamma, double* gy_out);
+/* prox!(y, g::IndBox, x, gamma) -> 0 : y_i = min(hi_i, max(lo_i, x_i)); scalar bounds lo/hi are used
+ * where lo_vec / hi_vec are NULL.  test/problems/test_nonconvex_qp.jl:19,33 */
+pg_status pg_prox_indbox(pg_ctx* ctx, int32_t dtype, int64_t n, void* y, const void* x, double lo,
+                         double hi, const void* lo_vec, const void* hi_vec, double* gy_out);
+/* g(x) for NormL1 (lam ||x||_1) */
+pg_status pg_norml1_value(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, double lam, double* out);
+
+/* ------------------------------------------------------------------ BLAS-1 / broadcasts -- */
+/* out .= a .* x .+ b .* y   (y may be NULL when b == 0); covers `y .= x .- gamma .* grad`
+ * (forward_backward.jl:117), `res .= x .- z` (:120), `x .+ 1` via pg_add_scalar */
+pg_status pg_axpby(pg_ctx* ctx, int32_t dtype, int64_t n, void* out, double a, const void* x, double b,
+                   const void* y);
+pg_status pg_add_scalar(pg_ctx* ctx, int32_t dtype, int64_t n, void* out, const void* x, double c);
+pg_status pg_fill(pg_ctx* ctx, int32_t dtype, int64_t n, void* out, double c);
+/* x .= z .+ beta .* (z .- z_prev)   fast_forward_backward.jl:135 */
+pg_status pg_extrapolate(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, const void* z, const void* z_prev,
+                         double beta);
+pg_status pg_dot(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* y, double* out);
+pg_status pg_nrm2sq(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, double* out); /* norm(x)^2 */
+pg_status pg_nrminf(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, double* out); /* norm(x, Inf) */
+/* fused forward-backward epilogue: y = x - gamma grad ; z = prox_{gamma g}(y) ; res = x - z and the
+ * four reductions the iteration needs: scalars_out = { g(z), ||res||_inf, <grad,res>, ||res||^2 }
+ * (forward_backward.jl:117-120 + fb_tools.jl:3-5 + forward_backward.jl:125-126).
+ * g_kind in {PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX}; g_p0 = lam | lo ; g_p1 = hi. */
+pg_status pg_fb_epilogue(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* grad, double gamma,
+                         int32_t g_kind, double g_p0, double g_p1, void* y, void* z, void* res,
+                         double* scalars_out /* host, 4 doubles; NULL = leave on device */);
+
+/* ------------------------------------------------------------------ fused iterations ---- */
+/* Options = the keyword arguments of ForwardBackwardIteration (forward_backward.jl:38-48) and
+ * FastForwardBackwardIteration (fast_forward_backward.jl:44-56), f = LeastSquares, g by kind. */
+typedef struct pg_iter_opts {
+  int32_t fast;          /* 0 = ForwardBackward, 1 = FastForwardBackward                         */
+  int32_t adaptive;      /* -1 = default (gamma <= 0 && Lf <= 0), else 0/1                        */
+  double Lf;             /* <= 0: nothing                                                        */
+  double gamma;          /* <= 0: nothing (then 1/Lf, or estimated: fb_tools.jl:7-12)             */
+  double minimum_gamma;  /* 1e-7  */
+  double reduce_gamma;   /* 0.5   */
+  double increase_gamma; /* 1.0   */
+  double mf;             /* FFB: convexity modulus (0)                                           */
+  int32_t seq_kind;      /* FFB: PG_SEQ_*                                                        */
+  double seq_p0, seq_p1; /* PG_SEQ_CONSTANT: (m, stepsize)                                       */
+  int32_t g_kind;        /* PG_G_*                                                               */
+  double g_p0, g_p1;     /* NormL1: lam | IndBox: lo, hi                                         */
+} pg_iter_opts;
+
+/* the scalar part of ForwardBackwardState / FastForwardBackwardState plus line-search telemetry */
+typedef struct pg_iter_scalars {
+  double gamma;    /* state.gamma                                                               */
+  double f_x;      /* state.f_x                                                                 */
+  double g_z;      /* state.g_z                                                                 */
+  double res_inf;  /* norm(state.res, Inf)   (stop rule: res_inf / gamma <= tol)                */
+  double beta;     /* last extrapolation coefficient (FFB)                                      */
+  double f_z;      /* f(z) of the last accepted line-search trial (adaptive), else NaN          */
+  double f_z_upp;  /* quadratic model value at the accepted trial (adaptive), else NaN          */
+  int32_t n_backtracks; /* rejected trials in this step                                         */
+  int32_t flags;        /* PG_FLAG_*                                                            */
+  int64_t a_passes;     /* cumulative full reads of A since pg_iter_init (telemetry)            */
+} pg_iter_scalars;
+
+/* device vectors of the state (forward_backward.jl:52-63, fast_forward_backward.jl:60-71); the
+ * pointers change across steps exactly where the reference swaps references (x <-> z, ...) */
+typedef struct pg_iter_state {
+  void* x;
+  void* grad_f_x;
+  void* y;
+  void* z;
+  void* res;
+  void* z_prev;   /* FFB only, else NULL */
+  void* grad_f_z; /* FB only, else NULL  */
+} pg_iter_state;
+
+pg_status pg_iter_opts_default(pg_iter_opts* opts);
+/* ForwardBackwardIteration(; f, g, x0, ...) / FastForwardBackwardIteration(; ...) */
+pg_status pg_iter_create(pg_ctx* ctx, pg_ls* f, const pg_iter_opts* opts, pg_iter** out);
+pg_status pg_iter_destroy(pg_iter* it);
+/* Base.iterate(iter): forward_backward.jl:65-84 / fast_forward_backward.jl:73-97.
+ * x0 is a DEVICE n-vector; it is copied, never mutated (test_lasso_small.jl:54). */
+pg_status pg_iter_init(pg_iter* it, const void* x0, pg_iter_scalars* out);
+/* Base.iterate(iter, state): forward_backward.jl:86-123 / fast_forward_backward.jl:106-145.
+ * host_beta is used only with PG_SEQ_HOST. */
+pg_status pg_iter_step(pg_iter* it, double host_beta, pg_iter_scalars* out);
+/* IterativeAlgorithm loop (src/ProximalAlgorithms.jl:114-123) with the default stopping rule:
+ * runs until k >= maxit or res_inf/gamma <= tol; *k_out counts the init state like the reference.
+ * Call after pg_iter_init; k_start is the current k (1 right after init). */
+pg_status pg_iter_run(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out,
+                      pg_iter_scalars* out);
+pg_status pg_iter_state_view(pg_iter* it, pg_iter_state* out);
+
+/* ------------------------------------------------------------------ L-BFGS (config 4) --- */
+/* LBFGSOperator{M}: src/accel/lbfgs.jl:5-95 */
+pg_status pg_lbfgs_create(pg_ctx* ctx, int32_t dtype, int32_t M, int64_t n, pg_lbfgs** out);
+pg_status pg_lbfgs_destroy(pg_lbfgs* L);
+pg_status pg_lbfgs_update(pg_lbfgs* L, const void* s, const void* y); /* update!  lbfgs.jl:30-50 */
+pg_status pg_lbfgs_reset(pg_lbfgs* L);                               /* reset!   lbfgs.jl:52-55 */
+pg_status pg_lbfgs_apply(pg_lbfgs* L, void* d, const void* v);       /* mul!     lbfgs.jl:64-95 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROXGRAD_HIP_H */

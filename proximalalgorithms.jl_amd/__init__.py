@@ -1,0 +1,31 @@
+"""proximalalgorithms.jl_amd -- MI355X-native proximal-gradient engine behind the ProximalAlgorithms.jl
+iterator API (ForwardBackward / FastForwardBackward on LeastSquares + NormL1 / IndBox).
+
+Host-side mirror of the reference's interface (same names, keyword arguments and return conventions);
+all arithmetic runs in hand-written HIP kernels of libproxgrad_hip.so (csrc/, C ABI in
+include/proxgrad_hip.h).  There is no CPU fallback: without the library or a gfx950 device, calls raise.
+"""
+from ._lib import ProxGradError
+from .algorithm import IterativeAlgorithm
+from .device import Context, HIPMatrix, HIPVector, as_hipvector, get_context
+from .fast_forward_backward import (FastForwardBackward, FastForwardBackwardIteration, FastForwardBackwardState,
+                                    FastProximalGradient, FastProximalGradientIteration)
+from .fb_tools import backtrack_stepsize_, f_model, lower_bound_smoothness_constant
+from .forward_backward import (ForwardBackward, ForwardBackwardIteration, ForwardBackwardState, ProximalGradient,
+                               ProximalGradientIteration)
+from .lbfgs import LBFGS, LBFGSOperator
+from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, FixedNesterovSequence,
+                       SimpleNesterovSequence, next_)
+from .operators import (IndBox, LeastSquares, NormL1, Zero, gradient_, prox, prox_, value_and_gradient)
+from .sharding import ScaleComm, TorchDistributedComm, allreduce_sum_, shard_rows
+
+__all__ = [
+    "ProxGradError", "IterativeAlgorithm", "Context", "HIPMatrix", "HIPVector", "as_hipvector", "get_context",
+    "FastForwardBackward", "FastForwardBackwardIteration", "FastForwardBackwardState", "FastProximalGradient",
+    "FastProximalGradientIteration", "backtrack_stepsize_", "f_model", "lower_bound_smoothness_constant",
+    "ForwardBackward", "ForwardBackwardIteration", "ForwardBackwardState", "ProximalGradient",
+    "ProximalGradientIteration", "LBFGS", "LBFGSOperator", "AdaptiveNesterovSequence", "ConstantNesterovSequence",
+    "FixedNesterovSequence", "SimpleNesterovSequence", "next_", "IndBox", "LeastSquares", "NormL1", "Zero",
+    "gradient_", "prox", "prox_", "value_and_gradient", "ScaleComm", "TorchDistributedComm", "allreduce_sum_",
+    "shard_rows",
+]

@@ -1,0 +1,58 @@
+"""Host handle of the fused HIP iteration object (pg_iter) shared by the FB / FFB iterators."""
+import ctypes as C
+import warnings
+import weakref
+
+from . import _lib
+from ._lib import call
+from .device import HIPVector
+
+
+class FusedIteration:
+    def __init__(self, f, g, *, fast, Lf, gamma, adaptive, minimum_gamma, reduce_gamma, increase_gamma, mf=0.0,
+                 seq_kind=_lib.PG_SEQ_ADAPTIVE, seq_p0=0.0, seq_p1=0.0):
+        self.f, self.g = f, g
+        self.ctx = f.ctx
+        o = _lib.pg_iter_opts()
+        call("pg_iter_opts_default", C.byref(o))
+        o.fast = 1 if fast else 0
+        o.adaptive = -1 if adaptive is None else (1 if adaptive else 0)
+        o.Lf = float(Lf) if Lf is not None else -1.0
+        o.gamma = float(gamma) if gamma is not None else -1.0
+        o.minimum_gamma = float(minimum_gamma)
+        o.reduce_gamma = float(reduce_gamma)
+        o.increase_gamma = float(increase_gamma)
+        o.mf = float(mf)
+        o.seq_kind = int(seq_kind)
+        o.seq_p0, o.seq_p1 = float(seq_p0), float(seq_p1)
+        o.g_kind = g.g_kind
+        o.g_p0, o.g_p1 = g.g_params()
+        self.opts = o
+        h = C.c_void_p()
+        call("pg_iter_create", self.ctx.handle, f.handle, C.byref(o), C.byref(h))
+        self._h = h
+        self._finalizer = weakref.finalize(self, _lib.load().pg_iter_destroy, h)
+        self.scalars = _lib.pg_iter_scalars()
+        self.n = f.A.n
+        self.dtype = f.A.dtype
+
+    def init(self, x0):
+        call("pg_iter_init", self._h, x0.vp, C.byref(self.scalars))
+        return self.scalars
+
+    def step(self, host_beta=0.0):
+        call("pg_iter_step", self._h, float(host_beta), C.byref(self.scalars))
+        if self.scalars.flags & _lib.PG_FLAG_GAMMA_TOO_SMALL:
+            warnings.warn(f"stepsize `gamma` became too small ({self.scalars.gamma})")  # fb_tools.jl:59-61
+        return self.scalars
+
+    def run(self, k_start, maxit, tol):
+        k = C.c_int64()
+        call("pg_iter_run", self._h, int(k_start), int(maxit), float(tol), C.byref(k), C.byref(self.scalars))
+        return k.value, self.scalars
+
+    def view(self):
+        st = _lib.pg_iter_state()
+        call("pg_iter_state_view", self._h, C.byref(st))
+        mk = lambda p: HIPVector(self.ctx, p, self.n, self.dtype, owner=self) if p else None
+        return {name: mk(getattr(st, name)) for name, _ in _lib.pg_iter_state._fields_}

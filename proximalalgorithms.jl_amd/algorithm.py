@@ -1,0 +1,38 @@
+"""IterativeAlgorithm -- mirror of src/ProximalAlgorithms.jl:58-123."""
+import numpy as np
+
+from .device import HIPVector
+
+
+class IterativeAlgorithm:
+    """Wrapper for an iterator type adding termination and verbosity options
+    (src/ProximalAlgorithms.jl:58-112).  Calling it merges the keyword arguments, builds the iterator
+    and loops: ``for (k, state) in enumerate(iter)`` -> returns ``(solution, k)`` when
+    ``k >= maxit or stop(iter, state)`` (:114-123)."""
+
+    def __init__(self, iterator_type, *, maxit, stop, solution, verbose, freq, display, **kwargs):
+        self.iterator_type = iterator_type
+        self.maxit = int(maxit)
+        self.stop = stop
+        self.solution = solution
+        self.verbose = bool(verbose)
+        self.freq = int(freq)
+        self.display = display
+        self.kwargs = kwargs
+
+    def __call__(self, **kwargs):
+        merged = dict(self.kwargs)
+        merged.update(kwargs)
+        x0 = merged.get("x0")
+        host_x0 = x0 is not None and not isinstance(x0, HIPVector)
+        it = self.iterator_type(**merged)
+        for k, state in enumerate(it, start=1):
+            if k >= self.maxit or self.stop(it, state):
+                if self.verbose:
+                    self.display(k, it, state)
+                sol = self.solution(it, state)
+                if host_x0 and isinstance(sol, HIPVector):
+                    sol = sol.numpy()  # eltype/array kind of the answer follows x0 (test_lasso_small.jl:51)
+                return sol, k
+            if self.verbose and k % self.freq == 0:
+                self.display(k, it, state)

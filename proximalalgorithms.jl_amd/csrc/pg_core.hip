@@ -1,0 +1,396 @@
+// Context, memory helpers and the dense column-major matrix object (upload / generate / download).
+#include <cstdarg>
+
+#include "pg_internal.h"
+
+static thread_local std::string g_last_error;
+
+void pg_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+extern "C" {
+
+int32_t pg_abi_version(void) { return PG_ABI_VERSION; }
+const char* pg_last_error(void) { return g_last_error.c_str(); }
+
+pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out) {
+  PG_REQUIRE(out != nullptr, "out is null");
+  *out = nullptr;
+  int count = 0;
+  PG_HIP(hipGetDeviceCount(&count));
+  PG_REQUIRE(device >= 0 && device < count, "device index out of range");
+  PG_HIP(hipSetDevice(device));
+  pg_ctx* c = new pg_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  hipError_t e = hipGetDeviceProperties(&c->prop, device);
+  if (e != hipSuccess) {
+    delete c;
+    pg_set_error("hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    return PG_ERR_HIP;
+  }
+  c->num_cu = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+  if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+    pg_set_error("libproxgrad_hip is built for gfx950 (MI355X) only; device %d is %s", device,
+                 c->prop.gcnArchName);
+    delete c;
+    return PG_ERR_UNSUPPORTED;
+  }
+  if (hipMalloc(&c->red_partials, sizeof(double) * PG_RED_MAX_BLOCKS * PG_RED_MAX_NS) != hipSuccess ||
+      hipMalloc(&c->red_counter, sizeof(unsigned) * 8) != hipSuccess ||
+      hipMalloc(&c->dscal, sizeof(double) * PG_S_COUNT) != hipSuccess ||
+      hipHostMalloc(&c->hscal, sizeof(double) * PG_S_COUNT, hipHostMallocDefault) != hipSuccess) {
+    pg_set_error("context workspace allocation failed");
+    pg_ctx_destroy(c);
+    return PG_ERR_ALLOC;
+  }
+  PG_HIP(hipMemset(c->red_counter, 0, sizeof(unsigned) * 8));
+  PG_HIP(hipMemset(c->dscal, 0, sizeof(double) * PG_S_COUNT));
+  PG_HIP(hipDeviceSynchronize());
+  *out = c;
+  return PG_OK;
+}
+
+pg_status pg_ctx_destroy(pg_ctx* c) {
+  if (!c) return PG_OK;
+  if (c->red_partials) (void)hipFree(c->red_partials);
+  if (c->red_counter) (void)hipFree(c->red_counter);
+  if (c->dscal) (void)hipFree(c->dscal);
+  if (c->hscal) (void)hipHostFree(c->hscal);
+  for (int k = 0; k < PG_K_COUNT; ++k)
+    for (auto& pr : c->prof_events[k]) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  for (auto e : c->prof_pool) (void)hipEventDestroy(e);
+  delete c;
+  return PG_OK;
+}
+
+pg_status pg_ctx_set_stream(pg_ctx* c, void* stream) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  c->stream = (hipStream_t)stream;
+  return PG_OK;
+}
+
+pg_status pg_ctx_set_allreduce(pg_ctx* c, pg_allreduce_fn fn, void* user) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  c->allreduce = fn;
+  c->allreduce_user = user;
+  return PG_OK;
+}
+
+pg_status pg_ctx_sync(pg_ctx* c) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  PG_HIP(hipStreamSynchronize(c->stream));
+  return PG_OK;
+}
+
+pg_status pg_ctx_profile_enable(pg_ctx* c, int32_t enable) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  c->profiling = enable != 0;
+  return PG_OK;
+}
+
+pg_status pg_ctx_profile_reset(pg_ctx* c) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  PG_HIP(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < PG_K_COUNT; ++k) {
+    for (auto& pr : c->prof_events[k]) {
+      c->prof_pool.push_back(pr.first);
+      c->prof_pool.push_back(pr.second);
+    }
+    c->prof_events[k].clear();
+  }
+  return PG_OK;
+}
+
+pg_status pg_ctx_profile_read(pg_ctx* c, int32_t kernel, int64_t* launches, double* total_ms) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  PG_REQUIRE(kernel >= 0 && kernel < PG_K_COUNT, "unknown kernel id");
+  PG_HIP(hipStreamSynchronize(c->stream));
+  double tot = 0.0;
+  for (auto& pr : c->prof_events[kernel]) {
+    float ms = 0.f;
+    PG_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+  }
+  if (launches) *launches = (int64_t)c->prof_events[kernel].size();
+  if (total_ms) *total_ms = tot;
+  return PG_OK;
+}
+
+pg_status pg_ctx_device_info(pg_ctx* c, pg_device_info* out) {
+  PG_REQUIRE(c != nullptr && out != nullptr, "null argument");
+  memset(out, 0, sizeof(*out));
+  out->device = c->device;
+  out->compute_units = c->prop.multiProcessorCount;
+  out->wavefront_size = c->prop.warpSize;
+  out->lds_bytes_per_cu = (int32_t)c->prop.maxSharedMemoryPerMultiProcessor;
+  out->global_mem_bytes = (int64_t)c->prop.totalGlobalMem;
+  out->clock_khz = c->prop.clockRate;
+  strncpy(out->arch, c->prop.gcnArchName, sizeof(out->arch) - 1);
+  strncpy(out->name, c->prop.name, sizeof(out->name) - 1);
+  return PG_OK;
+}
+
+pg_status pg_malloc(pg_ctx* c, size_t bytes, void** dptr) {
+  PG_REQUIRE(c != nullptr && dptr != nullptr, "null argument");
+  *dptr = nullptr;
+  if (bytes == 0) return PG_OK;
+  PG_HIP(hipSetDevice(c->device));
+  hipError_t e = hipMalloc(dptr, bytes);
+  if (e != hipSuccess) {
+    pg_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return PG_ERR_ALLOC;
+  }
+  return PG_OK;
+}
+
+pg_status pg_free(pg_ctx* c, void* dptr) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  if (dptr) PG_HIP(hipFree(dptr));
+  return PG_OK;
+}
+
+pg_status pg_memcpy_h2d(pg_ctx* c, void* dst, const void* src, size_t bytes) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  if (bytes == 0) return PG_OK;
+  PG_REQUIRE(dst != nullptr && src != nullptr, "null pointer");
+  PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  PG_HIP(hipStreamSynchronize(c->stream));  // host buffer is only pinned for the duration of the call
+  return PG_OK;
+}
+
+pg_status pg_memcpy_d2h(pg_ctx* c, void* dst, const void* src, size_t bytes) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  if (bytes == 0) return PG_OK;
+  PG_REQUIRE(dst != nullptr && src != nullptr, "null pointer");
+  PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  PG_HIP(hipStreamSynchronize(c->stream));
+  return PG_OK;
+}
+
+pg_status pg_memcpy_d2d(pg_ctx* c, void* dst, const void* src, size_t bytes) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  if (bytes == 0) return PG_OK;
+  PG_REQUIRE(dst != nullptr && src != nullptr, "null pointer");
+  PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return PG_OK;
+}
+
+pg_status pg_memset_zero(pg_ctx* c, void* dst, size_t bytes) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  if (bytes == 0) return PG_OK;
+  PG_REQUIRE(dst != nullptr, "null pointer");
+  PG_HIP(hipMemsetAsync(dst, 0, bytes, c->stream));
+  return PG_OK;
+}
+
+}  // extern "C"
+
+static hipEvent_t prof_get_event(pg_ctx* c) {
+  if (!c->prof_pool.empty()) {
+    hipEvent_t e = c->prof_pool.back();
+    c->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+pg_prof_scope::pg_prof_scope(pg_ctx* ctx, int k) : c(ctx), kind(k) {
+  if (!c->profiling) return;
+  start = prof_get_event(c);
+  stop = prof_get_event(c);
+  if (start && stop) (void)hipEventRecord(start, c->stream);
+}
+
+pg_prof_scope::~pg_prof_scope() {
+  if (!c->profiling || !start || !stop) return;
+  (void)hipEventRecord(stop, c->stream);
+  c->prof_events[kind].emplace_back(start, stop);
+}
+
+pg_status pg_read_scalars(pg_ctx* c, int first, int count) {
+  PG_HIP(hipMemcpyAsync(c->hscal + first, c->dscal + first, sizeof(double) * count, hipMemcpyDeviceToHost,
+                        c->stream));
+  PG_HIP(hipStreamSynchronize(c->stream));
+  return PG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// matrix
+// ---------------------------------------------------------------------------------------------
+
+// murmur3 fmix32 -- must match oracle/proxgrad_oracle.py::_mix32 bit for bit
+__device__ __forceinline__ uint32_t pg_mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+// centred sum of eight hashed 16-bit uniforms (Irwin-Hall(8)); oracle: counter_ih8
+__device__ __forceinline__ int pg_ih8(uint32_t hseed, uint32_t i, uint32_t j) {
+  uint32_t h = pg_mix32(hseed ^ j);
+  h = pg_mix32(h ^ (i * 0x9E3779B1u));
+  int s = 0;
+#pragma unroll
+  for (uint32_t t = 0; t < 4; ++t) {
+    uint32_t w = pg_mix32(h + t * 0x632BE5ABu);
+    s += (int)(w & 0xFFFFu) + (int)(w >> 16);
+  }
+  return s - 4 * 65535;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void generate_kernel(T* __restrict__ A, int64_t m, int64_t n, int64_t ld,
+                                                       uint32_t hseed, uint32_t row_offset, float scale) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  const int64_t vec_per_col = ld / VEC;
+  const int64_t total = vec_per_col * n;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t j = idx / vec_per_col;
+    const int64_t i0 = (idx - j * vec_per_col) * VEC;
+    V v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int64_t i = i0 + e;
+      float val = 0.0f;
+      if (i < m) val = (float)pg_ih8(hseed, row_offset + (uint32_t)i, (uint32_t)j) * scale;
+      v[e] = (T)val;
+    }
+    *reinterpret_cast<V*>(A + j * ld + i0) = v;
+  }
+}
+
+static inline uint32_t host_mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+extern "C" {
+
+pg_status pg_mat_create(pg_ctx* c, int32_t dtype, int64_t m, int64_t n, pg_mat** out) {
+  PG_REQUIRE(c != nullptr && out != nullptr, "null argument");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "dtype must be PG_F32 or PG_F64");
+  PG_REQUIRE(m >= 0 && n >= 0, "negative dimension");
+  PG_REQUIRE(m < (int64_t)1 << 32 && n < (int64_t)1 << 32, "dimension >= 2^32");
+  *out = nullptr;
+  pg_mat* A = new pg_mat();
+  A->ctx = c;
+  A->dtype = dtype;
+  A->m = m;
+  A->n = n;
+  const int64_t row_quantum = 1024 / (int64_t)pg_sizeof(dtype);  // one 64-lane x 16 B wave load
+  A->ld = pg_round_up(m > 0 ? m : 1, row_quantum);
+  const size_t bytes = (size_t)A->ld * (size_t)(n > 0 ? n : 1) * pg_sizeof(dtype);
+  PG_HIP(hipSetDevice(c->device));
+  hipError_t e = hipMalloc(&A->data, bytes);
+  if (e != hipSuccess) {
+    pg_set_error("hipMalloc(%zu bytes) for a %lld x %lld matrix failed: %s", bytes, (long long)m, (long long)n,
+                 hipGetErrorString(e));
+    delete A;
+    return PG_ERR_ALLOC;
+  }
+  if (A->ld != m) {  // padding rows must read as zero
+    e = hipMemsetAsync(A->data, 0, bytes, c->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(A->data);
+      delete A;
+      pg_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+      return PG_ERR_HIP;
+    }
+  }
+  *out = A;
+  return PG_OK;
+}
+
+pg_status pg_mat_destroy(pg_mat* A) {
+  if (!A) return PG_OK;
+  if (A->data) (void)hipFree(A->data);
+  if (A->partials) (void)hipFree(A->partials);
+  delete A;
+  return PG_OK;
+}
+
+pg_status pg_mat_upload(pg_mat* A, const void* host, int64_t ld_host) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  if (A->m == 0 || A->n == 0) return PG_OK;
+  PG_REQUIRE(host != nullptr, "host pointer is null");
+  PG_REQUIRE(ld_host >= A->m, "ld_host < m");
+  const size_t es = pg_sizeof(A->dtype);
+  PG_HIP(hipMemcpy2DAsync(A->data, (size_t)A->ld * es, host, (size_t)ld_host * es, (size_t)A->m * es,
+                          (size_t)A->n, hipMemcpyHostToDevice, A->ctx->stream));
+  PG_HIP(hipStreamSynchronize(A->ctx->stream));
+  return PG_OK;
+}
+
+pg_status pg_mat_set_from_device(pg_mat* A, const void* dev, int64_t ld_dev) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  if (A->m == 0 || A->n == 0) return PG_OK;
+  PG_REQUIRE(dev != nullptr, "device pointer is null");
+  PG_REQUIRE(ld_dev >= A->m, "ld_dev < m");
+  const size_t es = pg_sizeof(A->dtype);
+  PG_HIP(hipMemcpy2DAsync(A->data, (size_t)A->ld * es, dev, (size_t)ld_dev * es, (size_t)A->m * es, (size_t)A->n,
+                          hipMemcpyDeviceToDevice, A->ctx->stream));
+  return PG_OK;
+}
+
+pg_status pg_mat_download(pg_mat* A, void* host, int64_t ld_host) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  if (A->m == 0 || A->n == 0) return PG_OK;
+  PG_REQUIRE(host != nullptr, "host pointer is null");
+  PG_REQUIRE(ld_host >= A->m, "ld_host < m");
+  const size_t es = pg_sizeof(A->dtype);
+  PG_HIP(hipMemcpy2DAsync(host, (size_t)ld_host * es, A->data, (size_t)A->ld * es, (size_t)A->m * es,
+                          (size_t)A->n, hipMemcpyDeviceToHost, A->ctx->stream));
+  PG_HIP(hipStreamSynchronize(A->ctx->stream));
+  return PG_OK;
+}
+
+pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double scale) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  PG_REQUIRE(row_offset >= 0 && row_offset + A->m <= (int64_t)1 << 32, "row_offset out of range");
+  if (A->m == 0 || A->n == 0) return PG_OK;
+  const uint32_t hseed = host_mix32(seed ^ 0x9E3779B9u);
+  const int64_t vecs = A->ld / (16 / (int64_t)pg_sizeof(A->dtype)) * A->n;
+  int64_t blocks = (vecs + 255) / 256;
+  const int64_t cap = (int64_t)A->ctx->num_cu * 32;
+  if (blocks > cap) blocks = cap;
+  if (A->dtype == PG_F32)
+    hipLaunchKernelGGL(generate_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream,
+                       (float*)A->data, A->m, A->n, A->ld, hseed, (uint32_t)row_offset, (float)scale);
+  else
+    hipLaunchKernelGGL(generate_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream,
+                       (double*)A->data, A->m, A->n, A->ld, hseed, (uint32_t)row_offset, (float)scale);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int32_t* dtype, void** dptr) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  if (m) *m = A->m;
+  if (n) *n = A->n;
+  if (ld) *ld = A->ld;
+  if (dtype) *dtype = A->dtype;
+  if (dptr) *dptr = A->data;
+  return PG_OK;
+}
+
+}  // extern "C"

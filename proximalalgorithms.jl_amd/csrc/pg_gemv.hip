@@ -1,0 +1,564 @@
+// The two GEMV orientations on the column-major store of A, and the LeastSquares operator built on
+// them (reference: benchmark/benchmarks.jl:11-17  res = A*x - b ; (norm(res)^2/2, A'res)).
+//
+// Both passes are pure HBM streams over A (0.5 flop/byte in f32): no MFMA, no LDS staging of A.  Every
+// wave issues 16-byte-per-lane loads (1 KiB per wave instruction) of whole 1 KiB row groups of a column,
+// non-temporal because A (64 GiB at the headline size) is streamed exactly once per pass.
+//
+//   pass N  (y = A x):     wave = (row tile of R KiB, column slot); accumulators in VGPRs, x_j wave-uniform;
+//                          deterministic two-stage reduction over the column slots.
+//   pass T  (g = A' r):    r staged once per workgroup in LDS (<= 64 KiB); wave = C adjacent columns streamed
+//                          top to bottom; per-column DPP/shuffle wave reduction; no cross-wave traffic.
+#include "pg_internal.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+
+template <typename V>
+__device__ __forceinline__ V nt_load(const V* p) {
+  return __builtin_nontemporal_load(p);
+}
+
+// -------------------------------------------------------------------------------------------------
+// pass N, stage 1: partials[slot][i] = sum_{j in columns of slot} A[i, j] * x[j]
+// grid: ceil(n_tiles * S / 4) blocks of 4 waves.  Consecutive waves take consecutive row tiles of the
+// same column block, so a workgroup reads 4*R KiB contiguous bytes of each column it touches.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int R, int U>
+__global__ __launch_bounds__(256) void gemv_n_partial_kernel(const T* __restrict__ A, int64_t ld, int64_t n,
+                                                             int n_rowgroups, int n_tiles, int S,
+                                                             const T* __restrict__ x, T* __restrict__ partials) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int tile = (int)(gw % n_tiles);
+  const int64_t slot = gw / n_tiles;
+  if (slot >= S) return;
+  const int rg0 = tile * R;
+  const int r_eff = min(R, n_rowgroups - rg0);
+
+  V acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = (V)(T(0));
+
+  const int64_t ncb = (n + U - 1) / U;
+  const T* __restrict__ a_base = A + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
+  for (int64_t cb = slot; cb < ncb; cb += S) {
+    const int64_t j0 = cb * U;
+    T xs[U];
+    int64_t jc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = j0 + u;
+      jc[u] = j < n ? j : n - 1;
+      const T xv = x[jc[u]];
+      xs[u] = j < n ? xv : T(0);
+    }
+    V a[U][R];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r < r_eff) a[u][r] = nt_load(reinterpret_cast<const V*>(a_base + jc[u] * ld + r * (WAVE * VEC)));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r < r_eff) acc[r] += a[u][r] * xs[u];
+      }
+    }
+  }
+  T* __restrict__ p = partials + slot * ld + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r < r_eff) *reinterpret_cast<V*>(p + r * (WAVE * VEC)) = acc[r];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// pass N, stage 2: y[i] = sum_s partials[s][i] - b[i]   (i < m; fixed summation order), optional
+// f = f_scale * sum_i y[i]^2 -> dscal[PG_S_F] (+ typed copy for the all-reduce payload).
+// 256 threads = 64 rows x 4 slot groups.
+// -------------------------------------------------------------------------------------------------
+template <typename T, bool WITH_F>
+__global__ __launch_bounds__(256) void gemv_n_finish_kernel(const T* __restrict__ partials, int64_t ld, int64_t m,
+                                                            int S, const T* __restrict__ b, T* __restrict__ y,
+                                                            int64_t y_len, double f_scale,
+                                                            double* __restrict__ red_partials,
+                                                            unsigned* __restrict__ red_counter,
+                                                            double* __restrict__ f_out, T* __restrict__ f_out_typed) {
+  __shared__ double sm_rows[4][64];
+  const int rx = threadIdx.x & 63;
+  const int sg = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + rx;
+  double acc = 0.0;
+  if (i < ld) {
+    for (int s = sg; s < S; s += 4) acc += (double)partials[(int64_t)s * ld + i];
+  }
+  sm_rows[sg][rx] = acc;
+  __syncthreads();
+  double sq = 0.0;
+  if (sg == 0) {
+    double v = ((sm_rows[0][rx] + sm_rows[1][rx]) + sm_rows[2][rx]) + sm_rows[3][rx];
+    T out = T(0);
+    if (i < m) {
+      if (b != nullptr) v -= (double)b[i];
+      out = (T)v;
+      sq = (double)out * (double)out;
+    }
+    if (i < y_len) y[i] = out;
+  }
+  if constexpr (WITH_F) {
+    double v[1] = {sq};
+    const double ps[1] = {f_scale};
+    __syncthreads();
+    const bool last = grid_reduce_finalize<1, 0u>(v, red_partials, red_counter, f_out, ps);
+    // mirror f in working precision (slot n of the all-reduce payload)
+    if (last && threadIdx.x == 0 && f_out_typed != nullptr) *f_out_typed = (T)(*f_out);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// pass T: g[j] = sum_{i in row chunk} A[i, j] * r[i]
+// r chunk staged in LDS; each wave streams C adjacent columns, UR row groups per step.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int C, int UR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict__ A, int64_t ld, int64_t n,
+                                                            int64_t m, int rg_begin, int nrg,
+                                                            const T* __restrict__ r, T* __restrict__ g) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  V* lds_r = reinterpret_cast<V*>(smem_raw);
+
+  const int64_t row0 = (int64_t)rg_begin * (WAVE * VEC);
+  for (int idx = threadIdx.x; idx < nrg * WAVE; idx += WAVES * 64) {
+    const int64_t i0 = row0 + (int64_t)idx * VEC;
+    V v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = (i0 + e < m) ? r[i0 + e] : T(0);
+    lds_r[idx] = v;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
+  const int64_t total_waves = (int64_t)gridDim.x * WAVES;
+  const int64_t ncg = (n + C - 1) / C;
+
+  for (int64_t cg = gw; cg < ncg; cg += total_waves) {
+    const int64_t j0 = cg * C;
+    const T* __restrict__ p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t j = (j0 + c < n) ? (j0 + c) : (n - 1);
+      p[c] = A + j * ld + row0 + lane * VEC;
+    }
+    T acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = T(0);
+
+    int rg = 0;
+    for (; rg + UR <= nrg; rg += UR) {
+      V a[C][UR];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+          a[c][u] = nt_load(reinterpret_cast<const V*>(p[c] + (int64_t)(rg + u) * (WAVE * VEC)));
+      }
+      V rv[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) rv[u] = lds_r[(rg + u) * WAVE + lane];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[c] = fma(a[c][u][e], rv[u][e], acc[c]);
+        }
+      }
+    }
+    for (; rg < nrg; ++rg) {
+      const V rv = lds_r[rg * WAVE + lane];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const V a = nt_load(reinterpret_cast<const V*>(p[c] + (int64_t)rg * (WAVE * VEC)));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[c] = fma(a[e], rv[e], acc[c]);
+      }
+    }
+    // wave reduction (xor butterfly: every lane ends with the full sums, fixed order)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc[c] += pg_shfl_xor(acc[c], off);
+    }
+    T out = acc[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) out = (lane == c) ? acc[c] : out;
+    if (lane < C && j0 + lane < n) g[j0 + lane] = out;
+  }
+}
+
+// g[j] = sum_k chunks[k][j]
+template <typename T>
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const T* __restrict__ chunks, int nchunks, int64_t n,
+                                                         T* __restrict__ g) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+    double a = 0.0;
+    for (int k = 0; k < nchunks; ++k) a += (double)chunks[(int64_t)k * n + j];
+    g[j] = (T)a;
+  }
+}
+
+template <typename T>
+__global__ void cast_scalar_kernel(const T* __restrict__ in, double* __restrict__ out) {
+  *out = (double)(*in);
+}
+
+constexpr int64_t LDS_R_BYTES = 64 * 1024;  // r chunk per workgroup in pass T (2 workgroups per CU)
+
+// ----------------------------------------------------------------------------------------------
+// host-side launch planning
+// ----------------------------------------------------------------------------------------------
+struct PlanN {
+  int R, U, n_rowgroups, n_tiles, S;
+};
+
+PlanN plan_n(const pg_mat* A) {
+  PlanN p;
+  const int64_t rows_per_rg = 1024 / (int64_t)pg_sizeof(A->dtype);
+  p.n_rowgroups = (int)(A->ld / rows_per_rg);
+  if (p.n_rowgroups >= 4) {
+    p.R = 4;
+    p.U = 4;
+  } else if (p.n_rowgroups >= 2) {
+    p.R = 2;
+    p.U = 8;
+  } else {
+    p.R = 1;
+    p.U = 8;
+  }
+  p.n_tiles = (p.n_rowgroups + p.R - 1) / p.R;
+  const int64_t ncb = A->n > 0 ? (A->n + p.U - 1) / p.U : 1;
+  const int64_t target_waves = (int64_t)A->ctx->num_cu * 16;
+  int64_t S = target_waves / p.n_tiles;
+  if (S < 1) S = 1;
+  if (S > ncb) S = ncb;
+  if (S > 1024) S = 1024;
+  p.S = (int)S;
+  return p;
+}
+
+pg_status ensure_partials(pg_mat* A, int S) {
+  if (A->partials && A->partials_slots >= S) return PG_OK;
+  if (A->partials) {
+    PG_HIP(hipStreamSynchronize(A->ctx->stream));
+    PG_HIP(hipFree(A->partials));
+    A->partials = nullptr;
+  }
+  const size_t bytes = (size_t)S * (size_t)A->ld * pg_sizeof(A->dtype);
+  hipError_t e = hipMalloc(&A->partials, bytes);
+  if (e != hipSuccess) {
+    pg_set_error("hipMalloc(%zu) for GEMV partial sums failed: %s", bytes, hipGetErrorString(e));
+    return PG_ERR_ALLOC;
+  }
+  A->partials_slots = S;
+  return PG_OK;
+}
+
+template <typename T>
+pg_status launch_n_partial(pg_mat* A, const PlanN& p, const T* x) {
+  const int64_t waves = (int64_t)p.n_tiles * p.S;
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  hipStream_t st = A->ctx->stream;
+  pg_prof_scope prof(A->ctx, PG_K_GEMV_N);
+  const T* Ad = (const T*)A->data;
+  T* part = (T*)A->partials;
+  if (p.R == 4)
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, 4, 4>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
+                       p.n_rowgroups, p.n_tiles, p.S, x, part);
+  else if (p.R == 2)
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, 2, 8>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
+                       p.n_rowgroups, p.n_tiles, p.S, x, part);
+  else
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, 1, 8>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
+                       p.n_rowgroups, p.n_tiles, p.S, x, part);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// y = A x - b (b nullable), y has y_len >= m valid slots (entries in [m, y_len) are zeroed);
+// with_f: dscal[PG_S_F] = f_scale * ||y||^2 (and typed mirror)
+template <typename T>
+pg_status gemv_n(pg_mat* A, const T* x, const T* b, T* y, int64_t y_len, bool with_f, double f_scale,
+                 T* f_typed) {
+  pg_ctx* c = A->ctx;
+  if (A->m == 0) {
+    if (with_f) PG_HIP(hipMemsetAsync(c->dscal + PG_S_F, 0, sizeof(double), c->stream));
+    if (with_f && f_typed) PG_HIP(hipMemsetAsync(f_typed, 0, sizeof(T), c->stream));
+    return PG_OK;
+  }
+  PlanN p = plan_n(A);
+  PG_TRY(ensure_partials(A, p.S));
+  if (A->n == 0) {
+    PG_HIP(hipMemsetAsync(A->partials, 0, (size_t)p.S * A->ld * sizeof(T), c->stream));
+  } else {
+    PG_TRY(launch_n_partial<T>(A, p, x));
+  }
+  const unsigned blocks = (unsigned)((A->ld + 63) / 64);
+  if (blocks > (unsigned)PG_RED_MAX_BLOCKS && with_f) {
+    pg_set_error("m too large for the fused residual reduction (%lld rows)", (long long)A->m);
+    return PG_ERR_UNSUPPORTED;
+  }
+  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+  if (with_f)
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3(blocks), dim3(256), 0, c->stream,
+                       (const T*)A->partials, A->ld, A->m, p.S, b, y, y_len, f_scale, c->red_partials,
+                       c->red_counter, c->dscal + PG_S_F, f_typed);
+  else
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3(blocks), dim3(256), 0, c->stream,
+                       (const T*)A->partials, A->ld, A->m, p.S, b, y, y_len, 0.0, (double*)nullptr,
+                       (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+template <typename T, int C, int UR>
+pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
+  constexpr int WAVES = 8;
+  pg_ctx* c = A->ctx;
+  const size_t lds = (size_t)nrg * 1024;
+  const int64_t ncg = (A->n + C - 1) / C;
+  // workgroups per CU limited by LDS (160 KiB) and by 32 waves
+  int per_cu = (int)(160 * 1024 / (lds > 0 ? lds : 1));
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  int64_t blocks = (int64_t)c->num_cu * per_cu;
+  const int64_t need = (ncg + WAVES - 1) / WAVES;
+  if (blocks > need) blocks = need;
+  if (blocks < 1) blocks = 1;
+  pg_prof_scope prof(c, PG_K_GEMV_T);
+  hipLaunchKernelGGL((gemv_t_kernel<T, C, UR, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, c->stream,
+                     (const T*)A->data, A->ld, A->n, A->m, rg_begin, nrg, r, g);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// g = A' r ; gchunks: workspace [nchunks * n] used only when m spans several LDS chunks (may be null when
+// a single chunk suffices)
+template <typename T>
+pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
+  pg_ctx* c = A->ctx;
+  if (A->n == 0) return PG_OK;
+  if (A->m == 0) {
+    PG_HIP(hipMemsetAsync(g, 0, (size_t)A->n * sizeof(T), c->stream));
+    return PG_OK;
+  }
+  const int64_t rows_per_rg = 1024 / (int64_t)sizeof(T);
+  const int n_rowgroups = (int)(A->ld / rows_per_rg);
+  const int rg_per_chunk = (int)(LDS_R_BYTES / 1024);
+  const int nchunks = (n_rowgroups + rg_per_chunk - 1) / rg_per_chunk;
+  if (nchunks == 1) return launch_t<T, 4, 4>(A, 0, n_rowgroups, r, g);
+  if (*gchunks_ws == nullptr) {
+    hipError_t e = hipMalloc((void**)gchunks_ws, (size_t)nchunks * A->n * sizeof(T));
+    if (e != hipSuccess) {
+      pg_set_error("hipMalloc for gradient chunk partials failed: %s", hipGetErrorString(e));
+      return PG_ERR_ALLOC;
+    }
+  }
+  for (int k = 0; k < nchunks; ++k) {
+    const int rb = k * rg_per_chunk;
+    const int nr = (rb + rg_per_chunk <= n_rowgroups) ? rg_per_chunk : (n_rowgroups - rb);
+    PG_TRY((launch_t<T, 4, 4>(A, rb, nr, r, *gchunks_ws + (int64_t)k * A->n)));
+  }
+  int64_t blocks = (A->n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sum_chunks_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const T*)*gchunks_ws,
+                     nchunks, A->n, g);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// all-reduce helper
+pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
+  if (!c->allreduce) return PG_OK;
+  int rc = c->allreduce(c->allreduce_user, buf, count, dtype, (void*)c->stream);
+  if (rc != 0) {
+    pg_set_error("all-reduce callback failed with code %d", rc);
+    return PG_ERR_COLLECTIVE;
+  }
+  return PG_OK;
+}
+
+template <typename T>
+pg_status ls_residual_t(pg_ls* f, const T* x) {
+  pg_mat* A = f->A;
+  T* f_typed = f->ctx->allreduce ? ((T*)f->gbuf + A->n) : nullptr;
+  PG_TRY(gemv_n<T>(A, x, (const T*)f->b, (T*)f->r, A->ld, true, 0.5 * f->lam, f_typed));
+  f->a_passes += 1;
+  return PG_OK;
+}
+
+template <typename T>
+pg_status ls_value_t(pg_ls* f, const T* x) {
+  PG_TRY(ls_residual_t<T>(f, x));
+  pg_ctx* c = f->ctx;
+  if (c->allreduce) {
+    T* ft = (T*)f->gbuf + f->A->n;
+    PG_TRY(do_allreduce(c, ft, 1, f->A->dtype));
+    hipLaunchKernelGGL(cast_scalar_kernel<T>, dim3(1), dim3(1), 0, c->stream, (const T*)ft, c->dscal + PG_S_F);
+    PG_LAUNCH_CHECK();
+  }
+  return PG_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ v, int64_t n, T a) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) v[j] *= a;
+}
+
+template <typename T>
+pg_status ls_vg_t(pg_ls* f, const T* x, T* grad_out) {
+  pg_ctx* c = f->ctx;
+  pg_mat* A = f->A;
+  PG_TRY(ls_residual_t<T>(f, x));
+  T* gdst = c->allreduce ? (T*)f->gbuf : grad_out;
+  T* chunks = (T*)f->gchunks;
+  PG_TRY(gemv_t<T>(A, (const T*)f->r, gdst, &chunks));
+  f->gchunks = chunks;
+  f->a_passes += 1;
+  if (f->lam != 1.0 && A->n > 0) {
+    int64_t blocks = (A->n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, c->stream, gdst, A->n, (T)f->lam);
+    PG_LAUNCH_CHECK();
+  }
+  if (c->allreduce) {
+    PG_TRY(do_allreduce(c, f->gbuf, A->n + 1, A->dtype));
+    hipLaunchKernelGGL(cast_scalar_kernel<T>, dim3(1), dim3(1), 0, c->stream, (const T*)f->gbuf + A->n,
+                       c->dscal + PG_S_F);
+    PG_LAUNCH_CHECK();
+    if (A->n > 0)
+      PG_HIP(hipMemcpyAsync(grad_out, f->gbuf, (size_t)A->n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  }
+  return PG_OK;
+}
+
+}  // namespace
+
+pg_status pg_ls_residual_async(pg_ls* f, const void* x) {
+  return f->A->dtype == PG_F32 ? ls_residual_t<float>(f, (const float*)x) : ls_residual_t<double>(f, (const double*)x);
+}
+pg_status pg_ls_value_async(pg_ls* f, const void* x) {
+  return f->A->dtype == PG_F32 ? ls_value_t<float>(f, (const float*)x) : ls_value_t<double>(f, (const double*)x);
+}
+pg_status pg_ls_vg_async(pg_ls* f, const void* x, void* grad_out) {
+  return f->A->dtype == PG_F32 ? ls_vg_t<float>(f, (const float*)x, (float*)grad_out)
+                               : ls_vg_t<double>(f, (const double*)x, (double*)grad_out);
+}
+
+extern "C" {
+
+pg_status pg_mat_mul(pg_mat* A, const void* x, void* y) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  PG_REQUIRE((A->n == 0 || x != nullptr) && (A->m == 0 || y != nullptr), "null vector");
+  if (A->dtype == PG_F32)
+    return gemv_n<float>(A, (const float*)x, nullptr, (float*)y, A->m, false, 0.0, nullptr);
+  return gemv_n<double>(A, (const double*)x, nullptr, (double*)y, A->m, false, 0.0, nullptr);
+}
+
+pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  PG_REQUIRE((A->m == 0 || r != nullptr) && (A->n == 0 || g != nullptr), "null vector");
+  // chunk workspace is cached on a throw-away pointer here (rare path: m > 16384 rows f32)
+  if (A->dtype == PG_F32) {
+    float* ws = nullptr;
+    pg_status s = gemv_t<float>(A, (const float*)r, (float*)g, &ws);
+    if (ws) {
+      (void)hipStreamSynchronize(A->ctx->stream);
+      (void)hipFree(ws);
+    }
+    return s;
+  }
+  double* ws = nullptr;
+  pg_status s = gemv_t<double>(A, (const double*)r, (double*)g, &ws);
+  if (ws) {
+    (void)hipStreamSynchronize(A->ctx->stream);
+    (void)hipFree(ws);
+  }
+  return s;
+}
+
+pg_status pg_ls_create(pg_ctx* c, pg_mat* A, const void* b, double lam, pg_ls** out) {
+  PG_REQUIRE(c != nullptr && A != nullptr && out != nullptr, "null argument");
+  PG_REQUIRE(A->ctx == c, "matrix belongs to another context");
+  PG_REQUIRE(A->m == 0 || b != nullptr, "b is null");
+  *out = nullptr;
+  pg_ls* f = new pg_ls();
+  f->ctx = c;
+  f->A = A;
+  f->b = b;
+  f->lam = lam;
+  const size_t es = pg_sizeof(A->dtype);
+  if (hipMalloc(&f->r, (size_t)A->ld * es) != hipSuccess ||
+      hipMalloc(&f->gbuf, (size_t)(A->n + 1) * es) != hipSuccess) {
+    pg_set_error("LeastSquares workspace allocation failed");
+    pg_ls_destroy(f);
+    return PG_ERR_ALLOC;
+  }
+  PG_HIP(hipMemsetAsync(f->r, 0, (size_t)A->ld * es, c->stream));
+  PG_HIP(hipMemsetAsync(f->gbuf, 0, (size_t)(A->n + 1) * es, c->stream));
+  *out = f;
+  return PG_OK;
+}
+
+pg_status pg_ls_destroy(pg_ls* f) {
+  if (!f) return PG_OK;
+  if (f->r) (void)hipFree(f->r);
+  if (f->gbuf) (void)hipFree(f->gbuf);
+  if (f->gchunks) (void)hipFree(f->gchunks);
+  delete f;
+  return PG_OK;
+}
+
+pg_status pg_ls_value_and_gradient(pg_ls* f, const void* x, void* grad_out, double* f_out) {
+  PG_REQUIRE(f != nullptr, "f is null");
+  PG_REQUIRE(f->A->n == 0 || (x != nullptr && grad_out != nullptr), "null vector");
+  PG_TRY(pg_ls_vg_async(f, x, grad_out));
+  if (f_out) {
+    PG_TRY(pg_read_scalars(f->ctx, PG_S_F, 1));
+    *f_out = f->ctx->hscal[PG_S_F];
+  }
+  return PG_OK;
+}
+
+pg_status pg_ls_gradient(pg_ls* f, void* grad_out, const void* x, double* f_out) {
+  return pg_ls_value_and_gradient(f, x, grad_out, f_out);
+}
+
+pg_status pg_ls_value(pg_ls* f, const void* x, double* f_out) {
+  PG_REQUIRE(f != nullptr, "f is null");
+  PG_REQUIRE(f->A->n == 0 || x != nullptr, "null vector");
+  PG_TRY(pg_ls_value_async(f, x));
+  if (f_out) {
+    PG_TRY(pg_read_scalars(f->ctx, PG_S_F, 1));
+    *f_out = f->ctx->hscal[PG_S_F];
+  }
+  return PG_OK;
+}
+
+pg_status pg_ls_residual_ptr(pg_ls* f, const void** r_out) {
+  PG_REQUIRE(f != nullptr && r_out != nullptr, "null argument");
+  *r_out = f->r;
+  return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,239 @@
+// Internal definitions shared by the translation units of libproxgrad_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "proxgrad_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------------
+void pg_set_error(const char* fmt, ...);
+
+#define PG_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e__ = (call);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      pg_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__);   \
+      return PG_ERR_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+#define PG_REQUIRE(cond, msg)                                  \
+  do {                                                         \
+    if (!(cond)) {                                             \
+      pg_set_error("invalid argument: %s (%s)", msg, #cond);   \
+      return PG_ERR_INVALID;                                   \
+    }                                                          \
+  } while (0)
+
+#define PG_TRY(expr)                  \
+  do {                                \
+    pg_status s__ = (expr);           \
+    if (s__ != PG_OK) return s__;     \
+  } while (0)
+
+#define PG_LAUNCH_CHECK()                                                                   \
+  do {                                                                                      \
+    hipError_t e__ = hipGetLastError();                                                     \
+    if (e__ != hipSuccess) {                                                                \
+      pg_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__,    \
+                   __LINE__);                                                               \
+      return PG_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+// scalar-block slots (device doubles)
+enum {
+  PG_S_F = 0,        // f = lam/2 ||Ax-b||^2 of the last residual evaluation
+  PG_S_GZ = 1,       // g(z)
+  PG_S_RESINF = 2,   // ||res||_inf
+  PG_S_DOT = 3,      // <grad, res>
+  PG_S_RESSQ = 4,    // ||res||^2
+  PG_S_MISC = 5,     // dot / nrm2sq / nrminf / prox value results
+  PG_S_COUNT = 16
+};
+
+constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize
+constexpr int PG_RED_MAX_NS = 4;
+
+struct pg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop{};
+  int num_cu = 256;
+  // reduction workspace
+  double* red_partials = nullptr;  // [PG_RED_MAX_BLOCKS * PG_RED_MAX_NS]
+  unsigned* red_counter = nullptr; // [8]
+  double* dscal = nullptr;         // [PG_S_COUNT]  device scalar block
+  double* hscal = nullptr;         // [PG_S_COUNT]  pinned host mirror
+  // collective
+  pg_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  // event-pair kernel timing (pg_ctx_profile_*)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[PG_K_COUNT];
+  std::vector<hipEvent_t> prof_pool;
+};
+
+// RAII bracket: records an event pair around a kernel launch when profiling is enabled
+struct pg_prof_scope {
+  pg_ctx* c;
+  int kind;
+  hipEvent_t start = nullptr, stop = nullptr;
+  pg_prof_scope(pg_ctx* ctx, int k);
+  ~pg_prof_scope();
+};
+
+struct pg_mat {
+  pg_ctx* ctx = nullptr;
+  int dtype = PG_F32;
+  int64_t m = 0, n = 0, ld = 0;  // ld in elements, multiple of 1 KiB / sizeof(T)
+  void* data = nullptr;          // [ld * n], padding rows are zero
+  // workspace for y = A x partial sums (lazy)
+  void* partials = nullptr;
+  int64_t partials_slots = 0;
+};
+
+struct pg_ls {
+  pg_ctx* ctx = nullptr;
+  pg_mat* A = nullptr;
+  const void* b = nullptr;  // device m-vector (borrowed)
+  double lam = 1.0;
+  void* r = nullptr;     // [ld] residual A x - b
+  void* gbuf = nullptr;  // [n + 1] gradient ++ f, the all-reduce payload
+  void* gchunks = nullptr;  // [nchunks * n] partial gradients when m needs several LDS chunks
+  int64_t a_passes = 0;     // telemetry: full reads of A
+};
+
+static inline size_t pg_sizeof(int dtype) { return dtype == PG_F64 ? 8 : 4; }
+static inline int64_t pg_round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// scalar read-back: copy `count` doubles starting at slot `first` to the pinned mirror and sync
+pg_status pg_read_scalars(pg_ctx* ctx, int first, int count);
+
+// ---------------------------------------------------------------------------------------------
+// internal (device-pointer, asynchronous) building blocks used by the fused iterations
+// ---------------------------------------------------------------------------------------------
+// r = A x - b (b may be null), f -> dscal[PG_S_F]; local rows only (no collective)
+pg_status pg_ls_residual_async(pg_ls* f, const void* x);
+// full evaluation: local passes, then the all-reduce of [grad ; f] when sharded.  Leaves the gradient in
+// *grad_ptr_out (either grad_out or f->gbuf) and f in dscal[PG_S_F].
+pg_status pg_ls_vg_async(pg_ls* f, const void* x, void* grad_out);
+pg_status pg_ls_value_async(pg_ls* f, const void* x);
+pg_status pg_fb_epilogue_async(pg_ctx* ctx, int dtype, int64_t n, const void* x, const void* grad, double gamma,
+                               int g_kind, double g_p0, double g_p1, void* y, void* z, void* res);
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+  using type = f32x4;
+  static constexpr int N = 4;
+};
+template <>
+struct VecOf<double> {
+  using type = f64x2;
+  static constexpr int N = 2;
+};
+
+__device__ __forceinline__ double pg_shfl_down(double v, int off) { return __shfl_down(v, off, 64); }
+__device__ __forceinline__ float pg_shfl_down(float v, int off) { return __shfl_down(v, off, 64); }
+__device__ __forceinline__ double pg_shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ float pg_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+
+// Deterministic grid-wide reduction of NS doubles per thread (bit k of MAXMASK: slot k is a max, else a
+// sum).  256-thread blocks, gridDim.x <= PG_RED_MAX_BLOCKS.  Every block publishes its partial with an
+// agent-scope release; the last block to arrive (ticket counter) acquires, combines all partials in a
+// fixed order and writes out[k] * post_scale[k].  The counter is reset for the next launch.  Returns true
+// (to all its threads) in the finalizing block only; out[] is then visible to that block's thread 0.
+template <int NS, unsigned MAXMASK>
+__device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __restrict__ partials,
+                                                     unsigned* __restrict__ counter, double* __restrict__ out,
+                                                     const double (&post_scale)[NS]) {
+  __shared__ double sm[4 * NS];
+  __shared__ int sm_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      double o = pg_shfl_down(v[k], off);
+      v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sm[wave * NS + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      double a = sm[k];
+      for (int w = 1; w < 4; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      partials[(size_t)blockIdx.x * NS + k] = a;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = (t == gridDim.x - 1);
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sm_last = last;
+  }
+  __syncthreads();
+  if (!sm_last) return false;
+  double acc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) acc[k] = ((MAXMASK >> k) & 1u) ? -INFINITY : 0.0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      double p = __hip_atomic_load(&partials[(size_t)b * NS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc[k] = ((MAXMASK >> k) & 1u) ? fmax(acc[k], p) : (acc[k] + p);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      double o = pg_shfl_down(acc[k], off);
+      acc[k] = ((MAXMASK >> k) & 1u) ? fmax(acc[k], o) : (acc[k] + o);
+    }
+  }
+  __syncthreads();  // sm reuse
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sm[wave * NS + k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      double a = sm[k];
+      for (int w = 1; w < 4; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      out[k] = a * post_scale[k];
+    }
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return true;  // every thread of the finalizing block
+}
+#endif  // __HIPCC__

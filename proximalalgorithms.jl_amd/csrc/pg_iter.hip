@@ -1,0 +1,367 @@
+// Fused ForwardBackward / FastForwardBackward iterations for f = LeastSquares, g in {Zero, NormL1, IndBox}.
+//
+// Host-side control flow restates the reference line by line; all array work is enqueued as the kernels of
+// pg_gemv.hip / pg_vec.hip on the context stream.  Scalars that the reference holds in R = real(eltype(x0))
+// (gamma, f_x, g_z, the Nesterov recurrences, the line-search compare) are held in T here as well.
+//
+//   init : forward_backward.jl:65-84   / fast_forward_backward.jl:73-97
+//   step : forward_backward.jl:86-123  / fast_forward_backward.jl:106-145
+//   line search : src/utilities/fb_tools.jl:3-5 (f_model), :7-12 (L estimate), :24-63 (backtrack_stepsize!)
+//   sequences   : src/accel/nesterov.jl:14-17, :36, :51-54, :56-103
+//   driver loop : src/ProximalAlgorithms.jl:114-123
+#include <limits>
+#include <utility>
+
+#include "pg_internal.h"
+
+struct pg_iter {
+  pg_ctx* ctx = nullptr;
+  pg_ls* f = nullptr;
+  pg_iter_opts o{};
+  int dtype = PG_F32;
+  int64_t n = 0;
+  void* slab = nullptr;  // one allocation holding all state vectors
+  // state vectors (device)
+  void *x = nullptr, *grad_f_x = nullptr, *y = nullptr, *z = nullptr, *res = nullptr, *z_prev = nullptr,
+       *grad_f_z = nullptr;
+  // scalars (held in double, always rounded through T)
+  double gamma = 0, f_x = 0, g_z = 0, res_inf = 0, dot_gr = 0, res_sq = 0, beta = 0;
+  double f_z = NAN, f_z_upp = NAN;
+  int n_backtracks = 0, flags = 0;
+  bool adaptive = false;
+  bool initialized = false;
+  // extrapolation sequence state (nesterov.jl)
+  double seq_stepsize = -1, seq_theta = -1;  // AdaptiveNesterovSequence :56-60
+  double seq_t = 1;                          // FixedNesterovSequence state
+  int64_t seq_k = 1;                         // SimpleNesterovSequence state
+  int64_t passes0 = 0;
+};
+
+namespace {
+
+template <typename T>
+struct Arith {
+  static double r(double v) { return (double)(T)v; }  // round to working precision
+};
+
+// ---- Nesterov sequences, evaluated in T like the reference's R ----------------------------------
+template <typename T>
+double seq_next(pg_iter* it, double gamma_d, double host_beta) {
+  switch (it->o.seq_kind) {
+    case PG_SEQ_FIXED: {  // nesterov.jl:14-17
+      const T t = (T)it->seq_t;
+      const T t_next = (T(1) + std::sqrt(T(1) + T(4) * t * t)) / T(2);
+      it->seq_t = (double)t_next;
+      return (double)((t - T(1)) / t_next);
+    }
+    case PG_SEQ_SIMPLE: {  // nesterov.jl:36
+      const int64_t k = it->seq_k++;
+      return (double)((T)(k - 1) / (T)(k + 2));
+    }
+    case PG_SEQ_CONSTANT: {  // nesterov.jl:51-54
+      const T k_inverse = (T)it->o.seq_p0 * (T)it->o.seq_p1;
+      return (double)((T(1) - std::sqrt(k_inverse)) / (T(1) + std::sqrt(k_inverse)));
+    }
+    case PG_SEQ_HOST:
+      return (double)(T)host_beta;
+    case PG_SEQ_ADAPTIVE:
+    default: {  // nesterov.jl:89-103
+      const T m = (T)it->o.mf;
+      const T stepsize = (T)gamma_d;
+      T s_step = (T)it->seq_stepsize, s_theta = (T)it->seq_theta;
+      if (s_step < T(0)) {
+        s_step = stepsize;
+        s_theta = m > T(0) ? std::sqrt(m * stepsize) : T(1);
+      }
+      const T b = s_theta * s_theta / s_step - m;
+      const T delta = b * b + T(4) * (s_theta * s_theta) / (s_step * stepsize);
+      const T theta = stepsize * (-b + std::sqrt(delta)) / T(2);
+      const T beta = stepsize * s_theta * (T(1) - s_theta) / (s_step * theta + stepsize * s_theta * s_theta);
+      it->seq_stepsize = (double)stepsize;
+      it->seq_theta = (double)theta;
+      return (double)beta;
+    }
+  }
+}
+
+inline size_t vec_bytes(const pg_iter* it) {
+  return (size_t)pg_round_up((int64_t)((size_t)(it->n > 0 ? it->n : 1) * pg_sizeof(it->dtype)), 256);
+}
+
+// epilogue + read back {g_z, res_inf, <grad,res>, ||res||^2} and f (slot 0) in one copy
+template <typename T>
+pg_status epilogue_and_read(pg_iter* it, bool read_f) {
+  pg_ctx* c = it->ctx;
+  PG_TRY(pg_fb_epilogue_async(c, it->dtype, it->n, it->x, it->grad_f_x, it->gamma, it->o.g_kind, it->o.g_p0,
+                              it->o.g_p1, it->y, it->z, it->res));
+  PG_TRY(pg_read_scalars(c, PG_S_F, 5));
+  if (read_f) it->f_x = Arith<T>::r(c->hscal[PG_S_F]);
+  it->g_z = Arith<T>::r(c->hscal[PG_S_GZ]);
+  it->res_inf = Arith<T>::r(c->hscal[PG_S_RESINF]);
+  it->dot_gr = Arith<T>::r(c->hscal[PG_S_DOT]);
+  it->res_sq = Arith<T>::r(c->hscal[PG_S_RESSQ]);
+  return PG_OK;
+}
+
+// f_model: fb_tools.jl:3-5   f_x - real(dot(grad, res)) + (L / 2) * norm(res)^2, L = alpha / gamma, alpha = 1
+template <typename T>
+double f_model(const pg_iter* it) {
+  const T L = T(1) / (T)it->gamma;
+  return (double)((T)it->f_x - (T)it->dot_gr + (L / T(2)) * (T)it->res_sq);
+}
+
+// backtrack_stepsize!: fb_tools.jl:24-63 with A === nothing.  On entry the epilogue scalars describe the
+// current (x, grad_f_x, gamma_prev) triple; gamma has already been multiplied by increase_gamma by the
+// caller (forward_backward.jl:91), exactly like the reference, where y/z/res are NOT recomputed for the
+// increased gamma before the first test.  keep_grad: also produce grad f(z) into grad_f_z (FB).
+template <typename T>
+pg_status backtrack(pg_iter* it, bool keep_grad) {
+  pg_ctx* c = it->ctx;
+  const T eps = std::numeric_limits<T>::epsilon();
+  const T min_gamma = (T)it->o.minimum_gamma, reduce = (T)it->o.reduce_gamma;
+  T f_upp = (T)f_model<T>(it);  // :42
+  // :44  f(z) (and grad f(z) when it is kept)
+  if (keep_grad)
+    PG_TRY(pg_ls_vg_async(it->f, it->z, it->grad_f_z));
+  else
+    PG_TRY(pg_ls_value_async(it->f, it->z));
+  PG_TRY(pg_read_scalars(c, PG_S_F, 1));
+  T f_z = (T)c->hscal[PG_S_F];
+  T tol = T(10) * eps * (T(1) + std::fabs(f_z));  // :45
+  it->n_backtracks = 0;
+  while (f_z > f_upp + tol && (T)it->gamma >= min_gamma) {  // :46
+    it->gamma = (double)((T)it->gamma * reduce);            // :47
+    PG_TRY(epilogue_and_read<T>(it, false));                // :48-50 y, z, g_z, res
+    f_upp = (T)f_model<T>(it);                              // :51
+    if (keep_grad)
+      PG_TRY(pg_ls_vg_async(it->f, it->z, it->grad_f_z));   // :53
+    else
+      PG_TRY(pg_ls_value_async(it->f, it->z));
+    PG_TRY(pg_read_scalars(c, PG_S_F, 1));
+    f_z = (T)c->hscal[PG_S_F];
+    tol = T(10) * eps * (T(1) + std::fabs(f_z));  // :54
+    it->n_backtracks++;
+  }
+  if ((T)it->gamma < min_gamma) it->flags |= PG_FLAG_GAMMA_TOO_SMALL;  // :59-61 (@warn)
+  it->f_z = (double)f_z;
+  it->f_z_upp = (double)f_upp;
+  return PG_OK;
+}
+
+template <typename T>
+pg_status iter_init(pg_iter* it, const void* x0) {
+  pg_ctx* c = it->ctx;
+  const int64_t n = it->n;
+  const size_t nb = (size_t)n * sizeof(T);
+  it->flags = 0;
+  it->n_backtracks = 0;
+  it->beta = 0;
+  it->f_z = it->f_z_upp = NAN;
+  it->seq_stepsize = it->seq_theta = -1;
+  it->seq_t = 1;
+  it->seq_k = 1;
+  it->passes0 = it->f->a_passes;
+  // x = copy(x0)                                                         fb:66 / ffb:74
+  if (n > 0) PG_HIP(hipMemcpyAsync(it->x, x0, nb, hipMemcpyDeviceToDevice, c->stream));
+  // f_x, grad_f_x = value_and_gradient(f, x)                             fb:67 / ffb:75
+  PG_TRY(pg_ls_vg_async(it->f, it->x, it->grad_f_x));
+  PG_TRY(pg_read_scalars(c, PG_S_F, 1));
+  it->f_x = Arith<T>::r(c->hscal[PG_S_F]);
+  // gamma = iter.gamma === nothing ? 1 / lower_bound_smoothness_constant(f, I, x, grad_f_x) : iter.gamma
+  double gamma = it->o.gamma > 0 ? it->o.gamma : (it->o.Lf > 0 ? (double)(T(1) / (T)it->o.Lf) : -1.0);
+  if (gamma <= 0) {
+    // fb_tools.jl:7-12: xeps = x .+ 1 ; grad at xeps ; norm(grad_eps - grad) / sqrt(length(x))
+    // scratch: y <- xeps, res <- grad_eps, z <- grad_eps - grad   (all overwritten by the epilogue below)
+    PG_TRY(pg_add_scalar(c, it->dtype, n, it->y, it->x, 1.0));
+    PG_TRY(pg_ls_vg_async(it->f, it->y, it->res));
+    PG_TRY(pg_axpby(c, it->dtype, n, it->z, 1.0, it->res, -1.0, it->grad_f_x));
+    double nrm2 = 0;
+    PG_TRY(pg_nrm2sq(c, it->dtype, n, it->z, &nrm2));
+    const T Lest = (T)std::sqrt((T)nrm2) / (T)std::sqrt((double)n);
+    gamma = (double)(T(1) / Lest);
+  }
+  it->gamma = Arith<T>::r(gamma);
+  // y = x - gamma .* grad_f_x ; z, g_z = prox(g, y, gamma) ; res = x - z    fb:71-72,81 / ffb:79-80,89
+  PG_TRY(epilogue_and_read<T>(it, false));
+  if (it->o.fast && n > 0)  // z_prev = copy(x)                            ffb:69
+    PG_HIP(hipMemcpyAsync(it->z_prev, it->x, nb, hipMemcpyDeviceToDevice, c->stream));
+  it->initialized = true;
+  return PG_OK;
+}
+
+template <typename T>
+pg_status iter_step(pg_iter* it, double host_beta) {
+  it->flags = 0;
+  it->n_backtracks = 0;
+  it->f_z = it->f_z_upp = NAN;
+  if (!it->o.fast) {
+    // ---------------- ForwardBackward: forward_backward.jl:86-123 ----------------
+    if (it->adaptive) {
+      it->gamma = (double)((T)it->gamma * (T)it->o.increase_gamma);  // :91
+      PG_TRY(backtrack<T>(it, true));                                // :92-108
+      it->f_x = it->f_z;                                             // :92 (state.f_x = f_Az)
+      std::swap(it->x, it->z);                                       // :109
+      std::swap(it->grad_f_x, it->grad_f_z);                         // :110
+      PG_TRY(epilogue_and_read<T>(it, false));                       // :117-120
+    } else {
+      std::swap(it->x, it->z);                                       // :112
+      PG_TRY(pg_ls_vg_async(it->f, it->x, it->grad_f_x));            // :113-114
+      PG_TRY(epilogue_and_read<T>(it, true));                        // :117-120
+    }
+  } else {
+    // ---------------- FastForwardBackward: fast_forward_backward.jl:106-145 ----------------
+    if (it->adaptive) {
+      it->gamma = (double)((T)it->gamma * (T)it->o.increase_gamma);  // :111
+      PG_TRY(backtrack<T>(it, false));                               // :112-127 (grad at z discarded)
+    } else {
+      if (it->o.gamma > 0 || it->o.Lf > 0)                           // :131 (state.gamma = iter.gamma)
+        it->gamma = Arith<T>::r(it->o.gamma > 0 ? it->o.gamma : (double)(T(1) / (T)it->o.Lf));
+    }
+    it->beta = seq_next<T>(it, it->gamma, host_beta);                // :134
+    PG_TRY(pg_extrapolate(it->ctx, it->dtype, it->n, it->x, it->z, it->z_prev, it->beta));  // :135
+    std::swap(it->z_prev, it->z);                                    // :136
+    PG_TRY(pg_ls_vg_async(it->f, it->x, it->grad_f_x));              // :138-139
+    PG_TRY(epilogue_and_read<T>(it, true));                          // :140-142
+  }
+  return PG_OK;
+}
+
+void fill_scalars(const pg_iter* it, pg_iter_scalars* s) {
+  if (!s) return;
+  s->gamma = it->gamma;
+  s->f_x = it->f_x;
+  s->g_z = it->g_z;
+  s->res_inf = it->res_inf;
+  s->beta = it->beta;
+  s->f_z = it->f_z;
+  s->f_z_upp = it->f_z_upp;
+  s->n_backtracks = it->n_backtracks;
+  s->flags = it->flags;
+  s->a_passes = it->f->a_passes - it->passes0;
+}
+
+}  // namespace
+
+extern "C" {
+
+pg_status pg_iter_opts_default(pg_iter_opts* o) {
+  PG_REQUIRE(o != nullptr, "opts is null");
+  memset(o, 0, sizeof(*o));
+  o->fast = 0;
+  o->adaptive = -1;
+  o->Lf = -1;
+  o->gamma = -1;
+  o->minimum_gamma = 1e-7;   // forward_backward.jl:45
+  o->reduce_gamma = 0.5;     // :46
+  o->increase_gamma = 1.0;   // :47
+  o->mf = 0;                 // fast_forward_backward.jl:48
+  o->seq_kind = PG_SEQ_ADAPTIVE;
+  o->g_kind = PG_G_ZERO;
+  return PG_OK;
+}
+
+pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** out) {
+  PG_REQUIRE(c != nullptr && f != nullptr && o != nullptr && out != nullptr, "null argument");
+  PG_REQUIRE(f->ctx == c, "f belongs to another context");
+  PG_REQUIRE(o->g_kind == PG_G_ZERO || o->g_kind == PG_G_NORML1 || o->g_kind == PG_G_INDBOX, "unknown g_kind");
+  PG_REQUIRE(o->seq_kind >= PG_SEQ_ADAPTIVE && o->seq_kind <= PG_SEQ_HOST, "unknown seq_kind");
+  *out = nullptr;
+  pg_iter* it = new pg_iter();
+  it->ctx = c;
+  it->f = f;
+  it->o = *o;
+  it->dtype = f->A->dtype;
+  it->n = f->A->n;
+  // adaptive::Bool = gamma === nothing        forward_backward.jl:43-44
+  const bool gamma_known = (o->gamma > 0) || (o->Lf > 0);
+  it->adaptive = o->adaptive < 0 ? !gamma_known : (o->adaptive != 0);
+  const size_t vb = vec_bytes(it);
+  const int nvec = 6;
+  PG_HIP(hipSetDevice(c->device));
+  hipError_t e = hipMalloc(&it->slab, vb * nvec);
+  if (e != hipSuccess) {
+    pg_set_error("state allocation (%zu bytes) failed: %s", vb * nvec, hipGetErrorString(e));
+    delete it;
+    return PG_ERR_ALLOC;
+  }
+  e = hipMemsetAsync(it->slab, 0, vb * nvec, c->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(it->slab);
+    delete it;
+    pg_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return PG_ERR_HIP;
+  }
+  char* base = (char*)it->slab;
+  it->x = base + 0 * vb;
+  it->grad_f_x = base + 1 * vb;
+  it->y = base + 2 * vb;
+  it->z = base + 3 * vb;
+  it->res = base + 4 * vb;
+  if (o->fast)
+    it->z_prev = base + 5 * vb;
+  else
+    it->grad_f_z = base + 5 * vb;
+  *out = it;
+  return PG_OK;
+}
+
+pg_status pg_iter_destroy(pg_iter* it) {
+  if (!it) return PG_OK;
+  if (it->slab) {
+    (void)hipStreamSynchronize(it->ctx->stream);
+    (void)hipFree(it->slab);
+  }
+  delete it;
+  return PG_OK;
+}
+
+pg_status pg_iter_init(pg_iter* it, const void* x0, pg_iter_scalars* out) {
+  PG_REQUIRE(it != nullptr, "iterator is null");
+  PG_REQUIRE(it->n == 0 || x0 != nullptr, "x0 is null");
+  PG_TRY(it->dtype == PG_F32 ? iter_init<float>(it, x0) : iter_init<double>(it, x0));
+  fill_scalars(it, out);
+  return PG_OK;
+}
+
+pg_status pg_iter_step(pg_iter* it, double host_beta, pg_iter_scalars* out) {
+  PG_REQUIRE(it != nullptr, "iterator is null");
+  PG_REQUIRE(it->initialized, "pg_iter_init has not been called");
+  PG_TRY(it->dtype == PG_F32 ? iter_step<float>(it, host_beta) : iter_step<double>(it, host_beta));
+  fill_scalars(it, out);
+  return PG_OK;
+}
+
+// IterativeAlgorithm: for (k, state) in enumerate(iter): if k >= maxit || stop(iter, state) return (.., k)
+pg_status pg_iter_run(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out,
+                      pg_iter_scalars* out) {
+  PG_REQUIRE(it != nullptr && k_out != nullptr, "null argument");
+  PG_REQUIRE(it->initialized, "pg_iter_init has not been called");
+  PG_REQUIRE(it->o.seq_kind != PG_SEQ_HOST || !it->o.fast, "PG_SEQ_HOST needs per-step coefficients");
+  int64_t k = k_start;
+  const bool f32 = it->dtype == PG_F32;
+  for (;;) {
+    // default_stopping_criterion: norm(res, Inf) / gamma <= tol   (in R)
+    const bool stop = f32 ? ((float)it->res_inf / (float)it->gamma <= (float)tol)
+                          : (it->res_inf / it->gamma <= tol);
+    if (k >= maxit || stop) break;
+    PG_TRY(f32 ? iter_step<float>(it, 0.0) : iter_step<double>(it, 0.0));
+    ++k;
+  }
+  *k_out = k;
+  fill_scalars(it, out);
+  return PG_OK;
+}
+
+pg_status pg_iter_state_view(pg_iter* it, pg_iter_state* out) {
+  PG_REQUIRE(it != nullptr && out != nullptr, "null argument");
+  out->x = it->x;
+  out->grad_f_x = it->grad_f_x;
+  out->y = it->y;
+  out->z = it->z;
+  out->res = it->res;
+  out->z_prev = it->z_prev;
+  out->grad_f_z = it->grad_f_z;
+  return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// Elementwise / BLAS-1 kernels over n-vectors: the broadcasts, prox operators and reductions of the
+// forward-backward iteration body (forward_backward.jl:117-120, fast_forward_backward.jl:135-142,
+// fb_tools.jl:3-5,48-50) and the fused forward-backward epilogue.
+//
+// All are HBM-bound streams: 16-byte-per-lane loads/stores when every pointer is 16-byte aligned
+// (always true for library- and torch-allocated vectors), scalar tail; reductions accumulate per thread in
+// fp64 and finish with the deterministic grid reduction of pg_internal.h.
+#include "pg_ew.h"
+
+namespace {
+
+using namespace pgew;
+
+// ---- functors ---------------------------------------------------------------------------------
+template <typename T>
+struct AxpbyF {  // out = a x + b y   (y nullable)
+  T* out;
+  const T* x;
+  const T* y;
+  T a, b;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double*) const {
+    Pack<T, N> xv = ld<T, N>(x, i), o;
+    if (y != nullptr) {
+      Pack<T, N> yv = ld<T, N>(y, i);
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.v[e] = a * xv.v[e] + b * yv.v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.v[e] = a * xv.v[e];
+    }
+    st<T, N>(out, i, o);
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+template <typename T>
+struct AddScalarF {  // out = x + c  (x nullable: fill)
+  T* out;
+  const T* x;
+  T c;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double*) const {
+    Pack<T, N> o;
+    if (x != nullptr) {
+      Pack<T, N> xv = ld<T, N>(x, i);
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.v[e] = xv.v[e] + c;
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.v[e] = c;
+    }
+    st<T, N>(out, i, o);
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+template <typename T>
+struct ExtrapolateF {  // x = z + beta (z - z_prev)      fast_forward_backward.jl:135
+  T* x;
+  const T* z;
+  const T* zp;
+  T beta;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double*) const {
+    Pack<T, N> zv = ld<T, N>(z, i), pv = ld<T, N>(zp, i), o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) o.v[e] = zv.v[e] + beta * (zv.v[e] - pv.v[e]);
+    st<T, N>(x, i, o);
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+template <typename T>
+struct DotF {  // acc[0] = sum x y
+  const T* x;
+  const T* y;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i), yv = ld<T, N>(y, i);
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[0] += (double)xv.v[e] * (double)yv.v[e];
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+template <typename T>
+struct NrmInfF {  // acc[0] = max |x|
+  const T* x;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i);
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[0] = fmax(acc[0], fabs((double)xv.v[e]));
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+template <typename T>
+struct Norm1F {  // acc[0] = lam * sum |x|
+  const T* x;
+  double lam;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i);
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[0] += fabs((double)xv.v[e]);
+  }
+  __device__ double post_scale(int) const { return lam; }
+};
+
+// soft threshold exactly as ProximalOperators' NormL1 prox!:
+//   y = x + (x <= -gl ? gl : (x >= gl ? -gl : -x))
+template <typename T>
+__device__ __forceinline__ T soft_threshold(T x, T gl) {
+  return x <= -gl ? x + gl : (x >= gl ? x - gl : T(0));
+}
+
+template <typename T>
+struct ProxL1F {  // y = soft(x, gamma lam); acc[0] = lam sum |y|
+  T* y;
+  const T* x;
+  T gl;
+  double lam;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i), o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      o.v[e] = soft_threshold(xv.v[e], gl);
+      acc[0] += fabs((double)o.v[e]);
+    }
+    st<T, N>(y, i, o);
+  }
+  __device__ double post_scale(int) const { return lam; }
+};
+
+template <typename T>
+struct ProxBoxF {  // y = min(hi, max(lo, x))   (vector bounds optional)
+  T* y;
+  const T* x;
+  T lo, hi;
+  const T* lov;
+  const T* hiv;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double*) const {
+    Pack<T, N> xv = ld<T, N>(x, i), o;
+    Pack<T, N> l, h;
+    if (lov != nullptr) l = ld<T, N>(lov, i);
+    if (hiv != nullptr) h = ld<T, N>(hiv, i);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const T le = lov != nullptr ? l.v[e] : lo;
+      const T he = hiv != nullptr ? h.v[e] : hi;
+      o.v[e] = fmin(he, fmax(le, xv.v[e]));
+    }
+    st<T, N>(y, i, o);
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+// fused forward-backward epilogue:
+//   y = x - gamma grad ; z = prox_{gamma g}(y) ; res = x - z
+//   acc = { g(z)/lam = sum|z| , max|res| , sum grad*res , sum res^2 }
+template <typename T, int GKIND>
+struct EpilogueF {
+  const T* x;
+  const T* grad;
+  T* y;
+  T* z;
+  T* res;
+  T* grad_copy;  // nullable: also materialise grad here (sharded path keeps it in the all-reduce buffer)
+  T gamma, p0, p1;  // p0 = gamma*lam (NormL1) | lo (IndBox) ; p1 = hi
+  double gscale;    // lam for NormL1 else 0
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i), gv = ld<T, N>(grad, i), yv, zv, rv;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      yv.v[e] = xv.v[e] - gamma * gv.v[e];
+      if constexpr (GKIND == PG_G_NORML1)
+        zv.v[e] = soft_threshold(yv.v[e], p0);
+      else if constexpr (GKIND == PG_G_INDBOX)
+        zv.v[e] = fmin(p1, fmax(p0, yv.v[e]));
+      else
+        zv.v[e] = yv.v[e];
+      rv.v[e] = xv.v[e] - zv.v[e];
+      if constexpr (GKIND == PG_G_NORML1) acc[0] += fabs((double)zv.v[e]);
+      acc[1] = fmax(acc[1], fabs((double)rv.v[e]));
+      acc[2] += (double)gv.v[e] * (double)rv.v[e];
+      acc[3] += (double)rv.v[e] * (double)rv.v[e];
+    }
+    st<T, N>(y, i, yv);
+    st<T, N>(z, i, zv);
+    st<T, N>(res, i, rv);
+    if (grad_copy != nullptr) st<T, N>(grad_copy, i, gv);
+  }
+  __device__ double post_scale(int k) const { return k == 0 ? gscale : 1.0; }
+};
+
+template <typename T>
+pg_status epilogue_t(pg_ctx* c, int64_t n, const T* x, const T* grad, double gamma, int g_kind, double g_p0,
+                     double g_p1, T* y, T* z, T* res, T* grad_copy) {
+  const bool v = aligned16(x) && aligned16(grad) && aligned16(y) && aligned16(z) && aligned16(res) &&
+                 (grad_copy == nullptr || aligned16(grad_copy));
+  const T gm = (T)gamma;
+  pg_prof_scope prof(c, PG_K_EPILOGUE);
+  if (g_kind == PG_G_NORML1) {
+    EpilogueF<T, PG_G_NORML1> f{x, grad, y, z, res, grad_copy, gm, (T)(gm * (T)g_p0), T(0), (double)(T)g_p0};
+    return launch_ew<T, decltype(f), 4, 0x2u>(c, n, v, f, c->dscal + PG_S_GZ);
+  }
+  if (g_kind == PG_G_INDBOX) {
+    EpilogueF<T, PG_G_INDBOX> f{x, grad, y, z, res, grad_copy, gm, (T)g_p0, (T)g_p1, 0.0};
+    return launch_ew<T, decltype(f), 4, 0x2u>(c, n, v, f, c->dscal + PG_S_GZ);
+  }
+  if (g_kind == PG_G_ZERO) {
+    EpilogueF<T, PG_G_ZERO> f{x, grad, y, z, res, grad_copy, gm, T(0), T(0), 0.0};
+    return launch_ew<T, decltype(f), 4, 0x2u>(c, n, v, f, c->dscal + PG_S_GZ);
+  }
+  pg_set_error("unknown g_kind %d", g_kind);
+  return PG_ERR_INVALID;
+}
+
+#define PG_DISPATCH(dtype, CALL_F32, CALL_F64)                    \
+  do {                                                            \
+    if ((dtype) == PG_F32) return CALL_F32;                       \
+    if ((dtype) == PG_F64) return CALL_F64;                       \
+    pg_set_error("dtype must be PG_F32 or PG_F64, got %d", dtype); \
+    return PG_ERR_INVALID;                                        \
+  } while (0)
+
+template <typename T>
+pg_status axpby_t(pg_ctx* c, int64_t n, void* out, double a, const void* x, double b, const void* y) {
+  AxpbyF<T> f{(T*)out, (const T*)x, (b != 0.0 ? (const T*)y : nullptr), (T)a, (T)b};
+  const bool v = aligned16(out) && aligned16(x) && (f.y == nullptr || aligned16(y));
+  return launch_ew<T, AxpbyF<T>, 0, 0u>(c, n, v, f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status add_scalar_t(pg_ctx* c, int64_t n, void* out, const void* x, double cst) {
+  AddScalarF<T> f{(T*)out, (const T*)x, (T)cst};
+  const bool v = aligned16(out) && (x == nullptr || aligned16(x));
+  return launch_ew<T, AddScalarF<T>, 0, 0u>(c, n, v, f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status extrapolate_t(pg_ctx* c, int64_t n, void* x, const void* z, const void* zp, double beta) {
+  pg_prof_scope prof(c, PG_K_EXTRAPOLATE);
+  ExtrapolateF<T> f{(T*)x, (const T*)z, (const T*)zp, (T)beta};
+  const bool v = aligned16(x) && aligned16(z) && aligned16(zp);
+  return launch_ew<T, ExtrapolateF<T>, 0, 0u>(c, n, v, f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status dot_t(pg_ctx* c, int64_t n, const void* x, const void* y) {
+  DotF<T> f{(const T*)x, (const T*)y};
+  return launch_ew<T, DotF<T>, 1, 0u>(c, n, aligned16(x) && aligned16(y), f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status nrminf_t(pg_ctx* c, int64_t n, const void* x) {
+  NrmInfF<T> f{(const T*)x};
+  return launch_ew<T, NrmInfF<T>, 1, 0x1u>(c, n, aligned16(x), f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status norm1_t(pg_ctx* c, int64_t n, const void* x, double lam) {
+  Norm1F<T> f{(const T*)x, (double)(T)lam};
+  return launch_ew<T, Norm1F<T>, 1, 0u>(c, n, aligned16(x), f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status prox_l1_t(pg_ctx* c, int64_t n, void* y, const void* x, double lam, double gamma) {
+  ProxL1F<T> f{(T*)y, (const T*)x, (T)((T)gamma * (T)lam), (double)(T)lam};
+  return launch_ew<T, ProxL1F<T>, 1, 0u>(c, n, aligned16(x) && aligned16(y), f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status prox_box_t(pg_ctx* c, int64_t n, void* y, const void* x, double lo, double hi, const void* lov,
+                     const void* hiv) {
+  ProxBoxF<T> f{(T*)y, (const T*)x, (T)lo, (T)hi, (const T*)lov, (const T*)hiv};
+  const bool v = aligned16(x) && aligned16(y) && (!lov || aligned16(lov)) && (!hiv || aligned16(hiv));
+  return launch_ew<T, ProxBoxF<T>, 0, 0u>(c, n, v, f, c->dscal + PG_S_MISC);
+}
+
+pg_status finish_scalar(pg_ctx* c, int slot, double* out) {
+  if (!out) return PG_OK;
+  PG_TRY(pg_read_scalars(c, slot, 1));
+  *out = c->hscal[slot];
+  return PG_OK;
+}
+
+}  // namespace
+
+pg_status pg_fb_epilogue_async(pg_ctx* c, int dtype, int64_t n, const void* x, const void* grad, double gamma,
+                               int g_kind, double g_p0, double g_p1, void* y, void* z, void* res) {
+  PG_DISPATCH(dtype,
+              epilogue_t<float>(c, n, (const float*)x, (const float*)grad, gamma, g_kind, g_p0, g_p1, (float*)y,
+                                (float*)z, (float*)res, nullptr),
+              epilogue_t<double>(c, n, (const double*)x, (const double*)grad, gamma, g_kind, g_p0, g_p1,
+                                 (double*)y, (double*)z, (double*)res, nullptr));
+}
+
+extern "C" {
+
+#define PG_VEC_ARGS_OK(c, n) \
+  PG_REQUIRE((c) != nullptr, "ctx is null"); \
+  PG_REQUIRE((n) >= 0, "negative length")
+
+pg_status pg_axpby(pg_ctx* c, int32_t dtype, int64_t n, void* out, double a, const void* x, double b,
+                   const void* y) {
+  PG_VEC_ARGS_OK(c, n);
+  if (n == 0) return PG_OK;
+  PG_REQUIRE(out != nullptr && x != nullptr && (b == 0.0 || y != nullptr), "null vector");
+  PG_DISPATCH(dtype, axpby_t<float>(c, n, out, a, x, b, y), axpby_t<double>(c, n, out, a, x, b, y));
+}
+
+pg_status pg_add_scalar(pg_ctx* c, int32_t dtype, int64_t n, void* out, const void* x, double cst) {
+  PG_VEC_ARGS_OK(c, n);
+  if (n == 0) return PG_OK;
+  PG_REQUIRE(out != nullptr && x != nullptr, "null vector");
+  PG_DISPATCH(dtype, add_scalar_t<float>(c, n, out, x, cst), add_scalar_t<double>(c, n, out, x, cst));
+}
+
+pg_status pg_fill(pg_ctx* c, int32_t dtype, int64_t n, void* out, double cst) {
+  PG_VEC_ARGS_OK(c, n);
+  if (n == 0) return PG_OK;
+  PG_REQUIRE(out != nullptr, "null vector");
+  PG_DISPATCH(dtype, add_scalar_t<float>(c, n, out, nullptr, cst), add_scalar_t<double>(c, n, out, nullptr, cst));
+}
+
+pg_status pg_extrapolate(pg_ctx* c, int32_t dtype, int64_t n, void* x, const void* z, const void* zp,
+                         double beta) {
+  PG_VEC_ARGS_OK(c, n);
+  if (n == 0) return PG_OK;
+  PG_REQUIRE(x != nullptr && z != nullptr && zp != nullptr, "null vector");
+  PG_DISPATCH(dtype, extrapolate_t<float>(c, n, x, z, zp, beta), extrapolate_t<double>(c, n, x, z, zp, beta));
+}
+
+pg_status pg_dot(pg_ctx* c, int32_t dtype, int64_t n, const void* x, const void* y, double* out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? dot_t<float>(c, n, x, y) : dot_t<double>(c, n, x, y));
+  return finish_scalar(c, PG_S_MISC, out);
+}
+
+pg_status pg_nrm2sq(pg_ctx* c, int32_t dtype, int64_t n, const void* x, double* out) {
+  return pg_dot(c, dtype, n, x, x, out);
+}
+
+pg_status pg_nrminf(pg_ctx* c, int32_t dtype, int64_t n, const void* x, double* out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || x != nullptr, "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? nrminf_t<float>(c, n, x) : nrminf_t<double>(c, n, x));
+  return finish_scalar(c, PG_S_MISC, out);
+}
+
+pg_status pg_norml1_value(pg_ctx* c, int32_t dtype, int64_t n, const void* x, double lam, double* out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || x != nullptr, "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? norm1_t<float>(c, n, x, lam) : norm1_t<double>(c, n, x, lam));
+  return finish_scalar(c, PG_S_MISC, out);
+}
+
+pg_status pg_prox_norml1(pg_ctx* c, int32_t dtype, int64_t n, void* y, const void* x, double lam, double gamma,
+                         double* gy_out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? prox_l1_t<float>(c, n, y, x, lam, gamma) : prox_l1_t<double>(c, n, y, x, lam, gamma));
+  return finish_scalar(c, PG_S_MISC, gy_out);
+}
+
+pg_status pg_prox_indbox(pg_ctx* c, int32_t dtype, int64_t n, void* y, const void* x, double lo, double hi,
+                         const void* lo_vec, const void* hi_vec, double* gy_out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  if (n > 0)
+    PG_TRY(dtype == PG_F32 ? prox_box_t<float>(c, n, y, x, lo, hi, lo_vec, hi_vec)
+                           : prox_box_t<double>(c, n, y, x, lo, hi, lo_vec, hi_vec));
+  if (gy_out) *gy_out = 0.0;
+  return PG_OK;
+}
+
+pg_status pg_fb_epilogue(pg_ctx* c, int32_t dtype, int64_t n, const void* x, const void* grad, double gamma,
+                         int32_t g_kind, double g_p0, double g_p1, void* y, void* z, void* res,
+                         double* scalars_out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x && grad && y && z && res), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(pg_fb_epilogue_async(c, dtype, n, x, grad, gamma, g_kind, g_p0, g_p1, y, z, res));
+  if (scalars_out) {
+    PG_TRY(pg_read_scalars(c, PG_S_GZ, 4));
+    for (int k = 0; k < 4; ++k) scalars_out[k] = c->hscal[PG_S_GZ + k];
+  }
+  return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+"""Device context, vectors and the dense matrix object (host-side handles over the C ABI).
+
+PyTorch is used here only as plumbing: device memory (``torch.empty``), the current HIP stream and
+``torch.distributed``; every arithmetic operation goes through libproxgrad_hip's kernels.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import PG_F32, PG_F64, call
+
+_NP2PG = {np.dtype(np.float32): PG_F32, np.dtype(np.float64): PG_F64}
+_PG2NP = {PG_F32: np.dtype(np.float32), PG_F64: np.dtype(np.float64)}
+
+
+def pg_dtype(dtype):
+    dt = np.dtype(dtype)
+    if dt not in _NP2PG:
+        raise TypeError(f"unsupported element type {dt}; the HIP engine computes in Float32 or Float64")
+    return _NP2PG[dt]
+
+
+class Context:
+    """One HIP device + stream + workspace (pg_ctx).  One host thread at a time."""
+
+    def __init__(self, device=None, stream=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise _lib.ProxGradError("no HIP device visible: the proximal-gradient engine needs an MI355X (gfx950)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.torch_device).cuda_stream
+        self.stream = int(stream)
+        h = C.c_void_p()
+        call("pg_ctx_create", self.device, C.c_void_p(self.stream), C.byref(h))
+        self._h = h
+        self._allreduce_cb = None
+        self._finalizer = weakref.finalize(self, _lib.load().pg_ctx_destroy, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        call("pg_ctx_sync", self._h)
+
+    def device_info(self):
+        info = _lib.pg_device_info()
+        call("pg_ctx_device_info", self._h, C.byref(info))
+        return {"device": info.device, "compute_units": info.compute_units, "wavefront_size": info.wavefront_size,
+                "lds_bytes_per_cu": info.lds_bytes_per_cu, "global_mem_bytes": info.global_mem_bytes,
+                "clock_khz": info.clock_khz, "arch": info.arch.decode(), "name": info.name.decode()}
+
+    def profile(self, enable=True):
+        call("pg_ctx_profile_enable", self._h, 1 if enable else 0)
+
+    def profile_reset(self):
+        call("pg_ctx_profile_reset", self._h)
+
+    def profile_read(self):
+        """{kernel name: (launches, total_ms)} measured with HIP events on this context's stream."""
+        out = {}
+        for k, name in enumerate(_lib.KERNEL_NAMES):
+            n, ms = C.c_int64(), C.c_double()
+            call("pg_ctx_profile_read", self._h, k, C.byref(n), C.byref(ms))
+            out[name] = (n.value, ms.value)
+        return out
+
+    def set_allreduce(self, fn):
+        """fn(ptr:int, count:int, pg_dtype:int, stream:int) -> None performs an in-place SUM all-reduce on the
+        device buffer; None clears it.  Used for row-sharded LeastSquares."""
+        if fn is None:
+            self._allreduce_cb = None
+            call("pg_ctx_set_allreduce", self._h, _lib.ALLREDUCE_FN(), None)
+            return
+
+        def _cb(user, buf, count, dtype, stream):
+            try:
+                fn(int(buf), int(count), int(dtype), int(stream or 0))
+                return 0
+            except Exception as exc:  # surfaced as PG_ERR_COLLECTIVE
+                import traceback
+
+                traceback.print_exc()
+                self._allreduce_error = exc
+                return 1
+
+        self._allreduce_cb = _lib.ALLREDUCE_FN(_cb)  # keep alive
+        call("pg_ctx_set_allreduce", self._h, self._allreduce_cb, None)
+
+
+_default_ctx = {}
+
+
+def get_context(device=None):
+    """Process-wide default context of a device (created on first use with torch's current stream)."""
+    import torch
+
+    if device is None:
+        if not torch.cuda.is_available():
+            raise _lib.ProxGradError("no HIP device visible: the proximal-gradient engine needs an MI355X (gfx950)")
+        device = torch.cuda.current_device()
+    device = int(device)
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class _RawDeviceArray:
+    """__cuda_array_interface__ view of a raw pointer (lets torch wrap library-owned memory)."""
+
+    def __init__(self, ptr, n, np_dtype, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": np.dtype(np_dtype).str,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class HIPVector:
+    """A device n-vector of Float32/Float64 (the ``Tx`` of the reference's iterators).
+
+    Owns nothing itself: ``owner`` keeps the backing allocation alive (a torch tensor for vectors
+    allocated here, the iterator object for views of library-owned state)."""
+
+    __slots__ = ("ctx", "ptr", "n", "dtype", "owner", "__weakref__")
+
+    def __init__(self, ctx, ptr, n, dtype, owner=None):
+        self.ctx = ctx
+        self.ptr = int(ptr) if ptr else 0
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self.owner = owner
+
+    # ---- construction (Julia: similar / zero / copy / Array(x)) ----
+    @classmethod
+    def empty(cls, n, dtype, ctx=None):
+        import torch
+
+        ctx = ctx or get_context()
+        tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        pg_dtype(dtype)
+        t = torch.empty(max(int(n), 1), dtype=tdt, device=ctx.torch_device)
+        return cls(ctx, t.data_ptr(), n, dtype, owner=t)
+
+    @classmethod
+    def zeros(cls, n, dtype, ctx=None):
+        v = cls.empty(n, dtype, ctx)
+        call("pg_memset_zero", v.ctx.handle, C.c_void_p(v.ptr), v.nbytes)
+        return v
+
+    @classmethod
+    def from_numpy(cls, arr, ctx=None):
+        arr = np.ascontiguousarray(arr)
+        if arr.ndim != 1:
+            raise ValueError("HIPVector.from_numpy expects a 1-D array")
+        v = cls.empty(arr.shape[0], arr.dtype, ctx)
+        if v.n:
+            call("pg_memcpy_h2d", v.ctx.handle, C.c_void_p(v.ptr), arr.ctypes.data_as(C.c_void_p), v.nbytes)
+        return v
+
+    @classmethod
+    def from_torch(cls, t, ctx=None):
+        import torch
+
+        if t.dim() != 1 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("expected a contiguous 1-D device tensor")
+        dt = {torch.float32: np.float32, torch.float64: np.float64}[t.dtype]
+        ctx = ctx or get_context(t.device.index)
+        return cls(ctx, t.data_ptr(), t.shape[0], dt, owner=t)
+
+    @property
+    def nbytes(self):
+        return self.n * self.dtype.itemsize
+
+    @property
+    def pg_dtype(self):
+        return pg_dtype(self.dtype)
+
+    @property
+    def vp(self):
+        return C.c_void_p(self.ptr)
+
+    def __len__(self):
+        return self.n
+
+    def similar(self):
+        return HIPVector.empty(self.n, self.dtype, self.ctx)
+
+    def copy(self):
+        out = self.similar()
+        out.copy_from(self)
+        return out
+
+    def copy_from(self, other):
+        """copyto!(self, other)"""
+        if isinstance(other, HIPVector):
+            _check_same(self, other)
+            call("pg_memcpy_d2d", self.ctx.handle, self.vp, other.vp, self.nbytes)
+        else:
+            arr = np.ascontiguousarray(other, dtype=self.dtype)
+            if arr.shape != (self.n,):
+                raise ValueError("shape mismatch")
+            if self.n:
+                call("pg_memcpy_h2d", self.ctx.handle, self.vp, arr.ctypes.data_as(C.c_void_p), self.nbytes)
+        return self
+
+    def numpy(self):
+        out = np.empty(self.n, dtype=self.dtype)
+        if self.n:
+            call("pg_memcpy_d2h", self.ctx.handle, out.ctypes.data_as(C.c_void_p), self.vp, self.nbytes)
+        return out
+
+    def torch(self):
+        """Zero-copy torch view (used for collectives)."""
+        import torch
+
+        if self.owner is not None and isinstance(self.owner, torch.Tensor) and self.owner.data_ptr() == self.ptr:
+            return self.owner[: self.n]
+        return torch.as_tensor(_RawDeviceArray(self.ptr, self.n, self.dtype, self.owner), device=self.ctx.torch_device)
+
+    # ---- BLAS-1 (all through the C ABI) ----
+    def fill_(self, c):
+        call("pg_fill", self.ctx.handle, self.pg_dtype, self.n, self.vp, float(c))
+        return self
+
+    def axpby_(self, a, x, b=0.0, y=None):
+        """self .= a .* x .+ b .* y"""
+        _check_same(self, x)
+        if y is not None:
+            _check_same(self, y)
+        call("pg_axpby", self.ctx.handle, self.pg_dtype, self.n, self.vp, float(a), x.vp, float(b),
+             y.vp if y is not None else None)
+        return self
+
+    def add_scalar_(self, x, c):
+        _check_same(self, x)
+        call("pg_add_scalar", self.ctx.handle, self.pg_dtype, self.n, self.vp, x.vp, float(c))
+        return self
+
+    def dot(self, other):
+        _check_same(self, other)
+        out = C.c_double()
+        call("pg_dot", self.ctx.handle, self.pg_dtype, self.n, self.vp, other.vp, C.byref(out))
+        return self.dtype.type(out.value)
+
+    def norm(self):
+        out = C.c_double()
+        call("pg_nrm2sq", self.ctx.handle, self.pg_dtype, self.n, self.vp, C.byref(out))
+        return self.dtype.type(np.sqrt(self.dtype.type(out.value)))
+
+    def norm_inf(self):
+        out = C.c_double()
+        call("pg_nrminf", self.ctx.handle, self.pg_dtype, self.n, self.vp, C.byref(out))
+        return self.dtype.type(out.value)
+
+    def __repr__(self):
+        return f"HIPVector(n={self.n}, dtype={self.dtype}, device={self.ctx.device})"
+
+
+def _check_same(a, b):
+    if a.n != b.n or a.dtype != b.dtype:
+        raise ValueError(f"vector mismatch: ({a.n}, {a.dtype}) vs ({b.n}, {b.dtype})")
+
+
+def as_hipvector(x, ctx=None):
+    if isinstance(x, HIPVector):
+        return x
+    try:
+        import torch
+
+        if isinstance(x, torch.Tensor):
+            return HIPVector.from_torch(x, ctx)
+    except ImportError:  # pragma: no cover
+        pass
+    return HIPVector.from_numpy(np.asarray(x), ctx)
+
+
+class HIPMatrix:
+    """Dense column-major m x n matrix on the device (Julia ``Matrix{T}``), library-owned, leading
+    dimension padded to 1 KiB (pg_mat)."""
+
+    def __init__(self, m, n, dtype, ctx=None):
+        self.ctx = ctx or get_context()
+        self.m, self.n = int(m), int(n)
+        self.dtype = np.dtype(dtype)
+        h = C.c_void_p()
+        call("pg_mat_create", self.ctx.handle, pg_dtype(dtype), self.m, self.n, C.byref(h))
+        self._h = h
+        self._finalizer = weakref.finalize(self, _lib.load().pg_mat_destroy, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def shape(self):
+        return (self.m, self.n)
+
+    @classmethod
+    def from_numpy(cls, A, ctx=None):
+        A = np.asarray(A)
+        if A.ndim != 2:
+            raise ValueError("expected a 2-D array")
+        Af = np.asfortranarray(A)  # Julia layout
+        M = cls(Af.shape[0], Af.shape[1], Af.dtype, ctx)
+        if Af.size:
+            call("pg_mat_upload", M._h, Af.ctypes.data_as(C.c_void_p), max(Af.shape[0], 1))
+        return M
+
+    @classmethod
+    def synthetic(cls, m, n, dtype=np.float32, seed=0, row_offset=0, m_global=None, ctx=None):
+        """SURVEY 8(d) instance, generated on the device; bit-identical to the oracle's generator."""
+        import math
+
+        m_global = m if m_global is None else m_global
+        ih8_std = 65536.0 * math.sqrt(8.0 / 12.0) * math.sqrt(1.0 - 1.0 / 65536.0**2)
+        scale = float(np.float32(1.0 / (ih8_std * math.sqrt(m_global))))
+        M = cls(m, n, dtype, ctx)
+        call("pg_mat_generate", M._h, C.c_uint32(seed & 0xFFFFFFFF), int(row_offset), scale)
+        return M
+
+    def info(self):
+        m, n, ld, dt, p = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_void_p()
+        call("pg_mat_info", self._h, C.byref(m), C.byref(n), C.byref(ld), C.byref(dt), C.byref(p))
+        return {"m": m.value, "n": n.value, "ld": ld.value, "dtype": dt.value, "ptr": p.value}
+
+    def numpy(self):
+        out = np.empty((self.m, self.n), dtype=self.dtype, order="F")
+        if out.size:
+            call("pg_mat_download", self._h, out.ctypes.data_as(C.c_void_p), max(self.m, 1))
+        return out
+
+    def mul(self, x, out=None):
+        """mul!(out, A, x)"""
+        out = out if out is not None else HIPVector.empty(self.m, self.dtype, self.ctx)
+        call("pg_mat_mul", self._h, x.vp, out.vp)
+        return out
+
+    def mul_adjoint(self, r, out=None):
+        """mul!(out, A', r)"""
+        out = out if out is not None else HIPVector.empty(self.n, self.dtype, self.ctx)
+        call("pg_mat_mul_adjoint", self._h, r.vp, out.vp)
+        return out

@@ -1,0 +1,148 @@
+"""ForwardBackward (proximal gradient) -- mirror of src/algorithms/forward_backward.jl.
+
+Two engines behind one iterator type:
+  * ``fused``   : f = LeastSquares, g in {NormL1, IndBox, Zero}: the whole iteration body runs inside
+                  libproxgrad_hip (csrc/pg_iter.hip) -- one C call per iteration.
+  * ``generic`` : any operator objects honouring value_and_gradient / prox_ (drop-in boundary #2); the body
+                  below is the reference's, on device vectors.
+"""
+import numpy as np
+
+from .algorithm import IterativeAlgorithm
+from .device import HIPVector, as_hipvector
+from .fb_tools import backtrack_stepsize_, lower_bound_smoothness_constant
+from .operators import Zero, fused_supported, prox_, value_and_gradient
+from ._fused import FusedIteration
+
+
+class ForwardBackwardState:
+    """forward_backward.jl:52-63"""
+
+    __slots__ = ("x", "f_x", "grad_f_x", "gamma", "y", "z", "g_z", "res", "grad_f_z", "res_inf", "n_backtracks")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class ForwardBackwardIteration:
+    """forward_backward.jl:38-48 (keyword constructor), Base.iterate :65-84 / :86-123.
+
+    Iterating yields the (mutated in place) state object forever (``IteratorSize = IsInfinite``)."""
+
+    def __init__(self, *, f=None, g=None, x0, Lf=None, gamma=None, adaptive=None, minimum_gamma=1e-7,
+                 reduce_gamma=0.5, increase_gamma=1.0, engine=None):
+        self.f = f if f is not None else Zero()
+        self.g = g if g is not None else Zero()
+        ctx = getattr(self.f, "ctx", None)
+        self.x0 = as_hipvector(x0, ctx)
+        R = self.x0.dtype.type
+        self.Lf = Lf
+        self.gamma = gamma if gamma is not None else (None if Lf is None else R(1) / R(Lf))  # :43
+        self.adaptive = (self.gamma is None) if adaptive is None else bool(adaptive)  # :44
+        self.minimum_gamma = R(minimum_gamma)
+        self.reduce_gamma = R(reduce_gamma)
+        self.increase_gamma = R(increase_gamma)
+        if engine is None:
+            engine = "fused" if fused_supported(self.f, self.g) else "generic"
+        if engine == "fused" and not fused_supported(self.f, self.g):
+            raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox(scalar bounds), Zero}")
+        self.engine = engine
+        self.counters = {}
+
+    # ---- fused engine ----
+    def _iter_fused(self):
+        R = self.x0.dtype.type
+        fi = FusedIteration(self.f, self.g, fast=False, Lf=self.Lf, gamma=self.gamma, adaptive=self.adaptive,
+                            minimum_gamma=self.minimum_gamma, reduce_gamma=self.reduce_gamma,
+                            increase_gamma=self.increase_gamma)
+        self._fused = fi
+        state = ForwardBackwardState()
+
+        def refresh(sc):
+            v = fi.view()
+            state.x, state.grad_f_x, state.y, state.z, state.res, state.grad_f_z = (
+                v["x"], v["grad_f_x"], v["y"], v["z"], v["res"], v["grad_f_z"])
+            state.f_x, state.gamma, state.g_z = R(sc.f_x), R(sc.gamma), R(sc.g_z)
+            state.res_inf = R(sc.res_inf)
+            state.n_backtracks = sc.n_backtracks
+            self.counters["backtracks"] = self.counters.get("backtracks", 0) + sc.n_backtracks
+            self.counters["a_passes"] = sc.a_passes
+
+        refresh(fi.init(self.x0))
+        yield state
+        while True:
+            refresh(fi.step())
+            yield state
+
+    # ---- generic engine: the reference body on device vectors ----
+    def _iter_generic(self):
+        R = self.x0.dtype.type
+        x = self.x0.copy()  # :66
+        f_x, grad_f_x = value_and_gradient(self.f, x)  # :67
+        if self.gamma is None:  # :68-70
+            gamma = R(R(1) / lower_bound_smoothness_constant(self.f, x, grad_f_x))
+        else:
+            gamma = R(self.gamma)
+        y = x.similar().axpby_(1.0, x, -gamma, grad_f_x)  # :71
+        z = x.similar()
+        g_z = prox_(z, self.g, y, gamma)  # :72
+        res = x.similar().axpby_(1.0, x, -1.0, z)
+        s = ForwardBackwardState(x=x, f_x=R(f_x), grad_f_x=grad_f_x, gamma=gamma, y=y, z=z, g_z=g_z, res=res,
+                                 grad_f_z=x.similar())
+        s.res_inf = None
+        yield s
+        while True:
+            if self.adaptive:  # :90-110
+                s.gamma = R(s.gamma * self.increase_gamma)
+                s.gamma, s.g_z, s.f_x, _ = backtrack_stepsize_(
+                    s.gamma, self.f, self.g, s.x, s.f_x, s.grad_f_x, s.y, s.z, s.g_z, s.res, s.grad_f_z,
+                    minimum_gamma=self.minimum_gamma, reduce_gamma=self.reduce_gamma, counters=self.counters)
+                s.x, s.z = s.z, s.x
+                s.grad_f_x, s.grad_f_z = s.grad_f_z, s.grad_f_x
+            else:  # :111-115
+                s.x, s.z = s.z, s.x
+                s.f_x, grad = value_and_gradient(self.f, s.x)
+                s.grad_f_x.copy_from(grad)
+            s.y.axpby_(1.0, s.x, -s.gamma, s.grad_f_x)  # :117
+            s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :118
+            s.res.axpby_(1.0, s.x, -1.0, s.z)  # :120
+            s.res_inf = None
+            yield s
+
+    def __iter__(self):
+        return self._iter_fused() if self.engine == "fused" else self._iter_generic()
+
+
+def _res_inf(state):
+    return state.res_inf if state.res_inf is not None else state.res.norm_inf()
+
+
+def default_stopping_criterion(tol, iteration, state):
+    """norm(state.res, Inf) / state.gamma <= tol   (forward_backward.jl:125-126)"""
+    R = state.res.dtype.type
+    return R(_res_inf(state)) / R(state.gamma) <= R(tol)
+
+
+def default_solution(iteration, state):
+    """forward_backward.jl:127 -- state.z (aliased, not copied)"""
+    return state.z
+
+
+def default_display(it, iteration, state):
+    """forward_backward.jl:128-129"""
+    print("%5d | %.3e | %.3e" % (it, state.gamma, _res_inf(state) / state.gamma))
+
+
+def ForwardBackward(*, maxit=10_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
+                    display=default_display, **kwargs):
+    """forward_backward.jl:161-179"""
+    if stop is None:
+        stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
+    return IterativeAlgorithm(ForwardBackwardIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose,
+                              freq=freq, display=display, **kwargs)
+
+
+# Aliases (forward_backward.jl:183-184)
+ProximalGradientIteration = ForwardBackwardIteration
+ProximalGradient = ForwardBackward

@@ -1,0 +1,48 @@
+"""L-BFGS operator on the device -- mirror of src/accel/lbfgs.jl (LBFGSOperator, update!, reset!, mul!, *)."""
+import ctypes as C
+import weakref
+
+from . import _lib
+from ._lib import call
+from .device import HIPVector, get_context, pg_dtype
+
+
+class LBFGSOperator:
+    """LBFGSOperator{M}(x)  (lbfgs.jl:5-26): circular (s, y) memory of size M, H = <s,y>/<y,y>."""
+
+    def __init__(self, M, x):
+        self.ctx = x.ctx
+        self.M, self.n, self.dtype = int(M), x.n, x.dtype
+        h = C.c_void_p()
+        call("pg_lbfgs_create", self.ctx.handle, pg_dtype(self.dtype), self.M, self.n, C.byref(h))
+        self._h = h
+        self._finalizer = weakref.finalize(self, _lib.load().pg_lbfgs_destroy, h)
+
+    def update_(self, s, y):
+        """update!(L, s, y)  lbfgs.jl:30-50"""
+        call("pg_lbfgs_update", self._h, s.vp, y.vp)
+        return self
+
+    def reset_(self):
+        """reset!(L)  lbfgs.jl:52-55"""
+        call("pg_lbfgs_reset", self._h)
+        return self
+
+    def mul_(self, d, v):
+        """mul!(d, L, v)  lbfgs.jl:64-95 (two-loop recursion)"""
+        call("pg_lbfgs_apply", self._h, d.vp, v.vp)
+        return d
+
+    def __mul__(self, v):
+        """L * v  lbfgs.jl:57-60"""
+        return self.mul_(v.similar(), v)
+
+
+class LBFGS:
+    """LBFGS(M): acceleration-style tag with `initialize` (lbfgs.jl:97-105)."""
+
+    def __init__(self, M):
+        self.M = int(M)
+
+    def initialize(self, x):
+        return LBFGSOperator(self.M, x)

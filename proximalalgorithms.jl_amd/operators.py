@@ -1,0 +1,206 @@
+"""Operator surface of the hot path (drop-in boundary #2).
+
+Mirrors, for device vectors, the three generic functions the reference's iterators call:
+
+  * ``value_and_gradient(f, x) -> (f(x), grad)``      src/ProximalAlgorithms.jl:27-40
+  * ``prox_(y, g, x, gamma) -> g(y)``  (``prox!``)    ProximalCore.jl (call sites forward_backward.jl:118 ...)
+  * ``prox(g, x, gamma) -> (y, g(y))``                ProximalCore.jl (call sites forward_backward.jl:72 ...)
+  * ``gradient_(y, f, x) -> f(x)``     (``gradient!``) ProximalCore <= 0.1 callers
+
+and the operator types on the path: ``LeastSquares`` (with the value_and_gradient method of
+benchmark/benchmarks.jl:11-17), ``NormL1``, ``IndBox`` (ProximalOperators.jl) and ``Zero``
+(ProximalCore.jl).  Custom operators plug in exactly like in the reference
+(docs/src/guide/custom_objectives.jl:13-21): any object with ``value_and_gradient(x)`` /
+``prox_(y, x, gamma)`` methods works with the generic iteration path.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import PG_G_INDBOX, PG_G_NORML1, PG_G_ZERO, call
+from .device import HIPMatrix, HIPVector, as_hipvector, get_context
+
+
+class LeastSquares:
+    """f(x) = lam/2 ||A x - b||^2 on the device (ProximalOperators.LeastSquares(A, b[, lam])).
+
+    ``A``: numpy 2-D array (uploaded, column-major) or :class:`HIPMatrix`; ``b``: numpy / HIPVector.
+    Row-sharded use (one process per GPU): pass the local row block and ``comm`` (see sharding.py);
+    every evaluation then all-reduces [grad ; f] over the shards.
+    """
+
+    def __init__(self, A, b, lam=1.0, ctx=None, comm=None):
+        if not isinstance(A, HIPMatrix):
+            A = HIPMatrix.from_numpy(A, ctx)
+        self.A = A
+        self.ctx = A.ctx
+        self.b = as_hipvector(b, self.ctx)
+        if self.b.n != A.m or self.b.dtype != A.dtype:
+            raise ValueError(f"b must have length {A.m} and dtype {A.dtype}")
+        self.lam = float(lam)
+        self.comm = comm
+        if comm is not None:
+            comm.attach(self.ctx)
+        h = C.c_void_p()
+        call("pg_ls_create", self.ctx.handle, A.handle, self.b.vp, self.lam, C.byref(h))
+        self._h = h
+        self._finalizer = weakref.finalize(self, _lib.load().pg_ls_destroy, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def dtype(self):
+        return self.A.dtype
+
+    def value_and_gradient(self, x, out=None):
+        """benchmark/benchmarks.jl:11-17: res = A*x - b ; (norm(res)^2 / 2, A' * res)"""
+        grad = out if out is not None else HIPVector.empty(self.A.n, self.dtype, self.ctx)
+        f = C.c_double()
+        call("pg_ls_value_and_gradient", self._h, x.vp, grad.vp, C.byref(f))
+        return self.dtype.type(f.value), grad
+
+    def gradient_(self, y, x):
+        """ProximalCore.gradient!(y, f, x) -> f(x)"""
+        f = C.c_double()
+        call("pg_ls_gradient", self._h, y.vp, x.vp, C.byref(f))
+        return self.dtype.type(f.value)
+
+    def __call__(self, x):
+        f = C.c_double()
+        call("pg_ls_value", self._h, x.vp, C.byref(f))
+        return self.dtype.type(f.value)
+
+    def residual(self):
+        """A x - b of the last evaluation (view of the library-owned m-vector)."""
+        p = C.c_void_p()
+        call("pg_ls_residual_ptr", self._h, C.byref(p))
+        return HIPVector(self.ctx, p.value, self.A.m, self.dtype, owner=self)
+
+
+class NormL1:
+    """g(x) = lam ||x||_1 (ProximalOperators.NormL1(lam)); prox = soft threshold."""
+
+    g_kind = PG_G_NORML1
+
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("parameter lam must be nonnegative")
+        self.lam = float(lam)
+
+    def g_params(self):
+        return self.lam, 0.0
+
+    def prox_(self, y, x, gamma):
+        out = C.c_double()
+        call("pg_prox_norml1", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, self.lam, float(gamma), C.byref(out))
+        return x.dtype.type(out.value)
+
+    def __call__(self, x):
+        out = C.c_double()
+        call("pg_norml1_value", x.ctx.handle, x.pg_dtype, x.n, x.vp, self.lam, C.byref(out))
+        return x.dtype.type(out.value)
+
+
+class IndBox:
+    """Indicator of {lo <= x <= hi} (ProximalOperators.IndBox(lo, hi)); prox = projection (clamp).
+    Bounds are scalars or vectors."""
+
+    g_kind = PG_G_INDBOX
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi
+        self._scalar = np.isscalar(lo) and np.isscalar(hi)
+        if self._scalar and lo > hi:
+            raise ValueError("bounds must satisfy lo <= hi")
+        self._lov = self._hiv = None
+
+    def g_params(self):
+        if not self._scalar:
+            raise TypeError("vector bounds are not supported by the fused iteration; use engine='generic'")
+        return float(self.lo), float(self.hi)
+
+    def _vectors(self, x):
+        if self._scalar:
+            return None, None
+        if self._lov is None:
+            lo = np.broadcast_to(np.asarray(self.lo, dtype=x.dtype), (x.n,))
+            hi = np.broadcast_to(np.asarray(self.hi, dtype=x.dtype), (x.n,))
+            self._lov, self._hiv = HIPVector.from_numpy(lo, x.ctx), HIPVector.from_numpy(hi, x.ctx)
+        return self._lov, self._hiv
+
+    def prox_(self, y, x, gamma):
+        lov, hiv = self._vectors(x)
+        out = C.c_double()
+        call("pg_prox_indbox", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp,
+             float(self.lo) if self._scalar else 0.0, float(self.hi) if self._scalar else 0.0,
+             lov.vp if lov is not None else None, hiv.vp if hiv is not None else None, C.byref(out))
+        return x.dtype.type(0)
+
+    def __call__(self, x):
+        xs = x.numpy()
+        ok = np.all(xs >= np.asarray(self.lo)) and np.all(xs <= np.asarray(self.hi))
+        return x.dtype.type(0) if ok else x.dtype.type(np.inf)
+
+
+class Zero:
+    """ProximalCore.Zero: f(x) = 0; value_and_gradient -> (0, zero(x)) (src/ProximalAlgorithms.jl:38-40);
+    prox = identity."""
+
+    g_kind = PG_G_ZERO
+
+    def g_params(self):
+        return 0.0, 0.0
+
+    def value_and_gradient(self, x, out=None):
+        g = out if out is not None else x.similar()
+        g.fill_(0.0)
+        return x.dtype.type(0), g
+
+    def prox_(self, y, x, gamma):
+        if y.ptr != x.ptr:
+            y.copy_from(x)
+        return x.dtype.type(0)
+
+    def __call__(self, x):
+        return x.dtype.type(0)
+
+
+# ---- the generic functions ---------------------------------------------------------------------
+
+
+def value_and_gradient(f, x):
+    """ProximalAlgorithms.value_and_gradient(f, x) -> (f(x), grad f(x))"""
+    return f.value_and_gradient(x)
+
+
+def gradient_(y, f, x):
+    """ProximalCore.gradient!(y, f, x) -> f(x)"""
+    if hasattr(f, "gradient_"):
+        return f.gradient_(y, x)
+    fx, g = f.value_and_gradient(x)
+    y.copy_from(g)
+    return fx
+
+
+def prox_(y, g, x, gamma):
+    """ProximalCore.prox!(y, g, x, gamma) -> g(y)"""
+    return g.prox_(y, x, gamma)
+
+
+def prox(g, x, gamma):
+    """ProximalCore.prox(g, x, gamma) -> (y, g(y))"""
+    y = x.similar()
+    return y, g.prox_(y, x, gamma)
+
+
+def fused_supported(f, g):
+    """True when (f, g) is the pair the fused HIP iteration is specialised for."""
+    if not isinstance(f, LeastSquares) or not isinstance(g, (NormL1, IndBox, Zero)):
+        return False
+    if isinstance(g, IndBox) and not g._scalar:
+        return False
+    return True

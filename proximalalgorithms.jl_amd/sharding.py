@@ -1,0 +1,87 @@
+"""Row sharding of A over the GPUs of one node: one process per GPU, rows of A and entries
+of b are the independent units; every gradient evaluation ends with ONE sum all-reduce of [grad ; f]
+(n+1 elements) over RCCL/xGMI, every f-only evaluation with a 1-element all-reduce.  All n-vectors are
+replicated, so the elementwise epilogue and its reductions need no communication.
+"""
+import numpy as np
+
+
+def shard_rows(m_global, world_size, rank):
+    """Contiguous, balanced row partition: returns (row_offset, m_local)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, rem = divmod(int(m_global), int(world_size))
+    m_local = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, m_local
+
+
+def allreduce_sum_(tensor, group=None):
+    """In-place SUM all-reduce of a torch tensor over the process group (RCCL on GPUs, gloo on CPU)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+class TorchDistributedComm:
+    """All-reduce provider backed by torch.distributed (backend "nccl" == RCCL on ROCm).  ``attach(ctx)``
+    registers the C callback the library invokes between the local GEMV passes and the replicated epilogue;
+    the collective is enqueued on the context's stream (torch's current stream), so no host sync is added."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._views = {}
+        self.calls = 0
+        self.elements = 0
+
+    def _view(self, ctx, ptr, count, pg_dtype):
+        import torch
+
+        from .device import _PG2NP, _RawDeviceArray
+
+        key = (ptr, count, pg_dtype)
+        t = self._views.get(key)
+        if t is None:
+            t = torch.as_tensor(_RawDeviceArray(ptr, count, _PG2NP[pg_dtype], None), device=ctx.torch_device)
+            self._views[key] = t
+        return t
+
+    def attach(self, ctx):
+        def fn(ptr, count, pg_dtype, stream):
+            self.calls += 1
+            self.elements += count
+            allreduce_sum_(self._view(ctx, ptr, count, pg_dtype), self.group)
+
+        ctx.set_allreduce(fn)
+
+
+class ScaleComm:
+    """Test double for the collective on a single GPU: emulates ``world_size`` ranks holding IDENTICAL row
+    shards (the SUM all-reduce of identical buffers is a multiplication by world_size), using the library's
+    own axpby kernel on the payload.  Exercises the C-side pack / reduce / unpack path without RCCL."""
+
+    def __init__(self, world_size):
+        self.world_size = int(world_size)
+        self.calls = 0
+        self.elements = 0
+
+    def attach(self, ctx):
+        import ctypes as C
+
+        from ._lib import call
+
+        def fn(ptr, count, pg_dtype, stream):
+            self.calls += 1
+            self.elements += count
+            call("pg_axpby", ctx.handle, pg_dtype, count, C.c_void_p(ptr), float(self.world_size), C.c_void_p(ptr), 0.0,
+                 None)
+
+        ctx.set_allreduce(fn)

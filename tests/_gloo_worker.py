@@ -1,0 +1,69 @@
+"""Worker for test_world_size_2_gloo_sharded_path (launched by torch.distributed.run, backend gloo, CPU).
+
+The compute engine on CPU is the oracle (allowed: this is test code); what is under test is the package's
+host-side sharding logic: shard_rows, allreduce_sum_ with the [grad ; f] payload convention, and that the
+sharded operator drives the iteration to the unsharded answer."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import proxgrad_oracle as o  # noqa: E402
+import proximalalgorithms.jl_amd as pa  # noqa: E402
+
+
+class ShardedOracleLS:
+    """LeastSquares over a row shard with the payload convention of csrc/pg_gemv.hip: buf = [grad ; f]."""
+
+    def __init__(self, A_loc, b_loc):
+        self.loc = o.LeastSquares(A_loc, b_loc)
+        self.calls = 0
+
+    def value_and_gradient(self, x):
+        f, g = self.loc.value_and_gradient(x)
+        buf = torch.from_numpy(np.concatenate([g, np.array([f], dtype=g.dtype)]))
+        pa.allreduce_sum_(buf)
+        self.calls += 1
+        out = buf.numpy()
+        return out[-1], out[:-1].copy()
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 2
+    m, n = 96, 160
+    for dtype in (np.float32, np.float64):
+        A, b, _ = o.synthetic_lasso(m, n, seed=0, dtype=dtype)
+        lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
+        off, cnt = pa.shard_rows(m, world, rank)
+        A_loc = o.synthetic_matrix(cnt, n, seed=0, dtype=dtype, row_offset=off, m_global=m)
+        assert np.array_equal(A_loc, A[off:off + cnt])  # shards regenerate the same entries
+        f_sh = ShardedOracleLS(A_loc, b[off:off + cnt])
+        x = np.random.default_rng(1).standard_normal(n).astype(dtype)
+        fs, gs = f_sh.value_and_gradient(x)
+        ff, gf = o.LeastSquares(A, b).value_and_gradient(x)
+        tol = 1e-5 if dtype == np.float32 else 1e-12
+        assert abs(fs - ff) <= tol * abs(ff) and np.max(np.abs(gs - gf)) <= tol * np.linalg.norm(gf)
+        z_sh, k_sh = o.fast_forward_backward(tol=1e-5, x0=np.zeros(n, dtype), f=f_sh, g=o.NormL1(lam))
+        z, k = o.fast_forward_backward(tol=1e-5, x0=np.zeros(n, dtype), f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        assert abs(k_sh - k) <= 3, (k_sh, k)
+        assert np.max(np.abs(z_sh - z)) <= (1e-4 if dtype == np.float32 else 1e-9)
+        # replicated vectors stay replicated: both ranks hold the same iterate
+        t = torch.from_numpy(z_sh.astype(np.float64).copy())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        assert torch.equal(gathered[0], gathered[1])
+    dist.barrier()
+    if rank == 0:
+        print("GLOO_SHARDED_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

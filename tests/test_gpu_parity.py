@@ -1,0 +1,489 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the ctypes host layer) against the CPU oracle
+and the reference's known answers.  Run with ``pytest -m gpu`` on an MI355X.
+
+Tolerances (written here, as the contract asks):
+  * elementwise kernels (prox, clamp, broadcasts)      : bit-exact, except where an FMA contraction may differ
+                                                         from numpy's separate multiply/add: 2 ulp
+  * GEMV / reductions, Float32                          : 2e-5 relative to the operand-norm bound
+  * GEMV / reductions, Float64                          : 1e-12 relative
+  * fixed-step iterate sequences z_k, k <= 50           : 1e-5 * max(1, ||z_k||_inf) (f32), 1e-11 (f64)
+  * adaptive runs                                       : identical gamma sequence on the fixtures
+  * final objective                                     : 1e-6 relative (north_star)
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import reference_vectors as rv
+from oracle import proxgrad_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.dirname(os.path.abspath(rv.__file__))
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import proximalalgorithms.jl_amd as pa
+
+    pa.get_context()  # raises loudly when the HIP library / device is missing
+    return pa
+
+
+def rtol(dtype):
+    return 2e-5 if np.dtype(dtype) == np.float32 else 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("m,n", [(64, 48), (300, 17), (1, 5)])
+def test_generate_bit_identical_to_oracle(pa, m, n):
+    A = pa.HIPMatrix.synthetic(m, n, np.float32, seed=3).numpy()
+    assert np.array_equal(A, o.synthetic_matrix(m, n, seed=3))
+    # row shards regenerate the same entries
+    off = m // 3
+    top = pa.HIPMatrix.synthetic(off, n, np.float32, seed=3, row_offset=0, m_global=m).numpy()
+    bot = pa.HIPMatrix.synthetic(m - off, n, np.float32, seed=3, row_offset=off, m_global=m).numpy()
+    assert np.array_equal(np.vstack([top, bot]), A)
+    A64 = pa.HIPMatrix.synthetic(m, n, np.float64, seed=3).numpy()
+    assert np.array_equal(A64, A.astype(np.float64))
+
+
+SHAPES = [(1, 1), (4, 5), (5, 5), (200, 500), (255, 33), (256, 64), (257, 1001), (1000, 7), (1023, 129),
+          (1024, 1024), (4099, 300), (17000, 65)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_gemv_both_orientations(pa, dtype, m, n):
+    rng = np.random.default_rng(m * 1000 + n)
+    A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype))
+    x = rng.standard_normal(n).astype(dtype)
+    r = rng.standard_normal(m).astype(dtype)
+    Ad = pa.HIPMatrix.from_numpy(A)
+    assert np.array_equal(Ad.numpy(), A)  # upload/download round trip through the padded store
+    y = Ad.mul(pa.HIPVector.from_numpy(x)).numpy()
+    g = Ad.mul_adjoint(pa.HIPVector.from_numpy(r)).numpy()
+    A64 = A.astype(np.float64)
+    y_ref, g_ref = A64 @ x.astype(np.float64), A64.T @ r.astype(np.float64)
+    y_bound = np.abs(A64) @ np.abs(x.astype(np.float64))
+    g_bound = np.abs(A64).T @ np.abs(r.astype(np.float64))
+    assert np.all(np.abs(y - y_ref) <= rtol(dtype) * np.maximum(y_bound, 1e-30))
+    assert np.all(np.abs(g - g_ref) <= rtol(dtype) * np.maximum(g_bound, 1e-30))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,n", [(4, 5), (200, 500), (1000, 2000), (3000, 129)])
+@pytest.mark.parametrize("lam", [1.0, 2.5])
+def test_least_squares_value_and_gradient(pa, dtype, m, n, lam):
+    rng = np.random.default_rng(7)
+    A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / np.sqrt(m).astype(dtype))
+    b = rng.standard_normal(m).astype(dtype)
+    x = rng.standard_normal(n).astype(dtype)
+    f = pa.LeastSquares(A, b, lam)
+    xd = pa.HIPVector.from_numpy(x)
+    fx, grad = pa.value_and_gradient(f, xd)
+    fo, go = o.LeastSquares(A, b, lam).value_and_gradient(x)
+    assert fx.dtype == dtype
+    assert abs(float(fx) - float(fo)) <= 10 * rtol(dtype) * abs(float(fo))
+    scale = np.linalg.norm(go)
+    assert np.max(np.abs(grad.numpy() - go)) <= 10 * rtol(dtype) * scale
+    assert abs(float(f(xd)) - float(fo)) <= 10 * rtol(dtype) * abs(float(fo))
+    np.testing.assert_allclose(f.residual().numpy(), A @ x - b, rtol=0, atol=50 * rtol(dtype) * np.linalg.norm(b))
+    y = xd.similar()
+    assert pa.gradient_(y, f, xd) == fx
+    assert np.array_equal(y.numpy(), grad.numpy())  # deterministic: same kernels, same order
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 1000, 4097, 100003])
+def test_prox_operators_bit_exact(pa, dtype, n):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 2).astype(dtype)
+    x[::7] = 0
+    xd = pa.HIPVector.from_numpy(x)
+    lam, gamma = dtype(0.37), dtype(1.3)
+    y, gy = pa.prox(pa.NormL1(lam), xd, gamma)
+    yo, gyo = o.NormL1(lam).prox(x, gamma)
+    assert np.array_equal(y.numpy(), yo)
+    assert abs(float(gy) - float(gyo)) <= 1e-6 * max(1.0, abs(float(gyo)))
+    assert abs(float(pa.NormL1(lam)(xd)) - float(o.NormL1(lam)(x))) <= 1e-6 * max(1.0, float(o.NormL1(lam)(x)))
+    # in place (y aliases x)
+    x2 = xd.copy()
+    pa.prox_(x2, pa.NormL1(lam), x2, gamma)
+    assert np.array_equal(x2.numpy(), yo)
+    # IndBox: scalar and vector bounds (test_nonconvex_qp.jl:33 restates it as min.(upp, max.(low, .)))
+    z, gz = pa.prox(pa.IndBox(-0.5, 0.8), xd, gamma)
+    assert np.array_equal(z.numpy(), np.minimum(dtype(0.8), np.maximum(dtype(-0.5), x))) and gz == 0
+    lo = (-np.abs(rng.standard_normal(n))).astype(dtype)
+    hi = np.abs(rng.standard_normal(n)).astype(dtype)
+    z, _ = pa.prox(pa.IndBox(lo, hi), xd, gamma)
+    assert np.array_equal(z.numpy(), np.minimum(hi, np.maximum(lo, x)))
+    assert xd.numpy().tolist() == x.tolist()  # inputs untouched
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [1, 5, 1023, 100003])
+def test_blas1(pa, dtype, n):
+    rng = np.random.default_rng(n + 1)
+    x, y = rng.standard_normal(n).astype(dtype), rng.standard_normal(n).astype(dtype)
+    xd, yd = pa.HIPVector.from_numpy(x), pa.HIPVector.from_numpy(y)
+    ulp2 = 2 * np.finfo(dtype).eps
+    out = xd.similar().axpby_(1.0, xd, -0.25, yd).numpy()
+    np.testing.assert_allclose(out, x - dtype(0.25) * y, rtol=0, atol=ulp2 * (np.abs(x) + np.abs(y)).max())
+    assert np.array_equal(xd.similar().axpby_(1.0, xd, -1.0, yd).numpy(), x - y)  # res .= x .- z is exact
+    assert np.array_equal(xd.similar().add_scalar_(xd, 1.0).numpy(), x + dtype(1))
+    assert np.array_equal(xd.similar().fill_(2.5).numpy(), np.full(n, 2.5, dtype))
+    assert np.array_equal(xd.copy().numpy(), x)
+    d64 = float(np.dot(x.astype(np.float64), y.astype(np.float64)))
+    bound = float(np.dot(np.abs(x).astype(np.float64), np.abs(y).astype(np.float64)))
+    assert abs(float(xd.dot(yd)) - d64) <= 4 * np.finfo(dtype).eps * bound
+    assert abs(float(xd.norm()) - np.linalg.norm(x.astype(np.float64))) <= 4 * np.finfo(dtype).eps * np.linalg.norm(x)
+    assert xd.norm_inf() == np.max(np.abs(x))
+    from proximalalgorithms.jl_amd.fast_forward_backward import call_extrapolate
+
+    w = xd.similar()
+    call_extrapolate(w, xd, yd, dtype(0.6))
+    np.testing.assert_allclose(w.numpy(), x + dtype(0.6) * (x - y), rtol=0, atol=ulp2 * (np.abs(x) + np.abs(y)).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_epilogue_against_oracle(pa, dtype):
+    import ctypes as C
+
+    from proximalalgorithms.jl_amd import _lib
+
+    n = 10007
+    rng = np.random.default_rng(5)
+    x, grad = rng.standard_normal(n).astype(dtype), rng.standard_normal(n).astype(dtype)
+    gamma, lam = dtype(0.3), dtype(0.9)
+    xd, gd = pa.HIPVector.from_numpy(x), pa.HIPVector.from_numpy(grad)
+    y, z, res = xd.similar(), xd.similar(), xd.similar()
+    sc = (C.c_double * 4)()
+    _lib.call("pg_fb_epilogue", xd.ctx.handle, xd.pg_dtype, n, xd.vp, gd.vp, float(gamma), _lib.PG_G_NORML1,
+              float(lam), 0.0, y.vp, z.vp, res.vp, sc)
+    yo = x - gamma * grad
+    zo, gzo = o.NormL1(lam).prox(y.numpy(), gamma)  # prox of the device y: exact thereafter
+    np.testing.assert_allclose(y.numpy(), yo, rtol=0, atol=2 * np.finfo(dtype).eps * (np.abs(x) + np.abs(grad)).max())
+    assert np.array_equal(z.numpy(), zo)
+    assert np.array_equal(res.numpy(), x - zo)
+    r64 = (x - zo).astype(np.float64)
+    assert abs(sc[0] - float(lam) * np.abs(zo.astype(np.float64)).sum()) <= 1e-12 * n
+    assert sc[1] == np.max(np.abs(x - zo))
+    assert abs(sc[2] - np.dot(grad.astype(np.float64), r64)) <= 1e-10 * n
+    assert abs(sc[3] - np.dot(r64, r64)) <= 1e-10 * n
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's known-answer problems through the mirrored API (both engines)
+# ------------------------------------------------------------------------------------------------
+
+
+def lasso_small(dtype):
+    A = np.asfortranarray(rv.LASSO_SMALL_A.astype(dtype))
+    b = rv.LASSO_SMALL_B.astype(dtype)
+    R = np.dtype(dtype).type
+    lam = R(0.1) * R(np.max(np.abs(A.T @ b)))
+    Lf = R(np.linalg.norm(A, 2) ** 2)
+    return A, b, lam, Lf
+
+
+LASSO_CASES = [
+    # name, solver, kwargs-builder, bound key
+    ("fb_fixed", "ForwardBackward", lambda Lf, R: dict(Lf=Lf)),
+    ("fb_adaptive", "ForwardBackward", lambda Lf, R: dict(adaptive=True)),
+    ("fb_adaptive_regret", "ForwardBackward", lambda Lf, R: dict(adaptive=True, increase_gamma=R(1.01))),
+    ("ffb_fixed", "FastForwardBackward", lambda Lf, R: dict(Lf=Lf)),
+    ("ffb_adaptive", "FastForwardBackward", lambda Lf, R: dict(adaptive=True)),
+    ("ffb_adaptive_regret", "FastForwardBackward", lambda Lf, R: dict(adaptive=True, increase_gamma=R(1.01))),
+    ("ffb_fixed_custom_seq", "FastForwardBackward", lambda Lf, R: dict(Lf=Lf, extrapolation_sequence="fixed")),
+]
+
+
+@pytest.mark.parametrize("engine", ["fused", "generic"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", LASSO_CASES, ids=[c[0] for c in LASSO_CASES])
+def test_lasso_small_known_answers(pa, dtype, case, engine):
+    """test/problems/test_lasso_small.jl:46-135 (x_star, TOL = 1e-4, iteration bounds, x0 untouched)."""
+    name, solver_name, mk = case
+    A, b, lam, Lf = lasso_small(dtype)
+    R = np.dtype(dtype).type
+    kw = mk(Lf, R)
+    if kw.get("extrapolation_sequence") == "fixed":
+        kw["extrapolation_sequence"] = pa.FixedNesterovSequence(dtype)
+    x0 = np.zeros(5, dtype)
+    x0_backup = x0.copy()
+    solver = getattr(pa, solver_name)(tol=rv.LASSO_SMALL_TOL, engine=engine)
+    x, it = solver(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), **kw)
+    assert isinstance(x, np.ndarray) and x.dtype == dtype
+    assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+    assert it < rv.LASSO_SMALL_BOUNDS[name]
+    assert np.array_equal(x0, x0_backup)
+    # and the oracle's iteration count (same decisions on this fixture)
+    okw = dict(kw)
+    if "extrapolation_sequence" in okw:
+        okw["extrapolation_sequence"] = o.fixed_nesterov_sequence(dtype)
+    ofun = o.forward_backward if solver_name == "ForwardBackward" else o.fast_forward_backward
+    _, it_o = ofun(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), **okw)
+    assert it == it_o
+
+
+SC_CASES = [
+    ("fb_fixed", "ForwardBackward", lambda T: dict(Lf=T(rv.SC_LF))),
+    ("fb_adaptive", "ForwardBackward", lambda T: dict(adaptive=True)),
+    ("fb_adaptive_regret", "ForwardBackward", lambda T: dict(adaptive=True, increase_gamma=T(1.01))),
+    ("ffb_fixed_mf", "FastForwardBackward", lambda T: dict(Lf=T(rv.SC_LF), mf=T(rv.SC_MF))),
+    ("ffb_adaptive", "FastForwardBackward", lambda T: dict(adaptive=True)),
+    ("ffb_adaptive_regret", "FastForwardBackward", lambda T: dict(adaptive=True, increase_gamma=T(1.01))),
+    ("ffb_constant_seq", "FastForwardBackward", lambda T: dict(gamma=T(1) / T(rv.SC_LF), mf=T(rv.SC_MF), extrapolation_sequence="constant")),
+]
+
+
+@pytest.mark.parametrize("engine", ["fused", "generic"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", SC_CASES, ids=[c[0] for c in SC_CASES])
+def test_lasso_strongly_convex_known_answers(pa, dtype, case, engine):
+    """test/problems/test_lasso_small_strongly_convex.jl:65-144"""
+    name, solver_name, mk = case
+    A, b, lam, x0 = rv.strongly_convex_problem(dtype)
+    x0_backup = x0.copy()
+    kw = mk(dtype)
+    if kw.get("extrapolation_sequence") == "constant":
+        kw["extrapolation_sequence"] = pa.ConstantNesterovSequence(dtype(rv.SC_MF), dtype(1) / dtype(rv.SC_LF))
+    solver = getattr(pa, solver_name)(tol=rv.SC_TOL, engine=engine)
+    y, it = solver(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), **kw)
+    assert y.dtype == dtype
+    assert np.max(np.abs(y - rv.SC_XSTAR.astype(dtype))) <= rv.SC_TOL
+    assert it < rv.SC_BOUNDS[name]
+    assert np.array_equal(x0, x0_backup)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_indbox_fixed_point(pa, dtype):
+    """IndBox through ForwardBackward: the solution is a fixed point of the projected-gradient map
+    (the check of test/problems/test_nonconvex_qp.jl:33-34, on a convex least-squares objective)."""
+    rng = np.random.default_rng(0)
+    A = np.asfortranarray(rng.standard_normal((30, 12)).astype(dtype))
+    b = rng.standard_normal(30).astype(dtype)
+    Lf = dtype(np.linalg.norm(A, 2) ** 2)
+    low, upp = dtype(-0.1), dtype(0.15)
+    for engine in ("fused", "generic"):
+        x, it = pa.ForwardBackward(tol=1e-4, engine=engine)(x0=np.zeros(12, dtype), f=pa.LeastSquares(A, b),
+                                                            g=pa.IndBox(low, upp), Lf=Lf)
+        gamma = dtype(1) / Lf
+        z = np.minimum(upp, np.maximum(low, x - gamma * (A.T @ (A @ x - b))))
+        assert np.max(np.abs(x - z)) / gamma <= 2e-4
+        xo, ito = o.forward_backward(tol=1e-4, x0=np.zeros(12, dtype), f=o.LeastSquares(A, b), g=o.IndBox(low, upp), Lf=Lf)
+        assert it == ito and np.max(np.abs(x - xo)) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# iterate-sequence parity against the oracle
+# ------------------------------------------------------------------------------------------------
+
+
+def synthetic_problem(m, n, dtype, seed=0):
+    A, b, _ = o.synthetic_lasso(m, n, seed=seed, dtype=dtype)
+    lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
+    return A, b, lam
+
+
+def power_Lf(A, iters=50):
+    v = np.ones(A.shape[1]) / np.sqrt(A.shape[1])
+    A64 = A.astype(np.float64)
+    for _ in range(iters):
+        v = A64.T @ (A64 @ v)
+        v /= np.linalg.norm(v)
+    return float(np.linalg.norm(A64 @ v) ** 2) * 1.02
+
+
+@pytest.mark.parametrize("engine", ["fused", "generic"])
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("dtype,m,n", [(np.float32, 200, 500), (np.float64, 200, 500), (np.float32, 1000, 3000)])
+def test_fixed_step_iterate_sequence(pa, dtype, m, n, fast, engine):
+    """z_k on the GPU follows the CPU restatement for k <= 50; same objective."""
+    A, b, lam = synthetic_problem(m, n, dtype)
+    Lf = dtype(power_Lf(A))
+    x0 = np.zeros(n, dtype)
+    It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
+    Io = o.FastForwardBackwardIteration if fast else o.ForwardBackwardIteration
+    it_g = It(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0, Lf=Lf, engine=engine)
+    it_o = Io(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0, Lf=Lf)
+    tol = 1e-5 if dtype == np.float32 else 1e-11
+    for k, (sg, so) in enumerate(itertools.islice(zip(it_g, it_o), 50)):
+        zg = sg.z.numpy()
+        assert np.max(np.abs(zg - so.z)) <= tol * max(1.0, np.max(np.abs(so.z))), k
+        assert abs(float(sg.gamma) - float(so.gamma)) == 0
+        assert abs(float(sg.f_x) - float(so.f_x)) <= 20 * rtol(dtype) * max(1.0, abs(float(so.f_x)))
+        assert abs(float(sg.g_z) - float(so.g_z)) <= 20 * rtol(dtype) * max(1.0, abs(float(so.g_z)))
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    obj = lambda z: 0.5 * np.sum((A64 @ z - b64) ** 2) + float(lam) * np.sum(np.abs(z))
+    assert abs(obj(zg.astype(np.float64)) - obj(so.z.astype(np.float64))) <= 1e-6 * obj(so.z.astype(np.float64))
+
+
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("name", ["lasso_tiny", "lasso_small", "lasso_medium"])
+def test_shipped_instances_adaptive_gamma_sequence(pa, name, fast):
+    """benchmark/benchmarks.jl:47-61 settings on the shipped data (Float64, x0 = 0, adaptive, tol = 1e-6):
+    identical backtracking decisions (gamma sequence) for the first 300 iterations, same stored optimum."""
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    A, b, xstar, lam = d["A"], d["b"], d["xstar"], float(d["lam"])
+    x0 = np.zeros(A.shape[1])
+    It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
+    Io = o.FastForwardBackwardIteration if fast else o.ForwardBackwardIteration
+    it_g = It(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0)
+    it_o = Io(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0)
+    for k, (sg, so) in enumerate(itertools.islice(zip(it_g, it_o), 300)):
+        assert float(sg.gamma) == pytest.approx(float(so.gamma), rel=1e-12), k
+        assert np.max(np.abs(sg.z.numpy() - so.z)) <= 1e-9 * max(1.0, np.max(np.abs(so.z))), k
+    if name != "lasso_tiny":
+        solver = (pa.FastForwardBackward if fast else pa.ForwardBackward)(tol=1e-6)
+        z, k = solver(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam))
+        assert k < 10_000 and np.max(np.abs(z - xstar)) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_adaptive_synthetic_final_objective(pa, dtype):
+    """compare gamma up to the first differing decision, then the final objective."""
+    m, n = 500, 2000
+    A, b, lam = synthetic_problem(m, n, dtype, seed=1)
+    x0 = np.zeros(n, dtype)
+    zg, kg = pa.FastForwardBackward(tol=1e-5, maxit=3000)(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam))
+    zo, ko = o.fast_forward_backward(tol=1e-5, maxit=3000, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    obj = lambda z: 0.5 * np.sum((A64 @ z - b64) ** 2) + float(lam) * np.sum(np.abs(z))
+    assert abs(obj(zg.astype(np.float64)) - obj(zo.astype(np.float64))) <= 1e-6 * obj(zo.astype(np.float64))
+    assert abs(kg - ko) <= max(5, 0.05 * ko)
+
+
+def test_run_loop_in_library_matches_python_loop(pa):
+    """pg_iter_run (IterativeAlgorithm loop inside the library) == the host loop, same k."""
+    dtype = np.float32
+    A, b, lam, Lf = lasso_small(dtype)
+    f, g = pa.LeastSquares(A, b), pa.NormL1(lam)
+    it = pa.FastForwardBackwardIteration(f=f, g=g, x0=np.zeros(5, dtype), Lf=Lf)
+    gen = iter(it)
+    next(gen)
+    k, sc = it._fused.run(1, 10_000, rv.LASSO_SMALL_TOL)
+    x, k_host = pa.FastForwardBackward(tol=rv.LASSO_SMALL_TOL)(x0=np.zeros(5, dtype), f=f, g=g, Lf=Lf)
+    assert k == k_host
+    assert np.array_equal(it._fused.view()["z"].numpy(), x)
+
+
+def test_deterministic_bitwise_rerun(pa):
+    """Two runs give bit-identical iterates (no float atomics; exposes races)."""
+    A, b, lam = synthetic_problem(700, 1500, np.float32, seed=2)
+    outs = []
+    for _ in range(2):
+        it = pa.FastForwardBackwardIteration(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=np.zeros(1500, np.float32))
+        for s in itertools.islice(it, 30):
+            pass
+        outs.append((s.z.numpy().copy(), float(s.f_x), float(s.gamma)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
+# ------------------------------------------------------------------------------------------------
+# L-BFGS golden vectors
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lbfgs_golden_directions(pa, dtype):
+    """test/accel/test_lbfgs.jl:103-133"""
+    Q, q, xs = rv.LBFGS_Q.astype(dtype), rv.LBFGS_q.astype(dtype), rv.LBFGS_XS.astype(dtype)
+    V = pa.HIPVector.from_numpy
+    H = pa.LBFGS(rv.LBFGS_MEM).initialize(V(np.zeros(10, dtype)))
+    x = xs[0]
+    grad = Q @ x + q
+    d = H * V(-grad)
+    tol = np.sqrt(np.finfo(dtype).eps)
+    ref = rv.LBFGS_DIRS_REF[0]
+    assert np.linalg.norm(d.numpy() - ref) <= tol * np.linalg.norm(ref)
+    for i in range(1, 5):
+        x_prev, grad_prev = x, grad
+        x = xs[i]
+        grad = Q @ x + q
+        H.update_(V(x - x_prev), V(grad - grad_prev))
+        H.mul_(d, V(-grad))
+        ref = rv.LBFGS_DIRS_REF[i]
+        assert np.linalg.norm(d.numpy() - ref) <= tol * max(np.linalg.norm(ref), np.linalg.norm(d.numpy()))
+    H.reset_()
+    assert np.array_equal((H * V(x)).numpy(), x)
+
+
+def test_lbfgs_large_matches_oracle(pa):
+    n, M = 20011, 5
+    rng = np.random.default_rng(3)
+    Ho, Hg = o.LBFGSOperator(M, np.zeros(n, np.float32)), pa.LBFGSOperator(M, pa.HIPVector.zeros(n, np.float32))
+    for _ in range(8):
+        s = rng.standard_normal(n).astype(np.float32)
+        y = (s + 0.1 * rng.standard_normal(n)).astype(np.float32)
+        Ho.update(s, y)
+        Hg.update_(pa.HIPVector.from_numpy(s), pa.HIPVector.from_numpy(y))
+    v = rng.standard_normal(n).astype(np.float32)
+    d_o = Ho * v
+    d_g = (Hg * pa.HIPVector.from_numpy(v)).numpy()
+    assert np.linalg.norm(d_g - d_o) <= 1e-4 * np.linalg.norm(d_o)
+
+
+# ------------------------------------------------------------------------------------------------
+# row sharding: the collective plumbing on one GPU
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sharded_payload_with_emulated_allreduce(pa, dtype):
+    """Two 'ranks' holding identical row shards: the SUM all-reduce equals x2, so the sharded operator on one
+    shard must equal the plain operator on the stacked matrix [A; A], [b; b]."""
+    m, n = 300, 700
+    A, b, lam = synthetic_problem(m, n, dtype, seed=4)
+    ctx2 = pa.Context()  # separate context so the callback does not leak into other tests
+    comm = pa.ScaleComm(2)
+    f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
+    f_full = pa.LeastSquares(np.vstack([A, A]), np.concatenate([b, b]))
+    x = np.random.default_rng(0).standard_normal(n).astype(dtype)
+    fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
+    ff, gf = f_full.value_and_gradient(pa.HIPVector.from_numpy(x))
+    assert comm.calls == 1 and comm.elements == n + 1
+    assert abs(float(fs) - float(ff)) <= 20 * rtol(dtype) * abs(float(ff))
+    assert np.max(np.abs(gs.numpy() - gf.numpy())) <= 20 * rtol(dtype) * np.linalg.norm(gf.numpy())
+    assert abs(float(f_sh(pa.HIPVector.from_numpy(x, ctx2))) - float(ff)) <= 20 * rtol(dtype) * abs(float(ff))
+    assert comm.calls == 2 and comm.elements == n + 2
+    # whole adaptive FFB run, sharded vs stacked
+    lam2 = dtype(2) * lam
+    z1, k1 = pa.FastForwardBackward(tol=1e-4, maxit=500)(x0=pa.HIPVector.zeros(n, dtype, ctx2), f=f_sh, g=pa.NormL1(lam2))
+    z2, k2 = pa.FastForwardBackward(tol=1e-4, maxit=500)(x0=np.zeros(n, dtype), f=f_full, g=pa.NormL1(lam2))
+    assert abs(k1 - k2) <= 3
+    assert np.max(np.abs(z1.numpy() - z2)) <= 1e-3 * max(1.0, np.max(np.abs(z2)))
+
+
+def test_nccl_world_size_one(pa):
+    """torch.distributed (backend nccl == RCCL) with one rank: the real callback path end to end."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m, n = 256, 512
+        A, b, lam = synthetic_problem(m, n, np.float32, seed=5)
+        ctx2 = pa.Context()
+        comm = pa.TorchDistributedComm()
+        f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
+        f_pl = pa.LeastSquares(A, b)
+        x = np.random.default_rng(1).standard_normal(n).astype(np.float32)
+        fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
+        fp, gp = f_pl.value_and_gradient(pa.HIPVector.from_numpy(x))
+        assert comm.calls == 1
+        assert float(fs) == pytest.approx(float(fp), rel=1e-6)
+        assert np.array_equal(gs.numpy(), gp.numpy())
+    finally:
+        dist.destroy_process_group()
