@@ -230,7 +230,9 @@ def test_lasso_small_known_answers(pa, dtype, case, engine):
         okw["extrapolation_sequence"] = o.fixed_nesterov_sequence(dtype)
     ofun = o.forward_backward if solver_name == "ForwardBackward" else o.fast_forward_backward
     _, it_o = ofun(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), **okw)
-    assert it == it_o
+    # Float64: identical; Float32: reductions are summed in a different order than OpenBLAS, which can move
+    # the stopping test (res_inf / gamma <= tol) or a backtracking near-tie by an iteration
+    assert abs(it - it_o) <= (0 if dtype == np.float64 else 2), (it, it_o)
 
 
 SC_CASES = [
