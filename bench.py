@@ -200,8 +200,20 @@ def main():
     dom = max(kern, key=lambda k_: kern[k_]["avg_ms"]) if kern else None
     roofline = None
     if dom:
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process);
+        # only quoted when they were collected on this exact workload
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            rec = pmc.get(args.workload)
+            if rec and world == 1 and args.m is None and args.n is None:
+                traffic = rec["kernels"][dom]["hbm_bytes"]
+                traffic_src = rec["source"]
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(kern[dom]["GBps"], 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": round(kern[dom]["avg_ms"], 4), "launches": kern[dom]["launches"],
                     "algorithmic_bytes_per_launch": m_loc * n * es + (n * es if dom == "gemv_n_partial" else (m_loc + n) * es),
                     "per_kernel": {k_: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1), "launches": v["launches"]}

@@ -1,0 +1,260 @@
+# ProximalAlgorithmsHIP.jl -- Julia-side binding of libproxgrad_hip.so (include/proxgrad_hip.h).
+#
+# STATUS: UNEXECUTED.  The build image has no Julia toolchain; this file is the reference-side glue a
+# maintainer would add (INTEGRATION.md).  It defines device array / operator types whose methods `ccall`
+# the C ABI, and iterator types that plug into `ProximalAlgorithms.IterativeAlgorithm` unchanged:
+#
+#     using ProximalAlgorithms, ProximalAlgorithmsHIP
+#     f = HIPLeastSquares(A, b); g = HIPNormL1(lam)
+#     x, it = HIPFastForwardBackward(tol = 1e-6)(x0 = zeros(Float32, n), f = f, g = g)
+#
+module ProximalAlgorithmsHIP
+
+using ProximalAlgorithms
+using ProximalCore
+using LinearAlgebra
+using Printf
+
+const libpg = get(ENV, "PROXGRAD_HIP_LIB", "libproxgrad_hip.so")
+
+const PG_F32, PG_F64 = Int32(0), Int32(1)
+pg_dtype(::Type{Float32}) = PG_F32
+pg_dtype(::Type{Float64}) = PG_F64
+
+struct ProxGradError <: Exception
+    code::Int32
+    msg::String
+end
+
+function check(status::Int32)
+    status == 0 && return nothing
+    throw(ProxGradError(status, unsafe_string(ccall((:pg_last_error, libpg), Cstring, ()))))
+end
+
+# ---------------------------------------------------------------- context ------------------------------------
+mutable struct HIPContext
+    handle::Ptr{Cvoid}
+    function HIPContext(device::Integer = 0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pg_ctx_create, libpg), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h))
+        ctx = new(h[])
+        finalizer(c -> ccall((:pg_ctx_destroy, libpg), Int32, (Ptr{Cvoid},), c.handle), ctx)
+    end
+end
+const DEFAULT_CTX = Ref{Union{Nothing,HIPContext}}(nothing)
+default_ctx() = (DEFAULT_CTX[] === nothing && (DEFAULT_CTX[] = HIPContext()); DEFAULT_CTX[])
+
+# ---------------------------------------------------------------- device vector ------------------------------
+# The `Tx` of the iterators.  Owns its buffer unless `owner !== nothing` (views of library-owned state).
+mutable struct HIPVector{T} <: AbstractVector{T}
+    ctx::HIPContext
+    ptr::Ptr{Cvoid}
+    n::Int
+    owner::Any
+end
+function HIPVector{T}(::UndefInitializer, n::Integer; ctx = default_ctx()) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_malloc, libpg), Int32, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, n * sizeof(T), p))
+    v = HIPVector{T}(ctx, p[], n, nothing)
+    finalizer(v -> v.owner === nothing && ccall((:pg_free, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), v.ctx.handle, v.ptr), v)
+end
+function HIPVector(x::Vector{T}; ctx = default_ctx()) where {T}
+    v = HIPVector{T}(undef, length(x); ctx)
+    GC.@preserve x check(ccall((:pg_memcpy_h2d, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                               ctx.handle, v.ptr, pointer(x), sizeof(x)))
+    v
+end
+Base.size(v::HIPVector) = (v.n,)
+Base.similar(v::HIPVector{T}) where {T} = HIPVector{T}(undef, v.n; ctx = v.ctx)
+function Base.Array(v::HIPVector{T}) where {T}
+    out = Vector{T}(undef, v.n)
+    GC.@preserve out check(ccall((:pg_memcpy_d2h, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                                 v.ctx.handle, pointer(out), v.ptr, sizeof(out)))
+    out
+end
+function Base.copyto!(dst::HIPVector{T}, src::HIPVector{T}) where {T}
+    check(ccall((:pg_memcpy_d2d, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                dst.ctx.handle, dst.ptr, src.ptr, dst.n * sizeof(T)))
+    dst
+end
+Base.copy(v::HIPVector) = copyto!(similar(v), v)
+function LinearAlgebra.dot(x::HIPVector{T}, y::HIPVector{T}) where {T}
+    out = Ref{Float64}(0)
+    check(ccall((:pg_dot, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}),
+                x.ctx.handle, pg_dtype(T), x.n, x.ptr, y.ptr, out))
+    T(out[])
+end
+function LinearAlgebra.norm(x::HIPVector{T}, p::Real = 2) where {T}
+    out = Ref{Float64}(0)
+    if p == Inf
+        check(ccall((:pg_nrminf, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ref{Float64}),
+                    x.ctx.handle, pg_dtype(T), x.n, x.ptr, out))
+        return T(out[])
+    end
+    check(ccall((:pg_nrm2sq, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ref{Float64}),
+                x.ctx.handle, pg_dtype(T), x.n, x.ptr, out))
+    sqrt(T(out[]))
+end
+# out .= a .* x .+ b .* y  (the broadcasts of the iteration bodies lower to this)
+function axpby!(out::HIPVector{T}, a, x::HIPVector{T}, b, y::HIPVector{T}) where {T}
+    check(ccall((:pg_axpby, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Cvoid}),
+                out.ctx.handle, pg_dtype(T), out.n, out.ptr, a, x.ptr, b, y.ptr))
+    out
+end
+
+# ---------------------------------------------------------------- matrix + LeastSquares ----------------------
+mutable struct HIPMatrix{T}
+    ctx::HIPContext
+    handle::Ptr{Cvoid}
+    m::Int
+    n::Int
+end
+function HIPMatrix(A::Matrix{T}; ctx = default_ctx()) where {T}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    m, n = size(A)
+    check(ccall((:pg_mat_create, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Int64, Ref{Ptr{Cvoid}}), ctx.handle, pg_dtype(T), m, n, h))
+    M = HIPMatrix{T}(ctx, h[], m, n)
+    finalizer(M -> ccall((:pg_mat_destroy, libpg), Int32, (Ptr{Cvoid},), M.handle), M)
+    GC.@preserve A check(ccall((:pg_mat_upload, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), M.handle, pointer(A), max(m, 1)))
+    M
+end
+
+# f(x) = lam/2 ||A x - b||^2 : replaces ProximalOperators.LeastSquares + benchmark/benchmarks.jl:11-17
+mutable struct HIPLeastSquares{T}
+    A::HIPMatrix{T}
+    b::HIPVector{T}
+    handle::Ptr{Cvoid}
+end
+function HIPLeastSquares(A::Matrix{T}, b::Vector{T}, lam::Real = 1) where {T}
+    Ad = HIPMatrix(A)
+    bd = HIPVector(b; ctx = Ad.ctx)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_ls_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ref{Ptr{Cvoid}}),
+                Ad.ctx.handle, Ad.handle, bd.ptr, lam, h))
+    f = HIPLeastSquares{T}(Ad, bd, h[])
+    finalizer(f -> ccall((:pg_ls_destroy, libpg), Int32, (Ptr{Cvoid},), f.handle), f)
+end
+function ProximalAlgorithms.value_and_gradient(f::HIPLeastSquares{T}, x::HIPVector{T}) where {T}
+    grad = similar(x)
+    fx = Ref{Float64}(0)
+    check(ccall((:pg_ls_value_and_gradient, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}),
+                f.handle, x.ptr, grad.ptr, fx))
+    T(fx[]), grad
+end
+function (f::HIPLeastSquares{T})(x::HIPVector{T}) where {T}
+    fx = Ref{Float64}(0)
+    check(ccall((:pg_ls_value, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), f.handle, x.ptr, fx))
+    T(fx[])
+end
+
+# ---------------------------------------------------------------- prox operators -----------------------------
+struct HIPNormL1{R}
+    lambda::R
+end
+function ProximalCore.prox!(y::HIPVector{T}, g::HIPNormL1, x::HIPVector{T}, gamma) where {T}
+    gy = Ref{Float64}(0)
+    check(ccall((:pg_prox_norml1, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
+                x.ctx.handle, pg_dtype(T), x.n, y.ptr, x.ptr, g.lambda, gamma, gy))
+    T(gy[])
+end
+struct HIPIndBox{R}
+    lo::R
+    hi::R
+end
+function ProximalCore.prox!(y::HIPVector{T}, g::HIPIndBox, x::HIPVector{T}, gamma) where {T}
+    gy = Ref{Float64}(0)
+    check(ccall((:pg_prox_indbox, libpg), Int32,
+                (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}),
+                x.ctx.handle, pg_dtype(T), x.n, y.ptr, x.ptr, g.lo, g.hi, C_NULL, C_NULL, gy))
+    T(0)
+end
+ProximalCore.prox(g::Union{HIPNormL1,HIPIndBox}, x::HIPVector, gamma) = (y = similar(x); (y, ProximalCore.prox!(y, g, x, gamma)))
+# With these methods the reference's own ForwardBackwardIteration / FastForwardBackwardIteration run unchanged
+# on HIPVector once the broadcasts in their bodies are routed to axpby! (Base.Broadcast style for HIPVector).
+
+# ---------------------------------------------------------------- fused iterators ----------------------------
+# C structs of include/proxgrad_hip.h
+struct PgIterOpts
+    fast::Int32; adaptive::Int32; Lf::Float64; gamma::Float64; minimum_gamma::Float64; reduce_gamma::Float64
+    increase_gamma::Float64; mf::Float64; seq_kind::Int32; seq_p0::Float64; seq_p1::Float64
+    g_kind::Int32; g_p0::Float64; g_p1::Float64
+end
+struct PgIterScalars
+    gamma::Float64; f_x::Float64; g_z::Float64; res_inf::Float64; beta::Float64; f_z::Float64; f_z_upp::Float64
+    n_backtracks::Int32; flags::Int32; a_passes::Int64
+end
+struct PgIterState
+    x::Ptr{Cvoid}; grad_f_x::Ptr{Cvoid}; y::Ptr{Cvoid}; z::Ptr{Cvoid}; res::Ptr{Cvoid}; z_prev::Ptr{Cvoid}; grad_f_z::Ptr{Cvoid}
+end
+g_spec(g::HIPNormL1) = (Int32(1), Float64(g.lambda), 0.0)
+g_spec(g::HIPIndBox) = (Int32(2), Float64(g.lo), Float64(g.hi))
+
+# keyword constructor mirrors ForwardBackwardIteration / FastForwardBackwardIteration (forward_backward.jl:38-48)
+Base.@kwdef struct HIPForwardBackwardIteration{R,Tf,Tg,Tx}
+    f::Tf
+    g::Tg
+    x0::Tx
+    fast::Bool = false
+    mf::R = real(eltype(x0))(0)
+    Lf::Union{Nothing,R} = nothing
+    gamma::Union{Nothing,R} = Lf === nothing ? nothing : (1 / Lf)
+    adaptive::Bool = gamma === nothing
+    minimum_gamma::R = real(eltype(x0))(1e-7)
+    reduce_gamma::R = real(eltype(x0))(0.5)
+    increase_gamma::R = real(eltype(x0))(1.0)
+end
+Base.IteratorSize(::Type{<:HIPForwardBackwardIteration}) = Base.IsInfinite()
+
+mutable struct HIPIterState{R,T}
+    handle::Ptr{Cvoid}
+    x::HIPVector{T}; grad_f_x::HIPVector{T}; y::HIPVector{T}; z::HIPVector{T}; res::HIPVector{T}
+    f_x::R; gamma::R; g_z::R; res_inf::R
+end
+
+function refresh!(st::HIPIterState{R,T}, sc::PgIterScalars, ctx, n) where {R,T}
+    v = Ref(PgIterState(C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+    check(ccall((:pg_iter_state_view, libpg), Int32, (Ptr{Cvoid}, Ref{PgIterState}), st.handle, v))
+    mk(p) = HIPVector{T}(ctx, p, n, st)   # non-owning views, pointers follow the library's swaps
+    st.x, st.grad_f_x, st.y, st.z, st.res = mk(v[].x), mk(v[].grad_f_x), mk(v[].y), mk(v[].z), mk(v[].res)
+    st.f_x, st.gamma, st.g_z, st.res_inf = R(sc.f_x), R(sc.gamma), R(sc.g_z), R(sc.res_inf)
+    st
+end
+
+function Base.iterate(iter::HIPForwardBackwardIteration{R}) where {R}
+    T = eltype(iter.x0)
+    x0 = iter.x0 isa HIPVector ? iter.x0 : HIPVector(iter.x0; ctx = iter.f.A.ctx)   # x0 is copied, never mutated
+    kind, p0, p1 = g_spec(iter.g)
+    opts = Ref(PgIterOpts(iter.fast, iter.adaptive, something(iter.Lf, -1.0), something(iter.gamma, -1.0),
+                          iter.minimum_gamma, iter.reduce_gamma, iter.increase_gamma, iter.mf, 0, 0.0, 0.0, kind, p0, p1))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_iter_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterOpts}, Ref{Ptr{Cvoid}}),
+                iter.f.A.ctx.handle, iter.f.handle, opts, h))
+    sc = Ref{PgIterScalars}()
+    check(ccall((:pg_iter_init, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterScalars}), h[], x0.ptr, sc))
+    st = HIPIterState{R,T}(h[], x0, x0, x0, x0, x0, R(0), R(0), R(0), R(0))
+    finalizer(s -> ccall((:pg_iter_destroy, libpg), Int32, (Ptr{Cvoid},), s.handle), st)
+    refresh!(st, sc[], iter.f.A.ctx, length(x0))
+    return st, st
+end
+function Base.iterate(iter::HIPForwardBackwardIteration, st::HIPIterState)
+    sc = Ref{PgIterScalars}()
+    check(ccall((:pg_iter_step, libpg), Int32, (Ptr{Cvoid}, Float64, Ref{PgIterScalars}), st.handle, 0.0, sc))
+    (sc[].flags & 1) != 0 && @warn "stepsize `gamma` became too small ($(sc[].gamma))"   # fb_tools.jl:59-61
+    refresh!(st, sc[], iter.f.A.ctx, st.x.n)
+    return st, st
+end
+
+default_stopping_criterion(tol, ::HIPForwardBackwardIteration, st::HIPIterState) = st.res_inf / st.gamma <= tol
+default_solution(::HIPForwardBackwardIteration, st::HIPIterState) = Array(st.z)
+default_display(it, ::HIPForwardBackwardIteration, st::HIPIterState) =
+    @printf("%5d | %.3e | %.3e\n", it, st.gamma, st.res_inf / st.gamma)
+
+HIPForwardBackward(; maxit = 10_000, tol = 1e-8, stop = (iter, state) -> default_stopping_criterion(tol, iter, state),
+                   solution = default_solution, verbose = false, freq = 100, display = default_display, kwargs...) =
+    ProximalAlgorithms.IterativeAlgorithm(HIPForwardBackwardIteration; maxit, stop, solution, verbose, freq, display, kwargs...)
+HIPFastForwardBackward(; kwargs...) = HIPForwardBackward(; fast = true, kwargs...)
+
+export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
+       HIPForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward
+
+end # module
