@@ -51,6 +51,10 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-cols", type=int, default=16384)
     p.add_argument("--cpu-steps", type=int, default=10)
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
+    p.add_argument("--share-device", action="store_true",
+                   help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
     return p.parse_args()
 
 
@@ -112,10 +116,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     m_glob, n = WORKLOADS[args.workload]
     m_glob = args.m or m_glob

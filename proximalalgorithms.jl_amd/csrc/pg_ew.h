@@ -4,9 +4,11 @@
 
 namespace pgew {
 
-inline unsigned grid_for(int64_t n_items, int num_cu) {
+inline unsigned grid_for(int64_t n_items, int num_cu, bool reduces) {
   int64_t blocks = (n_items + 255) / 256;
-  const int64_t cap = (int64_t)num_cu * 8;  // <= 2048 blocks on MI355X, grid-stride the rest
+  // <= 2048 blocks on MI355X for pure streams, grid-stride the rest; kernels that end in the ticketed grid
+  // reduction use <= 2 per CU: its single-counter fan-in costs ~12 ns per arriving workgroup
+  const int64_t cap = (int64_t)num_cu * (reduces ? 2 : 8);
   if (blocks > cap) blocks = cap;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
@@ -78,7 +80,7 @@ __device__ __forceinline__ void st(T* __restrict__ p, int64_t i, const Pack<T, N
 template <typename T, typename F, int NS, unsigned MAXMASK>
 pg_status launch_ew(pg_ctx* c, int64_t n, bool vec_ok, const F& f, double* out_dev) {
   if (n <= 0 && NS == 0) return PG_OK;
-  const unsigned blocks = grid_for(n / VecOf<T>::N + 1, c->num_cu);
+  const unsigned blocks = grid_for(n / VecOf<T>::N + 1, c->num_cu, NS > 0);
   hipLaunchKernelGGL((ew_kernel<T, F, NS, MAXMASK>), dim3(blocks), dim3(256), 0, c->stream, n, vec_ok, f,
                      c->red_partials, c->red_counter, out_dev);
   PG_LAUNCH_CHECK();

@@ -9,6 +9,8 @@
 //                          deterministic two-stage reduction over the column slots.
 //   pass T  (g = A' r):    r staged once per workgroup in LDS (<= 64 KiB); wave = C adjacent columns streamed
 //                          top to bottom; per-column DPP/shuffle wave reduction; no cross-wave traffic.
+#include <cstdlib>
+
 #include "pg_internal.h"
 
 namespace {
@@ -22,58 +24,77 @@ __device__ __forceinline__ V nt_load(const V* p) {
 
 // -------------------------------------------------------------------------------------------------
 // pass N, stage 1: partials[slot][i] = sum_{j in columns of slot} A[i, j] * x[j]
-// grid: ceil(n_tiles * S / 4) blocks of 4 waves.  Consecutive waves take consecutive row tiles of the
-// same column block, so a workgroup reads 4*R KiB contiguous bytes of each column it touches.
+// Workgroup = 4 waves = TB adjacent row tiles x TW column slots (TB * TW = 4).  Waves that share a slot take
+// adjacent row tiles, so they read TB*R KiB contiguous bytes of each column; waves that share a tile are
+// combined through LDS (fixed order) before the partial is written: S_eff = ceil(S / TW) partial vectors.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int R, int U>
+template <typename T, int R, int U, int TW>
 __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const T* __restrict__ A, int64_t ld, int64_t n,
-                                                             int n_rowgroups, int n_tiles, int S,
+                                                             int n_rowgroups, int n_tile_groups, int S,
                                                              const T* __restrict__ x, T* __restrict__ partials) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
+  constexpr int TB = 4 / TW;
+  __shared__ V lds_acc[TW > 1 ? 4 * R * WAVE : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
-  const int tile = (int)(gw % n_tiles);
-  const int64_t slot = gw / n_tiles;
-  if (slot >= S) return;
-  const int rg0 = tile * R;
-  const int r_eff = min(R, n_rowgroups - rg0);
+  const int tb = wave % TB, tw = wave / TB;
+  const int tg = (int)(blockIdx.x % (unsigned)n_tile_groups);
+  const int64_t sg = blockIdx.x / (unsigned)n_tile_groups;
+  const int64_t slot = sg * TW + tw;
+  const int rg0 = (tg * TB + tb) * R;
+  const int r_eff = max(0, min(R, n_rowgroups - rg0));
+  const bool active = slot < S && r_eff > 0;
 
   V acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = (V)(T(0));
 
-  const int64_t ncb = (n + U - 1) / U;
-  const T* __restrict__ a_base = A + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
-  for (int64_t cb = slot; cb < ncb; cb += S) {
-    const int64_t j0 = cb * U;
-    T xs[U];
-    int64_t jc[U];
+  if (active) {
+    const int64_t ncb = (n + U - 1) / U;
+    const T* __restrict__ a_base = A + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
+    for (int64_t cb = slot; cb < ncb; cb += S) {
+      const int64_t j0 = cb * U;
+      T xs[U];
+      int64_t jc[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t j = j0 + u;
-      jc[u] = j < n ? j : n - 1;
-      const T xv = x[jc[u]];
-      xs[u] = j < n ? xv : T(0);
-    }
-    V a[U][R];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (r < r_eff) a[u][r] = nt_load(reinterpret_cast<const V*>(a_base + jc[u] * ld + r * (WAVE * VEC)));
+      for (int u = 0; u < U; ++u) {
+        const int64_t j = j0 + u;
+        jc[u] = j < n ? j : n - 1;
+        const T xv = x[jc[u]];
+        xs[u] = j < n ? xv : T(0);
       }
-    }
+      V a[U][R];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (r < r_eff) acc[r] += a[u][r] * xs[u];
+        for (int r = 0; r < R; ++r) {
+          if (r < r_eff) a[u][r] = nt_load(reinterpret_cast<const V*>(a_base + jc[u] * ld + r * (WAVE * VEC)));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (r < r_eff) acc[r] += a[u][r] * xs[u];
+        }
       }
     }
   }
-  T* __restrict__ p = partials + slot * ld + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
+  if constexpr (TW > 1) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) lds_acc[(wave * R + r) * WAVE + lane] = acc[r];
+    __syncthreads();
+    if (tw != 0 || r_eff <= 0) return;
+#pragma unroll
+    for (int k = 1; k < TW; ++k) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] += lds_acc[((k * TB + tb) * R + r) * WAVE + lane];
+    }
+  } else {
+    if (!active) return;
+  }
+  T* __restrict__ p = partials + sg * ld + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (r < r_eff) *reinterpret_cast<V*>(p + r * (WAVE * VEC)) = acc[r];
@@ -81,45 +102,51 @@ __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const T* __restrict
 }
 
 // -------------------------------------------------------------------------------------------------
-// pass N, stage 2: y[i] = sum_s partials[s][i] - b[i]   (i < m; fixed summation order), optional
-// f = f_scale * sum_i y[i]^2 -> dscal[PG_S_F] (+ typed copy for the all-reduce payload).
-// 256 threads = 64 rows x 4 slot groups.
+// pass N, stage 2: y[i] = sum_s partials[s][i] - b[i]   (i < m; fixed summation order, fp64), optional
+// f = f_scale * sum_i y[i]^2 -> f_out (+ typed copy for the all-reduce payload).
+// 1024 threads = 64 rows x 16 slot groups; row groups are grid-strided.
 // -------------------------------------------------------------------------------------------------
 template <typename T, bool WITH_F>
-__global__ __launch_bounds__(256) void gemv_n_finish_kernel(const T* __restrict__ partials, int64_t ld, int64_t m,
-                                                            int S, const T* __restrict__ b, T* __restrict__ y,
-                                                            int64_t y_len, double f_scale,
-                                                            double* __restrict__ red_partials,
-                                                            unsigned* __restrict__ red_counter,
-                                                            double* __restrict__ f_out, T* __restrict__ f_out_typed) {
-  __shared__ double sm_rows[4][64];
+__global__ __launch_bounds__(1024) void gemv_n_finish_kernel(const T* __restrict__ partials, int64_t ld, int64_t m,
+                                                             int S, const T* __restrict__ b, T* __restrict__ y,
+                                                             int64_t y_len, double f_scale,
+                                                             double* __restrict__ red_partials,
+                                                             unsigned* __restrict__ red_counter,
+                                                             double* __restrict__ f_out, T* __restrict__ f_out_typed) {
+  __shared__ double sm_rows[16][64];
   const int rx = threadIdx.x & 63;
   const int sg = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + rx;
-  double acc = 0.0;
-  if (i < ld) {
-    for (int s = sg; s < S; s += 4) acc += (double)partials[(int64_t)s * ld + i];
-  }
-  sm_rows[sg][rx] = acc;
-  __syncthreads();
   double sq = 0.0;
-  if (sg == 0) {
-    double v = ((sm_rows[0][rx] + sm_rows[1][rx]) + sm_rows[2][rx]) + sm_rows[3][rx];
-    T out = T(0);
-    if (i < m) {
-      if (b != nullptr) v -= (double)b[i];
-      out = (T)v;
-      sq = (double)out * (double)out;
+  for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < ld; row0 += (int64_t)gridDim.x * 64) {
+    const int64_t i = row0 + rx;
+    double acc = 0.0;
+    if (i < ld) {
+      for (int s = sg; s < S; s += 16) acc += (double)partials[(int64_t)s * ld + i];
     }
-    if (i < y_len) y[i] = out;
+    sm_rows[sg][rx] = acc;
+    __syncthreads();
+    if (sg == 0) {
+      double v = sm_rows[0][rx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) v += sm_rows[k][rx];
+      T out = T(0);
+      if (i < m) {
+        if (b != nullptr) v -= (double)b[i];
+        out = (T)v;
+        sq += (double)out * (double)out;
+      }
+      if (i < y_len) y[i] = out;
+    }
+    __syncthreads();
   }
   if constexpr (WITH_F) {
-    double v[1] = {sq};
+    // wave 0 holds the row contributions; all 16 waves take part in the grid reduction
+    double v[1] = {sg == 0 ? sq : 0.0};
     const double ps[1] = {f_scale};
-    __syncthreads();
-    const bool last = grid_reduce_finalize<1, 0u>(v, red_partials, red_counter, f_out, ps);
+    double fin[1];
+    const bool last = grid_reduce_finalize<1, 0u, 16>(v, red_partials, red_counter, f_out, ps, fin);
     // mirror f in working precision (slot n of the all-reduce payload)
-    if (last && threadIdx.x == 0 && f_out_typed != nullptr) *f_out_typed = (T)(*f_out);
+    if (last && threadIdx.x == 0 && f_out_typed != nullptr) *f_out_typed = (T)fin[0];
   }
 }
 
@@ -229,31 +256,49 @@ constexpr int64_t LDS_R_BYTES = 64 * 1024;  // r chunk per workgroup in pass T (
 // host-side launch planning
 // ----------------------------------------------------------------------------------------------
 struct PlanN {
-  int R, U, n_rowgroups, n_tiles, S;
+  int R, U, TW, n_rowgroups, n_tiles, n_tile_groups, S, S_eff;
 };
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// Launch geometry of pass N.  Tunables (environment, for experiments): PG_N_R, PG_N_U, PG_N_TW, PG_N_WAVES_PER_CU.
 PlanN plan_n(const pg_mat* A) {
   PlanN p;
   const int64_t rows_per_rg = 1024 / (int64_t)pg_sizeof(A->dtype);
   p.n_rowgroups = (int)(A->ld / rows_per_rg);
+  // Measured on MI355X (scripts/tune_gemv.py, profiles/r1_tune_gemv.log): both passes peak with ~32-64 KiB of
+  // loads in flight per CU (R*U KiB per wave x 8 waves/CU); more in flight costs 3-5 % (DRAM queueing).
   if (p.n_rowgroups >= 4) {
     p.R = 4;
-    p.U = 4;
+    p.U = 2;
   } else if (p.n_rowgroups >= 2) {
     p.R = 2;
-    p.U = 8;
+    p.U = 4;
   } else {
     p.R = 1;
     p.U = 8;
   }
+  p.R = env_int("PG_N_R", p.R);
+  p.U = env_int("PG_N_U", p.U);
   p.n_tiles = (p.n_rowgroups + p.R - 1) / p.R;
+  // waves sharing a row tile inside a workgroup (LDS-combined): all 4 when there are fewer than 4 tiles
+  p.TW = p.n_tiles >= 4 ? 1 : (p.n_tiles >= 2 ? 2 : 4);
+  p.TW = env_int("PG_N_TW", p.TW);
+  if (p.TW != 1 && p.TW != 2 && p.TW != 4) p.TW = 1;
+  const int TB = 4 / p.TW;
+  p.n_tile_groups = (p.n_tiles + TB - 1) / TB;
   const int64_t ncb = A->n > 0 ? (A->n + p.U - 1) / p.U : 1;
-  const int64_t target_waves = (int64_t)A->ctx->num_cu * 16;
-  int64_t S = target_waves / p.n_tiles;
+  const int64_t target_waves = (int64_t)A->ctx->num_cu * env_int("PG_N_WAVES_PER_CU", 8);
+  int64_t S = target_waves / ((int64_t)p.n_tile_groups * TB);
   if (S < 1) S = 1;
   if (S > ncb) S = ncb;
-  if (S > 1024) S = 1024;
+  S = (S + p.TW - 1) / p.TW * p.TW;
+  if (S > 4096) S = 4096;
   p.S = (int)S;
+  p.S_eff = (p.S + p.TW - 1) / p.TW;
   return p;
 }
 
@@ -274,25 +319,49 @@ pg_status ensure_partials(pg_mat* A, int S) {
   return PG_OK;
 }
 
-template <typename T>
-pg_status launch_n_partial(pg_mat* A, const PlanN& p, const T* x) {
-  const int64_t waves = (int64_t)p.n_tiles * p.S;
-  const unsigned blocks = (unsigned)((waves + 3) / 4);
+template <typename T, int R, int U>
+pg_status launch_n_ru(pg_mat* A, const PlanN& p, const T* x) {
+  const int64_t blocks64 = (int64_t)p.n_tile_groups * ((p.S + p.TW - 1) / p.TW);
+  const unsigned blocks = (unsigned)blocks64;
   hipStream_t st = A->ctx->stream;
   pg_prof_scope prof(A->ctx, PG_K_GEMV_N);
   const T* Ad = (const T*)A->data;
   T* part = (T*)A->partials;
-  if (p.R == 4)
-    hipLaunchKernelGGL((gemv_n_partial_kernel<T, 4, 4>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
-                       p.n_rowgroups, p.n_tiles, p.S, x, part);
-  else if (p.R == 2)
-    hipLaunchKernelGGL((gemv_n_partial_kernel<T, 2, 8>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
-                       p.n_rowgroups, p.n_tiles, p.S, x, part);
+  if (p.TW == 1)
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, R, U, 1>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
+                       p.n_rowgroups, p.n_tile_groups, p.S, x, part);
+  else if (p.TW == 2)
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, R, U, 2>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
+                       p.n_rowgroups, p.n_tile_groups, p.S, x, part);
   else
-    hipLaunchKernelGGL((gemv_n_partial_kernel<T, 1, 8>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
-                       p.n_rowgroups, p.n_tiles, p.S, x, part);
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, R, U, 4>), dim3(blocks), dim3(256), 0, st, Ad, A->ld, A->n,
+                       p.n_rowgroups, p.n_tile_groups, p.S, x, part);
   PG_LAUNCH_CHECK();
   return PG_OK;
+}
+
+template <typename T>
+pg_status launch_n_partial(pg_mat* A, const PlanN& p, const T* x) {
+#define PG_N_CASE(RR, UU) \
+  if (p.R == RR && p.U == UU) return launch_n_ru<T, RR, UU>(A, p, x)
+  PG_N_CASE(4, 4);
+  PG_N_CASE(2, 8);
+  PG_N_CASE(1, 8);
+  PG_N_CASE(4, 2);
+  PG_N_CASE(4, 8);
+  PG_N_CASE(2, 4);
+  PG_N_CASE(8, 2);
+  PG_N_CASE(8, 4);
+  PG_N_CASE(2, 16);
+  PG_N_CASE(1, 16);
+  PG_N_CASE(4, 1);
+  PG_N_CASE(8, 1);
+  PG_N_CASE(16, 1);
+  PG_N_CASE(16, 2);
+  PG_N_CASE(2, 2);
+#undef PG_N_CASE
+  pg_set_error("no gemv_n instantiation for R=%d U=%d", p.R, p.U);
+  return PG_ERR_UNSUPPORTED;
 }
 
 // y = A x - b (b nullable), y has y_len >= m valid slots (entries in [m, y_len) are zeroed);
@@ -307,39 +376,39 @@ pg_status gemv_n(pg_mat* A, const T* x, const T* b, T* y, int64_t y_len, bool wi
     return PG_OK;
   }
   PlanN p = plan_n(A);
-  PG_TRY(ensure_partials(A, p.S));
+  PG_TRY(ensure_partials(A, p.S_eff));
   if (A->n == 0) {
-    PG_HIP(hipMemsetAsync(A->partials, 0, (size_t)p.S * A->ld * sizeof(T), c->stream));
+    PG_HIP(hipMemsetAsync(A->partials, 0, (size_t)p.S_eff * A->ld * sizeof(T), c->stream));
   } else {
     PG_TRY(launch_n_partial<T>(A, p, x));
   }
-  const unsigned blocks = (unsigned)((A->ld + 63) / 64);
-  if (blocks > (unsigned)PG_RED_MAX_BLOCKS && with_f) {
-    pg_set_error("m too large for the fused residual reduction (%lld rows)", (long long)A->m);
-    return PG_ERR_UNSUPPORTED;
-  }
+  int64_t fb = (A->ld + 63) / 64;
+  if (fb > 1024) fb = 1024;  // row groups are grid-strided beyond this
+  const unsigned blocks = (unsigned)fb;
   pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
   if (with_f)
-    hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3(blocks), dim3(256), 0, c->stream,
-                       (const T*)A->partials, A->ld, A->m, p.S, b, y, y_len, f_scale, c->red_partials,
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3(blocks), dim3(1024), 0, c->stream,
+                       (const T*)A->partials, A->ld, A->m, p.S_eff, b, y, y_len, f_scale, c->red_partials,
                        c->red_counter, c->dscal + PG_S_F, f_typed);
   else
-    hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3(blocks), dim3(256), 0, c->stream,
-                       (const T*)A->partials, A->ld, A->m, p.S, b, y, y_len, 0.0, (double*)nullptr,
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3(blocks), dim3(1024), 0, c->stream,
+                       (const T*)A->partials, A->ld, A->m, p.S_eff, b, y, y_len, 0.0, (double*)nullptr,
                        (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
 
-template <typename T, int C, int UR>
-pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
-  constexpr int WAVES = 8;
+template <typename T, int C, int UR, int WAVES>
+pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
   pg_ctx* c = A->ctx;
   const size_t lds = (size_t)nrg * 1024;
   const int64_t ncg = (A->n + C - 1) / C;
   // workgroups per CU limited by LDS (160 KiB) and by 32 waves
-  int per_cu = (int)(160 * 1024 / (lds > 0 ? lds : 1));
-  if (per_cu > 4) per_cu = 4;
+  int lds_cap = (int)(160 * 1024 / (lds > 0 ? lds : 1));
+  const int wave_cap = 32 / WAVES;
+  if (lds_cap > wave_cap) lds_cap = wave_cap;
+  int per_cu = env_int("PG_T_BLOCKS_PER_CU", 1);  // 1: C*UR KiB x WAVES in flight per CU is the sweet spot
+  if (per_cu > lds_cap) per_cu = lds_cap;
   if (per_cu < 1) per_cu = 1;
   int64_t blocks = (int64_t)c->num_cu * per_cu;
   const int64_t need = (ncg + WAVES - 1) / WAVES;
@@ -350,6 +419,38 @@ pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
                      (const T*)A->data, A->ld, A->n, A->m, rg_begin, nrg, r, g);
   PG_LAUNCH_CHECK();
   return PG_OK;
+}
+
+// Tunables (environment, for experiments): PG_T_C, PG_T_UR, PG_T_WAVES, PG_T_BLOCKS_PER_CU.
+template <typename T>
+pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
+  const int C = env_int("PG_T_C", 2), UR = env_int("PG_T_UR", 4), W = env_int("PG_T_WAVES", 8);
+#define PG_T_CASE(CC, UU, WW) \
+  if (C == CC && UR == UU && W == WW) return launch_t_cuw<T, CC, UU, WW>(A, rg_begin, nrg, r, g)
+  PG_T_CASE(4, 4, 8);
+  PG_T_CASE(4, 4, 4);
+  PG_T_CASE(4, 4, 16);
+  PG_T_CASE(2, 8, 8);
+  PG_T_CASE(8, 2, 8);
+  PG_T_CASE(4, 8, 8);
+  PG_T_CASE(8, 4, 8);
+  PG_T_CASE(2, 4, 8);
+  PG_T_CASE(4, 2, 8);
+  PG_T_CASE(2, 4, 16);
+  PG_T_CASE(4, 2, 16);
+  PG_T_CASE(2, 4, 4);
+  PG_T_CASE(2, 8, 4);
+  PG_T_CASE(2, 16, 4);
+  PG_T_CASE(2, 16, 8);
+  PG_T_CASE(1, 8, 8);
+  PG_T_CASE(1, 16, 8);
+  PG_T_CASE(1, 16, 4);
+  PG_T_CASE(2, 2, 8);
+  PG_T_CASE(2, 4, 2);
+  PG_T_CASE(2, 8, 2);
+#undef PG_T_CASE
+  pg_set_error("no gemv_t instantiation for C=%d UR=%d WAVES=%d", C, UR, W);
+  return PG_ERR_UNSUPPORTED;
 }
 
 // g = A' r ; gchunks: workspace [nchunks * n] used only when m spans several LDS chunks (may be null when
@@ -366,7 +467,7 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
   const int n_rowgroups = (int)(A->ld / rows_per_rg);
   const int rg_per_chunk = (int)(LDS_R_BYTES / 1024);
   const int nchunks = (n_rowgroups + rg_per_chunk - 1) / rg_per_chunk;
-  if (nchunks == 1) return launch_t<T, 4, 4>(A, 0, n_rowgroups, r, g);
+  if (nchunks == 1) return launch_t<T>(A, 0, n_rowgroups, r, g);
   if (*gchunks_ws == nullptr) {
     hipError_t e = hipMalloc((void**)gchunks_ws, (size_t)nchunks * A->n * sizeof(T));
     if (e != hipSuccess) {
@@ -377,7 +478,7 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
   for (int k = 0; k < nchunks; ++k) {
     const int rb = k * rg_per_chunk;
     const int nr = (rb + rg_per_chunk <= n_rowgroups) ? rg_per_chunk : (n_rowgroups - rb);
-    PG_TRY((launch_t<T, 4, 4>(A, rb, nr, r, *gchunks_ws + (int64_t)k * A->n)));
+    PG_TRY(launch_t<T>(A, rb, nr, r, *gchunks_ws + (int64_t)k * A->n));
   }
   int64_t blocks = (A->n + 255) / 256;
   if (blocks > 2048) blocks = 2048;

@@ -75,8 +75,8 @@ struct pg_ctx {
   // reduction workspace
   double* red_partials = nullptr;  // [PG_RED_MAX_BLOCKS * PG_RED_MAX_NS]
   unsigned* red_counter = nullptr; // [8]
-  double* dscal = nullptr;         // [PG_S_COUNT]  device scalar block
-  double* hscal = nullptr;         // [PG_S_COUNT]  pinned host mirror
+  double* hscal = nullptr;         // [PG_S_COUNT]  scalar block: mapped pinned host memory
+  double* dscal = nullptr;         //               ... and its device-side address (kernels store here)
   // collective
   pg_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -160,15 +160,15 @@ __device__ __forceinline__ double pg_shfl_xor(double v, int m) { return __shfl_x
 __device__ __forceinline__ float pg_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 
 // Deterministic grid-wide reduction of NS doubles per thread (bit k of MAXMASK: slot k is a max, else a
-// sum).  256-thread blocks, gridDim.x <= PG_RED_MAX_BLOCKS.  Every block publishes its partial with an
+// sum).  NW-wave (NW*64-thread) blocks, every thread of the block must call it; gridDim.x <= PG_RED_MAX_BLOCKS.  Every block publishes its partial with an
 // agent-scope release; the last block to arrive (ticket counter) acquires, combines all partials in a
 // fixed order and writes out[k] * post_scale[k].  The counter is reset for the next launch.  Returns true
 // (to all its threads) in the finalizing block only; out[] is then visible to that block's thread 0.
-template <int NS, unsigned MAXMASK>
+template <int NS, unsigned MAXMASK, int NW = 4>
 __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __restrict__ partials,
                                                      unsigned* __restrict__ counter, double* __restrict__ out,
-                                                     const double (&post_scale)[NS]) {
-  __shared__ double sm[4 * NS];
+                                                     const double (&post_scale)[NS], double* final_vals = nullptr) {
+  __shared__ double sm[NW * NS];
   __shared__ int sm_last;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -189,7 +189,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double a = sm[k];
-      for (int w = 1; w < 4; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      for (int w = 1; w < NW; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
       partials[(size_t)blockIdx.x * NS + k] = a;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -204,7 +204,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
   double acc[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) acc[k] = ((MAXMASK >> k) & 1u) ? -INFINITY : 0.0;
-  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += NW * 64) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double p = __hip_atomic_load(&partials[(size_t)b * NS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -229,8 +229,9 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double a = sm[k];
-      for (int w = 1; w < 4; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      for (int w = 1; w < NW; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
       out[k] = a * post_scale[k];
+      if (final_vals != nullptr) final_vals[k] = a * post_scale[k];  // valid on thread 0 of the finalizing block
     }
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

@@ -6,22 +6,23 @@ from . import _lib
 from .algorithm import IterativeAlgorithm
 from .device import as_hipvector
 from .fb_tools import backtrack_stepsize_, lower_bound_smoothness_constant
-from .forward_backward import _res_inf
+from .forward_backward import _LazyVectors, _res_inf
 from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, FixedNesterovSequence,
                        SimpleNesterovSequence)
 from .operators import Zero, fused_supported, prox_, value_and_gradient
 from ._fused import FusedIteration
 
 
-class FastForwardBackwardState:
+class FastForwardBackwardState(_LazyVectors):
     """fast_forward_backward.jl:60-71"""
 
-    __slots__ = ("x", "f_x", "grad_f_x", "gamma", "y", "z", "g_z", "res", "z_prev", "extrapolation_sequence",
-                 "res_inf", "beta", "n_backtracks")
+    _vector_fields = ("x", "grad_f_x", "y", "z", "res", "z_prev")
 
     def __init__(self, **kw):
-        for k in self.__slots__:
-            setattr(self, k, kw.get(k))
+        self.f_x = self.gamma = self.g_z = self.res_inf = self.beta = self.extrapolation_sequence = None
+        self.n_backtracks = 0
+        for k, v in kw.items():
+            setattr(self, k, v)
 
 
 class FastForwardBackwardIteration:
@@ -72,10 +73,10 @@ class FastForwardBackwardIteration:
         self._fused = fi
         state = FastForwardBackwardState(extrapolation_sequence=self.extrapolation_sequence)
 
+        state._bind(fi)
+
         def refresh(sc):
-            v = fi.view()
-            state.x, state.grad_f_x, state.y, state.z, state.res, state.z_prev = (
-                v["x"], v["grad_f_x"], v["y"], v["z"], v["res"], v["z_prev"])
+            state._invalidate()
             state.f_x, state.gamma, state.g_z = R(sc.f_x), R(sc.gamma), R(sc.g_z)
             state.res_inf, state.beta = R(sc.res_inf), R(sc.beta)
             state.n_backtracks = sc.n_backtracks

@@ -15,14 +15,43 @@ from .operators import Zero, fused_supported, prox_, value_and_gradient
 from ._fused import FusedIteration
 
 
-class ForwardBackwardState:
+class _LazyVectors:
+    """State base: the vector fields of a fused iteration are views of library-owned memory whose pointers
+    change when the library swaps references (x <-> z, ...); they are materialised on first access after a step
+    (one C call) so that a plain `for state in iteration` loop pays nothing for them."""
+
+    _vector_fields = ()
+
+    def _bind(self, fused):
+        object.__setattr__(self, "_fused", fused)
+        object.__setattr__(self, "_views", None)
+
+    def _invalidate(self):
+        object.__setattr__(self, "_views", None)
+
+    def __getattr__(self, name):  # only reached when normal lookup fails
+        if name in type(self)._vector_fields:
+            fused = self.__dict__.get("_fused")
+            if fused is None:
+                return None
+            views = self.__dict__.get("_views")
+            if views is None:
+                views = fused.view()
+                object.__setattr__(self, "_views", views)
+            return views[name]
+        raise AttributeError(name)
+
+
+class ForwardBackwardState(_LazyVectors):
     """forward_backward.jl:52-63"""
 
-    __slots__ = ("x", "f_x", "grad_f_x", "gamma", "y", "z", "g_z", "res", "grad_f_z", "res_inf", "n_backtracks")
+    _vector_fields = ("x", "grad_f_x", "y", "z", "res", "grad_f_z")
 
     def __init__(self, **kw):
-        for k in self.__slots__:
-            setattr(self, k, kw.get(k))
+        self.f_x = self.gamma = self.g_z = self.res_inf = None
+        self.n_backtracks = 0
+        for k, v in kw.items():
+            setattr(self, k, v)
 
 
 class ForwardBackwardIteration:
@@ -59,10 +88,10 @@ class ForwardBackwardIteration:
         self._fused = fi
         state = ForwardBackwardState()
 
+        state._bind(fi)
+
         def refresh(sc):
-            v = fi.view()
-            state.x, state.grad_f_x, state.y, state.z, state.res, state.grad_f_z = (
-                v["x"], v["grad_f_x"], v["y"], v["z"], v["res"], v["grad_f_z"])
+            state._invalidate()
             state.f_x, state.gamma, state.g_z = R(sc.f_x), R(sc.gamma), R(sc.g_z)
             state.res_inf = R(sc.res_inf)
             state.n_backtracks = sc.n_backtracks

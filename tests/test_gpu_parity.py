@@ -489,3 +489,95 @@ def test_nccl_world_size_one(pa):
         assert np.array_equal(gs.numpy(), gp.numpy())
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# two real ranks on one GPU (gloo transport, device tensors): the production sharded code path
+# ------------------------------------------------------------------------------------------------
+
+
+def _run_bench(extra, nproc=1, port=29641):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "small", "--steps", "12", "--warmup", "2", "--no-cpu-baseline"] + extra
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc)] + common
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("mode", ["fixed", "adaptive"])
+def test_two_ranks_one_gpu_matches_single_rank(pa, mode):
+    """bench.py with 2 processes (row shards of 1024 rows each) sharing cuda:0 over gloo == 1 process:
+    same lambda / Lf (they come from all-reduced quantities) and the same iterate after 14 steps."""
+    one = _run_bench(["--mode", mode])
+    two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device"], nproc=2)
+    assert two["n_gpus"] == 2 and two["config"]["m_per_gpu"] * 2 == one["config"]["m"]
+    assert two["config"]["lambda"] == pytest.approx(one["config"]["lambda"], rel=1e-5)
+    if mode == "fixed":
+        assert two["config"]["Lf"] == pytest.approx(one["config"]["Lf"], rel=1e-4)
+    f1, f2 = one["config"]["final"], two["config"]["final"]
+    assert f2["gamma"] == pytest.approx(f1["gamma"], rel=1e-4)
+    assert f2["f_x"] == pytest.approx(f1["f_x"], rel=2e-4)
+    assert f2["g_z"] == pytest.approx(f1["g_z"], rel=2e-4)
+    assert two["config"]["a_passes_per_step"] == one["config"]["a_passes_per_step"]
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full size (m = 16384, n = 2^20, 64 GiB): size-independent properties
+# ------------------------------------------------------------------------------------------------
+
+
+def test_headline_size_properties(pa):
+    """At the headline size the oracle cannot hold A; check what does not depend on size:
+    A e_j is column j and A' e_i is row i of the (bit-reproducible) generator, the adjoint identity
+    <A x, r> = <x, A' r>, linearity, and f(x) = ||Ax - b||^2 / 2 consistency between the two entry points."""
+    import torch
+
+    m, n = 16384, 1 << 20
+    free, _ = torch.cuda.mem_get_info()
+    if free < 70 * 2**30:
+        pytest.skip("needs 64 GiB of free HBM")
+    A = pa.HIPMatrix.synthetic(m, n, np.float32, seed=0)
+    V = pa.HIPVector.from_numpy
+    rows = np.arange(m, dtype=np.uint64)
+    scale = o.synthetic_scale(m)
+    for j in (0, 1, 12345, n // 2 + 7, n - 1):  # columns, including the last one (64-bit addressing)
+        e = np.zeros(n, np.float32)
+        e[j] = 1
+        col = A.mul(V(e)).numpy()
+        assert np.array_equal(col, o.counter_ih8(0, rows, np.uint64(j)).astype(np.float32) * scale), j
+    cols = np.arange(n, dtype=np.uint64)
+    for i in (0, 255, 256, 8191, m - 1):
+        e = np.zeros(m, np.float32)
+        e[i] = 1
+        row = A.mul_adjoint(V(e)).numpy()
+        assert np.array_equal(row, o.counter_ih8(0, np.uint64(i), cols).astype(np.float32) * scale), i
+    rng = np.random.default_rng(0)
+    x1, x2 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal(m).astype(np.float32)
+    y1, y2 = A.mul(V(x1)).numpy().astype(np.float64), A.mul(V(x2)).numpy().astype(np.float64)
+    y12 = A.mul(V((0.5 * x1 - 2.0 * x2).astype(np.float32))).numpy().astype(np.float64)
+    assert np.max(np.abs(y12 - (0.5 * y1 - 2.0 * y2))) <= 2e-5 * np.max(np.abs(y1) + np.abs(y2)) * 8
+    g = A.mul_adjoint(V(r)).numpy().astype(np.float64)
+    lhs, rhs = float(np.dot(y1, r.astype(np.float64))), float(np.dot(x1.astype(np.float64), g))
+    assert abs(lhs - rhs) <= 1e-5 * np.sqrt(np.dot(y1, y1) * np.dot(r, r))
+    b = V(r)
+    f = pa.LeastSquares(A, b)
+    fx, grad = f.value_and_gradient(V(x1))
+    res = y1 - r.astype(np.float64)
+    assert abs(float(fx) - 0.5 * np.dot(res, res)) <= 1e-5 * 0.5 * np.dot(res, res)
+    assert abs(float(f(V(x1))) - float(fx)) == 0
+    g_res = A.mul_adjoint(V(res.astype(np.float32))).numpy()
+    assert np.max(np.abs(grad.numpy() - g_res)) <= 1e-4 * np.max(np.abs(g_res))
+    # two evaluations are bit-identical (deterministic reductions at full size)
+    fx2, grad2 = f.value_and_gradient(V(x1))
+    assert fx2 == fx and np.array_equal(grad2.numpy(), grad.numpy())
