@@ -99,7 +99,10 @@ pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every
  * launch of the kernels below is bracketed by an event pair; pg_ctx_profile_read synchronises the stream and
  * returns the launch count and summed duration since the last reset. */
-enum { PG_K_GEMV_N = 0, PG_K_GEMV_N_FINISH = 1, PG_K_GEMV_T = 2, PG_K_EPILOGUE = 3, PG_K_EXTRAPOLATE = 4, PG_K_COUNT = 5 };
+enum {
+  PG_K_GEMV_N = 0, PG_K_GEMV_N_FINISH = 1, PG_K_GEMV_T = 2, PG_K_EPILOGUE = 3, PG_K_EXTRAPOLATE = 4, PG_K_DR_STEP = 5,
+  PG_K_COUNT = 6
+};
 pg_status pg_ctx_profile_enable(pg_ctx* ctx, int32_t enable);
 pg_status pg_ctx_profile_reset(pg_ctx* ctx);
 pg_status pg_ctx_profile_read(pg_ctx* ctx, int32_t kernel, int64_t* launches, double* total_ms);
@@ -178,6 +181,20 @@ pg_status pg_nrminf(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, double
 pg_status pg_fb_epilogue(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* grad, double gamma,
                          int32_t g_kind, double g_p0, double g_p1, void* y, void* z, void* res,
                          double* scalars_out /* host, 4 doubles; NULL = leave on device */);
+
+/* ------------------------------------------------------------------ Douglas-Rachford (config 3) --- */
+/* Separable quadratic f(x) = sum_i d_i x_i^2 / 2 + q_i x_i  (ProximalOperators Tilt(SqrNormL2(d), q), i.e.
+ * Quadratic(Diagonal(d), q)): prox!(y, f, x, gamma) -> f(y), y_i = (x_i - gamma q_i) / (1 + gamma d_i).
+ * d / q are used where d_vec / q_vec are NULL. */
+pg_status pg_prox_sepquad(pg_ctx* ctx, int32_t dtype, int64_t n, void* y, const void* x, const void* d_vec, double d,
+                          const void* q_vec, double q, double gamma, double* fy_out);
+/* One DouglasRachfordIteration step, fused into a single HBM sweep (src/algorithms/douglas_rachford.jl:53-63):
+ *   prox!(y, f, x, gamma); r .= 2 .* y .- x; prox!(z, g, r, gamma); res .= y .- z; x .-= res
+ * x is updated in place, y (the solution, :70) is always written; r, z, res may be NULL (not materialised).
+ * scalars_out = { norm(res, Inf), f(y), g(z) } (stop rule :65-69: norm(res, Inf) / gamma <= tol). */
+pg_status pg_dr_step(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, void* y, void* r, void* z, void* res,
+                     const void* d_vec, double d, const void* q_vec, double q, int32_t g_kind, double g_p0,
+                     double g_p1, double gamma, double* scalars_out /* host, 3 doubles; NULL = no sync */);
 
 /* ------------------------------------------------------------------ fused iterations ---- */
 /* Options = the keyword arguments of ForwardBackwardIteration (forward_backward.jl:38-48) and

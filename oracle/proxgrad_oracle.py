@@ -96,6 +96,44 @@ class LeastSquares:
     def __call__(self, x):
         return self.value_and_gradient(x)[0]
 
+    def prox(self, x, gamma):
+        """ProximalOperators.LeastSquares prox (direct solve): argmin_z lam/2 ||Az - b||^2 + ||z - x||^2 / (2 gamma)
+        = (A'A + I / (lam gamma)) \\ (A'b + x / (lam gamma)).  Used only to pin the DouglasRachford restatement
+        against test/problems/test_lasso_small.jl:205-214 (prox of LeastSquares is not on the GPU path)."""
+        R = _R(x)
+        c = R(1) / (R(self.lam) * R(gamma))
+        n = self.A.shape[1]
+        M = (self.A.T @ self.A + c * np.eye(n, dtype=x.dtype)).astype(x.dtype)
+        y = np.linalg.solve(M, self.A.T @ self.b + c * x).astype(x.dtype)
+        return y, self(y)
+
+
+class SeparableQuadratic:
+    """f(x) = sum_i d_i x_i^2 / 2 + q_i x_i  (ProximalOperators Tilt(SqrNormL2(d), q)):
+    prox_{gamma f}(x) = (x - gamma q) ./ (1 + gamma d)."""
+
+    def __init__(self, d, q):
+        self.d, self.q = d, q
+
+    def prox(self, x, gamma):
+        R = _R(x)
+        d = np.asarray(self.d, dtype=x.dtype)
+        q = np.asarray(self.q, dtype=x.dtype)
+        y = ((x - R(gamma) * q) / (R(1) + R(gamma) * d)).astype(x.dtype)
+        return y, self(y)
+
+    def value_and_gradient(self, x):
+        d = np.asarray(self.d, dtype=x.dtype)
+        q = np.asarray(self.q, dtype=x.dtype)
+        return self(x), (d * x + q).astype(x.dtype)
+
+    def __call__(self, x):
+        R = _R(x)
+        d = np.broadcast_to(np.asarray(self.d, dtype=np.float64), x.shape)
+        q = np.broadcast_to(np.asarray(self.q, dtype=np.float64), x.shape)
+        x64 = x.astype(np.float64)
+        return R(np.sum(0.5 * d * x64 * x64 + q * x64))
+
 
 class Quadratic:
     """f(x) = <x, Qx>/2 + <q, x>   (ProximalOperators.Quadratic; used by
@@ -462,6 +500,15 @@ def run(iteration, *, maxit=10_000, tol=1e-8, stop=None, trace=None):
         done = stop(iteration, state) if stop is not None else default_stopping_criterion(tol, state)
         if k >= maxit or done:
             return state.z, k
+
+
+def douglas_rachford(*, maxit=1_000, tol=1e-8, **kw):
+    """DouglasRachford(; maxit, tol)(; kwargs...)  douglas_rachford.jl:101-119; stop :65-69; solution :70 (state.y)."""
+    it = DouglasRachfordIteration(**kw)
+    R = _R(it.x0)
+    for k, s in enumerate(it, start=1):
+        if k >= maxit or _norm_inf(s.res) / it.gamma <= R(tol):
+            return s.y, k
 
 
 def forward_backward(*, maxit=10_000, tol=1e-8, trace=None, **kw):

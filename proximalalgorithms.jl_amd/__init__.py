@@ -8,6 +8,7 @@ include/proxgrad_hip.h).  There is no CPU fallback: without the library or a gfx
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .device import Context, HIPMatrix, HIPVector, as_hipvector, get_context
+from .douglas_rachford import DouglasRachford, DouglasRachfordIteration, DouglasRachfordState
 from .fast_forward_backward import (FastForwardBackward, FastForwardBackwardIteration, FastForwardBackwardState,
                                     FastProximalGradient, FastProximalGradientIteration)
 from .fb_tools import backtrack_stepsize_, f_model, lower_bound_smoothness_constant
@@ -16,11 +17,13 @@ from .forward_backward import (ForwardBackward, ForwardBackwardIteration, Forwar
 from .lbfgs import LBFGS, LBFGSOperator
 from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, FixedNesterovSequence,
                        SimpleNesterovSequence, next_)
-from .operators import (IndBox, LeastSquares, NormL1, Zero, gradient_, prox, prox_, value_and_gradient)
+from .operators import (IndBox, LeastSquares, NormL1, SeparableQuadratic, Zero, gradient_, prox, prox_,
+                        value_and_gradient)
 from .sharding import ScaleComm, TorchDistributedComm, allreduce_sum_, shard_rows
 
 __all__ = [
-    "ProxGradError", "IterativeAlgorithm", "Context", "HIPMatrix", "HIPVector", "as_hipvector", "get_context",
+    "ProxGradError", "IterativeAlgorithm", "DouglasRachford", "DouglasRachfordIteration", "DouglasRachfordState",
+    "SeparableQuadratic", "Context", "HIPMatrix", "HIPVector", "as_hipvector", "get_context",
     "FastForwardBackward", "FastForwardBackwardIteration", "FastForwardBackwardState", "FastProximalGradient",
     "FastProximalGradientIteration", "backtrack_stepsize_", "f_model", "lower_bound_smoothness_constant",
     "ForwardBackward", "ForwardBackwardIteration", "ForwardBackwardState", "ProximalGradient",

@@ -10,8 +10,8 @@ PG_F32, PG_F64 = 0, 1
 PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX = 0, 1, 2
 PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST = 0, 1, 2, 3, 4
 PG_FLAG_GAMMA_TOO_SMALL = 1
-PG_K_GEMV_N, PG_K_GEMV_N_FINISH, PG_K_GEMV_T, PG_K_EPILOGUE, PG_K_EXTRAPOLATE = range(5)
-KERNEL_NAMES = ["gemv_n_partial", "gemv_n_finish", "gemv_t", "fb_epilogue", "extrapolate"]
+PG_K_GEMV_N, PG_K_GEMV_N_FINISH, PG_K_GEMV_T, PG_K_EPILOGUE, PG_K_EXTRAPOLATE, PG_K_DR_STEP = range(6)
+KERNEL_NAMES = ["gemv_n_partial", "gemv_n_finish", "gemv_t", "fb_epilogue", "extrapolate", "dr_step"]
 
 
 class ProxGradError(RuntimeError):
@@ -90,6 +90,8 @@ SIGNATURES = {
     "pg_nrm2sq": [_vp, _i32, _i64, _vp, _pf64],
     "pg_nrminf": [_vp, _i32, _i64, _vp, _pf64],
     "pg_fb_epilogue": [_vp, _i32, _i64, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _pf64],
+    "pg_prox_sepquad": [_vp, _i32, _i64, _vp, _vp, _vp, _f64, _vp, _f64, _f64, _pf64],
+    "pg_dr_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _i32, _f64, _f64, _f64, _pf64],
     "pg_iter_opts_default": [C.POINTER(pg_iter_opts)],
     "pg_iter_create": [_vp, _vp, C.POINTER(pg_iter_opts), C.POINTER(_vp)],
     "pg_iter_destroy": [_vp],

@@ -4,11 +4,16 @@
 
 namespace pgew {
 
+// Launch geometry.  Pure streams: 256-thread workgroups, <= 8 per CU (grid-stride the rest).  Kernels that end in
+// the ticketed grid reduction: 1024-thread workgroups (16 waves keep ~48 KiB of loads in flight per CU), ONE per CU:
+// the single-counter fan-in of the reduction costs ~12 ns per arriving workgroup, so 256 arrivals (~3 us), not 2048.
+constexpr int EW_BS_STREAM = 256;
+constexpr int EW_BS_REDUCE = 1024;
+
 inline unsigned grid_for(int64_t n_items, int num_cu, bool reduces) {
-  int64_t blocks = (n_items + 255) / 256;
-  // <= 2048 blocks on MI355X for pure streams, grid-stride the rest; kernels that end in the ticketed grid
-  // reduction use <= 2 per CU: its single-counter fan-in costs ~12 ns per arriving workgroup
-  const int64_t cap = (int64_t)num_cu * (reduces ? 2 : 8);
+  const int bs = reduces ? EW_BS_REDUCE : EW_BS_STREAM;
+  int64_t blocks = (n_items + bs - 1) / bs;
+  const int64_t cap = (int64_t)num_cu * (reduces ? 1 : 8);
   if (blocks > cap) blocks = cap;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
@@ -20,15 +25,15 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Generic elementwise driver: F is a functor with
 //   template<int N> __device__ void operator()(int64_t i0, /*lane-private*/ Acc&) processing N consecutive
 // elements starting at i0 (N = VEC for the vector body, 1 for tails / unaligned operands).
-template <typename T, typename F, int NS, unsigned MAXMASK>
-__global__ __launch_bounds__(256) void ew_kernel(int64_t n, bool vec_ok, F f, double* __restrict__ red_partials,
+template <typename T, typename F, int NS, unsigned MAXMASK, int BS>
+__global__ __launch_bounds__(BS) void ew_kernel(int64_t n, bool vec_ok, F f, double* __restrict__ red_partials,
                                                  unsigned* __restrict__ red_counter, double* __restrict__ out) {
   constexpr int VEC = VecOf<T>::N;
   double acc[NS > 0 ? NS : 1];
 #pragma unroll
   for (int k = 0; k < (NS > 0 ? NS : 1); ++k) acc[k] = 0.0;
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t nthreads = (int64_t)gridDim.x * 256;
+  const int64_t tid = (int64_t)blockIdx.x * BS + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * BS;
   if (vec_ok) {
     const int64_t nvec = n / VEC;
     for (int64_t v = tid; v < nvec; v += nthreads) f.template apply<VEC>(v * VEC, acc);
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void ew_kernel(int64_t n, bool vec_ok, F f, do
     double ps[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) ps[k] = f.post_scale(k);
-    grid_reduce_finalize<NS, MAXMASK>(acc, red_partials, red_counter, out, ps);
+    grid_reduce_finalize<NS, MAXMASK, BS / 64>(acc, red_partials, red_counter, out, ps);
   }
 }
 
@@ -80,8 +85,9 @@ __device__ __forceinline__ void st(T* __restrict__ p, int64_t i, const Pack<T, N
 template <typename T, typename F, int NS, unsigned MAXMASK>
 pg_status launch_ew(pg_ctx* c, int64_t n, bool vec_ok, const F& f, double* out_dev) {
   if (n <= 0 && NS == 0) return PG_OK;
+  constexpr int BS = NS > 0 ? EW_BS_REDUCE : EW_BS_STREAM;
   const unsigned blocks = grid_for(n / VecOf<T>::N + 1, c->num_cu, NS > 0);
-  hipLaunchKernelGGL((ew_kernel<T, F, NS, MAXMASK>), dim3(blocks), dim3(256), 0, c->stream, n, vec_ok, f,
+  hipLaunchKernelGGL((ew_kernel<T, F, NS, MAXMASK, BS>), dim3(blocks), dim3(BS), 0, c->stream, n, vec_ok, f,
                      c->red_partials, c->red_counter, out_dev);
   PG_LAUNCH_CHECK();
   return PG_OK;

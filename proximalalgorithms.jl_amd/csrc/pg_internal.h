@@ -60,7 +60,8 @@ enum {
   PG_S_RESINF = 2,   // ||res||_inf
   PG_S_DOT = 3,      // <grad, res>
   PG_S_RESSQ = 4,    // ||res||^2
-  PG_S_MISC = 5,     // dot / nrm2sq / nrminf / prox value results
+  PG_S_MISC = 5,     // dot / nrm2sq / nrminf / prox value results (2 slots)
+  PG_S_DR = 8,       // Douglas-Rachford step: { ||res||_inf, f(y), g(z) }
   PG_S_COUNT = 16
 };
 
@@ -160,8 +161,8 @@ __device__ __forceinline__ double pg_shfl_xor(double v, int m) { return __shfl_x
 __device__ __forceinline__ float pg_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 
 // Deterministic grid-wide reduction of NS doubles per thread (bit k of MAXMASK: slot k is a max, else a
-// sum).  NW-wave (NW*64-thread) blocks, every thread of the block must call it; gridDim.x <= PG_RED_MAX_BLOCKS.  Every block publishes its partial with an
-// agent-scope release; the last block to arrive (ticket counter) acquires, combines all partials in a
+// sum).  NW-wave (NW*64-thread) blocks, every thread of the block must call it; gridDim.x <= PG_RED_MAX_BLOCKS.  Every block publishes its partial with
+// write-through agent-scope stores; the last block to arrive (ticket counter) combines all partials in a
 // fixed order and writes out[k] * post_scale[k].  The counter is reset for the next launch.  Returns true
 // (to all its threads) in the finalizing block only; out[] is then visible to that block's thread 0.
 template <int NS, unsigned MAXMASK, int NW = 4>
@@ -186,18 +187,19 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    // Publish this workgroup's partial with 8-byte agent-scope (write-through, sc1) stores, drain them, then
+    // take a ticket.  No release/acquire fences: a release here would write back every dirty line the kernel
+    // body left in this XCD's L2 (measured: several us per launch on the streaming kernels); the partials are
+    // read back below with agent-scope loads, which bypass the reader's L1.
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double a = sm[k];
       for (int w = 1; w < NW; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
-      partials[(size_t)blockIdx.x * NS + k] = a;
+      __hip_atomic_store(&partials[(size_t)blockIdx.x * NS + k], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int last = (t == gridDim.x - 1);
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    sm_last = last;
+    sm_last = (t == gridDim.x - 1);
   }
   __syncthreads();
   if (!sm_last) return false;

@@ -198,6 +198,86 @@ struct EpilogueF {
   __device__ double post_scale(int k) const { return k == 0 ? gscale : 1.0; }
 };
 
+// separable quadratic f(x) = sum_i d_i x_i^2 / 2 + q_i x_i  (ProximalOperators: Tilt(SqrNormL2(d), q) /
+// Quadratic(Diagonal(d), q)); prox_{gamma f}(x)_i = (x_i - gamma q_i) / (1 + gamma d_i)
+template <typename T>
+struct SepQuadParams {
+  const T* dv;  // nullable -> scalar ds
+  const T* qv;  // nullable -> scalar qs
+  T ds, qs;
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void sepquad_prox(const SepQuadParams<T>& f, T gamma, int64_t i, const Pack<T, N>& x,
+                                             Pack<T, N>& y, double* fval) {
+  Pack<T, N> d, q;
+  if (f.dv != nullptr) d = ld<T, N>(f.dv, i);
+  if (f.qv != nullptr) q = ld<T, N>(f.qv, i);
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const T de = f.dv != nullptr ? d.v[e] : f.ds;
+    const T qe = f.qv != nullptr ? q.v[e] : f.qs;
+    y.v[e] = (x.v[e] - gamma * qe) / (T(1) + gamma * de);
+    if (fval != nullptr) *fval += 0.5 * (double)de * (double)y.v[e] * (double)y.v[e] + (double)qe * (double)y.v[e];
+  }
+}
+
+template <typename T>
+struct ProxSepQuadF {  // y = prox_{gamma f}(x); acc[0] = f(y)
+  T* y;
+  const T* x;
+  SepQuadParams<T> f;
+  T gamma;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i), yv;
+    sepquad_prox<T, N>(f, gamma, i, xv, yv, &acc[0]);
+    st<T, N>(y, i, yv);
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+// One Douglas-Rachford iteration (douglas_rachford.jl:53-63), f separable quadratic, g by kind:
+//   y = prox_{gamma f}(x) ; r = 2y - x ; z = prox_{gamma g}(r) ; res = y - z ; x -= res
+//   acc = { max|res| , f(y) , g(z)/lam }
+// y is always written (it is the solution, :70); r / z / res only when the caller wants the full state.
+template <typename T, int GKIND>
+struct DRStepF {
+  T* x;
+  T* y;
+  T* r;    // nullable
+  T* z;    // nullable
+  T* res;  // nullable
+  SepQuadParams<T> f;
+  T gamma, p0, p1;  // g: p0 = gamma*lam (NormL1) | lo (IndBox) ; p1 = hi
+  double gscale;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i), yv, rv, zv, sv;
+    sepquad_prox<T, N>(f, gamma, i, xv, yv, &acc[1]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      rv.v[e] = T(2) * yv.v[e] - xv.v[e];
+      if constexpr (GKIND == PG_G_NORML1)
+        zv.v[e] = soft_threshold(rv.v[e], p0);
+      else if constexpr (GKIND == PG_G_INDBOX)
+        zv.v[e] = fmin(p1, fmax(p0, rv.v[e]));
+      else
+        zv.v[e] = rv.v[e];
+      sv.v[e] = yv.v[e] - zv.v[e];
+      xv.v[e] = xv.v[e] - sv.v[e];
+      acc[0] = fmax(acc[0], fabs((double)sv.v[e]));
+      if constexpr (GKIND == PG_G_NORML1) acc[2] += fabs((double)zv.v[e]);
+    }
+    st<T, N>(x, i, xv);
+    st<T, N>(y, i, yv);
+    if (r != nullptr) st<T, N>(r, i, rv);
+    if (z != nullptr) st<T, N>(z, i, zv);
+    if (res != nullptr) st<T, N>(res, i, sv);
+  }
+  __device__ double post_scale(int k) const { return k == 2 ? gscale : 1.0; }
+};
+
 template <typename T>
 pg_status epilogue_t(pg_ctx* c, int64_t n, const T* x, const T* grad, double gamma, int g_kind, double g_p0,
                      double g_p1, T* y, T* z, T* res, T* grad_copy) {
@@ -274,6 +354,38 @@ pg_status prox_box_t(pg_ctx* c, int64_t n, void* y, const void* x, double lo, do
   ProxBoxF<T> f{(T*)y, (const T*)x, (T)lo, (T)hi, (const T*)lov, (const T*)hiv};
   const bool v = aligned16(x) && aligned16(y) && (!lov || aligned16(lov)) && (!hiv || aligned16(hiv));
   return launch_ew<T, ProxBoxF<T>, 0, 0u>(c, n, v, f, c->dscal + PG_S_MISC);
+}
+
+template <typename T>
+pg_status prox_sepquad_t(pg_ctx* c, int64_t n, void* y, const void* x, const void* dv, double ds, const void* qv,
+                         double qs, double gamma) {
+  ProxSepQuadF<T> f{(T*)y, (const T*)x, {(const T*)dv, (const T*)qv, (T)ds, (T)qs}, (T)gamma};
+  const bool v = aligned16(x) && aligned16(y) && (!dv || aligned16(dv)) && (!qv || aligned16(qv));
+  return launch_ew<T, ProxSepQuadF<T>, 1, 0u>(c, n, v, f, c->dscal + PG_S_MISC);
+}
+
+template <typename T>
+pg_status dr_step_t(pg_ctx* c, int64_t n, void* x, void* y, void* r, void* z, void* res, const void* dv, double ds,
+                    const void* qv, double qs, int g_kind, double g_p0, double g_p1, double gamma) {
+  const bool v = aligned16(x) && aligned16(y) && (!r || aligned16(r)) && (!z || aligned16(z)) &&
+                 (!res || aligned16(res)) && (!dv || aligned16(dv)) && (!qv || aligned16(qv));
+  const T gm = (T)gamma;
+  SepQuadParams<T> fp{(const T*)dv, (const T*)qv, (T)ds, (T)qs};
+  pg_prof_scope prof(c, PG_K_DR_STEP);
+  if (g_kind == PG_G_NORML1) {
+    DRStepF<T, PG_G_NORML1> f{(T*)x, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)(gm * (T)g_p0), T(0), (double)(T)g_p0};
+    return launch_ew<T, decltype(f), 3, 0x1u>(c, n, v, f, c->dscal + PG_S_DR);
+  }
+  if (g_kind == PG_G_INDBOX) {
+    DRStepF<T, PG_G_INDBOX> f{(T*)x, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)g_p0, (T)g_p1, 0.0};
+    return launch_ew<T, decltype(f), 3, 0x1u>(c, n, v, f, c->dscal + PG_S_DR);
+  }
+  if (g_kind == PG_G_ZERO) {
+    DRStepF<T, PG_G_ZERO> f{(T*)x, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, T(0), T(0), 0.0};
+    return launch_ew<T, decltype(f), 3, 0x1u>(c, n, v, f, c->dscal + PG_S_DR);
+  }
+  pg_set_error("unknown g_kind %d", g_kind);
+  return PG_ERR_INVALID;
 }
 
 pg_status finish_scalar(pg_ctx* c, int slot, double* out) {
@@ -389,6 +501,31 @@ pg_status pg_fb_epilogue(pg_ctx* c, int32_t dtype, int64_t n, const void* x, con
   if (scalars_out) {
     PG_TRY(pg_read_scalars(c, PG_S_GZ, 4));
     for (int k = 0; k < 4; ++k) scalars_out[k] = c->hscal[PG_S_GZ + k];
+  }
+  return PG_OK;
+}
+
+pg_status pg_prox_sepquad(pg_ctx* c, int32_t dtype, int64_t n, void* y, const void* x, const void* d_vec, double d,
+                          const void* q_vec, double q, double gamma, double* fy_out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? prox_sepquad_t<float>(c, n, y, x, d_vec, d, q_vec, q, gamma)
+                         : prox_sepquad_t<double>(c, n, y, x, d_vec, d, q_vec, q, gamma));
+  return finish_scalar(c, PG_S_MISC, fy_out);
+}
+
+pg_status pg_dr_step(pg_ctx* c, int32_t dtype, int64_t n, void* x, void* y, void* r, void* z, void* res,
+                     const void* d_vec, double d, const void* q_vec, double q, int32_t g_kind, double g_p0,
+                     double g_p1, double gamma, double* scalars_out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? dr_step_t<float>(c, n, x, y, r, z, res, d_vec, d, q_vec, q, g_kind, g_p0, g_p1, gamma)
+                         : dr_step_t<double>(c, n, x, y, r, z, res, d_vec, d, q_vec, q, g_kind, g_p0, g_p1, gamma));
+  if (scalars_out) {
+    PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
+    for (int k = 0; k < 3; ++k) scalars_out[k] = c->hscal[PG_S_DR + k];
   }
   return PG_OK;
 }

@@ -1,0 +1,101 @@
+"""DouglasRachford splitting -- mirror of src/algorithms/douglas_rachford.jl (BASELINE config 3).
+
+Engines: ``fused`` (f = SeparableQuadratic, g in {IndBox(scalars), NormL1, Zero}: the five array statements of
+douglas_rachford.jl:58-62 run as ONE HBM sweep, pg_dr_step) and ``generic`` (any two operators with ``prox_``).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import call
+from .algorithm import IterativeAlgorithm
+from .device import HIPVector, as_hipvector
+from .operators import IndBox, NormL1, SeparableQuadratic, Zero, prox_
+
+
+class DouglasRachfordState:
+    """douglas_rachford.jl:45-51"""
+
+    def __init__(self, x):
+        self.x = x
+        self.y = x.similar()
+        self.r = x.similar()
+        self.z = x.similar()
+        self.res = x.similar()
+        self.res_inf = None
+        self.f_y = None
+        self.g_z = None
+
+
+def _fused_ok(f, g):
+    if not isinstance(f, SeparableQuadratic) or not isinstance(g, (IndBox, NormL1, Zero)):
+        return False
+    return not (isinstance(g, IndBox) and not g._scalar)
+
+
+class DouglasRachfordIteration:
+    """douglas_rachford.jl:30-41 (keyword constructor: f, g, x0, gamma) and Base.iterate :53-63.
+    ``materialize=False`` (fused engine only) skips writing r, z, res: x and y are the only n-vector writes."""
+
+    def __init__(self, *, f=None, g=None, x0, gamma, engine=None, materialize=True):
+        self.f = f if f is not None else Zero()
+        self.g = g if g is not None else Zero()
+        self.x0 = as_hipvector(x0)
+        self.gamma = self.x0.dtype.type(gamma)
+        if engine is None:
+            engine = "fused" if _fused_ok(self.f, self.g) else "generic"
+        if engine == "fused" and not _fused_ok(self.f, self.g):
+            raise TypeError("engine='fused' needs f = SeparableQuadratic and g in {IndBox(scalar bounds), NormL1, Zero}")
+        self.engine = engine
+        self.materialize = bool(materialize)
+
+    def __iter__(self):
+        R = self.x0.dtype.type
+        s = DouglasRachfordState(self.x0.copy())  # state = DouglasRachfordState(x = copy(iter.x0))  (:55)
+        if self.engine == "fused":
+            dv, d, qv, q = self.f.c_params()
+            p0, p1 = self.g.g_params()
+            sc = (C.c_double * 3)()
+            opt = (lambda v: v.vp) if self.materialize else (lambda v: None)
+            while True:
+                call("pg_dr_step", s.x.ctx.handle, s.x.pg_dtype, s.x.n, s.x.vp, s.y.vp, opt(s.r), opt(s.z), opt(s.res),
+                     dv, d, qv, q, self.g.g_kind, p0, p1, float(self.gamma), sc)
+                s.res_inf, s.f_y, s.g_z = R(sc[0]), R(sc[1]), R(sc[2])
+                yield s
+        else:
+            while True:
+                s.f_y = prox_(s.y, self.f, s.x, self.gamma)  # :58
+                s.r.axpby_(2.0, s.y, -1.0, s.x)  # :59
+                s.g_z = prox_(s.z, self.g, s.r, self.gamma)  # :60
+                s.res.axpby_(1.0, s.y, -1.0, s.z)  # :61
+                s.x.axpby_(1.0, s.x, -1.0, s.res)  # :62
+                s.res_inf = None
+                yield s
+
+
+def default_stopping_criterion(tol, iteration, state):
+    """norm(state.res, Inf) / iter.gamma <= tol   (douglas_rachford.jl:65-69)"""
+    R = state.x.dtype.type
+    res_inf = state.res_inf if state.res_inf is not None else state.res.norm_inf()
+    return R(res_inf) / R(iteration.gamma) <= R(tol)
+
+
+def default_solution(iteration, state):
+    """douglas_rachford.jl:70"""
+    return state.y
+
+
+def default_display(it, iteration, state):
+    """douglas_rachford.jl:71-72"""
+    res_inf = state.res_inf if state.res_inf is not None else state.res.norm_inf()
+    print("%5d | %.3e" % (it, res_inf / iteration.gamma))
+
+
+def DouglasRachford(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
+                    display=default_display, **kwargs):
+    """douglas_rachford.jl:101-119"""
+    if stop is None:
+        stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
+    return IterativeAlgorithm(DouglasRachfordIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose,
+                              freq=freq, display=display, **kwargs)

@@ -146,6 +146,32 @@ class IndBox:
         return x.dtype.type(0) if ok else x.dtype.type(np.inf)
 
 
+class SeparableQuadratic:
+    """f(x) = sum_i d_i x_i^2 / 2 + q_i x_i with d >= 0 -- the smooth term of a box-constrained QP with diagonal
+    Hessian (ProximalOperators: ``Tilt(SqrNormL2(d), q)`` == ``Quadratic(Diagonal(d), q)``).  ``d``/``q`` are scalars
+    or vectors.  prox_{gamma f}(x) = (x - gamma q) ./ (1 + gamma d); value_and_gradient = (f(x), d .* x + q)."""
+
+    def __init__(self, d, q, ctx=None):
+        self._d_scalar, self._q_scalar = np.isscalar(d), np.isscalar(q)
+        self.d = float(d) if self._d_scalar else as_hipvector(d, ctx)
+        self.q = float(q) if self._q_scalar else as_hipvector(q, ctx)
+
+    def c_params(self):
+        """(d_vec, d, q_vec, q) as the C ABI takes them"""
+        return (None if self._d_scalar else self.d.vp, self.d if self._d_scalar else 0.0,
+                None if self._q_scalar else self.q.vp, self.q if self._q_scalar else 0.0)
+
+    def prox_(self, y, x, gamma):
+        dv, d, qv, q = self.c_params()
+        out = C.c_double()
+        call("pg_prox_sepquad", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, dv, d, qv, q, float(gamma), C.byref(out))
+        return x.dtype.type(out.value)
+
+    def __call__(self, x):
+        y = x.similar()
+        return self.prox_(y, x, 0.0)  # prox with gamma = 0 is the identity and returns f(x)
+
+
 class Zero:
     """ProximalCore.Zero: f(x) = 0; value_and_gradient -> (0, zero(x)) (src/ProximalAlgorithms.jl:38-40);
     prox = identity."""

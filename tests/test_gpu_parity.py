@@ -581,3 +581,56 @@ def test_headline_size_properties(pa):
     # two evaluations are bit-identical (deterministic reductions at full size)
     fx2, grad2 = f.value_and_gradient(V(x1))
     assert fx2 == fx and np.array_equal(grad2.numpy(), grad.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# DouglasRachford (SURVEY 8(f) row 1 / BASELINE config 3): box-constrained QP with diagonal Hessian
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [1, 5, 1000, 100003])
+def test_sepquad_prox(pa, dtype, n):
+    rng = np.random.default_rng(n)
+    d, q, x = np.abs(rng.standard_normal(n)).astype(dtype), rng.standard_normal(n).astype(dtype), rng.standard_normal(n).astype(dtype)
+    for dd, qq in ((d, q), (dtype(0.7), q), (d, dtype(-0.3)), (dtype(2.0), dtype(0.1))):
+        f, fo = pa.SeparableQuadratic(dd, qq), o.SeparableQuadratic(dd, qq)
+        y, fy = pa.prox(f, pa.HIPVector.from_numpy(x), dtype(0.4))
+        yo, fyo = fo.prox(x, dtype(0.4))
+        np.testing.assert_allclose(y.numpy(), yo, rtol=4 * np.finfo(dtype).eps, atol=4 * np.finfo(dtype).eps)
+        assert abs(float(fy) - float(fyo)) <= 1e-5 * max(1.0, abs(float(fyo)))
+        assert abs(float(f(pa.HIPVector.from_numpy(x))) - float(fo(x))) <= 1e-5 * max(1.0, abs(float(fo(x))))
+
+
+@pytest.mark.parametrize("engine,materialize", [("fused", True), ("fused", False), ("generic", True)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("gname", ["box", "l1"])
+def test_douglas_rachford_box_qp(pa, dtype, engine, materialize, gname):
+    """DR on  min 1/2 x'Dx + q'x  s.t. lo <= x <= hi  (and with an L1 term): iterate sequence vs the oracle,
+    fixed point / KKT of the answer."""
+    n = 20011
+    rng = np.random.default_rng(1)
+    d = (0.1 + np.abs(rng.standard_normal(n))).astype(dtype)
+    q = rng.standard_normal(n).astype(dtype)
+    lo, hi = dtype(-0.5), dtype(0.25)
+    gamma = dtype(1.3)
+    x0 = rng.standard_normal(n).astype(dtype)
+    x0_backup = x0.copy()
+    g, go = (pa.IndBox(lo, hi), o.IndBox(lo, hi)) if gname == "box" else (pa.NormL1(dtype(0.2)), o.NormL1(dtype(0.2)))
+    it_g = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=g, x0=x0, gamma=gamma, engine=engine,
+                                       materialize=materialize)
+    it_o = o.DouglasRachfordIteration(f=o.SeparableQuadratic(d, q), g=go, x0=x0, gamma=gamma)
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    for k, (sg, so) in enumerate(itertools.islice(zip(it_g, it_o), 40)):
+        assert np.max(np.abs(sg.y.numpy() - so.y)) <= tol * max(1.0, np.max(np.abs(so.y))), k
+        assert np.max(np.abs(sg.x.numpy() - so.x)) <= tol * max(1.0, np.max(np.abs(so.x))), k
+        ri = sg.res_inf if sg.res_inf is not None else sg.res.norm_inf()
+        assert abs(float(ri) - float(np.max(np.abs(so.res)))) <= tol * max(1.0, float(np.max(np.abs(so.res))))
+        if materialize:
+            assert np.max(np.abs(sg.z.numpy() - so.z)) <= tol * max(1.0, np.max(np.abs(so.z)))
+    y, kg = pa.DouglasRachford(tol=1e-5, engine=engine)(x0=x0, f=pa.SeparableQuadratic(d, q), g=g, gamma=gamma)
+    yo, ko = o.douglas_rachford(tol=1e-5, x0=x0, f=o.SeparableQuadratic(d, q), g=go, gamma=gamma)
+    assert abs(kg - ko) <= 2 and np.max(np.abs(y - yo)) <= 1e-4
+    assert np.array_equal(x0, x0_backup)
+    if gname == "box":  # closed form: clamp(-q / d, lo, hi)
+        assert np.max(np.abs(y - np.clip(-q / d, lo, hi))) <= 1e-4

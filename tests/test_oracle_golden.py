@@ -283,3 +283,28 @@ def test_synthetic_generator_reproducible_and_shardable():
     assert np.array_equal(np.vstack([top, bot]), A)
     big = o.synthetic_matrix(512, 512, seed=0)
     assert abs(big.std() * np.sqrt(512) - 1) < 0.01 and abs(big.mean()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_douglas_rachford_pin(dtype):
+    """test/problems/test_lasso_small.jl:205-214: DouglasRachford(gamma = 10/||A||^2, tol = 1e-4) with
+    f = LeastSquares (prox), g = NormL1 reaches x_star in fewer than 30 iterations."""
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    y, it = o.douglas_rachford(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam),
+                               gamma=dtype(10) / Lf)
+    assert y.dtype == dtype
+    assert np.max(np.abs(y - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+    assert it < 30
+    assert np.all(x0 == 0)
+
+
+def test_separable_quadratic_prox_is_the_minimiser():
+    rng = np.random.default_rng(0)
+    d, q, x = np.abs(rng.standard_normal(7)), rng.standard_normal(7), rng.standard_normal(7)
+    f = o.SeparableQuadratic(d, q)
+    y, fy = f.prox(x, 0.7)
+    obj = lambda z: f(z) + np.sum((z - x) ** 2) / (2 * 0.7)
+    for _ in range(50):
+        assert obj(y) <= obj(y + 1e-3 * rng.standard_normal(7)) + 1e-12
+    assert fy == f(y)
