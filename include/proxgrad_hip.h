@@ -182,6 +182,15 @@ pg_status pg_fb_epilogue(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, c
                          int32_t g_kind, double g_p0, double g_p1, void* y, void* z, void* res,
                          double* scalars_out /* host, 4 doubles; NULL = leave on device */);
 
+/* ------------------------------------------------------------------ smooth losses (config 4) ---- */
+/* The smooth term f of PANOC's  minimize f(A x) + g(x)  (src/algorithms/panoc.jl:39-52), evaluated on an
+ * m-vector u = A x:  value_and_gradient(f, u) -> (f(u), grad f(u))   (panoc.jl:90,182,216,240 ; fb_tools.jl:44).
+ *   PG_LOSS_SQDIST   f(u) = ||u - b||^2 / 2              benchmark/benchmarks.jl:19-28 (SquaredDistance)
+ *   PG_LOSS_LOGISTIC f(u) = sum(log.(1 .+ exp.(-(u .- b))))  test/problems/test_sparse_logistic_small.jl:20-26 */
+enum { PG_LOSS_SQDIST = 0, PG_LOSS_LOGISTIC = 1 };
+pg_status pg_loss_value_and_gradient(pg_ctx* ctx, int32_t dtype, int32_t loss, int64_t m, const void* u,
+                                     const void* b, void* grad, double* f_out);
+
 /* ------------------------------------------------------------------ Douglas-Rachford (config 3) --- */
 /* Separable quadratic f(x) = sum_i d_i x_i^2 / 2 + q_i x_i  (ProximalOperators Tilt(SqrNormL2(d), q), i.e.
  * Quadratic(Diagonal(d), q)): prox!(y, f, x, gamma) -> f(y), y_i = (x_i - gamma q_i) / (1 + gamma d_i).

@@ -691,3 +691,228 @@ def synthetic_lasso(m, n, seed=0, dtype=np.float32, row_offset=0, m_global=None,
     noise = noise_all[row_offset:row_offset + m]
     b = (A @ x_true + dtype(0.01) * noise).astype(dtype)
     return A, b, x_true
+
+
+# --------------------------------------------------------------------------------------
+# "next" rows: PANOC                            src/algorithms/panoc.jl:39-255
+# (BASELINE config 4; smooth terms as the reference's tests define them)
+# --------------------------------------------------------------------------------------
+
+
+class SquaredDistance:
+    """f(u) = ||u - b||^2 / 2  -- benchmark/benchmarks.jl:19-28 (SquaredDistance) and the closure
+    `x -> norm(x - b)^2 / 2` of test/problems/test_lasso_small.jl:32-33.  Generalized quadratic."""
+
+    is_generalized_quadratic = True
+
+    def __init__(self, b):
+        self.b = np.asarray(b)
+
+    def value_and_gradient(self, u):
+        R = _R(u)
+        diff = u - self.b
+        return R(_norm(diff) ** 2 / R(2)), diff
+
+    def __call__(self, u):
+        return self.value_and_gradient(u)[0]
+
+
+class LogisticLoss:
+    """f(u) = sum(log.(1 .+ exp.(-(u .- b))))  -- test/problems/test_sparse_logistic_small.jl:20-26
+    (labels are assumed all one); gradient -1 ./ (1 .+ exp.(u .- b))."""
+
+    is_generalized_quadratic = False
+
+    def __init__(self, b):
+        self.b = np.asarray(b)
+
+    def value_and_gradient(self, u):
+        R = _R(u)
+        t = u - self.b
+        val = R(np.sum(np.log(R(1) + np.exp(-t)), dtype=u.dtype))
+        grad = (-R(1) / (R(1) + np.exp(t))).astype(u.dtype)
+        return val, grad
+
+    def __call__(self, u):
+        return self.value_and_gradient(u)[0]
+
+
+class Composed:
+    """x -> f(A x): value_and_gradient = (f(Ax), A' grad f(Ax)); the `fA_autodiff` closures of the tests."""
+
+    def __init__(self, f, A):
+        self.f, self.A = f, np.asarray(A)
+
+    def value_and_gradient(self, x):
+        v, gu = self.f.value_and_gradient(self.A @ x)
+        return v, self.A.T @ gu
+
+    def __call__(self, x):
+        return self.f(self.A @ x)
+
+
+def lower_bound_smoothness_constant_A(f, A, x, grad_f_Ax):
+    """fb_tools.jl:7-12 with a general linear map A:
+    xeps = x .+ 1 ; grad f at A*xeps ; norm(A' * (grad_eps - grad)) / sqrt(length(x))"""
+    R = _R(x)
+    xeps = x + R(1)
+    _, grad_eps = value_and_gradient(f, A @ xeps)
+    return R(_norm(A.T @ (grad_eps - grad_f_Ax)) / R(math.sqrt(x.size)))
+
+
+def backtrack_stepsize_A(gamma, f, A, g, x, f_Ax, At_grad_f_Ax, y, z, g_z, res, Az, grad_f_Az, *, alpha=1.0,
+                         minimum_gamma=1e-7, reduce_gamma=0.5):
+    """fb_tools.jl:24-63 with a linear map A (Az = A*z is recomputed, :43,:52)."""
+    R = _R(x)
+    gamma, alpha, minimum_gamma, reduce_gamma = R(gamma), R(alpha), R(minimum_gamma), R(reduce_gamma)
+    eps = R(np.finfo(R).eps)
+    f_Az_upp = f_model(f_Ax, At_grad_f_Ax, res, alpha / gamma)
+    Az[...] = A @ z
+    f_Az, grad_tmp = value_and_gradient(f, Az)
+    tol = R(10) * eps * (R(1) + abs(f_Az))
+    while f_Az > f_Az_upp + tol and gamma >= minimum_gamma:
+        gamma = R(gamma * reduce_gamma)
+        y[...] = x - gamma * At_grad_f_Ax
+        z_new, g_z = prox(g, y, gamma)
+        z[...] = z_new
+        res[...] = x - z
+        f_Az_upp = f_model(f_Ax, At_grad_f_Ax, res, alpha / gamma)
+        Az[...] = A @ z
+        f_Az, grad_tmp = value_and_gradient(f, Az)
+        tol = R(10) * eps * (R(1) + abs(f_Az))
+    if grad_f_Az is not None:
+        grad_f_Az[...] = grad_tmp
+    return gamma, g_z, f_Az, f_Az_upp
+
+
+class PANOCIteration:
+    """panoc.jl:39-52 (options), :87-112 (init), :138-255 (step).  directions: ("lbfgs", M) or None
+    (NoAcceleration)."""
+
+    def __init__(self, *, f=None, A, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
+                 minimum_gamma=1e-7, max_backtracks=20, directions=("lbfgs", 5)):
+        R = _R(x0)
+        self.f = f if f is not None else Zero()
+        self.A = np.asarray(A)
+        self.g = g if g is not None else Zero()
+        self.x0 = x0
+        self.alpha, self.beta = R(alpha), R(beta)
+        self.Lf = Lf
+        self.gamma = gamma if gamma is not None else (None if Lf is None else self.alpha / R(Lf))  # :47
+        self.adaptive = (self.gamma is None) if adaptive is None else adaptive  # :48
+        self.minimum_gamma = R(minimum_gamma)
+        self.max_backtracks = max_backtracks
+        self.directions = directions
+
+    def _f_model(self, s):  # :84-85
+        return f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / s.gamma)
+
+    def init(self):
+        R = _R(self.x0)
+        A = self.A
+        x = self.x0.copy()  # :88
+        Ax = A @ x  # :89
+        f_Ax, grad_f_Ax = value_and_gradient(self.f, Ax)  # :90
+        if self.gamma is None:  # :91-94
+            gamma = R(self.alpha / lower_bound_smoothness_constant_A(self.f, A, x, grad_f_Ax))
+        else:
+            gamma = R(self.gamma)
+        At_grad = A.T @ grad_f_Ax  # :95
+        y = x - gamma * At_grad  # :96
+        z, g_z = prox(self.g, y, gamma)  # :97
+        H = LBFGSOperator(self.directions[1], x) if self.directions else None  # :109
+        e = lambda v: np.empty_like(v)
+        return _State(x=x, Ax=Ax, f_Ax=R(f_Ax), grad_f_Ax=np.array(grad_f_Ax, copy=True), At_grad_f_Ax=At_grad, gamma=gamma,
+                      y=y, z=z, g_z=g_z, res=x - z, H=H, tau=R(0), x_prev=e(x), res_prev=e(x), d=e(x), Ad=e(Ax),
+                      x_d=e(x), Ax_d=e(Ax), f_Ax_d=R(0), grad_f_Ax_d=e(Ax), At_grad_f_Ax_d=e(x), z_curr=e(x), Az=e(Ax),
+                      grad_f_Az=e(Ax), At_grad_f_Az=e(x))
+
+    def step(self, s):
+        R = _R(s.x)
+        A = self.A
+        inf = R(np.inf)
+        f_Az, a, b, c = inf, inf, inf, inf  # :139
+        if self.adaptive:  # :141-161
+            gamma_prev = s.gamma
+            s.gamma, s.g_z, f_Az, f_Az_upp = backtrack_stepsize_A(
+                s.gamma, self.f, A, self.g, s.x, s.f_Ax, s.At_grad_f_Ax, s.y, s.z, s.g_z, s.res, s.Az, s.grad_f_Az,
+                alpha=self.alpha, minimum_gamma=self.minimum_gamma)
+            if s.gamma != gamma_prev and s.H is not None:
+                s.H.reset()
+        else:
+            f_Az_upp = self._f_model(s)  # :163
+        FBE_x = R(f_Az_upp + s.g_z)  # :167
+        if s.H is not None:  # :170 set_next_direction! :114-117
+            s.H.mul(s.d, s.res)
+            s.d *= R(-1)
+        else:
+            s.d[...] = -s.res
+        s.x_prev[...] = s.x  # :173-174
+        s.res_prev[...] = s.res
+        s.tau = R(1)  # :177
+        s.Ad[...] = A @ s.d  # :178
+        s.x_d[...] = s.x + s.d  # :180
+        s.Ax_d[...] = s.Ax + s.Ad
+        s.f_Ax_d, g_d = value_and_gradient(self.f, s.Ax_d)  # :182
+        s.grad_f_Ax_d[...] = g_d
+        s.At_grad_f_Ax_d[...] = A.T @ s.grad_f_Ax_d  # :184
+        s.x[...] = s.x_d  # :186-191
+        s.Ax[...] = s.Ax_d
+        s.grad_f_Ax[...] = s.grad_f_Ax_d
+        s.At_grad_f_Ax[...] = s.At_grad_f_Ax_d
+        s.z_curr[...] = s.z
+        s.f_Ax = s.f_Ax_d
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :193
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))  # :194
+        threshold = R(FBE_x - sigma * _norm(s.res) ** 2 + tol)  # :195
+        s.y[...] = s.x - s.gamma * s.At_grad_f_Ax  # :197
+        z_new, s.g_z = prox(self.g, s.y, s.gamma)  # :198
+        s.z[...] = z_new
+        s.res[...] = s.x - s.z  # :199
+        FBE_x_new = R(self._f_model(s) + s.g_z)  # :200
+        quad = getattr(self.f, "is_generalized_quadratic", False)
+        for k in range(1, self.max_backtracks + 1):  # :202-250
+            if FBE_x_new <= threshold:
+                break
+            if np.isinf(f_Az):  # :207-209
+                s.Az[...] = A @ s.z_curr
+            s.tau = R(0) if k >= self.max_backtracks else R(s.tau / R(2))  # :211
+            s.x[...] = s.tau * s.x_d + (R(1) - s.tau) * s.z_curr  # :212
+            s.Ax[...] = s.tau * s.Ax_d + (R(1) - s.tau) * s.Az  # :213
+            if quad:  # :215-237
+                if np.isinf(f_Az):
+                    f_Az, g_Az = value_and_gradient(self.f, s.Az)
+                    s.grad_f_Az[...] = g_Az
+                if np.isinf(c):
+                    s.At_grad_f_Az[...] = A.T @ s.grad_f_Az
+                    c = f_Az
+                    b = R(_dot(s.Ax_d, s.grad_f_Az) - _dot(s.Az, s.grad_f_Az))
+                    a = R(s.f_Ax_d - b - c)
+                s.f_Ax = R(a * s.tau**2 + b * s.tau + c)
+                s.grad_f_Ax[...] = s.tau * s.grad_f_Ax_d + (R(1) - s.tau) * s.grad_f_Az
+                s.At_grad_f_Ax[...] = s.tau * s.At_grad_f_Ax_d + (R(1) - s.tau) * s.At_grad_f_Az
+            else:  # :238-244
+                s.f_Ax, g_x = value_and_gradient(self.f, s.Ax)
+                s.grad_f_Ax[...] = g_x
+                s.At_grad_f_Ax[...] = A.T @ s.grad_f_Ax
+            s.y[...] = s.x - s.gamma * s.At_grad_f_Ax  # :246
+            z_new, s.g_z = prox(self.g, s.y, s.gamma)  # :247
+            s.z[...] = z_new
+            s.res[...] = s.x - s.z  # :248
+            FBE_x_new = R(self._f_model(s) + s.g_z)  # :249
+        if s.H is not None:  # :252 update_direction_state! :122-126
+            s.x_prev[...] = s.x - s.x_prev
+            s.res_prev[...] = s.res - s.res_prev
+            s.H.update(s.x_prev, s.res_prev)
+        return s
+
+    def __iter__(self):
+        s = self.init()
+        yield s
+        while True:
+            yield self.step(s)
+
+
+def panoc(*, maxit=1_000, tol=1e-8, **kw):
+    """PANOC(; maxit, tol)(; kwargs...)  panoc.jl:297-315; stop :256-257; solution :258 (state.z)."""
+    return run(PANOCIteration(**kw), maxit=maxit, tol=tol)

@@ -17,13 +17,15 @@ from .forward_backward import (ForwardBackward, ForwardBackwardIteration, Forwar
 from .lbfgs import LBFGS, LBFGSOperator
 from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, FixedNesterovSequence,
                        SimpleNesterovSequence, next_)
-from .operators import (IndBox, LeastSquares, NormL1, SeparableQuadratic, Zero, gradient_, prox, prox_,
-                        value_and_gradient)
+from .operators import (Composed, IndBox, LeastSquares, LogisticLoss, NormL1, SeparableQuadratic, SquaredDistance,
+                        Zero, gradient_, prox, prox_, value_and_gradient)
+from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
 from .sharding import ScaleComm, TorchDistributedComm, allreduce_sum_, shard_rows
 
 __all__ = [
     "ProxGradError", "IterativeAlgorithm", "DouglasRachford", "DouglasRachfordIteration", "DouglasRachfordState",
-    "SeparableQuadratic", "Context", "HIPMatrix", "HIPVector", "as_hipvector", "get_context",
+    "SeparableQuadratic", "PANOC", "PANOCIteration", "PANOCState", "NoAcceleration", "Composed", "LogisticLoss",
+    "SquaredDistance", "Context", "HIPMatrix", "HIPVector", "as_hipvector", "get_context",
     "FastForwardBackward", "FastForwardBackwardIteration", "FastForwardBackwardState", "FastProximalGradient",
     "FastProximalGradientIteration", "backtrack_stepsize_", "f_model", "lower_bound_smoothness_constant",
     "ForwardBackward", "ForwardBackwardIteration", "ForwardBackwardState", "ProximalGradient",

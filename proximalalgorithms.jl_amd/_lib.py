@@ -90,6 +90,7 @@ SIGNATURES = {
     "pg_nrm2sq": [_vp, _i32, _i64, _vp, _pf64],
     "pg_nrminf": [_vp, _i32, _i64, _vp, _pf64],
     "pg_fb_epilogue": [_vp, _i32, _i64, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _pf64],
+    "pg_loss_value_and_gradient": [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _pf64],
     "pg_prox_sepquad": [_vp, _i32, _i64, _vp, _vp, _vp, _f64, _vp, _f64, _f64, _pf64],
     "pg_dr_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _i32, _f64, _f64, _f64, _pf64],
     "pg_iter_opts_default": [C.POINTER(pg_iter_opts)],

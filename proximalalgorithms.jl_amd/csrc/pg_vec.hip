@@ -278,6 +278,34 @@ struct DRStepF {
   __device__ double post_scale(int k) const { return k == 2 ? gscale : 1.0; }
 };
 
+// smooth losses on m-vectors (the `f` of PANOC's f(Ax)); acc[0] = f(u), grad written elementwise
+//   LOSS 0: squared distance  f(u) = ||u - b||^2 / 2 , grad = u - b     (benchmark/benchmarks.jl:19-28)
+//   LOSS 1: logistic          f(u) = sum log(1 + exp(-(u - b))), grad = -1 / (1 + exp(u - b))
+//                             (test/problems/test_sparse_logistic_small.jl:20-26, labels all one)
+template <typename T, int LOSS>
+struct LossF {
+  T* grad;
+  const T* u;
+  const T* b;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> uv = ld<T, N>(u, i), bv = ld<T, N>(b, i), g;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const T t = uv.v[e] - bv.v[e];
+      if constexpr (LOSS == 0) {
+        g.v[e] = t;
+        acc[0] += (double)t * (double)t;
+      } else {
+        acc[0] += (double)log(T(1) + exp(-t));
+        g.v[e] = -T(1) / (T(1) + exp(t));
+      }
+    }
+    st<T, N>(grad, i, g);
+  }
+  __device__ double post_scale(int) const { return LOSS == 0 ? 0.5 : 1.0; }
+};
+
 template <typename T>
 pg_status epilogue_t(pg_ctx* c, int64_t n, const T* x, const T* grad, double gamma, int g_kind, double g_p0,
                      double g_p1, T* y, T* z, T* res, T* grad_copy) {
@@ -386,6 +414,17 @@ pg_status dr_step_t(pg_ctx* c, int64_t n, void* x, void* y, void* r, void* z, vo
   }
   pg_set_error("unknown g_kind %d", g_kind);
   return PG_ERR_INVALID;
+}
+
+template <typename T>
+pg_status loss_t(pg_ctx* c, int loss, int64_t m, const void* u, const void* b, void* grad) {
+  const bool v = aligned16(u) && aligned16(b) && aligned16(grad);
+  if (loss == 0) {
+    LossF<T, 0> f{(T*)grad, (const T*)u, (const T*)b};
+    return launch_ew<T, decltype(f), 1, 0u>(c, m, v, f, c->dscal + PG_S_MISC);
+  }
+  LossF<T, 1> f{(T*)grad, (const T*)u, (const T*)b};
+  return launch_ew<T, decltype(f), 1, 0u>(c, m, v, f, c->dscal + PG_S_MISC);
 }
 
 pg_status finish_scalar(pg_ctx* c, int slot, double* out) {
@@ -528,6 +567,16 @@ pg_status pg_dr_step(pg_ctx* c, int32_t dtype, int64_t n, void* x, void* y, void
     for (int k = 0; k < 3; ++k) scalars_out[k] = c->hscal[PG_S_DR + k];
   }
   return PG_OK;
+}
+
+pg_status pg_loss_value_and_gradient(pg_ctx* c, int32_t dtype, int32_t loss, int64_t m, const void* u, const void* b,
+                                     void* grad, double* f_out) {
+  PG_VEC_ARGS_OK(c, m);
+  PG_REQUIRE(m == 0 || (u != nullptr && b != nullptr && grad != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_REQUIRE(loss == PG_LOSS_SQDIST || loss == PG_LOSS_LOGISTIC, "unknown loss");
+  PG_TRY(dtype == PG_F32 ? loss_t<float>(c, loss, m, u, b, grad) : loss_t<double>(c, loss, m, u, b, grad));
+  return finish_scalar(c, PG_S_MISC, f_out);
 }
 
 }  // extern "C"

@@ -172,6 +172,60 @@ class SeparableQuadratic:
         return self.prox_(y, x, 0.0)  # prox with gamma = 0 is the identity and returns f(x)
 
 
+class _Loss:
+    """Smooth loss on an m-vector u (= A x): ``value_and_gradient(u) -> (f(u), grad)``."""
+
+    loss_id = None
+    is_generalized_quadratic = False
+
+    def __init__(self, b, ctx=None):
+        self.b = as_hipvector(b, ctx)
+
+    def value_and_gradient(self, u, out=None):
+        grad = out if out is not None else u.similar()
+        f = C.c_double()
+        call("pg_loss_value_and_gradient", u.ctx.handle, u.pg_dtype, self.loss_id, u.n, u.vp, self.b.vp, grad.vp,
+             C.byref(f))
+        return u.dtype.type(f.value), grad
+
+    def __call__(self, u):
+        return self.value_and_gradient(u)[0]
+
+
+class SquaredDistance(_Loss):
+    """f(u) = ||u - b||^2 / 2 (benchmark/benchmarks.jl:19-28; `x -> norm(x - b)^2 / 2` of
+    test_lasso_small.jl:32-33).  Generalized quadratic: PANOC uses the interpolation branch (panoc.jl:215-237)."""
+
+    loss_id = 0
+    is_generalized_quadratic = True
+
+
+class LogisticLoss(_Loss):
+    """f(u) = sum(log.(1 .+ exp.(-(u .- b)))), labels all one (test_sparse_logistic_small.jl:20-26)."""
+
+    loss_id = 1
+
+
+class Composed:
+    """x -> f(A x) as one smooth term (the `fA_autodiff` closures of the reference's tests):
+    value_and_gradient(x) = (f(Ax), A' grad f(Ax)) -- two GEMV passes over the device matrix."""
+
+    def __init__(self, f, A, ctx=None):
+        self.f = f
+        self.A = A if isinstance(A, HIPMatrix) else HIPMatrix.from_numpy(A, ctx)
+        self.ctx = self.A.ctx
+        self._Ax = HIPVector.empty(self.A.m, self.A.dtype, self.ctx)
+        self._gu = HIPVector.empty(self.A.m, self.A.dtype, self.ctx)
+
+    def value_and_gradient(self, x, out=None):
+        self.A.mul(x, self._Ax)
+        v, gu = self.f.value_and_gradient(self._Ax, out=self._gu)
+        return v, self.A.mul_adjoint(gu, out if out is not None else None)
+
+    def __call__(self, x):
+        return self.f(self.A.mul(x, self._Ax))
+
+
 class Zero:
     """ProximalCore.Zero: f(x) = 0; value_and_gradient -> (0, zero(x)) (src/ProximalAlgorithms.jl:38-40);
     prox = identity."""

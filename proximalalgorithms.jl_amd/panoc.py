@@ -1,0 +1,251 @@
+"""PANOC -- mirror of src/algorithms/panoc.jl (BASELINE config 4): minimize f(A x) + g(x).
+
+The iteration body is the reference's, statement by statement, on device vectors; every array statement is a HIP
+kernel of libproxgrad_hip (the two GEMV orientations for `mul!` with A and A', the loss kernels, prox, AXPYs,
+reductions, and the device L-BFGS two-loop recursion).  At config-4 size (16384 x 10^6) an iteration is 2-4 passes
+over a 61 GiB matrix, so host-side sequencing of the ~40 small kernels is noise.
+"""
+import warnings
+
+import numpy as np
+
+from .algorithm import IterativeAlgorithm
+from .device import HIPMatrix, HIPVector, as_hipvector
+from .lbfgs import LBFGS, LBFGSOperator
+from .operators import Zero, prox_, value_and_gradient
+
+
+class NoAcceleration:
+    """src/accel/noaccel.jl:1-5"""
+
+    def initialize(self, x):
+        return None
+
+
+class _Identity:
+    """LinearAlgebra.I as the default `A` (panoc.jl:41)."""
+
+    def mul(self, x, out=None):
+        if out is None:
+            return x.copy()
+        return out.copy_from(x)
+
+    mul_adjoint = mul
+
+
+def _f_model(f_x, grad, res, L):
+    """fb_tools.jl:3-5"""
+    R = res.dtype.type
+    return R(R(f_x) - grad.dot(res) + (R(L) / R(2)) * res.norm() ** 2)
+
+
+class PANOCState:
+    """panoc.jl:56-82"""
+
+    pass
+
+
+class PANOCIteration:
+    """panoc.jl:39-52 (keyword constructor), Base.iterate :87-112 / :138-255."""
+
+    def __init__(self, *, f=None, A=None, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
+                 minimum_gamma=1e-7, max_backtracks=20, directions=None):
+        self.f = f if f is not None else Zero()
+        if A is None:
+            A = _Identity()
+        elif not isinstance(A, (HIPMatrix, _Identity)):
+            A = HIPMatrix.from_numpy(A)
+        self.A = A
+        self.g = g if g is not None else Zero()
+        self.x0 = as_hipvector(x0, getattr(A, "ctx", None))
+        R = self.x0.dtype.type
+        self.alpha, self.beta = R(alpha), R(beta)
+        self.Lf = Lf
+        self.gamma = gamma if gamma is not None else (None if Lf is None else self.alpha / R(Lf))  # :47
+        self.adaptive = (self.gamma is None) if adaptive is None else bool(adaptive)  # :48
+        self.minimum_gamma = R(minimum_gamma)
+        self.max_backtracks = int(max_backtracks)
+        self.directions = directions if directions is not None else LBFGS(5)  # :51
+        self.counters = {"A_passes": 0}
+
+    # mul! with A / A' (counted: each is one full read of A)
+    def _mul(self, out, x):
+        self.counters["A_passes"] += 1
+        return self.A.mul(x, out)
+
+    def _mul_adj(self, out, r):
+        self.counters["A_passes"] += 1
+        return self.A.mul_adjoint(r, out)
+
+    def _model(self, s):  # :84-85
+        return _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / s.gamma)
+
+    def _lower_bound_smoothness_constant(self, x, grad_f_Ax):
+        """fb_tools.jl:7-12"""
+        R = x.dtype.type
+        xeps = x.similar().add_scalar_(x, 1.0)
+        Axeps = self._mul(None, xeps)
+        _, grad_eps = value_and_gradient(self.f, Axeps)
+        diff = grad_eps.axpby_(1.0, grad_eps, -1.0, grad_f_Ax)
+        return R(self._mul_adj(None, diff).norm() / R(np.sqrt(x.n)))
+
+    def _backtrack_stepsize(self, s):
+        """backtrack_stepsize!  fb_tools.jl:24-63 with the linear map A and alpha = iter.alpha"""
+        R = s.x.dtype.type
+        eps = R(np.finfo(R).eps)
+        gamma, reduce_gamma = R(s.gamma), R(0.5)
+        f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)  # :42
+        self._mul(s.Az, s.z)  # :43
+        f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)  # :44 (grad kept: :56-58)
+        tol = R(10) * eps * (R(1) + abs(f_Az))
+        while f_Az > f_Az_upp + tol and gamma >= self.minimum_gamma:  # :46
+            gamma = R(gamma * reduce_gamma)
+            s.y.axpby_(1.0, s.x, -gamma, s.At_grad_f_Ax)
+            s.g_z = prox_(s.z, self.g, s.y, gamma)
+            s.res.axpby_(1.0, s.x, -1.0, s.z)
+            f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)
+            self._mul(s.Az, s.z)
+            f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)
+            tol = R(10) * eps * (R(1) + abs(f_Az))
+        if gamma < self.minimum_gamma:
+            warnings.warn(f"stepsize `gamma` became too small ({gamma})")
+        return gamma, f_Az, f_Az_upp
+
+    def _init(self):
+        R = self.x0.dtype.type
+        s = PANOCState()
+        s.x = self.x0.copy()  # :88
+        s.Ax = self._mul(None, s.x)  # :89
+        s.grad_f_Ax = s.Ax.similar()
+        s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :90
+        if self.gamma is None:  # :91-94
+            s.gamma = R(self.alpha / self._lower_bound_smoothness_constant(s.x, s.grad_f_Ax))
+        else:
+            s.gamma = R(self.gamma)
+        s.At_grad_f_Ax = self._mul_adj(None, s.grad_f_Ax)  # :95
+        s.y = s.x.similar().axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :96
+        s.z = s.x.similar()
+        s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :97
+        s.res = s.x.similar().axpby_(1.0, s.x, -1.0, s.z)
+        s.H = self.directions.initialize(s.x)  # :109
+        s.tau = R(0)
+        for name in ("x_prev", "res_prev", "d", "x_d", "At_grad_f_Ax_d", "z_curr", "At_grad_f_Az"):
+            setattr(s, name, s.x.similar())
+        for name in ("Ad", "Ax_d", "grad_f_Ax_d", "Az", "grad_f_Az"):
+            setattr(s, name, s.Ax.similar())
+        s.f_Ax_d = R(0)
+        s.res_inf = None
+        return s
+
+    def _step(self, s):
+        R = s.x.dtype.type
+        inf = R(np.inf)
+        f_Az, a, b, c = inf, inf, inf, inf  # :139
+        if self.adaptive:  # :141-161
+            gamma_prev = s.gamma
+            s.gamma, f_Az, f_Az_upp = self._backtrack_stepsize(s)
+            if s.gamma != gamma_prev and s.H is not None:
+                s.H.reset_()
+        else:
+            f_Az_upp = self._model(s)  # :163
+        FBE_x = R(f_Az_upp + s.g_z)  # :167
+        if s.H is not None:  # :170 (set_next_direction! :114-117)
+            s.H.mul_(s.d, s.res)
+            s.d.axpby_(-1.0, s.d)
+        else:
+            s.d.axpby_(-1.0, s.res)
+        s.x_prev.copy_from(s.x)  # :173-174
+        s.res_prev.copy_from(s.res)
+        s.tau = R(1)  # :177
+        self._mul(s.Ad, s.d)  # :178
+        s.x_d.axpby_(1.0, s.x, 1.0, s.d)  # :180
+        s.Ax_d.axpby_(1.0, s.Ax, 1.0, s.Ad)  # :181
+        s.f_Ax_d, _ = value_and_gradient_into(self.f, s.Ax_d, s.grad_f_Ax_d)  # :182-183
+        self._mul_adj(s.At_grad_f_Ax_d, s.grad_f_Ax_d)  # :184
+        s.x.copy_from(s.x_d)  # :186-191
+        s.Ax.copy_from(s.Ax_d)
+        s.grad_f_Ax.copy_from(s.grad_f_Ax_d)
+        s.At_grad_f_Ax.copy_from(s.At_grad_f_Ax_d)
+        s.z_curr.copy_from(s.z)
+        s.f_Ax = s.f_Ax_d
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :193
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))  # :194
+        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :195
+        s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :197
+        s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :198
+        s.res.axpby_(1.0, s.x, -1.0, s.z)  # :199
+        FBE_x_new = R(self._model(s) + s.g_z)  # :200
+        quad = getattr(self.f, "is_generalized_quadratic", False)
+        for k in range(1, self.max_backtracks + 1):  # :202-250
+            if FBE_x_new <= threshold:
+                break
+            if np.isinf(f_Az):  # :207-209
+                self._mul(s.Az, s.z_curr)
+            s.tau = R(0) if k >= self.max_backtracks else R(s.tau / R(2))  # :211
+            s.x.axpby_(s.tau, s.x_d, R(1) - s.tau, s.z_curr)  # :212
+            s.Ax.axpby_(s.tau, s.Ax_d, R(1) - s.tau, s.Az)  # :213
+            if quad:  # :215-237
+                if np.isinf(f_Az):
+                    f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)
+                if np.isinf(c):
+                    self._mul_adj(s.At_grad_f_Az, s.grad_f_Az)
+                    c = f_Az
+                    b = R(s.Ax_d.dot(s.grad_f_Az) - s.Az.dot(s.grad_f_Az))
+                    a = R(s.f_Ax_d - b - c)
+                s.f_Ax = R(a * s.tau**2 + b * s.tau + c)
+                s.grad_f_Ax.axpby_(s.tau, s.grad_f_Ax_d, R(1) - s.tau, s.grad_f_Az)
+                s.At_grad_f_Ax.axpby_(s.tau, s.At_grad_f_Ax_d, R(1) - s.tau, s.At_grad_f_Az)
+            else:  # :238-244
+                s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)
+                self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)
+            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :246
+            s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :247
+            s.res.axpby_(1.0, s.x, -1.0, s.z)  # :248
+            FBE_x_new = R(self._model(s) + s.g_z)  # :249
+        if s.H is not None:  # :252 (update_direction_state! :122-126)
+            s.x_prev.axpby_(1.0, s.x, -1.0, s.x_prev)
+            s.res_prev.axpby_(1.0, s.res, -1.0, s.res_prev)
+            s.H.update_(s.x_prev, s.res_prev)
+        return s
+
+    def __iter__(self):
+        s = self._init()
+        yield s
+        while True:
+            yield self._step(s)
+
+
+def value_and_gradient_into(f, u, grad_out):
+    """value_and_gradient(f, u) with the gradient copied into a preallocated vector (`state.grad .= grad`)."""
+    try:
+        v, g = f.value_and_gradient(u, out=grad_out)
+    except TypeError:
+        v, g = f.value_and_gradient(u)
+    if g is not grad_out and g.ptr != grad_out.ptr:
+        grad_out.copy_from(g)
+    return v, grad_out
+
+
+def default_stopping_criterion(tol, iteration, state):
+    """panoc.jl:256-257"""
+    R = state.res.dtype.type
+    return R(state.res.norm_inf()) / R(state.gamma) <= R(tol)
+
+
+def default_solution(iteration, state):
+    """panoc.jl:258"""
+    return state.z
+
+
+def default_display(it, iteration, state):
+    """panoc.jl:259-266"""
+    print("%5d | %.3e | %.3e | %.3e" % (it, state.gamma, state.res.norm_inf() / state.gamma, state.tau))
+
+
+def PANOC(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=10,
+          display=default_display, **kwargs):
+    """panoc.jl:297-315"""
+    if stop is None:
+        stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
+    return IterativeAlgorithm(PANOCIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose, freq=freq,
+                              display=display, **kwargs)

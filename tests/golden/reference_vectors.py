@@ -148,3 +148,11 @@ NESTEROV_FIXED_GAMMA = 1.7  # test_nesterov.jl:65
 NCQP_Q_DIAG = np.array([-0.5, 1.0])
 NCQP_q = np.array([0.3, 0.5])
 NCQP_LOW, NCQP_UPP = -1.0, 1.0
+
+# ---- test/problems/test_sparse_logistic_small.jl:8-36 (A, b as LASSO_SMALL_*; lam = 0.1; TOL = 1e-6) ----
+LOGISTIC_XSTAR = np.array([0, 0, 2.114635341704963e-01, 0, 2.845881348733116e00])
+LOGISTIC_LAM = 0.1
+LOGISTIC_TOL = 1e-6
+LOGISTIC_BOUNDS = {"fb_adaptive": 1100, "fb_adaptive_regret": 500, "ffb_adaptive": 500, "ffb_adaptive_regret": 200,
+                   "panoc_adaptive": 50}  # :45,60,71,86,108
+PANOC_LASSO_BOUNDS = {"fixed": 20, "adaptive": 20}  # test_lasso_small.jl:167,179

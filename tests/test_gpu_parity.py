@@ -634,3 +634,92 @@ def test_douglas_rachford_box_qp(pa, dtype, engine, materialize, gname):
     assert np.array_equal(x0, x0_backup)
     if gname == "box":  # closed form: clamp(-q / d, lo, hi)
         assert np.max(np.abs(y - np.clip(-q / d, lo, hi))) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# PANOC (SURVEY 8(f) row 2 / BASELINE config 4)
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m", [1, 5, 1000, 100003])
+def test_loss_kernels(pa, dtype, m):
+    rng = np.random.default_rng(m)
+    u, b = (2 * rng.standard_normal(m)).astype(dtype), rng.standard_normal(m).astype(dtype)
+    ud = pa.HIPVector.from_numpy(u)
+    for L, Lo in ((pa.SquaredDistance, o.SquaredDistance), (pa.LogisticLoss, o.LogisticLoss)):
+        v, g = L(b).value_and_gradient(ud)
+        vo, go = Lo(b).value_and_gradient(u)
+        assert abs(float(v) - float(vo)) <= 1e-5 * max(1.0, abs(float(vo)))
+        np.testing.assert_allclose(g.numpy(), go, rtol=8 * np.finfo(dtype).eps, atol=8 * np.finfo(dtype).eps)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_panoc_known_answers(pa, dtype):
+    """test_lasso_small.jl:159-181 (it < 20) and test_sparse_logistic_small.jl:101-110 (it < 50), plus FB / FFB on
+    the composed logistic term (:38-73)."""
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    for kw, key in ((dict(Lf=Lf), "fixed"), (dict(adaptive=True), "adaptive")):
+        x, it = pa.PANOC(tol=rv.LASSO_SMALL_TOL)(x0=x0, f=pa.SquaredDistance(b), A=A, g=pa.NormL1(lam), **kw)
+        assert isinstance(x, np.ndarray) and x.dtype == dtype
+        assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+        assert it < rv.PANOC_LASSO_BOUNDS[key]
+        _, ito = o.panoc(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.SquaredDistance(b), A=A, g=o.NormL1(lam), **kw)
+        assert abs(it - ito) <= 1
+    assert np.all(x0 == 0)
+    xs = rv.LOGISTIC_XSTAR.astype(dtype)
+    lam_l = dtype(rv.LOGISTIC_LAM)
+    x, it = pa.PANOC(tol=rv.LOGISTIC_TOL, adaptive=True)(x0=x0, f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam_l))
+    assert np.max(np.abs(x - xs)) <= 1e-4 and it < rv.LOGISTIC_BOUNDS["panoc_adaptive"]
+    fA = pa.Composed(pa.LogisticLoss(b), A)
+    x, it = pa.ForwardBackward(tol=rv.LOGISTIC_TOL, adaptive=True)(x0=x0, f=fA, g=pa.NormL1(lam_l))
+    assert np.max(np.abs(x - xs)) <= 1e-4 and it < rv.LOGISTIC_BOUNDS["fb_adaptive"]
+    x, it = pa.FastForwardBackward(tol=rv.LOGISTIC_TOL, adaptive=True)(x0=x0, f=fA, g=pa.NormL1(lam_l))
+    assert np.max(np.abs(x - xs)) <= 1e-4 and it < rv.LOGISTIC_BOUNDS["ffb_adaptive"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fb_equals_panoc_without_acceleration(pa, dtype):
+    """test/problems/test_equivalence.jl:51-84 on the device."""
+    A, b, lam, Lf = lasso_small(dtype)
+    gamma = dtype(0.95) / Lf
+    x0 = np.zeros(5, dtype)
+    fb = pa.ForwardBackwardIteration(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0, gamma=gamma)
+    pn = pa.PANOCIteration(f=pa.Composed(pa.SquaredDistance(b), A), g=pa.NormL1(lam), x0=x0, gamma=gamma,
+                           max_backtracks=1, directions=pa.NoAcceleration())
+    for s_fb, s_pn in itertools.islice(zip(fb, pn), 10):
+        np.testing.assert_allclose(s_fb.z.numpy(), s_pn.z.numpy(), rtol=1e-4 if dtype == np.float32 else 1e-8, atol=1e-6)
+
+
+@pytest.mark.parametrize("loss", ["sqdist", "logistic"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_panoc_against_oracle_synthetic(pa, dtype, loss):
+    """Adaptive PANOC with L-BFGS(5) on a 300 x 800 problem: same gamma sequence and iterates for the first
+    iterations (f64 tight; f32: the quasi-Newton direction amplifies rounding, so objective-level agreement)."""
+    m, n = 300, 800
+    A, b, lam = synthetic_problem(m, n, dtype, seed=7)
+    if loss == "logistic":
+        lam = dtype(0.02)
+    L, Lo = (pa.SquaredDistance, o.SquaredDistance) if loss == "sqdist" else (pa.LogisticLoss, o.LogisticLoss)
+    x0 = np.zeros(n, dtype)
+    it_g = pa.PANOCIteration(f=L(b), A=A, g=pa.NormL1(lam), x0=x0)
+    it_o = o.PANOCIteration(f=Lo(b), A=A, g=o.NormL1(lam), x0=x0)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+
+    def obj(z):
+        t = A64 @ z.astype(np.float64) - b64
+        fv = 0.5 * np.sum(t * t) if loss == "sqdist" else np.sum(np.log1p(np.exp(-t)))
+        return fv + float(lam) * np.sum(np.abs(z))
+
+    for k, (sg, so) in enumerate(itertools.islice(zip(it_g, it_o), 12)):
+        if dtype == np.float64:
+            assert float(sg.gamma) == pytest.approx(float(so.gamma), rel=1e-12)
+            assert np.max(np.abs(sg.z.numpy() - so.z)) <= 1e-8 * max(1.0, np.max(np.abs(so.z))), k
+        else:
+            assert abs(obj(sg.z.numpy()) - obj(so.z)) <= 2e-3 * abs(obj(so.z)), k
+    zg, kg = pa.PANOC(tol=1e-4 if dtype == np.float32 else 1e-7, maxit=300)(x0=x0, f=L(b), A=A, g=pa.NormL1(lam))
+    zo, ko = o.panoc(tol=1e-4 if dtype == np.float32 else 1e-7, maxit=300, x0=x0, f=Lo(b), A=A, g=o.NormL1(lam))
+    # f32 logistic: the stop rule (res_inf / gamma <= 1e-4) leaves the objective converged to ~1e-6 relative only
+    assert abs(obj(zg) - obj(zo)) <= (1e-5 if (dtype == np.float32 and loss == "logistic") else 1e-6) * abs(obj(zo))
+    assert kg <= max(ko + 10, int(1.5 * ko))

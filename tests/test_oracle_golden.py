@@ -308,3 +308,57 @@ def test_separable_quadratic_prox_is_the_minimiser():
     for _ in range(50):
         assert obj(y) <= obj(y + 1e-3 * rng.standard_normal(7)) + 1e-12
     assert fy == f(y)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+class TestPANOCPins:
+    def test_lasso_small_fixed_and_adaptive(self, dtype):
+        """test/problems/test_lasso_small.jl:159-181: PANOC(tol=1e-4) with f = ||. - b||^2/2, A, g = NormL1"""
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        for kw, key in ((dict(Lf=Lf), "fixed"), (dict(adaptive=True), "adaptive")):
+            x, it = o.panoc(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.SquaredDistance(b), A=A, g=o.NormL1(lam), **kw)
+            assert x.dtype == dtype and np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+            assert it < rv.PANOC_LASSO_BOUNDS[key]
+            assert np.all(x0 == 0)
+
+    def test_quadratic_shortcut_equals_general_branch(self, dtype):
+        """panoc.jl:215-244: the interpolation branch for generalized-quadratic f gives the same iterates as
+        recomputing f and its gradient."""
+        A, b, lam, Lf = lasso_small(dtype)
+
+        class NotQuad(o.SquaredDistance):
+            is_generalized_quadratic = False
+
+        x0 = np.zeros(5, dtype)
+        it1 = o.PANOCIteration(f=o.SquaredDistance(b), A=A, g=o.NormL1(lam), x0=x0, adaptive=True)
+        it2 = o.PANOCIteration(f=NotQuad(b), A=A, g=o.NormL1(lam), x0=x0, adaptive=True)
+        for s1, s2 in itertools.islice(zip(it1, it2), 12):
+            np.testing.assert_allclose(s1.z, s2.z, rtol=2e-4 if dtype == np.float32 else 1e-9, atol=1e-6)
+
+    def test_sparse_logistic(self, dtype):
+        """test/problems/test_sparse_logistic_small.jl:101-110 (+ FB/FFB :38-73 on the composed smooth term)"""
+        A = np.asfortranarray(rv.LASSO_SMALL_A.astype(dtype))
+        b = rv.LASSO_SMALL_B.astype(dtype)
+        lam = dtype(rv.LOGISTIC_LAM)
+        xs = rv.LOGISTIC_XSTAR.astype(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.panoc(tol=rv.LOGISTIC_TOL, adaptive=True, x0=x0, f=o.LogisticLoss(b), A=A, g=o.NormL1(lam))
+        assert np.max(np.abs(x - xs)) <= 1e-4 and it < rv.LOGISTIC_BOUNDS["panoc_adaptive"]
+        fA = o.Composed(o.LogisticLoss(b), A)
+        x, it = o.forward_backward(tol=rv.LOGISTIC_TOL, adaptive=True, x0=x0, f=fA, g=o.NormL1(lam))
+        assert np.max(np.abs(x - xs)) <= 1e-4 and it < rv.LOGISTIC_BOUNDS["fb_adaptive"]
+        x, it = o.fast_forward_backward(tol=rv.LOGISTIC_TOL, adaptive=True, x0=x0, f=fA, g=o.NormL1(lam))
+        assert np.max(np.abs(x - xs)) <= 1e-4 and it < rv.LOGISTIC_BOUNDS["ffb_adaptive"]
+
+    def test_fb_equals_panoc_without_acceleration(self, dtype):
+        """test/problems/test_equivalence.jl:51-84: ForwardBackwardIteration == PANOCIteration(max_backtracks = 1,
+        directions = NoAcceleration()) on z for 10 iterations (gamma = 0.95 / ||A||^2)."""
+        A, b, lam, Lf = lasso_small(dtype)
+        gamma = dtype(0.95) / Lf
+        x0 = np.zeros(5, dtype)
+        fb = o.ForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0, gamma=gamma)
+        pn = o.PANOCIteration(f=o.Composed(o.SquaredDistance(b), A), A=np.eye(5, dtype=dtype), g=o.NormL1(lam), x0=x0,
+                              gamma=gamma, max_backtracks=1, directions=None)
+        for s_fb, s_pn in itertools.islice(zip(fb, pn), 10):
+            np.testing.assert_allclose(s_fb.z, s_pn.z, rtol=1e-4 if dtype == np.float32 else 1e-8, atol=1e-6)
