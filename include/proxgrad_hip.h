@@ -221,6 +221,9 @@ typedef struct pg_iter_opts {
   double seq_p0, seq_p1; /* PG_SEQ_CONSTANT: (m, stepsize)                                       */
   int32_t g_kind;        /* PG_G_*                                                               */
   double g_p0, g_p1;     /* NormL1: lam | IndBox: lo, hi                                         */
+  int32_t reuse_residual; /* FFB adaptive: 1 (default) = form A x - b at the extrapolated point from the residuals
+                          * the line search already holds, (1+beta)(A z - b) - beta (A z_prev - b): 2 passes over A per
+                          * iteration instead of 3 (the reference does 4); 0 = recompute A x like the reference */
 } pg_iter_opts;
 
 /* the scalar part of ForwardBackwardState / FastForwardBackwardState plus line-search telemetry */

@@ -28,7 +28,7 @@ class pg_iter_opts(C.Structure):
     _fields_ = [("fast", C.c_int32), ("adaptive", C.c_int32), ("Lf", C.c_double), ("gamma", C.c_double),
                 ("minimum_gamma", C.c_double), ("reduce_gamma", C.c_double), ("increase_gamma", C.c_double),
                 ("mf", C.c_double), ("seq_kind", C.c_int32), ("seq_p0", C.c_double), ("seq_p1", C.c_double),
-                ("g_kind", C.c_int32), ("g_p0", C.c_double), ("g_p1", C.c_double)]
+                ("g_kind", C.c_int32), ("g_p0", C.c_double), ("g_p1", C.c_double), ("reuse_residual", C.c_int32)]
 
 
 class pg_iter_scalars(C.Structure):

@@ -22,6 +22,10 @@ inline unsigned grid_for(int64_t n_items, int num_cu, bool reduces) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// hook run by thread 0 of the finalizing workgroup with the reduced values (overload per functor when needed)
+template <typename F>
+__device__ __forceinline__ void ew_on_final(const F&, const double*) {}
+
 // Generic elementwise driver: F is a functor with
 //   template<int N> __device__ void operator()(int64_t i0, /*lane-private*/ Acc&) processing N consecutive
 // elements starting at i0 (N = VEC for the vector body, 1 for tails / unaligned operands).
@@ -45,7 +49,9 @@ __global__ __launch_bounds__(BS) void ew_kernel(int64_t n, bool vec_ok, F f, dou
     double ps[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) ps[k] = f.post_scale(k);
-    grid_reduce_finalize<NS, MAXMASK, BS / 64>(acc, red_partials, red_counter, out, ps);
+    double fin[NS];
+    const bool last = grid_reduce_finalize<NS, MAXMASK, BS / 64>(acc, red_partials, red_counter, out, ps, fin);
+    if (last && threadIdx.x == 0) ew_on_final(f, fin);
   }
 }
 

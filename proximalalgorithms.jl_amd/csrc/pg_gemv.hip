@@ -527,10 +527,11 @@ __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ v, int64_t n
 }
 
 template <typename T>
-pg_status ls_vg_t(pg_ls* f, const T* x, T* grad_out) {
+pg_status ls_grad_stage_t(pg_ls* f, T* grad_out) {
+  // second half of a gradient evaluation: g = lam A' r from the residual already in f->r (and f already in
+  // dscal[PG_S_F] / gbuf[n]), then the all-reduce of [grad ; f] when the rows are sharded
   pg_ctx* c = f->ctx;
   pg_mat* A = f->A;
-  PG_TRY(ls_residual_t<T>(f, x));
   T* gdst = c->allreduce ? (T*)f->gbuf : grad_out;
   T* chunks = (T*)f->gchunks;
   PG_TRY(gemv_t<T>(A, (const T*)f->r, gdst, &chunks));
@@ -553,8 +554,17 @@ pg_status ls_vg_t(pg_ls* f, const T* x, T* grad_out) {
   return PG_OK;
 }
 
+template <typename T>
+pg_status ls_vg_t(pg_ls* f, const T* x, T* grad_out) {
+  PG_TRY(ls_residual_t<T>(f, x));
+  return ls_grad_stage_t<T>(f, grad_out);
+}
+
 }  // namespace
 
+pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out) {
+  return f->A->dtype == PG_F32 ? ls_grad_stage_t<float>(f, (float*)grad_out) : ls_grad_stage_t<double>(f, (double*)grad_out);
+}
 pg_status pg_ls_residual_async(pg_ls* f, const void* x) {
   return f->A->dtype == PG_F32 ? ls_residual_t<float>(f, (const float*)x) : ls_residual_t<double>(f, (const double*)x);
 }

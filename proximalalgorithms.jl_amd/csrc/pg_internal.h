@@ -132,6 +132,11 @@ pg_status pg_ls_residual_async(pg_ls* f, const void* x);
 // *grad_ptr_out (either grad_out or f->gbuf) and f in dscal[PG_S_F].
 pg_status pg_ls_vg_async(pg_ls* f, const void* x, void* grad_out);
 pg_status pg_ls_value_async(pg_ls* f, const void* x);
+// g = lam A' r (+ all-reduce) from the residual currently held in f->r; f must already be in dscal[PG_S_F]
+pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out);
+// r_out = a r1 + b r2 over m elements, dscal[PG_S_F] = f_scale ||r_out||^2, optional typed mirror of f
+pg_status pg_residual_combo_async(pg_ctx* ctx, int dtype, int64_t m, void* r_out, double a, const void* r1, double b,
+                                  const void* r2, double f_scale, void* f_typed);
 pg_status pg_fb_epilogue_async(pg_ctx* ctx, int dtype, int64_t n, const void* x, const void* grad, double gamma,
                                int g_kind, double g_p0, double g_p1, void* y, void* z, void* res);
 

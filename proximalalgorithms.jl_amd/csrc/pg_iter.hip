@@ -35,6 +35,9 @@ struct pg_iter {
   double seq_t = 1;                          // FixedNesterovSequence state
   int64_t seq_k = 1;                         // SimpleNesterovSequence state
   int64_t passes0 = 0;
+  // residual reuse (adaptive FFB): A z - b and A z_prev - b, so that A x - b at the extrapolated point needs no pass
+  void *rz = nullptr, *rz_prev = nullptr;
+  bool rz_valid = false;
 };
 
 namespace {
@@ -142,6 +145,10 @@ pg_status backtrack(pg_iter* it, bool keep_grad) {
     tol = T(10) * eps * (T(1) + std::fabs(f_z));  // :54
     it->n_backtracks++;
   }
+  if (!keep_grad && it->rz != nullptr && it->f->A->m > 0) {  // residual A z - b of the accepted trial
+    PG_HIP(hipMemcpyAsync(it->rz, it->f->r, (size_t)it->f->A->m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    it->rz_valid = true;
+  }
   if ((T)it->gamma < min_gamma) it->flags |= PG_FLAG_GAMMA_TOO_SMALL;  // :59-61 (@warn)
   it->f_z = (double)f_z;
   it->f_z_upp = (double)f_upp;
@@ -167,6 +174,10 @@ pg_status iter_init(pg_iter* it, const void* x0) {
   PG_TRY(pg_ls_vg_async(it->f, it->x, it->grad_f_x));
   PG_TRY(pg_read_scalars(c, PG_S_F, 1));
   it->f_x = Arith<T>::r(c->hscal[PG_S_F]);
+  it->rz_valid = false;
+  if (it->rz_prev != nullptr && it->f->A->m > 0) {  // z_prev = copy(x): its residual is the one just computed
+    PG_HIP(hipMemcpyAsync(it->rz_prev, it->f->r, (size_t)it->f->A->m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  }
   // gamma = iter.gamma === nothing ? 1 / lower_bound_smoothness_constant(f, I, x, grad_f_x) : iter.gamma
   double gamma = it->o.gamma > 0 ? it->o.gamma : (it->o.Lf > 0 ? (double)(T(1) / (T)it->o.Lf) : -1.0);
   if (gamma <= 0) {
@@ -220,7 +231,20 @@ pg_status iter_step(pg_iter* it, double host_beta) {
     it->beta = seq_next<T>(it, it->gamma, host_beta);                // :134
     PG_TRY(pg_extrapolate(it->ctx, it->dtype, it->n, it->x, it->z, it->z_prev, it->beta));  // :135
     std::swap(it->z_prev, it->z);                                    // :136
-    PG_TRY(pg_ls_vg_async(it->f, it->x, it->grad_f_x));              // :138-139
+    if (it->adaptive && it->rz != nullptr && it->rz_valid) {
+      // :138-139 without re-reading A for A*x:  A x - b = (1 + beta)(A z - b) - beta (A z_prev - b); the line
+      // search has just produced A z - b.  One pass (A' r) instead of two.
+      pg_ls* f = it->f;
+      void* f_typed = it->ctx->allreduce ? (void*)((char*)f->gbuf + (size_t)f->A->n * sizeof(T)) : nullptr;
+      PG_TRY(pg_residual_combo_async(it->ctx, it->dtype, f->A->m, f->r, (double)(T(1) + (T)it->beta),
+                                     it->rz, (double)(-(T)it->beta), it->rz_prev, 0.5 * f->lam, f_typed));
+      PG_TRY(pg_ls_grad_stage_async(f, it->grad_f_x));
+      std::swap(it->rz_prev, it->rz);  // the residual at the new z_prev
+      it->rz_valid = false;
+    } else {
+      PG_TRY(pg_ls_vg_async(it->f, it->x, it->grad_f_x));            // :138-139
+      if (it->rz_prev != nullptr) it->rz_valid = false;
+    }
     PG_TRY(epilogue_and_read<T>(it, true));                          // :140-142
   }
   return PG_OK;
@@ -257,6 +281,7 @@ pg_status pg_iter_opts_default(pg_iter_opts* o) {
   o->mf = 0;                 // fast_forward_backward.jl:48
   o->seq_kind = PG_SEQ_ADAPTIVE;
   o->g_kind = PG_G_ZERO;
+  o->reuse_residual = 1;
   return PG_OK;
 }
 
@@ -277,14 +302,16 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   it->adaptive = o->adaptive < 0 ? !gamma_known : (o->adaptive != 0);
   const size_t vb = vec_bytes(it);
   const int nvec = 6;
+  const bool reuse = o->fast && o->reuse_residual != 0;
+  const size_t mb = reuse ? (size_t)pg_round_up((int64_t)((size_t)(f->A->m > 0 ? f->A->m : 1) * pg_sizeof(it->dtype)), 256) : 0;
   PG_HIP(hipSetDevice(c->device));
-  hipError_t e = hipMalloc(&it->slab, vb * nvec);
+  hipError_t e = hipMalloc(&it->slab, vb * nvec + 2 * mb);
   if (e != hipSuccess) {
     pg_set_error("state allocation (%zu bytes) failed: %s", vb * nvec, hipGetErrorString(e));
     delete it;
     return PG_ERR_ALLOC;
   }
-  e = hipMemsetAsync(it->slab, 0, vb * nvec, c->stream);
+  e = hipMemsetAsync(it->slab, 0, vb * nvec + 2 * mb, c->stream);
   if (e != hipSuccess) {
     (void)hipFree(it->slab);
     delete it;
@@ -301,6 +328,10 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
     it->z_prev = base + 5 * vb;
   else
     it->grad_f_z = base + 5 * vb;
+  if (reuse) {
+    it->rz = base + 6 * vb;
+    it->rz_prev = base + 6 * vb + mb;
+  }
   *out = it;
   return PG_OK;
 }

@@ -306,6 +306,33 @@ struct LossF {
   __device__ double post_scale(int) const { return LOSS == 0 ? 0.5 : 1.0; }
 };
 
+// r = a r1 + b r2 ; acc[0] = sum r^2  (residual at the extrapolated point from the residuals at z and z_prev:
+// A x - b = (1 + beta)(A z - b) - beta (A z_prev - b), the b terms cancel exactly)
+template <typename T>
+struct ResidualComboF {
+  T* r;
+  const T* r1;
+  const T* r2;
+  T a, b;
+  double fscale;
+  T* f_typed;  // nullable: mirror of f in working precision (slot n of the all-reduce payload)
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> u = ld<T, N>(r1, i), w = ld<T, N>(r2, i), o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      o.v[e] = a * u.v[e] + b * w.v[e];
+      acc[0] += (double)o.v[e] * (double)o.v[e];
+    }
+    st<T, N>(r, i, o);
+  }
+  __device__ double post_scale(int) const { return fscale; }
+};
+template <typename T>
+__device__ __forceinline__ void ew_on_final(const ResidualComboF<T>& f, const double* fin) {
+  if (f.f_typed != nullptr) *f.f_typed = (T)fin[0];
+}
+
 template <typename T>
 pg_status epilogue_t(pg_ctx* c, int64_t n, const T* x, const T* grad, double gamma, int g_kind, double g_p0,
                      double g_p1, T* y, T* z, T* res, T* grad_copy) {
@@ -435,6 +462,17 @@ pg_status finish_scalar(pg_ctx* c, int slot, double* out) {
 }
 
 }  // namespace
+
+pg_status pg_residual_combo_async(pg_ctx* c, int dtype, int64_t m, void* r_out, double a, const void* r1, double b,
+                                  const void* r2, double f_scale, void* f_typed) {
+  const bool v = aligned16(r_out) && aligned16(r1) && aligned16(r2);
+  if (dtype == PG_F32) {
+    ResidualComboF<float> f{(float*)r_out, (const float*)r1, (const float*)r2, (float)a, (float)b, f_scale, (float*)f_typed};
+    return launch_ew<float, ResidualComboF<float>, 1, 0u>(c, m, v, f, c->dscal + PG_S_F);
+  }
+  ResidualComboF<double> f{(double*)r_out, (const double*)r1, (const double*)r2, a, b, f_scale, (double*)f_typed};
+  return launch_ew<double, ResidualComboF<double>, 1, 0u>(c, m, v, f, c->dscal + PG_S_F);
+}
 
 pg_status pg_fb_epilogue_async(pg_ctx* c, int dtype, int64_t n, const void* x, const void* grad, double gamma,
                                int g_kind, double g_p0, double g_p1, void* y, void* z, void* res) {

@@ -723,3 +723,29 @@ def test_panoc_against_oracle_synthetic(pa, dtype, loss):
     # f32 logistic: the stop rule (res_inf / gamma <= 1e-4) leaves the objective converged to ~1e-6 relative only
     assert abs(obj(zg) - obj(zo)) <= (1e-5 if (dtype == np.float32 and loss == "logistic") else 1e-6) * abs(obj(zo))
     assert kg <= max(ko + 10, int(1.5 * ko))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ffb_adaptive_residual_reuse(pa, dtype):
+    """Adaptive FFB forms A x - b at the extrapolated point from the line search's residuals
+    ((1+beta)(A z - b) - beta (A z_prev - b)): 2 passes over A per iteration instead of 3, same iterates as the
+    recomputing path (and as the oracle) to rounding."""
+    A, b, lam = synthetic_problem(400, 1200, dtype, seed=9)
+    x0 = np.zeros(1200, dtype)
+    its = [pa.FastForwardBackwardIteration(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0, reuse_residual=r)
+           for r in (True, False)]
+    it_o = o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0)
+    tol = 2e-5 if dtype == np.float32 else 1e-11
+    nbt = 0
+    for k, (s1, s2, so) in enumerate(itertools.islice(zip(its[0], its[1], it_o), 60)):
+        assert float(s1.gamma) == float(s2.gamma), k
+        # the initial gamma comes from a norm (fb_tools.jl:11): fp64-accumulated here, BLAS nrm2 in the oracle
+        assert float(s1.gamma) == pytest.approx(float(so.gamma), rel=1e-6 if dtype == np.float32 else 1e-12), k
+        z1, z2 = s1.z.numpy(), s2.z.numpy()
+        assert np.max(np.abs(z1 - z2)) <= tol * max(1.0, np.max(np.abs(z2))), k
+        assert np.max(np.abs(z1 - so.z)) <= tol * max(1.0, np.max(np.abs(so.z))), k
+        assert abs(float(s1.f_x) - float(so.f_x)) <= 20 * rtol(dtype) * max(1.0, abs(float(so.f_x)))
+        nbt += s1.n_backtracks
+    steps = 59
+    assert its[0].counters["a_passes"] == 2 + 2 + 2 * steps + nbt  # init (2 evaluations), then 2 per step
+    assert its[1].counters["a_passes"] == 2 + 2 + 3 * steps + nbt
