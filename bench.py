@@ -53,6 +53,7 @@ def parse_args():
     p.add_argument("--cpu-steps", type=int, default=10)
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
+    p.add_argument("--no-overlap", action="store_true", help="disable the chunked asynchronous all-reduce (N > 1)")
     p.add_argument("--share-device", action="store_true",
                    help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
     return p.parse_args()
@@ -143,7 +144,7 @@ def main():
     noise = np.random.default_rng(args.seed + 54321).standard_normal(m_glob).astype(dtype)[row_off:row_off + m_loc]
     b = A.mul(pa.HIPVector.from_numpy(x_true, ctx))  # rows are independent: no collective
     b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
-    comm = pa.TorchDistributedComm() if world > 1 else None
+    comm = pa.TorchDistributedComm(overlap=not args.no_overlap) if world > 1 else None
     f = pa.LeastSquares(A, b, comm=comm)
     zero_n = pa.HIPVector.zeros(n, dtype, ctx)
     _, g0 = f.value_and_gradient(zero_n)  # = -A'b (all-reduced over the shards)

@@ -74,6 +74,8 @@ typedef struct pg_lbfgs pg_lbfgs;
 /* SUM all-reduce over the row shards, in place on a device buffer, ordered on `stream`.
  * Returns 0 on success. */
 typedef int (*pg_allreduce_fn)(void* user, void* dev_buf, int64_t count, int32_t dtype, void* stream);
+/* Make `stream` wait for every all-reduce issued through the asynchronous begin callback.  Returns 0 on success. */
+typedef int (*pg_allreduce_wait_fn)(void* user, void* stream);
 
 typedef struct pg_device_info {
   int32_t device;
@@ -94,6 +96,11 @@ pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out);
 pg_status pg_ctx_destroy(pg_ctx* ctx);
 pg_status pg_ctx_set_stream(pg_ctx* ctx, void* stream);
 pg_status pg_ctx_set_allreduce(pg_ctx* ctx, pg_allreduce_fn fn, void* user);
+/* Optional asynchronous pair: `begin` issues a SUM all-reduce that is ordered after the work already enqueued on
+ * `stream` but does NOT block later work on it (e.g. ncclAllReduce on a side stream behind an event); `wait` makes
+ * `stream` wait for all of them.  With the pair registered, a gradient evaluation runs A'r in column chunks and
+ * overlaps each chunk's collective with the next chunk's pass (only the last chunk's collective is exposed). */
+pg_status pg_ctx_set_allreduce_async(pg_ctx* ctx, pg_allreduce_fn begin, pg_allreduce_wait_fn wait, void* user);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every

@@ -43,6 +43,7 @@ class pg_iter_state(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+ALLREDUCE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
 _pf64 = C.POINTER(C.c_double)
@@ -53,6 +54,7 @@ SIGNATURES = {
     "pg_ctx_destroy": [_vp],
     "pg_ctx_set_stream": [_vp, _vp],
     "pg_ctx_set_allreduce": [_vp, ALLREDUCE_FN, _vp],
+    "pg_ctx_set_allreduce_async": [_vp, ALLREDUCE_FN, ALLREDUCE_WAIT_FN, _vp],
     "pg_ctx_sync": [_vp],
     "pg_ctx_device_info": [_vp, C.POINTER(pg_device_info)],
     "pg_ctx_profile_enable": [_vp, _i32],

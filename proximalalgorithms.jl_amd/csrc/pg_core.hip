@@ -85,6 +85,15 @@ pg_status pg_ctx_set_allreduce(pg_ctx* c, pg_allreduce_fn fn, void* user) {
   return PG_OK;
 }
 
+pg_status pg_ctx_set_allreduce_async(pg_ctx* c, pg_allreduce_fn begin, pg_allreduce_wait_fn wait, void* user) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  PG_REQUIRE((begin == nullptr) == (wait == nullptr), "begin and wait must be given together");
+  c->allreduce_begin = begin;
+  c->allreduce_wait = wait;
+  if (begin != nullptr) c->allreduce_user = user;
+  return PG_OK;
+}
+
 pg_status pg_ctx_sync(pg_ctx* c) {
   PG_REQUIRE(c != nullptr, "ctx is null");
   PG_HIP(hipStreamSynchronize(c->stream));

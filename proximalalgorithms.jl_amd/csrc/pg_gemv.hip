@@ -399,10 +399,10 @@ pg_status gemv_n(pg_mat* A, const T* x, const T* b, T* y, int64_t y_len, bool wi
 }
 
 template <typename T, int C, int UR, int WAVES>
-pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
+pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64_t col0, int64_t ncols) {
   pg_ctx* c = A->ctx;
   const size_t lds = (size_t)nrg * 1024;
-  const int64_t ncg = (A->n + C - 1) / C;
+  const int64_t ncg = (ncols + C - 1) / C;
   // workgroups per CU limited by LDS (160 KiB) and by 32 waves
   int lds_cap = (int)(160 * 1024 / (lds > 0 ? lds : 1));
   const int wave_cap = 32 / WAVES;
@@ -416,17 +416,17 @@ pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
   if (blocks < 1) blocks = 1;
   pg_prof_scope prof(c, PG_K_GEMV_T);
   hipLaunchKernelGGL((gemv_t_kernel<T, C, UR, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, c->stream,
-                     (const T*)A->data, A->ld, A->n, A->m, rg_begin, nrg, r, g);
+                     (const T*)A->data + col0 * A->ld, A->ld, ncols, A->m, rg_begin, nrg, r, g);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
 
 // Tunables (environment, for experiments): PG_T_C, PG_T_UR, PG_T_WAVES, PG_T_BLOCKS_PER_CU.
 template <typename T>
-pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g) {
+pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64_t col0, int64_t ncols) {
   const int C = env_int("PG_T_C", 2), UR = env_int("PG_T_UR", 4), W = env_int("PG_T_WAVES", 8);
 #define PG_T_CASE(CC, UU, WW) \
-  if (C == CC && UR == UU && W == WW) return launch_t_cuw<T, CC, UU, WW>(A, rg_begin, nrg, r, g)
+  if (C == CC && UR == UU && W == WW) return launch_t_cuw<T, CC, UU, WW>(A, rg_begin, nrg, r, g, col0, ncols)
   PG_T_CASE(4, 4, 8);
   PG_T_CASE(4, 4, 4);
   PG_T_CASE(4, 4, 16);
@@ -467,7 +467,7 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
   const int n_rowgroups = (int)(A->ld / rows_per_rg);
   const int rg_per_chunk = (int)(LDS_R_BYTES / 1024);
   const int nchunks = (n_rowgroups + rg_per_chunk - 1) / rg_per_chunk;
-  if (nchunks == 1) return launch_t<T>(A, 0, n_rowgroups, r, g);
+  if (nchunks == 1) return launch_t<T>(A, 0, n_rowgroups, r, g, 0, A->n);
   if (*gchunks_ws == nullptr) {
     hipError_t e = hipMalloc((void**)gchunks_ws, (size_t)nchunks * A->n * sizeof(T));
     if (e != hipSuccess) {
@@ -478,7 +478,7 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
   for (int k = 0; k < nchunks; ++k) {
     const int rb = k * rg_per_chunk;
     const int nr = (rb + rg_per_chunk <= n_rowgroups) ? rg_per_chunk : (n_rowgroups - rb);
-    PG_TRY(launch_t<T>(A, rb, nr, r, *gchunks_ws + (int64_t)k * A->n));
+    PG_TRY(launch_t<T>(A, rb, nr, r, *gchunks_ws + (int64_t)k * A->n, 0, A->n));
   }
   int64_t blocks = (A->n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -490,7 +490,17 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
 
 // all-reduce helper
 pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
-  if (!c->allreduce) return PG_OK;
+  if (!c->allreduce) {
+    if (c->allreduce_begin && c->allreduce_wait) {  // only the asynchronous pair is registered
+      int rc = c->allreduce_begin(c->allreduce_user, buf, count, dtype, (void*)c->stream);
+      if (rc == 0) rc = c->allreduce_wait(c->allreduce_user, (void*)c->stream);
+      if (rc != 0) {
+        pg_set_error("all-reduce callback failed with code %d", rc);
+        return PG_ERR_COLLECTIVE;
+      }
+    }
+    return PG_OK;
+  }
   int rc = c->allreduce(c->allreduce_user, buf, count, dtype, (void*)c->stream);
   if (rc != 0) {
     pg_set_error("all-reduce callback failed with code %d", rc);
@@ -502,7 +512,7 @@ pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
 template <typename T>
 pg_status ls_residual_t(pg_ls* f, const T* x) {
   pg_mat* A = f->A;
-  T* f_typed = f->ctx->allreduce ? ((T*)f->gbuf + A->n) : nullptr;
+  T* f_typed = (f->ctx->allreduce || f->ctx->allreduce_begin) ? ((T*)f->gbuf + A->n) : nullptr;
   PG_TRY(gemv_n<T>(A, x, (const T*)f->b, (T*)f->r, A->ld, true, 0.5 * f->lam, f_typed));
   f->a_passes += 1;
   return PG_OK;
@@ -512,7 +522,7 @@ template <typename T>
 pg_status ls_value_t(pg_ls* f, const T* x) {
   PG_TRY(ls_residual_t<T>(f, x));
   pg_ctx* c = f->ctx;
-  if (c->allreduce) {
+  if (c->allreduce || c->allreduce_begin) {
     T* ft = (T*)f->gbuf + f->A->n;
     PG_TRY(do_allreduce(c, ft, 1, f->A->dtype));
     hipLaunchKernelGGL(cast_scalar_kernel<T>, dim3(1), dim3(1), 0, c->stream, (const T*)ft, c->dscal + PG_S_F);
@@ -532,19 +542,57 @@ pg_status ls_grad_stage_t(pg_ls* f, T* grad_out) {
   // dscal[PG_S_F] / gbuf[n]), then the all-reduce of [grad ; f] when the rows are sharded
   pg_ctx* c = f->ctx;
   pg_mat* A = f->A;
-  T* gdst = c->allreduce ? (T*)f->gbuf : grad_out;
-  T* chunks = (T*)f->gchunks;
-  PG_TRY(gemv_t<T>(A, (const T*)f->r, gdst, &chunks));
-  f->gchunks = chunks;
-  f->a_passes += 1;
-  if (f->lam != 1.0 && A->n > 0) {
-    int64_t blocks = (A->n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(scale_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, c->stream, gdst, A->n, (T)f->lam);
-    PG_LAUNCH_CHECK();
+  const bool sharded = c->allreduce != nullptr || c->allreduce_begin != nullptr;
+  T* gdst = sharded ? (T*)f->gbuf : grad_out;
+  const int64_t rows_per_rg = 1024 / (int64_t)sizeof(T);
+  const int n_rowgroups = (int)(A->ld / rows_per_rg);
+  // Pipelined collective: pass T runs in K column chunks; the all-reduce of chunk k is issued
+  // asynchronously (RCCL's own stream) as soon as its columns are done and overlaps pass T of chunk k+1; only the
+  // last chunk's collective is exposed.  The payload's trailing f rides with the last chunk.
+  int K = env_int("PG_ALLREDUCE_CHUNKS", 4);
+  const bool pipelined = c->allreduce_begin != nullptr && c->allreduce_wait != nullptr && K > 1 && A->m > 0 &&
+                         (int64_t)n_rowgroups * 1024 <= LDS_R_BYTES && A->n >= (int64_t)K * 4096;
+  if (pipelined) {
+    const int64_t per = (A->n / K + 255) / 256 * 256;  // keep chunk starts 1 KiB aligned
+    for (int k = 0; k < K; ++k) {
+      const int64_t c0 = (int64_t)k * per;
+      if (c0 >= A->n) break;
+      const bool is_last = (k == K - 1) || (c0 + per >= A->n);
+      const int64_t nc = is_last ? (A->n - c0) : per;
+      PG_TRY(launch_t<T>(A, 0, n_rowgroups, (const T*)f->r, gdst + c0, c0, nc));
+      if (f->lam != 1.0) {
+        int64_t blocks = (nc + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(scale_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, c->stream, gdst + c0, nc, (T)f->lam);
+        PG_LAUNCH_CHECK();
+      }
+      int rc = c->allreduce_begin(c->allreduce_user, gdst + c0, nc + (is_last ? 1 : 0), A->dtype, (void*)c->stream);
+      if (rc != 0) {
+        pg_set_error("asynchronous all-reduce callback failed with code %d", rc);
+        return PG_ERR_COLLECTIVE;
+      }
+      if (is_last) break;
+    }
+    f->a_passes += 1;
+    int rc = c->allreduce_wait(c->allreduce_user, (void*)c->stream);
+    if (rc != 0) {
+      pg_set_error("all-reduce wait callback failed with code %d", rc);
+      return PG_ERR_COLLECTIVE;
+    }
+  } else {
+    T* chunks = (T*)f->gchunks;
+    PG_TRY(gemv_t<T>(A, (const T*)f->r, gdst, &chunks));
+    f->gchunks = chunks;
+    f->a_passes += 1;
+    if (f->lam != 1.0 && A->n > 0) {
+      int64_t blocks = (A->n + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(scale_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, c->stream, gdst, A->n, (T)f->lam);
+      PG_LAUNCH_CHECK();
+    }
+    if (sharded) PG_TRY(do_allreduce(c, f->gbuf, A->n + 1, A->dtype));
   }
-  if (c->allreduce) {
-    PG_TRY(do_allreduce(c, f->gbuf, A->n + 1, A->dtype));
+  if (sharded) {
     hipLaunchKernelGGL(cast_scalar_kernel<T>, dim3(1), dim3(1), 0, c->stream, (const T*)f->gbuf + A->n,
                        c->dscal + PG_S_F);
     PG_LAUNCH_CHECK();

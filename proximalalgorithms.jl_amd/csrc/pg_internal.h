@@ -80,6 +80,8 @@ struct pg_ctx {
   double* dscal = nullptr;         //               ... and its device-side address (kernels store here)
   // collective
   pg_allreduce_fn allreduce = nullptr;
+  pg_allreduce_fn allreduce_begin = nullptr;  // asynchronous issue (overlaps with following kernels)
+  pg_allreduce_wait_fn allreduce_wait = nullptr;
   void* allreduce_user = nullptr;
   // event-pair kernel timing (pg_ctx_profile_*)
   bool profiling = false;

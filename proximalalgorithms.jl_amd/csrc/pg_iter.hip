@@ -235,7 +235,7 @@ pg_status iter_step(pg_iter* it, double host_beta) {
       // :138-139 without re-reading A for A*x:  A x - b = (1 + beta)(A z - b) - beta (A z_prev - b); the line
       // search has just produced A z - b.  One pass (A' r) instead of two.
       pg_ls* f = it->f;
-      void* f_typed = it->ctx->allreduce ? (void*)((char*)f->gbuf + (size_t)f->A->n * sizeof(T)) : nullptr;
+      void* f_typed = (it->ctx->allreduce || it->ctx->allreduce_begin) ? (void*)((char*)f->gbuf + (size_t)f->A->n * sizeof(T)) : nullptr;
       PG_TRY(pg_residual_combo_async(it->ctx, it->dtype, f->A->m, f->r, (double)(T(1) + (T)it->beta),
                                      it->rz, (double)(-(T)it->beta), it->rz_prev, 0.5 * f->lam, f_typed));
       PG_TRY(pg_ls_grad_stage_async(f, it->grad_f_x));

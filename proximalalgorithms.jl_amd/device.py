@@ -94,6 +94,37 @@ class Context:
         self._allreduce_cb = _lib.ALLREDUCE_FN(_cb)  # keep alive
         call("pg_ctx_set_allreduce", self._h, self._allreduce_cb, None)
 
+    def set_allreduce_async(self, begin, wait):
+        """begin(ptr, count, pg_dtype, stream) issues an asynchronous SUM all-reduce ordered after the stream's
+        current work; wait(stream) makes the stream wait for all of them (see pg_ctx_set_allreduce_async)."""
+        if begin is None:
+            self._allreduce_async_cbs = None
+            call("pg_ctx_set_allreduce_async", self._h, _lib.ALLREDUCE_FN(), _lib.ALLREDUCE_WAIT_FN(), None)
+            return
+
+        def _b(user, buf, count, dtype, stream):
+            try:
+                begin(int(buf), int(count), int(dtype), int(stream or 0))
+                return 0
+            except Exception:
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def _w(user, stream):
+            try:
+                wait(int(stream or 0))
+                return 0
+            except Exception:
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._allreduce_async_cbs = (_lib.ALLREDUCE_FN(_b), _lib.ALLREDUCE_WAIT_FN(_w))
+        call("pg_ctx_set_allreduce_async", self._h, self._allreduce_async_cbs[0], self._allreduce_async_cbs[1], None)
+
 
 _default_ctx = {}
 

@@ -30,12 +30,13 @@ class TorchDistributedComm:
     registers the C callback the library invokes between the local GEMV passes and the replicated epilogue;
     the collective is enqueued on the context's stream (torch's current stream), so no host sync is added."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, overlap=True):
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
+        self.overlap = bool(overlap)  # pipeline the [grad ; f] all-reduce with pass T (column chunks)
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._views = {}
@@ -55,12 +56,31 @@ class TorchDistributedComm:
         return t
 
     def attach(self, ctx):
+        import torch.distributed as dist
+
         def fn(ptr, count, pg_dtype, stream):
             self.calls += 1
             self.elements += count
             allreduce_sum_(self._view(ctx, ptr, count, pg_dtype), self.group)
 
+        pending = []
+
+        def begin(ptr, count, pg_dtype, stream):
+            # async_op=True: RCCL runs the collective on its own stream behind an event recorded on the current
+            # stream; the current stream is NOT made to wait until wait() -> the next pass-T chunk overlaps it
+            self.calls += 1
+            self.elements += count
+            pending.append(dist.all_reduce(self._view(ctx, ptr, count, pg_dtype), op=dist.ReduceOp.SUM,
+                                           group=self.group, async_op=True))
+
+        def wait(stream):
+            for w in pending:
+                w.wait()
+            pending.clear()
+
         ctx.set_allreduce(fn)
+        if self.overlap:
+            ctx.set_allreduce_async(begin, wait)
 
 
 class ScaleComm:
@@ -68,10 +88,12 @@ class ScaleComm:
     shards (the SUM all-reduce of identical buffers is a multiplication by world_size), using the library's
     own axpby kernel on the payload.  Exercises the C-side pack / reduce / unpack path without RCCL."""
 
-    def __init__(self, world_size):
+    def __init__(self, world_size, overlap=False):
         self.world_size = int(world_size)
+        self.overlap = bool(overlap)  # also register the begin/wait pair -> exercises the chunked pass-T path
         self.calls = 0
         self.elements = 0
+        self.waits = 0
 
     def attach(self, ctx):
         import ctypes as C
@@ -84,4 +106,9 @@ class ScaleComm:
             call("pg_axpby", ctx.handle, pg_dtype, count, C.c_void_p(ptr), float(self.world_size), C.c_void_p(ptr), 0.0,
                  None)
 
+        def wait(stream):
+            self.waits += 1
+
         ctx.set_allreduce(fn)
+        if self.overlap:
+            ctx.set_allreduce_async(fn, wait)

@@ -438,24 +438,25 @@ def test_lbfgs_large_matches_oracle(pa):
 # ------------------------------------------------------------------------------------------------
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_sharded_payload_with_emulated_allreduce(pa, dtype):
+def test_sharded_payload_with_emulated_allreduce(pa, dtype, overlap):
     """Two 'ranks' holding identical row shards: the SUM all-reduce equals x2, so the sharded operator on one
     shard must equal the plain operator on the stacked matrix [A; A], [b; b]."""
-    m, n = 300, 700
+    m, n = 300, 700 if not overlap else 20000  # the chunked (pipelined) path needs n >= 4 * 4096
     A, b, lam = synthetic_problem(m, n, dtype, seed=4)
     ctx2 = pa.Context()  # separate context so the callback does not leak into other tests
-    comm = pa.ScaleComm(2)
+    comm = pa.ScaleComm(2, overlap=overlap)
     f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
     f_full = pa.LeastSquares(np.vstack([A, A]), np.concatenate([b, b]))
     x = np.random.default_rng(0).standard_normal(n).astype(dtype)
     fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
     ff, gf = f_full.value_and_gradient(pa.HIPVector.from_numpy(x))
-    assert comm.calls == 1 and comm.elements == n + 1
+    assert comm.calls == (4 if overlap else 1) and comm.elements == n + 1 and comm.waits == (1 if overlap else 0)
     assert abs(float(fs) - float(ff)) <= 20 * rtol(dtype) * abs(float(ff))
     assert np.max(np.abs(gs.numpy() - gf.numpy())) <= 20 * rtol(dtype) * np.linalg.norm(gf.numpy())
     assert abs(float(f_sh(pa.HIPVector.from_numpy(x, ctx2))) - float(ff)) <= 20 * rtol(dtype) * abs(float(ff))
-    assert comm.calls == 2 and comm.elements == n + 2
+    assert comm.calls == (5 if overlap else 2) and comm.elements == n + 2
     # whole adaptive FFB run, sharded vs stacked
     lam2 = dtype(2) * lam
     z1, k1 = pa.FastForwardBackward(tol=1e-4, maxit=500)(x0=pa.HIPVector.zeros(n, dtype, ctx2), f=f_sh, g=pa.NormL1(lam2))
