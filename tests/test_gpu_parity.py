@@ -750,3 +750,62 @@ def test_ffb_adaptive_residual_reuse(pa, dtype):
     steps = 59
     assert its[0].counters["a_passes"] == 2 + 2 + 2 * steps + nbt  # init (2 evaluations), then 2 per step
     assert its[1].counters["a_passes"] == 2 + 2 + 3 * steps + nbt
+
+
+# ------------------------------------------------------------------------------------------------
+# randomized shapes: every launch-geometry branch of the two GEMV passes (row-tile tails, LDS combine widths,
+# column-block tails, multi-chunk rows) against fp64 numpy
+# ------------------------------------------------------------------------------------------------
+
+
+def _random_shapes(seed, count):
+    rng = np.random.default_rng(seed)
+    anchors = [1, 2, 3, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097]
+    shapes = []
+    for _ in range(count):
+        m = int(rng.choice(anchors)) if rng.random() < 0.6 else int(rng.integers(1, 6000))
+        n = int(rng.choice(anchors)) if rng.random() < 0.4 else int(rng.integers(1, 3000))
+        shapes.append((m, n))
+    shapes += [(16385, 40), (33000, 17), (20000, 130)]  # more rows than one LDS chunk of pass T (16384 f32 / 8192 f64)
+    return shapes
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gemv_random_shapes(pa, dtype):
+    rng = np.random.default_rng(99)
+    for m, n in _random_shapes(5, 40):
+        A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype))
+        x, r, b = rng.standard_normal(n).astype(dtype), rng.standard_normal(m).astype(dtype), rng.standard_normal(m).astype(dtype)
+        f = pa.LeastSquares(A, b)
+        A64 = A.astype(np.float64)
+        fx, g = f.value_and_gradient(pa.HIPVector.from_numpy(x))
+        res = A64 @ x.astype(np.float64) - b.astype(np.float64)
+        g_ref = A64.T @ res
+        bound_r = np.abs(A64) @ np.abs(x.astype(np.float64)) + np.abs(b)
+        assert np.all(np.abs(f.residual().numpy() - res) <= rtol(dtype) * np.maximum(bound_r, 1e-30)), (m, n)
+        assert abs(float(fx) - 0.5 * res @ res) <= 20 * rtol(dtype) * max(0.5 * res @ res, 1e-30), (m, n)
+        g_bound = np.abs(A64).T @ bound_r
+        assert np.all(np.abs(g.numpy() - g_ref) <= 4 * rtol(dtype) * np.maximum(g_bound, 1e-30)), (m, n)
+        y = f.A.mul_adjoint(pa.HIPVector.from_numpy(r)).numpy()
+        assert np.all(np.abs(y - A64.T @ r) <= rtol(dtype) * np.maximum(np.abs(A64).T @ np.abs(r), 1e-30)), (m, n)
+
+
+def test_gemv_geometry_overrides_agree(pa):
+    """The tunable launch geometries (PG_N_*, PG_T_* environment overrides read at launch time) all compute the same
+    product: different wave/row-tile decompositions, LDS combine widths and column groupings."""
+    m, n = 3000, 2500
+    rng = np.random.default_rng(3)
+    A = pa.HIPMatrix.from_numpy(np.asfortranarray(rng.standard_normal((m, n)).astype(np.float32)))
+    x, r = pa.HIPVector.from_numpy(rng.standard_normal(n).astype(np.float32)), pa.HIPVector.from_numpy(rng.standard_normal(m).astype(np.float32))
+    y0, g0 = A.mul(x).numpy(), A.mul_adjoint(r).numpy()
+    keys = ["PG_N_R", "PG_N_U", "PG_N_TW", "PG_N_WAVES_PER_CU", "PG_T_C", "PG_T_UR", "PG_T_WAVES", "PG_T_BLOCKS_PER_CU"]
+    try:
+        for R, U, TW, W in [(4, 4, 1, 16), (2, 8, 2, 4), (8, 2, 4, 8), (1, 16, 4, 32), (16, 1, 1, 2), (2, 2, 2, 12)]:
+            os.environ.update(PG_N_R=str(R), PG_N_U=str(U), PG_N_TW=str(TW), PG_N_WAVES_PER_CU=str(W))
+            assert np.max(np.abs(A.mul(x).numpy() - y0)) <= 1e-4 * np.max(np.abs(y0)), (R, U, TW, W)
+        for C, UR, W, B in [(4, 4, 8, 2), (1, 16, 4, 1), (8, 2, 8, 1), (2, 8, 2, 3), (4, 2, 16, 2)]:
+            os.environ.update(PG_T_C=str(C), PG_T_UR=str(UR), PG_T_WAVES=str(W), PG_T_BLOCKS_PER_CU=str(B))
+            assert np.max(np.abs(A.mul_adjoint(r).numpy() - g0)) <= 1e-4 * np.max(np.abs(g0)), (C, UR, W, B)
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
