@@ -809,3 +809,24 @@ def test_gemv_geometry_overrides_agree(pa):
     finally:
         for k in keys:
             os.environ.pop(k, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# the C ABI from a plain C client (no Python, no torch in the process): what a Julia `ccall` host sees
+# ------------------------------------------------------------------------------------------------
+
+
+def test_c_abi_client_standalone(pa, tmp_path):
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "proximalalgorithms.jl_amd")
+    exe = str(tmp_path / "ffb_smoke")
+    cc = subprocess.run(["gcc", "-O2", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "ffb_smoke.c"),
+                         "-L", pkg, "-lproxgrad_hip", "-lm", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    for args in ([], ["200", "500"], ["257", "1030"]):
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, LD_LIBRARY_PATH=pkg + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
+        assert run.returncode == 0 and "C_ABI_OK" in run.stdout, run.stdout + run.stderr
