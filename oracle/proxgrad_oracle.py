@@ -916,3 +916,239 @@ class PANOCIteration:
 def panoc(*, maxit=1_000, tol=1e-8, **kw):
     """PANOC(; maxit, tol)(; kwargs...)  panoc.jl:297-315; stop :256-257; solution :258 (state.z)."""
     return run(PANOCIteration(**kw), maxit=maxit, tol=tol)
+
+
+# --------------------------------------------------------------------------------------
+# "next" rows: ZeroFPR                          src/algorithms/zerofpr.jl:39-225
+# --------------------------------------------------------------------------------------
+
+
+class ZeroFPRIteration:
+    """zerofpr.jl:39-52 (options), :85-111 (init), :142-220 (step)."""
+
+    def __init__(self, *, f=None, A, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
+                 minimum_gamma=1e-7, max_backtracks=20, directions=("lbfgs", 5)):
+        R = _R(x0)
+        self.f = f if f is not None else Zero()
+        self.A = np.asarray(A)
+        self.g = g if g is not None else Zero()
+        self.x0 = x0
+        self.alpha, self.beta = R(alpha), R(beta)
+        self.gamma = gamma if gamma is not None else (None if Lf is None else self.alpha / R(Lf))
+        self.adaptive = (self.gamma is None) if adaptive is None else adaptive
+        self.minimum_gamma = R(minimum_gamma)
+        self.max_backtracks = max_backtracks
+        self.directions = directions
+
+    def _f_model(self, s):  # :82-83
+        return f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / s.gamma)
+
+    def init(self):
+        R = _R(self.x0)
+        A = self.A
+        x = self.x0.copy()
+        Ax = A @ x
+        f_Ax, grad_f_Ax = value_and_gradient(self.f, Ax)
+        gamma = R(self.alpha / lower_bound_smoothness_constant_A(self.f, A, x, grad_f_Ax)) if self.gamma is None else R(self.gamma)
+        At_grad = A.T @ grad_f_Ax
+        y = x - gamma * At_grad
+        xbar, g_xbar = prox(self.g, y, gamma)
+        H = LBFGSOperator(self.directions[1], x) if self.directions else None
+        e = lambda v: np.empty_like(v)
+        return _State(x=x, Ax=Ax, f_Ax=R(f_Ax), grad_f_Ax=np.array(grad_f_Ax, copy=True), At_grad_f_Ax=At_grad, gamma=gamma,
+                      y=y, xbar=xbar, g_xbar=g_xbar, res=x - xbar, H=H, tau=R(0), Axbar=e(Ax), grad_f_Axbar=e(Ax),
+                      At_grad_f_Axbar=e(x), xbarbar=e(x), res_xbar=e(x), xbar_prev=e(x), res_xbar_prev=e(x),
+                      is_prev_set=False, d=e(x), Ad=e(Ax))
+
+    def step(self, s):
+        R = _R(s.x)
+        A = self.A
+        if self.adaptive:  # :143-164
+            gamma_prev = s.gamma
+            s.gamma, s.g_xbar, f_Axbar, f_Axbar_upp = backtrack_stepsize_A(
+                s.gamma, self.f, A, self.g, s.x, s.f_Ax, s.At_grad_f_Ax, s.y, s.xbar, s.g_xbar, s.res, s.Axbar,
+                s.grad_f_Axbar, alpha=self.alpha, minimum_gamma=self.minimum_gamma)
+            if s.gamma != gamma_prev and s.H is not None:
+                s.H.reset()
+        else:  # :165-170
+            s.Axbar[...] = A @ s.xbar
+            f_Axbar, g_ = value_and_gradient(self.f, s.Axbar)
+            s.grad_f_Axbar[...] = g_
+            f_Axbar_upp = self._f_model(s)
+        FBE_x = R(f_Axbar_upp + s.g_xbar)  # :173
+        s.At_grad_f_Axbar[...] = A.T @ s.grad_f_Axbar  # :176
+        s.y[...] = s.xbar - s.gamma * s.At_grad_f_Axbar
+        xbb, _ = prox(self.g, s.y, s.gamma)
+        s.xbarbar[...] = xbb
+        s.res_xbar[...] = s.xbar - s.xbarbar  # :179
+        if s.is_prev_set and s.H is not None:  # :181-183, :123-126
+            s.xbar_prev[...] = s.xbar - s.xbar_prev
+            s.res_xbar_prev[...] = s.res_xbar - s.res_xbar_prev
+            s.H.update(s.xbar_prev, s.res_xbar_prev)
+        s.xbar_prev[...] = s.xbar  # :185-187
+        s.res_xbar_prev[...] = s.res_xbar
+        s.is_prev_set = True
+        if s.H is not None:  # :189, :113-116
+            s.H.mul(s.d, s.res_xbar)
+            s.d *= R(-1)
+        else:
+            s.d[...] = -s.res
+        s.tau = R(1)  # :192
+        s.Ad[...] = A @ s.d
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :195
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
+        threshold = R(FBE_x - sigma * _norm(s.res) ** 2 + tol)  # :197
+        for k in range(1, self.max_backtracks + 1):  # :199-217
+            s.x[...] = s.xbar_prev + s.tau * s.d
+            s.Ax[...] = s.Axbar + s.tau * s.Ad
+            s.f_Ax, g_ = value_and_gradient(self.f, s.Ax)
+            s.grad_f_Ax[...] = g_
+            s.At_grad_f_Ax[...] = A.T @ s.grad_f_Ax
+            s.y[...] = s.x - s.gamma * s.At_grad_f_Ax
+            xb, s.g_xbar = prox(self.g, s.y, s.gamma)
+            s.xbar[...] = xb
+            s.res[...] = s.x - s.xbar
+            FBE_x = R(self._f_model(s) + s.g_xbar)
+            if FBE_x <= threshold:
+                break
+            s.tau = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))
+        return s
+
+    def __iter__(self):
+        s = self.init()
+        yield s
+        while True:
+            yield self.step(s)
+
+
+def zerofpr(*, maxit=1_000, tol=1e-8, **kw):
+    """ZeroFPR(; maxit, tol)(; kwargs...); stop zerofpr.jl:222-223 ; solution :224 (state.xbar)."""
+    it = ZeroFPRIteration(**kw)
+    R = _R(it.x0)
+    for k, s in enumerate(it, start=1):
+        if k >= maxit or _norm_inf(s.res) / s.gamma <= R(tol):
+            return s.xbar, k
+
+
+# --------------------------------------------------------------------------------------
+# "next" rows: PANOCplus                        src/algorithms/panocplus.jl:39-250
+# --------------------------------------------------------------------------------------
+
+
+class PANOCplusIteration:
+    """panocplus.jl:39-52 (options), :85-128 (init), :168-240 (step)."""
+
+    def __init__(self, *, f=None, A, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
+                 minimum_gamma=1e-7, max_backtracks=20, directions=("lbfgs", 5)):
+        R = _R(x0)
+        self.f = f if f is not None else Zero()
+        self.A = np.asarray(A)
+        self.g = g if g is not None else Zero()
+        self.x0 = x0
+        self.alpha, self.beta = R(alpha), R(beta)
+        self.gamma = gamma if gamma is not None else (None if Lf is None else self.alpha / R(Lf))
+        self.adaptive = (self.gamma is None) if adaptive is None else adaptive
+        self.minimum_gamma = R(minimum_gamma)
+        self.max_backtracks = max_backtracks
+        self.directions = directions
+
+    def _f_model(self, s):
+        return f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / s.gamma)
+
+    def init(self):
+        R = _R(self.x0)
+        A = self.A
+        x = self.x0.copy()
+        Ax = A @ x
+        f_Ax, grad_f_Ax = value_and_gradient(self.f, Ax)
+        gamma = R(self.alpha / lower_bound_smoothness_constant_A(self.f, A, x, grad_f_Ax)) if self.gamma is None else R(self.gamma)
+        At_grad = A.T @ grad_f_Ax
+        y = x - gamma * At_grad
+        z, g_z = prox(self.g, y, gamma)
+        H = LBFGSOperator(self.directions[1], x) if self.directions else None
+        e = lambda v: np.empty_like(v)
+        s = _State(x=x, Ax=Ax, f_Ax=R(f_Ax), grad_f_Ax=np.array(grad_f_Ax, copy=True), At_grad_f_Ax=At_grad, gamma=gamma, y=y,
+                   z=z, g_z=g_z, res=x - z, H=H, tau=R(0), x_prev=e(x), res_prev=e(x), d=e(x), Az=e(Ax), grad_f_Az=e(Ax),
+                   At_grad_f_Az=e(x))
+        if self.gamma is None or self.adaptive:  # :105-121
+            s.gamma, s.g_z, _, _ = backtrack_stepsize_A(
+                s.gamma, self.f, A, self.g, s.x, s.f_Ax, s.At_grad_f_Ax, s.y, s.z, s.g_z, s.res, s.Az, s.grad_f_Az,
+                alpha=self.alpha, minimum_gamma=self.minimum_gamma)
+        else:  # :122-126
+            s.Az[...] = A @ s.z
+            _, g_ = value_and_gradient(self.f, s.Az)
+            s.grad_f_Az[...] = g_
+        s.At_grad_f_Az[...] = A.T @ s.grad_f_Az  # :127
+        return s
+
+    def step(self, s):
+        R = _R(s.x)
+        A = self.A
+        s.x_prev[...] = s.x  # :170-171
+        s.res_prev[...] = s.res
+        FBE_x = R(self._f_model(s) + s.g_z)  # :174
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
+        threshold = R(FBE_x - sigma * _norm(s.res) ** 2 + tol)  # :178
+        tau_backtracks = 0
+        can_update_direction = True
+        while True:  # :183-235
+            if can_update_direction:
+                if s.H is not None:  # :130-138
+                    s.H.mul(s.d, s.res_prev)
+                    s.d *= R(-1)
+                else:
+                    s.d[...] = -s.res_prev
+                s.tau = R(1)
+                s.x[...] = s.x_prev + s.d
+                tau_backtracks = 0
+            else:
+                s.x[...] = (R(1) - s.tau) * (s.x_prev - s.res_prev) + s.tau * (s.x_prev + s.d)
+                tau_backtracks += 1
+            s.Ax[...] = A @ s.x  # :199
+            s.f_Ax, g_ = value_and_gradient(self.f, s.Ax)
+            s.grad_f_Ax[...] = g_
+            s.At_grad_f_Ax[...] = A.T @ s.grad_f_Ax
+            s.y[...] = s.x - s.gamma * s.At_grad_f_Ax  # :204
+            zz, s.g_z = prox(self.g, s.y, s.gamma)
+            s.z[...] = zz
+            s.res[...] = s.x - s.z
+            f_Az_upp = self._f_model(s)  # :208
+            s.Az[...] = A @ s.z  # :210
+            f_Az, g_ = value_and_gradient(self.f, s.Az)
+            s.grad_f_Az[...] = g_
+            if self.gamma is None or self.adaptive:  # :213-224
+                tol2 = R(10) * R(np.finfo(R).eps) * (R(1) + abs(f_Az))
+                if f_Az > f_Az_upp + tol2 and s.gamma >= self.minimum_gamma:
+                    s.gamma = R(s.gamma * R(0.5))
+                    can_update_direction = True
+                    if s.H is not None:
+                        s.H.reset()
+                    continue
+            s.At_grad_f_Az[...] = A.T @ s.grad_f_Az  # :225
+            FBE_x_new = R(f_Az_upp + s.g_z)  # :227
+            if FBE_x_new <= threshold or tau_backtracks >= self.max_backtracks:
+                break
+            s.tau = R(0) if tau_backtracks >= self.max_backtracks - 1 else R(s.tau / R(2))  # :231
+            can_update_direction = False
+        if s.H is not None:  # :237, :140-148
+            s.x_prev[...] = s.x - s.x_prev
+            s.res_prev[...] = s.res - s.res_prev
+            s.H.update(s.x_prev, s.res_prev)
+        return s
+
+    def __iter__(self):
+        s = self.init()
+        yield s
+        while True:
+            yield self.step(s)
+
+
+def panocplus(*, maxit=1_000, tol=1e-8, **kw):
+    """PANOCplus(; maxit, tol)(; kwargs...); stop panocplus.jl:243-244:
+    norm(res / gamma - At_grad_f_Ax + At_grad_f_Az, Inf) <= tol ; solution :245 (state.z)."""
+    it = PANOCplusIteration(**kw)
+    R = _R(it.x0)
+    for k, s in enumerate(it, start=1):
+        if k >= maxit or _norm_inf(s.res / s.gamma - s.At_grad_f_Ax + s.At_grad_f_Az) <= R(tol):
+            return s.z, k

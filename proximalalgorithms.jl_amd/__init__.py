@@ -20,9 +20,13 @@ from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, Fixed
 from .operators import (Composed, IndBox, LeastSquares, LogisticLoss, NormL1, SeparableQuadratic, SquaredDistance,
                         Zero, gradient_, prox, prox_, value_and_gradient)
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
+from .panocplus import PANOCplus, PANOCplusIteration
 from .sharding import ScaleComm, TorchDistributedComm, allreduce_sum_, shard_rows
 
+from .zerofpr import ZeroFPR, ZeroFPRIteration
+
 __all__ = [
+    "ZeroFPR", "ZeroFPRIteration", "PANOCplus", "PANOCplusIteration",
     "ProxGradError", "IterativeAlgorithm", "DouglasRachford", "DouglasRachfordIteration", "DouglasRachfordState",
     "SeparableQuadratic", "PANOC", "PANOCIteration", "PANOCState", "NoAcceleration", "Composed", "LogisticLoss",
     "SquaredDistance", "Context", "HIPMatrix", "HIPVector", "as_hipvector", "get_context",

@@ -89,27 +89,28 @@ class PANOCIteration:
         diff = grad_eps.axpby_(1.0, grad_eps, -1.0, grad_f_Ax)
         return R(self._mul_adj(None, diff).norm() / R(np.sqrt(x.n)))
 
-    def _backtrack_stepsize(self, s):
-        """backtrack_stepsize!  fb_tools.jl:24-63 with the linear map A and alpha = iter.alpha"""
+    def _backtrack_stepsize(self, s, z, g_z, Az, grad_f_Az):
+        """backtrack_stepsize!  fb_tools.jl:24-63 with the linear map A and alpha = iter.alpha; z / Az / grad_f_Az
+        are the forward-backward point and its images (state.z | state.xbar ...).  Returns (gamma, g_z, f_Az, f_Az_upp)."""
         R = s.x.dtype.type
         eps = R(np.finfo(R).eps)
         gamma, reduce_gamma = R(s.gamma), R(0.5)
         f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)  # :42
-        self._mul(s.Az, s.z)  # :43
-        f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)  # :44 (grad kept: :56-58)
+        self._mul(Az, z)  # :43
+        f_Az, _ = value_and_gradient_into(self.f, Az, grad_f_Az)  # :44 (grad kept: :56-58)
         tol = R(10) * eps * (R(1) + abs(f_Az))
         while f_Az > f_Az_upp + tol and gamma >= self.minimum_gamma:  # :46
             gamma = R(gamma * reduce_gamma)
             s.y.axpby_(1.0, s.x, -gamma, s.At_grad_f_Ax)
-            s.g_z = prox_(s.z, self.g, s.y, gamma)
-            s.res.axpby_(1.0, s.x, -1.0, s.z)
+            g_z = prox_(z, self.g, s.y, gamma)
+            s.res.axpby_(1.0, s.x, -1.0, z)
             f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)
-            self._mul(s.Az, s.z)
-            f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)
+            self._mul(Az, z)
+            f_Az, _ = value_and_gradient_into(self.f, Az, grad_f_Az)
             tol = R(10) * eps * (R(1) + abs(f_Az))
         if gamma < self.minimum_gamma:
             warnings.warn(f"stepsize `gamma` became too small ({gamma})")
-        return gamma, f_Az, f_Az_upp
+        return gamma, g_z, f_Az, f_Az_upp
 
     def _init(self):
         R = self.x0.dtype.type
@@ -143,7 +144,7 @@ class PANOCIteration:
         f_Az, a, b, c = inf, inf, inf, inf  # :139
         if self.adaptive:  # :141-161
             gamma_prev = s.gamma
-            s.gamma, f_Az, f_Az_upp = self._backtrack_stepsize(s)
+            s.gamma, s.g_z, f_Az, f_Az_upp = self._backtrack_stepsize(s, s.z, s.g_z, s.Az, s.grad_f_Az)
             if s.gamma != gamma_prev and s.H is not None:
                 s.H.reset_()
         else:

@@ -1,0 +1,130 @@
+"""PANOCplus -- mirror of src/algorithms/panocplus.jl.  Same device primitives as PANOC."""
+import warnings
+
+import numpy as np
+
+from .algorithm import IterativeAlgorithm
+from .operators import prox_
+from .panoc import PANOCIteration, value_and_gradient_into
+
+
+class PANOCplusState:
+    """panocplus.jl:56-75"""
+
+    pass
+
+
+class PANOCplusIteration(PANOCIteration):
+    """panocplus.jl:39-52 (same keyword constructor as PANOC), Base.iterate :85-128 / :168-240."""
+
+    def _init(self):
+        R = self.x0.dtype.type
+        s = PANOCplusState()
+        s.x = self.x0.copy()  # :86
+        s.Ax = self._mul(None, s.x)
+        s.grad_f_Ax = s.Ax.similar()
+        s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)
+        if self.gamma is None:
+            s.gamma = R(self.alpha / self._lower_bound_smoothness_constant(s.x, s.grad_f_Ax))
+        else:
+            s.gamma = R(self.gamma)
+        s.At_grad_f_Ax = self._mul_adj(None, s.grad_f_Ax)
+        s.y = s.x.similar().axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)
+        s.z = s.x.similar()
+        s.g_z = prox_(s.z, self.g, s.y, s.gamma)
+        s.res = s.x.similar().axpby_(1.0, s.x, -1.0, s.z)
+        s.H = self.directions.initialize(s.x)
+        s.tau = R(0)
+        for name in ("x_prev", "res_prev", "d", "At_grad_f_Az"):
+            setattr(s, name, s.x.similar())
+        for name in ("Az", "grad_f_Az"):
+            setattr(s, name, s.Ax.similar())
+        if self.gamma is None or self.adaptive:  # :105-121
+            s.gamma, s.g_z, _, _ = self._backtrack_stepsize(s, s.z, s.g_z, s.Az, s.grad_f_Az)
+        else:  # :122-126
+            self._mul(s.Az, s.z)
+            value_and_gradient_into(self.f, s.Az, s.grad_f_Az)
+        self._mul_adj(s.At_grad_f_Az, s.grad_f_Az)  # :127
+        return s
+
+    def _step(self, s):
+        R = s.x.dtype.type
+        s.x_prev.copy_from(s.x)  # :170-171
+        s.res_prev.copy_from(s.res)
+        FBE_x = R(self._model(s) + s.g_z)  # :174
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :176
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
+        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :178
+        tau_backtracks = 0
+        can_update_direction = True
+        while True:  # :183-235
+            if can_update_direction:
+                if s.H is not None:  # set_next_direction! :130-138
+                    s.H.mul_(s.d, s.res_prev)
+                    s.d.axpby_(-1.0, s.d)
+                else:
+                    s.d.axpby_(-1.0, s.res_prev)
+                s.tau = R(1)  # :189
+                s.x.axpby_(1.0, s.x_prev, 1.0, s.d)  # :190
+                tau_backtracks = 0
+            else:  # :193-196   x = (1 - tau) (x_prev - res_prev) + tau (x_prev + d) = x_prev - (1 - tau) res_prev + tau d
+                s.x.axpby_(1.0, s.x_prev, -(R(1) - s.tau), s.res_prev)
+                s.x.axpby_(1.0, s.x, s.tau, s.d)
+                tau_backtracks += 1
+            self._mul(s.Ax, s.x)  # :199
+            s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :200-201
+            self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :202
+            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :204
+            s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :205
+            s.res.axpby_(1.0, s.x, -1.0, s.z)  # :206
+            f_Az_upp = self._model(s)  # :208
+            self._mul(s.Az, s.z)  # :210
+            f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)  # :211-212
+            if self.gamma is None or self.adaptive:  # :213-224
+                tol2 = R(10) * R(np.finfo(R).eps) * (R(1) + abs(f_Az))
+                if f_Az > f_Az_upp + tol2 and s.gamma >= self.minimum_gamma:
+                    s.gamma = R(s.gamma * R(0.5))
+                    if s.gamma < self.minimum_gamma:
+                        warnings.warn(f"stepsize `gamma` became too small ({s.gamma})")
+                    can_update_direction = True
+                    if s.H is not None:
+                        s.H.reset_()
+                    continue
+            self._mul_adj(s.At_grad_f_Az, s.grad_f_Az)  # :225
+            FBE_x_new = R(f_Az_upp + s.g_z)  # :227
+            if FBE_x_new <= threshold or tau_backtracks >= self.max_backtracks:
+                break
+            s.tau = R(0) if tau_backtracks >= self.max_backtracks - 1 else R(s.tau / R(2))  # :231
+            can_update_direction = False
+        if s.H is not None:  # :237 (update_direction_state! :140-148)
+            s.x_prev.axpby_(1.0, s.x, -1.0, s.x_prev)
+            s.res_prev.axpby_(1.0, s.res, -1.0, s.res_prev)
+            s.H.update_(s.x_prev, s.res_prev)
+        return s
+
+
+def default_stopping_criterion(tol, iteration, state):
+    """panocplus.jl:243-244: norm(res / gamma - At_grad_f_Ax + At_grad_f_Az, Inf) <= tol"""
+    R = state.res.dtype.type
+    t = state.res.similar().axpby_(1.0 / float(state.gamma), state.res, -1.0, state.At_grad_f_Ax)
+    t.axpby_(1.0, t, 1.0, state.At_grad_f_Az)
+    return R(t.norm_inf()) <= R(tol)
+
+
+def default_solution(iteration, state):
+    """panocplus.jl:245"""
+    return state.z
+
+
+def default_display(it, iteration, state):
+    """panocplus.jl:246-253"""
+    print("%5d | %.3e | %.3e | %.3e" % (it, state.gamma, state.res.norm_inf() / state.gamma, state.tau))
+
+
+def PANOCplus(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=10,
+              display=default_display, **kwargs):
+    """panocplus.jl:282-300"""
+    if stop is None:
+        stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
+    return IterativeAlgorithm(PANOCplusIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose,
+                              freq=freq, display=display, **kwargs)

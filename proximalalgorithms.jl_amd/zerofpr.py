@@ -1,0 +1,115 @@
+"""ZeroFPR -- mirror of src/algorithms/zerofpr.jl: minimize f(A x) + g(x) with a quasi-Newton
+direction on the forward-backward residual and a line search on the forward-backward envelope.  Same device
+primitives as PANOC (panoc.py); every array statement is a kernel of libproxgrad_hip."""
+import numpy as np
+
+from .algorithm import IterativeAlgorithm
+from .operators import prox_
+from .panoc import PANOCIteration, value_and_gradient_into
+
+
+class ZeroFPRState:
+    """zerofpr.jl:56-80"""
+
+    pass
+
+
+class ZeroFPRIteration(PANOCIteration):
+    """zerofpr.jl:39-52 (same keyword constructor as PANOC), Base.iterate :85-111 / :142-220."""
+
+    def _init(self):
+        R = self.x0.dtype.type
+        s = ZeroFPRState()
+        s.x = self.x0.copy()  # :86
+        s.Ax = self._mul(None, s.x)
+        s.grad_f_Ax = s.Ax.similar()
+        s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :88
+        if self.gamma is None:  # :89-92
+            s.gamma = R(self.alpha / self._lower_bound_smoothness_constant(s.x, s.grad_f_Ax))
+        else:
+            s.gamma = R(self.gamma)
+        s.At_grad_f_Ax = self._mul_adj(None, s.grad_f_Ax)  # :93
+        s.y = s.x.similar().axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :94
+        s.xbar = s.x.similar()
+        s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :95
+        s.res = s.x.similar().axpby_(1.0, s.x, -1.0, s.xbar)
+        s.H = self.directions.initialize(s.x)
+        s.tau = R(0)
+        for name in ("At_grad_f_Axbar", "xbarbar", "res_xbar", "xbar_prev", "res_xbar_prev", "d"):
+            setattr(s, name, s.x.similar())
+        for name in ("Axbar", "grad_f_Axbar", "Ad"):
+            setattr(s, name, s.Ax.similar())
+        s.is_prev_set = False
+        return s
+
+    def _step(self, s):
+        R = s.x.dtype.type
+        if self.adaptive:  # :143-164
+            gamma_prev = s.gamma
+            s.gamma, s.g_xbar, f_Axbar, f_Axbar_upp = self._backtrack_stepsize(s, s.xbar, s.g_xbar, s.Axbar, s.grad_f_Axbar)
+            if s.gamma != gamma_prev and s.H is not None:
+                s.H.reset_()
+        else:  # :165-170
+            self._mul(s.Axbar, s.xbar)
+            f_Axbar, _ = value_and_gradient_into(self.f, s.Axbar, s.grad_f_Axbar)
+            f_Axbar_upp = self._model(s)
+        FBE_x = R(f_Axbar_upp + s.g_xbar)  # :173
+        self._mul_adj(s.At_grad_f_Axbar, s.grad_f_Axbar)  # :176
+        s.y.axpby_(1.0, s.xbar, -s.gamma, s.At_grad_f_Axbar)  # :177
+        prox_(s.xbarbar, self.g, s.y, s.gamma)  # :178
+        s.res_xbar.axpby_(1.0, s.xbar, -1.0, s.xbarbar)  # :179
+        if s.is_prev_set and s.H is not None:  # :181-183 (update_direction_state! :118-126)
+            s.xbar_prev.axpby_(1.0, s.xbar, -1.0, s.xbar_prev)
+            s.res_xbar_prev.axpby_(1.0, s.res_xbar, -1.0, s.res_xbar_prev)
+            s.H.update_(s.xbar_prev, s.res_xbar_prev)
+        s.xbar_prev.copy_from(s.xbar)  # :185-187
+        s.res_xbar_prev.copy_from(s.res_xbar)
+        s.is_prev_set = True
+        if s.H is not None:  # :189 (set_next_direction! :113-116)
+            s.H.mul_(s.d, s.res_xbar)
+            s.d.axpby_(-1.0, s.d)
+        else:
+            s.d.axpby_(-1.0, s.res)
+        s.tau = R(1)  # :192
+        self._mul(s.Ad, s.d)  # :193
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :195
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
+        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :197
+        for k in range(1, self.max_backtracks + 1):  # :199-217
+            s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :200
+            s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :201
+            s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :203-204
+            self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :205
+            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :206
+            s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :207
+            s.res.axpby_(1.0, s.x, -1.0, s.xbar)  # :208
+            FBE_x = R(self._model(s) + s.g_xbar)  # :209
+            if FBE_x <= threshold:
+                break
+            s.tau = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))  # :215
+        return s
+
+
+def default_stopping_criterion(tol, iteration, state):
+    """zerofpr.jl:222-223"""
+    R = state.res.dtype.type
+    return R(state.res.norm_inf()) / R(state.gamma) <= R(tol)
+
+
+def default_solution(iteration, state):
+    """zerofpr.jl:224"""
+    return state.xbar
+
+
+def default_display(it, iteration, state):
+    """zerofpr.jl:225-232"""
+    print("%5d | %.3e | %.3e | %.3e" % (it, state.gamma, state.res.norm_inf() / state.gamma, state.tau))
+
+
+def ZeroFPR(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=10,
+            display=default_display, **kwargs):
+    """zerofpr.jl:262-280"""
+    if stop is None:
+        stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
+    return IterativeAlgorithm(ZeroFPRIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose, freq=freq,
+                              display=display, **kwargs)

@@ -830,3 +830,55 @@ def test_c_abi_client_standalone(pa, tmp_path):
         run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600,
                              env=dict(os.environ, LD_LIBRARY_PATH=pkg + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
         assert run.returncode == 0 and "C_ABI_OK" in run.stdout, run.stdout + run.stderr
+
+
+# ------------------------------------------------------------------------------------------------
+# ZeroFPR / PANOCplus
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("algo", ["ZeroFPR", "PANOCplus"])
+def test_zerofpr_panocplus_known_answers(pa, dtype, algo):
+    """test_lasso_small.jl:137-157 / :183-203 (it < 20) and test_sparse_logistic_small.jl:90-99 / :112-121."""
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    solver, osolver = getattr(pa, algo), (o.zerofpr if algo == "ZeroFPR" else o.panocplus)
+    for kw in (dict(Lf=Lf), dict(adaptive=True)):
+        x, it = solver(tol=rv.LASSO_SMALL_TOL)(x0=x0, f=pa.SquaredDistance(b), A=A, g=pa.NormL1(lam), **kw)
+        assert x.dtype == dtype and np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+        assert it < 20
+        _, ito = osolver(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.SquaredDistance(b), A=A, g=o.NormL1(lam), **kw)
+        assert abs(it - ito) <= 1
+    xs = rv.LOGISTIC_XSTAR.astype(dtype)
+    x, it = solver(tol=rv.LOGISTIC_TOL, adaptive=True)(x0=x0, f=pa.LogisticLoss(b), A=A, g=pa.NormL1(dtype(rv.LOGISTIC_LAM)))
+    assert np.max(np.abs(x - xs)) <= 1e-4 and it < (25 if algo == "ZeroFPR" else 50)
+    assert np.all(x0 == 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_panoc_equals_panocplus_on_device(pa, dtype):
+    """test/problems/test_equivalence.jl:86-114"""
+    A, b, lam, Lf = lasso_small(dtype)
+    gamma = dtype(0.95) / Lf
+    x0 = np.zeros(5, dtype)
+    p1 = pa.PANOCIteration(f=pa.Composed(pa.SquaredDistance(b), A), g=pa.NormL1(lam), x0=x0, gamma=gamma)
+    p2 = pa.PANOCplusIteration(f=pa.Composed(pa.SquaredDistance(b), A), g=pa.NormL1(lam), x0=x0, gamma=gamma)
+    for s1, s2 in itertools.islice(zip(p1, p2), 10):
+        np.testing.assert_allclose(s1.z.numpy(), s2.z.numpy(), rtol=2e-3 if dtype == np.float32 else 1e-7,
+                                   atol=1e-5 if dtype == np.float32 else 1e-9)
+
+
+@pytest.mark.parametrize("algo", ["ZeroFPR", "PANOCplus"])
+def test_zerofpr_panocplus_against_oracle_f64(pa, algo):
+    m, n = 300, 800
+    A, b, lam = synthetic_problem(m, n, np.float64, seed=11)
+    x0 = np.zeros(n)
+    It, Io = (pa.ZeroFPRIteration, o.ZeroFPRIteration) if algo == "ZeroFPR" else (pa.PANOCplusIteration, o.PANOCplusIteration)
+    it_g = It(f=pa.SquaredDistance(b), A=A, g=pa.NormL1(lam), x0=x0)
+    it_o = Io(f=o.SquaredDistance(b), A=A, g=o.NormL1(lam), x0=x0)
+    for k, (sg, so) in enumerate(itertools.islice(zip(it_g, it_o), 12)):
+        assert float(sg.gamma) == pytest.approx(float(so.gamma), rel=1e-12)
+        zg = (sg.xbar if algo == "ZeroFPR" else sg.z).numpy()
+        zo = so.xbar if algo == "ZeroFPR" else so.z
+        assert np.max(np.abs(zg - zo)) <= 1e-8 * max(1.0, np.max(np.abs(zo))), k

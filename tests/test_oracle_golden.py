@@ -362,3 +362,39 @@ class TestPANOCPins:
                               gamma=gamma, max_backtracks=1, directions=None)
         for s_fb, s_pn in itertools.islice(zip(fb, pn), 10):
             np.testing.assert_allclose(s_fb.z, s_pn.z, rtol=1e-4 if dtype == np.float32 else 1e-8, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+class TestZeroFPRPANOCplusPins:
+    def test_lasso_small(self, dtype):
+        """test/problems/test_lasso_small.jl:137-157 (ZeroFPR) and :183-203 (PANOCplus): it < 20"""
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        for solver in (o.zerofpr, o.panocplus):
+            for kw in (dict(Lf=Lf), dict(adaptive=True)):
+                x, it = solver(tol=rv.LASSO_SMALL_TOL, x0=x0, f=o.SquaredDistance(b), A=A, g=o.NormL1(lam), **kw)
+                assert x.dtype == dtype and np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+                assert it < 20, (solver.__name__, kw, it)
+
+    def test_sparse_logistic(self, dtype):
+        """test/problems/test_sparse_logistic_small.jl:90-99 (ZeroFPR, it < 25) and :112-121 (PANOCplus, it < 50)"""
+        A = np.asfortranarray(rv.LASSO_SMALL_A.astype(dtype))
+        b = rv.LASSO_SMALL_B.astype(dtype)
+        xs = rv.LOGISTIC_XSTAR.astype(dtype)
+        x0 = np.zeros(5, dtype)
+        x, it = o.zerofpr(tol=rv.LOGISTIC_TOL, adaptive=True, x0=x0, f=o.LogisticLoss(b), A=A, g=o.NormL1(dtype(rv.LOGISTIC_LAM)))
+        assert np.max(np.abs(x - xs)) <= 1e-4 and it < 25
+        x, it = o.panocplus(tol=rv.LOGISTIC_TOL, adaptive=True, x0=x0, f=o.LogisticLoss(b), A=A, g=o.NormL1(dtype(rv.LOGISTIC_LAM)))
+        assert np.max(np.abs(x - xs)) <= 1e-4 and it < 50
+
+    def test_panoc_equals_panocplus(self, dtype):
+        """test/problems/test_equivalence.jl:86-114: same z for 10 iterations at gamma = 0.95 / ||A||^2"""
+        A, b, lam, Lf = lasso_small(dtype)
+        gamma = dtype(0.95) / Lf
+        x0 = np.zeros(5, dtype)
+        fA = o.Composed(o.SquaredDistance(b), A)
+        eye = np.eye(5, dtype=dtype)
+        p1 = o.PANOCIteration(f=fA, A=eye, g=o.NormL1(lam), x0=x0, gamma=gamma)
+        p2 = o.PANOCplusIteration(f=fA, A=eye, g=o.NormL1(lam), x0=x0, gamma=gamma)
+        for s1, s2 in itertools.islice(zip(p1, p2), 10):
+            np.testing.assert_allclose(s1.z, s2.z, rtol=2e-3 if dtype == np.float32 else 1e-7, atol=1e-5 if dtype == np.float32 else 1e-9)
