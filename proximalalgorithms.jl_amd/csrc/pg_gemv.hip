@@ -269,8 +269,9 @@ PlanN plan_n(const pg_mat* A) {
   PlanN p;
   const int64_t rows_per_rg = 1024 / (int64_t)pg_sizeof(A->dtype);
   p.n_rowgroups = (int)(A->ld / rows_per_rg);
-  // Measured on MI355X (scripts/tune_gemv.py, profiles/r1_tune_gemv.log): both passes peak with ~32-64 KiB of
-  // loads in flight per CU (R*U KiB per wave x 8 waves/CU); more in flight costs 3-5 % (DRAM queueing).
+  // Measured on MI355X (scripts/tune_gemv.py, profiles/r1_tune_gemv.log): both passes peak with only ~6-8 MiB of
+  // loads in flight chip-wide (pass N: 768 waves x R*U KiB, i.e. 3 waves per CU on average, 192 workgroups);
+  // deeper queues cost 3-5 % (DRAM page conflicts / queueing), shallower ones starve the memory system.
   if (p.n_rowgroups >= 4) {
     p.R = 4;
     p.U = 2;
@@ -291,7 +292,8 @@ PlanN plan_n(const pg_mat* A) {
   const int TB = 4 / p.TW;
   p.n_tile_groups = (p.n_tiles + TB - 1) / TB;
   const int64_t ncb = A->n > 0 ? (A->n + p.U - 1) / p.U : 1;
-  const int64_t target_waves = (int64_t)A->ctx->num_cu * env_int("PG_N_WAVES_PER_CU", 8);
+  // ~3 active waves per CU for tall matrices (>= 8 row tiles), 4 otherwise (measured optimum, see above)
+  const int64_t target_waves = (int64_t)A->ctx->num_cu * env_int("PG_N_WAVES_PER_CU", p.n_tiles >= 8 ? 3 : 4);
   int64_t S = target_waves / ((int64_t)p.n_tile_groups * TB);
   if (S < 1) S = 1;
   if (S > ncb) S = ncb;
@@ -424,7 +426,21 @@ pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64
 // Tunables (environment, for experiments): PG_T_C, PG_T_UR, PG_T_WAVES, PG_T_BLOCKS_PER_CU.
 template <typename T>
 pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64_t col0, int64_t ncols) {
-  const int C = env_int("PG_T_C", 2), UR = env_int("PG_T_UR", 4), W = env_int("PG_T_WAVES", 8);
+  // default: 2 adjacent columns x UR row groups in flight per wave; 2-wave workgroups, one per CU, when a column
+  // is long enough for UR = 8 (512 waves x 16 KiB = 8 MiB in flight chip-wide); shorter columns use more waves
+  int dC = 2, dUR = 8, dW = 2;
+  if (nrg < 16) {  // short columns: 4 columns per wave so that a wave still moves >= 16 KiB per reduction
+    dC = 4;
+    dUR = 4;
+    dW = 4;
+  }
+  if (nrg < 4) {
+    dC = 2;
+    dUR = 2;
+    dW = 8;
+  }
+  if (nrg < 2) dC = 4;
+  const int C = env_int("PG_T_C", dC), UR = env_int("PG_T_UR", dUR), W = env_int("PG_T_WAVES", dW);
 #define PG_T_CASE(CC, UU, WW) \
   if (C == CC && UR == UU && W == WW) return launch_t_cuw<T, CC, UU, WW>(A, rg_begin, nrg, r, g, col0, ncols)
   PG_T_CASE(4, 4, 8);
@@ -448,6 +464,14 @@ pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64_t c
   PG_T_CASE(2, 2, 8);
   PG_T_CASE(2, 4, 2);
   PG_T_CASE(2, 8, 2);
+  PG_T_CASE(2, 16, 2);
+  PG_T_CASE(1, 16, 2);
+  PG_T_CASE(2, 8, 1);
+  PG_T_CASE(2, 16, 1);
+  PG_T_CASE(4, 8, 2);
+  PG_T_CASE(4, 4, 2);
+  PG_T_CASE(4, 8, 4);
+  PG_T_CASE(4, 2, 8);
 #undef PG_T_CASE
   pg_set_error("no gemv_t instantiation for C=%d UR=%d WAVES=%d", C, UR, W);
   return PG_ERR_UNSUPPORTED;

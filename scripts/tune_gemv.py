@@ -31,13 +31,13 @@ def setenv(**kw):
             os.environ[k] = str(v)
 
 
-NRU = [(4, 2), (4, 4), (4, 1), (8, 1), (8, 2), (16, 1), (16, 2), (2, 8), (2, 4), (2, 2)]
-NTW = [1, 2]
-NWPC = [2, 4, 6, 8, 12]
-TCUW = [(2, 4, 8), (2, 4, 4), (2, 8, 4), (2, 16, 4), (2, 16, 8), (2, 8, 8), (1, 8, 8), (1, 16, 8), (1, 16, 4), (2, 2, 8),
-        (2, 4, 2), (2, 8, 2), (4, 4, 8), (4, 4, 4), (2, 4, 16)]
-TB = [1, 2, 3]
-REPS = 8
+NRU = [(2, 2), (4, 1), (4, 2), (8, 1), (2, 4), (8, 2), (4, 4)]
+NTW = [1]
+NWPC = [3, 4, 5, 6, 7, 8, 10]
+TCUW = [(2, 4, 8), (2, 4, 4), (2, 8, 4), (2, 16, 4), (2, 8, 2), (2, 16, 2), (1, 16, 2), (1, 16, 4), (2, 8, 1), (2, 16, 1),
+        (4, 8, 2), (4, 4, 2), (4, 8, 4), (4, 4, 4), (2, 8, 8)]
+TB = [1, 2]
+REPS = 20
 
 
 def main():
