@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--cpu-steps", type=int, default=10)
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
+    p.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                   help="strong: the global problem is fixed and its rows are split over the ranks (default); weak: every "
+                        "rank holds --m rows (BASELINE config 5 = --scaling weak --m 16384 on 8 GPUs: 131072 x 2^20)")
     p.add_argument("--no-overlap", action="store_true", help="disable the chunked asynchronous all-reduce (N > 1)")
     p.add_argument("--share-device", action="store_true",
                    help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
@@ -129,6 +132,8 @@ def main():
 
     m_glob, n = WORKLOADS[args.workload]
     m_glob = args.m or m_glob
+    if args.scaling == "weak":
+        m_glob *= world
     n = args.n or n
     dtype = np.float32
     ctx = pa.get_context(local_rank)
@@ -245,7 +250,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
