@@ -22,6 +22,32 @@ __device__ __forceinline__ V nt_load(const V* p) {
   return __builtin_nontemporal_load(p);
 }
 
+// Wave-wide sum in every lane.  The four intra-row steps are DPP moves (no LDS round trip): quad_perm xor 1 and
+// xor 2, then row_half_mirror / row_mirror (lane i <-> 7-i / 15-i: after the quad steps every lane of a quad holds
+// the quad sum, so the mirrored partner contributes exactly the other quad / the other half-row); the two
+// cross-row steps (xor 16, xor 32) go through ds_bpermute.  Fixed order => deterministic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_allsum(T v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  (xor 1)
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  (xor 2)
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  v += pg_shfl_xor(v, 16);
+  v += pg_shfl_xor(v, 32);
+  return v;
+}
+
 // -------------------------------------------------------------------------------------------------
 // pass N, stage 1: partials[slot][i] = sum_{j in columns of slot} A[i, j] * x[j]
 // Workgroup = 4 waves = TB adjacent row tiles x TW column slots (TB * TW = 4).  Waves that share a slot take
@@ -221,12 +247,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict_
         for (int e = 0; e < VEC; ++e) acc[c] = fma(a[e], rv[e], acc[c]);
       }
     }
-    // wave reduction (xor butterfly: every lane ends with the full sums, fixed order)
+    // wave reduction: every lane ends with the full sums, fixed order
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) acc[c] += pg_shfl_xor(acc[c], off);
-    }
+    for (int c = 0; c < C; ++c) acc[c] = wave_allsum(acc[c]);
     T out = acc[0];
 #pragma unroll
     for (int c = 1; c < C; ++c) out = (lane == c) ? acc[c] : out;

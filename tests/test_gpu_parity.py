@@ -476,18 +476,23 @@ def test_nccl_world_size_one(pa):
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        m, n = 256, 512
-        A, b, lam = synthetic_problem(m, n, np.float32, seed=5)
-        ctx2 = pa.Context()
-        comm = pa.TorchDistributedComm()
-        f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
-        f_pl = pa.LeastSquares(A, b)
-        x = np.random.default_rng(1).standard_normal(n).astype(np.float32)
-        fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
-        fp, gp = f_pl.value_and_gradient(pa.HIPVector.from_numpy(x))
-        assert comm.calls == 1
-        assert float(fs) == pytest.approx(float(fp), rel=1e-6)
-        assert np.array_equal(gs.numpy(), gp.numpy())
+        for n, expect_calls in ((512, 1), (20000, 4)):  # blocking path; chunked asynchronous path (async_op=True + wait)
+            m = 256
+            A, b, lam = synthetic_problem(m, n, np.float32, seed=5)
+            ctx2 = pa.Context()
+            comm = pa.TorchDistributedComm()
+            f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
+            f_pl = pa.LeastSquares(A, b)
+            x = np.random.default_rng(1).standard_normal(n).astype(np.float32)
+            fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
+            fp, gp = f_pl.value_and_gradient(pa.HIPVector.from_numpy(x))
+            assert comm.calls == expect_calls and comm.elements == n + 1
+            assert float(fs) == pytest.approx(float(fp), rel=1e-6)
+            assert np.array_equal(gs.numpy(), gp.numpy())
+            # a short sharded FFB run through RCCL == the plain run
+            z1, k1 = pa.FastForwardBackward(tol=1e-3, maxit=40)(x0=pa.HIPVector.zeros(n, np.float32, ctx2), f=f_sh, g=pa.NormL1(lam))
+            z2, k2 = pa.FastForwardBackward(tol=1e-3, maxit=40)(x0=np.zeros(n, np.float32), f=f_pl, g=pa.NormL1(lam))
+            assert k1 == k2 and np.max(np.abs(z1.numpy() - z2)) <= 1e-5 * max(1.0, np.max(np.abs(z2)))
     finally:
         dist.destroy_process_group()
 
@@ -882,3 +887,30 @@ def test_zerofpr_panocplus_against_oracle_f64(pa, algo):
         zg = (sg.xbar if algo == "ZeroFPR" else sg.z).numpy()
         zo = so.xbar if algo == "ZeroFPR" else so.z
         assert np.max(np.abs(zg - zo)) <= 1e-8 * max(1.0, np.max(np.abs(zo))), k
+
+
+# ------------------------------------------------------------------------------------------------
+# verbose driver loop (test/problems/test_verbose.jl:36-78): the display path does not change results
+# ------------------------------------------------------------------------------------------------
+
+
+def test_verbose_display_does_not_change_results(pa, capsys):
+    dtype = np.float64
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    f, g = pa.LeastSquares(A, b), pa.NormL1(lam)
+    for solver_name, kw, bound in (("ForwardBackward", dict(Lf=Lf), 150), ("ForwardBackward", dict(adaptive=True), 300),
+                                   ("FastForwardBackward", dict(Lf=Lf), 100), ("FastForwardBackward", dict(adaptive=True), 200)):
+        x, it = getattr(pa, solver_name)(tol=rv.LASSO_SMALL_TOL, verbose=True, freq=10)(x0=x0, f=f, g=g, **kw)
+        xq, itq = getattr(pa, solver_name)(tol=rv.LASSO_SMALL_TOL)(x0=x0, f=f, g=g, **kw)
+        out = capsys.readouterr().out.strip().splitlines()
+        assert it == itq and np.array_equal(x, xq) and it < bound
+        assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR)) <= rv.LASSO_SMALL_TOL
+        # one line every `freq` iterations plus the final one (src/ProximalAlgorithms.jl:117-121), "%5d | %.3e | %.3e"
+        assert len(out) == it // 10 + (0 if it % 10 == 0 else 1) or len(out) == it // 10 + 1
+        k_last, gamma_s, res_s = [t.strip() for t in out[-1].split("|")]
+        assert int(k_last) == it and float(gamma_s) > 0 and float(res_s) <= rv.LASSO_SMALL_TOL
+    y, it = pa.DouglasRachford(tol=1e-6, verbose=True, freq=5)(x0=x0, f=pa.SeparableQuadratic(2.0, -1.0), g=pa.IndBox(-0.25, 0.25), gamma=1.0)
+    assert np.allclose(y, 0.25) and capsys.readouterr().out.count("|") >= 1
+    x, it = pa.PANOC(tol=rv.LASSO_SMALL_TOL, verbose=True, freq=2)(x0=x0, f=pa.SquaredDistance(b), A=A, g=g, Lf=Lf)
+    assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR)) <= rv.LASSO_SMALL_TOL and capsys.readouterr().out.count("|") >= 3
