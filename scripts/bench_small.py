@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""BASELINE config 1 and the reference's shipped instances: launch-bound sizes.  Reports solve time and it/s on the
+GPU (host loop and in-library loop pg_iter_run) next to the CPU restatement -- these sizes are far below what a GPU is
+for; the numbers document the per-iteration floor of the current (non-graph) path."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import proximalalgorithms.jl_amd as pa  # noqa: E402
+from oracle import proxgrad_oracle as o  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def instances():
+    A, b, _ = o.synthetic_lasso(200, 500, seed=0, dtype=np.float64)
+    yield "config1 synthetic 200x500 f64", A, b, 0.1 * np.max(np.abs(A.T @ b))
+    for name in ("lasso_tiny", "lasso_small", "lasso_medium"):
+        d = np.load(os.path.join(GOLDEN, name + ".npz"))
+        yield f"{name} {d['A'].shape[0]}x{d['A'].shape[1]} f64", d["A"], d["b"], float(d["lam"])
+
+
+def main():
+    pa.get_context()
+    out = []
+    for name, A, b, lam in instances():
+        n = A.shape[1]
+        x0 = np.zeros(n)
+        f, g = pa.LeastSquares(A, b), pa.NormL1(lam)
+        pa.FastForwardBackward(tol=1e-6)(x0=x0, f=f, g=g)  # warm-up
+        t0 = time.perf_counter()
+        z, k = pa.FastForwardBackward(tol=1e-6)(x0=x0, f=f, g=g)  # adaptive, like benchmark/benchmarks.jl:55-61
+        t_host = time.perf_counter() - t0
+        it = pa.FastForwardBackwardIteration(f=f, g=g, x0=x0)
+        gen = iter(it)
+        next(gen)
+        t0 = time.perf_counter()
+        k_lib, _ = it._fused.run(1, 10_000, 1e-6)
+        t_lib = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        zo, ko = o.fast_forward_backward(tol=1e-6, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
+        t_cpu = time.perf_counter() - t0
+        out.append({"instance": name, "k_gpu": k, "k_lib": k_lib, "k_cpu": ko, "gpu_host_loop_it_s": k / t_host,
+                    "gpu_library_loop_it_s": k_lib / t_lib, "cpu_numpy_it_s": ko / t_cpu,
+                    "max_abs_diff": float(np.max(np.abs(z - zo)))})
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

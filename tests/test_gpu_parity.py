@@ -438,17 +438,18 @@ def test_lbfgs_large_matches_oracle(pa):
 # ------------------------------------------------------------------------------------------------
 
 
+@pytest.mark.parametrize("ls_lam", [1.0, 2.5])
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_sharded_payload_with_emulated_allreduce(pa, dtype, overlap):
+def test_sharded_payload_with_emulated_allreduce(pa, dtype, overlap, ls_lam):
     """Two 'ranks' holding identical row shards: the SUM all-reduce equals x2, so the sharded operator on one
     shard must equal the plain operator on the stacked matrix [A; A], [b; b]."""
     m, n = 300, 700 if not overlap else 20000  # the chunked (pipelined) path needs n >= 4 * 4096
     A, b, lam = synthetic_problem(m, n, dtype, seed=4)
     ctx2 = pa.Context()  # separate context so the callback does not leak into other tests
     comm = pa.ScaleComm(2, overlap=overlap)
-    f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
-    f_full = pa.LeastSquares(np.vstack([A, A]), np.concatenate([b, b]))
+    f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), lam=ls_lam, comm=comm)
+    f_full = pa.LeastSquares(np.vstack([A, A]), np.concatenate([b, b]), lam=ls_lam)
     x = np.random.default_rng(0).standard_normal(n).astype(dtype)
     fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
     ff, gf = f_full.value_and_gradient(pa.HIPVector.from_numpy(x))
@@ -914,3 +915,57 @@ def test_verbose_display_does_not_change_results(pa, capsys):
     assert np.allclose(y, 0.25) and capsys.readouterr().out.count("|") >= 1
     x, it = pa.PANOC(tol=rv.LASSO_SMALL_TOL, verbose=True, freq=2)(x0=x0, f=pa.SquaredDistance(b), A=A, g=g, Lf=Lf)
     assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR)) <= rv.LASSO_SMALL_TOL and capsys.readouterr().out.count("|") >= 3
+
+
+# ------------------------------------------------------------------------------------------------
+# degenerate sizes and error paths
+# ------------------------------------------------------------------------------------------------
+
+
+def test_degenerate_sizes(pa):
+    # n = 0 columns: f(x) = ||b||^2 / 2, empty gradient
+    b = np.array([1.0, -2.0, 3.0])
+    f = pa.LeastSquares(np.zeros((3, 0)), b)
+    fx, g = f.value_and_gradient(pa.HIPVector.zeros(0, np.float64))
+    assert float(fx) == pytest.approx(7.0) and g.numpy().shape == (0,)
+    # m = 0 rows: f = 0, zero gradient
+    f = pa.LeastSquares(np.zeros((0, 4)), np.zeros(0))
+    fx, g = f.value_and_gradient(pa.HIPVector.from_numpy(np.ones(4)))
+    assert float(fx) == 0.0 and np.array_equal(g.numpy(), np.zeros(4))
+    # a solve on a 1 x 1 problem: min (a x - b)^2 / 2 + lam |x|  ->  soft threshold in closed form
+    a, bb, lam = 2.0, 3.0, 0.5
+    x, it = pa.ForwardBackward(tol=1e-10)(x0=np.zeros(1), f=pa.LeastSquares(np.array([[a]]), np.array([bb])), g=pa.NormL1(lam), Lf=a * a)
+    assert x[0] == pytest.approx((a * bb - lam) / (a * a), abs=1e-9)
+    # empty vectors through the BLAS-1 entry points
+    e = pa.HIPVector.zeros(0, np.float32)
+    assert float(e.dot(e)) == 0.0 and float(e.norm_inf()) == 0.0
+    y, gy = pa.prox(pa.NormL1(1.0), e, 1.0)
+    assert y.numpy().shape == (0,) and float(gy) == 0.0
+
+
+def test_error_paths_report_messages(pa):
+    import ctypes as C
+
+    from proximalalgorithms.jl_amd import _lib
+
+    lib = _lib.load()
+    ctx = pa.get_context()
+    h = C.c_void_p()
+    assert lib.pg_mat_create(ctx.handle, 7, 4, 4, C.byref(h)) == -1 and b"dtype" in lib.pg_last_error()
+    assert lib.pg_mat_create(ctx.handle, 0, -1, 4, C.byref(h)) == -1
+    assert lib.pg_ctx_create(99, None, C.byref(h)) == -1 and b"device" in lib.pg_last_error()
+    with pytest.raises(ValueError):
+        pa.LeastSquares(np.eye(3, dtype=np.float32), np.ones(4, np.float32))  # b of the wrong length
+    with pytest.raises(ValueError):
+        pa.LeastSquares(np.eye(3, dtype=np.float32), np.ones(3, np.float64))  # mixed precisions
+    with pytest.raises(TypeError):
+        pa.HIPVector.from_numpy(np.ones(3, np.int32))
+    with pytest.raises(pa.ProxGradError):
+        ctx2 = pa.Context()
+        A = pa.HIPMatrix.from_numpy(np.eye(3), ctx2)
+        _lib.call("pg_ls_create", ctx.handle, A.handle, pa.HIPVector.zeros(3, np.float64).vp, 1.0, C.byref(h))  # foreign context
+    x = pa.HIPVector.zeros(5, np.float32)
+    with pytest.raises(ValueError):
+        x.axpby_(1.0, pa.HIPVector.zeros(6, np.float32))
+    with pytest.raises(TypeError):
+        pa.ForwardBackwardIteration(f=pa.Zero(), g=pa.NormL1(1.0), x0=np.zeros(3), engine="fused")
