@@ -1,5 +1,7 @@
 // Generic elementwise / reduction driver shared by pg_vec.hip and pg_lbfgs.hip.
 #pragma once
+#include <cstdlib>
+
 #include "pg_internal.h"
 
 namespace pgew {
@@ -13,7 +15,8 @@ constexpr int EW_BS_REDUCE = 1024;
 inline unsigned grid_for(int64_t n_items, int num_cu, bool reduces) {
   const int bs = reduces ? EW_BS_REDUCE : EW_BS_STREAM;
   int64_t blocks = (n_items + bs - 1) / bs;
-  const int64_t cap = (int64_t)num_cu * (reduces ? 1 : 8);
+  static const int reduce_per_cu = getenv("PG_EW_REDUCE_BLOCKS_PER_CU") ? atoi(getenv("PG_EW_REDUCE_BLOCKS_PER_CU")) : 1;
+  const int64_t cap = (int64_t)num_cu * (reduces ? reduce_per_cu : 8);
   if (blocks > cap) blocks = cap;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
