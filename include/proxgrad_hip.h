@@ -274,6 +274,12 @@ pg_status pg_iter_step(pg_iter* it, double host_beta, pg_iter_scalars* out);
  * Call after pg_iter_init; k_start is the current k (1 right after init). */
 pg_status pg_iter_run(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out,
                       pg_iter_scalars* out);
+/* Device-resident variant for fixed-step runs: `check_every` iterations are enqueued back to
+ * back with no host synchronisation in between (nothing the host decides depends on them), then the scalar block is
+ * read once and the stopping rule evaluated; k_out advances in steps of `check_every` (capped by maxit).  With
+ * check_every = 1 this is pg_iter_run.  Not available with an adaptive step: backtracking is a host decision. */
+pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int32_t check_every,
+                              int64_t* k_out, pg_iter_scalars* out);
 pg_status pg_iter_state_view(pg_iter* it, pg_iter_state* out);
 
 /* ------------------------------------------------------------------ L-BFGS (config 4) --- */

@@ -47,9 +47,15 @@ class FusedIteration:
             warnings.warn(f"stepsize `gamma` became too small ({self.scalars.gamma})")  # fb_tools.jl:59-61
         return self.scalars
 
-    def run(self, k_start, maxit, tol):
+    def run(self, k_start, maxit, tol, check_every=1):
+        """IterativeAlgorithm loop inside the library; check_every > 1 (fixed step only) enqueues that many
+        iterations between host synchronisations (pg_iter_run_batched)."""
         k = C.c_int64()
-        call("pg_iter_run", self._h, int(k_start), int(maxit), float(tol), C.byref(k), C.byref(self.scalars))
+        if check_every > 1:
+            call("pg_iter_run_batched", self._h, int(k_start), int(maxit), float(tol), int(check_every), C.byref(k),
+                 C.byref(self.scalars))
+        else:
+            call("pg_iter_run", self._h, int(k_start), int(maxit), float(tol), C.byref(k), C.byref(self.scalars))
         return k.value, self.scalars
 
     def view(self):

@@ -38,6 +38,7 @@ struct pg_iter {
   // residual reuse (adaptive FFB): A z - b and A z_prev - b, so that A x - b at the extrapolated point needs no pass
   void *rz = nullptr, *rz_prev = nullptr;
   bool rz_valid = false;
+  bool defer_sync = false;  // pg_iter_run_batched: enqueue without reading the scalar block back
 };
 
 namespace {
@@ -97,6 +98,7 @@ pg_status epilogue_and_read(pg_iter* it, bool read_f) {
   pg_ctx* c = it->ctx;
   PG_TRY(pg_fb_epilogue_async(c, it->dtype, it->n, it->x, it->grad_f_x, it->gamma, it->o.g_kind, it->o.g_p0,
                               it->o.g_p1, it->y, it->z, it->res));
+  if (it->defer_sync) return PG_OK;  // scalars stay on the device side until the batch is synchronised
   PG_TRY(pg_read_scalars(c, PG_S_F, 5));
   if (read_f) it->f_x = Arith<T>::r(c->hscal[PG_S_F]);
   it->g_z = Arith<T>::r(c->hscal[PG_S_GZ]);
@@ -377,6 +379,43 @@ pg_status pg_iter_run(pg_iter* it, int64_t k_start, int64_t maxit, double tol, i
     if (k >= maxit || stop) break;
     PG_TRY(f32 ? iter_step<float>(it, 0.0) : iter_step<double>(it, 0.0));
     ++k;
+  }
+  *k_out = k;
+  fill_scalars(it, out);
+  return PG_OK;
+}
+
+// Fixed-step iterations need no scalar from the previous one (gamma is constant, beta comes from gamma), so a batch
+// of `check_every` iterations is enqueued back to back and the host synchronises once per batch: the stopping rule
+// is then evaluated every `check_every` iterations (k_out is a multiple of the batch size past k_start, or maxit).
+pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int32_t check_every,
+                              int64_t* k_out, pg_iter_scalars* out) {
+  PG_REQUIRE(it != nullptr && k_out != nullptr, "null argument");
+  PG_REQUIRE(it->initialized, "pg_iter_init has not been called");
+  PG_REQUIRE(check_every >= 1, "check_every must be >= 1");
+  PG_REQUIRE(!it->adaptive, "batched runs need a fixed step (the line search is a host decision per iteration)");
+  PG_REQUIRE(it->o.seq_kind != PG_SEQ_HOST || !it->o.fast, "PG_SEQ_HOST needs per-step coefficients");
+  int64_t k = k_start;
+  const bool f32 = it->dtype == PG_F32;
+  pg_ctx* c = it->ctx;
+  for (;;) {
+    const bool stop = f32 ? ((float)it->res_inf / (float)it->gamma <= (float)tol)
+                          : (it->res_inf / it->gamma <= tol);
+    if (k >= maxit || stop) break;
+    int64_t nb = maxit - k < check_every ? maxit - k : check_every;
+    it->defer_sync = true;
+    pg_status st = PG_OK;
+    for (int64_t j = 0; j < nb && st == PG_OK; ++j) st = f32 ? iter_step<float>(it, 0.0) : iter_step<double>(it, 0.0);
+    it->defer_sync = false;
+    PG_TRY(st);
+    k += nb;
+    // one synchronisation per batch: the scalar block now describes the last enqueued iteration
+    PG_TRY(pg_read_scalars(c, PG_S_F, 5));
+    it->f_x = f32 ? (double)(float)c->hscal[PG_S_F] : c->hscal[PG_S_F];
+    it->g_z = f32 ? (double)(float)c->hscal[PG_S_GZ] : c->hscal[PG_S_GZ];
+    it->res_inf = f32 ? (double)(float)c->hscal[PG_S_RESINF] : c->hscal[PG_S_RESINF];
+    it->dot_gr = f32 ? (double)(float)c->hscal[PG_S_DOT] : c->hscal[PG_S_DOT];
+    it->res_sq = f32 ? (double)(float)c->hscal[PG_S_RESSQ] : c->hscal[PG_S_RESSQ];
   }
   *k_out = k;
   fill_scalars(it, out);

@@ -2,6 +2,7 @@
 """BASELINE config 1 and the reference's shipped instances: launch-bound sizes.  Reports solve time and it/s on the
 GPU (host loop and in-library loop pg_iter_run) next to the CPU restatement -- these sizes are far below what a GPU is
 for; the numbers document the per-iteration floor of the current (non-graph) path."""
+import gc
 import json
 import os
 import sys
@@ -45,7 +46,17 @@ def main():
         t0 = time.perf_counter()
         zo, ko = o.fast_forward_backward(tol=1e-6, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
         t_cpu = time.perf_counter() - t0
-        out.append({"instance": name, "k_gpu": k, "k_lib": k_lib, "k_cpu": ko, "gpu_host_loop_it_s": k / t_host,
+        # fixed step (gamma = 1/Lf): one host synchronisation per iteration vs one per 32 iterations
+        Lf = float(np.linalg.norm(A, 2) ** 2)
+        fixed = {}
+        for ce in (1, 1, 32):  # the first pass is a warm-up
+            itf = pa.FastForwardBackwardIteration(f=f, g=g, x0=x0, Lf=Lf)
+            next(iter(itf))
+            gc.collect()  # destroying earlier iterators (hipFree) must not land inside the timed region
+            t0 = time.perf_counter()
+            kf, _ = itf._fused.run(1, 2001, 0.0, check_every=ce)
+            fixed[ce] = (kf - 1) / (time.perf_counter() - t0)
+        out.append({"instance": name, "gpu_fixed_step_it_s_sync_every_1": fixed[1], "gpu_fixed_step_it_s_sync_every_32": fixed[32], "k_gpu": k, "k_lib": k_lib, "k_cpu": ko, "gpu_host_loop_it_s": k / t_host,
                     "gpu_library_loop_it_s": k_lib / t_lib, "cpu_numpy_it_s": ko / t_cpu,
                     "max_abs_diff": float(np.max(np.abs(z - zo)))})
     print(json.dumps(out, indent=1))

@@ -969,3 +969,39 @@ def test_error_paths_report_messages(pa):
         x.axpby_(1.0, pa.HIPVector.zeros(6, np.float32))
     with pytest.raises(TypeError):
         pa.ForwardBackwardIteration(f=pa.Zero(), g=pa.NormL1(1.0), x0=np.zeros(3), engine="fused")
+
+
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_batched_device_resident_run(pa, dtype, fast):
+    """pg_iter_run_batched: `check_every` fixed-step iterations per host synchronisation give bit-identical iterates
+    to stepping one by one; the returned k is the first multiple of the batch at which the stop rule holds."""
+    import time
+
+    A, b, lam = synthetic_problem(300, 900, dtype, seed=13)
+    Lf = dtype(power_Lf(A))
+    x0 = np.zeros(900, dtype)
+    It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
+    f, g = pa.LeastSquares(A, b), pa.NormL1(lam)
+    tol = 1e-4
+    it1 = It(f=f, g=g, x0=x0, Lf=Lf)
+    gen1 = iter(it1)
+    next(gen1)
+    k1, sc1 = it1._fused.run(1, 5000, tol)
+    z1 = it1._fused.view()["z"].numpy().copy()
+    it2 = It(f=f, g=g, x0=x0, Lf=Lf)
+    gen2 = iter(it2)
+    next(gen2)
+    t0 = time.perf_counter()
+    k2, sc2 = it2._fused.run(1, 5000, tol, check_every=16)
+    t_batched = time.perf_counter() - t0
+    assert k1 <= k2 < k1 + 16 and (k2 - 1) % 16 == 0
+    # advance the one-by-one iterator to the same k: identical bits
+    for _ in range(k2 - k1):
+        it1._fused.step()
+    assert np.array_equal(it1._fused.view()["z"].numpy(), it2._fused.view()["z"].numpy())
+    assert float(sc2.res_inf) / float(sc2.gamma) <= tol
+    with pytest.raises(pa.ProxGradError):
+        ita = It(f=f, g=g, x0=x0)  # adaptive
+        next(iter(ita))
+        ita._fused.run(1, 100, tol, check_every=4)
