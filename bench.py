@@ -56,6 +56,8 @@ def parse_args():
     p.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                    help="strong: the global problem is fixed and its rows are split over the ranks (default); weak: every "
                         "rank holds --m rows (BASELINE config 5 = --scaling weak --m 16384 on 8 GPUs: 131072 x 2^20)")
+    p.add_argument("--collective", choices=["torch", "native"], default="torch",
+                   help="N > 1: all-reduce through torch.distributed (default) or the library's own RCCL communicator")
     p.add_argument("--no-overlap", action="store_true", help="disable the chunked asynchronous all-reduce (N > 1)")
     p.add_argument("--share-device", action="store_true",
                    help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
@@ -149,7 +151,10 @@ def main():
     noise = np.random.default_rng(args.seed + 54321).standard_normal(m_glob).astype(dtype)[row_off:row_off + m_loc]
     b = A.mul(pa.HIPVector.from_numpy(x_true, ctx))  # rows are independent: no collective
     b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
-    comm = pa.TorchDistributedComm(overlap=not args.no_overlap) if world > 1 else None
+    comm = None
+    if world > 1:
+        comm = (pa.NativeRcclComm(overlap=not args.no_overlap) if args.collective == "native"
+                else pa.TorchDistributedComm(overlap=not args.no_overlap))
     f = pa.LeastSquares(A, b, comm=comm)
     zero_n = pa.HIPVector.zeros(n, dtype, ctx)
     _, g0 = f.value_and_gradient(zero_n)  # = -A'b (all-reduced over the shards)

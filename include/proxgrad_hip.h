@@ -101,6 +101,15 @@ pg_status pg_ctx_set_allreduce(pg_ctx* ctx, pg_allreduce_fn fn, void* user);
  * `stream` wait for all of them.  With the pair registered, a gradient evaluation runs A'r in column chunks and
  * overlaps each chunk's collective with the next chunk's pass (only the last chunk's collective is exposed). */
 pg_status pg_ctx_set_allreduce_async(pg_ctx* ctx, pg_allreduce_fn begin, pg_allreduce_wait_fn wait, void* user);
+/* Native collective (no host callback): RCCL is bound at run time with dlopen.  Rank 0 calls
+ * pg_comm_get_unique_id and ships the PG_COMM_ID_BYTES bytes to every rank by any means (a file, MPI, sockets,
+ * torch.distributed ...); every rank then calls pg_ctx_comm_init, which creates the communicator (ncclCommInitRank)
+ * and installs the library's own all-reduce -- blocking form on the context stream, and with overlap != 0 also the
+ * asynchronous pair on a side stream behind events (chunked pass T, see pg_ctx_set_allreduce_async). */
+#define PG_COMM_ID_BYTES 128
+pg_status pg_comm_get_unique_id(void* id_out /* PG_COMM_ID_BYTES */);
+pg_status pg_ctx_comm_init(pg_ctx* ctx, const void* id, int32_t nranks, int32_t rank, int32_t overlap);
+pg_status pg_ctx_comm_destroy(pg_ctx* ctx);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every

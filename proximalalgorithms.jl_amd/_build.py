@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libproxgrad_hip.so")
-SOURCES = ["pg_core.hip", "pg_gemv.hip", "pg_vec.hip", "pg_iter.hip", "pg_lbfgs.hip"]
+SOURCES = ["pg_core.hip", "pg_gemv.hip", "pg_vec.hip", "pg_iter.hip", "pg_lbfgs.hip", "pg_comm.hip"]
 HEADERS = [os.path.join(CSRC, "pg_internal.h"), os.path.join(CSRC, "pg_ew.h"), os.path.join(INCLUDE, "proxgrad_hip.h")]
 ARCH = "gfx950"
 
@@ -55,7 +55,7 @@ def build(force=False, verbose=True):
     if failed:
         raise RuntimeError("hipcc compilation failed")
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

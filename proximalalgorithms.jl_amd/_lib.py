@@ -55,6 +55,9 @@ SIGNATURES = {
     "pg_ctx_set_stream": [_vp, _vp],
     "pg_ctx_set_allreduce": [_vp, ALLREDUCE_FN, _vp],
     "pg_ctx_set_allreduce_async": [_vp, ALLREDUCE_FN, ALLREDUCE_WAIT_FN, _vp],
+    "pg_comm_get_unique_id": [_vp],
+    "pg_ctx_comm_init": [_vp, _vp, _i32, _i32, _i32],
+    "pg_ctx_comm_destroy": [_vp],
     "pg_ctx_sync": [_vp],
     "pg_ctx_device_info": [_vp, C.POINTER(pg_device_info)],
     "pg_ctx_profile_enable": [_vp, _i32],

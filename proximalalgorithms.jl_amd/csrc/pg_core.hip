@@ -59,6 +59,7 @@ pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out) {
 
 pg_status pg_ctx_destroy(pg_ctx* c) {
   if (!c) return PG_OK;
+  if (c->comm) (void)pg_ctx_comm_destroy(c);
   if (c->red_partials) (void)hipFree(c->red_partials);
   if (c->red_counter) (void)hipFree(c->red_counter);
   if (c->hscal) (void)hipHostFree(c->hscal);

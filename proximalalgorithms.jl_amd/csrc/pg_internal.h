@@ -68,6 +68,14 @@ enum {
 constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize
 constexpr int PG_RED_MAX_NS = 4;
 
+// RCCL communicator bound by pg_ctx_comm_init (csrc/pg_comm.hip)
+struct pg_comm {
+  void* comm = nullptr;  // ncclComm_t
+  hipStream_t side = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  int nranks = 1, rank = 0;
+};
+
 struct pg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -83,6 +91,7 @@ struct pg_ctx {
   pg_allreduce_fn allreduce_begin = nullptr;  // asynchronous issue (overlaps with following kernels)
   pg_allreduce_wait_fn allreduce_wait = nullptr;
   void* allreduce_user = nullptr;
+  pg_comm* comm = nullptr;  // native RCCL path (optional)
   // event-pair kernel timing (pg_ctx_profile_*)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[PG_K_COUNT];

@@ -83,6 +83,42 @@ class TorchDistributedComm:
             ctx.set_allreduce_async(begin, wait)
 
 
+class NativeRcclComm:
+    """The library's own RCCL communicator (csrc/pg_comm.hip): no Python in the collective path.  The 128-byte
+    ncclUniqueId is created on rank 0 and shipped with torch.distributed (any backend) when world_size > 1."""
+
+    def __init__(self, world_size=None, rank=None, overlap=True):
+        import torch.distributed as dist
+
+        if world_size is None:
+            initialised = dist.is_available() and dist.is_initialized()
+            world_size = dist.get_world_size() if initialised else 1
+            rank = dist.get_rank() if initialised else 0
+        self.world_size, self.rank, self.overlap = int(world_size), int(rank), bool(overlap)
+        self._ctx = None
+
+    def attach(self, ctx):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from ._lib import call
+
+        if self._ctx is ctx:
+            return
+        if self._ctx is not None:
+            raise RuntimeError("a NativeRcclComm is bound to one context")
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            call("pg_comm_get_unique_id", ident)
+        if self.world_size > 1:
+            box = [bytes(ident.raw) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ident = C.create_string_buffer(box[0], 128)
+        call("pg_ctx_comm_init", ctx.handle, ident, self.world_size, self.rank, 1 if self.overlap else 0)
+        self._ctx = ctx
+
+
 class ScaleComm:
     """Test double for the collective on a single GPU: emulates ``world_size`` ranks holding IDENTICAL row
     shards (the SUM all-reduce of identical buffers is a multiplication by world_size), using the library's

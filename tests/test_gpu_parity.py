@@ -1005,3 +1005,24 @@ def test_batched_device_resident_run(pa, dtype, fast):
         ita = It(f=f, g=g, x0=x0)  # adaptive
         next(iter(ita))
         ita._fused.run(1, 100, tol, check_every=4)
+
+
+def test_native_rccl_communicator_world_size_one(pa):
+    """csrc/pg_comm.hip: RCCL bound with dlopen, communicator of one rank; blocking and chunked asynchronous paths."""
+    A, b, lam = synthetic_problem(256, 20000, np.float32, seed=5)
+    for overlap in (False, True):
+        ctx2 = pa.Context()
+        comm = pa.NativeRcclComm(world_size=1, rank=0, overlap=overlap)
+        f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
+        f_pl = pa.LeastSquares(A, b)
+        x = np.random.default_rng(1).standard_normal(20000).astype(np.float32)
+        fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
+        fp, gp = f_pl.value_and_gradient(pa.HIPVector.from_numpy(x))
+        assert float(fs) == pytest.approx(float(fp), rel=1e-6) and np.array_equal(gs.numpy(), gp.numpy())
+        assert float(f_sh(pa.HIPVector.from_numpy(x, ctx2))) == pytest.approx(float(fp), rel=1e-6)
+        z1, k1 = pa.FastForwardBackward(tol=1e-3, maxit=40)(x0=pa.HIPVector.zeros(20000, np.float32, ctx2), f=f_sh, g=pa.NormL1(lam))
+        z2, k2 = pa.FastForwardBackward(tol=1e-3, maxit=40)(x0=np.zeros(20000, np.float32), f=f_pl, g=pa.NormL1(lam))
+        assert k1 == k2 and np.max(np.abs(z1.numpy() - z2)) <= 1e-5 * max(1.0, np.max(np.abs(z2)))
+        from proximalalgorithms.jl_amd._lib import call
+
+        call("pg_ctx_comm_destroy", ctx2.handle)
