@@ -47,6 +47,7 @@ def parse_args():
     p.add_argument("--m", type=int, default=None, help="override rows (global)")
     p.add_argument("--n", type=int, default=None, help="override columns")
     p.add_argument("--mode", choices=["fixed", "adaptive"], default="fixed")
+    p.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="working precision (BASELINE metric: f32)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-cols", type=int, default=16384)
@@ -137,7 +138,7 @@ def main():
     if args.scaling == "weak":
         m_glob *= world
     n = args.n or n
-    dtype = np.float32
+    dtype = np.float32 if args.dtype == "f32" else np.float64
     ctx = pa.get_context(local_rank)
     row_off, m_loc = pa.shard_rows(m_glob, world, rank)
 
@@ -207,7 +208,7 @@ def main():
         elapsed = float(t.item())
 
     its = args.steps / elapsed
-    es = 4
+    es = 4 if args.dtype == "f32" else 8
     bytes_iter_local = a_passes / max(args.steps, 1) * m_loc * n * es + 10 * n * es + 3 * m_loc * es
     # dominant kernel = the slower GEMV pass; algorithmic bytes of one launch = the local A block + vectors
     kern = {}
@@ -226,7 +227,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             rec = pmc.get(args.workload)
-            if rec and world == 1 and args.m is None and args.n is None:
+            if rec and world == 1 and args.m is None and args.n is None and args.dtype == "f32":
                 traffic = rec["kernels"][dom]["hbm_bytes"]
                 traffic_src = rec["source"]
         except Exception:
@@ -247,7 +248,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(m_glob, n, args.cpu_sample_cols, args.cpu_steps, args.seed)
         line = {
-            "metric": "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, f32)" % (m_glob, n),
+            "metric": "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, %s)" % (m_glob, n, args.dtype),
             "value": round(its, 4),
             "unit": "it/s",
             "n_gpus": world,
@@ -257,10 +258,10 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "FFB LASSO m=%d n=%d Float32, %s step, rows of A sharded over %d GPU(s)"
-                                   % (m_glob, n, args.mode, world),
+            "config": {"workload": "FFB LASSO m=%d n=%d %s, %s step, rows of A sharded over %d GPU(s)"
+                                   % (m_glob, n, "Float32" if args.dtype == "f32" else "Float64", args.mode, world),
                        "m": m_glob, "n": n, "mode": args.mode, "row_shards": world, "m_per_gpu": m_loc,
                        "lambda": float(lam), "Lf": float(Lf) if Lf is not None else None, "seed": args.seed,
                        "a_passes_per_step": a_passes / max(args.steps, 1), "setup_s": round(t_setup, 2),
