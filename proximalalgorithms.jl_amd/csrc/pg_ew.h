@@ -43,7 +43,12 @@ __global__ __launch_bounds__(BS) void ew_kernel(int64_t n, bool vec_ok, F f, dou
   const int64_t nthreads = (int64_t)gridDim.x * BS;
   if (vec_ok) {
     const int64_t nvec = n / VEC;
-    for (int64_t v = tid; v < nvec; v += nthreads) f.template apply<VEC>(v * VEC, acc);
+    int64_t v = tid;
+    for (; v + nthreads < nvec; v += 2 * nthreads) {  // two independent vectors per trip: more loads in flight
+      f.template apply<VEC>(v * VEC, acc);
+      f.template apply<VEC>((v + nthreads) * VEC, acc);
+    }
+    if (v < nvec) f.template apply<VEC>(v * VEC, acc);
     for (int64_t i = nvec * VEC + tid; i < n; i += nthreads) f.template apply<1>(i, acc);
   } else {
     for (int64_t i = tid; i < n; i += nthreads) f.template apply<1>(i, acc);
@@ -87,6 +92,21 @@ __device__ __forceinline__ void st(T* __restrict__ p, int64_t i, const Pack<T, N
 #pragma unroll
     for (int e = 0; e < N; ++e) t[e] = r.v[e];
     *reinterpret_cast<V*>(p + i) = t;
+  }
+}
+
+// non-temporal store: for streams the kernel chain never reads back (keeps them from displacing re-read operands
+// in L2 / Infinity Cache)
+template <typename T, int N>
+__device__ __forceinline__ void st_nt(T* __restrict__ p, int64_t i, const Pack<T, N>& r) {
+  if constexpr (N == 1) {
+    __builtin_nontemporal_store(r.v[0], p + i);
+  } else {
+    using V = typename VecOf<T>::type;
+    V t;
+#pragma unroll
+    for (int e = 0; e < N; ++e) t[e] = r.v[e];
+    __builtin_nontemporal_store(t, reinterpret_cast<V*>(p + i));
   }
 }
 

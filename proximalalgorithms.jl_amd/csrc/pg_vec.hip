@@ -202,8 +202,8 @@ struct EpilogueF {
 // Quadratic(Diagonal(d), q)); prox_{gamma f}(x)_i = (x_i - gamma q_i) / (1 + gamma d_i)
 template <typename T>
 struct SepQuadParams {
-  const T* dv;  // nullable -> scalar ds
-  const T* qv;  // nullable -> scalar qs
+  const T* __restrict__ dv;  // nullable -> scalar ds
+  const T* __restrict__ qv;  // nullable -> scalar qs
   T ds, qs;
 };
 
@@ -243,11 +243,11 @@ struct ProxSepQuadF {  // y = prox_{gamma f}(x); acc[0] = f(y)
 // y is always written (it is the solution, :70); r / z / res only when the caller wants the full state.
 template <typename T, int GKIND>
 struct DRStepF {
-  T* x;
-  T* y;
-  T* r;    // nullable
-  T* z;    // nullable
-  T* res;  // nullable
+  T* __restrict__ x;
+  T* __restrict__ y;
+  T* __restrict__ r;    // nullable
+  T* __restrict__ z;    // nullable
+  T* __restrict__ res;  // nullable
   SepQuadParams<T> f;
   T gamma, p0, p1;  // g: p0 = gamma*lam (NormL1) | lo (IndBox) ; p1 = hi
   double gscale;
@@ -269,11 +269,11 @@ struct DRStepF {
       acc[0] = fmax(acc[0], fabs((double)sv.v[e]));
       if constexpr (GKIND == PG_G_NORML1) acc[2] += fabs((double)zv.v[e]);
     }
-    st<T, N>(x, i, xv);
-    st<T, N>(y, i, yv);
-    if (r != nullptr) st<T, N>(r, i, rv);
-    if (z != nullptr) st<T, N>(z, i, zv);
-    if (res != nullptr) st<T, N>(res, i, sv);
+    st<T, N>(x, i, xv);  // re-read by the next iteration: regular store
+    st_nt<T, N>(y, i, yv);
+    if (r != nullptr) st_nt<T, N>(r, i, rv);
+    if (z != nullptr) st_nt<T, N>(z, i, zv);
+    if (res != nullptr) st_nt<T, N>(res, i, sv);
   }
   __device__ double post_scale(int k) const { return k == 2 ? gscale : 1.0; }
 };
