@@ -289,6 +289,12 @@ pg_status pg_iter_run(pg_iter* it, int64_t k_start, int64_t maxit, double tol, i
  * check_every = 1 this is pg_iter_run.  Not available with an adaptive step: backtracking is a host decision. */
 pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int32_t check_every,
                               int64_t* k_out, pg_iter_scalars* out);
+/* Launch-bound sizes (0 < m * n <= 2^20 elements, e.g. the reference's shipped benchmark instances): the whole
+ * driver loop -- stop rule, line search, extrapolation sequence, both GEMV orientations, prox -- runs inside ONE
+ * launch of one 1024-thread workgroup (A stays L2-resident); same control flow and state as pg_iter_run, no host
+ * round trip per iteration.  The iterator can be stepped normally afterwards. */
+pg_status pg_iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out,
+                            pg_iter_scalars* out);
 pg_status pg_iter_state_view(pg_iter* it, pg_iter_state* out);
 
 /* ------------------------------------------------------------------ L-BFGS (config 4) --- */

@@ -58,6 +58,12 @@ class FusedIteration:
             call("pg_iter_run", self._h, int(k_start), int(maxit), float(tol), C.byref(k), C.byref(self.scalars))
         return k.value, self.scalars
 
+    def run_small(self, k_start, maxit, tol):
+        """Whole solve in one launch of one workgroup (pg_iter_run_small; m * n <= 2^20 elements)."""
+        k = C.c_int64()
+        call("pg_iter_run_small", self._h, int(k_start), int(maxit), float(tol), C.byref(k), C.byref(self.scalars))
+        return k.value, self.scalars
+
     def view(self):
         st = _lib.pg_iter_state()
         call("pg_iter_state_view", self._h, C.byref(st))

@@ -10,7 +10,11 @@ class IterativeAlgorithm:
     and loops: ``for (k, state) in enumerate(iter)`` -> returns ``(solution, k)`` when
     ``k >= maxit or stop(iter, state)`` (:114-123)."""
 
-    def __init__(self, iterator_type, *, maxit, stop, solution, verbose, freq, display, **kwargs):
+    def __init__(self, iterator_type, *, maxit, stop, solution, verbose, freq, display, device_loop=None, **kwargs):
+        # device_loop = (tol, check_every): run the loop with the DEFAULT stopping rule inside the library instead of
+        # stepping from the host (fused engines only): one launch for launch-bound sizes (pg_iter_run_small), else
+        # the in-library loop (pg_iter_run / pg_iter_run_batched)
+        self.device_loop = device_loop
         self.iterator_type = iterator_type
         self.maxit = int(maxit)
         self.stop = stop
@@ -26,6 +30,24 @@ class IterativeAlgorithm:
         x0 = merged.get("x0")
         host_x0 = x0 is not None and not isinstance(x0, HIPVector)
         it = self.iterator_type(**merged)
+        if self.device_loop is not None and getattr(it, "engine", None) == "fused" and not self.verbose:
+            tol, check_every = self.device_loop
+            gen = iter(it)
+            state = next(gen)  # Base.iterate(iter): k = 1
+            fused = it._fused
+            A = it.f.A
+            adaptive = bool(it.adaptive)
+            if A.m * A.n <= 32768 and A.m > 0 and A.n > 0 and it.f.comm is None:
+                k, _ = fused.run_small(1, self.maxit, tol)
+            elif check_every > 1 and not adaptive:
+                k, _ = fused.run(1, self.maxit, tol, check_every=check_every)
+            else:
+                k, _ = fused.run(1, self.maxit, tol)
+            state._invalidate()
+            sol = self.solution(it, state)
+            if host_x0 and isinstance(sol, HIPVector):
+                sol = sol.numpy()
+            return sol, k
         for k, state in enumerate(it, start=1):
             if k >= self.maxit or self.stop(it, state):
                 if self.verbose:

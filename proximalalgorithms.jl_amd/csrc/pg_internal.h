@@ -92,6 +92,8 @@ struct pg_ctx {
   pg_allreduce_wait_fn allreduce_wait = nullptr;
   void* allreduce_user = nullptr;
   pg_comm* comm = nullptr;  // native RCCL path (optional)
+  double* small_out = nullptr;       // result block of the single-workgroup solver (device address)
+  double* small_out_host = nullptr;  //   ... mapped pinned host memory
   // event-pair kernel timing (pg_ctx_profile_*)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[PG_K_COUNT];

@@ -48,44 +48,61 @@ struct Arith {
   static double r(double v) { return (double)(T)v; }  // round to working precision
 };
 
-// ---- Nesterov sequences, evaluated in T like the reference's R ----------------------------------
+// ---- Nesterov sequences, evaluated in T like the reference's R (host and device) -------------------
 template <typename T>
-double seq_next(pg_iter* it, double gamma_d, double host_beta) {
-  switch (it->o.seq_kind) {
+struct SeqState {
+  T stepsize, theta, t;  // AdaptiveNesterovSequence (stepsize, theta) ; FixedNesterovSequence (t)
+  long long k;           // SimpleNesterovSequence
+};
+
+template <typename T>
+__host__ __device__ inline T seq_next_hd(int kind, T mf, T p0, T p1, SeqState<T>& st, T gamma, T host_beta) {
+  switch (kind) {
     case PG_SEQ_FIXED: {  // nesterov.jl:14-17
-      const T t = (T)it->seq_t;
-      const T t_next = (T(1) + std::sqrt(T(1) + T(4) * t * t)) / T(2);
-      it->seq_t = (double)t_next;
-      return (double)((t - T(1)) / t_next);
+      const T t = st.t;
+      const T t_next = (T(1) + sqrt(T(1) + T(4) * t * t)) / T(2);
+      st.t = t_next;
+      return (t - T(1)) / t_next;
     }
     case PG_SEQ_SIMPLE: {  // nesterov.jl:36
-      const int64_t k = it->seq_k++;
-      return (double)((T)(k - 1) / (T)(k + 2));
+      const long long k = st.k++;
+      return (T)(k - 1) / (T)(k + 2);
     }
     case PG_SEQ_CONSTANT: {  // nesterov.jl:51-54
-      const T k_inverse = (T)it->o.seq_p0 * (T)it->o.seq_p1;
-      return (double)((T(1) - std::sqrt(k_inverse)) / (T(1) + std::sqrt(k_inverse)));
+      const T k_inverse = p0 * p1;
+      return (T(1) - sqrt(k_inverse)) / (T(1) + sqrt(k_inverse));
     }
     case PG_SEQ_HOST:
-      return (double)(T)host_beta;
+      return host_beta;
     case PG_SEQ_ADAPTIVE:
     default: {  // nesterov.jl:89-103
-      const T m = (T)it->o.mf;
-      const T stepsize = (T)gamma_d;
-      T s_step = (T)it->seq_stepsize, s_theta = (T)it->seq_theta;
+      const T m = mf;
+      const T stepsize = gamma;
+      T s_step = st.stepsize, s_theta = st.theta;
       if (s_step < T(0)) {
         s_step = stepsize;
-        s_theta = m > T(0) ? std::sqrt(m * stepsize) : T(1);
+        s_theta = m > T(0) ? (T)sqrt(m * stepsize) : T(1);
       }
       const T b = s_theta * s_theta / s_step - m;
       const T delta = b * b + T(4) * (s_theta * s_theta) / (s_step * stepsize);
-      const T theta = stepsize * (-b + std::sqrt(delta)) / T(2);
+      const T theta = stepsize * (-b + sqrt(delta)) / T(2);
       const T beta = stepsize * s_theta * (T(1) - s_theta) / (s_step * theta + stepsize * s_theta * s_theta);
-      it->seq_stepsize = (double)stepsize;
-      it->seq_theta = (double)theta;
-      return (double)beta;
+      st.stepsize = stepsize;
+      st.theta = theta;
+      return beta;
     }
   }
+}
+
+template <typename T>
+double seq_next(pg_iter* it, double gamma_d, double host_beta) {
+  SeqState<T> st{(T)it->seq_stepsize, (T)it->seq_theta, (T)it->seq_t, (long long)it->seq_k};
+  const T beta = seq_next_hd<T>(it->o.seq_kind, (T)it->o.mf, (T)it->o.seq_p0, (T)it->o.seq_p1, st, (T)gamma_d, (T)host_beta);
+  it->seq_stepsize = (double)st.stepsize;
+  it->seq_theta = (double)st.theta;
+  it->seq_t = (double)st.t;
+  it->seq_k = st.k;
+  return (double)beta;
 }
 
 inline size_t vec_bytes(const pg_iter* it) {
@@ -249,6 +266,381 @@ pg_status iter_step(pg_iter* it, double host_beta) {
     }
     PG_TRY(epilogue_and_read<T>(it, true));                          // :140-142
   }
+  return PG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-workgroup persistent solver for launch-bound sizes: the whole driver loop
+// (src/ProximalAlgorithms.jl:114-123) -- stop rule, line search, Nesterov recurrences, both GEMV orientations, prox --
+// runs inside ONE kernel launch of one 1024-thread workgroup; A stays L2-resident, vectors are exchanged between
+// phases through global memory + workgroup barriers, scalars are computed redundantly by every thread from
+// block-reduced values (so control flow is uniform without broadcasts).  Same control flow as iter_step above.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct SmallParams {
+  const T* A;
+  long long ld;
+  int m, n;
+  const T* b;
+  T* buf[8];  // roles at entry: 0 x, 1 grad_f_x, 2 y, 3 z, 4 res, 5 z_prev | grad_f_z, 6 rz, 7 rz_prev (6,7 optional)
+  T* r;       // residual scratch (m)
+  int fast, adaptive, reuse, g_kind, seq_kind, has_fixed_gamma;
+  T g_p0, g_p1, lam_ls;
+  T gamma, f_x, g_z, res_inf, dot_gr, res_sq, fixed_gamma;
+  T min_gamma, reduce_gamma, increase_gamma, mf, seq_p0, seq_p1;
+  SeqState<T> seq;
+  long long k_start, maxit;
+  T tol;
+  double* out;  // [32] results, mapped host memory
+};
+
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_WAVES = SMALL_THREADS / 64;
+
+// all-thread block reduction of 4 doubles (bit k of MAXMASK: max); every thread returns with the results
+template <unsigned MAXMASK>
+__device__ __forceinline__ void small_block_reduce(double (&v)[4], double* sm_red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = pg_shfl_xor(v[k], off);
+      v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
+    }
+  }
+  __syncthreads();  // sm_red free
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm_red[wave * 4 + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double a = sm_red[k];
+    for (int w = 1; w < SMALL_WAVES; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm_red[w * 4 + k]) : (a + sm_red[w * 4 + k]);
+    v[k] = a;
+  }
+}
+
+// r_out = A v - b ; returns sum r_out^2 (to every thread)
+template <typename T>
+__device__ double small_residual(const SmallParams<T>& p, const T* v, T* r_out, double* sm_part, double* sm_red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double sq = 0.0;
+  for (int rb = 0; rb < p.m; rb += 64) {
+    const int i = rb + lane;
+    double acc = 0.0;
+    if (i < p.m) {
+      for (int j = wave; j < p.n; j += SMALL_WAVES) acc += (double)p.A[i + (long long)j * p.ld] * (double)v[j];
+    }
+    sm_part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && i < p.m) {
+      double t = 0.0;
+      for (int w = 0; w < SMALL_WAVES; ++w) t += sm_part[w * 64 + lane];
+      const T ri = (T)(t - (double)p.b[i]);
+      r_out[i] = ri;
+      sq += (double)ri * (double)ri;
+    }
+    __syncthreads();
+  }
+  double v4[4] = {sq, 0.0, 0.0, 0.0};
+  small_block_reduce<0u>(v4, sm_red);
+  return v4[0];
+}
+
+// g_out = lam A' r
+template <typename T>
+__device__ void small_adjoint(const SmallParams<T>& p, const T* r, T* g_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < p.n; j += SMALL_WAVES) {
+    double acc = 0.0;
+    const T* col = p.A + (long long)j * p.ld;
+    for (int i = lane; i < p.m; i += 64) acc += (double)col[i] * (double)r[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += pg_shfl_xor(acc, off);
+    if (lane == 0) g_out[j] = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)acc) : (T)acc;
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ T small_soft(T x, T gl) {
+  return x <= -gl ? x + gl : (x >= gl ? x - gl : T(0));
+}
+
+// y = x - gamma g ; z = prox(y) ; res = x - z ; out = { g(z), ||res||_inf, <g,res>, ||res||^2 }
+template <typename T>
+__device__ void small_epilogue(const SmallParams<T>& p, const T* x, const T* g, T gamma, T* y, T* z, T* res,
+                               double (&out)[4], double* sm_red) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const T gl = gamma * p.g_p0;
+  for (int j = threadIdx.x; j < p.n; j += SMALL_THREADS) {
+    const T xv = x[j], gv = g[j];
+    const T yv = xv - gamma * gv;
+    T zv;
+    if (p.g_kind == PG_G_NORML1)
+      zv = small_soft(yv, gl);
+    else if (p.g_kind == PG_G_INDBOX)
+      zv = fmin(p.g_p1, fmax(p.g_p0, yv));
+    else
+      zv = yv;
+    const T rv = xv - zv;
+    y[j] = yv;
+    z[j] = zv;
+    res[j] = rv;
+    if (p.g_kind == PG_G_NORML1) acc[0] += fabs((double)zv);
+    acc[1] = fmax(acc[1], fabs((double)rv));
+    acc[2] += (double)gv * (double)rv;
+    acc[3] += (double)rv * (double)rv;
+  }
+  small_block_reduce<0x2u>(acc, sm_red);
+  out[0] = p.g_kind == PG_G_NORML1 ? acc[0] * (double)p.g_p0 : 0.0;
+  out[1] = acc[1];
+  out[2] = acc[2];
+  out[3] = acc[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams<T> p) {
+  __shared__ double sm_part[SMALL_WAVES * 64];
+  __shared__ double sm_red[SMALL_WAVES * 4];
+  T *x = p.buf[0], *grad = p.buf[1], *y = p.buf[2], *z = p.buf[3], *res = p.buf[4], *zp = p.buf[5], *rz = p.buf[6],
+    *rzp = p.buf[7];
+  T gamma = p.gamma, f_x = p.f_x, g_z = p.g_z, res_inf = p.res_inf, dot_gr = p.dot_gr, res_sq = p.res_sq;
+  T beta = T(0);
+  SeqState<T> seq = p.seq;
+  long long k = p.k_start, nbt_total = 0, passes = 0;
+  int flags = 0;
+  bool rz_valid = false;
+  const T eps = sizeof(T) == 4 ? (T)1.1920928955078125e-07 : (T)2.220446049250313e-16;
+  const T f_scale = (T)0.5 * p.lam_ls;
+  double e4[4];
+
+  auto model = [&]() -> T {  // fb_tools.jl:3-5 with L = 1 / gamma
+    const T L = T(1) / gamma;
+    return f_x - dot_gr + (L / T(2)) * res_sq;
+  };
+  auto set_epilogue = [&]() {
+    g_z = (T)e4[0];
+    res_inf = (T)e4[1];
+    dot_gr = (T)e4[2];
+    res_sq = (T)e4[3];
+  };
+
+  while (!(k >= p.maxit || res_inf / gamma <= p.tol)) {  // ProximalAlgorithms.jl:117 ; forward_backward.jl:125-126
+    if (p.fast) {
+      if (p.adaptive) {  // fast_forward_backward.jl:110-129 + fb_tools.jl:24-63
+        gamma = gamma * p.increase_gamma;
+        T f_upp = model();
+        T* rz_dst = p.reuse ? rz : p.r;  // without the residual buffers the line search uses the scratch residual
+        T f_z = f_scale * (T)small_residual(p, z, rz_dst, sm_part, sm_red);
+        passes += 1;
+        T tol_ls = T(10) * eps * (T(1) + fabs(f_z));
+        while (f_z > f_upp + tol_ls && gamma >= p.min_gamma) {
+          gamma = gamma * p.reduce_gamma;
+          small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);
+          set_epilogue();
+          f_upp = model();
+          f_z = f_scale * (T)small_residual(p, z, rz_dst, sm_part, sm_red);
+          passes += 1;
+          tol_ls = T(10) * eps * (T(1) + fabs(f_z));
+          nbt_total += 1;
+        }
+        if (gamma < p.min_gamma) flags |= PG_FLAG_GAMMA_TOO_SMALL;
+        rz_valid = true;
+      } else if (p.has_fixed_gamma) {
+        gamma = p.fixed_gamma;  // :131
+      }
+      beta = seq_next_hd<T>(p.seq_kind, p.mf, p.seq_p0, p.seq_p1, seq, gamma, T(0));  // :134
+      for (int j = threadIdx.x; j < p.n; j += SMALL_THREADS) x[j] = z[j] + beta * (z[j] - zp[j]);  // :135
+      __syncthreads();
+      {  // :136
+        T* t = zp;
+        zp = z;
+        z = t;
+      }
+      if (p.adaptive && p.reuse && rz_valid) {  // A x - b = (1 + beta)(A z - b) - beta (A z_prev - b)
+        const T ca = T(1) + beta, cb = -beta;
+        double sq = 0.0;
+        for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+          const T o = ca * rz[i] + cb * rzp[i];
+          p.r[i] = o;
+          sq += (double)o * (double)o;
+        }
+        double v4[4] = {sq, 0.0, 0.0, 0.0};
+        small_block_reduce<0u>(v4, sm_red);
+        f_x = (T)((double)f_scale * v4[0]);
+        T* t = rzp;
+        rzp = rz;
+        rz = t;
+        rz_valid = false;
+      } else {
+        f_x = f_scale * (T)small_residual(p, x, p.r, sm_part, sm_red);  // :138
+        passes += 1;
+        if (p.adaptive && p.reuse) {  // this residual belongs to x, not to z: nothing to reuse next time
+          rz_valid = false;
+        }
+      }
+      small_adjoint(p, p.r, grad);  // :138-139
+      passes += 1;
+      small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);  // :140-142
+      set_epilogue();
+    } else {
+      if (p.adaptive) {  // forward_backward.jl:90-110 ; gradient at z is kept (zp plays grad_f_z)
+        gamma = gamma * p.increase_gamma;
+        T f_upp = model();
+        T f_z = f_scale * (T)small_residual(p, z, p.r, sm_part, sm_red);
+        small_adjoint(p, p.r, zp);
+        passes += 2;
+        T tol_ls = T(10) * eps * (T(1) + fabs(f_z));
+        while (f_z > f_upp + tol_ls && gamma >= p.min_gamma) {
+          gamma = gamma * p.reduce_gamma;
+          small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);
+          set_epilogue();
+          f_upp = model();
+          f_z = f_scale * (T)small_residual(p, z, p.r, sm_part, sm_red);
+          small_adjoint(p, p.r, zp);
+          passes += 2;
+          tol_ls = T(10) * eps * (T(1) + fabs(f_z));
+          nbt_total += 1;
+        }
+        if (gamma < p.min_gamma) flags |= PG_FLAG_GAMMA_TOO_SMALL;
+        f_x = f_z;  // :92
+        T* t = x;   // :109
+        x = z;
+        z = t;
+        t = grad;   // :110
+        grad = zp;
+        zp = t;
+      } else {  // :111-115
+        T* t = x;
+        x = z;
+        z = t;
+        f_x = f_scale * (T)small_residual(p, x, p.r, sm_part, sm_red);
+        small_adjoint(p, p.r, grad);
+        passes += 2;
+      }
+      small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);  // :117-120
+      set_epilogue();
+    }
+    ++k;
+  }
+  if (threadIdx.x == 0) {
+    auto role = [&](const T* q) -> double {
+      for (int i = 0; i < 8; ++i)
+        if (p.buf[i] == q) return (double)i;
+      return -1.0;
+    };
+    double* o = p.out;
+    o[0] = (double)k;
+    o[1] = (double)gamma;
+    o[2] = (double)f_x;
+    o[3] = (double)g_z;
+    o[4] = (double)res_inf;
+    o[5] = (double)dot_gr;
+    o[6] = (double)res_sq;
+    o[7] = (double)beta;
+    o[8] = (double)seq.stepsize;
+    o[9] = (double)seq.theta;
+    o[10] = (double)seq.t;
+    o[11] = (double)seq.k;
+    o[12] = role(x);
+    o[13] = role(grad);
+    o[14] = role(y);
+    o[15] = role(z);
+    o[16] = role(res);
+    o[17] = role(zp);
+    o[18] = role(rz);
+    o[19] = role(rzp);
+    o[20] = (double)nbt_total;
+    o[21] = (double)flags;
+    o[22] = (double)passes;
+    o[23] = rz_valid ? 1.0 : 0.0;
+  }
+}
+
+template <typename T>
+pg_status iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out) {
+  pg_ctx* c = it->ctx;
+  pg_mat* A = it->f->A;
+  SmallParams<T> p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const T*)A->data;
+  p.ld = A->ld;
+  p.m = (int)A->m;
+  p.n = (int)A->n;
+  p.b = (const T*)it->f->b;
+  void* bufs[8] = {it->x, it->grad_f_x, it->y, it->z, it->res, it->o.fast ? it->z_prev : it->grad_f_z, it->rz, it->rz_prev};
+  for (int i = 0; i < 8; ++i) p.buf[i] = (T*)bufs[i];
+  p.r = (T*)it->f->r;
+  p.fast = it->o.fast;
+  p.adaptive = it->adaptive ? 1 : 0;
+  p.reuse = (it->rz != nullptr && it->rz_prev != nullptr) ? 1 : 0;
+  p.g_kind = it->o.g_kind;
+  p.seq_kind = it->o.seq_kind;
+  p.has_fixed_gamma = (it->o.gamma > 0 || it->o.Lf > 0) ? 1 : 0;
+  p.fixed_gamma = p.has_fixed_gamma ? (T)(it->o.gamma > 0 ? it->o.gamma : (double)(T(1) / (T)it->o.Lf)) : T(0);
+  p.g_p0 = (T)it->o.g_p0;
+  p.g_p1 = (T)it->o.g_p1;
+  p.lam_ls = (T)it->f->lam;
+  p.gamma = (T)it->gamma;
+  p.f_x = (T)it->f_x;
+  p.g_z = (T)it->g_z;
+  p.res_inf = (T)it->res_inf;
+  p.dot_gr = (T)it->dot_gr;
+  p.res_sq = (T)it->res_sq;
+  p.min_gamma = (T)it->o.minimum_gamma;
+  p.reduce_gamma = (T)it->o.reduce_gamma;
+  p.increase_gamma = (T)it->o.increase_gamma;
+  p.mf = (T)it->o.mf;
+  p.seq_p0 = (T)it->o.seq_p0;
+  p.seq_p1 = (T)it->o.seq_p1;
+  p.seq = SeqState<T>{(T)it->seq_stepsize, (T)it->seq_theta, (T)it->seq_t, (long long)it->seq_k};
+  p.k_start = k_start;
+  p.maxit = maxit;
+  p.tol = (T)tol;
+  if (!c->small_out) {
+    double* host = nullptr;
+    PG_HIP(hipHostMalloc((void**)&host, sizeof(double) * 32, hipHostMallocMapped));
+    c->small_out_host = host;
+    PG_HIP(hipHostGetDevicePointer((void**)&c->small_out, host, 0));
+  }
+  p.out = c->small_out;
+  hipLaunchKernelGGL(small_solver_kernel<T>, dim3(1), dim3(SMALL_THREADS), 0, c->stream, p);
+  PG_LAUNCH_CHECK();
+  PG_HIP(hipStreamSynchronize(c->stream));
+  const double* o = c->small_out_host;
+  *k_out = (int64_t)o[0];
+  it->gamma = o[1];
+  it->f_x = o[2];
+  it->g_z = o[3];
+  it->res_inf = o[4];
+  it->dot_gr = o[5];
+  it->res_sq = o[6];
+  it->beta = o[7];
+  it->seq_stepsize = o[8];
+  it->seq_theta = o[9];
+  it->seq_t = o[10];
+  it->seq_k = (int64_t)o[11];
+  auto at = [&](int idx) -> void* { return (idx >= 0 && idx < 8) ? bufs[idx] : nullptr; };
+  it->x = at((int)o[12]);
+  it->grad_f_x = at((int)o[13]);
+  it->y = at((int)o[14]);
+  it->z = at((int)o[15]);
+  it->res = at((int)o[16]);
+  if (it->o.fast)
+    it->z_prev = at((int)o[17]);
+  else
+    it->grad_f_z = at((int)o[17]);
+  it->rz = at((int)o[18]);
+  it->rz_prev = at((int)o[19]);
+  it->n_backtracks = (int)o[20];
+  it->flags = (int)o[21];
+  it->f->a_passes += (int64_t)o[22];
+  it->rz_valid = false;  // conservative: the next host-driven step recomputes A x
+  it->f_z = it->f_z_upp = NAN;
   return PG_OK;
 }
 
@@ -418,6 +810,25 @@ pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, doubl
     it->res_sq = f32 ? (double)(float)c->hscal[PG_S_RESSQ] : c->hscal[PG_S_RESSQ];
   }
   *k_out = k;
+  fill_scalars(it, out);
+  return PG_OK;
+}
+
+// Whole solve in one launch of one workgroup (launch-bound sizes: m * n <= 2^20 elements).
+pg_status pg_iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out,
+                            pg_iter_scalars* out) {
+  PG_REQUIRE(it != nullptr && k_out != nullptr, "null argument");
+  PG_REQUIRE(it->initialized, "pg_iter_init has not been called");
+  PG_REQUIRE(it->o.seq_kind != PG_SEQ_HOST || !it->o.fast, "PG_SEQ_HOST needs per-step coefficients");
+  PG_REQUIRE(it->ctx->allreduce == nullptr && it->ctx->allreduce_begin == nullptr,
+             "the single-workgroup solver does not support row-sharded operators");
+  pg_mat* A = it->f->A;
+  if (A->m * A->n > ((int64_t)1 << 20) || A->m >= ((int64_t)1 << 31) || A->n >= ((int64_t)1 << 31) || A->m == 0 || A->n == 0) {
+    pg_set_error("pg_iter_run_small is for launch-bound sizes (0 < m * n <= 2^20 elements); use pg_iter_run");
+    return PG_ERR_UNSUPPORTED;
+  }
+  PG_TRY(it->dtype == PG_F32 ? iter_run_small<float>(it, k_start, maxit, tol, k_out)
+                             : iter_run_small<double>(it, k_start, maxit, tol, k_out));
   fill_scalars(it, out);
   return PG_OK;
 }

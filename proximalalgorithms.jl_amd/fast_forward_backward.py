@@ -161,12 +161,15 @@ def default_display(it, iteration, state):
 
 
 def FastForwardBackward(*, maxit=10_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
-                        display=default_display, **kwargs):
-    """fast_forward_backward.jl:186-204"""
+                        display=default_display, device_loop=False, check_every=1, **kwargs):
+    """fast_forward_backward.jl:186-204.  device_loop=True (default stop/solution only): the driver loop runs inside
+    the library -- one kernel launch for launch-bound sizes, else the in-library loop (batched by `check_every` when
+    the step is fixed)."""
+    dl = (tol, int(check_every)) if (device_loop and stop is None and solution is default_solution) else None
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
     return IterativeAlgorithm(FastForwardBackwardIteration, maxit=maxit, stop=stop, solution=solution,
-                              verbose=verbose, freq=freq, display=display, **kwargs)
+                              verbose=verbose, freq=freq, display=display, device_loop=dl, **kwargs)
 
 
 # Aliases (fast_forward_backward.jl:208-209)

@@ -164,11 +164,12 @@ def default_display(it, iteration, state):
 
 
 def ForwardBackward(*, maxit=10_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
-                    display=default_display, **kwargs):
+                    display=default_display, device_loop=False, check_every=1, **kwargs):
     """forward_backward.jl:161-179"""
+    dl = (tol, int(check_every)) if (device_loop and stop is None and solution is default_solution) else None
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
-    return IterativeAlgorithm(ForwardBackwardIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose,
+    return IterativeAlgorithm(ForwardBackwardIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose, device_loop=dl,
                               freq=freq, display=display, **kwargs)
 
 

@@ -43,6 +43,16 @@ def main():
         t0 = time.perf_counter()
         k_lib, _ = it._fused.run(1, 10_000, 1e-6)
         t_lib = time.perf_counter() - t0
+        its = pa.FastForwardBackwardIteration(f=f, g=g, x0=x0)
+        next(iter(its))
+        its._fused.run_small(1, 3, 1e-6)  # warm-up (code object load)
+        its = pa.FastForwardBackwardIteration(f=f, g=g, x0=x0)
+        next(iter(its))
+        gc.collect()
+        t0 = time.perf_counter()
+        k_small, _ = its._fused.run_small(1, 10_000, 1e-6)
+        t_small = time.perf_counter() - t0
+        z_small = its._fused.view()["z"].numpy()
         t0 = time.perf_counter()
         zo, ko = o.fast_forward_backward(tol=1e-6, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
         t_cpu = time.perf_counter() - t0
@@ -57,7 +67,10 @@ def main():
             kf, _ = itf._fused.run(1, 2001, 0.0, check_every=ce)
             fixed[ce] = (kf - 1) / (time.perf_counter() - t0)
         out.append({"instance": name, "gpu_fixed_step_it_s_sync_every_1": fixed[1], "gpu_fixed_step_it_s_sync_every_32": fixed[32], "k_gpu": k, "k_lib": k_lib, "k_cpu": ko, "gpu_host_loop_it_s": k / t_host,
-                    "gpu_library_loop_it_s": k_lib / t_lib, "cpu_numpy_it_s": ko / t_cpu,
+                    "gpu_library_loop_it_s": k_lib / t_lib,
+                    "k_persistent": k_small, "gpu_persistent_kernel_it_s": k_small / t_small,
+                    "gpu_persistent_kernel_solve_ms": 1e3 * t_small, "cpu_numpy_solve_ms": 1e3 * t_cpu,
+                    "max_abs_diff_persistent": float(np.max(np.abs(z_small - zo))), "cpu_numpy_it_s": ko / t_cpu,
                     "max_abs_diff": float(np.max(np.abs(z - zo)))})
     print(json.dumps(out, indent=1))
 

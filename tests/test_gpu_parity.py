@@ -1026,3 +1026,80 @@ def test_native_rccl_communicator_world_size_one(pa):
         from proximalalgorithms.jl_amd._lib import call
 
         call("pg_ctx_comm_destroy", ctx2.handle)
+
+
+# ------------------------------------------------------------------------------------------------
+# single-workgroup persistent solver: the driver loop inside one kernel launch
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+@pytest.mark.parametrize("mode", ["fixed", "adaptive"])
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_small_persistent_solver_matches_host_loop(pa, dtype, fast, mode, reuse):
+    if not (fast and mode == "adaptive") and not reuse:
+        pytest.skip("reuse_residual only matters for adaptive FFB")
+    It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
+    Io = o.FastForwardBackwardIteration if fast else o.ForwardBackwardIteration
+    for (m, n, gname) in ((4, 5, "l1"), (50, 100, "l1"), (200, 500, "l1"), (130, 300, "box")):
+        if (m, n) == (4, 5):
+            A, b, lam, Lf = lasso_small(dtype)
+        else:
+            A, b, lam = synthetic_problem(m, n, dtype, seed=m)
+            Lf = dtype(power_Lf(A))
+        g, go = (pa.NormL1(lam), o.NormL1(lam)) if gname == "l1" else (pa.IndBox(dtype(-0.05), dtype(0.08)), o.IndBox(dtype(-0.05), dtype(0.08)))
+        kw = dict(Lf=Lf) if mode == "fixed" else {}
+        if fast:
+            kw["reuse_residual"] = reuse
+        tol = 1e-4 if dtype == np.float32 else 1e-8
+        x0 = np.zeros(n, dtype)
+        f = pa.LeastSquares(A, b)
+        it_h = It(f=f, g=g, x0=x0, **kw)
+        next(iter(it_h))
+        k_h, sc_h = it_h._fused.run(1, 3000, tol)
+        z_h = it_h._fused.view()["z"].numpy().copy()
+        it_s = It(f=f, g=g, x0=x0, **kw)
+        next(iter(it_s))
+        k_s, sc_s = it_s._fused.run_small(1, 3000, tol)
+        z_s = it_s._fused.view()["z"].numpy().copy()
+        okw = {k_: v for k_, v in kw.items() if k_ != "reuse_residual"}
+        z_o, k_o = (o.fast_forward_backward if fast else o.forward_backward)(tol=tol, maxit=3000, x0=x0, f=o.LeastSquares(A, b), g=go, **okw)
+        slack = 0 if dtype == np.float64 else max(2, k_o // 50)
+        assert abs(k_s - k_h) <= slack and abs(k_s - k_o) <= slack, (m, n, k_s, k_h, k_o)
+        ztol = 1e-4 if dtype == np.float32 else 1e-9
+        assert np.max(np.abs(z_s - z_h)) <= ztol * max(1.0, np.max(np.abs(z_h))), (m, n)
+        assert np.max(np.abs(z_s - z_o)) <= ztol * max(1.0, np.max(np.abs(z_o))), (m, n)
+        assert float(sc_s.res_inf) / float(sc_s.gamma) <= tol or k_s >= 3000
+        if dtype == np.float64:
+            assert float(sc_s.gamma) == pytest.approx(float(sc_h.gamma), rel=1e-12)
+        # the iterator stays usable: continue with ordinary host-driven steps from the persistent solver's state
+        s1 = it_s._fused.step()
+        assert np.isfinite(s1.f_x) and float(s1.gamma) > 0
+    with pytest.raises(pa.ProxGradError):
+        Ab, bb, lb = synthetic_problem(1100, 1000, np.float32, seed=1)
+        big = It(f=pa.LeastSquares(Ab, bb), g=pa.NormL1(lb), x0=np.zeros(1000, np.float32))
+        next(iter(big))
+        big._fused.run_small(1, 10, 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_device_loop_option_same_answers(pa, dtype):
+    """FastForwardBackward(..., device_loop=True): the default driver loop runs inside the library (one launch for
+    launch-bound sizes) and returns the same (solution, k) as the host loop on the reference's known-answer problem."""
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    f, g = pa.LeastSquares(A, b), pa.NormL1(lam)
+    for name, kw in (("ForwardBackward", dict(Lf=Lf)), ("ForwardBackward", {}), ("FastForwardBackward", dict(Lf=Lf)), ("FastForwardBackward", {})):
+        x_h, k_h = getattr(pa, name)(tol=rv.LASSO_SMALL_TOL)(x0=x0, f=f, g=g, **kw)
+        x_d, k_d = getattr(pa, name)(tol=rv.LASSO_SMALL_TOL, device_loop=True)(x0=x0, f=f, g=g, **kw)
+        assert abs(k_d - k_h) <= (0 if dtype == np.float64 else 2)
+        assert np.max(np.abs(x_d - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
+        assert np.max(np.abs(x_d - x_h)) <= 1e-4
+    # a larger problem takes the in-library loop (batched when the step is fixed)
+    A2, b2, lam2 = synthetic_problem(300, 900, dtype, seed=21)
+    Lf2 = dtype(power_Lf(A2))
+    f2, g2 = pa.LeastSquares(A2, b2), pa.NormL1(lam2)
+    x_h, k_h = pa.FastForwardBackward(tol=1e-4)(x0=np.zeros(900, dtype), f=f2, g=g2, Lf=Lf2)
+    x_d, k_d = pa.FastForwardBackward(tol=1e-4, device_loop=True, check_every=8)(x0=np.zeros(900, dtype), f=f2, g=g2, Lf=Lf2)
+    assert k_h <= k_d < k_h + 8 and np.max(np.abs(x_d - x_h)) <= 1e-3
