@@ -1,6 +1,4 @@
 """IterativeAlgorithm -- mirror of src/ProximalAlgorithms.jl:58-123."""
-import numpy as np
-
 from .device import HIPVector
 
 

@@ -5,12 +5,9 @@ douglas_rachford.jl:58-62 run as ONE HBM sweep, pg_dr_step) and ``generic`` (any
 """
 import ctypes as C
 
-import numpy as np
-
-from . import _lib
 from ._lib import call
 from .algorithm import IterativeAlgorithm
-from .device import HIPVector, as_hipvector
+from .device import as_hipvector
 from .operators import IndBox, NormL1, SeparableQuadratic, Zero, prox_
 
 

@@ -6,10 +6,8 @@ Two engines behind one iterator type:
   * ``generic`` : any operator objects honouring value_and_gradient / prox_ (drop-in boundary #2); the body
                   below is the reference's, on device vectors.
 """
-import numpy as np
-
 from .algorithm import IterativeAlgorithm
-from .device import HIPVector, as_hipvector
+from .device import as_hipvector
 from .fb_tools import backtrack_stepsize_, lower_bound_smoothness_constant
 from .operators import Zero, fused_supported, prox_, value_and_gradient
 from ._fused import FusedIteration

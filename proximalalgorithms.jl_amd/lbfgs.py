@@ -4,7 +4,7 @@ import weakref
 
 from . import _lib
 from ._lib import call
-from .device import HIPVector, get_context, pg_dtype
+from .device import pg_dtype
 
 
 class LBFGSOperator:

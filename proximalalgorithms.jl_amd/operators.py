@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import PG_G_INDBOX, PG_G_NORML1, PG_G_ZERO, call
-from .device import HIPMatrix, HIPVector, as_hipvector, get_context
+from .device import HIPMatrix, HIPVector, as_hipvector
 
 
 class LeastSquares:

@@ -10,8 +10,8 @@ import warnings
 import numpy as np
 
 from .algorithm import IterativeAlgorithm
-from .device import HIPMatrix, HIPVector, as_hipvector
-from .lbfgs import LBFGS, LBFGSOperator
+from .device import HIPMatrix, as_hipvector
+from .lbfgs import LBFGS
 from .operators import Zero, prox_, value_and_gradient
 
 

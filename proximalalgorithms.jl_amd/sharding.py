@@ -3,8 +3,6 @@ of b are the independent units; every gradient evaluation ends with ONE sum all-
 (n+1 elements) over RCCL/xGMI, every f-only evaluation with a 1-element all-reduce.  All n-vectors are
 replicated, so the elementwise epilogue and its reductions need no communication.
 """
-import numpy as np
-
 
 def shard_rows(m_global, world_size, rank):
     """Contiguous, balanced row partition: returns (row_offset, m_local)."""
