@@ -436,6 +436,10 @@ pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64
   if (per_cu > lds_cap) per_cu = lds_cap;
   if (per_cu < 1) per_cu = 1;
   int64_t blocks = (int64_t)c->num_cu * per_cu;
+  // long columns: 4-wave workgroups on only 3/4 of the CUs (192 x 4 waves x 16 KiB = 12 MiB in flight) measured
+  // 2-3 % faster than one workgroup on every CU; all workgroups are resident, so the column groups stay balanced
+  if (WAVES >= 4 && nrg >= 16 && per_cu == 1) blocks = (int64_t)c->num_cu * 3 / 4;
+  if (env_int("PG_T_BLOCKS", 0) > 0) blocks = env_int("PG_T_BLOCKS", 0);
   const int64_t need = (ncg + WAVES - 1) / WAVES;
   if (blocks > need) blocks = need;
   if (blocks < 1) blocks = 1;
@@ -451,14 +455,14 @@ template <typename T>
 pg_status launch_t(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64_t col0, int64_t ncols) {
   // default: 2 adjacent columns x UR row groups in flight per wave; 2-wave workgroups, one per CU, when a column
   // is long enough for UR = 8 (512 waves x 16 KiB = 8 MiB in flight chip-wide); shorter columns use more waves
-  int dC = 2, dUR = 8, dW = 2;
-  if (nrg < 16) {  // short columns: 4 columns per wave so that a wave still moves >= 16 KiB per reduction
-    dC = 4;
+  // (measured: scripts/tune_gemv.py and the block-count sweeps in profiles/r1_tune_gemv.log)
+  int dC = 2, dUR = 8, dW = 4;  // columns of >= 16 row groups (4096 f32 rows): 2 columns x 8 row groups per wave
+  if (nrg < 16) dW = 2;         // 8..15 row groups: the same tile, 2-wave workgroups on every CU
+  if (nrg < 8) {
     dUR = 4;
     dW = 4;
   }
   if (nrg < 4) {
-    dC = 2;
     dUR = 2;
     dW = 8;
   }
