@@ -315,9 +315,12 @@ PlanN plan_n(const pg_mat* A) {
   const int TB = 4 / p.TW;
   p.n_tile_groups = (p.n_tiles + TB - 1) / TB;
   const int64_t ncb = A->n > 0 ? (A->n + p.U - 1) / p.U : 1;
-  // ~3 active waves per CU for tall matrices (>= 8 row tiles), 4 otherwise (measured optimum, see above)
-  const int64_t target_waves = (int64_t)A->ctx->num_cu * env_int("PG_N_WAVES_PER_CU", p.n_tiles >= 8 ? 3 : 4);
-  int64_t S = target_waves / ((int64_t)p.n_tile_groups * TB);
+  // ~832 active waves chip-wide (3.25 per CU; x R*U = 8 KiB each = 6.5 MiB in flight) for tall matrices, ~896 for
+  // short ones: the measured optimum of the wave-count sweeps (profiles/r1_tune_gemv.log); +-128 waves costs 2-3 %
+  const int per_cu_x4 = env_int("PG_N_WAVES_PER_CU", 0) > 0 ? 4 * env_int("PG_N_WAVES_PER_CU", 0) : (p.n_tiles >= 8 ? 13 : 14);
+  const int64_t target_waves = (int64_t)A->ctx->num_cu * per_cu_x4 / 4;
+  const int64_t tw_abs = env_int("PG_N_WAVES", 0);
+  int64_t S = (tw_abs > 0 ? tw_abs : target_waves) / ((int64_t)p.n_tile_groups * TB);
   if (S < 1) S = 1;
   if (S > ncb) S = ncb;
   S = (S + p.TW - 1) / p.TW * p.TW;
