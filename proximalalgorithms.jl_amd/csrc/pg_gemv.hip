@@ -292,9 +292,9 @@ PlanN plan_n(const pg_mat* A) {
   PlanN p;
   const int64_t rows_per_rg = 1024 / (int64_t)pg_sizeof(A->dtype);
   p.n_rowgroups = (int)(A->ld / rows_per_rg);
-  // Measured on MI355X (scripts/tune_gemv.py, profiles/r1_tune_gemv.log): both passes peak with only ~6-8 MiB of
-  // loads in flight chip-wide (pass N: 768 waves x R*U KiB, i.e. 3 waves per CU on average, 192 workgroups);
-  // deeper queues cost 3-5 % (DRAM page conflicts / queueing), shallower ones starve the memory system.
+  // Wave tile: R KiB of each of U columns per step (8 KiB of loads in flight per wave).  Measured on MI355X
+  // (scripts/tune_gemv.py, profiles/r1_tune_block_counts.md): the pass peaks with ~6.5 MiB in flight chip-wide;
+  // deeper queues cost 3-8 % (DRAM page conflicts / queueing), shallower ones starve the memory system.
   if (p.n_rowgroups >= 4) {
     p.R = 4;
     p.U = 2;
