@@ -18,6 +18,7 @@ Extra legs in the same line:
                 this host on a bounded sample (same m, fewer columns), scaled to it/s of the full workload.
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -59,7 +60,12 @@ def parse_args():
                         "rank holds --m rows (BASELINE config 5 = --scaling weak --m 16384 on 8 GPUs: 131072 x 2^20)")
     p.add_argument("--collective", choices=["torch", "native"], default="torch",
                    help="N > 1: all-reduce through torch.distributed (default) or the library's own RCCL communicator")
-    p.add_argument("--no-overlap", action="store_true", help="disable the chunked asynchronous all-reduce (N > 1)")
+    p.add_argument("--overlap", action="store_true",
+                   help="pipeline the [grad ; f] all-reduce with pass T in column chunks (N > 1). Off by default: at the "
+                        "headline shard shape the chunking costs ~60 us/step, about what it can hide (DESIGN.md section 6)")
+    p.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
+    p.add_argument("--force-comm", action="store_true",
+                   help="diagnostic: attach the collective even with one rank (measures the cost of the sharded code path)")
     p.add_argument("--share-device", action="store_true",
                    help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
     return p.parse_args()
@@ -116,6 +122,12 @@ def main():
 
     import proximalalgorithms.jl_amd as pa
 
+    # stdout carries exactly ONE line (the JSON, written last by rank 0): RCCL prints a version banner through C
+    # stdio on fd 1 when a communicator is created, so everything else on fd 1 is routed to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,8 +138,12 @@ def main():
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -153,9 +169,9 @@ def main():
     b = A.mul(pa.HIPVector.from_numpy(x_true, ctx))  # rows are independent: no collective
     b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
     comm = None
-    if world > 1:
-        comm = (pa.NativeRcclComm(overlap=not args.no_overlap) if args.collective == "native"
-                else pa.TorchDistributedComm(overlap=not args.no_overlap))
+    if world > 1 or args.force_comm:
+        comm = (pa.NativeRcclComm(overlap=args.overlap) if args.collective == "native"
+                else pa.TorchDistributedComm(overlap=args.overlap))
     f = pa.LeastSquares(A, b, comm=comm)
     zero_n = pa.HIPVector.zeros(n, dtype, ctx)
     _, g0 = f.value_and_gradient(zero_n)  # = -A'b (all-reduced over the shards)
@@ -212,12 +228,17 @@ def main():
     bytes_iter_local = a_passes / max(args.steps, 1) * m_loc * n * es + 10 * n * es + 3 * m_loc * es
     # dominant kernel = the slower GEMV pass; algorithmic bytes of one launch = the local A block + vectors
     kern = {}
+    n_cnt = prof["gemv_n_partial"][0]
     for name, vec_bytes in (("gemv_n_partial", n * es), ("gemv_t", m_loc * es + n * es)):
         cnt, ms = prof[name]
         if cnt:
             avg_ms = ms / cnt
-            kern[name] = {"launches": cnt, "avg_ms": avg_ms,
-                          "GBps": (m_loc * n * es + vec_bytes) / (avg_ms * 1e-3) / 1e9}
+            # with a collective attached pass T runs as several column-chunk launches per evaluation
+            # (pg_gemv.hip ls_grad_stage_t): one launch then covers 1/chunks of the local block
+            evals = max(a_passes - n_cnt, 1) if name == "gemv_t" else cnt
+            launch_bytes = (m_loc * n * es + vec_bytes) * evals / cnt
+            kern[name] = {"launches": cnt, "avg_ms": avg_ms, "bytes": launch_bytes,
+                          "launches_per_pass": cnt / evals, "GBps": launch_bytes / (avg_ms * 1e-3) / 1e9}
     dom = max(kern, key=lambda k_: kern[k_]["avg_ms"]) if kern else None
     roofline = None
     if dom:
@@ -236,8 +257,9 @@ def main():
                     "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "avg_launch_ms": round(kern[dom]["avg_ms"], 4), "launches": kern[dom]["launches"],
-                    "algorithmic_bytes_per_launch": m_loc * n * es + (n * es if dom == "gemv_n_partial" else (m_loc + n) * es),
-                    "per_kernel": {k_: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1), "launches": v["launches"]}
+                    "algorithmic_bytes_per_launch": int(kern[dom]["bytes"]),
+                    "per_kernel": {k_: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1),
+                                        "launches": v["launches"], "launches_per_pass": round(v["launches_per_pass"], 2)}
                                    for k_, v in kern.items()},
                     "whole_iteration": {"algorithmic_bytes_per_gpu": int(bytes_iter_local),
                                         "GBps_per_gpu": round(bytes_iter_local * its / 1e9, 1),
@@ -270,10 +292,16 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    else:
+        line = None
+    if world > 1 or args.force_comm:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ class TorchDistributedComm:
     registers the C callback the library invokes between the local GEMV passes and the replicated epilogue;
     the collective is enqueued on the context's stream (torch's current stream), so no host sync is added."""
 
-    def __init__(self, group=None, overlap=True):
+    def __init__(self, group=None, overlap=False):
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()):
@@ -85,7 +85,7 @@ class NativeRcclComm:
     """The library's own RCCL communicator (csrc/pg_comm.hip): no Python in the collective path.  The 128-byte
     ncclUniqueId is created on rank 0 and shipped with torch.distributed (any backend) when world_size > 1."""
 
-    def __init__(self, world_size=None, rank=None, overlap=True):
+    def __init__(self, world_size=None, rank=None, overlap=False):
         import torch.distributed as dist
 
         if world_size is None:

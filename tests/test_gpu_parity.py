@@ -481,7 +481,7 @@ def test_nccl_world_size_one(pa):
             m = 256
             A, b, lam = synthetic_problem(m, n, np.float32, seed=5)
             ctx2 = pa.Context()
-            comm = pa.TorchDistributedComm()
+            comm = pa.TorchDistributedComm(overlap=True)
             f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
             f_pl = pa.LeastSquares(A, b)
             x = np.random.default_rng(1).standard_normal(n).astype(np.float32)
@@ -521,12 +521,12 @@ def _run_bench(extra, nproc=1, port=29641):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("mode", ["fixed", "adaptive"])
-def test_two_ranks_one_gpu_matches_single_rank(pa, mode):
+@pytest.mark.parametrize("mode,overlap", [("fixed", False), ("adaptive", False), ("fixed", True)])
+def test_two_ranks_one_gpu_matches_single_rank(pa, mode, overlap):
     """bench.py with 2 processes (row shards of 1024 rows each) sharing cuda:0 over gloo == 1 process:
     same lambda / Lf (they come from all-reduced quantities) and the same iterate after 14 steps."""
     one = _run_bench(["--mode", mode])
-    two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device"], nproc=2)
+    two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device"] + (["--overlap"] if overlap else []), nproc=2)
     assert two["n_gpus"] == 2 and two["config"]["m_per_gpu"] * 2 == one["config"]["m"]
     assert two["config"]["lambda"] == pytest.approx(one["config"]["lambda"], rel=1e-5)
     if mode == "fixed":
