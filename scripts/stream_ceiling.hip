@@ -1,0 +1,85 @@
+// HBM ceiling microbenchmark for MI355X ("report a measured stream-copy ceiling from the build's own
+// microbenchmark").  Read-only (the GEMV passes are >99.9 % reads) and copy, swept over launch geometry.
+//   hipcc -O3 --offload-arch=gfx950 scripts/stream_ceiling.hip -o /tmp/stream_ceiling && /tmp/stream_ceiling [GiB]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int U, bool NT>
+__global__ void read_kernel(const f4* __restrict__ p, size_t n4, float* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  f4 acc = {0, 0, 0, 0};
+  for (; i + (U - 1) * stride < n4; i += U * stride) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+  }
+  for (; i < n4; i += stride) acc += p[i];
+  float s = acc.x + acc.y + acc.z + acc.w;
+  if (s == 1.2345e-30f) out[0] = s;  // keep the loads alive
+}
+
+template <int U>
+__global__ void copy_kernel(const f4* __restrict__ p, f4* __restrict__ q, size_t n4) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i + (U - 1) * stride < n4; i += U * stride) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], q + i + u * stride);
+  }
+  for (; i < n4; i += stride) q[i] = p[i];
+}
+
+template <typename F>
+static double time_ms(F launch, int reps) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  launch();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int r = 0; r < reps; ++r) launch();
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const double gib = argc > 1 ? atof(argv[1]) : 16.0;
+  const size_t bytes = (size_t)(gib * (1ull << 30));
+  const size_t n4 = bytes / 16;
+  f4 *p, *q;
+  float* out;
+  CK(hipMalloc(&p, bytes)); CK(hipMalloc(&q, bytes)); CK(hipMalloc(&out, 4));
+  CK(hipMemset(p, 0, bytes)); CK(hipMemset(q, 0, bytes));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cu = prop.multiProcessorCount;
+  printf("# %s, %d CUs, buffer %.1f GiB\n# kind threads blocks unroll nt ms GB/s\n", prop.gcnArchName, cu, gib);
+  double best_r = 0, best_c = 0;
+  for (int threads : {256, 512, 1024})
+    for (int bpc : {1, 2, 4, 8, 16}) {
+      const int blocks = cu * bpc;
+      if ((long)threads * bpc > 2048) continue;
+#define RUN_R(U, NT) { double ms = time_ms([&] { hipLaunchKernelGGL((read_kernel<U, NT>), dim3(blocks), dim3(threads), 0, 0, p, n4, out); }, 3); \
+        double g = bytes / ms / 1e6; if (g > best_r) best_r = g; printf("read %d %d %d %d %.3f %.1f\n", threads, blocks, U, (int)NT, ms, g); }
+      RUN_R(1, true) RUN_R(2, true) RUN_R(4, true) RUN_R(8, true) RUN_R(4, false)
+#define RUN_C(U) { double ms = time_ms([&] { hipLaunchKernelGGL((copy_kernel<U>), dim3(blocks), dim3(threads), 0, 0, p, q, n4); }, 3); \
+        double g = 2.0 * bytes / ms / 1e6; if (g > best_c) best_c = g; printf("copy %d %d %d 1 %.3f %.1f\n", threads, blocks, U, ms, g); }
+      RUN_C(1) RUN_C(4)
+    }
+  printf("# best read-only %.1f GB/s, best copy (read+write) %.1f GB/s\n", best_r, best_c);
+  return 0;
+}
