@@ -221,6 +221,18 @@ pg_status pg_dr_step(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, void* y, vo
                      const void* d_vec, double d, const void* q_vec, double q, int32_t g_kind, double g_p0,
                      double g_p1, double gamma, double* scalars_out /* host, 3 doubles; NULL = no sync */);
 
+/* The DouglasRachford driver loop (src/ProximalAlgorithms.jl:114-123 with the default stop rule
+ * norm(res, Inf) / gamma <= tol, douglas_rachford.jl:65-69, evaluated in T) inside the library.  With block = 8 or 16
+ * that many iterations run per HBM sweep (f and g are separable, so the iterates of an element stay in registers;
+ * the stop rule of every inner iteration is still evaluated and, when one of them fires, the block is replayed up to
+ * it, so the state left behind is bit-identical to stepping with pg_dr_step).  block = 1 steps one by one.
+ * x_alt: caller-owned scratch n-vector (ping-pong partner of x; required when block > 1).  On return x, y (and r, z,
+ * res when given) hold the state of iteration *k_out; scalars_out as in pg_dr_step. */
+pg_status pg_dr_run(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, void* x_alt, void* y, void* r, void* z, void* res,
+                    const void* d_vec, double d, const void* q_vec, double q, int32_t g_kind, double g_p0, double g_p1,
+                    double gamma, double tol, int64_t maxit, int32_t block, int64_t* k_out,
+                    double* scalars_out /* host, 3 doubles, may be NULL */);
+
 /* ------------------------------------------------------------------ fused iterations ---- */
 /* Options = the keyword arguments of ForwardBackwardIteration (forward_backward.jl:38-48) and
  * FastForwardBackwardIteration (fast_forward_backward.jl:44-56), f = LeastSquares, g by kind. */

@@ -28,6 +28,13 @@ class IterativeAlgorithm:
         x0 = merged.get("x0")
         host_x0 = x0 is not None and not isinstance(x0, HIPVector)
         it = self.iterator_type(**merged)
+        if (self.device_loop is not None and getattr(it, "engine", None) == "fused" and not self.verbose
+                and hasattr(it, "device_run")):
+            state, k = it.device_run(self.maxit, *self.device_loop)  # iterations that carry their own in-library loop
+            sol = self.solution(it, state)
+            if host_x0 and isinstance(sol, HIPVector):
+                sol = sol.numpy()
+            return sol, k
         if self.device_loop is not None and getattr(it, "engine", None) == "fused" and not self.verbose:
             tol, check_every = self.device_loop
             gen = iter(it)

@@ -62,11 +62,12 @@ enum {
   PG_S_RESSQ = 4,    // ||res||^2
   PG_S_MISC = 5,     // dot / nrm2sq / nrminf / prox value results (2 slots)
   PG_S_DR = 8,       // Douglas-Rachford step: { ||res||_inf, f(y), g(z) }
-  PG_S_COUNT = 16
+  PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 16 inner iterations, f(y), g(z) }
+  PG_S_COUNT = 40
 };
 
 constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize
-constexpr int PG_RED_MAX_NS = 4;
+constexpr int PG_RED_MAX_NS = 18;
 
 // RCCL communicator bound by pg_ctx_comm_init (csrc/pg_comm.hip)
 struct pg_comm {

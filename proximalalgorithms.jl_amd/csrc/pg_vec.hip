@@ -207,6 +207,16 @@ struct SepQuadParams {
   T ds, qs;
 };
 
+// (x - gamma q) / (1 + gamma d) with every product rounded (no FMA contraction): the single-step and the
+// multi-iteration kernels must produce the same bits, and so does an unfused CPU evaluation
+template <typename T>
+__device__ __forceinline__ T sepquad_prox_elem(T x, T gamma, T de, T qe) {
+#pragma clang fp contract(off)
+  const T gq = gamma * qe;
+  const T den = T(1) + gamma * de;
+  return (x - gq) / den;
+}
+
 template <typename T, int N>
 __device__ __forceinline__ void sepquad_prox(const SepQuadParams<T>& f, T gamma, int64_t i, const Pack<T, N>& x,
                                              Pack<T, N>& y, double* fval) {
@@ -217,7 +227,7 @@ __device__ __forceinline__ void sepquad_prox(const SepQuadParams<T>& f, T gamma,
   for (int e = 0; e < N; ++e) {
     const T de = f.dv != nullptr ? d.v[e] : f.ds;
     const T qe = f.qv != nullptr ? q.v[e] : f.qs;
-    y.v[e] = (x.v[e] - gamma * qe) / (T(1) + gamma * de);
+    y.v[e] = sepquad_prox_elem(x.v[e], gamma, de, qe);
     if (fval != nullptr) *fval += 0.5 * (double)de * (double)y.v[e] * (double)y.v[e] + (double)qe * (double)y.v[e];
   }
 }
@@ -277,6 +287,92 @@ struct DRStepF {
   }
   __device__ double post_scale(int k) const { return k == 2 ? gscale : 1.0; }
 };
+
+// K Douglas-Rachford iterations per HBM sweep (temporal blocking): f and g are separable, so an element's K updates
+// depend on nothing but the element -- x, d, q are read once, the iterates stay in registers, and only the state of
+// the LAST iteration (x, y and optionally r, z, res) is written.  The stop rule of every one of the K iterations is
+// still evaluated: acc[j] = max|res| of inner iteration j (the host replays from x_in when an inner iteration other
+// than the last one satisfies it, so the returned state is exactly the one the step-by-step loop stops at).
+//   acc = { max|res|_0 .. max|res|_{K-1} , f(y_K) , g(z_K)/lam }
+template <typename T, int GKIND, int K>
+struct DRBlockArgs {
+  const T* __restrict__ x_in;
+  T* __restrict__ x_out;
+  T* __restrict__ y;
+  T* __restrict__ r;    // nullable
+  T* __restrict__ z;    // nullable
+  T* __restrict__ res;  // nullable
+  SepQuadParams<T> f;
+  T gamma, p0, p1;
+  double gscale;
+};
+
+template <typename T, int GKIND, int K, int N>
+__device__ __forceinline__ void dr_block_apply(const DRBlockArgs<T, GKIND, K>& a, int64_t i, T (&mx)[K], double& fy,
+                                               double& gz) {
+  Pack<T, N> xv = ld<T, N>(a.x_in, i), yv, rv, zv, sv, d, q;
+  if (a.f.dv != nullptr) d = ld<T, N>(a.f.dv, i);
+  if (a.f.qv != nullptr) q = ld<T, N>(a.f.qv, i);
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const T de = a.f.dv != nullptr ? d.v[e] : a.f.ds;
+    const T qe = a.f.qv != nullptr ? q.v[e] : a.f.qs;
+    T xe = xv.v[e], ye, re, ze, se;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ye = sepquad_prox_elem(xe, a.gamma, de, qe);
+      re = T(2) * ye - xe;
+      if constexpr (GKIND == PG_G_NORML1)
+        ze = soft_threshold(re, a.p0);
+      else if constexpr (GKIND == PG_G_INDBOX)
+        ze = fmin(a.p1, fmax(a.p0, re));
+      else
+        ze = re;
+      se = ye - ze;
+      xe = xe - se;
+      mx[j] = fmax(mx[j], fabs(se));
+    }
+    xv.v[e] = xe, yv.v[e] = ye, rv.v[e] = re, zv.v[e] = ze, sv.v[e] = se;
+    fy += 0.5 * (double)de * (double)ye * (double)ye + (double)qe * (double)ye;
+    if constexpr (GKIND == PG_G_NORML1) gz += fabs((double)ze);
+  }
+  st<T, N>(a.x_out, i, xv);
+  st_nt<T, N>(a.y, i, yv);
+  if (a.r != nullptr) st_nt<T, N>(a.r, i, rv);
+  if (a.z != nullptr) st_nt<T, N>(a.z, i, zv);
+  if (a.res != nullptr) st_nt<T, N>(a.res, i, sv);
+}
+
+// 512-thread workgroups, two per CU: the K running maxima live in T registers over the whole sweep (they only become
+// doubles for the grid reduction), which keeps the K = 16 body free of scratch spills
+constexpr int DR_BLOCK_BS = 512;
+
+template <typename T, int GKIND, int K>
+__global__ __launch_bounds__(DR_BLOCK_BS) void dr_block_kernel(int64_t n, bool vec_ok, DRBlockArgs<T, GKIND, K> a,
+                                                               double* __restrict__ red_partials,
+                                                               unsigned* __restrict__ red_counter,
+                                                               double* __restrict__ out) {
+  constexpr int VEC = VecOf<T>::N;
+  T mx[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) mx[j] = T(0);
+  double fy = 0.0, gz = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * DR_BLOCK_BS + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * DR_BLOCK_BS;
+  if (vec_ok) {
+    const int64_t nvec = n / VEC;
+    for (int64_t v = tid; v < nvec; v += nthreads) dr_block_apply<T, GKIND, K, VEC>(a, v * VEC, mx, fy, gz);
+    for (int64_t i = nvec * VEC + tid; i < n; i += nthreads) dr_block_apply<T, GKIND, K, 1>(a, i, mx, fy, gz);
+  } else {
+    for (int64_t i = tid; i < n; i += nthreads) dr_block_apply<T, GKIND, K, 1>(a, i, mx, fy, gz);
+  }
+  double v[K + 2], ps[K + 2];
+#pragma unroll
+  for (int j = 0; j < K; ++j) v[j] = (double)mx[j], ps[j] = 1.0;
+  v[K] = fy, ps[K] = 1.0;
+  v[K + 1] = gz, ps[K + 1] = a.gscale;
+  grid_reduce_finalize<K + 2, (1u << K) - 1u, DR_BLOCK_BS / 64>(v, red_partials, red_counter, out, ps);
+}
 
 // smooth losses on m-vectors (the `f` of PANOC's f(Ax)); acc[0] = f(u), grad written elementwise
 //   LOSS 0: squared distance  f(u) = ||u - b||^2 / 2 , grad = u - b     (benchmark/benchmarks.jl:19-28)
@@ -443,6 +539,98 @@ pg_status dr_step_t(pg_ctx* c, int64_t n, void* x, void* y, void* r, void* z, vo
   return PG_ERR_INVALID;
 }
 
+template <typename T, int GKIND, int K>
+pg_status dr_block_launch(pg_ctx* c, int64_t n, bool vec_ok, const DRBlockArgs<T, GKIND, K>& a) {
+  int64_t blocks = (n / VecOf<T>::N + DR_BLOCK_BS) / DR_BLOCK_BS;
+  if (blocks > (int64_t)c->num_cu * 2) blocks = (int64_t)c->num_cu * 2;
+  if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
+  hipLaunchKernelGGL((dr_block_kernel<T, GKIND, K>), dim3((unsigned)blocks), dim3(DR_BLOCK_BS), 0, c->stream, n, vec_ok, a,
+                     c->red_partials, c->red_counter, c->dscal + PG_S_DRRUN);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+template <typename T, int K>
+pg_status dr_block_t(pg_ctx* c, int64_t n, const void* x_in, void* x_out, void* y, void* r, void* z, void* res,
+                     const void* dv, double ds, const void* qv, double qs, int g_kind, double g_p0, double g_p1,
+                     double gamma) {
+  const bool v = aligned16(x_in) && aligned16(x_out) && aligned16(y) && (!r || aligned16(r)) && (!z || aligned16(z)) &&
+                 (!res || aligned16(res)) && (!dv || aligned16(dv)) && (!qv || aligned16(qv));
+  const T gm = (T)gamma;
+  SepQuadParams<T> fp{(const T*)dv, (const T*)qv, (T)ds, (T)qs};
+  pg_prof_scope prof(c, PG_K_DR_STEP);
+  if (g_kind == PG_G_NORML1) {
+    DRBlockArgs<T, PG_G_NORML1, K> a{(const T*)x_in, (T*)x_out, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)(gm * (T)g_p0),
+                                     T(0), (double)(T)g_p0};
+    return dr_block_launch(c, n, v, a);
+  }
+  if (g_kind == PG_G_INDBOX) {
+    DRBlockArgs<T, PG_G_INDBOX, K> a{(const T*)x_in, (T*)x_out, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)g_p0, (T)g_p1, 0.0};
+    return dr_block_launch(c, n, v, a);
+  }
+  if (g_kind == PG_G_ZERO) {
+    DRBlockArgs<T, PG_G_ZERO, K> a{(const T*)x_in, (T*)x_out, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, T(0), T(0), 0.0};
+    return dr_block_launch(c, n, v, a);
+  }
+  pg_set_error("unknown g_kind %d", g_kind);
+  return PG_ERR_INVALID;
+}
+
+// DouglasRachford driver loop (ProximalAlgorithms.jl:114-123 with the stop rule of douglas_rachford.jl:65-69) in
+// blocks of K iterations per sweep; returns the number of iterations k and leaves exactly the state of iteration k
+template <typename T>
+pg_status dr_run_t(pg_ctx* c, int64_t n, void* x, void* x_alt, void* y, void* r, void* z, void* res, const void* dv,
+                   double ds, const void* qv, double qs, int g_kind, double g_p0, double g_p1, double gamma, double tol,
+                   int64_t maxit, int K, int64_t* k_out, double* scalars_out) {
+  const T gm = (T)gamma, tl = (T)tol;
+  auto stop = [&](double res_inf) { return (T)res_inf / gm <= tl; };  // norm(res, Inf) / gamma <= tol  in T
+  void *cur = x, *alt = x_alt;
+  int64_t k = 0;
+  double sc[3] = {0, 0, 0};
+  bool done = false;
+  while (!done && k < maxit) {
+    if (K > 1 && maxit - k >= K) {
+      PG_TRY(K == 16 ? (dr_block_t<T, 16>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma))
+                     : (dr_block_t<T, 8>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma)));
+      PG_TRY(pg_read_scalars(c, PG_S_DRRUN, K + 2));
+      int hit = -1;
+      for (int j = 0; j < K && hit < 0; ++j)
+        if (k + j + 1 >= maxit || stop(c->hscal[PG_S_DRRUN + j])) hit = j;
+      if (hit < 0 || hit == K - 1) {
+        k += K;
+        std::swap(cur, alt);
+        sc[0] = c->hscal[PG_S_DRRUN + K - 1], sc[1] = c->hscal[PG_S_DRRUN + K], sc[2] = c->hscal[PG_S_DRRUN + K + 1];
+        done = hit >= 0;
+      } else {
+        // an inner iteration stopped: replay hit+1 single steps from the block's input (same arithmetic, same bits)
+        for (int j = 0; j <= hit; ++j)
+          PG_TRY(dr_step_t<T>(c, n, cur, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma));
+        PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
+        for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
+        k += hit + 1;
+        done = true;
+      }
+    } else {
+      PG_TRY(dr_step_t<T>(c, n, cur, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma));
+      PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
+      for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
+      ++k;
+      done = k >= maxit || stop(sc[0]);
+    }
+  }
+  if (cur != x && n > 0) {
+    if (hipMemcpyAsync(x, cur, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+      pg_set_error("hipMemcpyAsync failed");
+      return PG_ERR_HIP;
+    }
+    PG_TRY(pg_ctx_sync(c));
+  }
+  if (k_out) *k_out = k;
+  if (scalars_out)
+    for (int q3 = 0; q3 < 3; ++q3) scalars_out[q3] = sc[q3];
+  return PG_OK;
+}
+
 template <typename T>
 pg_status loss_t(pg_ctx* c, int loss, int64_t m, const void* u, const void* b, void* grad) {
   const bool v = aligned16(u) && aligned16(b) && aligned16(grad);
@@ -605,6 +793,22 @@ pg_status pg_dr_step(pg_ctx* c, int32_t dtype, int64_t n, void* x, void* y, void
     for (int k = 0; k < 3; ++k) scalars_out[k] = c->hscal[PG_S_DR + k];
   }
   return PG_OK;
+}
+
+pg_status pg_dr_run(pg_ctx* c, int32_t dtype, int64_t n, void* x, void* x_alt, void* y, void* r, void* z, void* res,
+                    const void* d_vec, double d, const void* q_vec, double q, int32_t g_kind, double g_p0, double g_p1,
+                    double gamma, double tol, int64_t maxit, int32_t block, int64_t* k_out, double* scalars_out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_REQUIRE(block == 1 || block == 8 || block == 16, "block must be 1, 8 or 16");
+  PG_REQUIRE(block == 1 || (x_alt != nullptr && x_alt != x) || n == 0, "x_alt (a second n-vector) is required when block > 1");
+  PG_REQUIRE(maxit >= 1, "maxit must be >= 1");
+  PG_REQUIRE(gamma > 0, "gamma must be positive");
+  return dtype == PG_F32 ? dr_run_t<float>(c, n, x, x_alt, y, r, z, res, d_vec, d, q_vec, q, g_kind, g_p0, g_p1, gamma,
+                                           tol, maxit, block, k_out, scalars_out)
+                         : dr_run_t<double>(c, n, x, x_alt, y, r, z, res, d_vec, d, q_vec, q, g_kind, g_p0, g_p1, gamma,
+                                            tol, maxit, block, k_out, scalars_out);
 }
 
 pg_status pg_loss_value_and_gradient(pg_ctx* c, int32_t dtype, int32_t loss, int64_t m, const void* u, const void* b,

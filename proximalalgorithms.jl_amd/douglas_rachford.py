@@ -47,6 +47,25 @@ class DouglasRachfordIteration:
         self.engine = engine
         self.materialize = bool(materialize)
 
+    def device_run(self, maxit, tol, block=16):
+        """The driver loop of ProximalAlgorithms.jl:114-123 with the default stop rule, inside the library
+        (pg_dr_run): ``block`` iterations per HBM sweep.  Returns ``(state, k)``; the state is bit-identical to the one
+        the step-by-step loop stops at."""
+        if self.engine != "fused":
+            raise TypeError("device_run needs the fused engine")
+        R = self.x0.dtype.type
+        s = DouglasRachfordState(self.x0.copy())
+        x_alt = s.x.similar()
+        dv, d, qv, q = self.f.c_params()
+        p0, p1 = self.g.g_params()
+        sc = (C.c_double * 3)()
+        k = C.c_int64()
+        opt = (lambda v: v.vp) if self.materialize else (lambda v: None)
+        call("pg_dr_run", s.x.ctx.handle, s.x.pg_dtype, s.x.n, s.x.vp, x_alt.vp, s.y.vp, opt(s.r), opt(s.z), opt(s.res),
+             dv, d, qv, q, self.g.g_kind, p0, p1, float(self.gamma), float(tol), int(maxit), int(block), C.byref(k), sc)
+        s.res_inf, s.f_y, s.g_z = R(sc[0]), R(sc[1]), R(sc[2])
+        return s, int(k.value)
+
     def __iter__(self):
         R = self.x0.dtype.type
         s = DouglasRachfordState(self.x0.copy())  # state = DouglasRachfordState(x = copy(iter.x0))  (:55)
@@ -90,9 +109,11 @@ def default_display(it, iteration, state):
 
 
 def DouglasRachford(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
-                    display=default_display, **kwargs):
-    """douglas_rachford.jl:101-119"""
+                    display=default_display, device_loop=False, check_every=16, **kwargs):
+    """douglas_rachford.jl:101-119.  device_loop=True (default stop rule, fused engine): the driver loop runs inside
+    the library, ``check_every`` (1, 8 or 16) iterations per HBM sweep; same iterates, same iteration count."""
+    dl = (tol, int(check_every)) if (device_loop and stop is None) else None
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
     return IterativeAlgorithm(DouglasRachfordIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose,
-                              freq=freq, display=display, **kwargs)
+                              freq=freq, display=display, device_loop=dl, **kwargs)

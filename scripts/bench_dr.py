@@ -56,6 +56,30 @@ def main():
                                            "frac": bytes_iter / (ms / cnt * 1e-3) / 1e9 / 8000.0},
                               "whole_iteration_GBps": bytes_iter * args.steps / dt / 1e9,
                               "res_inf": float(s.res_inf)}
+    # driver loop inside the library, K iterations per HBM sweep (pg_dr_run); tol = 0 so that exactly `steps` run
+    for block in (8, 16):
+        steps = max(args.steps, 10 * block) // block * block
+        itn = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma,
+                                          materialize=False)
+        itn.device_run(2 * block, 0.0, block)  # warm-up
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.sync()
+        t0 = time.perf_counter()
+        s, k = itn.device_run(steps, 0.0, block)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        cnt, ms = ctx.profile_read()["dr_step"]
+        ctx.profile(False)
+        assert k == steps
+        bytes_launch = 5 * n * 4  # x, d, q in; x, y out -- per K iterations
+        out["modes"]["device_loop_block%d" % block] = {
+            "value": steps / dt, "ms_per_step": 1e3 * dt / steps, "iterations": steps, "launches": cnt,
+            "algorithmic_bytes_per_launch": bytes_launch,
+            "roofline": {"bound": "hbm", "kernel": "dr_block<%d>" % block, "avg_launch_ms": ms / cnt,
+                         "achieved": bytes_launch / (ms / cnt * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": bytes_launch / (ms / cnt * 1e-3) / 1e9 / 8000.0},
+            "res_inf": float(s.res_inf)}
     if not args.no_cpu_baseline:
         ito = iter(o.DouglasRachfordIteration(f=o.SeparableQuadratic(d, q), g=o.IndBox(lo, hi), x0=x0, gamma=gamma))
         next(ito)

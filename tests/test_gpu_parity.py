@@ -643,6 +643,76 @@ def test_douglas_rachford_box_qp(pa, dtype, engine, materialize, gname):
         assert np.max(np.abs(y - np.clip(-q / d, lo, hi))) <= 1e-4
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("gname", ["box", "l1", "zero"])
+@pytest.mark.parametrize("block", [8, 16])
+def test_douglas_rachford_device_loop_is_bit_identical(pa, dtype, gname, block):
+    """pg_dr_run (K iterations per HBM sweep, stop rule evaluated for every inner iteration) leaves exactly the state
+    the step-by-step loop stops at: same k, same bits -- when the rule fires mid-block, at a block end, at maxit
+    (multiple of K or not, smaller than K)."""
+    n = 30011
+    rng = np.random.default_rng(7)
+    d = (0.1 + np.abs(rng.standard_normal(n))).astype(dtype)
+    q = rng.standard_normal(n).astype(dtype)
+    x0 = rng.standard_normal(n).astype(dtype)
+    gamma = dtype(1.3)
+    mk = {"box": lambda: pa.IndBox(dtype(-0.5), dtype(0.25)), "l1": lambda: pa.NormL1(dtype(0.2)), "zero": lambda: pa.Zero()}[gname]
+    f = pa.SeparableQuadratic(d, q)
+
+    def stepwise(maxit, tol):
+        it = pa.DouglasRachfordIteration(f=f, g=mk(), x0=x0, gamma=gamma)
+        for k, s in enumerate(it, start=1):
+            if k >= maxit or dtype(s.res_inf) / gamma <= dtype(tol):
+                return s, k
+
+    tols = [1e-3, 1e-5] if dtype == np.float32 else [1e-3, 1e-9, 1e-13]
+    cases = [(1000, t) for t in tols] + [(3, 0.0), (block, 0.0), (block + 5, 0.0), (3 * block, 0.0), (1, 0.0)]
+    seen = set()
+    for maxit, tol in cases:
+        s_ref, k_ref = stepwise(maxit, tol)
+        it = pa.DouglasRachfordIteration(f=f, g=mk(), x0=x0, gamma=gamma)
+        s_dev, k_dev = it.device_run(maxit, tol, block)
+        assert k_dev == k_ref, (maxit, tol)
+        seen.add(k_ref % block)
+        for name in ("x", "y", "r", "z", "res"):
+            assert np.array_equal(getattr(s_dev, name).numpy(), getattr(s_ref, name).numpy()), (name, maxit, tol)
+        assert float(s_dev.res_inf) == float(s_ref.res_inf)
+        assert float(s_dev.f_y) == pytest.approx(float(s_ref.f_y), rel=1e-12)
+        assert float(s_dev.g_z) == pytest.approx(float(s_ref.g_z), rel=1e-12)
+    assert len(seen) >= 3  # stops both inside blocks and at block ends were exercised
+    # the algorithm wrapper: same answer and count with and without the device loop
+    y1, k1 = pa.DouglasRachford(tol=tols[-1])(x0=x0, f=f, g=mk(), gamma=gamma)
+    y2, k2 = pa.DouglasRachford(tol=tols[-1], device_loop=True, check_every=block)(x0=x0, f=f, g=mk(), gamma=gamma)
+    assert k1 == k2 and np.array_equal(y1, y2)
+    # no x_alt / bad block -> error, not a crash
+    from proximalalgorithms.jl_amd import _lib
+
+    s = pa.DouglasRachfordState(pa.HIPVector.from_numpy(x0))
+    with pytest.raises(pa.ProxGradError):
+        _lib.call("pg_dr_run", s.x.ctx.handle, s.x.pg_dtype, n, s.x.vp, None, s.y.vp, None, None, None, None, 1.0, None, 0.0,
+                _lib.PG_G_ZERO, 0.0, 0.0, 1.0, 0.0, 10, 8, None, None)
+    with pytest.raises(pa.ProxGradError):
+        _lib.call("pg_dr_run", s.x.ctx.handle, s.x.pg_dtype, n, s.x.vp, s.r.vp, s.y.vp, None, None, None, None, 1.0, None, 0.0,
+                _lib.PG_G_ZERO, 0.0, 0.0, 1.0, 0.0, 10, 5, None, None)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_douglas_rachford_elementwise_bits_match_unfused_cpu(pa, dtype):
+    """The separable prox is evaluated without FMA contraction, so one fused DR step reproduces the unfused CPU
+    statements of douglas_rachford.jl:58-62 bit for bit."""
+    n = 10007
+    rng = np.random.default_rng(3)
+    d = (0.1 + np.abs(rng.standard_normal(n))).astype(dtype)
+    q = rng.standard_normal(n).astype(dtype)
+    x0 = rng.standard_normal(n).astype(dtype)
+    gamma = dtype(0.7)
+    it_g = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(dtype(-0.5), dtype(0.25)), x0=x0, gamma=gamma)
+    it_o = o.DouglasRachfordIteration(f=o.SeparableQuadratic(d, q), g=o.IndBox(dtype(-0.5), dtype(0.25)), x0=x0, gamma=gamma)
+    for sg, so in itertools.islice(zip(it_g, it_o), 5):
+        for name in ("y", "r", "z", "res", "x"):
+            assert np.array_equal(getattr(sg, name).numpy(), getattr(so, name)), name
+
+
 # ------------------------------------------------------------------------------------------------
 # PANOC (SURVEY 8(f) row 2 / BASELINE config 4)
 # ------------------------------------------------------------------------------------------------
