@@ -273,7 +273,11 @@ __global__ void cast_scalar_kernel(const T* __restrict__ in, double* __restrict_
   *out = (double)(*in);
 }
 
-constexpr int64_t LDS_R_BYTES = 64 * 1024;  // r chunk per workgroup in pass T (2 workgroups per CU)
+// r chunk per workgroup in pass T: gfx950 has 160 KiB of LDS per CU and pass T runs one workgroup per CU, so up to
+// 128 KiB of r are staged at once (f32 columns of 32768 rows, f64 of 16384) before row chunking sets in.  More than
+// 64 KiB of dynamic LDS has to be opted into per kernel (hipFuncSetAttribute, done once per instantiation).
+constexpr int64_t LDS_R_BYTES = 128 * 1024;
+constexpr int64_t LDS_DEFAULT_LIMIT = 64 * 1024;
 
 // ----------------------------------------------------------------------------------------------
 // host-side launch planning
@@ -446,6 +450,15 @@ pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64
   const int64_t need = (ncg + WAVES - 1) / WAVES;
   if (blocks > need) blocks = need;
   if (blocks < 1) blocks = 1;
+  if ((int64_t)lds > LDS_DEFAULT_LIMIT) {
+    static bool opted_in[64] = {};
+    const int dev = c->device & 63;
+    if (!opted_in[dev]) {
+      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_t_kernel<T, C, UR, WAVES>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_R_BYTES));
+      opted_in[dev] = true;
+    }
+  }
   pg_prof_scope prof(c, PG_K_GEMV_T);
   hipLaunchKernelGGL((gemv_t_kernel<T, C, UR, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, c->stream,
                      (const T*)A->data + col0 * A->ld, A->ld, ncols, A->m, rg_begin, nrg, r, g);

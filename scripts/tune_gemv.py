@@ -45,12 +45,13 @@ def main():
     if len(sys.argv) >= 3:
         shapes = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.argv) - 1, 2)]
     ctx = pa.get_context()
+    dt = np.float64 if os.environ.get("TUNE_DTYPE") == "f64" else np.float32
     for m, n in shapes:
-        A = pa.HIPMatrix.synthetic(m, n, np.float32, seed=0)
-        x = pa.HIPVector.from_numpy(np.random.default_rng(0).standard_normal(n).astype(np.float32))
-        r = pa.HIPVector.from_numpy(np.random.default_rng(1).standard_normal(m).astype(np.float32))
-        y, g = pa.HIPVector.empty(m, np.float32), pa.HIPVector.empty(n, np.float32)
-        bytes_a = m * n * 4
+        A = pa.HIPMatrix.synthetic(m, n, dt, seed=0)
+        x = pa.HIPVector.from_numpy(np.random.default_rng(0).standard_normal(n).astype(dt))
+        r = pa.HIPVector.from_numpy(np.random.default_rng(1).standard_normal(m).astype(dt))
+        y, g = pa.HIPVector.empty(m, dt), pa.HIPVector.empty(n, dt)
+        bytes_a = m * n * np.dtype(dt).itemsize
         print(f"=== m={m} n={n} ({bytes_a / 2**30:.1f} GiB) ===", flush=True)
         setenv(PG_N_R=None, PG_N_U=None, PG_N_TW=None, PG_N_WAVES_PER_CU=None)
         y_ref = A.mul(x, y).numpy().copy()
@@ -78,7 +79,7 @@ def main():
         g_ref = A.mul_adjoint(r, g).numpy().copy()
         res = []
         for (C, UR, W), B in itertools.product(TCUW, TB):
-            lds = max(m // 256, 1) * 1024
+            lds = max(m * np.dtype(dt).itemsize // 1024, 1) * 1024
             if B * lds > 160 * 1024 or B * W > 32:
                 continue
             setenv(PG_T_C=C, PG_T_UR=UR, PG_T_WAVES=W, PG_T_BLOCKS_PER_CU=B)

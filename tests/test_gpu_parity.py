@@ -842,7 +842,9 @@ def _random_shapes(seed, count):
         m = int(rng.choice(anchors)) if rng.random() < 0.6 else int(rng.integers(1, 6000))
         n = int(rng.choice(anchors)) if rng.random() < 0.4 else int(rng.integers(1, 3000))
         shapes.append((m, n))
-    shapes += [(16385, 40), (33000, 17), (20000, 130)]  # more rows than one LDS chunk of pass T (16384 f32 / 8192 f64)
+    # pass T stages up to 128 KiB of r in LDS (32768 f32 / 16384 f64 rows): above the 64 KiB default limit, exactly at
+    # the chunk size, and beyond it (several row chunks + sum_chunks)
+    shapes += [(16385, 40), (33000, 17), (20000, 130), (32768, 9), (32769, 9), (70000, 5)]
     return shapes
 
 
