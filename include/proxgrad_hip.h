@@ -307,6 +307,15 @@ pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, doubl
  * round trip per iteration.  The iterator can be stepped normally afterwards. */
 pg_status pg_iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out,
                             pg_iter_scalars* out);
+/* Cache-resident sizes (m <= 4096 f64 / 8192 f32 rows, A up to 256 MiB): the same driver loop in ONE cooperative
+ * launch of `blocks` 1024-thread workgroups (<= one per CU; 0 = chosen from the size of A) that meet at grid
+ * barriers: pass N as (row block, column slice) partial sums | barrier | every workgroup combines the residual into
+ * its LDS, then A' r, prox and the scalar partials per column | barrier.  A fixed-step iteration costs two grid
+ * barriers and no launch; the line search adds one per trial.  A stays L2-resident, the three residual vectors of
+ * the adaptive FFB iteration live in LDS.  Barriers are bounded: a workgroup that never arrives makes the call
+ * return an error instead of hanging.  Same control flow, state and follow-up use as pg_iter_run_small. */
+pg_status pg_iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int32_t blocks, int64_t* k_out,
+                           pg_iter_scalars* out);
 pg_status pg_iter_state_view(pg_iter* it, pg_iter_state* out);
 
 /* ------------------------------------------------------------------ L-BFGS (config 4) --- */

@@ -64,6 +64,14 @@ class FusedIteration:
         call("pg_iter_run_small", self._h, int(k_start), int(maxit), float(tol), C.byref(k), C.byref(self.scalars))
         return k.value, self.scalars
 
+    def run_coop(self, k_start, maxit, tol, blocks=0):
+        """Whole solve in one cooperative launch of up to one workgroup per CU (pg_iter_run_coop; cache-resident A,
+        m <= 4096 f64 / 8192 f32 rows).  blocks = 0: chosen from the size of A."""
+        k = C.c_int64()
+        call("pg_iter_run_coop", self._h, int(k_start), int(maxit), float(tol), int(blocks), C.byref(k),
+             C.byref(self.scalars))
+        return k.value, self.scalars
+
     def view(self):
         st = _lib.pg_iter_state()
         call("pg_iter_state_view", self._h, C.byref(st))

@@ -108,6 +108,7 @@ SIGNATURES = {
     "pg_iter_run": [_vp, _i64, _i64, _f64, C.POINTER(_i64), C.POINTER(pg_iter_scalars)],
     "pg_iter_run_batched": [_vp, _i64, _i64, _f64, _i32, C.POINTER(_i64), C.POINTER(pg_iter_scalars)],
     "pg_iter_run_small": [_vp, _i64, _i64, _f64, C.POINTER(_i64), C.POINTER(pg_iter_scalars)],
+    "pg_iter_run_coop": [_vp, _i64, _i64, _f64, _i32, C.POINTER(_i64), C.POINTER(pg_iter_scalars)],
     "pg_iter_state_view": [_vp, C.POINTER(pg_iter_state)],
     "pg_lbfgs_create": [_vp, _i32, _i32, _i64, C.POINTER(_vp)],
     "pg_lbfgs_destroy": [_vp],

@@ -64,6 +64,7 @@ pg_status pg_ctx_destroy(pg_ctx* c) {
   if (c->red_counter) (void)hipFree(c->red_counter);
   if (c->hscal) (void)hipHostFree(c->hscal);
   if (c->small_out_host) (void)hipHostFree(c->small_out_host);
+  if (c->coop_ws) (void)hipFree(c->coop_ws);
   for (int k = 0; k < PG_K_COUNT; ++k)
     for (auto& pr : c->prof_events[k]) {
       (void)hipEventDestroy(pr.first);

@@ -95,6 +95,8 @@ struct pg_ctx {
   pg_comm* comm = nullptr;  // native RCCL path (optional)
   double* small_out = nullptr;       // result block of the single-workgroup solver (device address)
   double* small_out_host = nullptr;  //   ... mapped pinned host memory
+  void* coop_ws = nullptr;           // workspace of the cooperative solver (barrier counter, partials)
+  size_t coop_ws_bytes = 0;
   // event-pair kernel timing (pg_ctx_profile_*)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[PG_K_COUNT];

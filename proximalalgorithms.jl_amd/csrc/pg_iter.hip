@@ -12,6 +12,9 @@
 #include <limits>
 #include <utility>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "pg_internal.h"
 
 struct pg_iter {
@@ -270,11 +273,15 @@ pg_status iter_step(pg_iter* it, double host_beta) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Single-workgroup persistent solver for launch-bound sizes: the whole driver loop
+// Persistent solvers for launch-bound sizes: the whole driver loop
 // (src/ProximalAlgorithms.jl:114-123) -- stop rule, line search, Nesterov recurrences, both GEMV orientations, prox --
-// runs inside ONE kernel launch of one 1024-thread workgroup; A stays L2-resident, vectors are exchanged between
-// phases through global memory + workgroup barriers, scalars are computed redundantly by every thread from
-// block-reduced values (so control flow is uniform without broadcasts).  Same control flow as iter_step above.
+// runs inside ONE kernel launch.  Scalars are computed redundantly by every thread from reduced values (so control
+// flow is uniform without broadcasts).  Same control flow as iter_step above.  Two back ends share the loop:
+//   * SmallOps: one 1024-thread workgroup; vectors are exchanged between phases through global memory + workgroup
+//     barriers (m * n <= 2^20).
+//   * CoopOps: W workgroups (one per CU, cooperative launch) that meet at grid barriers; A stays L2-resident (each
+//     workgroup keeps reading the same slices), the three residual vectors live in every workgroup's LDS, and a
+//     fixed-step iteration costs two grid barriers (pass N partials | combine + A' r + prox + scalar partials).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 struct SmallParams {
@@ -292,6 +299,12 @@ struct SmallParams {
   long long k_start, maxit;
   T tol;
   double* out;  // [32] results, mapped host memory
+  // cooperative back end only
+  int W, S, nrb, m_pad;     // workgroups; column slices and 64-row blocks of pass N; padded m
+  double* npart;            // [2][S][m_pad] pass-N partial sums (double buffered by pass parity)
+  double* spart;            // [2][W][4] scalar partials (double buffered by reduction parity)
+  unsigned long long* bar;  // arrival counter of the grid barrier (zeroed by the host before the launch)
+  int* abort_flag;
 };
 
 constexpr int SMALL_THREADS = 1024;
@@ -323,97 +336,403 @@ __device__ __forceinline__ void small_block_reduce(double (&v)[4], double* sm_re
   }
 }
 
-// r_out = A v - b ; returns sum r_out^2 (to every thread)
-template <typename T>
-__device__ double small_residual(const SmallParams<T>& p, const T* v, T* r_out, double* sm_part, double* sm_red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double sq = 0.0;
-  for (int rb = 0; rb < p.m; rb += 64) {
-    const int i = rb + lane;
-    double acc = 0.0;
-    if (i < p.m) {
-      for (int j = wave; j < p.n; j += SMALL_WAVES) acc += (double)p.A[i + (long long)j * p.ld] * (double)v[j];
-    }
-    sm_part[wave * 64 + lane] = acc;
-    __syncthreads();
-    if (wave == 0 && i < p.m) {
-      double t = 0.0;
-      for (int w = 0; w < SMALL_WAVES; ++w) t += sm_part[w * 64 + lane];
-      const T ri = (T)(t - (double)p.b[i]);
-      r_out[i] = ri;
-      sq += (double)ri * (double)ri;
-    }
-    __syncthreads();
-  }
-  double v4[4] = {sq, 0.0, 0.0, 0.0};
-  small_block_reduce<0u>(v4, sm_red);
-  return v4[0];
-}
-
-// g_out = lam A' r
-template <typename T>
-__device__ void small_adjoint(const SmallParams<T>& p, const T* r, T* g_out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < p.n; j += SMALL_WAVES) {
-    double acc = 0.0;
-    const T* col = p.A + (long long)j * p.ld;
-    for (int i = lane; i < p.m; i += 64) acc += (double)col[i] * (double)r[i];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += pg_shfl_xor(acc, off);
-    if (lane == 0) g_out[j] = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)acc) : (T)acc;
-  }
-  __syncthreads();
-}
-
 template <typename T>
 __device__ __forceinline__ T small_soft(T x, T gl) {
   return x <= -gl ? x + gl : (x >= gl ? x - gl : T(0));
 }
 
-// y = x - gamma g ; z = prox(y) ; res = x - z ; out = { g(z), ||res||_inf, <g,res>, ||res||^2 }
+// y = x - gamma g ; z = prox(y) ; res = x - z for one element; accumulates { |z|, max|res|, g res, res^2 }
 template <typename T>
-__device__ void small_epilogue(const SmallParams<T>& p, const T* x, const T* g, T gamma, T* y, T* z, T* res,
-                               double (&out)[4], double* sm_red) {
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const T gl = gamma * p.g_p0;
-  for (int j = threadIdx.x; j < p.n; j += SMALL_THREADS) {
-    const T xv = x[j], gv = g[j];
-    const T yv = xv - gamma * gv;
-    T zv;
-    if (p.g_kind == PG_G_NORML1)
-      zv = small_soft(yv, gl);
-    else if (p.g_kind == PG_G_INDBOX)
-      zv = fmin(p.g_p1, fmax(p.g_p0, yv));
-    else
-      zv = yv;
-    const T rv = xv - zv;
-    y[j] = yv;
-    z[j] = zv;
-    res[j] = rv;
-    if (p.g_kind == PG_G_NORML1) acc[0] += fabs((double)zv);
-    acc[1] = fmax(acc[1], fabs((double)rv));
-    acc[2] += (double)gv * (double)rv;
-    acc[3] += (double)rv * (double)rv;
-  }
-  small_block_reduce<0x2u>(acc, sm_red);
+__device__ __forceinline__ void small_epilogue_elem(const SmallParams<T>& p, T xv, T gv, T gamma, T gl, T& yv, T& zv,
+                                                    T& rv, double (&acc)[4]) {
+  yv = xv - gamma * gv;
+  if (p.g_kind == PG_G_NORML1)
+    zv = small_soft(yv, gl);
+  else if (p.g_kind == PG_G_INDBOX)
+    zv = fmin(p.g_p1, fmax(p.g_p0, yv));
+  else
+    zv = yv;
+  rv = xv - zv;
+  if (p.g_kind == PG_G_NORML1) acc[0] += fabs((double)zv);
+  acc[1] = fmax(acc[1], fabs((double)rv));
+  acc[2] += (double)gv * (double)rv;
+  acc[3] += (double)rv * (double)rv;
+}
+
+template <typename T>
+__device__ __forceinline__ void small_epilogue_out(const SmallParams<T>& p, const double (&acc)[4], double (&out)[4]) {
   out[0] = p.g_kind == PG_G_NORML1 ? acc[0] * (double)p.g_p0 : 0.0;
   out[1] = acc[1];
   out[2] = acc[2];
   out[3] = acc[3];
 }
 
+// ---- back end 1: one workgroup --------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams<T> p) {
-  __shared__ double sm_part[SMALL_WAVES * 64];
-  __shared__ double sm_red[SMALL_WAVES * 4];
-  T *x = p.buf[0], *grad = p.buf[1], *y = p.buf[2], *z = p.buf[3], *res = p.buf[4], *zp = p.buf[5], *rz = p.buf[6],
-    *rzp = p.buf[7];
+struct SmallOps {
+  const SmallParams<T>& p;
+  double* sm_part;
+  double* sm_red;
+  T *r0, *r1, *r2;  // residual slots: 0 = p.r, 1 = rz, 2 = rz_prev (global memory)
+
+  // a slot handle is the pointer itself (selecting among pointers by a run-time index costs scratch memory)
+  using Slot = T*;
+  __device__ __forceinline__ Slot slot(int i) const { return i == 0 ? r0 : (i == 1 ? r1 : r2); }
+  __device__ __forceinline__ bool is_slot(Slot s, int i) const { return s == slot(i); }
+  __device__ __forceinline__ T* rs(Slot s) const { return s; }
+  __device__ bool aborted() const { return false; }
+  __device__ bool leader() const { return true; }
+
+  // rs[slot] = A v - b ; returns sum r^2 (to every thread)
+  __device__ double residual(const T* v, Slot slot) {
+    T* r_out = rs(slot);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sq = 0.0;
+    for (int rb = 0; rb < p.m; rb += 64) {
+      const int i = rb + lane;
+      double acc = 0.0;
+      if (i < p.m) {
+        for (int j = wave; j < p.n; j += SMALL_WAVES) acc += (double)p.A[i + (long long)j * p.ld] * (double)v[j];
+      }
+      sm_part[wave * 64 + lane] = acc;
+      __syncthreads();
+      if (wave == 0 && i < p.m) {
+        double t = 0.0;
+        for (int w = 0; w < SMALL_WAVES; ++w) t += sm_part[w * 64 + lane];
+        const T ri = (T)(t - (double)p.b[i]);
+        r_out[i] = ri;
+        sq += (double)ri * (double)ri;
+      }
+      __syncthreads();
+    }
+    double v4[4] = {sq, 0.0, 0.0, 0.0};
+    small_block_reduce<0u>(v4, sm_red);
+    return v4[0];
+  }
+
+  __device__ void extrapolate(const T* a, const T* c, T beta, T* x) {  // x = a + beta (a - c)   ffb:135
+    for (int j = threadIdx.x; j < p.n; j += SMALL_THREADS) x[j] = a[j] + beta * (a[j] - c[j]);
+    __syncthreads();
+  }
+
+  __device__ double residual_extrap(const T* a, const T* c, T beta, T* x, Slot slot) {
+    extrapolate(a, c, beta, x);
+    return residual(x, slot);
+  }
+
+  // rs[so] = ca rs[sa] + cb rs[sb] ; returns sum of squares
+  __device__ double residual_combo(T ca, Slot sa, T cb, Slot sb, Slot so) {
+    const T *ra = rs(sa), *rb = rs(sb);
+    T* ro = rs(so);
+    double sq = 0.0;
+    for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+      const T o = ca * ra[i] + cb * rb[i];
+      ro[i] = o;
+      sq += (double)o * (double)o;
+    }
+    double v4[4] = {sq, 0.0, 0.0, 0.0};
+    small_block_reduce<0u>(v4, sm_red);
+    return v4[0];
+  }
+
+  // g_out = lam A' rs[slot]
+  __device__ void adjoint(Slot slot, T* g_out) {
+    const T* r = rs(slot);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < p.n; j += SMALL_WAVES) {
+      double acc = 0.0;
+      const T* col = p.A + (long long)j * p.ld;
+      for (int i = lane; i < p.m; i += 64) acc += (double)col[i] * (double)r[i];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc += pg_shfl_xor(acc, off);
+      if (lane == 0) g_out[j] = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)acc) : (T)acc;
+    }
+    __syncthreads();
+  }
+
+  // y = x - gamma g ; z = prox(y) ; res = x - z ; out = { g(z), ||res||_inf, <g,res>, ||res||^2 }
+  __device__ void epilogue(const T* x, const T* g, T gamma, T* y, T* z, T* res, double (&out)[4]) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const T gl = gamma * p.g_p0;
+    for (int j = threadIdx.x; j < p.n; j += SMALL_THREADS) {
+      T yv, zv, rv;
+      small_epilogue_elem(p, x[j], g[j], gamma, gl, yv, zv, rv, acc);
+      y[j] = yv;
+      z[j] = zv;
+      res[j] = rv;
+    }
+    small_block_reduce<0x2u>(acc, sm_red);
+    small_epilogue_out(p, acc, out);
+  }
+
+  // [x = ea + beta (ea - ec) when ea != nullptr] ; g = lam A' rs[slot] ; epilogue
+  __device__ void adjoint_epilogue(Slot slot, T* x, T* g, T gamma, T* y, T* z, T* res, double (&out)[4], const T* ea,
+                                   const T* ec, T beta) {
+    if (ea != nullptr) extrapolate(ea, ec, beta, x);
+    adjoint(slot, g);
+    epilogue(x, g, gamma, y, z, res, out);
+  }
+
+  __device__ void finish(Slot, Slot, Slot) {}
+  __device__ double barrier_ticks() const { return 0.0; }
+  __device__ double barrier_count() const { return 0.0; }
+};
+
+// ---- back end 2: W cooperating workgroups ------------------------------------------------------------------------
+// Everything one workgroup writes and another reads inside the kernel goes through agent-scope (sc1, write-through /
+// cache-bypassing) accesses; A and b are read-only and use ordinary cached loads.
+template <typename T>
+__device__ __forceinline__ T ld_ag(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void st_ag(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr long long COOP_SPIN_LIMIT = 4000000;  // polls (~1 us each) before a grid barrier gives up instead of hanging
+
+template <typename T>
+struct CoopOps {
+  const SmallParams<T>& p;
+  double* sm_part;
+  double* sm_red;
+  int* sm_flag;
+  T* lds_base;  // residual slots in LDS (m_pad elements each)
+  unsigned long long bar_target;
+  int npass, nred;
+  bool dead;
+  long long t_bar = 0, n_bar = 0;  // telemetry: 100 MHz ticks spent inside grid barriers, number of barriers
+
+  using Slot = int;  // index of an m_pad-sized LDS region
+  __device__ __forceinline__ Slot slot(int i) const { return i; }
+  __device__ __forceinline__ bool is_slot(Slot s, int i) const { return s == i; }
+  __device__ __forceinline__ T* rs(Slot s) const { return lds_base + (size_t)s * p.m_pad; }
+  __device__ bool aborted() const { return dead; }
+  __device__ bool leader() const { return blockIdx.x == 0; }
+
+  // Grid barrier: every thread drains its write-through stores, the workgroup's thread 0 takes a ticket on a
+  // monotonically increasing counter and polls it.  Bounded: on a timeout the solve is abandoned (flag), never hung.
+  __device__ void barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.W == 1 || dead) return;
+    const long long t_in = wall_clock64();
+    bar_target += (unsigned long long)p.W;
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(p.bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 1;
+      long long spins = 0;
+      while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if (spins > COOP_SPIN_LIMIT ||
+            ((spins & 4095) == 0 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          ok = 0;
+          break;
+        }
+      }
+      if (!ok) __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *sm_flag = ok;
+    }
+    __syncthreads();
+    if (*sm_flag == 0) dead = true;
+    t_bar += wall_clock64() - t_in;
+    n_bar += 1;
+  }
+
+  // grid-wide reduction of 4 doubles: block partial -> global slot -> barrier -> every workgroup sums the W partials in
+  // the same order (bit-identical results everywhere)
+  template <unsigned MAXMASK>
+  __device__ void grid_reduce(double (&v)[4]) {
+    small_block_reduce<MAXMASK>(v, sm_red);
+    if (p.W == 1) return;
+    double* slot = p.spart + (size_t)(nred & 1) * p.W * 4;
+    if (threadIdx.x < 4) st_ag(slot + (size_t)blockIdx.x * 4 + threadIdx.x, v[threadIdx.x]);
+    ++nred;
+    barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ((MAXMASK >> k) & 1u) ? -INFINITY : 0.0;
+    if (dead) return;
+    for (int w = threadIdx.x; w < p.W; w += SMALL_THREADS) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double o = ld_ag(slot + (size_t)w * 4 + k);
+        v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
+      }
+    }
+    small_block_reduce<MAXMASK>(v, sm_red);
+  }
+
+  // pass N: partial sums of A v over this workgroup's (64-row block, column slice) items; v_j = a_j, or
+  // a_j + beta (a_j - c_j) formed on the fly (the items of row block 0 also store it to x_out)
+  __device__ void pass_n(const T* a, const T* c, T beta, T* x_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* part = p.npart + (size_t)(npass & 1) * p.S * p.m_pad;
+    const int items = p.nrb * p.S;
+    const int cols_per = (p.n + p.S - 1) / p.S;
+    for (int item = blockIdx.x; item < items; item += p.W) {
+      const int rb = item / p.S, s = item - rb * p.S;
+      const int c0 = s * cols_per, c1 = (c0 + cols_per < p.n) ? (c0 + cols_per) : p.n;
+      const int i = rb * 64 + lane;
+      double acc = 0.0;
+      for (int j = c0 + wave; j < c1; j += SMALL_WAVES) {
+        T vj = ld_ag(a + j);
+        if (c != nullptr) {
+          const T cj = ld_ag(c + j);
+          vj = vj + beta * (vj - cj);
+          if (rb == 0 && lane == 0) st_ag(x_out + j, vj);
+        }
+        if (i < p.m) acc += (double)p.A[i + (long long)j * p.ld] * (double)vj;
+      }
+      __syncthreads();  // sm_part free (previous item)
+      sm_part[wave * 64 + lane] = acc;
+      __syncthreads();
+      if (wave == 0 && i < p.m) {
+        double t = 0.0;
+        for (int w = 0; w < SMALL_WAVES; ++w) t += sm_part[w * 64 + lane];
+        st_ag(part + (size_t)s * p.m_pad + i, t);
+      }
+    }
+    ++npass;
+    barrier();
+  }
+
+  // rs[slot] = sum_s partial[s] - b (every workgroup, same order) ; returns sum r^2
+  __device__ double combine(Slot slot) {
+    const double* part = p.npart + (size_t)((npass - 1) & 1) * p.S * p.m_pad;
+    double sq = 0.0;
+    T* dst = rs(slot);
+    if (!dead) {
+      for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+        double t = 0.0;
+        for (int s = 0; s < p.S; ++s) t += ld_ag(part + (size_t)s * p.m_pad + i);
+        const T ri = (T)(t - (double)p.b[i]);
+        dst[i] = ri;
+        sq += (double)ri * (double)ri;
+      }
+    }
+    double v4[4] = {sq, 0.0, 0.0, 0.0};
+    small_block_reduce<0u>(v4, sm_red);  // ends with a workgroup barrier: rs[slot] is complete
+    return v4[0];
+  }
+
+  __device__ double residual(const T* v, Slot slot) {
+    pass_n(v, nullptr, T(0), nullptr);
+    return combine(slot);
+  }
+
+  __device__ double residual_extrap(const T* a, const T* c, T beta, T* x, Slot slot) {
+    pass_n(a, c, beta, x);
+    return combine(slot);
+  }
+
+  __device__ double residual_combo(T ca, Slot sa, T cb, Slot sb, Slot so) {  // redundantly in every workgroup (LDS)
+    const T *ra = rs(sa), *rb = rs(sb);
+    T* ro = rs(so);
+    double sq = 0.0;
+    for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+      const T o = ca * ra[i] + cb * rb[i];
+      ro[i] = o;
+      sq += (double)o * (double)o;
+    }
+    double v4[4] = {sq, 0.0, 0.0, 0.0};
+    small_block_reduce<0u>(v4, sm_red);
+    return v4[0];
+  }
+
+  // one wave per column: g_j = lam A_j' r, optionally followed by the epilogue of element j (lane 0)
+  template <bool EPI>
+  __device__ void adjoint_cols(Slot slot, T* x, T* g, T gamma, T* y, T* z, T* res, double (&acc)[4], const T* ea,
+                               const T* ec, T beta) {
+    const T* r = rs(slot);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T gl = gamma * p.g_p0;
+    for (int j = blockIdx.x * SMALL_WAVES + wave; j < p.n; j += p.W * SMALL_WAVES) {
+      double a = 0.0;
+      const T* col = p.A + (long long)j * p.ld;
+      for (int i = lane; i < p.m; i += 64) a += (double)col[i] * (double)r[i];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) a += pg_shfl_xor(a, off);
+      if (lane == 0) {
+        const T gv = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)a) : (T)a;
+        st_ag(g + j, gv);
+        if (EPI) {
+          T xv;
+          if (ea != nullptr) {
+            const T av = ld_ag(ea + j), cv = ld_ag(ec + j);
+            xv = av + beta * (av - cv);
+            st_ag(x + j, xv);
+          } else {
+            xv = ld_ag(x + j);
+          }
+          T yv, zv, rv;
+          small_epilogue_elem(p, xv, gv, gamma, gl, yv, zv, rv, acc);
+          st_ag(y + j, yv);
+          st_ag(z + j, zv);
+          st_ag(res + j, rv);
+        }
+      }
+    }
+  }
+
+  __device__ void adjoint(Slot slot, T* g_out) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    adjoint_cols<false>(slot, nullptr, g_out, T(0), nullptr, nullptr, nullptr, acc, nullptr, nullptr, T(0));
+    barrier();
+  }
+
+  __device__ void epilogue(const T* x, const T* g, T gamma, T* y, T* z, T* res, double (&out)[4]) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const T gl = gamma * p.g_p0;
+    for (int j = blockIdx.x * SMALL_THREADS + threadIdx.x; j < p.n; j += p.W * SMALL_THREADS) {
+      T yv, zv, rv;
+      small_epilogue_elem(p, ld_ag(x + j), ld_ag(g + j), gamma, gl, yv, zv, rv, acc);
+      st_ag(y + j, yv);
+      st_ag(z + j, zv);
+      st_ag(res + j, rv);
+    }
+    grid_reduce<0x2u>(acc);
+    small_epilogue_out(p, acc, out);
+  }
+
+  __device__ void adjoint_epilogue(Slot slot, T* x, T* g, T gamma, T* y, T* z, T* res, double (&out)[4], const T* ea,
+                                   const T* ec, T beta) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    adjoint_cols<true>(slot, x, g, gamma, y, z, res, acc, ea, ec, beta);
+    grid_reduce<0x2u>(acc);
+    small_epilogue_out(p, acc, out);
+  }
+
+  __device__ double barrier_ticks() const { return (double)t_bar; }
+  __device__ double barrier_count() const { return (double)n_bar; }
+
+  // export the LDS-resident residuals (r, and the line-search pair when kept) for later host-driven steps
+  __device__ void finish(Slot s_r, Slot, Slot) {
+    if (blockIdx.x != 0) return;
+    const T *src = rs(s_r), *s1 = rs(1), *s2 = rs(2);
+    for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+      p.r[i] = src[i];
+      if (p.reuse) {
+        p.buf[6][i] = s1[i];  // slot-wise: the roles travel in the result block
+        p.buf[7][i] = s2[i];
+      }
+    }
+  }
+};
+
+// ---- the loop (both back ends) -------------------------------------------------------------------------------------
+template <typename T, typename Ops>
+__device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
+  T *x = p.buf[0], *grad = p.buf[1], *y = p.buf[2], *z = p.buf[3], *res = p.buf[4], *zp = p.buf[5];
+  typename Ops::Slot s_r = ops.slot(0), s_rz = ops.slot(1), s_rzp = ops.slot(2);  // scratch r, A z - b, A z_prev - b
   T gamma = p.gamma, f_x = p.f_x, g_z = p.g_z, res_inf = p.res_inf, dot_gr = p.dot_gr, res_sq = p.res_sq;
   T beta = T(0);
   SeqState<T> seq = p.seq;
   long long k = p.k_start, nbt_total = 0, passes = 0;
   int flags = 0;
   bool rz_valid = false;
+  const long long t_begin = wall_clock64();
   const T eps = sizeof(T) == 4 ? (T)1.1920928955078125e-07 : (T)2.220446049250313e-16;
   const T f_scale = (T)0.5 * p.lam_ls;
   double e4[4];
@@ -429,21 +748,21 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams
     res_sq = (T)e4[3];
   };
 
-  while (!(k >= p.maxit || res_inf / gamma <= p.tol)) {  // ProximalAlgorithms.jl:117 ; forward_backward.jl:125-126
+  while (!ops.aborted() && !(k >= p.maxit || res_inf / gamma <= p.tol)) {  // ProximalAlgorithms.jl:117 ; fb:125-126
     if (p.fast) {
       if (p.adaptive) {  // fast_forward_backward.jl:110-129 + fb_tools.jl:24-63
         gamma = gamma * p.increase_gamma;
         T f_upp = model();
-        T* rz_dst = p.reuse ? rz : p.r;  // without the residual buffers the line search uses the scratch residual
-        T f_z = f_scale * (T)small_residual(p, z, rz_dst, sm_part, sm_red);
+        const typename Ops::Slot s_dst = p.reuse ? s_rz : s_r;  // without the residual pair the line search uses the scratch slot
+        T f_z = f_scale * (T)ops.residual(z, s_dst);
         passes += 1;
         T tol_ls = T(10) * eps * (T(1) + fabs(f_z));
-        while (f_z > f_upp + tol_ls && gamma >= p.min_gamma) {
+        while (f_z > f_upp + tol_ls && gamma >= p.min_gamma && !ops.aborted()) {
           gamma = gamma * p.reduce_gamma;
-          small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);
+          ops.epilogue(x, grad, gamma, y, z, res, e4);
           set_epilogue();
           f_upp = model();
-          f_z = f_scale * (T)small_residual(p, z, rz_dst, sm_part, sm_red);
+          f_z = f_scale * (T)ops.residual(z, s_dst);
           passes += 1;
           tol_ls = T(10) * eps * (T(1) + fabs(f_z));
           nbt_total += 1;
@@ -454,54 +773,41 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams
         gamma = p.fixed_gamma;  // :131
       }
       beta = seq_next_hd<T>(p.seq_kind, p.mf, p.seq_p0, p.seq_p1, seq, gamma, T(0));  // :134
-      for (int j = threadIdx.x; j < p.n; j += SMALL_THREADS) x[j] = z[j] + beta * (z[j] - zp[j]);  // :135
-      __syncthreads();
-      {  // :136
+      {  // :136 (the extrapolation :135 is formed below from the swapped pair: x = zp + beta (zp - z))
         T* t = zp;
         zp = z;
         z = t;
       }
       if (p.adaptive && p.reuse && rz_valid) {  // A x - b = (1 + beta)(A z - b) - beta (A z_prev - b)
-        const T ca = T(1) + beta, cb = -beta;
-        double sq = 0.0;
-        for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
-          const T o = ca * rz[i] + cb * rzp[i];
-          p.r[i] = o;
-          sq += (double)o * (double)o;
-        }
-        double v4[4] = {sq, 0.0, 0.0, 0.0};
-        small_block_reduce<0u>(v4, sm_red);
-        f_x = (T)((double)f_scale * v4[0]);
-        T* t = rzp;
-        rzp = rz;
-        rz = t;
+        f_x = (T)((double)f_scale * ops.residual_combo(T(1) + beta, s_rz, -beta, s_rzp, s_r));
+        const typename Ops::Slot t = s_rzp;
+        s_rzp = s_rz;
+        s_rz = t;
         rz_valid = false;
+        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, zp, z, beta);  // :135, :138-142
       } else {
-        f_x = f_scale * (T)small_residual(p, x, p.r, sm_part, sm_red);  // :138
+        f_x = f_scale * (T)ops.residual_extrap(zp, z, beta, x, s_r);  // :135, :138
         passes += 1;
-        if (p.adaptive && p.reuse) {  // this residual belongs to x, not to z: nothing to reuse next time
-          rz_valid = false;
-        }
+        rz_valid = false;  // this residual belongs to x, not to z: nothing to reuse next time
+        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, nullptr, nullptr, T(0));  // :138-142
       }
-      small_adjoint(p, p.r, grad);  // :138-139
       passes += 1;
-      small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);  // :140-142
       set_epilogue();
     } else {
       if (p.adaptive) {  // forward_backward.jl:90-110 ; gradient at z is kept (zp plays grad_f_z)
         gamma = gamma * p.increase_gamma;
         T f_upp = model();
-        T f_z = f_scale * (T)small_residual(p, z, p.r, sm_part, sm_red);
-        small_adjoint(p, p.r, zp);
+        T f_z = f_scale * (T)ops.residual(z, s_r);
+        ops.adjoint(s_r, zp);
         passes += 2;
         T tol_ls = T(10) * eps * (T(1) + fabs(f_z));
-        while (f_z > f_upp + tol_ls && gamma >= p.min_gamma) {
+        while (f_z > f_upp + tol_ls && gamma >= p.min_gamma && !ops.aborted()) {
           gamma = gamma * p.reduce_gamma;
-          small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);
+          ops.epilogue(x, grad, gamma, y, z, res, e4);
           set_epilogue();
           f_upp = model();
-          f_z = f_scale * (T)small_residual(p, z, p.r, sm_part, sm_red);
-          small_adjoint(p, p.r, zp);
+          f_z = f_scale * (T)ops.residual(z, s_r);
+          ops.adjoint(s_r, zp);
           passes += 2;
           tol_ls = T(10) * eps * (T(1) + fabs(f_z));
           nbt_total += 1;
@@ -514,20 +820,21 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams
         t = grad;   // :110
         grad = zp;
         zp = t;
+        ops.epilogue(x, grad, gamma, y, z, res, e4);  // :117-120
       } else {  // :111-115
         T* t = x;
         x = z;
         z = t;
-        f_x = f_scale * (T)small_residual(p, x, p.r, sm_part, sm_red);
-        small_adjoint(p, p.r, grad);
+        f_x = f_scale * (T)ops.residual(x, s_r);
         passes += 2;
+        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, nullptr, nullptr, T(0));  // :113-120
       }
-      small_epilogue(p, x, grad, gamma, y, z, res, e4, sm_red);  // :117-120
       set_epilogue();
     }
     ++k;
   }
-  if (threadIdx.x == 0) {
+  ops.finish(s_r, s_rz, s_rzp);
+  if (ops.leader() && threadIdx.x == 0) {
     auto role = [&](const T* q) -> double {
       for (int i = 0; i < 8; ++i)
         if (p.buf[i] == q) return (double)i;
@@ -552,28 +859,59 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams
     o[15] = role(z);
     o[16] = role(res);
     o[17] = role(zp);
-    o[18] = role(rz);
-    o[19] = role(rzp);
+    o[18] = ops.is_slot(s_rz, 1) ? 6.0 : 7.0;
+    o[19] = ops.is_slot(s_rzp, 2) ? 7.0 : 6.0;
     o[20] = (double)nbt_total;
     o[21] = (double)flags;
     o[22] = (double)passes;
     o[23] = rz_valid ? 1.0 : 0.0;
+    o[24] = ops.aborted() ? 1.0 : 0.0;
+    o[25] = (double)(wall_clock64() - t_begin);  // telemetry (100 MHz ticks): whole loop, inside grid barriers, count
+    o[26] = ops.barrier_ticks();
+    o[27] = ops.barrier_count();
   }
 }
 
 template <typename T>
-pg_status iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out) {
-  pg_ctx* c = it->ctx;
+__global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams<T> p) {
+  __shared__ double sm_part[SMALL_WAVES * 64];
+  __shared__ double sm_red[SMALL_WAVES * 4];
+  SmallOps<T> ops{p, sm_part, sm_red, p.r, p.buf[6], p.buf[7]};
+  solver_loop<T, SmallOps<T>>(p, ops);
+}
+
+template <typename T>
+__global__ __launch_bounds__(SMALL_THREADS) void coop_solver_kernel(SmallParams<T> p) {
+  __shared__ double sm_part[SMALL_WAVES * 64];
+  __shared__ double sm_red[SMALL_WAVES * 4];
+  __shared__ int sm_flag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char coop_lds[];
+  T* base = reinterpret_cast<T*>(coop_lds);
+  CoopOps<T> ops{p, sm_part, sm_red, &sm_flag, base, 0ull, 0, 0, false};
+  if (p.reuse) {  // the line-search residual pair continues from the host-driven steps (written by earlier kernels)
+    for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+      ops.rs(1)[i] = p.buf[6][i];
+      ops.rs(2)[i] = p.buf[7][i];
+    }
+  }
+  __syncthreads();
+  solver_loop<T, CoopOps<T>>(p, ops);
+}
+
+template <typename T>
+void small_fill_params(pg_iter* it, SmallParams<T>& p, void* (&bufs)[8], int64_t k_start, int64_t maxit, double tol) {
   pg_mat* A = it->f->A;
-  SmallParams<T> p;
   memset(&p, 0, sizeof(p));
   p.A = (const T*)A->data;
   p.ld = A->ld;
   p.m = (int)A->m;
   p.n = (int)A->n;
   p.b = (const T*)it->f->b;
-  void* bufs[8] = {it->x, it->grad_f_x, it->y, it->z, it->res, it->o.fast ? it->z_prev : it->grad_f_z, it->rz, it->rz_prev};
-  for (int i = 0; i < 8; ++i) p.buf[i] = (T*)bufs[i];
+  void* roles[8] = {it->x, it->grad_f_x, it->y, it->z, it->res, it->o.fast ? it->z_prev : it->grad_f_z, it->rz, it->rz_prev};
+  for (int i = 0; i < 8; ++i) {
+    bufs[i] = roles[i];
+    p.buf[i] = (T*)roles[i];
+  }
   p.r = (T*)it->f->r;
   p.fast = it->o.fast;
   p.adaptive = it->adaptive ? 1 : 0;
@@ -601,17 +939,22 @@ pg_status iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol
   p.k_start = k_start;
   p.maxit = maxit;
   p.tol = (T)tol;
+  p.W = 1;
+}
+
+pg_status small_result_block(pg_ctx* c) {
   if (!c->small_out) {
     double* host = nullptr;
     PG_HIP(hipHostMalloc((void**)&host, sizeof(double) * 32, hipHostMallocMapped));
     c->small_out_host = host;
     PG_HIP(hipHostGetDevicePointer((void**)&c->small_out, host, 0));
   }
-  p.out = c->small_out;
-  hipLaunchKernelGGL(small_solver_kernel<T>, dim3(1), dim3(SMALL_THREADS), 0, c->stream, p);
-  PG_LAUNCH_CHECK();
-  PG_HIP(hipStreamSynchronize(c->stream));
-  const double* o = c->small_out_host;
+  return PG_OK;
+}
+
+// adopt the state the persistent kernel left behind (scalars, buffer roles, telemetry)
+void small_read_result(pg_iter* it, void* (&bufs)[8], int64_t* k_out) {
+  const double* o = it->ctx->small_out_host;
   *k_out = (int64_t)o[0];
   it->gamma = o[1];
   it->f_x = o[2];
@@ -634,13 +977,113 @@ pg_status iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol
     it->z_prev = at((int)o[17]);
   else
     it->grad_f_z = at((int)o[17]);
-  it->rz = at((int)o[18]);
-  it->rz_prev = at((int)o[19]);
+  if (it->rz != nullptr && it->rz_prev != nullptr) {
+    it->rz = at((int)o[18]);
+    it->rz_prev = at((int)o[19]);
+  }
   it->n_backtracks = (int)o[20];
   it->flags = (int)o[21];
   it->f->a_passes += (int64_t)o[22];
-  it->rz_valid = false;  // conservative: the next host-driven step recomputes A x
+  it->rz_valid = false;  // the next host-driven step evaluates A x itself
   it->f_z = it->f_z_upp = NAN;
+}
+
+template <typename T>
+pg_status iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int64_t* k_out) {
+  pg_ctx* c = it->ctx;
+  SmallParams<T> p;
+  void* bufs[8];
+  small_fill_params<T>(it, p, bufs, k_start, maxit, tol);
+  PG_TRY(small_result_block(c));
+  p.out = c->small_out;
+  hipLaunchKernelGGL(small_solver_kernel<T>, dim3(1), dim3(SMALL_THREADS), 0, c->stream, p);
+  PG_LAUNCH_CHECK();
+  PG_HIP(hipStreamSynchronize(c->stream));
+  small_read_result(it, bufs, k_out);
+  return PG_OK;
+}
+
+// cooperative multi-workgroup variant; blocks <= 0: chosen from the size of A (about 32 KiB of A per workgroup and pass)
+constexpr int64_t COOP_MAX_LDS = 96 * 1024;  // three residual vectors per workgroup
+
+template <typename T>
+pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int blocks, int64_t* k_out) {
+  pg_ctx* c = it->ctx;
+  pg_mat* A = it->f->A;
+  SmallParams<T> p;
+  void* bufs[8];
+  small_fill_params<T>(it, p, bufs, k_start, maxit, tol);
+  PG_TRY(small_result_block(c));
+  p.out = c->small_out;
+  p.m_pad = (int)pg_round_up(A->m, 64);
+  p.nrb = p.m_pad / 64;
+  const size_t lds = (size_t)3 * p.m_pad * sizeof(T);
+  const void* kern = reinterpret_cast<const void*>(&coop_solver_kernel<T>);
+  static bool opted_in[64] = {};
+  if (!opted_in[c->device & 63]) {
+    PG_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COOP_MAX_LDS));
+    opted_in[c->device & 63] = true;
+  }
+  int per_cu = 0;
+  PG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SMALL_THREADS, lds));
+  if (per_cu < 1) {
+    pg_set_error("the cooperative solver does not fit on a CU (%zu bytes of LDS)", lds);
+    return PG_ERR_UNSUPPORTED;
+  }
+  int W = blocks;
+  if (W <= 0) {
+    const int64_t bytes = A->m * A->n * (int64_t)sizeof(T);
+    W = (int)((bytes + 32767) / 32768);
+  }
+  if (W > c->num_cu) W = c->num_cu;  // one workgroup per CU: all of them are resident, the grid barrier cannot starve
+  if (W < 1) W = 1;
+  p.W = W;
+  int S = W / p.nrb;
+  const int s_cap = p.n / 16 > 1 ? p.n / 16 : 1;  // at least one column per wave and slice
+  if (S > s_cap) S = s_cap;
+  if (S < 1) S = 1;
+  p.S = S;
+  // workspace: [bar (8 B) | abort (4 B) | pad to 64 B][2][W][4] scalar partials [2][S][m_pad] pass-N partials
+  const size_t need = 64 + sizeof(double) * ((size_t)2 * W * 4 + (size_t)2 * S * p.m_pad);
+  if (c->coop_ws_bytes < need) {
+    if (c->coop_ws) {
+      PG_HIP(hipStreamSynchronize(c->stream));
+      (void)hipFree(c->coop_ws);
+      c->coop_ws = nullptr;
+      c->coop_ws_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&c->coop_ws, need);
+    if (e != hipSuccess) {
+      pg_set_error("hipMalloc for the cooperative solver workspace failed: %s", hipGetErrorString(e));
+      return PG_ERR_ALLOC;
+    }
+    c->coop_ws_bytes = need;
+  }
+  char* ws = (char*)c->coop_ws;
+  PG_HIP(hipMemsetAsync(ws, 0, 64, c->stream));
+  p.bar = (unsigned long long*)ws;
+  p.abort_flag = (int*)(ws + 8);
+  p.spart = (double*)(ws + 64);
+  p.npart = p.spart + (size_t)2 * W * 4;
+  void* args[1] = {(void*)&p};
+  hipError_t e = hipLaunchCooperativeKernel(kern, dim3((unsigned)W), dim3(SMALL_THREADS), args, (unsigned)lds, c->stream);
+  if (e != hipSuccess) {
+    pg_set_error("cooperative launch (%d workgroups, %zu bytes of LDS) failed: %s", W, lds, hipGetErrorString(e));
+    return PG_ERR_HIP;
+  }
+  PG_HIP(hipStreamSynchronize(c->stream));
+  small_read_result(it, bufs, k_out);
+  if (getenv("PG_COOP_VERBOSE")) {
+    const double* o = c->small_out_host;
+    const double its = (double)(*k_out - k_start);
+    fprintf(stderr, "[pg coop] %dx%d W=%d S=%d: %.0f iterations, %.2f us/iteration, %.1f barriers/iteration, %.2f us/barrier (%.0f %% of the loop)\n",
+            p.m, p.n, W, S, its, o[25] * 0.01 / (its > 0 ? its : 1), o[27] / (its > 0 ? its : 1),
+            o[27] > 0 ? o[26] * 0.01 / o[27] : 0.0, o[25] > 0 ? 100.0 * o[26] / o[25] : 0.0);
+  }
+  if (c->small_out_host[24] != 0.0) {
+    pg_set_error("the cooperative solver gave up at a grid barrier (a workgroup did not arrive)");
+    return PG_ERR_HIP;
+  }
   return PG_OK;
 }
 
@@ -829,6 +1272,29 @@ pg_status pg_iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double 
   }
   PG_TRY(it->dtype == PG_F32 ? iter_run_small<float>(it, k_start, maxit, tol, k_out)
                              : iter_run_small<double>(it, k_start, maxit, tol, k_out));
+  fill_scalars(it, out);
+  return PG_OK;
+}
+
+// Whole solve in one cooperative launch of up to one workgroup per CU that meet at grid barriers (sizes between the
+// single-workgroup solver and the streaming kernels: A stays cache-resident, three m-vectors live in LDS).
+pg_status pg_iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int32_t blocks, int64_t* k_out,
+                           pg_iter_scalars* out) {
+  PG_REQUIRE(it != nullptr && k_out != nullptr, "null argument");
+  PG_REQUIRE(it->initialized, "pg_iter_init has not been called");
+  PG_REQUIRE(it->o.seq_kind != PG_SEQ_HOST || !it->o.fast, "PG_SEQ_HOST needs per-step coefficients");
+  PG_REQUIRE(it->ctx->allreduce == nullptr && it->ctx->allreduce_begin == nullptr,
+             "the cooperative solver does not support row-sharded operators");
+  pg_mat* A = it->f->A;
+  const int64_t es = (int64_t)pg_sizeof(it->dtype);
+  if (A->m == 0 || A->n == 0 || A->n >= ((int64_t)1 << 31) || 3 * pg_round_up(A->m, 64) * es > COOP_MAX_LDS ||
+      A->m * A->n * es > ((int64_t)256 << 20)) {
+    pg_set_error("pg_iter_run_coop needs 0 < m <= %lld rows (three residual vectors in LDS) and at most 256 MiB of A; "
+                 "use pg_iter_run", (long long)(COOP_MAX_LDS / (3 * es)));
+    return PG_ERR_UNSUPPORTED;
+  }
+  PG_TRY(it->dtype == PG_F32 ? iter_run_coop<float>(it, k_start, maxit, tol, blocks, k_out)
+                             : iter_run_coop<double>(it, k_start, maxit, tol, blocks, k_out));
   fill_scalars(it, out);
   return PG_OK;
 }

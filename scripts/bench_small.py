@@ -53,6 +53,26 @@ def main():
         k_small, _ = its._fused.run_small(1, 10_000, 1e-6)
         t_small = time.perf_counter() - t0
         z_small = its._fused.view()["z"].numpy()
+        # cooperative multi-workgroup solver: adaptive (the benchmark's mode) and fixed step, several grid sizes
+        coop = {}
+        for blocks in (0, 0, 8, 32, 64, 128, 256):  # the first pass is a warm-up
+            itc = pa.FastForwardBackwardIteration(f=f, g=g, x0=x0)
+            next(iter(itc))
+            gc.collect()
+            t0 = time.perf_counter()
+            k_c, _ = itc._fused.run_coop(1, 10_000, 1e-6, blocks)
+            t_c = time.perf_counter() - t0
+            coop[blocks] = {"k": k_c, "it_s": k_c / t_c, "solve_ms": 1e3 * t_c}
+        z_coop = itc._fused.view()["z"].numpy()
+        Lf_c = float(np.linalg.norm(A, 2) ** 2)
+        coop_fixed = {}
+        for blocks in (0, 0, 8, 32, 64, 128, 256):
+            itc = pa.FastForwardBackwardIteration(f=f, g=g, x0=x0, Lf=Lf_c)
+            next(iter(itc))
+            gc.collect()
+            t0 = time.perf_counter()
+            k_c, _ = itc._fused.run_coop(1, 4001, 0.0, blocks)
+            coop_fixed[blocks] = (k_c - 1) / (time.perf_counter() - t0)
         t0 = time.perf_counter()
         zo, ko = o.fast_forward_backward(tol=1e-6, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam))
         t_cpu = time.perf_counter() - t0
@@ -70,6 +90,9 @@ def main():
                     "gpu_library_loop_it_s": k_lib / t_lib,
                     "k_persistent": k_small, "gpu_persistent_kernel_it_s": k_small / t_small,
                     "gpu_persistent_kernel_solve_ms": 1e3 * t_small, "cpu_numpy_solve_ms": 1e3 * t_cpu,
+                    "gpu_coop_adaptive": {str(b_): v for b_, v in coop.items()},
+                    "gpu_coop_fixed_step_it_s": {str(b_): v for b_, v in coop_fixed.items()},
+                    "max_abs_diff_coop": float(np.max(np.abs(z_coop - zo))),
                     "max_abs_diff_persistent": float(np.max(np.abs(z_small - zo))), "cpu_numpy_it_s": ko / t_cpu,
                     "max_abs_diff": float(np.max(np.abs(z - zo)))})
     print(json.dumps(out, indent=1))

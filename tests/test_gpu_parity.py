@@ -1109,12 +1109,19 @@ def test_native_rccl_communicator_world_size_one(pa):
 @pytest.mark.parametrize("mode", ["fixed", "adaptive"])
 @pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_small_persistent_solver_matches_host_loop(pa, dtype, fast, mode, reuse):
+@pytest.mark.parametrize("solver", ["small", "coop"])
+def test_small_persistent_solver_matches_host_loop(pa, dtype, fast, mode, reuse, solver):
+    """pg_iter_run_small (one workgroup) and pg_iter_run_coop (cooperating workgroups, grid barriers): same iteration
+    count and iterate as the host-driven loop and as the CPU restatement."""
     if not (fast and mode == "adaptive") and not reuse:
         pytest.skip("reuse_residual only matters for adaptive FFB")
     It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
     Io = o.FastForwardBackwardIteration if fast else o.ForwardBackwardIteration
-    for (m, n, gname) in ((4, 5, "l1"), (50, 100, "l1"), (200, 500, "l1"), (130, 300, "box")):
+    shapes = [(4, 5, "l1", 0), (50, 100, "l1", 0), (200, 500, "l1", 0), (130, 300, "box", 0)]
+    if solver == "coop":  # (m, n, g, workgroups): automatic and forced grid sizes, more row blocks than workgroups, ...
+        shapes += [(200, 500, "l1", 1), (200, 500, "l1", 7), (200, 500, "l1", 256), (700, 900, "l1", 0), (64, 3000, "l1", 0),
+                   (1000, 120, "box", 3), (513, 65, "l1", 40)]
+    for (m, n, gname, blocks) in shapes:
         if (m, n) == (4, 5):
             A, b, lam, Lf = lasso_small(dtype)
         else:
@@ -1133,7 +1140,7 @@ def test_small_persistent_solver_matches_host_loop(pa, dtype, fast, mode, reuse)
         z_h = it_h._fused.view()["z"].numpy().copy()
         it_s = It(f=f, g=g, x0=x0, **kw)
         next(iter(it_s))
-        k_s, sc_s = it_s._fused.run_small(1, 3000, tol)
+        k_s, sc_s = it_s._fused.run_small(1, 3000, tol) if solver == "small" else it_s._fused.run_coop(1, 3000, tol, blocks)
         z_s = it_s._fused.view()["z"].numpy().copy()
         okw = {k_: v for k_, v in kw.items() if k_ != "reuse_residual"}
         z_o, k_o = (o.fast_forward_backward if fast else o.forward_backward)(tol=tol, maxit=3000, x0=x0, f=o.LeastSquares(A, b), g=go, **okw)
@@ -1149,10 +1156,39 @@ def test_small_persistent_solver_matches_host_loop(pa, dtype, fast, mode, reuse)
         s1 = it_s._fused.step()
         assert np.isfinite(s1.f_x) and float(s1.gamma) > 0
     with pytest.raises(pa.ProxGradError):
-        Ab, bb, lb = synthetic_problem(1100, 1000, np.float32, seed=1)
-        big = It(f=pa.LeastSquares(Ab, bb), g=pa.NormL1(lb), x0=np.zeros(1000, np.float32))
+        mb = 1100 if solver == "small" else 9000  # too many elements / too many rows for three residuals in LDS
+        Ab, bb, lb = synthetic_problem(mb, 1000 if solver == "small" else 40, np.float32, seed=1)
+        big = It(f=pa.LeastSquares(Ab, bb), g=pa.NormL1(lb), x0=np.zeros(Ab.shape[1], np.float32))
         next(iter(big))
-        big._fused.run_small(1, 10, 1e-3)
+        (big._fused.run_small if solver == "small" else big._fused.run_coop)(1, 10, 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_coop_solver_continues_host_state_and_back(pa, dtype):
+    """Host-driven steps -> cooperative solver -> host-driven steps on adaptive FFB with residual reuse: the
+    line-search residual pair (A z - b, A z_prev - b) is carried into LDS and back, so the mixed run follows the
+    all-host run."""
+    A, b, lam = synthetic_problem(300, 700, dtype, seed=9)
+    x0 = np.zeros(700, dtype)
+    f = pa.LeastSquares(A, b)
+    ref = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=x0)
+    mix = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=x0)
+    it_r, it_m = iter(ref), iter(mix)
+    for _ in range(6):
+        s_r, s_m = next(it_r), next(it_m)
+    k, _ = mix._fused.run_coop(6, 26, 0.0)  # 20 iterations inside the kernel
+    assert k == 26
+    for _ in range(20):
+        s_r = next(it_r)
+    tol = 2e-4 if dtype == np.float32 else 1e-10
+    z_m = mix._fused.view()["z"].numpy()
+    assert np.max(np.abs(z_m - s_r.z.numpy())) <= tol * max(1.0, np.max(np.abs(z_m)))
+    for _ in range(5):  # and onwards from the kernel's state with host-driven steps
+        s_r = next(it_r)
+        sc = mix._fused.step()
+    z_m = mix._fused.view()["z"].numpy()
+    assert np.max(np.abs(z_m - s_r.z.numpy())) <= tol * max(1.0, np.max(np.abs(z_m)))
+    assert float(sc.gamma) == pytest.approx(float(s_r.gamma), rel=1e-3 if dtype == np.float32 else 1e-10)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
