@@ -300,8 +300,11 @@ struct SmallParams {
   T tol;
   double* out;  // [32] results, mapped host memory
   // cooperative back end only
-  int W, S, nrb, m_pad;     // workgroups; column slices and 64-row blocks of pass N; padded m
-  double* npart;            // [2][S][m_pad] pass-N partial sums (double buffered by pass parity)
+  int W, nrb, m_pad;        // workgroups; 64-row blocks; padded m
+  int cols_per, ncol_pad;   // columns owned by a workgroup (padded: LDS slice size)
+  int two_stage, rows_per;  // row-sliced combination of the pass-N partials (large W * m)
+  T* rfull;                 // [2][m_pad] the combined residual of the two-stage path
+  double* npart;            // [2][W][m_pad] pass-N partial sums (double buffered by pass parity)
   double* spart;            // [2][W][4] scalar partials (double buffered by reduction parity)
   unsigned long long* bar;  // arrival counter of the grid barrier (zeroed by the host before the launch)
   int* abort_flag;
@@ -380,6 +383,13 @@ struct SmallOps {
   __device__ __forceinline__ Slot slot(int i) const { return i == 0 ? r0 : (i == 1 ? r1 : r2); }
   __device__ __forceinline__ bool is_slot(Slot s, int i) const { return s == slot(i); }
   __device__ __forceinline__ T* rs(Slot s) const { return s; }
+  using Vec = T*;  // an n-vector handle is the global pointer
+  __device__ __forceinline__ Vec vec(int i) const { return p.buf[i]; }
+  __device__ __forceinline__ double role(Vec q) const {
+    for (int i = 0; i < 8; ++i)
+      if (p.buf[i] == q) return (double)i;
+    return -1.0;
+  }
   __device__ bool aborted() const { return false; }
   __device__ bool leader() const { return true; }
 
@@ -466,9 +476,9 @@ struct SmallOps {
   }
 
   // [x = ea + beta (ea - ec) when ea != nullptr] ; g = lam A' rs[slot] ; epilogue
-  __device__ void adjoint_epilogue(Slot slot, T* x, T* g, T gamma, T* y, T* z, T* res, double (&out)[4], const T* ea,
-                                   const T* ec, T beta) {
-    if (ea != nullptr) extrapolate(ea, ec, beta, x);
+  __device__ void adjoint_epilogue(Slot slot, T* x, T* g, T gamma, T* y, T* z, T* res, double (&out)[4], bool extrap,
+                                   const T* ea, const T* ec, T beta) {
+    if (extrap) extrapolate(ea, ec, beta, x);
     adjoint(slot, g);
     epilogue(x, g, gamma, y, z, res, out);
   }
@@ -479,8 +489,15 @@ struct SmallOps {
 };
 
 // ---- back end 2: W cooperating workgroups ------------------------------------------------------------------------
-// Everything one workgroup writes and another reads inside the kernel goes through agent-scope (sc1, write-through /
-// cache-bypassing) accesses; A and b are read-only and use ordinary cached loads.
+// Column ownership: workgroup w owns the columns [w * cols_per, ...) of A for BOTH GEMV orientations, so its slices
+// of the six n-vectors never leave its LDS (loaded once, written back once); only m-vectors cross workgroups:
+//   pass N   : partial_w = A[:, J_w] v[J_w]  -> global (write-through) | grid barrier | every workgroup sums the W
+//              partials in the same order into its LDS copy of r (large W * m: row-sliced in two stages)
+//   pass T   : g[J_w] = A[:, J_w]' r  from the LDS copy -- local
+//   epilogue : local; its four scalars meet in one more grid reduction.
+// A fixed-step iteration = two grid barriers and no launch; A stays L2-resident (each workgroup re-reads only its
+// own columns).  Everything one workgroup writes and another reads inside the kernel goes through agent-scope (sc1,
+// write-through / cache-bypassing) accesses; A and b are read-only and use ordinary cached loads.
 template <typename T>
 __device__ __forceinline__ T ld_ag(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -498,7 +515,8 @@ struct CoopOps {
   double* sm_part;
   double* sm_red;
   int* sm_flag;
-  T* lds_base;  // residual slots in LDS (m_pad elements each)
+  T* lds_base;  // [3][m_pad] residual slots, then [6][ncol_pad] slices of the n-vectors
+  int c0, nc;   // this workgroup's columns [c0, c0 + nc)
   unsigned long long bar_target;
   int npass, nred;
   bool dead;
@@ -508,8 +526,27 @@ struct CoopOps {
   __device__ __forceinline__ Slot slot(int i) const { return i; }
   __device__ __forceinline__ bool is_slot(Slot s, int i) const { return s == i; }
   __device__ __forceinline__ T* rs(Slot s) const { return lds_base + (size_t)s * p.m_pad; }
+  using Vec = int;  // index of an ncol_pad-sized LDS region (this workgroup's slice of an n-vector)
+  __device__ __forceinline__ Vec vec(int i) const { return i; }
+  __device__ __forceinline__ double role(Vec v) const { return (double)v; }
+  __device__ __forceinline__ T* vs(Vec v) const { return lds_base + (size_t)3 * p.m_pad + (size_t)v * p.ncol_pad; }
   __device__ bool aborted() const { return dead; }
   __device__ bool leader() const { return blockIdx.x == 0; }
+
+  __device__ void load_state() {
+    for (int h = 0; h < 6; ++h) {
+      T* dst = vs(h);
+      for (int j = threadIdx.x; j < nc; j += SMALL_THREADS) dst[j] = p.buf[h][c0 + j];
+    }
+    if (p.reuse) {  // the line-search residual pair continues from the host-driven steps
+      T *d1 = rs(1), *d2 = rs(2);
+      for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+        d1[i] = p.buf[6][i];
+        d2[i] = p.buf[7][i];
+      }
+    }
+    __syncthreads();
+  }
 
   // Grid barrier: every thread drains its write-through stores, the workgroup's thread 0 takes a ticket on a
   // monotonically increasing counter and polls it.  Bounded: on a timeout the solve is abandoned (flag), never hung.
@@ -564,67 +601,91 @@ struct CoopOps {
     small_block_reduce<MAXMASK>(v, sm_red);
   }
 
-  // pass N: partial sums of A v over this workgroup's (64-row block, column slice) items; v_j = a_j, or
-  // a_j + beta (a_j - c_j) formed on the fly (the items of row block 0 also store it to x_out)
-  __device__ void pass_n(const T* a, const T* c, T beta, T* x_out) {
+  // pass N over the own columns: partial_w[i] = sum_j A[i, c0 + j] v[j]   (v: LDS slice)
+  __device__ void pass_n(const T* v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* part = p.npart + (size_t)(npass & 1) * p.S * p.m_pad;
-    const int items = p.nrb * p.S;
-    const int cols_per = (p.n + p.S - 1) / p.S;
-    for (int item = blockIdx.x; item < items; item += p.W) {
-      const int rb = item / p.S, s = item - rb * p.S;
-      const int c0 = s * cols_per, c1 = (c0 + cols_per < p.n) ? (c0 + cols_per) : p.n;
+    double* part = p.npart + ((size_t)(npass & 1) * p.W + blockIdx.x) * p.m_pad;
+    const T* Aj = p.A + (long long)c0 * p.ld;
+    if (p.nrb >= SMALL_WAVES) {  // a wave per 64-row block, all own columns
+      for (int rb = wave; rb < p.nrb; rb += SMALL_WAVES) {
+        const int i = rb * 64 + lane;
+        double acc = 0.0;
+        if (i < p.m)
+          for (int j = 0; j < nc; ++j) acc += (double)Aj[i + (long long)j * p.ld] * (double)v[j];
+        st_ag(part + i, acc);
+      }
+    } else {  // few row blocks: G waves share one, each taking every G-th column; fixed-order combine through LDS
+      const int G = SMALL_WAVES / p.nrb;
+      const int rb = wave / G, cg = wave - rb * G;
       const int i = rb * 64 + lane;
       double acc = 0.0;
-      for (int j = c0 + wave; j < c1; j += SMALL_WAVES) {
-        T vj = ld_ag(a + j);
-        if (c != nullptr) {
-          const T cj = ld_ag(c + j);
-          vj = vj + beta * (vj - cj);
-          if (rb == 0 && lane == 0) st_ag(x_out + j, vj);
-        }
-        if (i < p.m) acc += (double)p.A[i + (long long)j * p.ld] * (double)vj;
-      }
-      __syncthreads();  // sm_part free (previous item)
+      if (rb < p.nrb && i < p.m)
+        for (int j = cg; j < nc; j += G) acc += (double)Aj[i + (long long)j * p.ld] * (double)v[j];
       sm_part[wave * 64 + lane] = acc;
       __syncthreads();
-      if (wave == 0 && i < p.m) {
+      if (rb < p.nrb && cg == 0) {
         double t = 0.0;
-        for (int w = 0; w < SMALL_WAVES; ++w) t += sm_part[w * 64 + lane];
-        st_ag(part + (size_t)s * p.m_pad + i, t);
+        for (int q = 0; q < G; ++q) t += sm_part[(wave + q) * 64 + lane];
+        st_ag(part + i, t);
       }
     }
     ++npass;
     barrier();
   }
 
-  // rs[slot] = sum_s partial[s] - b (every workgroup, same order) ; returns sum r^2
+  // rs(slot) = sum_w partial_w - b in every workgroup (same order everywhere) ; returns sum r^2
   __device__ double combine(Slot slot) {
-    const double* part = p.npart + (size_t)((npass - 1) & 1) * p.S * p.m_pad;
-    double sq = 0.0;
+    const double* part = p.npart + (size_t)((npass - 1) & 1) * p.W * p.m_pad;
     T* dst = rs(slot);
-    if (!dead) {
+    double sq = 0.0;
+    if (p.two_stage) {  // stage 1: each workgroup sums its own rows and publishes them; stage 2: everybody reads r
+      T* rf = p.rfull + (size_t)((npass - 1) & 1) * p.m_pad;
+      if (!dead) {
+        const int i0 = blockIdx.x * p.rows_per;
+        const int i1 = (i0 + p.rows_per < p.m) ? (i0 + p.rows_per) : p.m;
+        const int nrows = i1 > i0 ? i1 - i0 : 0;
+        for (int i = i0 + (int)threadIdx.x; i < i0 + nrows; i += SMALL_THREADS) {
+          double t = 0.0;
+          for (int w = 0; w < p.W; ++w) t += ld_ag(part + (size_t)w * p.m_pad + i);
+          st_ag(rf + i, (T)(t - (double)p.b[i]));
+        }
+      }
+      barrier();
+      if (!dead)
+        for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
+          const T ri = ld_ag(rf + i);
+          dst[i] = ri;
+          sq += (double)ri * (double)ri;
+        }
+    } else if (!dead) {
       for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
         double t = 0.0;
-        for (int s = 0; s < p.S; ++s) t += ld_ag(part + (size_t)s * p.m_pad + i);
+        for (int w = 0; w < p.W; ++w) t += ld_ag(part + (size_t)w * p.m_pad + i);
         const T ri = (T)(t - (double)p.b[i]);
         dst[i] = ri;
         sq += (double)ri * (double)ri;
       }
     }
     double v4[4] = {sq, 0.0, 0.0, 0.0};
-    small_block_reduce<0u>(v4, sm_red);  // ends with a workgroup barrier: rs[slot] is complete
+    small_block_reduce<0u>(v4, sm_red);  // ends with workgroup barriers: rs(slot) is complete
     return v4[0];
   }
 
-  __device__ double residual(const T* v, Slot slot) {
-    pass_n(v, nullptr, T(0), nullptr);
+  __device__ double residual(Vec v, Slot slot) {
+    pass_n(vs(v));
     return combine(slot);
   }
 
-  __device__ double residual_extrap(const T* a, const T* c, T beta, T* x, Slot slot) {
-    pass_n(a, c, beta, x);
-    return combine(slot);
+  __device__ void extrapolate(Vec a, Vec c, T beta, Vec x) {  // x = a + beta (a - c) on the own columns   ffb:135
+    const T *av = vs(a), *cv = vs(c);
+    T* xv = vs(x);
+    for (int j = threadIdx.x; j < nc; j += SMALL_THREADS) xv[j] = av[j] + beta * (av[j] - cv[j]);
+    __syncthreads();
+  }
+
+  __device__ double residual_extrap(Vec a, Vec c, T beta, Vec x, Slot slot) {
+    extrapolate(a, c, beta, x);
+    return residual(x, slot);
   }
 
   __device__ double residual_combo(T ca, Slot sa, T cb, Slot sb, Slot so) {  // redundantly in every workgroup (LDS)
@@ -641,74 +702,57 @@ struct CoopOps {
     return v4[0];
   }
 
-  // one wave per column: g_j = lam A_j' r, optionally followed by the epilogue of element j (lane 0)
-  template <bool EPI>
-  __device__ void adjoint_cols(Slot slot, T* x, T* g, T gamma, T* y, T* z, T* res, double (&acc)[4], const T* ea,
-                               const T* ec, T beta) {
+  // g[J_w] = lam A[:, J_w]' rs(slot): a wave per own column, no cross-workgroup traffic
+  __device__ void adjoint_local(Slot slot, Vec g) {
     const T* r = rs(slot);
+    T* gv = vs(g);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const T gl = gamma * p.g_p0;
-    for (int j = blockIdx.x * SMALL_WAVES + wave; j < p.n; j += p.W * SMALL_WAVES) {
+    for (int j = wave; j < nc; j += SMALL_WAVES) {
       double a = 0.0;
-      const T* col = p.A + (long long)j * p.ld;
+      const T* col = p.A + (long long)(c0 + j) * p.ld;
       for (int i = lane; i < p.m; i += 64) a += (double)col[i] * (double)r[i];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) a += pg_shfl_xor(a, off);
-      if (lane == 0) {
-        const T gv = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)a) : (T)a;
-        st_ag(g + j, gv);
-        if (EPI) {
-          T xv;
-          if (ea != nullptr) {
-            const T av = ld_ag(ea + j), cv = ld_ag(ec + j);
-            xv = av + beta * (av - cv);
-            st_ag(x + j, xv);
-          } else {
-            xv = ld_ag(x + j);
-          }
-          T yv, zv, rv;
-          small_epilogue_elem(p, xv, gv, gamma, gl, yv, zv, rv, acc);
-          st_ag(y + j, yv);
-          st_ag(z + j, zv);
-          st_ag(res + j, rv);
-        }
-      }
+      if (lane == 0) gv[j] = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)a) : (T)a;
     }
+    __syncthreads();
   }
 
-  __device__ void adjoint(Slot slot, T* g_out) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    adjoint_cols<false>(slot, nullptr, g_out, T(0), nullptr, nullptr, nullptr, acc, nullptr, nullptr, T(0));
-    barrier();
-  }
+  __device__ void adjoint(Slot slot, Vec g) { adjoint_local(slot, g); }
 
-  __device__ void epilogue(const T* x, const T* g, T gamma, T* y, T* z, T* res, double (&out)[4]) {
+  __device__ void epilogue(Vec x, Vec g, T gamma, Vec y, Vec z, Vec res, double (&out)[4]) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const T gl = gamma * p.g_p0;
-    for (int j = blockIdx.x * SMALL_THREADS + threadIdx.x; j < p.n; j += p.W * SMALL_THREADS) {
-      T yv, zv, rv;
-      small_epilogue_elem(p, ld_ag(x + j), ld_ag(g + j), gamma, gl, yv, zv, rv, acc);
-      st_ag(y + j, yv);
-      st_ag(z + j, zv);
-      st_ag(res + j, rv);
+    const T *xv = vs(x), *gv = vs(g);
+    T *yv = vs(y), *zv = vs(z), *rv = vs(res);
+    for (int j = threadIdx.x; j < nc; j += SMALL_THREADS) {
+      T yo, zo, ro;
+      small_epilogue_elem(p, xv[j], gv[j], gamma, gl, yo, zo, ro, acc);
+      yv[j] = yo;
+      zv[j] = zo;
+      rv[j] = ro;
     }
     grid_reduce<0x2u>(acc);
     small_epilogue_out(p, acc, out);
   }
 
-  __device__ void adjoint_epilogue(Slot slot, T* x, T* g, T gamma, T* y, T* z, T* res, double (&out)[4], const T* ea,
-                                   const T* ec, T beta) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    adjoint_cols<true>(slot, x, g, gamma, y, z, res, acc, ea, ec, beta);
-    grid_reduce<0x2u>(acc);
-    small_epilogue_out(p, acc, out);
+  __device__ void adjoint_epilogue(Slot slot, Vec x, Vec g, T gamma, Vec y, Vec z, Vec res, double (&out)[4],
+                                   bool extrap, Vec ea, Vec ec, T beta) {
+    if (extrap) extrapolate(ea, ec, beta, x);
+    adjoint_local(slot, g);
+    epilogue(x, g, gamma, y, z, res, out);
   }
 
   __device__ double barrier_ticks() const { return (double)t_bar; }
   __device__ double barrier_count() const { return (double)n_bar; }
 
-  // export the LDS-resident residuals (r, and the line-search pair when kept) for later host-driven steps
+  // write the LDS-resident state back: own slices of the six n-vectors; workgroup 0 also exports the residuals
   __device__ void finish(Slot s_r, Slot, Slot) {
+    __syncthreads();
+    for (int h = 0; h < 6; ++h) {
+      const T* src = vs(h);
+      for (int j = threadIdx.x; j < nc; j += SMALL_THREADS) p.buf[h][c0 + j] = src[j];
+    }
     if (blockIdx.x != 0) return;
     const T *src = rs(s_r), *s1 = rs(1), *s2 = rs(2);
     for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
@@ -724,7 +768,8 @@ struct CoopOps {
 // ---- the loop (both back ends) -------------------------------------------------------------------------------------
 template <typename T, typename Ops>
 __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
-  T *x = p.buf[0], *grad = p.buf[1], *y = p.buf[2], *z = p.buf[3], *res = p.buf[4], *zp = p.buf[5];
+  using Vec = typename Ops::Vec;
+  Vec x = ops.vec(0), grad = ops.vec(1), y = ops.vec(2), z = ops.vec(3), res = ops.vec(4), zp = ops.vec(5);
   typename Ops::Slot s_r = ops.slot(0), s_rz = ops.slot(1), s_rzp = ops.slot(2);  // scratch r, A z - b, A z_prev - b
   T gamma = p.gamma, f_x = p.f_x, g_z = p.g_z, res_inf = p.res_inf, dot_gr = p.dot_gr, res_sq = p.res_sq;
   T beta = T(0);
@@ -774,7 +819,7 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
       }
       beta = seq_next_hd<T>(p.seq_kind, p.mf, p.seq_p0, p.seq_p1, seq, gamma, T(0));  // :134
       {  // :136 (the extrapolation :135 is formed below from the swapped pair: x = zp + beta (zp - z))
-        T* t = zp;
+        Vec t = zp;
         zp = z;
         z = t;
       }
@@ -784,12 +829,12 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
         s_rzp = s_rz;
         s_rz = t;
         rz_valid = false;
-        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, zp, z, beta);  // :135, :138-142
+        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, true, zp, z, beta);  // :135, :138-142
       } else {
         f_x = f_scale * (T)ops.residual_extrap(zp, z, beta, x, s_r);  // :135, :138
         passes += 1;
         rz_valid = false;  // this residual belongs to x, not to z: nothing to reuse next time
-        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, nullptr, nullptr, T(0));  // :138-142
+        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, false, x, x, T(0));  // :138-142
       }
       passes += 1;
       set_epilogue();
@@ -814,7 +859,7 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
         }
         if (gamma < p.min_gamma) flags |= PG_FLAG_GAMMA_TOO_SMALL;
         f_x = f_z;  // :92
-        T* t = x;   // :109
+        Vec t = x;   // :109
         x = z;
         z = t;
         t = grad;   // :110
@@ -822,12 +867,12 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
         zp = t;
         ops.epilogue(x, grad, gamma, y, z, res, e4);  // :117-120
       } else {  // :111-115
-        T* t = x;
+        Vec t = x;
         x = z;
         z = t;
         f_x = f_scale * (T)ops.residual(x, s_r);
         passes += 2;
-        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, nullptr, nullptr, T(0));  // :113-120
+        ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, false, x, x, T(0));  // :113-120
       }
       set_epilogue();
     }
@@ -835,11 +880,6 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
   }
   ops.finish(s_r, s_rz, s_rzp);
   if (ops.leader() && threadIdx.x == 0) {
-    auto role = [&](const T* q) -> double {
-      for (int i = 0; i < 8; ++i)
-        if (p.buf[i] == q) return (double)i;
-      return -1.0;
-    };
     double* o = p.out;
     o[0] = (double)k;
     o[1] = (double)gamma;
@@ -853,12 +893,12 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
     o[9] = (double)seq.theta;
     o[10] = (double)seq.t;
     o[11] = (double)seq.k;
-    o[12] = role(x);
-    o[13] = role(grad);
-    o[14] = role(y);
-    o[15] = role(z);
-    o[16] = role(res);
-    o[17] = role(zp);
+    o[12] = ops.role(x);
+    o[13] = ops.role(grad);
+    o[14] = ops.role(y);
+    o[15] = ops.role(z);
+    o[16] = ops.role(res);
+    o[17] = ops.role(zp);
     o[18] = ops.is_slot(s_rz, 1) ? 6.0 : 7.0;
     o[19] = ops.is_slot(s_rzp, 2) ? 7.0 : 6.0;
     o[20] = (double)nbt_total;
@@ -886,15 +926,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void coop_solver_kernel(SmallParams<
   __shared__ double sm_red[SMALL_WAVES * 4];
   __shared__ int sm_flag;
   extern __shared__ __attribute__((aligned(16))) unsigned char coop_lds[];
-  T* base = reinterpret_cast<T*>(coop_lds);
-  CoopOps<T> ops{p, sm_part, sm_red, &sm_flag, base, 0ull, 0, 0, false};
-  if (p.reuse) {  // the line-search residual pair continues from the host-driven steps (written by earlier kernels)
-    for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
-      ops.rs(1)[i] = p.buf[6][i];
-      ops.rs(2)[i] = p.buf[7][i];
-    }
-  }
-  __syncthreads();
+  const int c0 = (int)blockIdx.x * p.cols_per;
+  int nc = p.n - c0;
+  if (nc > p.cols_per) nc = p.cols_per;
+  if (nc < 0) nc = 0;
+  CoopOps<T> ops{p, sm_part, sm_red, &sm_flag, reinterpret_cast<T*>(coop_lds), c0, nc, 0ull, 0, 0, false};
+  ops.load_state();
   solver_loop<T, CoopOps<T>>(p, ops);
 }
 
@@ -1004,7 +1041,7 @@ pg_status iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol
 }
 
 // cooperative multi-workgroup variant; blocks <= 0: chosen from the size of A (about 32 KiB of A per workgroup and pass)
-constexpr int64_t COOP_MAX_LDS = 96 * 1024;  // three residual vectors per workgroup
+constexpr int64_t COOP_MAX_LDS = 128 * 1024;  // three residual vectors + six n-vector slices per workgroup
 
 template <typename T>
 pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int blocks, int64_t* k_out) {
@@ -1017,34 +1054,41 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
   p.out = c->small_out;
   p.m_pad = (int)pg_round_up(A->m, 64);
   p.nrb = p.m_pad / 64;
-  const size_t lds = (size_t)3 * p.m_pad * sizeof(T);
-  const void* kern = reinterpret_cast<const void*>(&coop_solver_kernel<T>);
-  static bool opted_in[64] = {};
-  if (!opted_in[c->device & 63]) {
-    PG_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COOP_MAX_LDS));
-    opted_in[c->device & 63] = true;
-  }
-  int per_cu = 0;
-  PG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SMALL_THREADS, lds));
-  if (per_cu < 1) {
-    pg_set_error("the cooperative solver does not fit on a CU (%zu bytes of LDS)", lds);
-    return PG_ERR_UNSUPPORTED;
-  }
   int W = blocks;
   if (W <= 0) {
     const int64_t bytes = A->m * A->n * (int64_t)sizeof(T);
     W = (int)((bytes + 32767) / 32768);
   }
   if (W > c->num_cu) W = c->num_cu;  // one workgroup per CU: all of them are resident, the grid barrier cannot starve
+  if ((int64_t)W > A->n) W = (int)A->n;
   if (W < 1) W = 1;
+  // every workgroup keeps 3 m-vectors and its slice of 6 n-vectors in LDS: widen the grid until the slices fit
+  auto lds_for = [&](int w) -> int64_t {
+    const int64_t cols = (A->n + w - 1) / w;
+    return ((int64_t)3 * p.m_pad + 6 * pg_round_up(cols, 16)) * (int64_t)sizeof(T);
+  };
+  while (lds_for(W) > COOP_MAX_LDS && W < c->num_cu) ++W;
+  if (lds_for(W) > COOP_MAX_LDS) {
+    pg_set_error("the cooperative solver needs %lld bytes of LDS per workgroup for this shape (limit %lld); use pg_iter_run",
+                 (long long)lds_for(W), (long long)COOP_MAX_LDS);
+    return PG_ERR_UNSUPPORTED;
+  }
+  p.cols_per = (int)((A->n + W - 1) / W);
+  W = (int)((A->n + p.cols_per - 1) / p.cols_per);  // no workgroup without columns
+  p.ncol_pad = (int)pg_round_up(p.cols_per, 16);
   p.W = W;
-  int S = W / p.nrb;
-  const int s_cap = p.n / 16 > 1 ? p.n / 16 : 1;  // at least one column per wave and slice
-  if (S > s_cap) S = s_cap;
-  if (S < 1) S = 1;
-  p.S = S;
-  // workspace: [bar (8 B) | abort (4 B) | pad to 64 B][2][W][4] scalar partials [2][S][m_pad] pass-N partials
-  const size_t need = 64 + sizeof(double) * ((size_t)2 * W * 4 + (size_t)2 * S * p.m_pad);
+  p.two_stage = ((int64_t)W * A->m > 65536) ? 1 : 0;
+  p.rows_per = (int)((A->m + W - 1) / W);
+  const size_t lds = (size_t)lds_for(W);
+  const void* kern = reinterpret_cast<const void*>(&coop_solver_kernel<T>);
+  static bool opted_in[64] = {};
+  if (!opted_in[c->device & 63]) {
+    PG_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COOP_MAX_LDS));
+    opted_in[c->device & 63] = true;
+  }
+  // workspace: [bar (8 B) | abort (4 B) | pad to 64 B][2][W][4] scalar partials [2][W][m_pad] pass-N partials [2][m_pad] r
+  const size_t n_sp = (size_t)2 * W * 4, n_np = (size_t)2 * W * p.m_pad;
+  const size_t need = 64 + sizeof(double) * (n_sp + n_np) + sizeof(T) * (size_t)2 * p.m_pad;
   if (c->coop_ws_bytes < need) {
     if (c->coop_ws) {
       PG_HIP(hipStreamSynchronize(c->stream));
@@ -1064,7 +1108,8 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
   p.bar = (unsigned long long*)ws;
   p.abort_flag = (int*)(ws + 8);
   p.spart = (double*)(ws + 64);
-  p.npart = p.spart + (size_t)2 * W * 4;
+  p.npart = p.spart + n_sp;
+  p.rfull = (T*)(p.npart + n_np);
   void* args[1] = {(void*)&p};
   hipError_t e = hipLaunchCooperativeKernel(kern, dim3((unsigned)W), dim3(SMALL_THREADS), args, (unsigned)lds, c->stream);
   if (e != hipSuccess) {
@@ -1076,8 +1121,8 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
   if (getenv("PG_COOP_VERBOSE")) {
     const double* o = c->small_out_host;
     const double its = (double)(*k_out - k_start);
-    fprintf(stderr, "[pg coop] %dx%d W=%d S=%d: %.0f iterations, %.2f us/iteration, %.1f barriers/iteration, %.2f us/barrier (%.0f %% of the loop)\n",
-            p.m, p.n, W, S, its, o[25] * 0.01 / (its > 0 ? its : 1), o[27] / (its > 0 ? its : 1),
+    fprintf(stderr, "[pg coop] %dx%d W=%d cols/wg=%d two_stage=%d: %.0f iterations, %.2f us/iteration, %.1f barriers/iteration, %.2f us/barrier (%.0f %% of the loop)\n",
+            p.m, p.n, W, p.cols_per, p.two_stage, its, o[25] * 0.01 / (its > 0 ? its : 1), o[27] / (its > 0 ? its : 1),
             o[27] > 0 ? o[26] * 0.01 / o[27] : 0.0, o[25] > 0 ? 100.0 * o[26] / o[25] : 0.0);
   }
   if (c->small_out_host[24] != 0.0) {
@@ -1287,10 +1332,10 @@ pg_status pg_iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double t
              "the cooperative solver does not support row-sharded operators");
   pg_mat* A = it->f->A;
   const int64_t es = (int64_t)pg_sizeof(it->dtype);
-  if (A->m == 0 || A->n == 0 || A->n >= ((int64_t)1 << 31) || 3 * pg_round_up(A->m, 64) * es > COOP_MAX_LDS ||
+  if (A->m == 0 || A->n == 0 || A->n >= ((int64_t)1 << 31) || 3 * pg_round_up(A->m, 64) * es > COOP_MAX_LDS * 3 / 4 ||
       A->m * A->n * es > ((int64_t)256 << 20)) {
     pg_set_error("pg_iter_run_coop needs 0 < m <= %lld rows (three residual vectors in LDS) and at most 256 MiB of A; "
-                 "use pg_iter_run", (long long)(COOP_MAX_LDS / (3 * es)));
+                 "use pg_iter_run", (long long)(COOP_MAX_LDS / (4 * es)));
     return PG_ERR_UNSUPPORTED;
   }
   PG_TRY(it->dtype == PG_F32 ? iter_run_coop<float>(it, k_start, maxit, tol, blocks, k_out)
