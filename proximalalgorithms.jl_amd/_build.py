@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC,
-             "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+             "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"] + os.environ.get("PG_EXTRA_HIPCC_FLAGS", "").split()
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -10,8 +10,8 @@ class IterativeAlgorithm:
 
     def __init__(self, iterator_type, *, maxit, stop, solution, verbose, freq, display, device_loop=None, **kwargs):
         # device_loop = (tol, check_every): run the loop with the DEFAULT stopping rule inside the library instead of
-        # stepping from the host (fused engines only): one launch for launch-bound sizes (pg_iter_run_small), else
-        # the in-library loop (pg_iter_run / pg_iter_run_batched)
+        # stepping from the host (fused engines only): one launch for launch-bound sizes (pg_iter_run_small /
+        # pg_iter_run_coop), else the in-library loop (pg_iter_run / pg_iter_run_batched)
         self.device_loop = device_loop
         self.iterator_type = iterator_type
         self.maxit = int(maxit)
@@ -42,8 +42,16 @@ class IterativeAlgorithm:
             fused = it._fused
             A = it.f.A
             adaptive = bool(it.adaptive)
-            if A.m * A.n <= 32768 and A.m > 0 and A.n > 0 and it.f.comm is None:
+            nbytes = A.m * A.n * A.dtype.itemsize
+            unsharded = A.m > 0 and A.n > 0 and it.f.comm is None
+            # measured crossovers (scripts/bench_small.py, profiles/): one workgroup up to ~8k elements; the cooperative
+            # multi-workgroup kernel while A is a few MiB (its barriers beat launches + host round trips); beyond that
+            # the streaming kernels driven from the host
+            coop_rows = 3 * (-(-A.m // 64) * 64) * A.dtype.itemsize <= 96 * 1024
+            if unsharded and A.m * A.n <= 8192:
                 k, _ = fused.run_small(1, self.maxit, tol)
+            elif unsharded and coop_rows and nbytes <= ((16 << 20) if adaptive else (6 << 20)):
+                k, _ = fused.run_coop(1, self.maxit, tol)
             elif check_every > 1 and not adaptive:
                 k, _ = fused.run(1, self.maxit, tol, check_every=check_every)
             else:

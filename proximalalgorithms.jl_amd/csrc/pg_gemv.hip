@@ -26,23 +26,12 @@ __device__ __forceinline__ V nt_load(const V* p) {
 // xor 2, then row_half_mirror / row_mirror (lane i <-> 7-i / 15-i: after the quad steps every lane of a quad holds
 // the quad sum, so the mirrored partner contributes exactly the other quad / the other half-row); the two
 // cross-row steps (xor 16, xor 32) go through ds_bpermute.  Fixed order => deterministic.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
-  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
-}
 template <typename T>
 __device__ __forceinline__ T wave_allsum(T v) {
-  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  (xor 1)
-  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  (xor 2)
-  v += dpp_mov<0x141>(v);  // row_half_mirror
-  v += dpp_mov<0x140>(v);  // row_mirror
+  v += pg_dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  (xor 1)
+  v += pg_dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  (xor 2)
+  v += pg_dpp_mov<0x141>(v);  // row_half_mirror
+  v += pg_dpp_mov<0x140>(v);  // row_mirror
   v += pg_shfl_xor(v, 16);
   v += pg_shfl_xor(v, 32);
   return v;

@@ -181,6 +181,52 @@ __device__ __forceinline__ float pg_shfl_down(float v, int off) { return __shfl_
 __device__ __forceinline__ double pg_shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float pg_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 
+// DPP lane moves (no LDS round trip) for 4- and 8-byte values
+template <int CTRL>
+__device__ __forceinline__ float pg_dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double pg_dpp_mov(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ float pg_readlane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double pg_readlane(double v, int lane) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(unsigned)b, lane);
+  const int hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// 16-lane row reduction, result in every lane of the row: quad_perm xor 1, xor 2, then row_half_mirror / row_mirror
+// (after the quad steps every lane of a quad holds the quad total, so the mirrored partner contributes exactly the
+// other quad / the other half-row).  Fixed order.
+template <bool MAX, typename T>
+__device__ __forceinline__ T pg_row_allreduce(T v) {
+  T o = pg_dpp_mov<0xB1>(v);
+  v = MAX ? fmax(v, o) : (v + o);
+  o = pg_dpp_mov<0x4E>(v);
+  v = MAX ? fmax(v, o) : (v + o);
+  o = pg_dpp_mov<0x141>(v);
+  v = MAX ? fmax(v, o) : (v + o);
+  o = pg_dpp_mov<0x140>(v);
+  v = MAX ? fmax(v, o) : (v + o);
+  return v;
+}
+// whole-wave reduction, result (wave-uniform) in every lane: row reductions, then the four row totals travel through
+// scalar registers (v_readlane) and are combined as (r0 + r1) + (r2 + r3).  Every lane of the wave must be active.
+template <bool MAX, typename T>
+__device__ __forceinline__ T pg_wave_allreduce(T v) {
+  v = pg_row_allreduce<MAX, T>(v);
+  const T r0 = pg_readlane(v, 0), r1 = pg_readlane(v, 16), r2 = pg_readlane(v, 32), r3 = pg_readlane(v, 48);
+  const T a = MAX ? fmax(r0, r1) : (r0 + r1), b = MAX ? fmax(r2, r3) : (r2 + r3);
+  return MAX ? fmax(a, b) : (a + b);
+}
+
 // Deterministic grid-wide reduction of NS doubles per thread (bit k of MAXMASK: slot k is a max, else a
 // sum).  NW-wave (NW*64-thread) blocks, every thread of the block must call it; gridDim.x <= PG_RED_MAX_BLOCKS.  Every block publishes its partial with
 // write-through agent-scope stores; the last block to arrive (ticket counter) combines all partials in a

@@ -12,6 +12,7 @@
 #include <limits>
 #include <utility>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -283,6 +284,15 @@ pg_status iter_step(pg_iter* it, double host_beta) {
 //     workgroup keeps reading the same slices), the three residual vectors live in every workgroup's LDS, and a
 //     fixed-step iteration costs two grid barriers (pass N partials | combine + A' r + prox + scalar partials).
 // ---------------------------------------------------------------------------------------------
+// -DPG_COOP_TRACE: thread 0 of workgroup 0 stamps wall_clock64() at marked points of ONE iteration into the result
+// block (diagnostics only; the marks compile to nothing otherwise)
+#ifdef PG_COOP_TRACE
+#define PG_MARK(ops, id) (ops).mark(id)
+#else
+#define PG_MARK(ops, id) ((void)0)
+#endif
+constexpr int SMALL_OUT_DOUBLES = 96;
+
 template <typename T>
 struct SmallParams {
   const T* A;
@@ -313,30 +323,26 @@ struct SmallParams {
 constexpr int SMALL_THREADS = 1024;
 constexpr int SMALL_WAVES = SMALL_THREADS / 64;
 
-// all-thread block reduction of 4 doubles (bit k of MAXMASK: max); every thread returns with the results
+// all-thread block reduction of 4 doubles (bit k of MAXMASK: max); every thread returns with the results.
+// DPP / readlane wave reductions, the 16 wave totals meet in LDS and are reduced again inside a 16-lane row.
 template <unsigned MAXMASK>
 __device__ __forceinline__ void small_block_reduce(double (&v)[4], double* sm_red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double o = pg_shfl_xor(v[k], off);
-      v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
-    }
-  }
+  v[0] = pg_wave_allreduce<(MAXMASK & 1u) != 0>(v[0]);
+  v[1] = pg_wave_allreduce<(MAXMASK & 2u) != 0>(v[1]);
+  v[2] = pg_wave_allreduce<(MAXMASK & 4u) != 0>(v[2]);
+  v[3] = pg_wave_allreduce<(MAXMASK & 8u) != 0>(v[3]);
   __syncthreads();  // sm_red free
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) sm_red[wave * 4 + k] = v[k];
   }
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    double a = sm_red[k];
-    for (int w = 1; w < SMALL_WAVES; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm_red[w * 4 + k]) : (a + sm_red[w * 4 + k]);
-    v[k] = a;
-  }
+  static_assert(SMALL_WAVES == 16, "the second stage reduces one wave total per lane of a 16-lane row");
+  v[0] = pg_row_allreduce<(MAXMASK & 1u) != 0>(sm_red[(lane & 15) * 4 + 0]);
+  v[1] = pg_row_allreduce<(MAXMASK & 2u) != 0>(sm_red[(lane & 15) * 4 + 1]);
+  v[2] = pg_row_allreduce<(MAXMASK & 4u) != 0>(sm_red[(lane & 15) * 4 + 2]);
+  v[3] = pg_row_allreduce<(MAXMASK & 8u) != 0>(sm_red[(lane & 15) * 4 + 3]);
 }
 
 template <typename T>
@@ -370,12 +376,36 @@ __device__ __forceinline__ void small_epilogue_out(const SmallParams<T>& p, cons
   out[3] = acc[3];
 }
 
+// nesterov.jl recurrences evaluated by ONE wave and broadcast through LDS: their fp64 divisions and square roots are
+// slow when all 16 waves of the workgroup queue for the same SIMDs with identical work
+template <typename T>
+__device__ __forceinline__ T small_seq_next(const SmallParams<T>& p, SeqState<T>& seq, T gamma, double* sm_scal) {
+  if (threadIdx.x < 64) {
+    SeqState<T> s = seq;
+    const T b = seq_next_hd<T>(p.seq_kind, p.mf, p.seq_p0, p.seq_p1, s, gamma, T(0));
+    if (threadIdx.x == 0) {
+      sm_scal[0] = (double)b;
+      sm_scal[1] = (double)s.stepsize;
+      sm_scal[2] = (double)s.theta;
+      sm_scal[3] = (double)s.t;
+      sm_scal[4] = (double)s.k;
+    }
+  }
+  __syncthreads();
+  seq.stepsize = (T)sm_scal[1];
+  seq.theta = (T)sm_scal[2];
+  seq.t = (T)sm_scal[3];
+  seq.k = (long long)sm_scal[4];
+  return (T)sm_scal[0];
+}
+
 // ---- back end 1: one workgroup --------------------------------------------------------------------------------
 template <typename T>
 struct SmallOps {
   const SmallParams<T>& p;
   double* sm_part;
   double* sm_red;
+  double* sm_scal;
   T *r0, *r1, *r2;  // residual slots: 0 = p.r, 1 = rz, 2 = rz_prev (global memory)
 
   // a slot handle is the pointer itself (selecting among pointers by a run-time index costs scratch memory)
@@ -392,6 +422,11 @@ struct SmallOps {
   }
   __device__ bool aborted() const { return false; }
   __device__ bool leader() const { return true; }
+  __device__ T seq_next(SeqState<T>& seq, T gamma) { return small_seq_next(p, seq, gamma, sm_scal); }
+  bool tracing = false;
+  __device__ void mark(int id) const {
+    if (tracing && threadIdx.x == 0) p.out[32 + id] = (double)wall_clock64();
+  }
 
   // rs[slot] = A v - b ; returns sum r^2 (to every thread)
   __device__ double residual(const T* v, Slot slot) {
@@ -453,8 +488,7 @@ struct SmallOps {
       double acc = 0.0;
       const T* col = p.A + (long long)j * p.ld;
       for (int i = lane; i < p.m; i += 64) acc += (double)col[i] * (double)r[i];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) acc += pg_shfl_xor(acc, off);
+      acc = pg_wave_allreduce<false>(acc);
       if (lane == 0) g_out[j] = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)acc) : (T)acc;
     }
     __syncthreads();
@@ -514,6 +548,7 @@ struct CoopOps {
   const SmallParams<T>& p;
   double* sm_part;
   double* sm_red;
+  double* sm_scal;
   int* sm_flag;
   T* lds_base;  // [3][m_pad] residual slots, then [6][ncol_pad] slices of the n-vectors
   int c0, nc;   // this workgroup's columns [c0, c0 + nc)
@@ -532,6 +567,11 @@ struct CoopOps {
   __device__ __forceinline__ T* vs(Vec v) const { return lds_base + (size_t)3 * p.m_pad + (size_t)v * p.ncol_pad; }
   __device__ bool aborted() const { return dead; }
   __device__ bool leader() const { return blockIdx.x == 0; }
+  __device__ T seq_next(SeqState<T>& seq, T gamma) { return small_seq_next(p, seq, gamma, sm_scal); }
+  bool tracing = false;
+  __device__ void mark(int id) const {
+    if (tracing && blockIdx.x == 0 && threadIdx.x == 0) p.out[32 + id] = (double)wall_clock64();
+  }
 
   __device__ void load_state() {
     for (int h = 0; h < 6; ++h) {
@@ -583,11 +623,13 @@ struct CoopOps {
   template <unsigned MAXMASK>
   __device__ void grid_reduce(double (&v)[4]) {
     small_block_reduce<MAXMASK>(v, sm_red);
+    PG_MARK(*this, 18);
     if (p.W == 1) return;
     double* slot = p.spart + (size_t)(nred & 1) * p.W * 4;
     if (threadIdx.x < 4) st_ag(slot + (size_t)blockIdx.x * 4 + threadIdx.x, v[threadIdx.x]);
     ++nred;
     barrier();
+    PG_MARK(*this, 19);
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = ((MAXMASK >> k) & 1u) ? -INFINITY : 0.0;
     if (dead) return;
@@ -598,11 +640,14 @@ struct CoopOps {
         v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
       }
     }
+    PG_MARK(*this, 20);
     small_block_reduce<MAXMASK>(v, sm_red);
+    PG_MARK(*this, 21);
   }
 
   // pass N over the own columns: partial_w[i] = sum_j A[i, c0 + j] v[j]   (v: LDS slice)
   __device__ void pass_n(const T* v) {
+    PG_MARK(*this, 10);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* part = p.npart + ((size_t)(npass & 1) * p.W + blockIdx.x) * p.m_pad;
     const T* Aj = p.A + (long long)c0 * p.ld;
@@ -630,7 +675,25 @@ struct CoopOps {
       }
     }
     ++npass;
+    PG_MARK(*this, 11);
     barrier();
+    PG_MARK(*this, 12);
+  }
+
+  // sum over the workgroups w0 <= w < w1 of partial_w[i], four loads in flight
+  __device__ __forceinline__ double sum_partials(const double* part, int i, int w0, int w1) const {
+    double t = 0.0;
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
+      const double a0 = ld_ag(part + (size_t)w * p.m_pad + i), a1 = ld_ag(part + (size_t)(w + 1) * p.m_pad + i),
+                   a2 = ld_ag(part + (size_t)(w + 2) * p.m_pad + i), a3 = ld_ag(part + (size_t)(w + 3) * p.m_pad + i);
+      t += a0;
+      t += a1;
+      t += a2;
+      t += a3;
+    }
+    for (; w < w1; ++w) t += ld_ag(part + (size_t)w * p.m_pad + i);
+    return t;
   }
 
   // rs(slot) = sum_w partial_w - b in every workgroup (same order everywhere) ; returns sum r^2
@@ -643,12 +706,8 @@ struct CoopOps {
       if (!dead) {
         const int i0 = blockIdx.x * p.rows_per;
         const int i1 = (i0 + p.rows_per < p.m) ? (i0 + p.rows_per) : p.m;
-        const int nrows = i1 > i0 ? i1 - i0 : 0;
-        for (int i = i0 + (int)threadIdx.x; i < i0 + nrows; i += SMALL_THREADS) {
-          double t = 0.0;
-          for (int w = 0; w < p.W; ++w) t += ld_ag(part + (size_t)w * p.m_pad + i);
-          st_ag(rf + i, (T)(t - (double)p.b[i]));
-        }
+        for (int i = i0 + (int)threadIdx.x; i < i1; i += SMALL_THREADS)
+          st_ag(rf + i, (T)(sum_partials(part, i, 0, p.W) - (double)p.b[i]));
       }
       barrier();
       if (!dead)
@@ -657,11 +716,27 @@ struct CoopOps {
           dst[i] = ri;
           sq += (double)ri * (double)ri;
         }
+    } else if (p.m_pad * 2 <= SMALL_THREADS) {
+      // few rows: Q threads share a row, each summing a contiguous segment of the workgroups; the Q segment sums are
+      // added in segment order through LDS (same order in every workgroup)
+      const int Q = SMALL_THREADS / p.m_pad;  // 2 .. 16, Q * m_pad <= 1024 = the size of sm_part
+      const int q = (int)threadIdx.x / p.m_pad, i = (int)threadIdx.x - q * p.m_pad;
+      const int seg = (p.W + Q - 1) / Q;
+      if (!dead && q < Q && i < p.m) {
+        const int w0 = q * seg, w1 = (w0 + seg < p.W) ? (w0 + seg) : p.W;
+        sm_part[q * p.m_pad + i] = w0 < w1 ? sum_partials(part, i, w0, w1) : 0.0;
+      }
+      __syncthreads();
+      if (!dead && q == 0 && i < p.m) {
+        double t = sm_part[i];
+        for (int qq = 1; qq < Q; ++qq) t += sm_part[qq * p.m_pad + i];
+        const T ri = (T)(t - (double)p.b[i]);
+        dst[i] = ri;
+        sq = (double)ri * (double)ri;
+      }
     } else if (!dead) {
       for (int i = threadIdx.x; i < p.m; i += SMALL_THREADS) {
-        double t = 0.0;
-        for (int w = 0; w < p.W; ++w) t += ld_ag(part + (size_t)w * p.m_pad + i);
-        const T ri = (T)(t - (double)p.b[i]);
+        const T ri = (T)(sum_partials(part, i, 0, p.W) - (double)p.b[i]);
         dst[i] = ri;
         sq += (double)ri * (double)ri;
       }
@@ -681,6 +756,7 @@ struct CoopOps {
     T* xv = vs(x);
     for (int j = threadIdx.x; j < nc; j += SMALL_THREADS) xv[j] = av[j] + beta * (av[j] - cv[j]);
     __syncthreads();
+    PG_MARK(*this, 15);
   }
 
   __device__ double residual_extrap(Vec a, Vec c, T beta, Vec x, Slot slot) {
@@ -711,11 +787,11 @@ struct CoopOps {
       double a = 0.0;
       const T* col = p.A + (long long)(c0 + j) * p.ld;
       for (int i = lane; i < p.m; i += 64) a += (double)col[i] * (double)r[i];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) a += pg_shfl_xor(a, off);
+      a = pg_wave_allreduce<false>(a);
       if (lane == 0) gv[j] = p.lam_ls != T(1) ? (T)(p.lam_ls * (T)a) : (T)a;
     }
     __syncthreads();
+    PG_MARK(*this, 16);
   }
 
   __device__ void adjoint(Slot slot, Vec g) { adjoint_local(slot, g); }
@@ -732,6 +808,7 @@ struct CoopOps {
       zv[j] = zo;
       rv[j] = ro;
     }
+    PG_MARK(*this, 17);
     grid_reduce<0x2u>(acc);
     small_epilogue_out(p, acc, out);
   }
@@ -794,6 +871,10 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
   };
 
   while (!ops.aborted() && !(k >= p.maxit || res_inf / gamma <= p.tol)) {  // ProximalAlgorithms.jl:117 ; fb:125-126
+#ifdef PG_COOP_TRACE
+    ops.tracing = (k == p.k_start + 3);
+#endif
+    PG_MARK(ops, 0);
     if (p.fast) {
       if (p.adaptive) {  // fast_forward_backward.jl:110-129 + fb_tools.jl:24-63
         gamma = gamma * p.increase_gamma;
@@ -817,7 +898,9 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
       } else if (p.has_fixed_gamma) {
         gamma = p.fixed_gamma;  // :131
       }
-      beta = seq_next_hd<T>(p.seq_kind, p.mf, p.seq_p0, p.seq_p1, seq, gamma, T(0));  // :134
+      PG_MARK(ops, 1);
+      beta = ops.seq_next(seq, gamma);  // :134
+      PG_MARK(ops, 2);
       {  // :136 (the extrapolation :135 is formed below from the swapped pair: x = zp + beta (zp - z))
         Vec t = zp;
         zp = z;
@@ -832,12 +915,14 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
         ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, true, zp, z, beta);  // :135, :138-142
       } else {
         f_x = f_scale * (T)ops.residual_extrap(zp, z, beta, x, s_r);  // :135, :138
+        PG_MARK(ops, 3);
         passes += 1;
         rz_valid = false;  // this residual belongs to x, not to z: nothing to reuse next time
         ops.adjoint_epilogue(s_r, x, grad, gamma, y, z, res, e4, false, x, x, T(0));  // :138-142
       }
       passes += 1;
       set_epilogue();
+      PG_MARK(ops, 4);
     } else {
       if (p.adaptive) {  // forward_backward.jl:90-110 ; gradient at z is kept (zp plays grad_f_z)
         gamma = gamma * p.increase_gamma;
@@ -916,7 +1001,8 @@ template <typename T>
 __global__ __launch_bounds__(SMALL_THREADS) void small_solver_kernel(SmallParams<T> p) {
   __shared__ double sm_part[SMALL_WAVES * 64];
   __shared__ double sm_red[SMALL_WAVES * 4];
-  SmallOps<T> ops{p, sm_part, sm_red, p.r, p.buf[6], p.buf[7]};
+  __shared__ double sm_scal[8];
+  SmallOps<T> ops{p, sm_part, sm_red, sm_scal, p.r, p.buf[6], p.buf[7]};
   solver_loop<T, SmallOps<T>>(p, ops);
 }
 
@@ -924,13 +1010,14 @@ template <typename T>
 __global__ __launch_bounds__(SMALL_THREADS) void coop_solver_kernel(SmallParams<T> p) {
   __shared__ double sm_part[SMALL_WAVES * 64];
   __shared__ double sm_red[SMALL_WAVES * 4];
+  __shared__ double sm_scal[8];
   __shared__ int sm_flag;
   extern __shared__ __attribute__((aligned(16))) unsigned char coop_lds[];
   const int c0 = (int)blockIdx.x * p.cols_per;
   int nc = p.n - c0;
   if (nc > p.cols_per) nc = p.cols_per;
   if (nc < 0) nc = 0;
-  CoopOps<T> ops{p, sm_part, sm_red, &sm_flag, reinterpret_cast<T*>(coop_lds), c0, nc, 0ull, 0, 0, false};
+  CoopOps<T> ops{p, sm_part, sm_red, sm_scal, &sm_flag, reinterpret_cast<T*>(coop_lds), c0, nc, 0ull, 0, 0, false};
   ops.load_state();
   solver_loop<T, CoopOps<T>>(p, ops);
 }
@@ -982,7 +1069,7 @@ void small_fill_params(pg_iter* it, SmallParams<T>& p, void* (&bufs)[8], int64_t
 pg_status small_result_block(pg_ctx* c) {
   if (!c->small_out) {
     double* host = nullptr;
-    PG_HIP(hipHostMalloc((void**)&host, sizeof(double) * 32, hipHostMallocMapped));
+    PG_HIP(hipHostMalloc((void**)&host, sizeof(double) * SMALL_OUT_DOUBLES, hipHostMallocMapped));
     c->small_out_host = host;
     PG_HIP(hipHostGetDevicePointer((void**)&c->small_out, host, 0));
   }
@@ -1040,7 +1127,7 @@ pg_status iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double tol
   return PG_OK;
 }
 
-// cooperative multi-workgroup variant; blocks <= 0: chosen from the size of A (about 32 KiB of A per workgroup and pass)
+// cooperative multi-workgroup variant; blocks <= 0: chosen from the size of A
 constexpr int64_t COOP_MAX_LDS = 128 * 1024;  // three residual vectors + six n-vector slices per workgroup
 
 template <typename T>
@@ -1056,8 +1143,10 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
   p.nrb = p.m_pad / 64;
   int W = blocks;
   if (W <= 0) {
-    const int64_t bytes = A->m * A->n * (int64_t)sizeof(T);
-    W = (int)((bytes + 32767) / 32768);
+    // barrier and combination costs grow with the grid, the per-workgroup GEMV work shrinks with it: measured optima
+    // sit near sqrt(bytes of A / 1 KiB) workgroups (28 for 200x500 f64, ~40 for 500x1000 f64)
+    const double kib = (double)(A->m * A->n * (int64_t)sizeof(T)) / 1024.0;
+    W = (int)std::lround(std::sqrt(kib));
   }
   if (W > c->num_cu) W = c->num_cu;  // one workgroup per CU: all of them are resident, the grid barrier cannot starve
   if ((int64_t)W > A->n) W = (int)A->n;
@@ -1125,6 +1214,20 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
             p.m, p.n, W, p.cols_per, p.two_stage, its, o[25] * 0.01 / (its > 0 ? its : 1), o[27] / (its > 0 ? its : 1),
             o[27] > 0 ? o[26] * 0.01 / o[27] : 0.0, o[25] > 0 ? 100.0 * o[26] / o[25] : 0.0);
   }
+#ifdef PG_COOP_TRACE
+  {
+    const double* o = c->small_out_host + 32;
+    const char* names[22] = {"loop top", "before seq", "after seq", "after residual_extrap", "after adjoint_epilogue", "", "", "", "", "",
+                             "pass_n entry", "pass_n stored", "pass_n barrier done", "combine loaded", "combine reduced", "extrapolated",
+                             "adjoint done", "epilogue local done", "reduce: block", "reduce: barrier done", "reduce: loaded", "reduce: done"};
+    const int order[] = {0, 1, 2, 15, 10, 11, 12, 13, 14, 3, 16, 17, 18, 19, 20, 21, 4};
+    double prev = o[0];
+    for (int q : order) {
+      fprintf(stderr, "[pg coop trace] %-24s +%7.2f us (t = %8.2f)\n", names[q], (o[q] - prev) * 0.01, (o[q] - o[0]) * 0.01);
+      prev = o[q];
+    }
+  }
+#endif
   if (c->small_out_host[24] != 0.0) {
     pg_set_error("the cooperative solver gave up at a grid barrier (a workgroup did not arrive)");
     return PG_ERR_HIP;

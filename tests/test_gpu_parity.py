@@ -1204,10 +1204,17 @@ def test_device_loop_option_same_answers(pa, dtype):
         assert abs(k_d - k_h) <= (0 if dtype == np.float64 else 2)
         assert np.max(np.abs(x_d - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL
         assert np.max(np.abs(x_d - x_h)) <= 1e-4
-    # a larger problem takes the in-library loop (batched when the step is fixed)
-    A2, b2, lam2 = synthetic_problem(300, 900, dtype, seed=21)
-    Lf2 = dtype(power_Lf(A2))
-    f2, g2 = pa.LeastSquares(A2, b2), pa.NormL1(lam2)
-    x_h, k_h = pa.FastForwardBackward(tol=1e-4)(x0=np.zeros(900, dtype), f=f2, g=g2, Lf=Lf2)
-    x_d, k_d = pa.FastForwardBackward(tol=1e-4, device_loop=True, check_every=8)(x0=np.zeros(900, dtype), f=f2, g=g2, Lf=Lf2)
-    assert k_h <= k_d < k_h + 8 and np.max(np.abs(x_d - x_h)) <= 1e-3
+    # a cache-resident problem takes the cooperative kernel (same k), a larger one the in-library loop (batched when
+    # the step is fixed: k rounded up to the batch)
+    for (m2, n2, slack) in ((300, 900, 1), (1500, 2500, 8)):
+        A2, b2, lam2 = synthetic_problem(m2, n2, dtype, seed=21)
+        Lf2 = dtype(power_Lf(A2))
+        f2, g2 = pa.LeastSquares(A2, b2), pa.NormL1(lam2)
+        x_h, k_h = pa.FastForwardBackward(tol=1e-4)(x0=np.zeros(n2, dtype), f=f2, g=g2, Lf=Lf2)
+        x_d, k_d = pa.FastForwardBackward(tol=1e-4, device_loop=True, check_every=8)(x0=np.zeros(n2, dtype), f=f2, g=g2, Lf=Lf2)
+        # (FFB residuals are not monotone: a batched run may pass over the first k that satisfies the rule)
+        assert k_h - 1 <= k_d and (k_d < k_h + slack + 1 or (slack > 1 and (k_d - 1) % 8 == 0)), (m2, n2, k_h, k_d)
+        assert np.max(np.abs(x_d - x_h)) <= 1e-3
+        x_a, k_a = pa.FastForwardBackward(tol=1e-4)(x0=np.zeros(n2, dtype), f=f2, g=g2)
+        x_b, k_b = pa.FastForwardBackward(tol=1e-4, device_loop=True)(x0=np.zeros(n2, dtype), f=f2, g=g2)
+        assert abs(k_a - k_b) <= (0 if dtype == np.float64 else max(2, k_a // 50)) and np.max(np.abs(x_a - x_b)) <= 1e-3
