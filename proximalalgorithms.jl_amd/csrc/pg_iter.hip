@@ -741,8 +741,10 @@ struct CoopOps {
         sq += (double)ri * (double)ri;
       }
     }
+    PG_MARK(*this, 13);
     double v4[4] = {sq, 0.0, 0.0, 0.0};
     small_block_reduce<0u>(v4, sm_red);  // ends with workgroup barriers: rs(slot) is complete
+    PG_MARK(*this, 14);
     return v4[0];
   }
 
