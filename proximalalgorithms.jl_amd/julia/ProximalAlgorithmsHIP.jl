@@ -254,7 +254,49 @@ HIPForwardBackward(; maxit = 10_000, tol = 1e-8, stop = (iter, state) -> default
     ProximalAlgorithms.IterativeAlgorithm(HIPForwardBackwardIteration; maxit, stop, solution, verbose, freq, display, kwargs...)
 HIPFastForwardBackward(; kwargs...) = HIPForwardBackward(; fast = true, kwargs...)
 
+# The driver loop of ProximalAlgorithms.jl:114-123 with the default stopping rule, inside the library: no host round
+# trip per iteration.  Launch-bound sizes run as ONE kernel launch (pg_iter_run_small: one workgroup;
+# pg_iter_run_coop: cooperating workgroups with grid barriers while A is cache-resident); larger problems use the
+# streaming kernels (pg_iter_run).  Returns (solution, k) like IterativeAlgorithm.
+function hip_solve(iter::HIPForwardBackwardIteration{R}; maxit = 10_000, tol = 1e-8) where {R}
+    st, _ = iterate(iter)                                  # k = 1 (the state after init)
+    A = iter.f.A
+    T = eltype(iter.x0)
+    nbytes = A.m * A.n * sizeof(T)
+    k = Ref{Int64}(0)
+    sc = Ref{PgIterScalars}()
+    if A.m * A.n <= 8192
+        check(ccall((:pg_iter_run_small, libpg), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Ref{Int64}, Ref{PgIterScalars}),
+                    st.handle, 1, maxit, tol, k, sc))
+    elseif 3 * cld(A.m, 64) * 64 * sizeof(T) <= 96 * 1024 && nbytes <= (iter.adaptive ? 16 : 6) << 20
+        check(ccall((:pg_iter_run_coop, libpg), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Int32, Ref{Int64}, Ref{PgIterScalars}),
+                    st.handle, 1, maxit, tol, 0, k, sc))
+    else
+        check(ccall((:pg_iter_run, libpg), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Ref{Int64}, Ref{PgIterScalars}),
+                    st.handle, 1, maxit, tol, k, sc))
+    end
+    refresh!(st, sc[], A.ctx, st.x.n)
+    return Array(st.z), Int(k[])
+end
+
+# DouglasRachford on a separable quadratic + box / L1 (douglas_rachford.jl:53-70): the whole loop in the library,
+# 16 iterations per HBM sweep (pg_dr_run); d, q: scalars or HIPVectors; g: HIPIndBox / HIPNormL1.
+function hip_douglas_rachford(d, q, g, x0::Vector{T}; gamma, maxit = 1_000, tol = 1e-8, ctx = default_ctx()) where {T}
+    x, x_alt, y = HIPVector(x0; ctx), HIPVector{T}(undef, length(x0); ctx), HIPVector{T}(undef, length(x0); ctx)
+    vecptr(v) = v isa HIPVector ? v.ptr : C_NULL
+    scal(v) = v isa HIPVector ? 0.0 : Float64(v)
+    kind, p0, p1 = g_spec(g)
+    k = Ref{Int64}(0)
+    sc = zeros(Float64, 3)
+    check(ccall((:pg_dr_run, libpg), Int32,
+                (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64,
+                 Ptr{Cvoid}, Float64, Int32, Float64, Float64, Float64, Float64, Int64, Int32, Ref{Int64}, Ptr{Float64}),
+                ctx.handle, pg_dtype(T), length(x0), x.ptr, x_alt.ptr, y.ptr, C_NULL, C_NULL, C_NULL, vecptr(d), scal(d),
+                vecptr(q), scal(q), kind, p0, p1, Float64(gamma), Float64(tol), maxit, 16, k, sc))
+    return Array(y), Int(k[])                              # solution = state.y (douglas_rachford.jl:70)
+end
+
 export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
-       HIPForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward
+       HIPForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve, hip_douglas_rachford
 
 end # module
