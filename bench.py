@@ -98,14 +98,23 @@ def cpu_baseline(m, n, sample_cols, steps, seed):
         next(it)
     dt = time.perf_counter() - t0
     its_sample = steps / dt
+    one_thread = None
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
 
         cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+        # the single-thread figure (the reference's runbenchmarks.jl pins BLAS to one thread)
+        with threadpool_limits(limits=1, user_api="blas"):
+            s1 = max(2, steps // 5)
+            t0 = time.perf_counter()
+            for _ in range(s1):
+                next(it)
+            one_thread = s1 / (time.perf_counter() - t0) * ns / n
     except Exception:
         cores = os.cpu_count() or 1
     return {
         "value": its_sample * ns / n,
+        "value_1thread": one_thread,
         "unit": "it/s",
         "cores": int(cores),
         "kind": "port",
