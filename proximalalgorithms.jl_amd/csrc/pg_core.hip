@@ -342,14 +342,29 @@ pg_status pg_mat_destroy(pg_mat* A) {
   return PG_OK;
 }
 
+// host <-> device copy of the matrix body: one linear copy per 1 GiB when both sides are dense in the leading dimension
+// (the headline matrix is 64 GiB; a 2-D copy of 2^20 "rows" is needlessly slow), a 2-D copy otherwise
+static pg_status mat_copy(pg_mat* A, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, hipMemcpyKind kind) {
+  const size_t es = pg_sizeof(A->dtype), width = (size_t)A->m * es;
+  if (dst_pitch == width && src_pitch == width) {
+    const size_t total = width * (size_t)A->n, chunk = (size_t)1 << 30;
+    for (size_t off = 0; off < total; off += chunk) {
+      const size_t nb = total - off < chunk ? total - off : chunk;
+      PG_HIP(hipMemcpyAsync((char*)dst + off, (const char*)src + off, nb, kind, A->ctx->stream));
+    }
+    return PG_OK;
+  }
+  PG_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, (size_t)A->n, kind, A->ctx->stream));
+  return PG_OK;
+}
+
 pg_status pg_mat_upload(pg_mat* A, const void* host, int64_t ld_host) {
   PG_REQUIRE(A != nullptr, "matrix is null");
   if (A->m == 0 || A->n == 0) return PG_OK;
   PG_REQUIRE(host != nullptr, "host pointer is null");
   PG_REQUIRE(ld_host >= A->m, "ld_host < m");
   const size_t es = pg_sizeof(A->dtype);
-  PG_HIP(hipMemcpy2DAsync(A->data, (size_t)A->ld * es, host, (size_t)ld_host * es, (size_t)A->m * es,
-                          (size_t)A->n, hipMemcpyHostToDevice, A->ctx->stream));
+  PG_TRY(mat_copy(A, A->data, (size_t)A->ld * es, host, (size_t)ld_host * es, hipMemcpyHostToDevice));
   PG_HIP(hipStreamSynchronize(A->ctx->stream));
   return PG_OK;
 }
@@ -371,8 +386,7 @@ pg_status pg_mat_download(pg_mat* A, void* host, int64_t ld_host) {
   PG_REQUIRE(host != nullptr, "host pointer is null");
   PG_REQUIRE(ld_host >= A->m, "ld_host < m");
   const size_t es = pg_sizeof(A->dtype);
-  PG_HIP(hipMemcpy2DAsync(host, (size_t)ld_host * es, A->data, (size_t)A->ld * es, (size_t)A->m * es,
-                          (size_t)A->n, hipMemcpyDeviceToHost, A->ctx->stream));
+  PG_TRY(mat_copy(A, host, (size_t)ld_host * es, A->data, (size_t)A->ld * es, hipMemcpyDeviceToHost));
   PG_HIP(hipStreamSynchronize(A->ctx->stream));
   return PG_OK;
 }
