@@ -51,6 +51,8 @@ def parse_args():
     p.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="working precision (BASELINE metric: f32)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline", choices=["auto", "full", "sample"], default="auto",
+                   help="CPU leg on the downloaded full matrix (when host memory allows) or on a column sample")
     p.add_argument("--cpu-sample-cols", type=int, default=16384)
     p.add_argument("--cpu-steps", type=int, default=10)
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -69,6 +71,62 @@ def parse_args():
     p.add_argument("--share-device", action="store_true",
                    help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
     return p.parse_args()
+
+
+def _host_memory_limit():
+    """Bytes this process may use: the cgroup limit when there is one, else MemAvailable."""
+    lim = None
+    try:
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v != "max":
+            lim = int(v)
+    except Exception:
+        pass
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+                lim = avail if lim is None else min(lim, avail)
+    except Exception:
+        pass
+    return lim
+
+
+def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
+    """The SAME workload on the host cores: the device matrix is copied to host memory (a few seconds over PCIe) and the
+    oracle (numpy/OpenBLAS restatement of the reference's op sequence) steps on it for at most `budget_s` seconds."""
+    import numpy as np
+
+    from oracle import proxgrad_oracle as o
+
+    t0 = time.perf_counter()
+    A = A_dev.numpy()
+    b = b_dev.numpy()
+    t_dl = time.perf_counter() - t0
+    m, n = A.shape
+    it = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(n, A.dtype), Lf=Lf))
+    next(it)  # init (two passes), untimed like the GPU side
+    steps, t0 = 0, time.perf_counter()
+    while steps < max_steps and (steps < 2 or time.perf_counter() - t0 < budget_s):
+        next(it)
+        steps += 1
+    dt = time.perf_counter() - t0
+    one_thread = None
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+
+        cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {
+        "value": steps / dt,
+        "value_1thread": one_thread,
+        "unit": "it/s",
+        "cores": int(cores),
+        "kind": "port",
+        "sample": f"the full workload: oracle FFB fixed-step on the downloaded {m}x{n} {A.dtype.name} matrix "
+                  f"({A.nbytes / 2**30:.1f} GiB, copied to the host in {t_dl:.1f} s), {steps} iterations in {dt:.1f} s",
+    }
 
 
 def cpu_baseline(m, n, sample_cols, steps, seed):
@@ -277,7 +335,16 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(m_glob, n, args.cpu_sample_cols, args.cpu_steps, args.seed)
+            # the whole matrix when the host can hold it (3x headroom), else a column sample scaled linearly in n
+            need = 3 * m_glob * n * es
+            lim = _host_memory_limit()
+            if args.cpu_baseline == "full" or (args.cpu_baseline == "auto" and lim is not None and lim >= need):
+                cpu = cpu_baseline_full(A, b, lam, Lf)
+                # single-thread figure from the column sample (a one-thread pass over the whole matrix takes too long)
+                cpu["value_1thread"] = cpu_baseline(m_glob, n, args.cpu_sample_cols, max(2, args.cpu_steps // 2),
+                                                    args.seed)["value_1thread"]
+            else:
+                cpu = cpu_baseline(m_glob, n, args.cpu_sample_cols, args.cpu_steps, args.seed)
         line = {
             "metric": "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, %s)" % (m_glob, n, args.dtype),
             "value": round(its, 4),
