@@ -503,13 +503,13 @@ def test_nccl_world_size_one(pa):
 # ------------------------------------------------------------------------------------------------
 
 
-def _run_bench(extra, nproc=1, port=29641):
+def _run_bench(extra, nproc=1, port=29641, cpu_baseline=False):
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--workload", "small", "--steps", "12", "--warmup", "2", "--no-cpu-baseline"] + extra
+    common = ["--workload", "small", "--steps", "12", "--warmup", "2"] + ([] if cpu_baseline else ["--no-cpu-baseline"]) + extra
     if nproc == 1:
         cmd = [sys.executable, os.path.join(root, "bench.py")] + common
     else:
@@ -517,8 +517,30 @@ def _run_bench(extra, nproc=1, port=29641):
                "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc)] + common
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    return json.loads(line)
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, lines  # stdout carries exactly the one JSON line (library banners go to stderr)
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("cpu_mode", ["full", "sample"])
+def test_bench_line_contract(pa, cpu_mode):
+    """bench.py's driver-facing contract: ONE JSON line with the agreed keys, the roofline object measured from HIP
+    events of the dominant GEMV kernel, and the CPU leg (full downloaded matrix / column sample)."""
+    d = _run_bench(["--cpu-baseline", cpu_mode, "--cpu-steps", "4"], cpu_baseline=True)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "it/s" and d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] in ("gemv_t", "gemv_n_partial")
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3) and 0 < r["frac"] < 1
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-2)
+    assert r["launches"] == 12 and r["traffic"] is None  # PMC traffic is only quoted for the workload it was measured on
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "it/s" and c["cores"] >= 1 and c["value"] > 0
+    assert ("full workload" in c["sample"]) == (cpu_mode == "full")
 
 
 @pytest.mark.parametrize("mode,overlap", [("fixed", False), ("adaptive", False), ("fixed", True)])
