@@ -1264,3 +1264,20 @@ def test_fuzz_differential_against_oracle(pa):
         if fails:
             bad.append((desc, fails))
     assert not bad, bad
+
+
+def test_fuzz_newton_type_and_douglas_rachford(pa):
+    """scripts/fuzz_newton.py: PANOC / ZeroFPR / PANOCplus (objective-level agreement with the CPU restatement) and
+    DouglasRachford (bit-identical y and k for host stepping and the 1 / 8 / 16-iterations-per-sweep loops)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_newton", os.path.join(root, "scripts", "fuzz_newton.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = []
+    for seed in range(5000, 5060):
+        desc, fails = fz.one_case(seed)
+        if fails:
+            bad.append((desc, fails))
+    assert not bad, bad
