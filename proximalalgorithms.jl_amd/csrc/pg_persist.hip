@@ -332,7 +332,9 @@ struct CoopOps {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (p.W == 1 || dead) return;
+#ifdef PG_COOP_TRACE
     const long long t_in = wall_clock64();
+#endif
     bar_target += (unsigned long long)p.W;
     if (threadIdx.x == 0) {
       __hip_atomic_fetch_add(p.bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -352,8 +354,10 @@ struct CoopOps {
     }
     __syncthreads();
     if (*sm_flag == 0) dead = true;
+#ifdef PG_COOP_TRACE
     t_bar += wall_clock64() - t_in;
     n_bar += 1;
+#endif
   }
 
   // grid-wide reduction of 4 doubles: block partial -> global slot -> barrier -> every workgroup sums the W partials in
@@ -594,7 +598,9 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
   long long k = p.k_start, nbt_total = 0, passes = 0;
   int flags = 0;
   bool rz_valid = false;
+#ifdef PG_COOP_TRACE
   const long long t_begin = wall_clock64();
+#endif
   const T eps = sizeof(T) == 4 ? (T)1.1920928955078125e-07 : (T)2.220446049250313e-16;
   const T f_scale = (T)0.5 * p.lam_ls;
   double e4[4];
@@ -731,9 +737,13 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
     o[22] = (double)passes;
     o[23] = rz_valid ? 1.0 : 0.0;
     o[24] = ops.aborted() ? 1.0 : 0.0;
+#ifdef PG_COOP_TRACE
     o[25] = (double)(wall_clock64() - t_begin);  // telemetry (100 MHz ticks): whole loop, inside grid barriers, count
     o[26] = ops.barrier_ticks();
     o[27] = ops.barrier_count();
+#else
+    o[25] = o[26] = o[27] = 0.0;
+#endif
   }
 }
 
@@ -947,6 +957,7 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
   }
   PG_HIP(hipStreamSynchronize(c->stream));
   small_read_result(it, bufs, k_out);
+#ifdef PG_COOP_TRACE
   if (getenv("PG_COOP_VERBOSE")) {
     const double* o = c->small_out_host;
     const double its = (double)(*k_out - k_start);
@@ -954,7 +965,6 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
             p.m, p.n, W, p.cols_per, p.two_stage, its, o[25] * 0.01 / (its > 0 ? its : 1), o[27] / (its > 0 ? its : 1),
             o[27] > 0 ? o[26] * 0.01 / o[27] : 0.0, o[25] > 0 ? 100.0 * o[26] / o[25] : 0.0);
   }
-#ifdef PG_COOP_TRACE
   {
     const double* o = c->small_out_host + 32;
     const char* names[22] = {"loop top", "before seq", "after seq", "after residual_extrap", "after adjoint_epilogue", "", "", "", "", "",
