@@ -51,6 +51,8 @@ def parse_args():
     p.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="working precision (BASELINE metric: f32)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--kernel-events", choices=["gemv", "all", "none"], default="gemv",
+                   help="which kernels are bracketed by HIP event pairs in the timed region (none: no roofline object)")
     p.add_argument("--cpu-baseline", choices=["auto", "full", "sample"], default="auto",
                    help="CPU leg on the downloaded full matrix (when host memory allows) or on a column sample")
     p.add_argument("--cpu-sample-cols", type=int, default=16384)
@@ -272,7 +274,9 @@ def main():
         state = next(it)
         stop_rule(state)
     passes0 = iteration.counters.get("a_passes", 0)
-    ctx.profile(True)
+    # HIP event pairs around the two GEMV kernels only: each pair is a marker packet on the stream, and the roofline
+    # leg needs nothing else
+    ctx.profile(args.kernel_events != "none", kernels=None if args.kernel_events == "all" else ("gemv_n_partial", "gemv_t"))
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()

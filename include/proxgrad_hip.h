@@ -120,6 +120,9 @@ enum {
   PG_K_COUNT = 6
 };
 pg_status pg_ctx_profile_enable(pg_ctx* ctx, int32_t enable);
+/* Restrict the event pairs to a set of kernels (bit k = kernel k of the enum above; default all): every pair is a
+ * marker packet on the stream, so timing only the kernels of interest perturbs a short iteration less. */
+pg_status pg_ctx_profile_select(pg_ctx* ctx, uint32_t kernel_mask);
 pg_status pg_ctx_profile_reset(pg_ctx* ctx);
 pg_status pg_ctx_profile_read(pg_ctx* ctx, int32_t kernel, int64_t* launches, double* total_ms);
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pg_ctx_sync": [_vp],
     "pg_ctx_device_info": [_vp, C.POINTER(pg_device_info)],
     "pg_ctx_profile_enable": [_vp, _i32],
+    "pg_ctx_profile_select": [_vp, C.c_uint32],
     "pg_ctx_profile_reset": [_vp],
     "pg_ctx_profile_read": [_vp, _i32, C.POINTER(_i64), _pf64],
     "pg_malloc": [_vp, _sz, C.POINTER(_vp)],

@@ -109,6 +109,12 @@ pg_status pg_ctx_profile_enable(pg_ctx* c, int32_t enable) {
   return PG_OK;
 }
 
+pg_status pg_ctx_profile_select(pg_ctx* c, uint32_t kind_mask) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  c->prof_mask = kind_mask;
+  return PG_OK;
+}
+
 pg_status pg_ctx_profile_reset(pg_ctx* c) {
   PG_REQUIRE(c != nullptr, "ctx is null");
   PG_HIP(hipStreamSynchronize(c->stream));
@@ -218,7 +224,7 @@ static hipEvent_t prof_get_event(pg_ctx* c) {
 }
 
 pg_prof_scope::pg_prof_scope(pg_ctx* ctx, int k) : c(ctx), kind(k) {
-  if (!c->profiling) return;
+  if (!c->profiling || !((c->prof_mask >> k) & 1u)) return;
   start = prof_get_event(c);
   stop = prof_get_event(c);
   if (start && stop) (void)hipEventRecord(start, c->stream);

@@ -99,6 +99,7 @@ struct pg_ctx {
   size_t coop_ws_bytes = 0;
   // event-pair kernel timing (pg_ctx_profile_*)
   bool profiling = false;
+  uint32_t prof_mask = 0xFFFFFFFFu;  // kernel kinds that get an event pair while profiling (pg_ctx_profile_select)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[PG_K_COUNT];
   std::vector<hipEvent_t> prof_pool;
 };

@@ -57,7 +57,15 @@ class Context:
                 "lds_bytes_per_cu": info.lds_bytes_per_cu, "global_mem_bytes": info.global_mem_bytes,
                 "clock_khz": info.clock_khz, "arch": info.arch.decode(), "name": info.name.decode()}
 
-    def profile(self, enable=True):
+    def profile(self, enable=True, kernels=None):
+        """Bracket kernel launches with HIP event pairs; ``kernels``: names from _lib.KERNEL_NAMES to restrict the
+        pairs to (every pair is a marker packet on the stream), default all."""
+        mask = 0xFFFFFFFF
+        if kernels is not None:
+            mask = 0
+            for name in kernels:
+                mask |= 1 << _lib.KERNEL_NAMES.index(name)
+        call("pg_ctx_profile_select", self._h, mask)
         call("pg_ctx_profile_enable", self._h, 1 if enable else 0)
 
     def profile_reset(self):
