@@ -50,6 +50,9 @@ def parse_args():
     p.add_argument("--mode", choices=["fixed", "adaptive"], default="fixed")
     p.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="working precision (BASELINE metric: f32)")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--sweeps", choices=["one", "two"], default="one",
+                   help="one: the single-sweep iteration (A read once per iteration; single GPU) -- two: A x and A' r as "
+                        "separate sweeps like the reference (always the case when rows are sharded)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel-events", choices=["gemv", "all", "none"], default="gemv",
                    help="which kernels are bracketed by HIP event pairs in the timed region (none: no roofline object)")
@@ -260,7 +263,7 @@ def main():
     ctx.sync()
     t_setup = time.perf_counter() - t_setup
 
-    iteration = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=zero_n, Lf=Lf)
+    iteration = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=zero_n, Lf=Lf, single_sweep=args.sweeps == "one")
     it = iter(iteration)
     state = next(it)  # init (k = 1)
     stop_rule = lambda s: float(s.res_inf) / float(s.gamma) <= 1e-6  # benchmarks.jl:57 (evaluated, not acted on)
@@ -276,7 +279,8 @@ def main():
     passes0 = iteration.counters.get("a_passes", 0)
     # HIP event pairs around the two GEMV kernels only: each pair is a marker packet on the stream, and the roofline
     # leg needs nothing else
-    ctx.profile(args.kernel_events != "none", kernels=None if args.kernel_events == "all" else ("gemv_n_partial", "gemv_t"))
+    ctx.profile(args.kernel_events != "none",
+                kernels=None if args.kernel_events == "all" else ("gemv_n_partial", "gemv_t", "gemv_tn"))
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -296,17 +300,24 @@ def main():
 
     its = args.steps / elapsed
     es = 4 if args.dtype == "f32" else 8
-    bytes_iter_local = a_passes / max(args.steps, 1) * m_loc * n * es + 10 * n * es + 3 * m_loc * es
-    # dominant kernel = the slower GEMV pass; algorithmic bytes of one launch = the local A block + vectors
+    sweeps = a_passes / max(args.steps, 1)  # reads of A per iteration actually executed
+    # the algorithmic figure counts the passes the mode REQUIRES when A x and A' r are separate sweeps (2 for
+    # fixed-step FB / FFB and for adaptive FFB with the residual pair); the single-sweep iteration moves fewer bytes --
+    # both are reported, labelled
+    passes_alg = max(2.0, sweeps) if args.sweeps == "two" or world > 1 else 2.0
+    bytes_iter_local = passes_alg * m_loc * n * es + 10 * n * es + 3 * m_loc * es
+    bytes_moved_local = sweeps * m_loc * n * es + 10 * n * es + 3 * m_loc * es
+    # dominant kernel = the slowest sweep over A; algorithmic bytes of one launch = the local A block + its vectors
     kern = {}
     n_cnt = prof["gemv_n_partial"][0]
-    for name, vec_bytes in (("gemv_n_partial", n * es), ("gemv_t", m_loc * es + n * es)):
+    for name, vec_bytes in (("gemv_n_partial", n * es), ("gemv_t", m_loc * es + n * es),
+                            ("gemv_tn", (m_loc + 7 * n) * es)):
         cnt, ms = prof[name]
         if cnt:
             avg_ms = ms / cnt
             # with a collective attached pass T runs as several column-chunk launches per evaluation
             # (pg_gemv.hip ls_grad_stage_t): one launch then covers 1/chunks of the local block
-            evals = max(a_passes - n_cnt, 1) if name == "gemv_t" else cnt
+            evals = max(a_passes - n_cnt - prof["gemv_tn"][0], 1) if name == "gemv_t" else cnt
             launch_bytes = (m_loc * n * es + vec_bytes) * evals / cnt
             kern[name] = {"launches": cnt, "avg_ms": avg_ms, "bytes": launch_bytes,
                           "launches_per_pass": cnt / evals, "GBps": launch_bytes / (avg_ms * 1e-3) / 1e9}
@@ -334,7 +345,11 @@ def main():
                                    for k_, v in kern.items()},
                     "whole_iteration": {"algorithmic_bytes_per_gpu": int(bytes_iter_local),
                                         "GBps_per_gpu": round(bytes_iter_local * its / 1e9, 1),
-                                        "frac": round(bytes_iter_local * its / 1e9 / HBM_PEAK_GBS, 4)}}
+                                        "frac": round(bytes_iter_local * its / 1e9 / HBM_PEAK_GBS, 4),
+                                        "sweeps_of_A_per_iteration": round(sweeps, 3),
+                                        "hbm_bytes_moved_per_gpu": int(bytes_moved_local),
+                                        "hbm_GBps_moved_per_gpu": round(bytes_moved_local * its / 1e9, 1),
+                                        "frac_of_bytes_moved": round(bytes_moved_local * its / 1e9 / HBM_PEAK_GBS, 4)}}
 
     if rank == 0:
         cpu = None
@@ -366,7 +381,8 @@ def main():
                                    % (m_glob, n, "Float32" if args.dtype == "f32" else "Float64", args.mode, world),
                        "m": m_glob, "n": n, "mode": args.mode, "row_shards": world, "m_per_gpu": m_loc,
                        "lambda": float(lam), "Lf": float(Lf) if Lf is not None else None, "seed": args.seed,
-                       "a_passes_per_step": a_passes / max(args.steps, 1), "setup_s": round(t_setup, 2),
+                       "a_passes_per_step": a_passes / max(args.steps, 1), "sweeps": args.sweeps if world == 1 else "two",
+                       "setup_s": round(t_setup, 2),
                        "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
                                  "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
             "roofline": roofline,

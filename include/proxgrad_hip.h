@@ -117,7 +117,7 @@ pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
  * returns the launch count and summed duration since the last reset. */
 enum {
   PG_K_GEMV_N = 0, PG_K_GEMV_N_FINISH = 1, PG_K_GEMV_T = 2, PG_K_EPILOGUE = 3, PG_K_EXTRAPOLATE = 4, PG_K_DR_STEP = 5,
-  PG_K_COUNT = 6
+  PG_K_GEMV_TN = 6, PG_K_COUNT = 7
 };
 pg_status pg_ctx_profile_enable(pg_ctx* ctx, int32_t enable);
 /* Restrict the event pairs to a set of kernels (bit k = kernel k of the enum above; default all): every pair is a
@@ -166,6 +166,17 @@ pg_status pg_ls_value(pg_ls* f, const void* x, double* f_out);
 pg_status pg_ls_gradient(pg_ls* f, void* grad_out, const void* x, double* f_out);
 /* r = A x - b of the last evaluation (device m-vector, library-owned; valid until next call) */
 pg_status pg_ls_residual_ptr(pg_ls* f, const void** r_out);
+/* ONE sweep over A for a whole proximal-gradient iteration (benchmarks.jl:16 `f.A' * res`, forward_backward.jl:117-120 /
+ * fast_forward_backward.jl:140-142, then :135 and benchmarks.jl:15 of the NEXT iteration): with the residual held by f
+ * being that of x (last pg_ls_value / pg_ls_value_and_gradient / pg_ls_fused_pass evaluation),
+ *   grad = lam A' r ; y = x - gamma grad ; z_new = prox_{gamma g}(y) ; res = x - z_new ;
+ *   v_next = z_new + beta (z_new - z_old) ; f's residual := A v_next - b.
+ * A column's contribution to A v_next is accumulated while the column is still in registers, so A is read once.
+ * Unsharded operators with m <= 32768 (f32) / 16384 (f64) rows; PG_ERR_UNSUPPORTED otherwise.
+ * scalars_out (host, may be NULL) = { f(v_next), g(z_new), norm(res, Inf), dot(grad, res), norm(res)^2 }. */
+pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,
+                           double g_p0, double g_p1, void* grad, void* y, void* z_new, void* res, void* v_next,
+                           double* scalars_out);
 
 /* ------------------------------------------------------------------ prox operators ------ */
 /* ProximalCore.prox!(y, g::NormL1, x, gamma) -> g(y) : y_i = sign(x_i) max(|x_i| - gamma lam, 0),
@@ -255,6 +266,11 @@ typedef struct pg_iter_opts {
   int32_t reuse_residual; /* FFB adaptive: 1 (default) = form A x - b at the extrapolated point from the residuals
                           * the line search already holds, (1+beta)(A z - b) - beta (A z_prev - b): 2 passes over A per
                           * iteration instead of 3 (the reference does 4); 0 = recompute A x like the reference */
+  int32_t single_sweep;  /* 1 (default) = iterate with ONE read of A per iteration where the operator allows it
+                          * (pg_ls_fused_pass: unsharded, m <= 32768 f32 / 16384 f64 rows; FB / FFB with a fixed step, FFB
+                          * with the adaptive step and reuse_residual): the sweep that forms A' r also applies the prox
+                          * to each finished column and accumulates the NEXT residual from it while it is in registers.
+                          * Same iterates up to summation order.  0 = two sweeps (A x, then A' r) like the reference. */
 } pg_iter_opts;
 
 /* the scalar part of ForwardBackwardState / FastForwardBackwardState plus line-search telemetry */

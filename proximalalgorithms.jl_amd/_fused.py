@@ -10,7 +10,7 @@ from .device import HIPVector
 
 class FusedIteration:
     def __init__(self, f, g, *, fast, Lf, gamma, adaptive, minimum_gamma, reduce_gamma, increase_gamma, mf=0.0,
-                 seq_kind=_lib.PG_SEQ_ADAPTIVE, seq_p0=0.0, seq_p1=0.0, reuse_residual=True):
+                 seq_kind=_lib.PG_SEQ_ADAPTIVE, seq_p0=0.0, seq_p1=0.0, reuse_residual=True, single_sweep=True):
         self.f, self.g = f, g
         self.ctx = f.ctx
         o = _lib.pg_iter_opts()
@@ -28,6 +28,7 @@ class FusedIteration:
         o.g_kind = g.g_kind
         o.g_p0, o.g_p1 = g.g_params()
         o.reuse_residual = 1 if reuse_residual else 0
+        o.single_sweep = 1 if single_sweep else 0
         self.opts = o
         h = C.c_void_p()
         call("pg_iter_create", self.ctx.handle, f.handle, C.byref(o), C.byref(h))

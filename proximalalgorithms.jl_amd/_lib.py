@@ -11,7 +11,7 @@ PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX = 0, 1, 2
 PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST = 0, 1, 2, 3, 4
 PG_FLAG_GAMMA_TOO_SMALL = 1
 PG_K_GEMV_N, PG_K_GEMV_N_FINISH, PG_K_GEMV_T, PG_K_EPILOGUE, PG_K_EXTRAPOLATE, PG_K_DR_STEP = range(6)
-KERNEL_NAMES = ["gemv_n_partial", "gemv_n_finish", "gemv_t", "fb_epilogue", "extrapolate", "dr_step"]
+KERNEL_NAMES = ["gemv_n_partial", "gemv_n_finish", "gemv_t", "fb_epilogue", "extrapolate", "dr_step", "gemv_tn"]
 
 
 class ProxGradError(RuntimeError):
@@ -28,7 +28,8 @@ class pg_iter_opts(C.Structure):
     _fields_ = [("fast", C.c_int32), ("adaptive", C.c_int32), ("Lf", C.c_double), ("gamma", C.c_double),
                 ("minimum_gamma", C.c_double), ("reduce_gamma", C.c_double), ("increase_gamma", C.c_double),
                 ("mf", C.c_double), ("seq_kind", C.c_int32), ("seq_p0", C.c_double), ("seq_p1", C.c_double),
-                ("g_kind", C.c_int32), ("g_p0", C.c_double), ("g_p1", C.c_double), ("reuse_residual", C.c_int32)]
+                ("g_kind", C.c_int32), ("g_p0", C.c_double), ("g_p1", C.c_double), ("reuse_residual", C.c_int32),
+                ("single_sweep", C.c_int32)]
 
 
 class pg_iter_scalars(C.Structure):
@@ -85,6 +86,7 @@ SIGNATURES = {
     "pg_ls_value": [_vp, _vp, _pf64],
     "pg_ls_gradient": [_vp, _vp, _vp, _pf64],
     "pg_ls_residual_ptr": [_vp, C.POINTER(_vp)],
+    "pg_ls_fused_pass": [_vp, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_prox_norml1": [_vp, _i32, _i64, _vp, _vp, _f64, _f64, _pf64],
     "pg_prox_indbox": [_vp, _i32, _i64, _vp, _vp, _f64, _f64, _vp, _vp, _pf64],
     "pg_norml1_value": [_vp, _i32, _i64, _vp, _f64, _pf64],

@@ -246,6 +246,145 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict_
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// pass TN: ONE sweep over A for BOTH orientations of a proximal-gradient iteration (unsharded operator).
+// For a column j everything the next residual needs from it is known as soon as g_j = A_j' r is:
+//     g_j -> y_j = x_j - gamma g_j -> z_j = prox(y_j) -> res_j = x_j - z_j -> v_j = z_j + beta (z_j - zold_j)
+// (forward_backward.jl:117-120 / fast_forward_backward.jl:140-142 followed by :135 of the NEXT iteration), so
+// A_j v_j is accumulated while the column is still in registers and A is read once per iteration instead of twice.
+// A workgroup's WAVES waves share every column: wave w owns the 1 KiB row groups u * WAVES + w (u < U) -- its slice
+// of r and of the next residual live in registers for the whole kernel (no LDS staging) -- and the C column dot
+// products of a step meet in LDS (one workgroup barrier per step, fixed summation order).  Each workgroup leaves
+// a partial of A v in partials[blockIdx.x], reduced by gemv_n_finish_kernel like pass N's slots; thread c of the
+// workgroup writes column c's outputs and accumulates the epilogue scalars for the grid reduction.
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+struct TNArgs {
+  const T* A;
+  int64_t ld, n, m;
+  int nrg;  // 1 KiB row groups of a column
+  const T* r;      // [ld] A x - b (lam not applied)
+  const T* x;      // [n]
+  const T* z_old;  // [n] the prox output of the previous iteration (for v); may alias nothing written here
+  T gamma, beta, p0, p1, lam_ls;  // p0 = gamma * lam (NormL1) | lo (IndBox) ; p1 = hi
+  int g_kind;
+  double gscale;  // lam for NormL1 else 0
+  T *g_out, *y, *z_new, *res, *v_out;  // [n] each
+  T* partials;                         // [gridDim.x][ld]
+  double* red_partials;
+  unsigned* red_counter;
+  double* scal_out;  // 4 doubles: g(z), ||res||_inf, <g, res>, ||res||^2
+};
+
+template <typename T, int U, int C, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  __shared__ T sm_dot[2][C][WAVES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ncg = (a.n + C - 1) / C;
+
+  // this wave's rows: row groups rg(u) = u * WAVES + wave
+  V rk[U], racc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int rg = u * WAVES + wave;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
+    if (rg < a.nrg) {
+      rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)rg * (WAVE * VEC) + lane * VEC);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rk[u][e] = T(0);
+    }
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int buf = 0;
+  for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
+    const int64_t j0 = cg * C;
+    V col[C][U];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
+      const T* __restrict__ p = a.A + j * a.ld + lane * VEC;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rg = u * WAVES + wave;
+        if (rg < a.nrg) {
+          col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rg * (WAVE * VEC)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) col[c][u][e] = T(0);
+        }
+      }
+    }
+    // per-wave partial dot products, then the workgroup total in fixed wave order
+    T dot[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      T d = T(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d = fma(col[c][u][e], rk[u][e], d);
+      }
+      dot[c] = wave_allsum(d);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) sm_dot[buf][c][wave] = dot[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      T g = sm_dot[buf][c][0];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) g += sm_dot[buf][c][w];
+      const int64_t j = j0 + c;
+      const bool valid = j < a.n;
+      const int64_t jc = valid ? j : (a.n - 1);
+      if (a.lam_ls != T(1)) g = a.lam_ls * g;
+      const T xj = a.x[jc], zo = a.z_old[jc];
+      const T yj = xj - a.gamma * g;
+      T zj;
+      if (a.g_kind == PG_G_NORML1)
+        zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
+      else if (a.g_kind == PG_G_INDBOX)
+        zj = fmin(a.p1, fmax(a.p0, yj));
+      else
+        zj = yj;
+      const T rj = xj - zj;
+      const T vj = valid ? zj + a.beta * (zj - zo) : T(0);
+      if ((int)threadIdx.x == c && valid) {
+        a.g_out[j] = g;
+        a.y[j] = yj;
+        a.z_new[j] = zj;
+        a.res[j] = rj;
+        if (a.v_out != nullptr) a.v_out[j] = vj;
+        if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
+        acc[1] = fmax(acc[1], fabs((double)rj));
+        acc[2] += (double)g * (double)rj;
+        acc[3] += (double)rj * (double)rj;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) racc[u][e] = fma(col[c][u][e], vj, racc[u][e]);
+      }
+    }
+    buf ^= 1;
+  }
+  T* part = a.partials + (int64_t)blockIdx.x * a.ld + lane * VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int rg = u * WAVES + wave;
+    if (rg < a.nrg) *reinterpret_cast<V*>(part + (int64_t)rg * (WAVE * VEC)) = racc[u];
+  }
+  const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
+  grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
+}
+
 // g[j] = sum_k chunks[k][j]
 template <typename T>
 __global__ __launch_bounds__(256) void sum_chunks_kernel(const T* __restrict__ chunks, int nchunks, int64_t n,
@@ -544,6 +683,112 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
   return PG_OK;
 }
 
+// ---- pass TN launcher ------------------------------------------------------------------------------------------
+// Tunables (environment, for experiments): PG_TN_C (columns per step), PG_TN_BLOCKS_PER_CU, PG_TN_BLOCKS.
+template <typename T, int U, int C, int WAVES>
+pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  pg_ctx* c = A->ctx;
+  const int64_t ncg = (A->n + C - 1) / C;
+  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", 2);
+  if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
+  if (blocks > ncg) blocks = ncg;
+  if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  PG_TRY(ensure_partials(A, (int)blocks));
+  a.partials = (T*)A->partials;
+  *blocks_out = (int)blocks;
+  pg_prof_scope prof(c, PG_K_GEMV_TN);
+  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// true when the shape is covered: every wave keeps U <= 16 row groups of r and of the next residual in registers
+template <typename T>
+bool tn_supported(const pg_mat* A) {
+  const int64_t rows_per_rg = 1024 / (int64_t)sizeof(T);
+  const int64_t nrg = A->ld / rows_per_rg;
+  return A->m > 0 && A->n > 0 && nrg <= 16 * 8;
+}
+
+template <typename T>
+pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  const int nrg = a.nrg;
+  const int W = nrg <= 64 ? 4 : 8;
+  int U = 1;
+  while (U * W < nrg) U *= 2;
+  int C = env_int("PG_TN_C", 16 / U > 1 ? 16 / U : 1);
+  if (W == 8) C = 1;
+#define PG_TN_CASE(UU, CC, WW) \
+  if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)
+  PG_TN_CASE(16, 1, 4);
+  PG_TN_CASE(16, 2, 4);
+  PG_TN_CASE(8, 2, 4);
+  PG_TN_CASE(8, 4, 4);
+  PG_TN_CASE(4, 4, 4);
+  PG_TN_CASE(4, 8, 4);
+  PG_TN_CASE(2, 8, 4);
+  PG_TN_CASE(2, 16, 4);
+  PG_TN_CASE(1, 16, 4);
+  PG_TN_CASE(1, 32, 4);
+  PG_TN_CASE(16, 1, 8);
+#undef PG_TN_CASE
+  pg_set_error("no gemv_tn instantiation for U=%d C=%d WAVES=%d", U, C, W);
+  return PG_ERR_UNSUPPORTED;
+}
+
+// One sweep: g = lam A' r (r = f->r, the residual of x), epilogue for (x, g, gamma), v = z + beta (z - z_old),
+// then f->r = A v - b and dscal[PG_S_F] = lam/2 ||A v - b||^2; epilogue scalars -> dscal[PG_S_GZ..PG_S_RESSQ]
+template <typename T>
+pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, const T* x, const T* z_old, double gamma,
+                          double beta, int g_kind, double g_p0, double g_p1, T* g_out, T* y, T* z_new, T* res, T* v_out) {
+  pg_ctx* c = f->ctx;
+  pg_mat* A = f->A;
+  if (c->allreduce != nullptr || c->allreduce_begin != nullptr || !tn_supported<T>(A)) {
+    pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(128 * 1024 / sizeof(T)));
+    return PG_ERR_UNSUPPORTED;
+  }
+  TNArgs<T> a;
+  a.A = (const T*)A->data;
+  a.ld = A->ld;
+  a.n = A->n;
+  a.m = A->m;
+  a.nrg = (int)(A->ld / (1024 / (int64_t)sizeof(T)));
+  a.r = r_src;
+  a.x = x;
+  a.z_old = z_old;
+  const T gm = (T)gamma;
+  a.gamma = gm;
+  a.beta = (T)beta;
+  a.p0 = g_kind == PG_G_NORML1 ? (T)(gm * (T)g_p0) : (T)g_p0;
+  a.p1 = (T)g_p1;
+  a.lam_ls = (T)f->lam;
+  a.g_kind = g_kind;
+  a.gscale = g_kind == PG_G_NORML1 ? (double)(T)g_p0 : 0.0;
+  a.g_out = g_out;
+  a.y = y;
+  a.z_new = z_new;
+  a.res = res;
+  a.v_out = v_out;
+  a.partials = nullptr;
+  a.red_partials = c->red_partials;
+  a.red_counter = c->red_counter;
+  a.scal_out = c->dscal + PG_S_GZ;
+  int blocks = 0;
+  PG_TRY(launch_tn<T>(A, a, &blocks));
+  f->a_passes += 1;
+  int64_t fb = (A->ld + 63) / 64;
+  if (fb > 1024) fb = 1024;
+  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+  hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
+                     (const T*)A->partials, A->ld, A->m, blocks, (const T*)f->b, r_dst,
+                     r_dst == (T*)f->r ? A->ld : A->m /* only f->r is padded to ld */, 0.5 * f->lam,
+                     c->red_partials, c->red_counter, f_dst, (T*)nullptr);
+  PG_LAUNCH_CHECK();
+  if (r_dst == (T*)f->r) f->r_gen++;
+  return PG_OK;
+}
+
 // all-reduce helper
 pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
   if (!c->allreduce) {
@@ -571,6 +816,7 @@ pg_status ls_residual_t(pg_ls* f, const T* x) {
   T* f_typed = (f->ctx->allreduce || f->ctx->allreduce_begin) ? ((T*)f->gbuf + A->n) : nullptr;
   PG_TRY(gemv_n<T>(A, x, (const T*)f->b, (T*)f->r, A->ld, true, 0.5 * f->lam, f_typed));
   f->a_passes += 1;
+  f->r_gen++;
   return PG_OK;
 }
 
@@ -666,6 +912,27 @@ pg_status ls_vg_t(pg_ls* f, const T* x, T* grad_out) {
 
 }  // namespace
 
+pg_status pg_ls_fused_pass_async(pg_ls* f, const void* r_src, void* r_dst, double* f_dst, const void* x, const void* z_old,
+                                 double gamma, double beta, int g_kind, double g_p0, double g_p1, void* grad, void* y,
+                                 void* z_new, void* res, void* v_next) {
+  if (r_src == nullptr) r_src = f->r;
+  if (r_dst == nullptr) r_dst = f->r;
+  if (f_dst == nullptr) f_dst = f->ctx->dscal + PG_S_F;
+  return f->A->dtype == PG_F32
+             ? ls_fused_pass_t<float>(f, (const float*)r_src, (float*)r_dst, f_dst, (const float*)x, (const float*)z_old, gamma,
+                                      beta, g_kind, g_p0, g_p1, (float*)grad, (float*)y, (float*)z_new, (float*)res,
+                                      (float*)v_next)
+             : ls_fused_pass_t<double>(f, (const double*)r_src, (double*)r_dst, f_dst, (const double*)x, (const double*)z_old,
+                                       gamma, beta, g_kind, g_p0, g_p1, (double*)grad, (double*)y, (double*)z_new,
+                                       (double*)res, (double*)v_next);
+}
+
+bool pg_ls_fused_pass_supported(const pg_ls* f) {
+  const pg_ctx* c = f->ctx;
+  if (c->allreduce != nullptr || c->allreduce_begin != nullptr) return false;
+  return f->A->dtype == PG_F32 ? tn_supported<float>(f->A) : tn_supported<double>(f->A);
+}
+
 pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out) {
   return f->A->dtype == PG_F32 ? ls_grad_stage_t<float>(f, (float*)grad_out) : ls_grad_stage_t<double>(f, (double*)grad_out);
 }
@@ -741,6 +1008,22 @@ pg_status pg_ls_destroy(pg_ls* f) {
   if (f->gbuf) (void)hipFree(f->gbuf);
   if (f->gchunks) (void)hipFree(f->gchunks);
   delete f;
+  return PG_OK;
+}
+
+pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,
+                           double g_p0, double g_p1, void* grad, void* y, void* z_new, void* res, void* v_next,
+                           double* scalars_out) {
+  PG_REQUIRE(f != nullptr, "operator is null");
+  PG_REQUIRE(x && z_old && grad && y && z_new && res && v_next, "null vector");
+  PG_REQUIRE(g_kind == PG_G_ZERO || g_kind == PG_G_NORML1 || g_kind == PG_G_INDBOX, "unknown g_kind");
+  PG_REQUIRE(gamma > 0, "gamma must be positive");
+  PG_TRY(pg_ls_fused_pass_async(f, nullptr, nullptr, nullptr, x, z_old, gamma, beta, g_kind, g_p0, g_p1, grad, y, z_new, res,
+                                v_next));
+  if (scalars_out) {
+    PG_TRY(pg_read_scalars(f->ctx, PG_S_F, 5));
+    for (int k = 0; k < 5; ++k) scalars_out[k] = f->ctx->hscal[PG_S_F + k];
+  }
   return PG_OK;
 }
 

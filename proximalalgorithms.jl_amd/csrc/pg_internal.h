@@ -62,6 +62,7 @@ enum {
   PG_S_RESSQ = 4,    // ||res||^2
   PG_S_MISC = 5,     // dot / nrm2sq / nrminf / prox value results (2 slots)
   PG_S_DR = 8,       // Douglas-Rachford step: { ||res||_inf, f(y), g(z) }
+  PG_S_FNEXT = 34,   // f at the speculative next point of the single-sweep iteration (2 slots, alternating)
   PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 16 inner iterations, f(y), g(z) }
   PG_S_COUNT = 40
 };
@@ -132,6 +133,7 @@ struct pg_ls {
   void* gbuf = nullptr;  // [n + 1] gradient ++ f, the all-reduce payload
   void* gchunks = nullptr;  // [nchunks * n] partial gradients when m needs several LDS chunks
   int64_t a_passes = 0;     // telemetry: full reads of A
+  uint64_t r_gen = 0;       // bumped whenever r is rewritten (single-sweep iterations check their speculation)
 };
 
 static inline size_t pg_sizeof(int dtype) { return dtype == PG_F64 ? 8 : 4; }
@@ -149,6 +151,14 @@ pg_status pg_ls_residual_async(pg_ls* f, const void* x);
 // *grad_ptr_out (either grad_out or f->gbuf) and f in dscal[PG_S_F].
 pg_status pg_ls_vg_async(pg_ls* f, const void* x, void* grad_out);
 pg_status pg_ls_value_async(pg_ls* f, const void* x);
+// ONE sweep over A: g = lam A' r from the residual held in f->r (that of x), the epilogue for (x, g, gamma), v = z_new +
+// beta (z_new - z_old), then f->r = A v - b and dscal[PG_S_F] = lam/2 ||A v - b||^2; epilogue scalars in
+// dscal[PG_S_GZ .. PG_S_RESSQ].  Unsharded operators with <= 128 row groups only (pg_ls_fused_pass_supported).
+pg_status pg_ls_fused_pass_async(pg_ls* f, const void* r_src /* null: f->r */, void* r_dst /* null: f->r */,
+                                 double* f_dst /* device scalar; null: dscal[PG_S_F] */, const void* x, const void* z_old,
+                                 double gamma, double beta, int g_kind, double g_p0, double g_p1, void* grad, void* y,
+                                 void* z_new, void* res, void* v_next /* nullable */);
+bool pg_ls_fused_pass_supported(const pg_ls* f);
 // g = lam A' r (+ all-reduce) from the residual currently held in f->r; f must already be in dscal[PG_S_F]
 pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out);
 // r_out = a r1 + b r2 over m elements, dscal[PG_S_F] = f_scale ||r_out||^2, optional typed mirror of f

@@ -118,6 +118,8 @@ pg_status iter_init(pg_iter* it, const void* x0) {
   it->seq_t = 1;
   it->seq_k = 1;
   it->passes0 = it->f->a_passes;
+  it->sp_ready = false;
+  it->sp_slot = 0;
   // x = copy(x0)                                                         fb:66 / ffb:74
   if (n > 0) PG_HIP(hipMemcpyAsync(it->x, x0, nb, hipMemcpyDeviceToDevice, c->stream));
   // f_x, grad_f_x = value_and_gradient(f, x)                             fb:67 / ffb:75
@@ -150,11 +152,143 @@ pg_status iter_init(pg_iter* it, const void* x0) {
   return PG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-sweep iterations: ONE read of A per iteration (pg_ls_fused_pass_async).  The sweep that forms A' r for the
+// current point also runs the epilogue column by column and accumulates the residual of the NEXT point from the
+// column while it is still in registers.  What the reference does in the order
+//     [extrapolate :135 | A x :138] [A' r :138-139 | prox :140-142]          (one iteration)
+// is executed as            ... A x ] [A' r | prox | extrapolate | A x_next] [ ...      (one sweep)
+// i.e. a sweep is the second half of iteration k and the first half of iteration k+1.  The first half is speculative:
+// if iteration k satisfies the stop rule it is simply never committed (x_next is a separate buffer, the sequence is
+// advanced on a copy), so the state returned is exactly the reference's state k.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+SeqState<T> seq_load(const pg_iter* it) {
+  return SeqState<T>{(T)it->seq_stepsize, (T)it->seq_theta, (T)it->seq_t, (long long)it->seq_k};
+}
+
+template <typename T>
+pg_status read_sweep_scalars(pg_iter* it) {
+  pg_ctx* c = it->ctx;
+  PG_TRY(pg_read_scalars(c, PG_S_F, PG_S_COUNT));
+  it->g_z = Arith<T>::r(c->hscal[PG_S_GZ]);
+  it->res_inf = Arith<T>::r(c->hscal[PG_S_RESINF]);
+  it->dot_gr = Arith<T>::r(c->hscal[PG_S_DOT]);
+  it->res_sq = Arith<T>::r(c->hscal[PG_S_RESSQ]);
+  it->sp_f = Arith<T>::r(c->hscal[PG_S_FNEXT + it->sp_slot]);
+  return PG_OK;
+}
+
+template <typename T>
+pg_status iter_step_single_sweep(pg_iter* it) {
+  pg_ctx* c = it->ctx;
+  pg_ls* f = it->f;
+  const pg_iter_opts& o = it->o;
+  if (!it->adaptive) {
+    const double gfix = (o.gamma > 0 || o.Lf > 0) ? Arith<T>::r(o.gamma > 0 ? o.gamma : (double)(T(1) / (T)o.Lf)) : it->gamma;
+    if (o.fast) {
+      // ---- FastForwardBackward, fixed step: fast_forward_backward.jl:131-142 ----
+      if (!(it->sp_ready && it->sp_gen == f->r_gen)) {  // first half of this iteration (:131-138) on its own
+        SeqState<T> s = seq_load<T>(it);
+        it->sp_beta = (double)seq_next_hd<T>(o.seq_kind, (T)o.mf, (T)o.seq_p0, (T)o.seq_p1, s, (T)gfix, T(0));  // :134
+        it->spec_stepsize = (double)s.stepsize, it->spec_theta = (double)s.theta, it->spec_t = (double)s.t, it->spec_k = s.k;
+        PG_TRY(pg_extrapolate(c, it->dtype, it->n, it->x_next, it->z, it->z_prev, it->sp_beta));  // :135
+        PG_TRY(pg_ls_value_async(f, it->x_next));                                                 // :138 (A x - b, f)
+        PG_TRY(pg_read_scalars(c, PG_S_F, 1));
+        it->sp_f = Arith<T>::r(c->hscal[PG_S_F]);
+      }
+      // commit the first half
+      it->gamma = gfix;                                                                           // :131
+      it->beta = it->sp_beta;
+      it->seq_stepsize = it->spec_stepsize, it->seq_theta = it->spec_theta, it->seq_t = it->spec_t, it->seq_k = it->spec_k;
+      std::swap(it->x, it->x_next);
+      std::swap(it->z_prev, it->z);                                                               // :136
+      it->f_x = it->sp_f;
+      // second half (:138-142) + the next iteration's first half, one sweep
+      SeqState<T> s2 = seq_load<T>(it);
+      const double beta2 = (double)seq_next_hd<T>(o.seq_kind, (T)o.mf, (T)o.seq_p0, (T)o.seq_p1, s2, (T)it->gamma, T(0));
+      it->sp_slot ^= 1;
+      PG_TRY(pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev, it->gamma,
+                                    beta2, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, it->x_next));
+      it->sp_beta = beta2;
+      it->spec_stepsize = (double)s2.stepsize, it->spec_theta = (double)s2.theta, it->spec_t = (double)s2.t, it->spec_k = s2.k;
+      it->sp_gen = f->r_gen;
+      it->sp_ready = true;
+      PG_TRY(read_sweep_scalars<T>(it));
+    } else {
+      // ---- ForwardBackward, fixed step: forward_backward.jl:111-120 (the next point is the prox output itself) ----
+      if (!(it->sp_ready && it->sp_gen == f->r_gen)) {
+        PG_TRY(pg_ls_value_async(f, it->z));
+        PG_TRY(pg_read_scalars(c, PG_S_F, 1));
+        it->sp_f = Arith<T>::r(c->hscal[PG_S_F]);
+      }
+      std::swap(it->x, it->z);  // :112
+      it->f_x = it->sp_f;       // :113
+      it->sp_slot ^= 1;
+      PG_TRY(pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->x, it->gamma, 0.0,
+                                    o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr));
+      it->sp_gen = f->r_gen;
+      it->sp_ready = true;
+      PG_TRY(read_sweep_scalars<T>(it));
+    }
+    return PG_OK;
+  }
+  // ---- FastForwardBackward, adaptive step with the residual pair: fast_forward_backward.jl:110-142 ----
+  const T eps = std::numeric_limits<T>::epsilon();
+  const T min_gamma = (T)o.minimum_gamma, reduce = (T)o.reduce_gamma;
+  const size_t mb = (size_t)f->A->m * sizeof(T);
+  it->gamma = (double)((T)it->gamma * (T)o.increase_gamma);  // :111
+  T f_upp = (T)f_model<T>(it);                               // fb_tools.jl:42
+  T f_z;
+  if (it->sp_ready) {
+    f_z = (T)it->sp_f;  // the last sweep left A z - b in rz and f(z) with it: no pass for the first trial
+  } else {
+    PG_TRY(pg_ls_value_async(f, it->z));
+    if (mb) PG_HIP(hipMemcpyAsync(it->rz, f->r, mb, hipMemcpyDeviceToDevice, c->stream));
+    PG_TRY(pg_read_scalars(c, PG_S_F, 1));
+    f_z = (T)c->hscal[PG_S_F];
+  }
+  T tol = T(10) * eps * (T(1) + std::fabs(f_z));
+  while (f_z > f_upp + tol && (T)it->gamma >= min_gamma) {  // fb_tools.jl:46-55
+    it->gamma = (double)((T)it->gamma * reduce);
+    PG_TRY(epilogue_and_read<T>(it, false));
+    f_upp = (T)f_model<T>(it);
+    PG_TRY(pg_ls_value_async(f, it->z));
+    if (mb) PG_HIP(hipMemcpyAsync(it->rz, f->r, mb, hipMemcpyDeviceToDevice, c->stream));
+    PG_TRY(pg_read_scalars(c, PG_S_F, 1));
+    f_z = (T)c->hscal[PG_S_F];
+    tol = T(10) * eps * (T(1) + std::fabs(f_z));
+    it->n_backtracks++;
+  }
+  if ((T)it->gamma < min_gamma) it->flags |= PG_FLAG_GAMMA_TOO_SMALL;
+  it->f_z = (double)f_z;
+  it->f_z_upp = (double)f_upp;
+  it->beta = seq_next<T>(it, it->gamma, 0.0);                                                       // :134
+  PG_TRY(pg_extrapolate(c, it->dtype, it->n, it->x, it->z, it->z_prev, it->beta));                  // :135
+  std::swap(it->z_prev, it->z);                                                                     // :136
+  // A x - b = (1 + beta)(A z - b) - beta (A z_prev - b)   (:138 without reading A)
+  PG_TRY(pg_residual_combo_async(c, it->dtype, f->A->m, f->r, (double)(T(1) + (T)it->beta), it->rz,
+                                 (double)(-(T)it->beta), it->rz_prev, 0.5 * f->lam, nullptr));
+  f->r_gen++;
+  std::swap(it->rz_prev, it->rz);  // the residual at the new z_prev
+  // A' r, prox (:138-142) and the residual of the NEW z for the next line search, one sweep
+  it->sp_slot ^= 1;
+  PG_TRY(pg_ls_fused_pass_async(f, f->r, it->rz, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev, it->gamma, 0.0,
+                                o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr));
+  it->sp_ready = true;
+  it->rz_valid = false;
+  PG_TRY(read_sweep_scalars<T>(it));
+  it->f_x = Arith<T>::r(c->hscal[PG_S_F]);  // from the residual combination
+  return PG_OK;
+}
+
 template <typename T>
 pg_status iter_step(pg_iter* it, double host_beta) {
   it->flags = 0;
   it->n_backtracks = 0;
   it->f_z = it->f_z_upp = NAN;
+  if (it->single_sweep && !it->defer_sync) return iter_step_single_sweep<T>(it);
+  it->sp_ready = false;
   if (!it->o.fast) {
     // ---------------- ForwardBackward: forward_backward.jl:86-123 ----------------
     if (it->adaptive) {
@@ -218,6 +352,7 @@ pg_status pg_iter_opts_default(pg_iter_opts* o) {
   o->seq_kind = PG_SEQ_ADAPTIVE;
   o->g_kind = PG_G_ZERO;
   o->reuse_residual = 1;
+  o->single_sweep = 1;
   return PG_OK;
 }
 
@@ -237,8 +372,12 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   const bool gamma_known = (o->gamma > 0) || (o->Lf > 0);
   it->adaptive = o->adaptive < 0 ? !gamma_known : (o->adaptive != 0);
   const size_t vb = vec_bytes(it);
-  const int nvec = 6;
   const bool reuse = o->fast && o->reuse_residual != 0;
+  // one read of A per iteration where the fused sweep applies: FB / FFB with a fixed step, FFB adaptive with the residual
+  // pair; host-provided extrapolation coefficients arrive one step at a time, so they need the two-sweep path
+  it->single_sweep = o->single_sweep != 0 && pg_ls_fused_pass_supported(f) && !(o->fast && o->seq_kind == PG_SEQ_HOST) &&
+                     (!it->adaptive || (o->fast && reuse));
+  const int nvec = it->single_sweep ? 7 : 6;
   const size_t mb = reuse ? (size_t)pg_round_up((int64_t)((size_t)(f->A->m > 0 ? f->A->m : 1) * pg_sizeof(it->dtype)), 256) : 0;
   PG_HIP(hipSetDevice(c->device));
   hipError_t e = hipMalloc(&it->slab, vb * nvec + 2 * mb);
@@ -264,9 +403,10 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
     it->z_prev = base + 5 * vb;
   else
     it->grad_f_z = base + 5 * vb;
+  if (it->single_sweep) it->x_next = base + 6 * vb;
   if (reuse) {
-    it->rz = base + 6 * vb;
-    it->rz_prev = base + 6 * vb + mb;
+    it->rz = base + nvec * vb;
+    it->rz_prev = base + nvec * vb + mb;
   }
   *out = it;
   return PG_OK;

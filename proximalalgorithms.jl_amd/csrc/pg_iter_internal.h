@@ -30,6 +30,18 @@ struct pg_iter {
   void *rz = nullptr, *rz_prev = nullptr;
   bool rz_valid = false;
   bool defer_sync = false;  // pg_iter_run_batched: enqueue without reading the scalar block back
+  // single-sweep iterations (pg_ls_fused_pass): the sweep of iteration k also produces the extrapolated point of
+  // iteration k+1 and its residual.  sp_ready: that speculation is available -- fixed step: x_next, f->r = A x_next - b
+  // (valid while f->r_gen == sp_gen), sp_f = f(x_next), the sequence state after its beta in spec_*; adaptive step:
+  // rz = A z - b and sp_f = f(z).
+  bool single_sweep = false;
+  void* x_next = nullptr;
+  bool sp_ready = false;
+  uint64_t sp_gen = 0;
+  double sp_f = 0, sp_beta = 0;
+  int sp_slot = 0;
+  double spec_stepsize = -1, spec_theta = -1, spec_t = 1;
+  int64_t spec_k = 1;
 };
 
 

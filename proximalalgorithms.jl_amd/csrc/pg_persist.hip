@@ -859,6 +859,7 @@ void small_read_result(pg_iter* it, void* (&bufs)[8], int64_t* k_out) {
   it->flags = (int)o[21];
   it->f->a_passes += (int64_t)o[22];
   it->rz_valid = false;  // the next host-driven step evaluates A x itself
+  it->sp_ready = false;  // ... and any single-sweep speculation is gone
   it->f_z = it->f_z_upp = NAN;
 }
 

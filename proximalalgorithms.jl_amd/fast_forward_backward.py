@@ -29,7 +29,8 @@ class FastForwardBackwardIteration:
     """fast_forward_backward.jl:44-56 (keyword constructor), Base.iterate :73-97 / :106-145."""
 
     def __init__(self, *, f=None, g=None, x0, mf=0.0, Lf=None, gamma=None, adaptive=None, minimum_gamma=1e-7,
-                 reduce_gamma=0.5, increase_gamma=1.0, extrapolation_sequence=None, engine=None, reuse_residual=True):
+                 reduce_gamma=0.5, increase_gamma=1.0, extrapolation_sequence=None, engine=None, reuse_residual=True,
+                 single_sweep=True):
         self.f = f if f is not None else Zero()
         self.g = g if g is not None else Zero()
         ctx = getattr(self.f, "ctx", None)
@@ -45,6 +46,8 @@ class FastForwardBackwardIteration:
         self.extrapolation_sequence = extrapolation_sequence
         # fused engine, adaptive step: build A x - b from the residuals the line search holds (2 passes/iter, not 3)
         self.reuse_residual = bool(reuse_residual)
+        # fused engine: ONE read of A per iteration where the operator allows it (pg_ls_fused_pass); False = two sweeps
+        self.single_sweep = bool(single_sweep)
         if engine is None:
             engine = "fused" if fused_supported(self.f, self.g) else "generic"
         if engine == "fused" and not fused_supported(self.f, self.g):
@@ -72,7 +75,7 @@ class FastForwardBackwardIteration:
         fi = FusedIteration(self.f, self.g, fast=True, Lf=self.Lf, gamma=self.gamma, adaptive=self.adaptive,
                             minimum_gamma=self.minimum_gamma, reduce_gamma=self.reduce_gamma,
                             increase_gamma=self.increase_gamma, mf=self.mf, seq_kind=kind, seq_p0=p0, seq_p1=p1,
-                            reuse_residual=self.reuse_residual)
+                            reuse_residual=self.reuse_residual, single_sweep=self.single_sweep)
         self._fused = fi
         state = FastForwardBackwardState(extrapolation_sequence=self.extrapolation_sequence)
 

@@ -58,7 +58,8 @@ class ForwardBackwardIteration:
     Iterating yields the (mutated in place) state object forever (``IteratorSize = IsInfinite``)."""
 
     def __init__(self, *, f=None, g=None, x0, Lf=None, gamma=None, adaptive=None, minimum_gamma=1e-7,
-                 reduce_gamma=0.5, increase_gamma=1.0, engine=None):
+                 reduce_gamma=0.5, increase_gamma=1.0, engine=None, single_sweep=True):
+        self.single_sweep = bool(single_sweep)  # fused engine: one read of A per iteration where possible
         self.f = f if f is not None else Zero()
         self.g = g if g is not None else Zero()
         ctx = getattr(self.f, "ctx", None)
@@ -82,7 +83,7 @@ class ForwardBackwardIteration:
         R = self.x0.dtype.type
         fi = FusedIteration(self.f, self.g, fast=False, Lf=self.Lf, gamma=self.gamma, adaptive=self.adaptive,
                             minimum_gamma=self.minimum_gamma, reduce_gamma=self.reduce_gamma,
-                            increase_gamma=self.increase_gamma)
+                            increase_gamma=self.increase_gamma, single_sweep=self.single_sweep)
         self._fused = fi
         state = ForwardBackwardState()
 

@@ -177,7 +177,7 @@ ProximalCore.prox(g::Union{HIPNormL1,HIPIndBox}, x::HIPVector, gamma) = (y = sim
 struct PgIterOpts
     fast::Int32; adaptive::Int32; Lf::Float64; gamma::Float64; minimum_gamma::Float64; reduce_gamma::Float64
     increase_gamma::Float64; mf::Float64; seq_kind::Int32; seq_p0::Float64; seq_p1::Float64
-    g_kind::Int32; g_p0::Float64; g_p1::Float64; reuse_residual::Int32
+    g_kind::Int32; g_p0::Float64; g_p1::Float64; reuse_residual::Int32; single_sweep::Int32
 end
 struct PgIterScalars
     gamma::Float64; f_x::Float64; g_z::Float64; res_inf::Float64; beta::Float64; f_z::Float64; f_z_upp::Float64
@@ -225,7 +225,7 @@ function Base.iterate(iter::HIPForwardBackwardIteration{R}) where {R}
     x0 = iter.x0 isa HIPVector ? iter.x0 : HIPVector(iter.x0; ctx = iter.f.A.ctx)   # x0 is copied, never mutated
     kind, p0, p1 = g_spec(iter.g)
     opts = Ref(PgIterOpts(iter.fast, iter.adaptive, something(iter.Lf, -1.0), something(iter.gamma, -1.0),
-                          iter.minimum_gamma, iter.reduce_gamma, iter.increase_gamma, iter.mf, 0, 0.0, 0.0, kind, p0, p1, 1))
+                          iter.minimum_gamma, iter.reduce_gamma, iter.increase_gamma, iter.mf, 0, 0.0, 0.0, kind, p0, p1, 1, 1))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:pg_iter_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterOpts}, Ref{Ptr{Cvoid}}),
                 iter.f.A.ctx.handle, iter.f.handle, opts, h))

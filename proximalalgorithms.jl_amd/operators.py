@@ -74,6 +74,18 @@ class LeastSquares:
         call("pg_ls_value", self._h, x.vp, C.byref(f))
         return self.dtype.type(f.value)
 
+    def fused_pass(self, x, z_old, gamma, beta, g, grad, y, z_new, res, v_next):
+        """ONE sweep over A for a whole proximal-gradient iteration (pg_ls_fused_pass): with the residual held by this
+        operator being that of ``x``:  grad = lam A' r ; y = x - gamma grad ; z_new = prox_{gamma g}(y) ;
+        res = x - z_new ; v_next = z_new + beta (z_new - z_old) ; the residual becomes A v_next - b.
+        Returns (f(v_next), g(z_new), norm(res, Inf), dot(grad, res), norm(res)^2)."""
+        p0, p1 = g.g_params()
+        sc = (C.c_double * 5)()
+        call("pg_ls_fused_pass", self._h, x.vp, z_old.vp, float(gamma), float(beta), g.g_kind, p0, p1, grad.vp, y.vp,
+             z_new.vp, res.vp, v_next.vp, sc)
+        R = self.dtype.type
+        return tuple(R(v) for v in sc)
+
     def residual(self):
         """A x - b of the last evaluation (view of the library-owned m-vector)."""
         p = C.c_void_p()

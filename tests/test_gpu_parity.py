@@ -534,7 +534,7 @@ def test_bench_line_contract(pa, cpu_mode):
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] in ("gemv_t", "gemv_n_partial")
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] in ("gemv_t", "gemv_n_partial", "gemv_tn")
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3) and 0 < r["frac"] < 1
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-2)
     assert r["launches"] == 12 and r["traffic"] is None  # PMC traffic is only quoted for the workload it was measured on
@@ -547,7 +547,12 @@ def test_bench_line_contract(pa, cpu_mode):
 def test_two_ranks_one_gpu_matches_single_rank(pa, mode, overlap):
     """bench.py with 2 processes (row shards of 1024 rows each) sharing cuda:0 over gloo == 1 process:
     same lambda / Lf (they come from all-reduced quantities) and the same iterate after 14 steps."""
-    one = _run_bench(["--mode", mode])
+    one = _run_bench(["--mode", mode, "--sweeps", "two"])
+    one_ss = _run_bench(["--mode", mode])  # single sweep (default): same problem, same answers, half the reads of A
+    assert one_ss["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1) and one["config"]["a_passes_per_step"] >= 2
+    assert one_ss["config"]["final"]["f_x"] == pytest.approx(one["config"]["final"]["f_x"], rel=2e-4)
+    assert one_ss["config"]["final"]["g_z"] == pytest.approx(one["config"]["final"]["g_z"], rel=2e-4)
+    assert one_ss["roofline"]["kernel"] == "gemv_tn"
     two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device"] + (["--overlap"] if overlap else []), nproc=2)
     assert two["n_gpus"] == 2 and two["config"]["m_per_gpu"] * 2 == one["config"]["m"]
     assert two["config"]["lambda"] == pytest.approx(one["config"]["lambda"], rel=1e-5)
@@ -831,13 +836,15 @@ def test_ffb_adaptive_residual_reuse(pa, dtype):
     recomputing path (and as the oracle) to rounding."""
     A, b, lam = synthetic_problem(400, 1200, dtype, seed=9)
     x0 = np.zeros(1200, dtype)
-    its = [pa.FastForwardBackwardIteration(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0, reuse_residual=r)
-           for r in (True, False)]
+    its = [pa.FastForwardBackwardIteration(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0, reuse_residual=r, single_sweep=s)
+           for r, s in ((True, False), (False, False), (True, True))]
     it_o = o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0)
     tol = 2e-5 if dtype == np.float32 else 1e-11
     nbt = 0
-    for k, (s1, s2, so) in enumerate(itertools.islice(zip(its[0], its[1], it_o), 60)):
-        assert float(s1.gamma) == float(s2.gamma), k
+    for k, (s1, s2, s3, so) in enumerate(itertools.islice(zip(its[0], its[1], its[2], it_o), 60)):
+        assert float(s1.gamma) == float(s2.gamma) == float(s3.gamma), k
+        z3 = s3.z.numpy()
+        assert np.max(np.abs(z3 - so.z)) <= tol * max(1.0, np.max(np.abs(so.z))), k
         # the initial gamma comes from a norm (fb_tools.jl:11): fp64-accumulated here, BLAS nrm2 in the oracle
         assert float(s1.gamma) == pytest.approx(float(so.gamma), rel=1e-6 if dtype == np.float32 else 1e-12), k
         z1, z2 = s1.z.numpy(), s2.z.numpy()
@@ -848,6 +855,8 @@ def test_ffb_adaptive_residual_reuse(pa, dtype):
     steps = 59
     assert its[0].counters["a_passes"] == 2 + 2 + 2 * steps + nbt  # init (2 evaluations), then 2 per step
     assert its[1].counters["a_passes"] == 2 + 2 + 3 * steps + nbt
+    # single sweep: the first step still needs A z - b on its own, afterwards ONE read of A per iteration
+    assert its[2].counters["a_passes"] == 2 + 2 + 1 + 1 * steps + nbt
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1281,3 +1290,67 @@ def test_fuzz_newton_type_and_douglas_rachford(pa):
         if fails:
             bad.append((desc, fails))
     assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------
+# single-sweep pass (pg_ls_fused_pass): A' r, epilogue, next extrapolation and next residual in one read of A
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("gname", ["l1", "box", "zero"])
+def test_fused_single_sweep_pass_matches_separate_kernels(pa, dtype, gname):
+    rng = np.random.default_rng(11)
+    shapes = [(1, 1), (5, 3), (200, 500), (256, 64), (257, 65), (1000, 33), (4096, 40), (4097, 130), (16384, 24), (20000, 9)]
+    shapes += [(32768, 5)] if dtype == np.float32 else [(16385, 4)]
+    for (m, n) in shapes:
+        if dtype == np.float64 and m > 16384:
+            continue
+        A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+        b = rng.standard_normal(m).astype(dtype)
+        x, z_old = rng.standard_normal(n).astype(dtype), rng.standard_normal(n).astype(dtype)
+        lam_ls = dtype(1.0 if rng.random() < 0.5 else 0.7)
+        gamma, beta = dtype(0.3), dtype(0.6)
+        g = {"l1": pa.NormL1(dtype(0.2)), "box": pa.IndBox(dtype(-0.3), dtype(0.4)), "zero": pa.Zero()}[gname]
+        f = pa.LeastSquares(A, b, lam=lam_ls)
+        xd, zd = pa.HIPVector.from_numpy(x), pa.HIPVector.from_numpy(z_old)
+        # reference: the separate kernels
+        fx, grad_ref = f.value_and_gradient(xd)
+        y_ref, z_ref, res_ref = xd.similar(), xd.similar(), xd.similar()
+        from proximalalgorithms.jl_amd import _lib
+        import ctypes as C
+
+        sc = (C.c_double * 4)()
+        p0, p1 = g.g_params()
+        _lib.call("pg_fb_epilogue", xd.ctx.handle, xd.pg_dtype, n, xd.vp, grad_ref.vp, float(gamma), g.g_kind, p0, p1,
+                  y_ref.vp, z_ref.vp, res_ref.vp, sc)
+        v_ref = z_ref.numpy() + beta * (z_ref.numpy() - z_old)
+        f_v_ref = f(pa.HIPVector.from_numpy(v_ref.astype(dtype)))
+        r_v_ref = f.residual().numpy().copy()
+        # the single sweep, from the residual of x
+        f(xd)
+        grad, y, z_new, res, v = (xd.similar() for _ in range(5))
+        f_v, g_z, res_inf, dot_gr, res_sq = f.fused_pass(xd, zd, gamma, beta, g, grad, y, z_new, res, v)
+        tol = rtol(dtype)
+        A64 = A.astype(np.float64)
+        gb = float(lam_ls) * (np.abs(A64).T @ np.abs(A64 @ x.astype(np.float64) - b.astype(np.float64))) + 1e-30
+        assert np.all(np.abs(grad.numpy() - grad_ref.numpy()) <= 8 * tol * gb), (m, n)
+        sl = 20 * tol * float(gamma) * np.max(gb) + 4 * np.finfo(dtype).eps
+        for got, ref in ((y, y_ref), (z_new, z_ref), (res, res_ref)):
+            assert np.max(np.abs(got.numpy() - ref.numpy())) <= sl * max(1.0, np.max(np.abs(ref.numpy()))), (m, n)
+        assert np.max(np.abs(v.numpy() - v_ref)) <= 3 * sl * max(1.0, np.max(np.abs(v_ref))), (m, n)
+        assert float(res_inf) == pytest.approx(float(sc[1]), rel=1e-4, abs=sl)
+        assert float(g_z) == pytest.approx(float(sc[0]), rel=1e-4, abs=sl * n)
+        assert float(dot_gr) == pytest.approx(float(sc[2]), rel=1e-3, abs=1e-4 * max(1.0, abs(float(sc[2]))) + sl * n)
+        assert float(res_sq) == pytest.approx(float(sc[3]), rel=1e-3, abs=sl * n)
+        rb = np.abs(A64) @ np.abs(v_ref.astype(np.float64)) + np.abs(b) + 1e-30
+        assert np.all(np.abs(f.residual().numpy() - r_v_ref) <= 40 * tol * rb + 3 * sl * np.max(np.abs(A64).sum(axis=1))), (m, n)
+        assert float(f_v) == pytest.approx(float(f_v_ref), rel=2e-3 if dtype == np.float32 else 1e-9, abs=1e-6)
+    # rows beyond the register budget / sharded operators are refused, not mis-computed
+    if dtype == np.float64:
+        A = np.asfortranarray(rng.standard_normal((16385, 2)))
+        f = pa.LeastSquares(A, rng.standard_normal(16385))
+        xd = pa.HIPVector.from_numpy(rng.standard_normal(2))
+        f(xd)
+        with pytest.raises(pa.ProxGradError):
+            f.fused_pass(xd, xd, 0.1, 0.0, pa.Zero(), *(xd.similar() for _ in range(5)))
