@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--sweeps", choices=["one", "two"], default="one",
                    help="one: the single-sweep iteration (A read once per iteration; single GPU) -- two: A x and A' r as "
                         "separate sweeps like the reference (always the case when rows are sharded)")
+    p.add_argument("--sharding", choices=["auto", "rows", "cols"], default="auto",
+                   help="N > 1: how A is distributed (auto: column blocks for the fixed-step single-sweep run, row blocks "
+                        "otherwise)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel-events", choices=["gemv", "all", "none"], default="gemv",
                    help="which kernels are bracketed by HIP event pairs in the timed region (none: no roofline object)")
@@ -228,35 +231,69 @@ def main():
     n = args.n or n
     dtype = np.float32 if args.dtype == "f32" else np.float64
     ctx = pa.get_context(local_rank)
-    row_off, m_loc = pa.shard_rows(m_glob, world, rank)
+    # N > 1: column shards keep the single-sweep iteration on every GPU (one all-reduce of m + 4 N elements per
+    # iteration, fixed step); row shards (north_star's layout; the adaptive mode needs them) iterate with two sweeps and
+    # all-reduce [grad ; f] (n + 1 elements)
+    sharding = args.sharding
+    if sharding == "auto":
+        sharding = "cols" if (world > 1 or args.force_comm) and args.mode == "fixed" and args.sweeps == "one" and \
+            args.collective == "torch" else "rows"
+    if world == 1 and not args.force_comm:
+        sharding = "none"
+    cols = sharding == "cols"
+    if cols and args.mode != "fixed":
+        raise SystemExit("--sharding cols needs --mode fixed")
+    if cols:
+        row_off, m_loc = 0, m_glob
+        col_off, n_loc = pa.shard_cols(n, world, rank)
+    else:
+        row_off, m_loc = pa.shard_rows(m_glob, world, rank)
+        col_off, n_loc = 0, n
+
+    def allreduce_scalar(v, op):
+        """a Python scalar reduced over the ranks (setup only)"""
+        if world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
 
     # ---------------- problem setup (untimed): A resident in HBM, b, lam, Lf ----------------
     t_setup = time.perf_counter()
-    A = pa.HIPMatrix.synthetic(m_loc, n, dtype, seed=args.seed, row_offset=row_off, m_global=m_glob, ctx=ctx)
+    A = pa.HIPMatrix.synthetic(m_loc, n_loc, dtype, seed=args.seed, row_offset=row_off, col_offset=col_off, m_global=m_glob,
+                               ctx=ctx)
     rng = np.random.default_rng(args.seed + 12345)
     k = max(1, n // 1000)
     x_true = np.zeros(n, dtype)
     x_true[rng.choice(n, size=k, replace=False)] = rng.standard_normal(k).astype(dtype)
     noise = np.random.default_rng(args.seed + 54321).standard_normal(m_glob).astype(dtype)[row_off:row_off + m_loc]
-    b = A.mul(pa.HIPVector.from_numpy(x_true, ctx))  # rows are independent: no collective
+    b = A.mul(pa.HIPVector.from_numpy(x_true[col_off:col_off + n_loc], ctx))  # row shards: rows are independent
+    if cols and world > 1:
+        pa.allreduce_sum_(b.torch())  # column shards: b = sum_p A[:, J_p] x_true[J_p]
     b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
     comm = None
     if world > 1 or args.force_comm:
         comm = (pa.NativeRcclComm(overlap=args.overlap) if args.collective == "native"
-                else pa.TorchDistributedComm(overlap=args.overlap))
+                else pa.TorchDistributedComm(overlap=args.overlap, shard="cols" if cols else "rows"))
     f = pa.LeastSquares(A, b, comm=comm)
-    zero_n = pa.HIPVector.zeros(n, dtype, ctx)
-    _, g0 = f.value_and_gradient(zero_n)  # = -A'b (all-reduced over the shards)
-    lam = dtype(0.1) * g0.norm_inf()  # test_lasso_small.jl:29
+    zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)
+    _, g0 = f.value_and_gradient(zero_n)  # = -A'b (row shards: all-reduced; column shards: this rank's columns)
+    g0_inf = float(g0.norm_inf())
+    if cols:
+        g0_inf = allreduce_scalar(g0_inf, dist.ReduceOp.MAX)
+    lam = dtype(0.1) * dtype(g0_inf)  # test_lasso_small.jl:29
     Lf = None
     if args.mode == "fixed":
         f0 = pa.LeastSquares(A, pa.HIPVector.zeros(m_loc, dtype, ctx), comm=comm)  # x -> A'A x
-        v = pa.HIPVector.zeros(n, dtype, ctx).fill_(1.0 / math.sqrt(n))
+        v = pa.HIPVector.zeros(n_loc, dtype, ctx).fill_(1.0 / math.sqrt(n))
         w = v.similar()
         nrm = dtype(1)
         for _ in range(30):
             f0.value_and_gradient(v, out=w)
-            nrm = w.norm()
+            nrm2 = float(w.norm()) ** 2
+            if cols:
+                nrm2 = allreduce_scalar(nrm2, dist.ReduceOp.SUM)
+            nrm = dtype(math.sqrt(nrm2))
             v.axpby_(1.0 / float(nrm), w)
         Lf = dtype(1.1) * nrm  # ||A||^2 estimate (+10 % margin: power iteration under-estimates)
         del f0
@@ -304,21 +341,21 @@ def main():
     # the algorithmic figure counts the passes the mode REQUIRES when A x and A' r are separate sweeps (2 for
     # fixed-step FB / FFB and for adaptive FFB with the residual pair); the single-sweep iteration moves fewer bytes --
     # both are reported, labelled
-    passes_alg = max(2.0, sweeps) if args.sweeps == "two" or world > 1 else 2.0
-    bytes_iter_local = passes_alg * m_loc * n * es + 10 * n * es + 3 * m_loc * es
-    bytes_moved_local = sweeps * m_loc * n * es + 10 * n * es + 3 * m_loc * es
+    passes_alg = max(2.0, sweeps) if args.sweeps == "two" or (world > 1 and not cols) else 2.0
+    bytes_iter_local = passes_alg * m_loc * n_loc * es + 10 * n_loc * es + 3 * m_loc * es
+    bytes_moved_local = sweeps * m_loc * n_loc * es + 10 * n_loc * es + 3 * m_loc * es
     # dominant kernel = the slowest sweep over A; algorithmic bytes of one launch = the local A block + its vectors
     kern = {}
     n_cnt = prof["gemv_n_partial"][0]
-    for name, vec_bytes in (("gemv_n_partial", n * es), ("gemv_t", m_loc * es + n * es),
-                            ("gemv_tn", (m_loc + 7 * n) * es)):
+    for name, vec_bytes in (("gemv_n_partial", n_loc * es), ("gemv_t", m_loc * es + n_loc * es),
+                            ("gemv_tn", (m_loc + 7 * n_loc) * es)):
         cnt, ms = prof[name]
         if cnt:
             avg_ms = ms / cnt
             # with a collective attached pass T runs as several column-chunk launches per evaluation
             # (pg_gemv.hip ls_grad_stage_t): one launch then covers 1/chunks of the local block
             evals = max(a_passes - n_cnt - prof["gemv_tn"][0], 1) if name == "gemv_t" else cnt
-            launch_bytes = (m_loc * n * es + vec_bytes) * evals / cnt
+            launch_bytes = (m_loc * n_loc * es + vec_bytes) * evals / cnt
             kern[name] = {"launches": cnt, "avg_ms": avg_ms, "bytes": launch_bytes,
                           "launches_per_pass": cnt / evals, "GBps": launch_bytes / (avg_ms * 1e-3) / 1e9}
     dom = max(kern, key=lambda k_: kern[k_]["avg_ms"]) if kern else None
@@ -377,11 +414,13 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "FFB LASSO m=%d n=%d %s, %s step, rows of A sharded over %d GPU(s)"
-                                   % (m_glob, n, "Float32" if args.dtype == "f32" else "Float64", args.mode, world),
-                       "m": m_glob, "n": n, "mode": args.mode, "row_shards": world, "m_per_gpu": m_loc,
+            "config": {"workload": "FFB LASSO m=%d n=%d %s, %s step, %s of A sharded over %d GPU(s)"
+                                   % (m_glob, n, "Float32" if args.dtype == "f32" else "Float64", args.mode,
+                                      "columns" if cols else "rows", world),
+                       "m": m_glob, "n": n, "mode": args.mode, "sharding": sharding, "shards": world,
+                       "row_shards": 1 if cols else world, "m_per_gpu": m_loc, "n_per_gpu": n_loc,
                        "lambda": float(lam), "Lf": float(Lf) if Lf is not None else None, "seed": args.seed,
-                       "a_passes_per_step": a_passes / max(args.steps, 1), "sweeps": args.sweeps if world == 1 else "two",
+                       "a_passes_per_step": a_passes / max(args.steps, 1), "sweeps": args.sweeps if (world == 1 or cols) else "two",
                        "setup_s": round(t_setup, 2),
                        "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
                                  "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},

@@ -110,6 +110,12 @@ pg_status pg_ctx_set_allreduce_async(pg_ctx* ctx, pg_allreduce_fn begin, pg_allr
 pg_status pg_comm_get_unique_id(void* id_out /* PG_COMM_ID_BYTES */);
 pg_status pg_ctx_comm_init(pg_ctx* ctx, const void* id, int32_t nranks, int32_t rank, int32_t overlap);
 pg_status pg_ctx_comm_destroy(pg_ctx* ctx);
+/* Column sharding (the alternative to row sharding named in SURVEY 8(e)): rank `rank` of `nranks` holds the column block
+ * A[:, J_rank] and the J_rank slices of all n-vectors; b and the residual are replicated.  The registered collective
+ * (pg_ctx_set_allreduce / pg_ctx_comm_init) then carries A x (m elements) plus 4 * nranks scalar slots -- ONE all-reduce
+ * per iteration -- and A' r needs none, so the single-sweep iteration (pg_iter_opts.single_sweep) keeps working on
+ * every rank.  Fixed step sizes only.  nranks = 0 switches back to row sharding. */
+pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every
@@ -145,6 +151,8 @@ pg_status pg_mat_download(pg_mat* A, void* host_colmajor, int64_t ld_host); /* s
 /* synthetic instance of SURVEY 8(d): A[i,j] = ih8(seed, row_offset+i, j) * scale, identical
  * bit-for-bit to oracle/proxgrad_oracle.py::synthetic_matrix for every row shard */
 pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double scale);
+/* ... the block at (row_offset, col_offset) of the same global matrix (row shards use the first, column shards the second) */
+pg_status pg_mat_generate_block(pg_mat* A, uint32_t seed, int64_t row_offset, int64_t col_offset, double scale);
 pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int32_t* dtype, void** dptr);
 /* y = A x  (mul!(y, A, x)) and g = A' r  (mul!(g, A', r)) -- the two GEMV orientations on the
  * column-major store; used by LeastSquares and (later) PANOC's `mul!` with A: panoc.jl:150-190 */

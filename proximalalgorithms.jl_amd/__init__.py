@@ -21,7 +21,7 @@ from .operators import (Composed, IndBox, LeastSquares, LogisticLoss, NormL1, Se
                         Zero, gradient_, prox, prox_, value_and_gradient)
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
 from .panocplus import PANOCplus, PANOCplusIteration
-from .sharding import NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce_sum_, shard_rows
+from .sharding import NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce_sum_, shard_cols, shard_rows
 
 from .zerofpr import ZeroFPR, ZeroFPRIteration
 
@@ -36,5 +36,5 @@ __all__ = [
     "ProximalGradientIteration", "LBFGS", "LBFGSOperator", "AdaptiveNesterovSequence", "ConstantNesterovSequence",
     "FixedNesterovSequence", "SimpleNesterovSequence", "next_", "IndBox", "LeastSquares", "NormL1", "Zero",
     "gradient_", "prox", "prox_", "value_and_gradient", "NativeRcclComm", "ScaleComm", "TorchDistributedComm", "allreduce_sum_",
-    "shard_rows",
+    "shard_rows", "shard_cols",
 ]

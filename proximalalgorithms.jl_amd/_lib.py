@@ -63,6 +63,7 @@ SIGNATURES = {
     "pg_ctx_device_info": [_vp, C.POINTER(pg_device_info)],
     "pg_ctx_profile_enable": [_vp, _i32],
     "pg_ctx_profile_select": [_vp, C.c_uint32],
+    "pg_ctx_set_column_sharding": [_vp, _i32, _i32],
     "pg_ctx_profile_reset": [_vp],
     "pg_ctx_profile_read": [_vp, _i32, C.POINTER(_i64), _pf64],
     "pg_malloc": [_vp, _sz, C.POINTER(_vp)],
@@ -77,6 +78,7 @@ SIGNATURES = {
     "pg_mat_set_from_device": [_vp, _vp, _i64],
     "pg_mat_download": [_vp, _vp, _i64],
     "pg_mat_generate": [_vp, C.c_uint32, _i64, _f64],
+    "pg_mat_generate_block": [_vp, C.c_uint32, _i64, _i64, _f64],
     "pg_mat_info": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_vp)],
     "pg_mat_mul": [_vp, _vp, _vp],
     "pg_mat_mul_adjoint": [_vp, _vp, _vp],

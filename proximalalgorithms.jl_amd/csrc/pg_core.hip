@@ -109,6 +109,15 @@ pg_status pg_ctx_profile_enable(pg_ctx* c, int32_t enable) {
   return PG_OK;
 }
 
+pg_status pg_ctx_set_column_sharding(pg_ctx* c, int32_t nranks, int32_t rank) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  PG_REQUIRE(nranks >= 0 && (nranks == 0 || (rank >= 0 && rank < nranks)), "rank out of range");
+  c->shard_cols = nranks > 0 ? 1 : 0;
+  c->shard_nranks = nranks > 0 ? nranks : 1;
+  c->shard_rank = nranks > 0 ? rank : 0;
+  return PG_OK;
+}
+
 pg_status pg_ctx_profile_select(pg_ctx* c, uint32_t kind_mask) {
   PG_REQUIRE(c != nullptr, "ctx is null");
   c->prof_mask = kind_mask;
@@ -274,7 +283,7 @@ __device__ __forceinline__ int pg_ih8(uint32_t hseed, uint32_t i, uint32_t j) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void generate_kernel(T* __restrict__ A, int64_t m, int64_t n, int64_t ld,
-                                                       uint32_t hseed, uint32_t row_offset, float scale) {
+                                                       uint32_t hseed, uint32_t row_offset, uint32_t col_offset, float scale) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
   const int64_t vec_per_col = ld / VEC;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256) void generate_kernel(T* __restrict__ A, int64_
     for (int e = 0; e < VEC; ++e) {
       const int64_t i = i0 + e;
       float val = 0.0f;
-      if (i < m) val = (float)pg_ih8(hseed, row_offset + (uint32_t)i, (uint32_t)j) * scale;
+      if (i < m) val = (float)pg_ih8(hseed, row_offset + (uint32_t)i, col_offset + (uint32_t)j) * scale;
       v[e] = (T)val;
     }
     *reinterpret_cast<V*>(A + j * ld + i0) = v;
@@ -397,9 +406,10 @@ pg_status pg_mat_download(pg_mat* A, void* host, int64_t ld_host) {
   return PG_OK;
 }
 
-pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double scale) {
+pg_status pg_mat_generate_block(pg_mat* A, uint32_t seed, int64_t row_offset, int64_t col_offset, double scale) {
   PG_REQUIRE(A != nullptr, "matrix is null");
   PG_REQUIRE(row_offset >= 0 && row_offset + A->m <= (int64_t)1 << 32, "row_offset out of range");
+  PG_REQUIRE(col_offset >= 0 && col_offset + A->n <= (int64_t)1 << 32, "col_offset out of range");
   if (A->m == 0 || A->n == 0) return PG_OK;
   const uint32_t hseed = host_mix32(seed ^ 0x9E3779B9u);
   const int64_t vecs = A->ld / (16 / (int64_t)pg_sizeof(A->dtype)) * A->n;
@@ -407,13 +417,17 @@ pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double s
   const int64_t cap = (int64_t)A->ctx->num_cu * 32;
   if (blocks > cap) blocks = cap;
   if (A->dtype == PG_F32)
-    hipLaunchKernelGGL(generate_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream,
-                       (float*)A->data, A->m, A->n, A->ld, hseed, (uint32_t)row_offset, (float)scale);
+    hipLaunchKernelGGL(generate_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream, (float*)A->data, A->m,
+                       A->n, A->ld, hseed, (uint32_t)row_offset, (uint32_t)col_offset, (float)scale);
   else
-    hipLaunchKernelGGL(generate_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream,
-                       (double*)A->data, A->m, A->n, A->ld, hseed, (uint32_t)row_offset, (float)scale);
+    hipLaunchKernelGGL(generate_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream, (double*)A->data, A->m,
+                       A->n, A->ld, hseed, (uint32_t)row_offset, (uint32_t)col_offset, (float)scale);
   PG_LAUNCH_CHECK();
   return PG_OK;
+}
+
+pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double scale) {
+  return pg_mat_generate_block(A, seed, row_offset, 0, scale);
 }
 
 pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int32_t* dtype, void** dptr) {

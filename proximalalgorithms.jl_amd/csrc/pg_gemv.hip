@@ -737,6 +737,116 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   return PG_ERR_UNSUPPORTED;
 }
 
+// all-reduce helper
+pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
+  if (!c->allreduce) {
+    if (c->allreduce_begin && c->allreduce_wait) {  // only the asynchronous pair is registered
+      int rc = c->allreduce_begin(c->allreduce_user, buf, count, dtype, (void*)c->stream);
+      if (rc == 0) rc = c->allreduce_wait(c->allreduce_user, (void*)c->stream);
+      if (rc != 0) {
+        pg_set_error("all-reduce callback failed with code %d", rc);
+        return PG_ERR_COLLECTIVE;
+      }
+    }
+    return PG_OK;
+  }
+  int rc = c->allreduce(c->allreduce_user, buf, count, dtype, (void*)c->stream);
+  if (rc != 0) {
+    pg_set_error("all-reduce callback failed with code %d", rc);
+    return PG_ERR_COLLECTIVE;
+  }
+  return PG_OK;
+}
+
+// ---- column sharding ---------------------------------------------------------------------------------------------
+// This rank holds A[:, J_p] and the J_p slices of every n-vector; m-vectors are replicated.  What crosses ranks:
+//   * A x: every rank's partial A[:, J_p] x[J_p] (m elements), SUM all-reduce, then - b and the norm locally;
+//   * the four epilogue scalars { g(z), ||res||_inf, <g, res>, ||res||^2 }: each rank writes its values into its own
+//     group of four slots of a zeroed 4 * nranks vector; the SUM all-reduce then acts as an all-gather and every rank
+//     combines the groups in rank order (sum, max, sum, sum) -- one collective, deterministic, no MAX reduction needed.
+// A' r needs no collective at all (the columns are local), which is what lets the single-sweep iteration run with ONE
+// all-reduce of m + 4 * nranks elements per iteration.
+template <typename T>
+__global__ void col_pack_scalars_kernel(T* __restrict__ slots, int nranks, int rank, const double* __restrict__ s4) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 4 * nranks) slots[t] = (t >> 2) == rank ? (T)s4[t & 3] : T(0);
+}
+
+template <typename T>
+__global__ void col_unpack_scalars_kernel(const T* __restrict__ slots, int nranks, double* __restrict__ s4) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double gz = 0.0, ri = 0.0, dg = 0.0, rs = 0.0;
+  for (int p = 0; p < nranks; ++p) {
+    gz += (double)slots[4 * p + 0];
+    ri = fmax(ri, (double)slots[4 * p + 1]);
+    dg += (double)slots[4 * p + 2];
+    rs += (double)slots[4 * p + 3];
+  }
+  s4[0] = gz;
+  s4[1] = ri;
+  s4[2] = dg;
+  s4[3] = rs;
+}
+
+template <typename T>
+pg_status col_ensure_cbuf(pg_ls* f) {
+  if (f->cbuf) return PG_OK;
+  const size_t bytes = ((size_t)f->A->ld + 4 * (size_t)f->ctx->shard_nranks + 64) * sizeof(T);
+  hipError_t e = hipMalloc(&f->cbuf, bytes);
+  if (e != hipSuccess) {
+    pg_set_error("hipMalloc for the column-sharding payload failed: %s", hipGetErrorString(e));
+    return PG_ERR_ALLOC;
+  }
+  return PG_OK;
+}
+
+// dscal[PG_S_GZ..PG_S_RESSQ]: local values in, global values out
+template <typename T>
+pg_status col_allreduce_scalars_t(pg_ls* f) {
+  pg_ctx* c = f->ctx;
+  PG_TRY(col_ensure_cbuf<T>(f));
+  T* slots = (T*)f->cbuf + f->A->ld;
+  const int nr = c->shard_nranks;
+  hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((4 * nr + 63) / 64), dim3(64), 0, c->stream, slots, nr, c->shard_rank,
+                     (const double*)(c->dscal + PG_S_GZ));
+  PG_LAUNCH_CHECK();
+  PG_TRY(do_allreduce(c, slots, 4 * nr, f->A->dtype));
+  hipLaunchKernelGGL(col_unpack_scalars_kernel<T>, dim3(1), dim3(64), 0, c->stream, (const T*)slots, nr, c->dscal + PG_S_GZ);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+template <typename T>
+pg_status ls_residual_t(pg_ls* f, const T* x) {
+  pg_mat* A = f->A;
+  if (pg_col_sharded(f->ctx)) {  // r = sum_p A[:, J_p] x[J_p] - b
+    PG_TRY(gemv_n<T>(A, x, (const T*)nullptr, (T*)f->r, A->ld, false, 0.0, (T*)nullptr));
+    PG_TRY(do_allreduce(f->ctx, f->r, A->m, A->dtype));
+    PG_TRY(pg_residual_combo_async(f->ctx, A->dtype, A->m, f->r, 1.0, f->r, -1.0, f->b, 0.5 * f->lam, nullptr));
+    f->a_passes += 1;
+    f->r_gen++;
+    return PG_OK;
+  }
+  T* f_typed = pg_row_sharded(f->ctx) ? ((T*)f->gbuf + A->n) : nullptr;
+  PG_TRY(gemv_n<T>(A, x, (const T*)f->b, (T*)f->r, A->ld, true, 0.5 * f->lam, f_typed));
+  f->a_passes += 1;
+  f->r_gen++;
+  return PG_OK;
+}
+
+template <typename T>
+pg_status ls_value_t(pg_ls* f, const T* x) {
+  PG_TRY(ls_residual_t<T>(f, x));
+  pg_ctx* c = f->ctx;
+  if (pg_row_sharded(c)) {
+    T* ft = (T*)f->gbuf + f->A->n;
+    PG_TRY(do_allreduce(c, ft, 1, f->A->dtype));
+    hipLaunchKernelGGL(cast_scalar_kernel<T>, dim3(1), dim3(1), 0, c->stream, (const T*)ft, c->dscal + PG_S_F);
+    PG_LAUNCH_CHECK();
+  }
+  return PG_OK;
+}
+
 // One sweep: g = lam A' r (r = f->r, the residual of x), epilogue for (x, g, gamma), v = z + beta (z - z_old),
 // then f->r = A v - b and dscal[PG_S_F] = lam/2 ||A v - b||^2; epilogue scalars -> dscal[PG_S_GZ..PG_S_RESSQ]
 template <typename T>
@@ -744,10 +854,13 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
                           double beta, int g_kind, double g_p0, double g_p1, T* g_out, T* y, T* z_new, T* res, T* v_out) {
   pg_ctx* c = f->ctx;
   pg_mat* A = f->A;
-  if (c->allreduce != nullptr || c->allreduce_begin != nullptr || !tn_supported<T>(A)) {
-    pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(128 * 1024 / sizeof(T)));
+  if (pg_row_sharded(c) || !tn_supported<T>(A)) {
+    pg_set_error("the single-sweep pass needs an unsharded or column-sharded operator with at most %d rows",
+                 (int)(128 * 1024 / sizeof(T)));
     return PG_ERR_UNSUPPORTED;
   }
+  const bool cols = pg_col_sharded(c);
+  if (cols) PG_TRY(col_ensure_cbuf<T>(f));
   TNArgs<T> a;
   a.A = (const T*)A->data;
   a.ld = A->ld;
@@ -779,6 +892,29 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   f->a_passes += 1;
   int64_t fb = (A->ld + 63) / 64;
   if (fb > 1024) fb = 1024;
+  if (cols) {
+    // [sum of the workgroup partials of A[:, J_p] v[J_p] ; this rank's four scalars in its slots] -> ONE all-reduce ->
+    // r = . - b and its norm ; scalars combined in rank order
+    T* payload = (T*)f->cbuf;
+    const int nr = c->shard_nranks;
+    {
+      pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+      hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
+                         (const T*)A->partials, A->ld, A->m, blocks, (const T*)nullptr, payload, A->ld, 0.0,
+                         (double*)nullptr, (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+      PG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((4 * nr + 63) / 64), dim3(64), 0, c->stream, payload + A->ld, nr,
+                       c->shard_rank, (const double*)(c->dscal + PG_S_GZ));
+    PG_LAUNCH_CHECK();
+    PG_TRY(do_allreduce(c, payload, A->ld + 4 * nr, A->dtype));
+    PG_TRY(pg_residual_combo_async(c, A->dtype, A->m, r_dst, 1.0, payload, -1.0, f->b, 0.5 * f->lam, nullptr, f_dst));
+    hipLaunchKernelGGL(col_unpack_scalars_kernel<T>, dim3(1), dim3(64), 0, c->stream, (const T*)(payload + A->ld), nr,
+                       c->dscal + PG_S_GZ);
+    PG_LAUNCH_CHECK();
+    if (r_dst == (T*)f->r) f->r_gen++;
+    return PG_OK;
+  }
   pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
   hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
                      (const T*)A->partials, A->ld, A->m, blocks, (const T*)f->b, r_dst,
@@ -786,50 +922,6 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
                      c->red_partials, c->red_counter, f_dst, (T*)nullptr);
   PG_LAUNCH_CHECK();
   if (r_dst == (T*)f->r) f->r_gen++;
-  return PG_OK;
-}
-
-// all-reduce helper
-pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
-  if (!c->allreduce) {
-    if (c->allreduce_begin && c->allreduce_wait) {  // only the asynchronous pair is registered
-      int rc = c->allreduce_begin(c->allreduce_user, buf, count, dtype, (void*)c->stream);
-      if (rc == 0) rc = c->allreduce_wait(c->allreduce_user, (void*)c->stream);
-      if (rc != 0) {
-        pg_set_error("all-reduce callback failed with code %d", rc);
-        return PG_ERR_COLLECTIVE;
-      }
-    }
-    return PG_OK;
-  }
-  int rc = c->allreduce(c->allreduce_user, buf, count, dtype, (void*)c->stream);
-  if (rc != 0) {
-    pg_set_error("all-reduce callback failed with code %d", rc);
-    return PG_ERR_COLLECTIVE;
-  }
-  return PG_OK;
-}
-
-template <typename T>
-pg_status ls_residual_t(pg_ls* f, const T* x) {
-  pg_mat* A = f->A;
-  T* f_typed = (f->ctx->allreduce || f->ctx->allreduce_begin) ? ((T*)f->gbuf + A->n) : nullptr;
-  PG_TRY(gemv_n<T>(A, x, (const T*)f->b, (T*)f->r, A->ld, true, 0.5 * f->lam, f_typed));
-  f->a_passes += 1;
-  f->r_gen++;
-  return PG_OK;
-}
-
-template <typename T>
-pg_status ls_value_t(pg_ls* f, const T* x) {
-  PG_TRY(ls_residual_t<T>(f, x));
-  pg_ctx* c = f->ctx;
-  if (c->allreduce || c->allreduce_begin) {
-    T* ft = (T*)f->gbuf + f->A->n;
-    PG_TRY(do_allreduce(c, ft, 1, f->A->dtype));
-    hipLaunchKernelGGL(cast_scalar_kernel<T>, dim3(1), dim3(1), 0, c->stream, (const T*)ft, c->dscal + PG_S_F);
-    PG_LAUNCH_CHECK();
-  }
   return PG_OK;
 }
 
@@ -844,7 +936,7 @@ pg_status ls_grad_stage_t(pg_ls* f, T* grad_out) {
   // dscal[PG_S_F] / gbuf[n]), then the all-reduce of [grad ; f] when the rows are sharded
   pg_ctx* c = f->ctx;
   pg_mat* A = f->A;
-  const bool sharded = c->allreduce != nullptr || c->allreduce_begin != nullptr;
+  const bool sharded = pg_row_sharded(c);  // column shards own their columns: A' r is local
   T* gdst = sharded ? (T*)f->gbuf : grad_out;
   const int64_t rows_per_rg = 1024 / (int64_t)sizeof(T);
   const int n_rowgroups = (int)(A->ld / rows_per_rg);
@@ -852,7 +944,7 @@ pg_status ls_grad_stage_t(pg_ls* f, T* grad_out) {
   // asynchronously (RCCL's own stream) as soon as its columns are done and overlaps pass T of chunk k+1; only the
   // last chunk's collective is exposed.  The payload's trailing f rides with the last chunk.
   int K = env_int("PG_ALLREDUCE_CHUNKS", 4);
-  const bool pipelined = c->allreduce_begin != nullptr && c->allreduce_wait != nullptr && K > 1 && A->m > 0 &&
+  const bool pipelined = sharded && c->allreduce_begin != nullptr && c->allreduce_wait != nullptr && K > 1 && A->m > 0 &&
                          (int64_t)n_rowgroups * 1024 <= LDS_R_BYTES && A->n >= (int64_t)K * 4096;
   if (pipelined) {
     const int64_t per = (A->n / K + 255) / 256 * 256;  // keep chunk starts 1 KiB aligned
@@ -927,9 +1019,14 @@ pg_status pg_ls_fused_pass_async(pg_ls* f, const void* r_src, void* r_dst, doubl
                                        (double*)res, (double*)v_next);
 }
 
+pg_status pg_ls_allreduce_epilogue_scalars(pg_ls* f) {
+  if (!pg_col_sharded(f->ctx)) return PG_OK;
+  return f->A->dtype == PG_F32 ? col_allreduce_scalars_t<float>(f) : col_allreduce_scalars_t<double>(f);
+}
+
 bool pg_ls_fused_pass_supported(const pg_ls* f) {
   const pg_ctx* c = f->ctx;
-  if (c->allreduce != nullptr || c->allreduce_begin != nullptr) return false;
+  if (pg_row_sharded(c)) return false;
   return f->A->dtype == PG_F32 ? tn_supported<float>(f->A) : tn_supported<double>(f->A);
 }
 
@@ -1007,6 +1104,7 @@ pg_status pg_ls_destroy(pg_ls* f) {
   if (f->r) (void)hipFree(f->r);
   if (f->gbuf) (void)hipFree(f->gbuf);
   if (f->gchunks) (void)hipFree(f->gchunks);
+  if (f->cbuf) (void)hipFree(f->cbuf);
   delete f;
   return PG_OK;
 }

@@ -94,6 +94,9 @@ struct pg_ctx {
   pg_allreduce_wait_fn allreduce_wait = nullptr;
   void* allreduce_user = nullptr;
   pg_comm* comm = nullptr;  // native RCCL path (optional)
+  // column sharding (pg_ctx_set_column_sharding): this rank holds a column block of A and the matching slices of all
+  // n-vectors; m-vectors are replicated and what crosses ranks is A x (m elements) and four epilogue scalars
+  int shard_cols = 0, shard_nranks = 1, shard_rank = 0;
   double* small_out = nullptr;       // result block of the single-workgroup solver (device address)
   double* small_out_host = nullptr;  //   ... mapped pinned host memory
   void* coop_ws = nullptr;           // workspace of the cooperative solver (barrier counter, partials)
@@ -132,9 +135,14 @@ struct pg_ls {
   void* r = nullptr;     // [ld] residual A x - b
   void* gbuf = nullptr;  // [n + 1] gradient ++ f, the all-reduce payload
   void* gchunks = nullptr;  // [nchunks * n] partial gradients when m needs several LDS chunks
+  void* cbuf = nullptr;     // [ld + 4 * nranks] column sharding: the all-reduce payload [A x partial ; scalar slots]
   int64_t a_passes = 0;     // telemetry: full reads of A
   uint64_t r_gen = 0;       // bumped whenever r is rewritten (single-sweep iterations check their speculation)
 };
+
+// which way a registered collective is used
+static inline bool pg_row_sharded(const pg_ctx* c) { return (c->allreduce != nullptr || c->allreduce_begin != nullptr) && !c->shard_cols; }
+static inline bool pg_col_sharded(const pg_ctx* c) { return (c->allreduce != nullptr || c->allreduce_begin != nullptr) && c->shard_cols; }
 
 static inline size_t pg_sizeof(int dtype) { return dtype == PG_F64 ? 8 : 4; }
 static inline int64_t pg_round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
@@ -163,7 +171,9 @@ bool pg_ls_fused_pass_supported(const pg_ls* f);
 pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out);
 // r_out = a r1 + b r2 over m elements, dscal[PG_S_F] = f_scale ||r_out||^2, optional typed mirror of f
 pg_status pg_residual_combo_async(pg_ctx* ctx, int dtype, int64_t m, void* r_out, double a, const void* r1, double b,
-                                  const void* r2, double f_scale, void* f_typed);
+                                  const void* r2, double f_scale, void* f_typed, double* f_dst = nullptr);
+// column sharding: global sums / max of the four epilogue scalars in dscal[PG_S_GZ..PG_S_RESSQ] (one small all-reduce)
+pg_status pg_ls_allreduce_epilogue_scalars(pg_ls* f);
 pg_status pg_fb_epilogue_async(pg_ctx* ctx, int dtype, int64_t n, const void* x, const void* grad, double gamma,
                                int g_kind, double g_p0, double g_p1, void* y, void* z, void* res);
 

@@ -46,6 +46,7 @@ pg_status epilogue_and_read(pg_iter* it, bool read_f) {
   pg_ctx* c = it->ctx;
   PG_TRY(pg_fb_epilogue_async(c, it->dtype, it->n, it->x, it->grad_f_x, it->gamma, it->o.g_kind, it->o.g_p0,
                               it->o.g_p1, it->y, it->z, it->res));
+  PG_TRY(pg_ls_allreduce_epilogue_scalars(it->f));  // column shards: the kernel's sums cover this rank's columns only
   if (it->defer_sync) return PG_OK;  // scalars stay on the device side until the batch is synchronised
   PG_TRY(pg_read_scalars(c, PG_S_F, 5));
   if (read_f) it->f_x = Arith<T>::r(c->hscal[PG_S_F]);
@@ -319,7 +320,7 @@ pg_status iter_step(pg_iter* it, double host_beta) {
       // :138-139 without re-reading A for A*x:  A x - b = (1 + beta)(A z - b) - beta (A z_prev - b); the line
       // search has just produced A z - b.  One pass (A' r) instead of two.
       pg_ls* f = it->f;
-      void* f_typed = (it->ctx->allreduce || it->ctx->allreduce_begin) ? (void*)((char*)f->gbuf + (size_t)f->A->n * sizeof(T)) : nullptr;
+      void* f_typed = pg_row_sharded(it->ctx) ? (void*)((char*)f->gbuf + (size_t)f->A->n * sizeof(T)) : nullptr;
       PG_TRY(pg_residual_combo_async(it->ctx, it->dtype, f->A->m, f->r, (double)(T(1) + (T)it->beta),
                                      it->rz, (double)(-(T)it->beta), it->rz_prev, 0.5 * f->lam, f_typed));
       PG_TRY(pg_ls_grad_stage_async(f, it->grad_f_x));
@@ -371,6 +372,12 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   // adaptive::Bool = gamma === nothing        forward_backward.jl:43-44
   const bool gamma_known = (o->gamma > 0) || (o->Lf > 0);
   it->adaptive = o->adaptive < 0 ? !gamma_known : (o->adaptive != 0);
+  if (pg_col_sharded(c) && (it->adaptive || !gamma_known)) {
+    delete it;
+    pg_set_error("column-sharded operators iterate with a fixed step (give Lf or gamma): the line search and the "
+                 "step-size estimate reduce over n-vectors that are distributed");
+    return PG_ERR_UNSUPPORTED;
+  }
   const size_t vb = vec_bytes(it);
   const bool reuse = o->fast && o->reuse_residual != 0;
   // one read of A per iteration where the fused sweep applies: FB / FFB with a fixed step, FFB adaptive with the residual

@@ -652,14 +652,15 @@ pg_status finish_scalar(pg_ctx* c, int slot, double* out) {
 }  // namespace
 
 pg_status pg_residual_combo_async(pg_ctx* c, int dtype, int64_t m, void* r_out, double a, const void* r1, double b,
-                                  const void* r2, double f_scale, void* f_typed) {
+                                  const void* r2, double f_scale, void* f_typed, double* f_dst) {
   const bool v = aligned16(r_out) && aligned16(r1) && aligned16(r2);
+  if (f_dst == nullptr) f_dst = c->dscal + PG_S_F;
   if (dtype == PG_F32) {
     ResidualComboF<float> f{(float*)r_out, (const float*)r1, (const float*)r2, (float)a, (float)b, f_scale, (float*)f_typed};
-    return launch_ew<float, ResidualComboF<float>, 1, 0u>(c, m, v, f, c->dscal + PG_S_F);
+    return launch_ew<float, ResidualComboF<float>, 1, 0u>(c, m, v, f, f_dst);
   }
   ResidualComboF<double> f{(double*)r_out, (const double*)r1, (const double*)r2, a, b, f_scale, (double*)f_typed};
-  return launch_ew<double, ResidualComboF<double>, 1, 0u>(c, m, v, f, c->dscal + PG_S_F);
+  return launch_ew<double, ResidualComboF<double>, 1, 0u>(c, m, v, f, f_dst);
 }
 
 pg_status pg_fb_epilogue_async(pg_ctx* c, int dtype, int64_t n, const void* x, const void* grad, double gamma,

@@ -57,6 +57,10 @@ class Context:
                 "lds_bytes_per_cu": info.lds_bytes_per_cu, "global_mem_bytes": info.global_mem_bytes,
                 "clock_khz": info.clock_khz, "arch": info.arch.decode(), "name": info.name.decode()}
 
+    def set_column_sharding(self, nranks, rank):
+        """This context's operators hold a COLUMN block of A (see pg_ctx_set_column_sharding); nranks = 0: row sharding."""
+        call("pg_ctx_set_column_sharding", self._h, int(nranks), int(rank))
+
     def profile(self, enable=True, kernels=None):
         """Bracket kernel launches with HIP event pairs; ``kernels``: names from _lib.KERNEL_NAMES to restrict the
         pairs to (every pair is a marker packet on the stream), default all."""
@@ -352,15 +356,16 @@ class HIPMatrix:
         return M
 
     @classmethod
-    def synthetic(cls, m, n, dtype=np.float32, seed=0, row_offset=0, m_global=None, ctx=None):
-        """SURVEY 8(d) instance, generated on the device; bit-identical to the oracle's generator."""
+    def synthetic(cls, m, n, dtype=np.float32, seed=0, row_offset=0, m_global=None, ctx=None, col_offset=0):
+        """SURVEY 8(d) instance, generated on the device; bit-identical to the oracle's generator.  (row_offset,
+        col_offset): position of this m x n block in the global matrix (row / column shards)."""
         import math
 
         m_global = m if m_global is None else m_global
         ih8_std = 65536.0 * math.sqrt(8.0 / 12.0) * math.sqrt(1.0 - 1.0 / 65536.0**2)
         scale = float(np.float32(1.0 / (ih8_std * math.sqrt(m_global))))
         M = cls(m, n, dtype, ctx)
-        call("pg_mat_generate", M._h, C.c_uint32(seed & 0xFFFFFFFF), int(row_offset), scale)
+        call("pg_mat_generate_block", M._h, C.c_uint32(seed & 0xFFFFFFFF), int(row_offset), int(col_offset), scale)
         return M
 
     def info(self):

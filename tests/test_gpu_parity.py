@@ -543,18 +543,29 @@ def test_bench_line_contract(pa, cpu_mode):
     assert ("full workload" in c["sample"]) == (cpu_mode == "full")
 
 
-@pytest.mark.parametrize("mode,overlap", [("fixed", False), ("adaptive", False), ("fixed", True)])
-def test_two_ranks_one_gpu_matches_single_rank(pa, mode, overlap):
-    """bench.py with 2 processes (row shards of 1024 rows each) sharing cuda:0 over gloo == 1 process:
-    same lambda / Lf (they come from all-reduced quantities) and the same iterate after 14 steps."""
+@pytest.mark.parametrize("mode,sharding,overlap", [("fixed", "rows", False), ("adaptive", "rows", False), ("fixed", "rows", True),
+                                                   ("fixed", "cols", False), ("fixed", "auto", False)])
+def test_two_ranks_one_gpu_matches_single_rank(pa, mode, sharding, overlap):
+    """bench.py with 2 processes sharing cuda:0 over gloo == 1 process: same lambda / Lf (they come from all-reduced
+    quantities) and the same iterate after 14 steps -- row shards (1024 rows each, two sweeps, [grad ; f] all-reduced)
+    and column shards (8192 columns each, the single-sweep iteration with one all-reduce of m + 8 elements)."""
     one = _run_bench(["--mode", mode, "--sweeps", "two"])
     one_ss = _run_bench(["--mode", mode])  # single sweep (default): same problem, same answers, half the reads of A
     assert one_ss["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1) and one["config"]["a_passes_per_step"] >= 2
     assert one_ss["config"]["final"]["f_x"] == pytest.approx(one["config"]["final"]["f_x"], rel=2e-4)
     assert one_ss["config"]["final"]["g_z"] == pytest.approx(one["config"]["final"]["g_z"], rel=2e-4)
     assert one_ss["roofline"]["kernel"] == "gemv_tn"
-    two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device"] + (["--overlap"] if overlap else []), nproc=2)
-    assert two["n_gpus"] == 2 and two["config"]["m_per_gpu"] * 2 == one["config"]["m"]
+    two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", sharding] +
+                     (["--overlap"] if overlap else []), nproc=2)
+    assert two["n_gpus"] == 2
+    cols = sharding in ("cols", "auto")
+    assert two["config"]["sharding"] == ("cols" if cols else "rows")
+    if cols:
+        assert two["config"]["n_per_gpu"] * 2 == one["config"]["n"] and two["config"]["m_per_gpu"] == one["config"]["m"]
+        assert two["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1) and two["roofline"]["kernel"] == "gemv_tn"
+    else:
+        assert two["config"]["m_per_gpu"] * 2 == one["config"]["m"]
+        assert two["config"]["a_passes_per_step"] == one["config"]["a_passes_per_step"]
     assert two["config"]["lambda"] == pytest.approx(one["config"]["lambda"], rel=1e-5)
     if mode == "fixed":
         assert two["config"]["Lf"] == pytest.approx(one["config"]["Lf"], rel=1e-4)
@@ -562,7 +573,7 @@ def test_two_ranks_one_gpu_matches_single_rank(pa, mode, overlap):
     assert f2["gamma"] == pytest.approx(f1["gamma"], rel=1e-4)
     assert f2["f_x"] == pytest.approx(f1["f_x"], rel=2e-4)
     assert f2["g_z"] == pytest.approx(f1["g_z"], rel=2e-4)
-    assert two["config"]["a_passes_per_step"] == one["config"]["a_passes_per_step"]
+    assert f2["res_inf_over_gamma"] == pytest.approx(f1["res_inf_over_gamma"], rel=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------
