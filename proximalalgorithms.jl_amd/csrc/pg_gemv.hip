@@ -277,6 +277,33 @@ struct TNArgs {
 };
 
 template <typename T, int U, int C, int WAVES>
+struct TNTile {
+  using V = typename VecOf<T>::type;
+  static constexpr int VEC = VecOf<T>::N;
+  V col[C][U];
+
+  // this wave's row groups u * WAVES + wave of the C columns of group cg
+  __device__ __forceinline__ void load(const TNArgs<T>& a, int64_t cg, int wave, int lane) {
+    const int64_t j0 = cg * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
+      const T* __restrict__ p = a.A + j * a.ld + lane * VEC;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rg = u * WAVES + wave;
+        if (rg < a.nrg) {
+          col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rg * (WAVE * VEC)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) col[c][u][e] = T(0);
+        }
+      }
+    }
+  }
+};
+
+template <typename T, int U, int C, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -300,26 +327,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
     }
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  int buf = 0;
-  for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
+
+  // one column group: dot products -> workgroup totals (fixed wave order) -> epilogue -> next-residual accumulation
+  auto process = [&](const TNTile<T, U, C, WAVES>& t, int64_t cg, int buf) {
     const int64_t j0 = cg * C;
-    V col[C][U];
+    // the per-column scalars are fetched before the barrier so that their latency hides behind the dot products
+    T xs[C], zos[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
-      const T* __restrict__ p = a.A + j * a.ld + lane * VEC;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int rg = u * WAVES + wave;
-        if (rg < a.nrg) {
-          col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rg * (WAVE * VEC)));
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) col[c][u][e] = T(0);
-        }
-      }
+      const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
+      xs[c] = a.x[jc];
+      zos[c] = a.z_old[jc];
     }
-    // per-wave partial dot products, then the workgroup total in fixed wave order
     T dot[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) d = fma(col[c][u][e], rk[u][e], d);
+        for (int e = 0; e < VEC; ++e) d = fma(t.col[c][u][e], rk[u][e], d);
       }
       dot[c] = wave_allsum(d);
     }
@@ -343,9 +362,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
       for (int w = 1; w < WAVES; ++w) g += sm_dot[buf][c][w];
       const int64_t j = j0 + c;
       const bool valid = j < a.n;
-      const int64_t jc = valid ? j : (a.n - 1);
       if (a.lam_ls != T(1)) g = a.lam_ls * g;
-      const T xj = a.x[jc], zo = a.z_old[jc];
+      const T xj = xs[c], zo = zos[c];
       const T yj = xj - a.gamma * g;
       T zj;
       if (a.g_kind == PG_G_NORML1)
@@ -370,10 +388,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) racc[u][e] = fma(col[c][u][e], vj, racc[u][e]);
+        for (int e = 0; e < VEC; ++e) racc[u][e] = fma(t.col[c][u][e], vj, racc[u][e]);
       }
     }
-    buf ^= 1;
+  };
+
+  // two register tiles: the loads of the next column group are in flight while the current one is reduced, exchanged
+  // through LDS and folded into the next residual (the kernel would otherwise idle the memory system at every barrier)
+  TNTile<T, U, C, WAVES> ta, tb;
+  int64_t cg = blockIdx.x;
+  if (cg < ncg) ta.load(a, cg, wave, lane);
+  while (cg < ncg) {
+    const int64_t cg1 = cg + gridDim.x;
+    if (cg1 < ncg) tb.load(a, cg1, wave, lane);
+    process(ta, cg, 0);
+    if (cg1 >= ncg) break;
+    const int64_t cg2 = cg1 + gridDim.x;
+    if (cg2 < ncg) ta.load(a, cg2, wave, lane);
+    process(tb, cg1, 1);
+    cg = cg2;
   }
   T* part = a.partials + (int64_t)blockIdx.x * a.ld + lane * VEC;
 #pragma unroll
@@ -689,7 +722,7 @@ template <typename T, int U, int C, int WAVES>
 pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   const int64_t ncg = (A->n + C - 1) / C;
-  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", 2);
+  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", 1);
   if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
   if (blocks > ncg) blocks = ncg;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
@@ -717,7 +750,9 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int W = nrg <= 64 ? 4 : 8;
   int U = 1;
   while (U * W < nrg) U *= 2;
-  int C = env_int("PG_TN_C", 16 / U > 1 ? 16 / U : 1);
+  // two register tiles of C * U KiB per wave (one in flight, one being consumed), one workgroup per CU: the measured
+  // optimum (scripts/tune_tn.py) is C * U = 32 -- 7.0 TB/s at 16384 x 2^20, 6.8 TB/s at 8192 x 262144
+  int C = env_int("PG_TN_C", 32 / U > 1 ? 32 / U : 1);
   if (W == 8) C = 1;
 #define PG_TN_CASE(UU, CC, WW) \
   if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)
