@@ -237,7 +237,7 @@ def main():
     sharding = args.sharding
     if sharding == "auto":
         sharding = "cols" if (world > 1 or args.force_comm) and args.mode == "fixed" and args.sweeps == "one" and \
-            args.collective == "torch" else "rows"
+            args.collective == "torch" and args.scaling == "strong" else "rows"
     if world == 1 and not args.force_comm:
         sharding = "none"
     cols = sharding == "cols"

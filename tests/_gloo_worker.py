@@ -59,6 +59,55 @@ def main():
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         assert torch.equal(gathered[0], gathered[1])
+    # ---- column shards: the single-sweep protocol of csrc/pg_gemv.hip (ls_fused_pass_t, column mode) on the CPU ----
+    # every rank holds A[:, J_p] and the J_p slices of the n-vectors; per iteration ONE all-reduce of
+    # [partial of A v (m) ; 4 * world scalar slots]; the slots turn the SUM into an all-gather (sum, max, sum, sum)
+    for dtype in (np.float32, np.float64):
+        A, b, _ = o.synthetic_lasso(m, n, seed=0, dtype=dtype)
+        lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
+        Lf = dtype(1.05 * np.linalg.norm(A.astype(np.float64), 2) ** 2)
+        coff, ccnt = pa.shard_cols(n, world, rank)
+        A_loc = A[:, coff:coff + ccnt]
+        gamma = dtype(1) / Lf
+        ref = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(n, dtype), Lf=Lf))
+        s_ref = next(ref)
+
+        def exchange(part, scal):
+            slots = np.zeros(4 * world, dtype)
+            slots[4 * rank:4 * rank + 4] = scal
+            buf = torch.from_numpy(np.concatenate([part, slots]))
+            pa.allreduce_sum_(buf)
+            out = buf.numpy()
+            sl = out[m:].reshape(world, 4)
+            return out[:m].copy(), (sl[:, 0].sum(), sl[:, 1].max(), sl[:, 2].sum(), sl[:, 3].sum())
+
+        # init (state 1): x = x0, z = prox(x - gamma grad), z_prev = x   -- local slices
+        x = np.zeros(ccnt, dtype)
+        r, _ = exchange(A_loc @ x, np.zeros(4, dtype))
+        r = r - b
+        grad = A_loc.T @ r
+        z, _ = o.NormL1(lam).prox(x - gamma * grad, gamma)
+        z_prev = x.copy()
+        seq = o.AdaptiveNesterovSequence(dtype(0))
+        beta = seq.next(gamma)
+        x_next = z + beta * (z - z_prev)
+        r, _ = exchange(A_loc @ x_next, np.zeros(4, dtype))  # first half of iteration 2 on its own
+        r = r - b
+        for k in range(2, 40):
+            s_ref = next(ref)
+            x, z_prev = x_next, z
+            beta2 = seq.next(gamma)
+            grad = A_loc.T @ r  # local: the columns are ours
+            z, _ = o.NormL1(lam).prox(x - gamma * grad, gamma)
+            res = x - z
+            x_next = z + beta2 * (z - z_prev)
+            part, (gz, res_inf, dot_gr, res_sq) = exchange(
+                A_loc @ x_next, np.array([np.sum(np.abs(z)), np.max(np.abs(res)), grad @ res, res @ res], dtype))
+            r = part - b
+            tol = 2e-4 if dtype == np.float32 else 1e-10
+            assert np.max(np.abs(z - s_ref.z[coff:coff + ccnt])) <= tol * max(1.0, np.max(np.abs(s_ref.z))), k
+            assert abs(res_inf - np.max(np.abs(s_ref.res))) <= tol * max(1.0, np.max(np.abs(s_ref.res))), k
+            assert abs(lam * gz - s_ref.g_z) <= 10 * tol * max(1.0, abs(s_ref.g_z)), k
     dist.barrier()
     if rank == 0:
         print("GLOO_SHARDED_OK")

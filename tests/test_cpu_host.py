@@ -89,6 +89,7 @@ def test_shard_rows_partition():
             assert o0 + c0 == o1
         assert parts[-1][0] + parts[-1][1] == m
         assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+        assert parts == [pa.shard_cols(m, w, r) for r in range(w)]  # column shards use the same balanced partition
 
 
 def test_world_size_2_gloo_sharded_path():
