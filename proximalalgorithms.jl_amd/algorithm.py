@@ -50,7 +50,7 @@ class IterativeAlgorithm:
             coop_rows = 3 * (-(-A.m // 64) * 64) * A.dtype.itemsize <= 96 * 1024
             if unsharded and A.m * A.n <= 8192:
                 k, _ = fused.run_small(1, self.maxit, tol)
-            elif unsharded and coop_rows and nbytes <= ((16 << 20) if adaptive else (6 << 20)):
+            elif unsharded and coop_rows and nbytes <= ((10 << 20) if adaptive else (6 << 20)):
                 k, _ = fused.run_coop(1, self.maxit, tol)
             elif check_every > 1 and not adaptive:
                 k, _ = fused.run(1, self.maxit, tol, check_every=check_every)

@@ -268,7 +268,7 @@ function hip_solve(iter::HIPForwardBackwardIteration{R}; maxit = 10_000, tol = 1
     if A.m * A.n <= 8192
         check(ccall((:pg_iter_run_small, libpg), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Ref{Int64}, Ref{PgIterScalars}),
                     st.handle, 1, maxit, tol, k, sc))
-    elseif 3 * cld(A.m, 64) * 64 * sizeof(T) <= 96 * 1024 && nbytes <= (iter.adaptive ? 16 : 6) << 20
+    elseif 3 * cld(A.m, 64) * 64 * sizeof(T) <= 96 * 1024 && nbytes <= (iter.adaptive ? 10 : 6) << 20
         check(ccall((:pg_iter_run_coop, libpg), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Int32, Ref{Int64}, Ref{PgIterScalars}),
                     st.handle, 1, maxit, tol, 0, k, sc))
     else

@@ -13,12 +13,13 @@ for (m, n, dt) in ((100, 200, np.float64), (130, 300, np.float64), (300, 700, np
     row = []
     for kw in (dict(Lf=Lf), {}):
         res = {}
-        for name in ("coop", "coop", "host", "small"):
+        for name in ("coop", "coop", "host", "host1", "small"):
             if name == "small" and m * n > 2**20: continue
             it = pa.FastForwardBackwardIteration(f=f, g=g, x0=np.zeros(n, dt), **kw); next(iter(it)); gc.collect()
             t0 = time.perf_counter()
             if name == "coop": k, _ = it._fused.run_coop(1, 401, 0.0, 0)
             elif name == "small": k, _ = it._fused.run_small(1, 401, 0.0)
+            elif name == "host1": k, _ = it._fused.run(1, 401, 0.0)  # single-sweep steps, one sync per iteration
             else: k, _ = it._fused.run(1, 401, 0.0, check_every=(16 if kw else 1))
             res[name] = (k - 1) / (time.perf_counter() - t0)
         row.append({k_: round(v) for k_, v in res.items()})
