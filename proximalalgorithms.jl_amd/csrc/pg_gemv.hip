@@ -303,7 +303,7 @@ struct TNTile {
   }
 };
 
-template <typename T, int U, int C, int WAVES>
+template <typename T, int U, int C, int WAVES, bool DOUBLE_BUFFER>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -395,18 +395,28 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
 
   // two register tiles: the loads of the next column group are in flight while the current one is reduced, exchanged
   // through LDS and folded into the next residual (the kernel would otherwise idle the memory system at every barrier)
-  TNTile<T, U, C, WAVES> ta, tb;
-  int64_t cg = blockIdx.x;
-  if (cg < ncg) ta.load(a, cg, wave, lane);
-  while (cg < ncg) {
-    const int64_t cg1 = cg + gridDim.x;
-    if (cg1 < ncg) tb.load(a, cg1, wave, lane);
-    process(ta, cg, 0);
-    if (cg1 >= ncg) break;
-    const int64_t cg2 = cg1 + gridDim.x;
-    if (cg2 < ncg) ta.load(a, cg2, wave, lane);
-    process(tb, cg1, 1);
-    cg = cg2;
+  if constexpr (DOUBLE_BUFFER) {
+    TNTile<T, U, C, WAVES> ta, tb;
+    int64_t cg = blockIdx.x;
+    if (cg < ncg) ta.load(a, cg, wave, lane);
+    while (cg < ncg) {
+      const int64_t cg1 = cg + gridDim.x;
+      if (cg1 < ncg) tb.load(a, cg1, wave, lane);
+      process(ta, cg, 0);
+      if (cg1 >= ncg) break;
+      const int64_t cg2 = cg1 + gridDim.x;
+      if (cg2 < ncg) ta.load(a, cg2, wave, lane);
+      process(tb, cg1, 1);
+      cg = cg2;
+    }
+  } else {  // 8-wave workgroups have half the registers per wave: one tile, two workgroups per CU overlap instead
+    TNTile<T, U, C, WAVES> t;
+    int buf = 0;
+    for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
+      t.load(a, cg, wave, lane);
+      process(t, cg, buf);
+      buf ^= 1;
+    }
   }
   T* part = a.partials + (int64_t)blockIdx.x * a.ld + lane * VEC;
 #pragma unroll
@@ -722,7 +732,7 @@ template <typename T, int U, int C, int WAVES>
 pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   const int64_t ncg = (A->n + C - 1) / C;
-  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", 1);
+  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", WAVES == 4 ? 1 : 2);
   if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
   if (blocks > ncg) blocks = ncg;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
@@ -731,7 +741,7 @@ pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.partials = (T*)A->partials;
   *blocks_out = (int)blocks;
   pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
+  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES, WAVES == 4>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -754,6 +764,7 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // optimum (scripts/tune_tn.py) is C * U = 32 -- 7.0 TB/s at 16384 x 2^20, 6.8 TB/s at 8192 x 262144
   int C = env_int("PG_TN_C", 32 / U > 1 ? 32 / U : 1);
   if (W == 8) C = 1;
+  if (sizeof(T) == 8 && U == 1 && C > 16) C = 16;  // <f64, 1, 32> would spill
 #define PG_TN_CASE(UU, CC, WW) \
   if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)
   PG_TN_CASE(16, 1, 4);
