@@ -5,17 +5,21 @@
 
 A "step" is ONE FastForwardBackward iteration (fast_forward_backward.jl:106-145) of the fused HIP engine on
 the headline workload  m = 16384, n = 2^20, Float32, fixed step gamma = 1/Lf  (BASELINE.json north_star).
-A (64 GiB) is generated on the device and is resident in HBM before the timed region.  For N > 1 the driver
-launches one process per GPU with torch.distributed.run; rows of A are sharded over the N ranks (STRONG
-scaling: the global problem is fixed) and each gradient evaluation ends with one RCCL all-reduce of n+1
-floats.  Rank 0 prints ONE JSON line.
+A (64 GiB) is generated on the device and is resident in HBM before the timed region.  By default an iteration
+reads A ONCE (the single-sweep iteration: A' r, prox, next extrapolation and next residual per column while
+it is in registers); --sweeps two runs A x and A' r as separate sweeps like the reference.  For N > 1 the
+driver launches one process per GPU with torch.distributed.run (STRONG scaling: the global problem is fixed):
+column blocks of A are sharded over the N ranks, which keeps the single sweep on every GPU with ONE RCCL
+all-reduce of m + 4 N floats per iteration (--sharding rows: row blocks, two sweeps, n+1 floats per gradient
+evaluation -- north_star's layout, used for the adaptive mode and weak scaling).  Rank 0 prints ONE JSON line.
 
 Extra legs in the same line:
-  roofline      HBM roofline of the dominant kernel (the slower of the two GEMV passes over A), timed live with
-                HIP event pairs on the launch stream (pg_ctx_profile_*), algorithmic bytes = one full read of the
-                local A block + its vectors.
+  roofline      HBM roofline of the dominant kernel (the slowest sweep over A), timed live with HIP event pairs
+                on the launch stream (pg_ctx_profile_*), algorithmic bytes = one full read of the local A block +
+                its vectors; whole_iteration reports the SURVEY 8(d) two-pass figure and the bytes actually moved.
   cpu_baseline  the CPU restatement (oracle/, numpy + OpenBLAS, same unfused op order as the reference) timed on
-                this host on a bounded sample (same m, fewer columns), scaled to it/s of the full workload.
+                this host on the SAME workload (the device matrix copied to host memory) when memory allows, else
+                on a bounded column sample scaled to it/s of the full workload.
 """
 import argparse
 import ctypes
