@@ -757,13 +757,13 @@ bool tn_supported(const pg_mat* A) {
 template <typename T>
 pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int nrg = a.nrg;
-  const int W = nrg <= 64 ? 4 : 8;
+  const int W = env_int("PG_TN_WAVES", nrg <= 64 ? 4 : 8) == 8 ? 8 : 4;
   int U = 1;
   while (U * W < nrg) U *= 2;
   // two register tiles of C * U KiB per wave (one in flight, one being consumed), one workgroup per CU: the measured
   // optimum (scripts/tune_tn.py) is C * U = 32 -- 7.0 TB/s at 16384 x 2^20, 6.8 TB/s at 8192 x 262144
   int C = env_int("PG_TN_C", 32 / U > 1 ? 32 / U : 1);
-  if (W == 8) C = 1;
+  if (W == 8 && U == 16) C = 1;
   if (sizeof(T) == 8 && U == 1 && C > 16) C = 16;  // <f64, 1, 32> would spill
 #define PG_TN_CASE(UU, CC, WW) \
   if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)
@@ -778,6 +778,10 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TN_CASE(1, 16, 4);
   PG_TN_CASE(1, 32, 4);
   PG_TN_CASE(16, 1, 8);
+  PG_TN_CASE(8, 2, 8);
+  PG_TN_CASE(8, 4, 8);
+  PG_TN_CASE(4, 4, 8);
+  PG_TN_CASE(4, 8, 8);
 #undef PG_TN_CASE
   pg_set_error("no gemv_tn instantiation for U=%d C=%d WAVES=%d", U, C, W);
   return PG_ERR_UNSUPPORTED;
