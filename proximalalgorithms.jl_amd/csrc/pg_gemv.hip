@@ -252,12 +252,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict_
 //     g_j -> y_j = x_j - gamma g_j -> z_j = prox(y_j) -> res_j = x_j - z_j -> v_j = z_j + beta (z_j - zold_j)
 // (forward_backward.jl:117-120 / fast_forward_backward.jl:140-142 followed by :135 of the NEXT iteration), so
 // A_j v_j is accumulated while the column is still in registers and A is read once per iteration instead of twice.
-// A workgroup's WAVES waves share every column: wave w owns the 1 KiB row groups u * WAVES + w (u < U) -- its slice
+// A workgroup's WAVES waves share every column: wave w owns the 1 KiB row groups w * U + u (u < U) -- its slice
 // of r and of the next residual live in registers for the whole kernel (no LDS staging) -- and the C column dot
 // products of a step meet in LDS (one workgroup barrier per step, fixed summation order).  Each workgroup leaves
 // a partial of A v in partials[blockIdx.x], reduced by gemv_n_finish_kernel like pass N's slots; thread c of the
 // workgroup writes column c's outputs and accumulates the epilogue scalars for the grid reduction.
 // -------------------------------------------------------------------------------------------------
+// row group owned by (wave, u): every wave streams a CONTIGUOUS run of U KiB of each column (measured +1.3 % over
+// interleaving the waves' row groups: longer bursts per wave)
+#define TN_RG(u, wave, U, WAVES) ((wave) * (U) + (u))
+
 template <typename T>
 struct TNArgs {
   const T* A;
@@ -282,7 +286,7 @@ struct TNTile {
   static constexpr int VEC = VecOf<T>::N;
   V col[C][U];
 
-  // this wave's row groups u * WAVES + wave of the C columns of group cg
+  // this wave's row groups wave * U + u of the C columns of group cg
   __device__ __forceinline__ void load(const TNArgs<T>& a, int64_t cg, int wave, int lane) {
     const int64_t j0 = cg * C;
 #pragma unroll
@@ -291,7 +295,7 @@ struct TNTile {
       const T* __restrict__ p = a.A + j * a.ld + lane * VEC;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int rg = u * WAVES + wave;
+        const int rg = TN_RG(u, wave, U, WAVES);
         if (rg < a.nrg) {
           col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rg * (WAVE * VEC)));
         } else {
@@ -312,11 +316,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ncg = (a.n + C - 1) / C;
 
-  // this wave's rows: row groups rg(u) = u * WAVES + wave
+  // this wave's rows: row groups rg(u) = wave * U + u
   V rk[U], racc[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int rg = u * WAVES + wave;
+    const int rg = TN_RG(u, wave, U, WAVES);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
     if (rg < a.nrg) {
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
   T* part = a.partials + (int64_t)blockIdx.x * a.ld + lane * VEC;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int rg = u * WAVES + wave;
+    const int rg = TN_RG(u, wave, U, WAVES);
     if (rg < a.nrg) *reinterpret_cast<V*>(part + (int64_t)rg * (WAVE * VEC)) = racc[u];
   }
   const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
