@@ -743,7 +743,7 @@ template <typename T, int U, int C, int WAVES>
 pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   const int64_t ncg = (A->n + C - 1) / C;
-  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", WAVES == 4 ? 1 : 2);
+  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", (WAVES == 4 && U >= 8) ? 1 : 2);
   if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
   if (blocks > ncg) blocks = ncg;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
@@ -773,7 +773,8 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   while (U * W < nrg) U *= 2;
   // two register tiles of C * U KiB per wave (one in flight, one being consumed), one workgroup per CU: the measured
   // optimum (scripts/tune_tn.py) is C * U = 32 -- 7.0 TB/s at 16384 x 2^20, 6.8 TB/s at 8192 x 262144
-  int C = env_int("PG_TN_C", 32 / U > 1 ? 32 / U : 1);
+  // (short columns, U <= 4: 16 KiB tiles and two workgroups per CU measured best -- 6.0 TB/s at 2048 x 2^20)
+  int C = env_int("PG_TN_C", U >= 8 ? 32 / U : 16 / U);
   if (W == 8 && U == 16) C = 1;
   if (sizeof(T) == 8 && U == 1 && C > 16) C = 16;  // <f64, 1, 32> would spill
 #define PG_TN_CASE(UU, CC, WW) \
