@@ -190,11 +190,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict_
 
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
-  const int64_t total_waves = (int64_t)gridDim.x * WAVES;
   const int64_t ncg = (n + C - 1) / C;
 
-  for (int64_t cg = gw; cg < ncg; cg += total_waves) {
+  // every workgroup walks its own contiguous run of column groups, its waves taking adjacent groups (one contiguous
+  // region of A per workgroup: measured 1-5 % over striding the groups across the whole grid)
+  const int64_t per_b = (ncg + gridDim.x - 1) / gridDim.x;
+  const int64_t b_lo = (int64_t)blockIdx.x * per_b, b_hi = (b_lo + per_b < ncg) ? (b_lo + per_b) : ncg;
+  for (int64_t cg = b_lo + wave; cg < b_hi; cg += WAVES) {
     const int64_t j0 = cg * C;
     const T* __restrict__ p[C];
 #pragma unroll
