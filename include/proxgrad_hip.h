@@ -158,6 +158,13 @@ pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int3
  * column-major store; used by LeastSquares and (later) PANOC's `mul!` with A: panoc.jl:150-190 */
 pg_status pg_mat_mul(pg_mat* A, const void* x, void* y);
 pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
+/* The single sweep for x -> f(A x) compositions (PANOC: panoc.jl:184, :197-199, and the `mul!(Az, A, z)` of the next line
+ * search, fb_tools.jl:43): for a caller-supplied m-vector r (= grad f(A x)),
+ *   At_r = A' r ; y = x - gamma At_r ; z = prox_{gamma g}(y) ; res = x - z ; Az = A z
+ * in ONE read of A.  scalars_out (host, may be NULL) = { g(z), norm(res, Inf), dot(At_r, res), norm(res)^2 }.
+ * Unsharded matrices with m <= 32768 (f32) / 16384 (f64) rows; PG_ERR_UNSUPPORTED otherwise. */
+pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
+                          void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out);
 
 /* ------------------------------------------------------------------ LeastSquares -------- */
 /* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the

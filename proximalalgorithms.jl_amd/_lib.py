@@ -82,6 +82,7 @@ SIGNATURES = {
     "pg_mat_info": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_vp)],
     "pg_mat_mul": [_vp, _vp, _vp],
     "pg_mat_mul_adjoint": [_vp, _vp, _vp],
+    "pg_mat_fused_tn": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_ls_create": [_vp, _vp, _vp, _f64, C.POINTER(_vp)],
     "pg_ls_destroy": [_vp],
     "pg_ls_value_and_gradient": [_vp, _vp, _vp, _pf64],

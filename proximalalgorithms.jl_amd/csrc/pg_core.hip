@@ -353,6 +353,7 @@ pg_status pg_mat_destroy(pg_mat* A) {
   if (!A) return PG_OK;
   if (A->data) (void)hipFree(A->data);
   if (A->partials) (void)hipFree(A->partials);
+  if (A->rpad) (void)hipFree(A->rpad);
   delete A;
   return PG_OK;
 }

@@ -989,6 +989,60 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   return PG_OK;
 }
 
+// Matrix-level form of the single sweep for x -> f(A x) compositions (PANOC, panoc.jl:184,197-199 and the A z of the
+// next line search :43): g = A' r for a caller-supplied m-vector r (= grad f(A x)), the epilogue for (x, g, gamma), and
+// Az = A z_new (no b, no norm) from the columns while they are in registers.
+template <typename T>
+pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_kind, double g_p0, double g_p1, T* g_out,
+                         T* y, T* z_new, T* res, T* Az_out) {
+  pg_ctx* c = A->ctx;
+  if (pg_row_sharded(c) || pg_col_sharded(c) || !tn_supported<T>(A)) {
+    pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(128 * 1024 / sizeof(T)));
+    return PG_ERR_UNSUPPORTED;
+  }
+  if (A->rpad == nullptr) {  // r zero-padded to the leading dimension (the kernel reads whole 1 KiB row groups)
+    PG_HIP(hipMalloc(&A->rpad, (size_t)A->ld * sizeof(T)));
+    PG_HIP(hipMemsetAsync(A->rpad, 0, (size_t)A->ld * sizeof(T), c->stream));
+  }
+  PG_HIP(hipMemcpyAsync(A->rpad, r, (size_t)A->m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  TNArgs<T> a;
+  a.A = (const T*)A->data;
+  a.ld = A->ld;
+  a.n = A->n;
+  a.m = A->m;
+  a.nrg = (int)(A->ld / (1024 / (int64_t)sizeof(T)));
+  a.r = (const T*)A->rpad;
+  a.x = x;
+  a.z_old = x;
+  const T gm = (T)gamma;
+  a.gamma = gm;
+  a.beta = T(0);
+  a.p0 = g_kind == PG_G_NORML1 ? (T)(gm * (T)g_p0) : (T)g_p0;
+  a.p1 = (T)g_p1;
+  a.lam_ls = T(1);
+  a.g_kind = g_kind;
+  a.gscale = g_kind == PG_G_NORML1 ? (double)(T)g_p0 : 0.0;
+  a.g_out = g_out;
+  a.y = y;
+  a.z_new = z_new;
+  a.res = res;
+  a.v_out = nullptr;
+  a.partials = nullptr;
+  a.red_partials = c->red_partials;
+  a.red_counter = c->red_counter;
+  a.scal_out = c->dscal + PG_S_GZ;
+  int blocks = 0;
+  PG_TRY(launch_tn<T>(A, a, &blocks));
+  int64_t fb = (A->ld + 63) / 64;
+  if (fb > 1024) fb = 1024;
+  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+  hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
+                     (const T*)A->partials, A->ld, A->m, blocks, (const T*)nullptr, Az_out, A->m, 0.0, (double*)nullptr,
+                     (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ v, int64_t n, T a) {
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) v[j] *= a;
@@ -1170,6 +1224,23 @@ pg_status pg_ls_destroy(pg_ls* f) {
   if (f->gchunks) (void)hipFree(f->gchunks);
   if (f->cbuf) (void)hipFree(f->cbuf);
   delete f;
+  return PG_OK;
+}
+
+pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
+                          void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  PG_REQUIRE(r && x && At_r && y && z && res && Az, "null vector");
+  PG_REQUIRE(g_kind == PG_G_ZERO || g_kind == PG_G_NORML1 || g_kind == PG_G_INDBOX, "unknown g_kind");
+  PG_REQUIRE(gamma > 0, "gamma must be positive");
+  PG_TRY(A->dtype == PG_F32 ? mat_fused_tn_t<float>(A, (const float*)r, (const float*)x, gamma, g_kind, g_p0, g_p1,
+                                                    (float*)At_r, (float*)y, (float*)z, (float*)res, (float*)Az)
+                            : mat_fused_tn_t<double>(A, (const double*)r, (const double*)x, gamma, g_kind, g_p0, g_p1,
+                                                     (double*)At_r, (double*)y, (double*)z, (double*)res, (double*)Az));
+  if (scalars_out) {
+    PG_TRY(pg_read_scalars(A->ctx, PG_S_GZ, 4));
+    for (int k = 0; k < 4; ++k) scalars_out[k] = A->ctx->hscal[PG_S_GZ + k];
+  }
   return PG_OK;
 }
 

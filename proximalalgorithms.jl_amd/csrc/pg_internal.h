@@ -125,6 +125,7 @@ struct pg_mat {
   // workspace for y = A x partial sums (lazy)
   void* partials = nullptr;
   int64_t partials_slots = 0;
+  void* rpad = nullptr;  // [ld] zero-padded copy of a caller's m-vector (pg_mat_fused_tn)
 };
 
 struct pg_ls {

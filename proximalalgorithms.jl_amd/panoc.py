@@ -9,6 +9,7 @@ import warnings
 
 import numpy as np
 
+from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .device import HIPMatrix, as_hipvector
 from .lbfgs import LBFGS
@@ -49,7 +50,7 @@ class PANOCIteration:
     """panoc.jl:39-52 (keyword constructor), Base.iterate :87-112 / :138-255."""
 
     def __init__(self, *, f=None, A=None, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
-                 minimum_gamma=1e-7, max_backtracks=20, directions=None):
+                 minimum_gamma=1e-7, max_backtracks=20, directions=None, single_sweep=True):
         self.f = f if f is not None else Zero()
         if A is None:
             A = _Identity()
@@ -67,6 +68,10 @@ class PANOCIteration:
         self.max_backtracks = int(max_backtracks)
         self.directions = directions if directions is not None else LBFGS(5)  # :51
         self.counters = {"A_passes": 0}
+        # A' grad f(A x) (:184), the forward-backward step (:197-199) and the A z of the next line search (fb_tools.jl:43)
+        # in ONE read of A (pg_mat_fused_tn) when A is a device matrix and g one of the fused prox kinds
+        self._fused_tn = bool(single_sweep) and isinstance(A, HIPMatrix) and hasattr(self.g, "g_kind") and \
+            not (hasattr(self.g, "_scalar") and not self.g._scalar)
 
     # mul! with A / A' (counted: each is one full read of A)
     def _mul(self, out, x):
@@ -96,10 +101,15 @@ class PANOCIteration:
         eps = R(np.finfo(R).eps)
         gamma, reduce_gamma = R(s.gamma), R(0.5)
         f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)  # :42
-        self._mul(Az, z)  # :43
+        if getattr(s, "Az_next_valid", False) and z is s.z:
+            Az.copy_from(s.Az_next)  # :43 -- the last sweep already formed A z
+            s.Az_next_valid = False
+        else:
+            self._mul(Az, z)  # :43
         f_Az, _ = value_and_gradient_into(self.f, Az, grad_f_Az)  # :44 (grad kept: :56-58)
         tol = R(10) * eps * (R(1) + abs(f_Az))
         while f_Az > f_Az_upp + tol and gamma >= self.minimum_gamma:  # :46
+            s.Az_next_valid = False
             gamma = R(gamma * reduce_gamma)
             s.y.axpby_(1.0, s.x, -gamma, s.At_grad_f_Ax)
             g_z = prox_(z, self.g, s.y, gamma)
@@ -132,8 +142,9 @@ class PANOCIteration:
         s.tau = R(0)
         for name in ("x_prev", "res_prev", "d", "x_d", "At_grad_f_Ax_d", "z_curr", "At_grad_f_Az"):
             setattr(s, name, s.x.similar())
-        for name in ("Ad", "Ax_d", "grad_f_Ax_d", "Az", "grad_f_Az"):
+        for name in ("Ad", "Ax_d", "grad_f_Ax_d", "Az", "grad_f_Az", "Az_next"):
             setattr(s, name, s.Ax.similar())
+        s.Az_next_valid = False
         s.f_Ax_d = R(0)
         s.res_inf = None
         return s
@@ -162,24 +173,43 @@ class PANOCIteration:
         s.x_d.axpby_(1.0, s.x, 1.0, s.d)  # :180
         s.Ax_d.axpby_(1.0, s.Ax, 1.0, s.Ad)  # :181
         s.f_Ax_d, _ = value_and_gradient_into(self.f, s.Ax_d, s.grad_f_Ax_d)  # :182-183
-        self._mul_adj(s.At_grad_f_Ax_d, s.grad_f_Ax_d)  # :184
-        s.x.copy_from(s.x_d)  # :186-191
-        s.Ax.copy_from(s.Ax_d)
-        s.grad_f_Ax.copy_from(s.grad_f_Ax_d)
-        s.At_grad_f_Ax.copy_from(s.At_grad_f_Ax_d)
-        s.z_curr.copy_from(s.z)
-        s.f_Ax = s.f_Ax_d
         sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :193
         tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))  # :194
-        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :195
-        s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :197
-        s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :198
-        s.res.axpby_(1.0, s.x, -1.0, s.z)  # :199
+        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :195 (the residual of the CURRENT point)
+        fused = False
+        if self._fused_tn:
+            # :184 and :197-199 in one read of A, which also leaves A z for the next iteration's line search
+            s.x.copy_from(s.x_d)  # :186-191
+            s.Ax.copy_from(s.Ax_d)
+            s.grad_f_Ax.copy_from(s.grad_f_Ax_d)
+            s.z_curr.copy_from(s.z)
+            s.f_Ax = s.f_Ax_d
+            try:
+                s.g_z = self.A.fused_tn(s.grad_f_Ax_d, s.x, s.gamma, self.g, s.At_grad_f_Ax_d, s.y, s.z, s.res, s.Az_next)[0]
+                fused = True
+            except ProxGradError:
+                self._fused_tn = False  # shape outside the kernel's range: separate sweeps from now on
+        if fused:
+            self.counters["A_passes"] += 1
+            s.At_grad_f_Ax.copy_from(s.At_grad_f_Ax_d)
+            s.Az_next_valid = True
+        else:
+            self._mul_adj(s.At_grad_f_Ax_d, s.grad_f_Ax_d)  # :184
+            s.x.copy_from(s.x_d)  # :186-191
+            s.Ax.copy_from(s.Ax_d)
+            s.grad_f_Ax.copy_from(s.grad_f_Ax_d)
+            s.At_grad_f_Ax.copy_from(s.At_grad_f_Ax_d)
+            s.z_curr.copy_from(s.z)
+            s.f_Ax = s.f_Ax_d
+            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :197
+            s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :198
+            s.res.axpby_(1.0, s.x, -1.0, s.z)  # :199
         FBE_x_new = R(self._model(s) + s.g_z)  # :200
         quad = getattr(self.f, "is_generalized_quadratic", False)
         for k in range(1, self.max_backtracks + 1):  # :202-250
             if FBE_x_new <= threshold:
                 break
+            s.Az_next_valid = False  # z is about to be recomputed
             if np.isinf(f_Az):  # :207-209
                 self._mul(s.Az, s.z_curr)
             s.tau = R(0) if k >= self.max_backtracks else R(s.tau / R(2))  # :211

@@ -53,11 +53,11 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
     passes = iteration.counters["A_passes"] - p0
-    gemv_ms = prof["gemv_n_partial"][1] + prof["gemv_t"][1]
+    gemv_ms = prof["gemv_n_partial"][1] + prof["gemv_t"][1] + prof["gemv_tn"][1]
     out = {"metric": "PANOC iters/sec, %s + L1, m=%d n=%d f32, LBFGS(5), adaptive" % (args.loss, m, n),
            "value": args.steps / dt, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,
            "dtype": "f32", "data": "synthetic", "A_passes_per_step": passes / args.steps,
-           "roofline": {"bound": "hbm", "kernels": "gemv_n_partial + gemv_t",
+           "roofline": {"bound": "hbm", "kernels": "gemv_n_partial + gemv_t + gemv_tn",
                         "achieved": passes * m * n * 4 / (gemv_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": passes * m * n * 4 / (gemv_ms * 1e-3) / 1e9 / 8000.0,
                         "gemv_time_fraction_of_step": gemv_ms * 1e-3 / dt},
