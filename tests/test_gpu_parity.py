@@ -1365,3 +1365,43 @@ def test_fused_single_sweep_pass_matches_separate_kernels(pa, dtype, gname):
         f(xd)
         with pytest.raises(pa.ProxGradError):
             f.fused_pass(xd, xd, 0.1, 0.0, pa.Zero(), *(xd.similar() for _ in range(5)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_panoc_single_sweep_equals_separate_sweeps(pa, dtype):
+    """PANOC with pg_mat_fused_tn (A' grad f(Ax), forward-backward step and the next line search's A z in one read of A)
+    follows the three-sweep iteration: same gamma / tau sequence, same iterates; one read of A less per iteration."""
+    A, b, lam = synthetic_problem(300, 800, dtype, seed=7)
+    x0 = np.zeros(800, dtype)
+    for loss, L in (("sqdist", pa.SquaredDistance), ("logistic", pa.LogisticLoss)):
+        lam_l = lam if loss == "sqdist" else dtype(0.02)
+        its = [pa.PANOCIteration(f=L(b), A=A, g=pa.NormL1(lam_l), x0=x0, single_sweep=ss) for ss in (True, False)]
+        # (Float32: the quasi-Newton directions amplify rounding differences, so only the first iterations are compared)
+        for k, (s1, s2) in enumerate(itertools.islice(zip(*its), 25 if dtype == np.float64 else 10)):
+            assert float(s1.gamma) == pytest.approx(float(s2.gamma), rel=1e-6 if dtype == np.float32 else 1e-12), k
+            assert float(s1.tau) == float(s2.tau), k
+            tol = (5e-4 if dtype == np.float32 else 1e-9) * max(1.0, np.max(np.abs(s2.z.numpy())))
+            assert np.max(np.abs(s1.z.numpy() - s2.z.numpy())) <= tol, (loss, k)
+        assert its[0].counters["A_passes"] < its[1].counters["A_passes"]
+    # the raw entry point against the separate kernels
+    rng = np.random.default_rng(5)
+    for (m, n) in ((7, 5), (300, 257), (5000, 33)):
+        Am = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+        M = pa.HIPMatrix.from_numpy(Am)
+        r, x = rng.standard_normal(m).astype(dtype), rng.standard_normal(n).astype(dtype)
+        rd, xd = pa.HIPVector.from_numpy(r), pa.HIPVector.from_numpy(x)
+        At_r, y, z, res = (xd.similar() for _ in range(4))
+        Az = rd.similar()
+        g = pa.NormL1(dtype(0.3))
+        gz, res_inf, dot_gr, res_sq = M.fused_tn(rd, xd, dtype(0.4), g, At_r, y, z, res, Az)
+        A64 = Am.astype(np.float64)
+        g_ref = A64.T @ r.astype(np.float64)
+        y_ref = x - dtype(0.4) * g_ref
+        z_ref = np.sign(y_ref) * np.maximum(np.abs(y_ref) - 0.4 * 0.3, 0)
+        tol = 50 * rtol(dtype)
+        scale = max(1.0, float(np.max(np.abs(g_ref))))
+        assert np.max(np.abs(At_r.numpy() - g_ref)) <= tol * scale
+        assert np.max(np.abs(z.numpy() - z_ref)) <= tol * scale
+        assert np.max(np.abs(Az.numpy() - A64 @ z.numpy().astype(np.float64))) <= tol * max(1.0, float(np.max(np.abs(A64 @ z_ref))))
+        assert float(res_inf) == pytest.approx(float(np.max(np.abs(x - z.numpy()))), rel=1e-5, abs=1e-6)
+        assert float(gz) == pytest.approx(0.3 * float(np.sum(np.abs(z.numpy().astype(np.float64)))), rel=1e-4, abs=1e-6)
