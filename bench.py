@@ -236,17 +236,14 @@ def main():
     dtype = np.float32 if args.dtype == "f32" else np.float64
     ctx = pa.get_context(local_rank)
     # N > 1: column shards keep the single-sweep iteration on every GPU (one all-reduce of m + 4 N elements per
-    # iteration, fixed step); row shards (north_star's layout; the adaptive mode needs them) iterate with two sweeps and
-    # all-reduce [grad ; f] (n + 1 elements)
+    # iteration); row shards (north_star's layout) iterate with two sweeps and all-reduce [grad ; f] (n + 1 elements)
     sharding = args.sharding
     if sharding == "auto":
-        sharding = "cols" if (world > 1 or args.force_comm) and args.mode == "fixed" and args.sweeps == "one" and \
-            args.collective == "torch" and args.scaling == "strong" else "rows"
+        sharding = "cols" if (world > 1 or args.force_comm) and args.sweeps == "one" and args.collective == "torch" and \
+            args.scaling == "strong" else "rows"
     if world == 1 and not args.force_comm:
         sharding = "none"
     cols = sharding == "cols"
-    if cols and args.mode != "fixed":
-        raise SystemExit("--sharding cols needs --mode fixed")
     if cols:
         row_off, m_loc = 0, m_glob
         col_off, n_loc = pa.shard_cols(n, world, rank)

@@ -114,7 +114,7 @@ pg_status pg_ctx_comm_destroy(pg_ctx* ctx);
  * A[:, J_rank] and the J_rank slices of all n-vectors; b and the residual are replicated.  The registered collective
  * (pg_ctx_set_allreduce / pg_ctx_comm_init) then carries A x (m elements) plus 4 * nranks scalar slots -- ONE all-reduce
  * per iteration -- and A' r needs none, so the single-sweep iteration (pg_iter_opts.single_sweep) keeps working on
- * every rank.  Fixed step sizes only.  nranks = 0 switches back to row sharding. */
+ * every rank (fixed step, or FastForwardBackward's adaptive step with reuse_residual).  nranks = 0: row sharding. */
 pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);

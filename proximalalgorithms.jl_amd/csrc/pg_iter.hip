@@ -141,7 +141,17 @@ pg_status iter_init(pg_iter* it, const void* x0) {
     PG_TRY(pg_axpby(c, it->dtype, n, it->z, 1.0, it->res, -1.0, it->grad_f_x));
     double nrm2 = 0;
     PG_TRY(pg_nrm2sq(c, it->dtype, n, it->z, &nrm2));
-    const T Lest = (T)std::sqrt((T)nrm2) / (T)std::sqrt((double)n);
+    double n_glob = (double)n;
+    if (pg_col_sharded(c)) {  // the n-vector is distributed: sum the squared norms and the lengths of the slices
+      c->hscal[PG_S_GZ] = c->hscal[PG_S_RESINF] = 0.0;
+      c->hscal[PG_S_DOT] = (double)n;  // mapped host memory: visible to the kernels launched next
+      c->hscal[PG_S_RESSQ] = nrm2;
+      PG_TRY(pg_ls_allreduce_epilogue_scalars(it->f));
+      PG_TRY(pg_read_scalars(c, PG_S_DOT, 2));
+      n_glob = c->hscal[PG_S_DOT];
+      nrm2 = c->hscal[PG_S_RESSQ];
+    }
+    const T Lest = (T)std::sqrt((T)nrm2) / (T)std::sqrt(n_glob);
     gamma = (double)(T(1) / Lest);
   }
   it->gamma = Arith<T>::r(gamma);
@@ -372,10 +382,9 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   // adaptive::Bool = gamma === nothing        forward_backward.jl:43-44
   const bool gamma_known = (o->gamma > 0) || (o->Lf > 0);
   it->adaptive = o->adaptive < 0 ? !gamma_known : (o->adaptive != 0);
-  if (pg_col_sharded(c) && (it->adaptive || !gamma_known)) {
+  if (pg_col_sharded(c) && it->adaptive && !(o->fast && o->reuse_residual != 0)) {
     delete it;
-    pg_set_error("column-sharded operators iterate with a fixed step (give Lf or gamma): the line search and the "
-                 "step-size estimate reduce over n-vectors that are distributed");
+    pg_set_error("column-sharded operators support the adaptive step for FastForwardBackward with reuse_residual only");
     return PG_ERR_UNSUPPORTED;
   }
   const size_t vb = vec_bytes(it);

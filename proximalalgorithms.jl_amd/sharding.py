@@ -7,7 +7,7 @@ all-reduce.  All n-vectors are replicated, so the elementwise epilogue and its r
 Column sharding (``shard="cols"``): every rank holds a column block of A and the matching slices of the n-vectors; b and
 the residual are replicated.  A' r is then local and what crosses ranks is A x (m elements) plus 4 * world scalar slots
 -- ONE all-reduce per iteration, 64x smaller than the row-sharded payload at the headline shape -- so every rank keeps
-the single-sweep iteration (A read once per iteration).  Fixed step sizes only.
+the single-sweep iteration (A read once per iteration).
 """
 
 def shard_rows(m_global, world_size, rank):

@@ -544,7 +544,7 @@ def test_bench_line_contract(pa, cpu_mode):
 
 
 @pytest.mark.parametrize("mode,sharding,overlap", [("fixed", "rows", False), ("adaptive", "rows", False), ("fixed", "rows", True),
-                                                   ("fixed", "cols", False), ("fixed", "auto", False)])
+                                                   ("fixed", "cols", False), ("fixed", "auto", False), ("adaptive", "cols", False)])
 def test_two_ranks_one_gpu_matches_single_rank(pa, mode, sharding, overlap):
     """bench.py with 2 processes sharing cuda:0 over gloo == 1 process: same lambda / Lf (they come from all-reduced
     quantities) and the same iterate after 14 steps -- row shards (1024 rows each, two sweeps, [grad ; f] all-reduced)
