@@ -7,8 +7,11 @@
 //
 //   pass N  (y = A x):     wave = (row tile of R KiB, column slot); accumulators in VGPRs, x_j wave-uniform;
 //                          deterministic two-stage reduction over the column slots.
-//   pass T  (g = A' r):    r staged once per workgroup in LDS (<= 64 KiB); wave = C adjacent columns streamed
+//   pass T  (g = A' r):    r staged once per workgroup in LDS (<= 128 KiB); wave = C adjacent columns streamed
 //                          top to bottom; per-column DPP/shuffle wave reduction; no cross-wave traffic.
+//   pass TN (single sweep): g = A' r, then per finished column the prox step and the column's contribution to the
+//                          NEXT residual while it is still in registers -- A read once per iteration
+//                          (pg_ls_fused_pass / pg_mat_fused_tn; column shards: one all-reduce of m + 4 N elements).
 #include <cstdlib>
 
 #include "pg_internal.h"
