@@ -195,11 +195,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ncg = (n + C - 1) / C;
 
-  // every workgroup walks its own contiguous run of column groups, its waves taking adjacent groups (one contiguous
-  // region of A per workgroup: measured 1-5 % over striding the groups across the whole grid)
-  const int64_t per_b = (ncg + gridDim.x - 1) / gridDim.x;
-  const int64_t b_lo = (int64_t)blockIdx.x * per_b, b_hi = (b_lo + per_b < ncg) ? (b_lo + per_b) : ncg;
-  for (int64_t cg = b_lo + wave; cg < b_hi; cg += WAVES) {
+  const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
+  const int64_t total_waves = (int64_t)gridDim.x * WAVES;
+  for (int64_t cg = gw; cg < ncg; cg += total_waves) {  // strided: see the note on blocked assignment in gemv_tn_kernel
     const int64_t j0 = cg * C;
     const T* __restrict__ p[C];
 #pragma unroll
@@ -406,29 +404,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
   // through LDS and folded into the next residual (the kernel would otherwise idle the memory system at every barrier)
   if constexpr (DOUBLE_BUFFER) {
     TNTile<T, U, C, WAVES> ta, tb;
-    // blocked assignment: every workgroup walks its own contiguous run of column groups (measured +3 % over striding
-    // the groups across the grid: each workgroup then streams one contiguous region of A front to back)
-    const int64_t per = (ncg + gridDim.x - 1) / gridDim.x;
-    int64_t cg = (int64_t)blockIdx.x * per;
-    const int64_t cg_end = (cg + per < ncg) ? (cg + per) : ncg;
-    const int64_t stride = 1;
-    if (cg < cg_end) ta.load(a, cg, wave, lane);
-    while (cg < cg_end) {
-      const int64_t cg1 = cg + stride;
-      if (cg1 < cg_end) tb.load(a, cg1, wave, lane);
-      process(ta, cg, 0);
-      if (cg1 >= cg_end) break;
-      const int64_t cg2 = cg1 + stride;
-      if (cg2 < cg_end) ta.load(a, cg2, wave, lane);
-      process(tb, cg1, 1);
-      cg = cg2;
+    // column groups are strided across the grid: all workgroups sweep one moving window of A.  (A blocked assignment --
+    // every workgroup streaming its own contiguous region -- measured 3 % faster on a freshly booted device and 3-10 %
+    // slower, alternating from process to process, on others: 256 far-apart streams depend on how the 64 GiB
+    // allocation happens to be mapped.  The strided form is stable to 0.5 %.)
+    const int64_t cnt = ncg > (int64_t)blockIdx.x ? (ncg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    auto at = [&](int64_t i) { return (int64_t)blockIdx.x + i * (int64_t)gridDim.x; };
+    int64_t i = 0;
+    if (i < cnt) ta.load(a, at(i), wave, lane);
+    while (i < cnt) {
+      if (i + 1 < cnt) tb.load(a, at(i + 1), wave, lane);
+      process(ta, at(i), 0);
+      if (i + 1 >= cnt) break;
+      if (i + 2 < cnt) ta.load(a, at(i + 2), wave, lane);
+      process(tb, at(i + 1), 1);
+      i += 2;
     }
   } else {  // 8-wave workgroups have half the registers per wave: one tile, two workgroups per CU overlap instead
     TNTile<T, U, C, WAVES> t;
     int buf = 0;
-    const int64_t per = (ncg + gridDim.x - 1) / gridDim.x;
-    const int64_t cg0 = (int64_t)blockIdx.x * per, cg_end = (cg0 + per < ncg) ? (cg0 + per) : ncg;
-    for (int64_t cg = cg0; cg < cg_end; ++cg) {
+    for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
       t.load(a, cg, wave, lane);
       process(t, cg, buf);
       buf ^= 1;
