@@ -101,7 +101,7 @@ class PANOCIteration:
         eps = R(np.finfo(R).eps)
         gamma, reduce_gamma = R(s.gamma), R(0.5)
         f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)  # :42
-        if getattr(s, "Az_next_valid", False) and z is s.z:
+        if getattr(s, "Az_next_valid", False) and getattr(s, "Az_next_of", None) is z:
             Az.copy_from(s.Az_next)  # :43 -- the last sweep already formed A z
             s.Az_next_valid = False
         else:
@@ -192,7 +192,7 @@ class PANOCIteration:
         if fused:
             self.counters["A_passes"] += 1
             s.At_grad_f_Ax.copy_from(s.At_grad_f_Ax_d)
-            s.Az_next_valid = True
+            s.Az_next_valid, s.Az_next_of = True, s.z
         else:
             self._mul_adj(s.At_grad_f_Ax_d, s.grad_f_Ax_d)  # :184
             s.x.copy_from(s.x_d)  # :186-191

@@ -3,6 +3,7 @@ direction on the forward-backward residual and a line search on the forward-back
 primitives as PANOC (panoc.py); every array statement is a kernel of libproxgrad_hip."""
 import numpy as np
 
+from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .operators import prox_
 from .panoc import PANOCIteration, value_and_gradient_into
@@ -37,8 +38,9 @@ class ZeroFPRIteration(PANOCIteration):
         s.tau = R(0)
         for name in ("At_grad_f_Axbar", "xbarbar", "res_xbar", "xbar_prev", "res_xbar_prev", "d"):
             setattr(s, name, s.x.similar())
-        for name in ("Axbar", "grad_f_Axbar", "Ad"):
+        for name in ("Axbar", "grad_f_Axbar", "Ad", "Az_next"):
             setattr(s, name, s.Ax.similar())
+        s.Az_next_valid, s.Az_next_of = False, None
         s.is_prev_set = False
         return s
 
@@ -50,7 +52,11 @@ class ZeroFPRIteration(PANOCIteration):
             if s.gamma != gamma_prev and s.H is not None:
                 s.H.reset_()
         else:  # :165-170
-            self._mul(s.Axbar, s.xbar)
+            if s.Az_next_valid and s.Az_next_of is s.xbar:
+                s.Axbar.copy_from(s.Az_next)  # the last sweep of the previous iteration already formed A xbar
+                s.Az_next_valid = False
+            else:
+                self._mul(s.Axbar, s.xbar)
             f_Axbar, _ = value_and_gradient_into(self.f, s.Axbar, s.grad_f_Axbar)
             f_Axbar_upp = self._model(s)
         FBE_x = R(f_Axbar_upp + s.g_xbar)  # :173
@@ -79,10 +85,22 @@ class ZeroFPRIteration(PANOCIteration):
             s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :200
             s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :201
             s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :203-204
-            self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :205
-            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :206
-            s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :207
-            s.res.axpby_(1.0, s.x, -1.0, s.xbar)  # :208
+            fused = False
+            if self._fused_tn:  # :205-208 and the A xbar of the next iteration (:43 / :166) in one read of A
+                try:
+                    s.g_xbar = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)[0]
+                    fused = True
+                except ProxGradError:
+                    self._fused_tn = False
+            if fused:
+                self.counters["A_passes"] += 1
+                s.Az_next_valid, s.Az_next_of = True, s.xbar
+            else:
+                self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :205
+                s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :206
+                s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :207
+                s.res.axpby_(1.0, s.x, -1.0, s.xbar)  # :208
+                s.Az_next_valid = False
             FBE_x = R(self._model(s) + s.g_xbar)  # :209
             if FBE_x <= threshold:
                 break
