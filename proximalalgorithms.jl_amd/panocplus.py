@@ -3,6 +3,7 @@ import warnings
 
 import numpy as np
 
+from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .operators import prox_
 from .panoc import PANOCIteration, value_and_gradient_into
@@ -73,12 +74,22 @@ class PANOCplusIteration(PANOCIteration):
                 tau_backtracks += 1
             self._mul(s.Ax, s.x)  # :199
             s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :200-201
-            self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :202
-            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :204
-            s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :205
-            s.res.axpby_(1.0, s.x, -1.0, s.z)  # :206
+            fused = False
+            if self._fused_tn:  # :202-206 and :210 in one read of A (pg_mat_fused_tn)
+                try:
+                    s.g_z = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res, s.Az)[0]
+                    fused = True
+                    self.counters["A_passes"] += 1
+                except ProxGradError:
+                    self._fused_tn = False
+            if not fused:
+                self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :202
+                s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :204
+                s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :205
+                s.res.axpby_(1.0, s.x, -1.0, s.z)  # :206
             f_Az_upp = self._model(s)  # :208
-            self._mul(s.Az, s.z)  # :210
+            if not fused:
+                self._mul(s.Az, s.z)  # :210
             f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)  # :211-212
             if self.gamma is None or self.adaptive:  # :213-224
                 tol2 = R(10) * R(np.finfo(R).eps) * (R(1) + abs(f_Az))
