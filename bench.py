@@ -239,8 +239,7 @@ def main():
     # iteration); row shards (north_star's layout) iterate with two sweeps and all-reduce [grad ; f] (n + 1 elements)
     sharding = args.sharding
     if sharding == "auto":
-        sharding = "cols" if (world > 1 or args.force_comm) and args.sweeps == "one" and args.collective == "torch" and \
-            args.scaling == "strong" else "rows"
+        sharding = "cols" if (world > 1 or args.force_comm) and args.sweeps == "one" and args.scaling == "strong" else "rows"
     if world == 1 and not args.force_comm:
         sharding = "none"
     cols = sharding == "cols"
@@ -274,7 +273,7 @@ def main():
     b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
     comm = None
     if world > 1 or args.force_comm:
-        comm = (pa.NativeRcclComm(overlap=args.overlap) if args.collective == "native"
+        comm = (pa.NativeRcclComm(overlap=args.overlap, shard="cols" if cols else "rows") if args.collective == "native"
                 else pa.TorchDistributedComm(overlap=args.overlap, shard="cols" if cols else "rows"))
     f = pa.LeastSquares(A, b, comm=comm)
     zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)

@@ -101,8 +101,12 @@ class NativeRcclComm:
     """The library's own RCCL communicator (csrc/pg_comm.hip): no Python in the collective path.  The 128-byte
     ncclUniqueId is created on rank 0 and shipped with torch.distributed (any backend) when world_size > 1."""
 
-    def __init__(self, world_size=None, rank=None, overlap=False):
+    def __init__(self, world_size=None, rank=None, overlap=False, shard="rows"):
         import torch.distributed as dist
+
+        if shard not in ("rows", "cols"):
+            raise ValueError("shard must be 'rows' or 'cols'")
+        self.shard = shard
 
         if world_size is None:
             initialised = dist.is_available() and dist.is_initialized()
@@ -129,7 +133,9 @@ class NativeRcclComm:
             box = [bytes(ident.raw) if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             ident = C.create_string_buffer(box[0], 128)
-        call("pg_ctx_comm_init", ctx.handle, ident, self.world_size, self.rank, 1 if self.overlap else 0)
+        call("pg_ctx_comm_init", ctx.handle, ident, self.world_size, self.rank,
+             1 if (self.overlap and self.shard == "rows") else 0)
+        ctx.set_column_sharding(self.world_size if self.shard == "cols" else 0, self.rank)
         self._ctx = ctx
 
 

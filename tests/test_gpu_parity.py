@@ -1124,9 +1124,9 @@ def test_batched_device_resident_run(pa, dtype, fast):
 def test_native_rccl_communicator_world_size_one(pa):
     """csrc/pg_comm.hip: RCCL bound with dlopen, communicator of one rank; blocking and chunked asynchronous paths."""
     A, b, lam = synthetic_problem(256, 20000, np.float32, seed=5)
-    for overlap in (False, True):
+    for overlap, shard in ((False, "rows"), (True, "rows"), (False, "cols")):  # cols: one rank owning every column
         ctx2 = pa.Context()
-        comm = pa.NativeRcclComm(world_size=1, rank=0, overlap=overlap)
+        comm = pa.NativeRcclComm(world_size=1, rank=0, overlap=overlap, shard=shard)
         f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), comm=comm)
         f_pl = pa.LeastSquares(A, b)
         x = np.random.default_rng(1).standard_normal(20000).astype(np.float32)
