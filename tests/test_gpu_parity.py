@@ -1132,7 +1132,11 @@ def test_native_rccl_communicator_world_size_one(pa):
         x = np.random.default_rng(1).standard_normal(20000).astype(np.float32)
         fs, gs = f_sh.value_and_gradient(pa.HIPVector.from_numpy(x, ctx2))
         fp, gp = f_pl.value_and_gradient(pa.HIPVector.from_numpy(x))
-        assert float(fs) == pytest.approx(float(fp), rel=1e-6) and np.array_equal(gs.numpy(), gp.numpy())
+        assert float(fs) == pytest.approx(float(fp), rel=1e-6)
+        if shard == "rows":
+            assert np.array_equal(gs.numpy(), gp.numpy())
+        else:  # column shards subtract b after the all-reduce (one more rounding of the residual)
+            np.testing.assert_allclose(gs.numpy(), gp.numpy(), rtol=1e-5, atol=1e-4)
         assert float(f_sh(pa.HIPVector.from_numpy(x, ctx2))) == pytest.approx(float(fp), rel=1e-6)
         z1, k1 = pa.FastForwardBackward(tol=1e-3, maxit=40)(x0=pa.HIPVector.zeros(20000, np.float32, ctx2), f=f_sh, g=pa.NormL1(lam))
         z2, k2 = pa.FastForwardBackward(tol=1e-3, maxit=40)(x0=np.zeros(20000, np.float32), f=f_pl, g=pa.NormL1(lam))
