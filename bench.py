@@ -386,7 +386,10 @@ def main():
                                         "sweeps_of_A_per_iteration": round(sweeps, 3),
                                         "hbm_bytes_moved_per_gpu": int(bytes_moved_local),
                                         "hbm_GBps_moved_per_gpu": round(bytes_moved_local * its / 1e9, 1),
-                                        "frac_of_bytes_moved": round(bytes_moved_local * its / 1e9 / HBM_PEAK_GBS, 4)}}
+                                        "frac_of_bytes_moved": round(bytes_moved_local * its / 1e9 / HBM_PEAK_GBS, 4),
+                                        "note": "algorithmic_bytes = SURVEY 8(d): A x and A' r as separate passes (2 m n s "
+                                                "+ vectors); frac > 1 means the iteration moves fewer bytes than that (the "
+                                                "single sweep reads A once); *_moved = bytes actually read/written"}}
 
     if rank == 0:
         cpu = None
