@@ -590,6 +590,12 @@ def test_four_ranks_one_gpu_column_shards(pa):
         assert f4["g_z"] == pytest.approx(f1["g_z"], rel=2e-4)
         assert f4["res_inf_over_gamma"] == pytest.approx(f1["res_inf_over_gamma"], rel=2e-3)
         assert four["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1)
+    # the driver's largest launch: eight ranks (here on one device), default sharding
+    eight = _run_bench(["--backend", "gloo", "--share-device"], nproc=8, port=29657)
+    one = _run_bench([])
+    assert eight["n_gpus"] == 8 and eight["config"]["sharding"] == "cols" and eight["config"]["n_per_gpu"] * 8 == one["config"]["n"]
+    assert eight["config"]["final"]["f_x"] == pytest.approx(one["config"]["final"]["f_x"], rel=2e-4)
+    assert eight["config"]["final"]["res_inf_over_gamma"] == pytest.approx(one["config"]["final"]["res_inf_over_gamma"], rel=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------
