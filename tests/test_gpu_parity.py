@@ -1105,6 +1105,23 @@ def test_error_paths_report_messages(pa):
         x.axpby_(1.0, pa.HIPVector.zeros(6, np.float32))
     with pytest.raises(TypeError):
         pa.ForwardBackwardIteration(f=pa.Zero(), g=pa.NormL1(1.0), x0=np.zeros(3), engine="fused")
+    # single-sweep entry points: null vectors, non-positive gamma, unknown g, rows beyond the register budget
+    f = pa.LeastSquares(np.eye(4, dtype=np.float32), np.ones(4, np.float32))
+    v = [pa.HIPVector.zeros(4, np.float32) for _ in range(7)]
+    f(v[0])
+    args = lambda gamma=0.1, kind=_lib.PG_G_NORML1, z=v[1].vp: (f.handle, v[0].vp, z, gamma, 0.5, kind, 0.1, 0.0, v[2].vp,
+                                                               v[3].vp, v[4].vp, v[5].vp, v[6].vp, None)
+    assert lib.pg_ls_fused_pass(*args()) == 0
+    assert lib.pg_ls_fused_pass(*args(gamma=0.0)) == -1 and b"gamma" in lib.pg_last_error()
+    assert lib.pg_ls_fused_pass(*args(kind=9)) == -1 and b"g_kind" in lib.pg_last_error()
+    assert lib.pg_ls_fused_pass(*args(z=None)) == -1 and b"null" in lib.pg_last_error()
+    tall = pa.HIPMatrix.from_numpy(np.ones((40000, 2), np.float32))
+    r, xx = pa.HIPVector.zeros(40000, np.float32), pa.HIPVector.zeros(2, np.float32)
+    with pytest.raises(pa.ProxGradError):
+        tall.fused_tn(r, xx, 0.1, pa.NormL1(0.1), xx.similar(), xx.similar(), xx.similar(), xx.similar(), r.similar())
+    with pytest.raises(pa.ProxGradError):
+        ctx.set_column_sharding(2, 5)  # rank out of range
+    ctx.set_column_sharding(0, 0)
 
 
 @pytest.mark.parametrize("fast", [False, True])
