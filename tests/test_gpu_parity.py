@@ -466,6 +466,14 @@ def test_sharded_payload_with_emulated_allreduce(pa, dtype, overlap, ls_lam):
     assert np.max(np.abs(z1.numpy() - z2)) <= 1e-3 * max(1.0, np.max(np.abs(z2)))
 
 
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a communicator is created; flushed here it lands in the
+    test's captured output instead of after pytest's summary line at interpreter exit."""
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+
+
 def test_nccl_world_size_one(pa):
     """torch.distributed (backend nccl == RCCL) with one rank: the real callback path end to end."""
     import torch
@@ -496,6 +504,7 @@ def test_nccl_world_size_one(pa):
             assert k1 == k2 and np.max(np.abs(z1.numpy() - z2)) <= 1e-5 * max(1.0, np.max(np.abs(z2)))
     finally:
         dist.destroy_process_group()
+        _flush_c_stdio()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1183,6 +1192,7 @@ def test_native_rccl_communicator_world_size_one(pa):
         from proximalalgorithms.jl_amd._lib import call
 
         call("pg_ctx_comm_destroy", ctx2.handle)
+    _flush_c_stdio()
 
 
 # ------------------------------------------------------------------------------------------------
