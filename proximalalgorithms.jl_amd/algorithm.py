@@ -45,12 +45,13 @@ class IterativeAlgorithm:
             nbytes = A.m * A.n * A.dtype.itemsize
             unsharded = A.m > 0 and A.n > 0 and it.f.comm is None
             # measured crossovers (scripts/bench_small.py, profiles/): one workgroup up to ~8k elements; the cooperative
-            # multi-workgroup kernel while A is a few MiB (its barriers beat launches + host round trips); beyond that
-            # the streaming kernels driven from the host
+            # multi-workgroup kernel while A is a few MiB (its barriers beat launches + host round trips: up to ~10 MiB
+            # with the adaptive step, ~8 MiB against per-iteration syncs, ~3 MiB against the batched fixed-step loop);
+            # beyond that the streaming kernels driven from the host
             coop_rows = 3 * (-(-A.m // 64) * 64) * A.dtype.itemsize <= 96 * 1024
             if unsharded and A.m * A.n <= 8192:
                 k, _ = fused.run_small(1, self.maxit, tol)
-            elif unsharded and coop_rows and nbytes <= ((10 << 20) if adaptive else (6 << 20)):
+            elif unsharded and coop_rows and nbytes <= ((10 << 20) if adaptive else ((3 << 20) if check_every > 1 else (8 << 20))):
                 k, _ = fused.run_coop(1, self.maxit, tol)
             elif check_every > 1 and not adaptive:
                 k, _ = fused.run(1, self.maxit, tol, check_every=check_every)

@@ -199,7 +199,8 @@ pg_status iter_step_single_sweep(pg_iter* it) {
     const double gfix = (o.gamma > 0 || o.Lf > 0) ? Arith<T>::r(o.gamma > 0 ? o.gamma : (double)(T(1) / (T)o.Lf)) : it->gamma;
     if (o.fast) {
       // ---- FastForwardBackward, fixed step: fast_forward_backward.jl:131-142 ----
-      if (!(it->sp_ready && it->sp_gen == f->r_gen)) {  // first half of this iteration (:131-138) on its own
+      const bool fresh_first_half = !(it->sp_ready && it->sp_gen == f->r_gen);
+      if (fresh_first_half) {  // first half of this iteration (:131-138) on its own
         SeqState<T> s = seq_load<T>(it);
         it->sp_beta = (double)seq_next_hd<T>(o.seq_kind, (T)o.mf, (T)o.seq_p0, (T)o.seq_p1, s, (T)gfix, T(0));  // :134
         it->spec_stepsize = (double)s.stepsize, it->spec_theta = (double)s.theta, it->spec_t = (double)s.t, it->spec_k = s.k;
@@ -214,7 +215,12 @@ pg_status iter_step_single_sweep(pg_iter* it) {
       it->seq_stepsize = it->spec_stepsize, it->seq_theta = it->spec_theta, it->seq_t = it->spec_t, it->seq_k = it->spec_k;
       std::swap(it->x, it->x_next);
       std::swap(it->z_prev, it->z);                                                               // :136
-      it->f_x = it->sp_f;
+      if (fresh_first_half || !it->defer_sync) {
+        it->f_x = it->sp_f;
+        it->fx_src = -1;
+      } else {
+        it->fx_src = PG_S_FNEXT + it->sp_slot;  // written by the previous sweep, read back with the batch
+      }
       // second half (:138-142) + the next iteration's first half, one sweep
       SeqState<T> s2 = seq_load<T>(it);
       const double beta2 = (double)seq_next_hd<T>(o.seq_kind, (T)o.mf, (T)o.seq_p0, (T)o.seq_p1, s2, (T)it->gamma, T(0));
@@ -225,22 +231,28 @@ pg_status iter_step_single_sweep(pg_iter* it) {
       it->spec_stepsize = (double)s2.stepsize, it->spec_theta = (double)s2.theta, it->spec_t = (double)s2.t, it->spec_k = s2.k;
       it->sp_gen = f->r_gen;
       it->sp_ready = true;
-      PG_TRY(read_sweep_scalars<T>(it));
+      if (!it->defer_sync) PG_TRY(read_sweep_scalars<T>(it));
     } else {
       // ---- ForwardBackward, fixed step: forward_backward.jl:111-120 (the next point is the prox output itself) ----
-      if (!(it->sp_ready && it->sp_gen == f->r_gen)) {
+      const bool fresh_first_half = !(it->sp_ready && it->sp_gen == f->r_gen);
+      if (fresh_first_half) {
         PG_TRY(pg_ls_value_async(f, it->z));
         PG_TRY(pg_read_scalars(c, PG_S_F, 1));
         it->sp_f = Arith<T>::r(c->hscal[PG_S_F]);
       }
       std::swap(it->x, it->z);  // :112
-      it->f_x = it->sp_f;       // :113
+      if (fresh_first_half || !it->defer_sync) {  // :113
+        it->f_x = it->sp_f;
+        it->fx_src = -1;
+      } else {
+        it->fx_src = PG_S_FNEXT + it->sp_slot;
+      }
       it->sp_slot ^= 1;
       PG_TRY(pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->x, it->gamma, 0.0,
                                     o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr));
       it->sp_gen = f->r_gen;
       it->sp_ready = true;
-      PG_TRY(read_sweep_scalars<T>(it));
+      if (!it->defer_sync) PG_TRY(read_sweep_scalars<T>(it));
     }
     return PG_OK;
   }
@@ -298,7 +310,7 @@ pg_status iter_step(pg_iter* it, double host_beta) {
   it->flags = 0;
   it->n_backtracks = 0;
   it->f_z = it->f_z_upp = NAN;
-  if (it->single_sweep && !it->defer_sync) return iter_step_single_sweep<T>(it);
+  if (it->single_sweep && !(it->defer_sync && it->adaptive)) return iter_step_single_sweep<T>(it);
   it->sp_ready = false;
   if (!it->o.fast) {
     // ---------------- ForwardBackward: forward_backward.jl:86-123 ----------------
@@ -500,8 +512,13 @@ pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, doubl
     PG_TRY(st);
     k += nb;
     // one synchronisation per batch: the scalar block now describes the last enqueued iteration
-    PG_TRY(pg_read_scalars(c, PG_S_F, 5));
-    it->f_x = f32 ? (double)(float)c->hscal[PG_S_F] : c->hscal[PG_S_F];
+    PG_TRY(pg_read_scalars(c, PG_S_F, PG_S_COUNT));
+    if (it->single_sweep) {  // f(x) of the last state came from the sweep before the last one; the last sweep's is speculative
+      if (it->fx_src >= 0) it->f_x = f32 ? (double)(float)c->hscal[it->fx_src] : c->hscal[it->fx_src];
+      it->fx_src = -1;
+      it->sp_f = f32 ? (double)(float)c->hscal[PG_S_FNEXT + it->sp_slot] : c->hscal[PG_S_FNEXT + it->sp_slot];
+    } else
+      it->f_x = f32 ? (double)(float)c->hscal[PG_S_F] : c->hscal[PG_S_F];
     it->g_z = f32 ? (double)(float)c->hscal[PG_S_GZ] : c->hscal[PG_S_GZ];
     it->res_inf = f32 ? (double)(float)c->hscal[PG_S_RESINF] : c->hscal[PG_S_RESINF];
     it->dot_gr = f32 ? (double)(float)c->hscal[PG_S_DOT] : c->hscal[PG_S_DOT];
