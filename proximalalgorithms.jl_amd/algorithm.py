@@ -44,7 +44,7 @@ class IterativeAlgorithm:
             adaptive = bool(it.adaptive)
             nbytes = A.m * A.n * A.dtype.itemsize
             unsharded = A.m > 0 and A.n > 0 and it.f.comm is None
-            # measured crossovers (scripts/bench_small.py, profiles/): one workgroup up to ~8k elements; the cooperative
+            # measured crossovers (tests/tools/bench_small.py, profiles/): one workgroup up to ~8k elements; the cooperative
             # multi-workgroup kernel while A is a few MiB (its barriers beat launches + host round trips: up to ~10 MiB
             # with the adaptive step, ~8 MiB against per-iteration syncs, ~3 MiB against the batched fixed-step loop);
             # beyond that the streaming kernels driven from the host

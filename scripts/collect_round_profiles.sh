@@ -14,4 +14,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof_fetch -- python3 be
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof_write -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof_write.log 2>&1
 for d in prof_headline prof_fetch prof_write; do python scripts/rocpd_summary.py gpurun_out/$d/*/*_results.db > gpurun_out/$d.md 2>&1; done
 python scripts/bench_panoc.py > gpurun_out/bench_panoc.json 2>/dev/null
-python scripts/bench_dr.py > gpurun_out/bench_dr.json 2>/dev/null
+python tests/tools/bench_dr.py > gpurun_out/bench_dr.json 2>/dev/null

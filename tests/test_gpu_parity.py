@@ -1316,7 +1316,7 @@ def test_device_loop_option_same_answers(pa, dtype):
 
 
 # ------------------------------------------------------------------------------------------------
-# randomised differential test (scripts/fuzz_parity.py; 600 cases were run clean in round 1)
+# randomised differential test (tests/tools/fuzz_parity.py; 600 cases were run clean in round 1)
 # ------------------------------------------------------------------------------------------------
 
 
@@ -1328,7 +1328,7 @@ def test_fuzz_differential_against_oracle(pa):
     import importlib.util
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "scripts", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tests", "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     bad = []
@@ -1340,12 +1340,12 @@ def test_fuzz_differential_against_oracle(pa):
 
 
 def test_fuzz_newton_type_and_douglas_rachford(pa):
-    """scripts/fuzz_newton.py: PANOC / ZeroFPR / PANOCplus (objective-level agreement with the CPU restatement) and
+    """tests/tools/fuzz_newton.py: PANOC / ZeroFPR / PANOCplus (objective-level agreement with the CPU restatement) and
     DouglasRachford (bit-identical y and k for host stepping and the 1 / 8 / 16-iterations-per-sweep loops)."""
     import importlib.util
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("fuzz_newton", os.path.join(root, "scripts", "fuzz_newton.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_newton", os.path.join(root, "tests", "tools", "fuzz_newton.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     bad = []

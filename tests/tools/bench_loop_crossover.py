@@ -3,7 +3,7 @@
 kernel (pg_iter_run_small), the cooperative multi-workgroup kernel (pg_iter_run_coop) and the host-driven streaming kernels
 (pg_iter_run, batched by 16 when the step is fixed).  Feeds the dispatch thresholds of algorithm.py."""
 import os, sys, time, gc, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import proximalalgorithms.jl_amd as pa
 from oracle import proxgrad_oracle as o
 for (m, n, dt) in ((100, 200, np.float64), (130, 300, np.float64), (300, 700, np.float32), (500, 1000, np.float32), (700, 1500, np.float64), (1000, 2000, np.float32), (1000, 2000, np.float64), (1500, 3000, np.float32), (2000, 4000, np.float32), (3000, 6000, np.float32), (4000, 8000, np.float32)):

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised differential test of the widened rows: PANOC / ZeroFPR / PANOCplus (L-BFGS directions,
 general A, squared-distance and logistic losses) and DouglasRachford (separable quadratic + box / L1, stepping and the
-K-iterations-per-sweep loop) against the CPU restatement.  Usage: python scripts/fuzz_newton.py [cases] [first_seed]."""
+K-iterations-per-sweep loop) against the CPU restatement.  Usage: python tests/tools/fuzz_newton.py [cases] [first_seed]."""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import proximalalgorithms.jl_amd as pa  # noqa: E402
 from oracle import proxgrad_oracle as o  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test: the GPU engine (every form of the driver loop) against the CPU restatement on random
-small / mid-size LASSO-type problems.  Usage: python scripts/fuzz_parity.py [cases] [first_seed].  Prints one line per
+small / mid-size LASSO-type problems.  Usage: python tests/tools/fuzz_parity.py [cases] [first_seed].  Prints one line per
 failing case and a summary; exit code 1 if anything failed."""
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import proximalalgorithms.jl_amd as pa  # noqa: E402
 from oracle import proxgrad_oracle as o  # noqa: E402
