@@ -743,7 +743,7 @@ template <typename T, int U, int C, int WAVES>
 pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   const int64_t ncg = (A->n + C - 1) / C;
-  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", (WAVES == 4 && U >= 8) ? 1 : 2);
+  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", ((WAVES == 4 && U >= 8) || (WAVES == 8 && U == 4)) ? 1 : 2);
   if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
   if (blocks > ncg) blocks = ncg;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
@@ -768,7 +768,9 @@ bool tn_supported(const pg_mat* A) {
 template <typename T>
 pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int nrg = a.nrg;
-  const int W = env_int("PG_TN_WAVES", nrg <= 64 ? 4 : 8) == 8 ? 8 : 4;
+  // 17..32 row groups (m = 8192 in Float32): eight waves of U = 4 with C = 8 columns per step measured 4 % faster than four
+  // waves of U = 8 (775 vs 742 it/s on 8192 x 262144, profiles/r1_tune_tn_geometry.log); 33..64 stay on four waves
+  const int W = env_int("PG_TN_WAVES", (nrg <= 16 || (nrg > 32 && nrg <= 64)) ? 4 : 8) == 8 ? 8 : 4;
   int U = 1;
   while (U * W < nrg) U *= 2;
   // two register tiles of C * U KiB per wave (one in flight, one being consumed), one workgroup per CU: the measured
@@ -776,6 +778,7 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // (short columns, U <= 4: 16 KiB tiles and two workgroups per CU measured best -- 6.0 TB/s at 2048 x 2^20)
   int C = env_int("PG_TN_C", U >= 8 ? 32 / U : 16 / U);
   if (W == 8 && U == 16) C = 1;
+  if (W == 8 && U == 4 && env_int("PG_TN_C", 0) == 0) C = 8;
   if (sizeof(T) == 8 && U == 1 && C > 16) C = 16;  // <f64, 1, 32> would spill
 #define PG_TN_CASE(UU, CC, WW) \
   if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)

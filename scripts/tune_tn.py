@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Sweep of the single-sweep kernel's launch geometry (environment tunables of csrc/pg_gemv.hip: PG_TN_C, PG_TN_BLOCKS):
-python scripts/tune_tn.py [m n]...  -> GB/s of gemv_tn per configuration."""
+"""Sweep of the single-sweep kernel's launch geometry (environment tunables of csrc/pg_gemv.hip: PG_TN_WAVES, PG_TN_C,
+PG_TN_BLOCKS_PER_CU): python scripts/tune_tn.py [m n]...  -> GB/s of gemv_tn per configuration, best first."""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import proximalalgorithms.jl_amd as pa
+
+KNOBS = ("PG_TN_WAVES", "PG_TN_C", "PG_TN_BLOCKS_PER_CU")
 
 def main():
     shapes = [(16384, 1 << 20), (16384, 131072), (8192, 262144)]
@@ -20,25 +22,31 @@ def main():
         g = pa.NormL1(0.3)
         res = []
         nrg = m * 4 // 1024
-        U = 1
-        while U * 4 < nrg: U *= 2
-        Cs = sorted({max(1, 16 // U), max(1, 32 // U)})
-        for C in Cs:
-            for blocks in (192, 256, 320, 384, 448, 512, 576, 640, 768, 1024):
-                os.environ["PG_TN_C"] = str(C); os.environ["PG_TN_BLOCKS"] = str(blocks)
-                try:
-                    for _ in range(2): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
-                    ctx.profile(True, kernels=("gemv_tn",)); ctx.profile_reset()
-                    for _ in range(8): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
-                    cnt, ms = ctx.profile_read()["gemv_tn"]; ctx.profile(False)
-                    res.append((m * n * 4 / (ms / cnt * 1e-3) / 1e9, C, blocks))
-                except Exception as e:
-                    print("  failed", C, blocks, str(e)[:80])
+        for W in (4, 8):
+            U = 1
+            while U * W < nrg: U *= 2
+            for C in sorted({max(1, 8 // U), max(1, 16 // U), max(1, 32 // U)}):
+                for bpc in (1, 2, 3, 4):
+                    os.environ.update(PG_TN_WAVES=str(W), PG_TN_C=str(C), PG_TN_BLOCKS_PER_CU=str(bpc))
+                    try:
+                        for _ in range(2): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
+                        ctx.profile(True, kernels=("gemv_tn",)); ctx.profile_reset()
+                        for _ in range(10): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
+                        cnt, ms = ctx.profile_read()["gemv_tn"]; ctx.profile(False)
+                        res.append((m * n * 4 / (ms / cnt * 1e-3) / 1e9, W, U, C, bpc))
+                    except Exception as e:
+                        ctx.profile(False)
+                        if bpc == 1: print(f"  W={W} U={U} C={C}: not instantiated")
+                        break
+        for k in KNOBS: os.environ.pop(k, None)
+        for _ in range(2): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
+        ctx.profile(True, kernels=("gemv_tn",)); ctx.profile_reset()
+        for _ in range(10): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
+        cnt, ms = ctx.profile_read()["gemv_tn"]; ctx.profile(False)
         res.sort(reverse=True)
-        print(f"=== {m}x{n} ===")
-        for gb, C, blocks in res[:8]: print(f"  C={C} blocks={blocks}: {gb:7.0f} GB/s")
+        print(f"=== {m}x{n} ===   default geometry: {m * n * 4 / (ms / cnt * 1e-3) / 1e9:7.0f} GB/s")
+        for gb, W, U, C, bpc in res[:10]: print(f"  W={W} U={U} C={C} blocks/CU={bpc}: {gb:7.0f} GB/s")
         print("  worst:", res[-1])
-        os.environ.pop("PG_TN_C"); os.environ.pop("PG_TN_BLOCKS")
         del f, A
 
 if __name__ == "__main__":

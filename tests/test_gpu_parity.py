@@ -1365,7 +1365,7 @@ def test_fuzz_newton_type_and_douglas_rachford(pa):
 @pytest.mark.parametrize("gname", ["l1", "box", "zero"])
 def test_fused_single_sweep_pass_matches_separate_kernels(pa, dtype, gname):
     rng = np.random.default_rng(11)
-    shapes = [(1, 1), (5, 3), (200, 500), (256, 64), (257, 65), (1000, 33), (4096, 40), (4097, 130), (16384, 24), (20000, 9)]
+    shapes = [(1, 1), (5, 3), (200, 500), (256, 64), (257, 65), (1000, 33), (4096, 40), (4097, 130), (8192, 70), (16384, 24), (20000, 9)]
     shapes += [(32768, 5)] if dtype == np.float32 else [(16385, 4)]
     for (m, n) in shapes:
         if dtype == np.float64 and m > 16384:
