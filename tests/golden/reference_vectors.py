@@ -156,3 +156,26 @@ LOGISTIC_TOL = 1e-6
 LOGISTIC_BOUNDS = {"fb_adaptive": 1100, "fb_adaptive_regret": 500, "ffb_adaptive": 500, "ffb_adaptive_regret": 200,
                    "panoc_adaptive": 50}  # :45,60,71,86,108
 PANOC_LASSO_BOUNDS = {"fixed": 20, "adaptive": 20}  # test_lasso_small.jl:167,179
+
+
+# ---- second group of pins: SFISTA / DRLS / AFBA on test_lasso_small.jl, DavisYin / AFBA on test_elasticnet.jl ----
+LASSO_SMALL_BOUNDS_EXT = {
+    "dr": 30,  # test_lasso_small.jl:212  DouglasRachford(gamma = 10 / opnorm(A)^2)
+    "drls_lbfgs": 17,  # :217  DRLS(tol = 10 TOL, directions = LBFGS(5)), x within 10 TOL
+    "drls_nesterov_fixed": 36,  # :220
+    "drls_nesterov_simple": 36,  # :221
+    "afba_f_g": 80,  # :247   AFBA(theta = 1, mu = 1, tol = 1e-6)(f = fA, g = g, beta_f = opnorm(A)^2), x within 1e-4
+    "afba_f_h": 100,  # :261  same with h = g instead of g
+    "afba_h_L_g": 150,  # :270  (h = f_prox, L = A, g = g), y0 in R^m
+    "sfista": 100,  # :281  SFISTA(tol = 10 TOL), x within 10 TOL
+}
+SC_BOUNDS_EXT = {"sfista": 40, "drls": 14}  # test_lasso_small_strongly_convex.jl:61, :151
+
+# test_elasticnet.jl:8-29: same A, b as the small LASSO; reg = NormL1(1) + SqrNormL2(1); loss = ||. - b||^2 / 2
+ELASTICNET_XSTAR = np.array([-0.6004983388704322, 0.0, 0.0, 0.195182724252491, 0.764119601328903])
+ELASTICNET_DYS = {"tol": 1e-6, "x_tol": 1e-3, "it": 140}  # :37-41 (<=)
+ELASTICNET_AFBA = [(2, 0, 130), (1, 1, 2000), (0, 1, 320), (0, 0, 194), (1, 0, 130)]  # :56 (theta, mu, maxit); x within 1e-4
+
+# test_nonconvex_qp.jl:9-31 (tiny): Q = Diagonal(-0.5, 1), q = (0.3, 0.5), box [-1, 1], gamma = 0.95 / max(diag Q)
+NCQP_Q_VEC = np.array([0.3, 0.5])
+NCQP_TOL = 1e-4

@@ -398,3 +398,130 @@ class TestZeroFPRPANOCplusPins:
         p2 = o.PANOCplusIteration(f=fA, A=eye, g=o.NormL1(lam), x0=x0, gamma=gamma)
         for s1, s2 in itertools.islice(zip(p1, p2), 10):
             np.testing.assert_allclose(s1.z, s2.z, rtol=2e-3 if dtype == np.float32 else 1e-7, atol=1e-5 if dtype == np.float32 else 1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# second group: SFISTA, DavisYin, LiLin, DRLS, AFBA / VuCondat / ChambollePock (oracle/proxgrad_oracle_ext.py)
+# ------------------------------------------------------------------------------------------------
+from oracle import proxgrad_oracle_ext as ox  # noqa: E402
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+class TestSecondGroupLassoSmall:
+    """test/problems/test_lasso_small.jl:205-283"""
+
+    def xs(self, dtype):
+        return rv.LASSO_SMALL_XSTAR.astype(dtype)
+
+    def test_sfista(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        y, it = ox.sfista(tol=10 * rv.LASSO_SMALL_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=Lf)
+        assert y.dtype == dtype and np.all(x0 == 0)
+        assert np.max(np.abs(y - self.xs(dtype))) <= 10 * rv.LASSO_SMALL_TOL
+        assert it < rv.LASSO_SMALL_BOUNDS_EXT["sfista"]
+
+    @pytest.mark.parametrize("directions,key", [("lbfgs", "drls_lbfgs"), ("nesterov_fixed", "drls_nesterov_fixed"),
+                                                ("nesterov_simple", "drls_nesterov_simple")])
+    def test_drls(self, dtype, directions, key):
+        A, b, lam, Lf = lasso_small(dtype)
+        x0 = np.zeros(5, dtype)
+        z, it = ox.drls(tol=10 * rv.LASSO_SMALL_TOL, directions=directions, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam),
+                        Lf=Lf)
+        assert z.dtype == dtype and np.all(x0 == 0)
+        assert np.max(np.abs(z - self.xs(dtype))) <= 10 * rv.LASSO_SMALL_TOL
+        assert it < rv.LASSO_SMALL_BOUNDS_EXT[key]
+
+    def test_afba(self, dtype):
+        A, b, lam, Lf = lasso_small(dtype)
+        R = np.dtype(dtype).type
+        x0 = np.zeros(5, dtype)
+        fA, g = o.LeastSquares(A, b), o.NormL1(lam)
+        (x, y), it = ox.afba(theta=1, mu=1, tol=R(1e-6), x0=x0, y0=np.zeros(5, dtype), f=fA, g=g, beta_f=Lf)
+        assert x.dtype == dtype and y.dtype == dtype
+        assert np.max(np.abs(x - self.xs(dtype))) <= 1e-4 and it <= rv.LASSO_SMALL_BOUNDS_EXT["afba_f_g"]
+        (x, y), it = ox.afba(theta=1, mu=1, tol=R(1e-6), x0=x0, y0=np.zeros(5, dtype), f=fA, h=g, beta_f=Lf)
+        assert np.max(np.abs(x - self.xs(dtype))) <= 1e-4 and it <= rv.LASSO_SMALL_BOUNDS_EXT["afba_f_h"]
+        (x, y), it = ox.afba(theta=1, mu=1, tol=R(1e-6), x0=x0, y0=np.zeros(4, dtype), h=ox.SqrDistance(b), L=A, g=g)
+        assert np.max(np.abs(x - self.xs(dtype))) <= 1e-4 and it <= rv.LASSO_SMALL_BOUNDS_EXT["afba_h_L_g"]
+        assert np.all(x0 == 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+class TestSecondGroupStronglyConvex:
+    """test/problems/test_lasso_small_strongly_convex.jl:56-65, :146-153"""
+
+    def test_sfista(self, dtype):
+        A, b, lam, x0 = rv.strongly_convex_problem(dtype)
+        x0b = x0.copy()
+        y, it = ox.sfista(tol=rv.SC_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=rv.SC_LF, mf=rv.SC_MF)
+        assert y.dtype == dtype and np.array_equal(x0, x0b)
+        assert np.linalg.norm(y - rv.SC_XSTAR.astype(dtype)) <= rv.SC_TOL
+        assert it < rv.SC_BOUNDS_EXT["sfista"]
+
+    def test_drls(self, dtype):
+        A, b, lam, x0 = rv.strongly_convex_problem(dtype)
+        x0b = x0.copy()
+        v, it = ox.drls(tol=rv.SC_TOL, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), mf=rv.SC_MF)
+        assert v.dtype == dtype and np.array_equal(x0, x0b)
+        assert np.max(np.abs(v - rv.SC_XSTAR.astype(dtype))) <= rv.SC_TOL
+        assert it < rv.SC_BOUNDS_EXT["drls"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dr_equals_drls_without_acceleration(dtype):
+    """test/problems/test_equivalence.jl:14-49"""
+    A, b, lam, Lf = lasso_small(dtype)
+    R = np.dtype(dtype).type
+    f, g = o.LeastSquares(A, b), o.NormL1(lam)
+    x0 = np.zeros(5, dtype)
+    gamma = R(10) / R(np.linalg.norm(A, 2) ** 2)
+    dr = iter(o.DouglasRachfordIteration(f=f, g=g, x0=x0, gamma=gamma))
+    dl = iter(ox.DRLSIteration(f=f, g=g, x0=x0, gamma=gamma, lam=1, c=-np.inf, max_backtracks=1, directions="none",
+                               Lf=Lf))
+    for _ in range(10):
+        a, bb = next(dr), next(dl)
+        assert np.allclose(a.x, bb.xbar, rtol=np.sqrt(np.finfo(dtype).eps), atol=0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+class TestElasticNet:
+    """test/problems/test_elasticnet.jl"""
+
+    def test_davis_yin(self, dtype):
+        A, b, _, Lf = lasso_small(dtype)
+        R = np.dtype(dtype).type
+        for x0 in (np.zeros(5, dtype), np.random.default_rng(3).standard_normal(5).astype(dtype)):
+            x, it = ox.davis_yin(tol=R(rv.ELASTICNET_DYS["tol"]), x0=x0.copy(), f=o.LeastSquares(A, b), g=o.NormL1(R(1)),
+                                 h=ox.SqrNormL2(R(1)), Lf=Lf)
+            assert x.dtype == dtype
+            assert np.max(np.abs(x - rv.ELASTICNET_XSTAR.astype(dtype))) <= rv.ELASTICNET_DYS["x_tol"]
+            if not x0.any():
+                assert it <= rv.ELASTICNET_DYS["it"]
+
+    @pytest.mark.parametrize("theta,mu,maxit", rv.ELASTICNET_AFBA)
+    def test_afba(self, dtype, theta, mu, maxit):
+        A, b, _, _ = lasso_small(dtype)
+        R = np.dtype(dtype).type
+        rng = np.random.default_rng(5)
+        for x0, y0 in ((np.zeros(5, dtype), np.zeros(4, dtype)),
+                       (rng.standard_normal(5).astype(dtype), rng.standard_normal(4).astype(dtype))):
+            (x, y), it = ox.afba(theta=theta, mu=mu, tol=R(1e-6), x0=x0, y0=y0, f=ox.SqrNormL2(R(1)), g=o.NormL1(R(1)),
+                                 h=ox.SqrDistance(b), L=A, beta_f=1)
+            assert x.dtype == dtype and y.dtype == dtype
+            assert np.max(np.abs(x - rv.ELASTICNET_XSTAR.astype(dtype))) <= 1e-4
+            if not x0.any():
+                assert it <= maxit
+
+
+def test_lilin_nonconvex_qp_tiny():
+    """test/problems/test_nonconvex_qp.jl:58-66 (Float64)"""
+    Q = np.diag(rv.NCQP_Q_DIAG)
+    q = rv.NCQP_Q_VEC
+    gamma = 0.95 / np.max(rv.NCQP_Q_DIAG)
+    x0 = np.zeros(2)
+    it_obj = ox.LiLinIteration(x0=x0, f=o.Quadratic(Q, q), g=o.IndBox(-1.0, 1.0), gamma=gamma)
+    x, it = ox.li_lin(tol=rv.NCQP_TOL, x0=x0, f=o.Quadratic(Q, q), g=o.IndBox(-1.0, 1.0), gamma=gamma)
+    z = np.minimum(1.0, np.maximum(-1.0, x - gamma * (Q @ x + q)))
+    assert np.max(np.abs(x - z)) / gamma <= rv.NCQP_TOL
+    assert np.all(x0 == 0) and it_obj.monitor_branch_taken == 0
