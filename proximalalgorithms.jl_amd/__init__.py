@@ -16,16 +16,27 @@ from .forward_backward import (ForwardBackward, ForwardBackwardIteration, Forwar
                                ProximalGradientIteration)
 from .lbfgs import LBFGS, LBFGSOperator
 from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, FixedNesterovSequence,
-                       SimpleNesterovSequence, next_)
-from .operators import (Composed, IndBox, LeastSquares, LogisticLoss, NormL1, SeparableQuadratic, SquaredDistance,
-                        Zero, gradient_, prox, prox_, value_and_gradient)
+                       NesterovExtrapolation, SimpleNesterovSequence, next_)
+from .operators import (Composed, Conjugate, IndBox, IndZero, LeastSquares, LogisticLoss, NormL1, Quadratic,
+                        SeparableQuadratic, SqrNormL2, SquaredDistance, Zero, convex_conjugate, gradient_, is_convex,
+                        is_generalized_quadratic, prox, prox_, value_and_gradient)
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
 from .panocplus import PANOCplus, PANOCplusIteration
 from .sharding import NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce_sum_, shard_cols, shard_rows
 
 from .zerofpr import ZeroFPR, ZeroFPRIteration
+from .sfista import SFISTA, SFISTAIteration
+from .davis_yin import DavisYin, DavisYinIteration
+from .li_lin import LiLin, LiLinIteration
+from .drls import DRLS, DRLSIteration
+from .primal_dual import (AFBA, AFBAIteration, ChambollePock, ChambollePockIteration, VuCondat, VuCondatIteration,
+                          AFBA_default_stepsizes)
 
 __all__ = [
+    "SFISTA", "SFISTAIteration", "DavisYin", "DavisYinIteration", "LiLin", "LiLinIteration", "DRLS", "DRLSIteration",
+    "AFBA", "AFBAIteration", "VuCondat", "VuCondatIteration", "ChambollePock", "ChambollePockIteration",
+    "AFBA_default_stepsizes", "NesterovExtrapolation", "Conjugate", "IndZero", "Quadratic", "SqrNormL2",
+    "convex_conjugate", "is_convex", "is_generalized_quadratic",
     "ZeroFPR", "ZeroFPRIteration", "PANOCplus", "PANOCplusIteration",
     "ProxGradError", "IterativeAlgorithm", "DouglasRachford", "DouglasRachfordIteration", "DouglasRachfordState",
     "SeparableQuadratic", "PANOC", "PANOCIteration", "PANOCState", "NoAcceleration", "Composed", "LogisticLoss",

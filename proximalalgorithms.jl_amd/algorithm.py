@@ -2,6 +2,13 @@
 from .device import HIPVector
 
 
+def _like_x0(sol, host_x0):
+    """eltype / array kind of the answer follows x0 (test_lasso_small.jl:51); tuples (primal-dual pairs) elementwise"""
+    if isinstance(sol, tuple):
+        return tuple(_like_x0(v, host_x0) for v in sol)
+    return sol.numpy() if (host_x0 and isinstance(sol, HIPVector)) else sol
+
+
 class IterativeAlgorithm:
     """Wrapper for an iterator type adding termination and verbosity options
     (src/ProximalAlgorithms.jl:58-112).  Calling it merges the keyword arguments, builds the iterator
@@ -31,10 +38,7 @@ class IterativeAlgorithm:
         if (self.device_loop is not None and getattr(it, "engine", None) == "fused" and not self.verbose
                 and hasattr(it, "device_run")):
             state, k = it.device_run(self.maxit, *self.device_loop)  # iterations that carry their own in-library loop
-            sol = self.solution(it, state)
-            if host_x0 and isinstance(sol, HIPVector):
-                sol = sol.numpy()
-            return sol, k
+            return _like_x0(self.solution(it, state), host_x0), k
         if self.device_loop is not None and getattr(it, "engine", None) == "fused" and not self.verbose:
             tol, check_every = self.device_loop
             gen = iter(it)
@@ -58,17 +62,11 @@ class IterativeAlgorithm:
             else:
                 k, _ = fused.run(1, self.maxit, tol)
             state._invalidate()
-            sol = self.solution(it, state)
-            if host_x0 and isinstance(sol, HIPVector):
-                sol = sol.numpy()
-            return sol, k
+            return _like_x0(self.solution(it, state), host_x0), k
         for k, state in enumerate(it, start=1):
             if k >= self.maxit or self.stop(it, state):
                 if self.verbose:
                     self.display(k, it, state)
-                sol = self.solution(it, state)
-                if host_x0 and isinstance(sol, HIPVector):
-                    sol = sol.numpy()  # eltype/array kind of the answer follows x0 (test_lasso_small.jl:51)
-                return sol, k
+                return _like_x0(self.solution(it, state), host_x0), k
             if self.verbose and k % self.freq == 0:
                 self.display(k, it, state)

@@ -1,0 +1,110 @@
+"""Li-Lin nonconvex accelerated proximal gradient -- mirror of src/algorithms/li_lin.jl (Algorithm 2 of Li & Lin 2015).
+
+Per iteration: f at z, one value_and_gradient at the extrapolated point y, the prox of g and a handful of AXPBYs; the
+monitor branch adds a plain proximal-gradient step from x.  All vector arithmetic runs in the library's HIP kernels.
+"""
+import numpy as np
+
+from .algorithm import IterativeAlgorithm
+from .device import as_hipvector
+from .operators import Zero, prox_, value_and_gradient
+
+
+class LiLinState:
+    """li_lin.jl:53-66"""
+
+
+class LiLinIteration:
+    """li_lin.jl:40-49 (f, g, x0, Lf | gamma, adaptive, delta = 1e-3, eta = 0.8); init :69-97; step :99-144.
+
+    li_lin.jl:108 reads an unbound name ``x`` in the monitor branch (UndefVarError in the reference); this mirror
+    evaluates the gradient at ``state.x`` as Algorithm 2 prescribes and counts the visits in ``monitor_branch_taken``."""
+
+    def __init__(self, *, x0, f=None, g=None, Lf=None, gamma=None, adaptive=False, delta=1e-3, eta=0.8):
+        self.x0 = as_hipvector(x0)
+        R = self.x0.dtype.type
+        self.f = f if f is not None else Zero()
+        self.g = g if g is not None else Zero()
+        if gamma is None and Lf is not None:
+            gamma = R(1) / R(Lf)
+        if gamma is None:
+            raise ValueError("either gamma or Lf must be given (the reference would fail on `nothing .* grad`)")
+        self.gamma = R(gamma)
+        self.adaptive, self.delta, self.eta = bool(adaptive), R(delta), R(eta)
+        self.monitor_branch_taken = 0
+
+    def __iter__(self):
+        R = self.x0.dtype.type
+        s = LiLinState()
+        s.y = self.x0.copy()
+        s.f_y, g = value_and_gradient(self.f, s.y)
+        s.grad_f_y = g.copy() if g is not None else None
+        s.gamma = self.gamma
+        s.y_forward = s.y.similar().axpby_(1.0, s.y, -float(s.gamma), s.grad_f_y)
+        s.z = s.y.similar()
+        s.g_z = prox_(s.z, self.g, s.y_forward, s.gamma)
+        Fy = R(s.f_y + self.g(s.y))
+        if not np.isfinite(Fy):
+            raise AssertionError("initial point must be feasible")  # :75
+        s.x = self.x0.copy()
+        s.res = s.y.similar().axpby_(1.0, s.y, -1.0, s.z)
+        s.theta, s.F_average, s.q = R(1), Fy, R(1)
+        v, xf = s.y.similar(), s.y.similar()
+        yield s
+        while True:
+            Fz = R(self.f(s.z) + s.g_z)  # :103
+            theta1 = R((R(1) + R(np.sqrt(R(R(1) + R(4) * s.theta * s.theta)))) / R(2))  # :104
+            if Fz <= s.F_average - self.delta * s.res.norm() ** 2:  # :106
+                case = 1
+            else:
+                self.monitor_branch_taken += 1
+                _, gx = value_and_gradient(self.f, s.x)
+                xf.axpby_(1.0, s.x, -float(s.gamma), gx)
+                g_v = prox_(v, self.g, xf, s.gamma)
+                Fv = R(self.f(v) + g_v)
+                case = 1 if Fz <= Fv else 2
+            if case == 1:
+                c = R((s.theta - R(1)) / theta1)
+                s.y.axpby_(R(R(1) + c), s.z, -float(c), s.x)  # z + c (z - x)   (:116)
+                s.x, s.z = s.z, s.x
+                Fx = Fz
+            else:
+                c1, c2 = R(s.theta / theta1), R((s.theta - R(1)) / theta1)
+                s.y.axpby_(R(R(1) + c1), s.z, R(c2 - c1), v)  # z + c1 (z - v) + c2 (v - x)   (:120-122)
+                s.y.axpby_(1.0, s.y, -float(c2), s.x)
+                s.x.copy_from(v)
+                Fx = Fv
+            s.f_y, g = value_and_gradient(self.f, s.y)  # :128
+            s.grad_f_y.copy_from(g)
+            s.y_forward.axpby_(1.0, s.y, -float(s.gamma), s.grad_f_y)
+            s.g_z = prox_(s.z, self.g, s.y_forward, s.gamma)
+            s.res.axpby_(1.0, s.y, -1.0, s.z)
+            s.theta = theta1
+            q1 = R(self.eta * s.q + R(1))  # :139-141
+            s.F_average = R((self.eta * s.q * s.F_average + Fx) / q1)
+            s.q = q1
+            yield s
+
+
+def default_stopping_criterion(tol, iteration, state):
+    """norm(state.res, Inf) / state.gamma <= tol  (li_lin.jl:146-147)"""
+    R = state.res.dtype.type
+    return state.res.norm_inf() / state.gamma <= R(tol)
+
+
+def default_solution(iteration, state):
+    """li_lin.jl:148"""
+    return state.z
+
+
+def default_display(it, iteration, state):
+    print("%5d | %.3e | %.3e" % (it, state.gamma, state.res.norm_inf() / state.gamma))
+
+
+def LiLin(*, maxit=10_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
+          display=default_display, **kwargs):
+    """li_lin.jl:183-201"""
+    if stop is None:
+        stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
+    return IterativeAlgorithm(LiLinIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose, freq=freq,
+                              display=display, **kwargs)

@@ -76,3 +76,14 @@ class AdaptiveNesterovSequence:
 def next_(seq, stepsize):
     """ProximalAlgorithms.next!(seq, stepsize)"""
     return seq.next(stepsize)
+
+
+class NesterovExtrapolation:
+    """nesterov.jl:105-113: acceleration-style tag; ``initialize(x)`` is a stateful iterator over the sequence type
+    (default SimpleNesterovSequence) in the precision of x."""
+
+    def __init__(self, sequence_type=SimpleNesterovSequence):
+        self.sequence_type = sequence_type
+
+    def initialize(self, x):
+        return iter(self.sequence_type(x.dtype.type))

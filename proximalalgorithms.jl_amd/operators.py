@@ -23,6 +23,16 @@ from ._lib import PG_G_INDBOX, PG_G_NORML1, PG_G_ZERO, call
 from .device import HIPMatrix, HIPVector, as_hipvector
 
 
+def is_convex(f):
+    """ProximalCore.is_convex(typeof(f)) (trait; operators of this package declare it as a class attribute)"""
+    return bool(getattr(f, "is_convex", False))
+
+
+def is_generalized_quadratic(f):
+    """ProximalCore.is_generalized_quadratic(typeof(f))"""
+    return bool(getattr(f, "is_generalized_quadratic", False))
+
+
 class LeastSquares:
     """f(x) = lam/2 ||A x - b||^2 on the device (ProximalOperators.LeastSquares(A, b[, lam])).
 
@@ -30,6 +40,9 @@ class LeastSquares:
     Row-sharded use (one process per GPU): pass the local row block and ``comm`` (see sharding.py);
     every evaluation then all-reduces [grad ; f] over the shards.
     """
+
+    is_convex = True
+    is_generalized_quadratic = True
 
     def __init__(self, A, b, lam=1.0, ctx=None, comm=None):
         if not isinstance(A, HIPMatrix):
@@ -86,6 +99,44 @@ class LeastSquares:
         R = self.dtype.type
         return tuple(R(v) for v in sc)
 
+    def prox_(self, y, x, gamma):
+        """ProximalCore.prox!(y, f, x, gamma) -> f(y): y = argmin lam/2 ||A z - b||^2 + ||z - x||^2 / (2 gamma)
+        = (lam A'A + I/gamma) \\ (lam A'b + x/gamma)  (ProximalOperators.LeastSquares, direct solver).
+
+        Like the reference's cached factorisation, the system matrix is prepared once per gamma on the host (float64
+        inverse of the min(m, n)-sized system: normal equations when m >= n, Woodbury when m < n -- meant for the
+        small / moderate sizes DouglasRachford-type splittings use it on); every application is device work:
+        one or three GEMV passes of the library plus AXPBYs.  Not available on sharded operators."""
+        if self.comm is not None:
+            raise TypeError("LeastSquares.prox_ is not available on a sharded operator")
+        R = self.dtype.type
+        gamma = float(R(gamma))
+        cache = getattr(self, "_prox_cache", None)
+        if cache is None or cache["gamma"] != gamma:
+            A64 = self.A.numpy().astype(np.float64)
+            m, n = A64.shape
+            cache = {"gamma": gamma, "q": x.similar(), "c0": self.A.mul_adjoint(self.b)}
+            cache["c0"].axpby_(self.lam, cache["c0"])  # lam A'b
+            if m >= n:
+                M = np.linalg.inv(self.lam * (A64.T @ A64) + np.eye(n) / gamma)
+                cache["M"] = HIPMatrix.from_numpy(np.asfortranarray(M.astype(self.dtype)), self.ctx)
+            else:
+                S = np.linalg.inv(np.eye(m) + gamma * self.lam * (A64 @ A64.T))
+                cache["S"] = HIPMatrix.from_numpy(np.asfortranarray(S.astype(self.dtype)), self.ctx)
+                cache["t"] = HIPVector.empty(m, self.dtype, self.ctx)
+                cache["t2"] = HIPVector.empty(m, self.dtype, self.ctx)
+                cache["w"] = x.similar()
+            self._prox_cache = cache
+        q = cache["q"].axpby_(1.0 / gamma, x, 1.0, cache["c0"])  # lam A'b + x / gamma
+        if "M" in cache:
+            cache["M"].mul(q, y)
+        else:
+            self.A.mul(q, cache["t"])
+            cache["S"].mul(cache["t"], cache["t2"])
+            self.A.mul_adjoint(cache["t2"], cache["w"])
+            y.axpby_(gamma, q, -gamma * gamma * self.lam, cache["w"])
+        return self(y)
+
     def residual(self):
         """A x - b of the last evaluation (view of the library-owned m-vector)."""
         p = C.c_void_p()
@@ -97,6 +148,7 @@ class NormL1:
     """g(x) = lam ||x||_1 (ProximalOperators.NormL1(lam)); prox = soft threshold."""
 
     g_kind = PG_G_NORML1
+    is_convex = True
 
     def __init__(self, lam=1.0):
         if lam < 0:
@@ -122,6 +174,7 @@ class IndBox:
     Bounds are scalars or vectors."""
 
     g_kind = PG_G_INDBOX
+    is_convex = True
 
     def __init__(self, lo, hi):
         self.lo, self.hi = lo, hi
@@ -162,6 +215,9 @@ class SeparableQuadratic:
     """f(x) = sum_i d_i x_i^2 / 2 + q_i x_i with d >= 0 -- the smooth term of a box-constrained QP with diagonal
     Hessian (ProximalOperators: ``Tilt(SqrNormL2(d), q)`` == ``Quadratic(Diagonal(d), q)``).  ``d``/``q`` are scalars
     or vectors.  prox_{gamma f}(x) = (x - gamma q) ./ (1 + gamma d); value_and_gradient = (f(x), d .* x + q)."""
+
+    is_convex = True  # d >= 0
+    is_generalized_quadratic = True
 
     def __init__(self, d, q, ctx=None):
         self._d_scalar, self._q_scalar = np.isscalar(d), np.isscalar(q)
@@ -209,13 +265,120 @@ class SquaredDistance(_Loss):
     test_lasso_small.jl:32-33).  Generalized quadratic: PANOC uses the interpolation branch (panoc.jl:215-237)."""
 
     loss_id = 0
+    is_convex = True
     is_generalized_quadratic = True
+
+    def __init__(self, b, lam=1.0, ctx=None):
+        super().__init__(b, ctx)
+        self.lam = float(lam)
+
+    def value_and_gradient(self, u, out=None):
+        v, g = super().value_and_gradient(u, out)
+        if self.lam != 1.0:
+            g.axpby_(self.lam, g)
+            v = u.dtype.type(self.lam) * v
+        return v, g
+
+    def prox_(self, y, x, gamma):
+        """Translate(SqrNormL2(lam), -b) (test_lasso_small.jl:38, test_elasticnet.jl:24):
+        prox = (x + lam gamma b) / (1 + lam gamma); returns f(y)"""
+        lg = self.lam * float(gamma)
+        y.axpby_(1.0 / (1.0 + lg), x, lg / (1.0 + lg), self.b)
+        return self(y)
+
+
+class SqrNormL2:
+    """f(x) = lam/2 ||x||^2 (ProximalOperators.SqrNormL2(lam), test_elasticnet.jl:23): prox = x / (1 + lam gamma),
+    gradient lam x."""
+
+    is_convex = True
+    is_generalized_quadratic = True
+
+    def __init__(self, lam=1.0):
+        if lam < 0:
+            raise ValueError("parameter lam must be nonnegative")
+        self.lam = float(lam)
+
+    def __call__(self, x):
+        R = x.dtype.type
+        return R(R(self.lam) / R(2) * x.norm() ** 2)
+
+    def prox_(self, y, x, gamma):
+        y.axpby_(1.0 / (1.0 + self.lam * float(gamma)), x)
+        return self(y)
+
+    def value_and_gradient(self, x, out=None):
+        g = out if out is not None else x.similar()
+        g.axpby_(self.lam, x)
+        return self(x), g
+
+
+class Quadratic:
+    """f(x) = <x, Q x> / 2 + <q, x> with a dense symmetric Q on the device (ProximalOperators.Quadratic; the closure
+    `x -> dot(Q * x, x) / 2 + dot(q, x)` of test_nonconvex_qp.jl:15-18): one GEMV pass per evaluation."""
+
+    def __init__(self, Q, q, ctx=None):
+        self.Q = Q if isinstance(Q, HIPMatrix) else HIPMatrix.from_numpy(np.asfortranarray(Q), ctx)
+        self.ctx = self.Q.ctx
+        self.q = as_hipvector(q, self.ctx)
+        self._Qx = HIPVector.empty(self.Q.m, self.Q.dtype, self.ctx)
+
+    def value_and_gradient(self, x, out=None):
+        R = x.dtype.type
+        self.Q.mul(x, self._Qx)
+        v = R(x.dot(self._Qx) / R(2) + self.q.dot(x))
+        g = out if out is not None else x.similar()
+        g.axpby_(1.0, self._Qx, 1.0, self.q)
+        return v, g
+
+    def __call__(self, x):
+        R = x.dtype.type
+        self.Q.mul(x, self._Qx)
+        return R(x.dot(self._Qx) / R(2) + self.q.dot(x))
+
+
+class IndZero:
+    """ProximalCore.IndZero: indicator of {0}.  Its conjugate is Zero (primal_dual.jl:187 evaluates
+    value_and_gradient(convex_conjugate(l), y))."""
+
+    def prox_(self, y, x, gamma):
+        y.fill_(0.0)
+        return x.dtype.type(0)
+
+
+class Conjugate:
+    """ProximalCore.convex_conjugate(f): prox through Moreau's identity,
+    prox_{gamma f*}(x) = x - gamma prox_{f / gamma}(x / gamma); returns f*(y) = <y, p> - f(p)."""
+
+    def __init__(self, f):
+        self.f = f
+        self._p = self._xs = None
+
+    def prox_(self, y, x, gamma):
+        R = x.dtype.type
+        if self._p is None or self._p.n != x.n:
+            self._p, self._xs = x.similar(), x.similar()
+        gamma = float(gamma)
+        self._xs.axpby_(1.0 / gamma, x)
+        fp = self.f.prox_(self._p, self._xs, 1.0 / gamma)
+        y.axpby_(1.0, x, -gamma, self._p)
+        return R(y.dot(self._p) - fp)
+
+
+def convex_conjugate(f):
+    """ProximalCore.convex_conjugate"""
+    if isinstance(f, IndZero):
+        return Zero()
+    if isinstance(f, Conjugate):
+        return f.f
+    return Conjugate(f)
 
 
 class LogisticLoss(_Loss):
     """f(u) = sum(log.(1 .+ exp.(-(u .- b)))), labels all one (test_sparse_logistic_small.jl:20-26)."""
 
     loss_id = 1
+    is_convex = True
 
 
 class Composed:
@@ -243,6 +406,8 @@ class Zero:
     prox = identity."""
 
     g_kind = PG_G_ZERO
+    is_convex = True
+    is_generalized_quadratic = True
 
     def g_params(self):
         return 0.0, 0.0
