@@ -154,6 +154,9 @@ pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double s
 /* ... the block at (row_offset, col_offset) of the same global matrix (row shards use the first, column shards the second) */
 pg_status pg_mat_generate_block(pg_mat* A, uint32_t seed, int64_t row_offset, int64_t col_offset, double scale);
 pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int32_t* dtype, void** dptr);
+/* A += alpha * u * w'  (u: m-vector, w: n-vector, device): the `L.H .+= (s - Hy) / dot(...) * sH` rank-one update of
+ * the Broyden operator, src/accel/broyden.jl:18-28 */
+pg_status pg_mat_rank1_update(pg_mat* A, double alpha, const void* u, const void* w);
 /* y = A x  (mul!(y, A, x)) and g = A' r  (mul!(g, A', r)) -- the two GEMV orientations on the
  * column-major store; used by LeastSquares and (later) PANOC's `mul!` with A: panoc.jl:150-190 */
 pg_status pg_mat_mul(pg_mat* A, const void* x, void* y);

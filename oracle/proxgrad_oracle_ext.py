@@ -271,6 +271,64 @@ def li_lin(*, maxit=10_000, tol=1e-8, **kw):
 
 
 # --------------------------------------------------------------------------------------
+# Anderson and Broyden accelerations               src/accel/anderson.jl, src/accel/broyden.jl
+# --------------------------------------------------------------------------------------
+
+
+class AndersonAccelerationOperator:
+    """anderson.jl:5-62: circular memory of M (s, y) pairs; mul!: d = v + (S - Y) pinv(Y'Y) Y'v."""
+
+    def __init__(self, M, x):
+        self.M, self.currmem, self.curridx = M, 0, 0
+        self.s_M = [np.zeros_like(x) for _ in range(M)]
+        self.y_M = [np.zeros_like(x) for _ in range(M)]
+
+    def update(self, s, y):
+        self.curridx = 1 if self.curridx + 1 > self.M else self.curridx + 1  # :29-32
+        self.currmem = min(self.currmem + 1, self.M)  # :33-36
+        self.s_M[self.curridx - 1][...] = s
+        self.y_M[self.curridx - 1][...] = y
+        return self
+
+    def reset(self):
+        self.currmem = self.curridx = 0
+
+    def __mul__(self, v):
+        if self.currmem == 0:
+            return v.copy()
+        S = np.stack(self.s_M[: self.currmem], axis=1)
+        Y = np.stack(self.y_M[: self.currmem], axis=1)
+        return (v + (S - Y) @ (np.linalg.pinv(Y.T @ Y) @ (Y.T @ v))).astype(v.dtype)  # :59
+
+
+class BroydenOperator:
+    """broyden.jl:5-43: dense H (identity at start), Powell-damped rank-one update."""
+
+    def __init__(self, x, theta_bar=0.2):
+        self.H = np.eye(x.size, dtype=x.dtype)
+        self.theta_bar = _R(x)(theta_bar)
+
+    def update(self, s, y):
+        R = _R(s)
+        Hy = self.H @ y  # :19
+        sH = s @ self.H  # :20
+        delta = R(_dot(Hy, s) / _norm(s) ** 2)  # :21
+        if abs(delta) >= self.theta_bar:  # :22-26
+            theta = R(1)
+        else:
+            sgn = R(1) if delta == 0 else R(np.sign(delta))
+            theta = R((R(1) - sgn * self.theta_bar) / (R(1) - delta))
+        self.H += np.outer((s - Hy) / R(_dot(s, (R(1) / theta - R(1)) * s + Hy)), sH).astype(s.dtype)  # :27
+        return self
+
+    def reset(self):
+        self.H[...] = np.eye(self.H.shape[0], dtype=self.H.dtype)
+
+    def __mul__(self, v):
+        return (self.H @ v).astype(v.dtype)
+
+
+# --------------------------------------------------------------------------------------
 # Douglas-Rachford line search (DRLS)              src/algorithms/drls.jl
 # --------------------------------------------------------------------------------------
 
@@ -290,7 +348,7 @@ def drls_C(convex, mf, Lf, gamma, lam):
 
 
 class DRLSIteration:
-    """drls.jl:65-80 (options; ``directions`` in {"lbfgs" (memory 5), "nesterov_fixed", "nesterov_simple", "none"}),
+    """drls.jl:65-80 (options; ``directions`` in {"lbfgs", "anderson" (memory 5), "broyden", "nesterov_fixed", "nesterov_simple", "none"}),
     init :112-134, direction hooks :136-158, step :160-197.  ``f_convex`` / ``f_quadratic`` restate the traits
     ProximalCore.is_convex / is_generalized_quadratic of the operator type (true for LeastSquares and the quadratics
     used by the pins)."""
@@ -330,6 +388,10 @@ class DRLSIteration:
         H = seq = None
         if self.directions == "lbfgs":
             H = LBFGSOperator(self.memory, s.x)
+        elif self.directions == "broyden":
+            H = BroydenOperator(s.x)
+        elif self.directions == "anderson":
+            H = AndersonAccelerationOperator(self.memory, s.x)
         elif self.directions in ("nesterov_fixed", "nesterov_simple"):
             seq = fixed_nesterov_sequence(R) if self.directions == "nesterov_fixed" else simple_nesterov_sequence(R)
         s.H = H

@@ -26,6 +26,8 @@ from .sharding import NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce
 
 from .zerofpr import ZeroFPR, ZeroFPRIteration
 from .sfista import SFISTA, SFISTAIteration
+from .anderson import AndersonAcceleration, AndersonAccelerationOperator
+from .broyden import Broyden, BroydenOperator
 from .davis_yin import DavisYin, DavisYinIteration
 from .li_lin import LiLin, LiLinIteration
 from .drls import DRLS, DRLSIteration
@@ -33,6 +35,7 @@ from .primal_dual import (AFBA, AFBAIteration, ChambollePock, ChambollePockItera
                           AFBA_default_stepsizes)
 
 __all__ = [
+    "AndersonAcceleration", "AndersonAccelerationOperator", "Broyden", "BroydenOperator",
     "SFISTA", "SFISTAIteration", "DavisYin", "DavisYinIteration", "LiLin", "LiLinIteration", "DRLS", "DRLSIteration",
     "AFBA", "AFBAIteration", "VuCondat", "VuCondatIteration", "ChambollePock", "ChambollePockIteration",
     "AFBA_default_stepsizes", "NesterovExtrapolation", "Conjugate", "IndZero", "Quadratic", "SqrNormL2",

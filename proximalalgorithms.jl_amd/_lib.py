@@ -80,6 +80,7 @@ SIGNATURES = {
     "pg_mat_generate": [_vp, C.c_uint32, _i64, _f64],
     "pg_mat_generate_block": [_vp, C.c_uint32, _i64, _i64, _f64],
     "pg_mat_info": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_vp)],
+    "pg_mat_rank1_update": [_vp, _f64, _vp, _vp],
     "pg_mat_mul": [_vp, _vp, _vp],
     "pg_mat_mul_adjoint": [_vp, _vp, _vp],
     "pg_mat_fused_tn": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],

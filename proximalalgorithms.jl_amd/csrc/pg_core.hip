@@ -312,6 +312,26 @@ static inline uint32_t host_mix32(uint32_t h) {
   return h;
 }
 
+// A[i, j] += alpha * u[i] * w[j] on the padded column-major store (rows >= m stay zero): the rank-one update of the
+// Broyden operator (src/accel/broyden.jl:18-28).  HBM-bound: one read and one write of A, 16-byte accesses along columns.
+template <typename T>
+__global__ void rank1_update_kernel(T* __restrict__ A, int64_t m, int64_t n, int64_t ld, T alpha, const T* __restrict__ u,
+                                    const T* __restrict__ w) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t vec_per_col = ld / V;
+  const int64_t total = vec_per_col * n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / vec_per_col;
+    const int64_t i0 = (t - j * vec_per_col) * V;
+    if (i0 >= m) continue;
+    const T s = alpha * w[j];
+    T* p = A + j * ld + i0;
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+      if (i0 + k < m) p[k] += s * u[i0 + k];
+  }
+}
+
 extern "C" {
 
 pg_status pg_mat_create(pg_ctx* c, int32_t dtype, int64_t m, int64_t n, pg_mat** out) {
@@ -423,6 +443,23 @@ pg_status pg_mat_generate_block(pg_mat* A, uint32_t seed, int64_t row_offset, in
   else
     hipLaunchKernelGGL(generate_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream, (double*)A->data, A->m,
                        A->n, A->ld, hseed, (uint32_t)row_offset, (uint32_t)col_offset, (float)scale);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+pg_status pg_mat_rank1_update(pg_mat* A, double alpha, const void* u, const void* w) {
+  PG_REQUIRE(A != nullptr && u != nullptr && w != nullptr, "null argument");
+  if (A->m == 0 || A->n == 0) return PG_OK;
+  const int64_t vecs = A->ld / (16 / (int64_t)pg_sizeof(A->dtype)) * A->n;
+  int64_t blocks = (vecs + 255) / 256;
+  const int64_t cap = (int64_t)A->ctx->num_cu * 32;
+  if (blocks > cap) blocks = cap;
+  if (A->dtype == PG_F32)
+    hipLaunchKernelGGL(rank1_update_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream, (float*)A->data, A->m,
+                       A->n, A->ld, (float)alpha, (const float*)u, (const float*)w);
+  else
+    hipLaunchKernelGGL(rank1_update_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, A->ctx->stream, (double*)A->data, A->m,
+                       A->n, A->ld, alpha, (const double*)u, (const double*)w);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

@@ -2,14 +2,14 @@
 
 A Douglas-Rachford step followed by a quasi-Newton / Nesterov direction and a backtracking line search on the
 Douglas-Rachford envelope.  f needs ``prox_`` (SeparableQuadratic, SqrNormL2, SquaredDistance, LeastSquares); the
-direction memory is the device L-BFGS operator (csrc/pg_lbfgs.hip); every vector statement is a HIP kernel of the
+direction memory is a device operator (L-BFGS, Broyden or Anderson); every vector statement is a HIP kernel of the
 library (prox, AXPBY, dot, norms).
 """
 import numpy as np
 
 from .algorithm import IterativeAlgorithm
 from .device import as_hipvector
-from .lbfgs import LBFGS, LBFGSOperator
+from .lbfgs import LBFGS
 from .operators import Zero, is_convex, is_generalized_quadratic, prox_
 from .panoc import NoAcceleration
 
@@ -84,7 +84,7 @@ class DRLSIteration:
         self._dr_tail(s)
         s.xbar_prev = s.xbar.copy()
         s.H = self.directions.initialize(s.x)
-        quasi_newton = isinstance(s.H, LBFGSOperator)
+        quasi_newton = hasattr(s.H, "mul_")  # QuasiNewtonStyle: LBFGS, Broyden, AndersonAcceleration
         nesterov = (not quasi_newton) and s.H is not None
         quadratic = is_generalized_quadratic(self.f)
         yield s

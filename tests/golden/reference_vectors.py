@@ -179,3 +179,17 @@ ELASTICNET_AFBA = [(2, 0, 130), (1, 1, 2000), (0, 1, 320), (0, 0, 194), (1, 0, 1
 # test_nonconvex_qp.jl:9-31 (tiny): Q = Diagonal(-0.5, 1), q = (0.3, 0.5), box [-1, 1], gamma = 0.95 / max(diag Q)
 NCQP_Q_VEC = np.array([0.3, 0.5])
 NCQP_TOL = 1e-4
+
+# ---- test/accel/test_anderson.jl:7-16 and test_broyden.jl:6-15 (same data): quadratic f(x) = <x, Hx>/2 + <x, l> ----
+ACCEL_H = np.array(
+    [
+        [0.63287, 0.330934, -0.156908, -0.294776, 0.10761],
+        [0.330934, 0.673201, 0.0459778, 0.231011, -0.235265],
+        [-0.156908, 0.0459778, 0.635812, -0.232261, -0.388775],
+        [-0.294776, 0.231011, -0.232261, 0.726854, -0.0691783],
+        [0.10761, -0.235265, -0.388775, -0.0691783, 0.336262],
+    ]
+)
+ACCEL_L = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+ACCEL_ITERS = 10  # :33  after 10 quasi-Newton steps f(x) <= f_star + (1 + |f_star|) sqrt(eps(R))
+LASSO_SMALL_BOUNDS_EXT.update({"drls_broyden": 19, "drls_anderson": 12})  # test_lasso_small.jl:218-219

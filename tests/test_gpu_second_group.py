@@ -379,3 +379,79 @@ def test_vu_condat_and_chambolle_pock_match_oracle(pa, dtype):
         pa.AFBAIteration(x0=x0, y0=y0, f=pa.SqrNormL2(1.0))  # beta_f must come with f (primal_dual.jl:96)
     with pytest.raises(ValueError):
         pa.AFBAIteration(x0=x0, y0=y0, theta=0.3, mu=0.7, h=pa.SquaredDistance(b), L=A)  # unsupported (theta, mu) (:414)
+
+
+# ------------------------------------------------------------------------------------------------
+# Anderson / Broyden operators (test/accel/test_anderson.jl, test_broyden.jl) and their use as directions
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["anderson", "broyden"])
+def test_anderson_and_broyden_on_device(pa, dtype, kind):
+    R = np.dtype(dtype).type
+    H, l = rv.ACCEL_H.astype(dtype), rv.ACCEL_L.astype(dtype)
+    f = lambda x: R(np.dot(x, H @ x) / R(2) + np.dot(x, l))
+    f_star = f(-np.linalg.solve(H, l))
+    fq = pa.Quadratic(np.asfortranarray(H), np.zeros(5, dtype))  # H x through the device GEMV
+    x = pa.HIPVector.zeros(5, dtype)
+    tag = pa.AndersonAcceleration(5) if kind == "anderson" else pa.Broyden()
+    acc = tag.initialize(x)
+    acc_o = ox.AndersonAccelerationOperator(5, np.zeros(5, dtype)) if kind == "anderson" else ox.BroydenOperator(np.zeros(5, dtype))
+    lv = pa.HIPVector.from_numpy(l)
+    grad = lambda v: fq.value_and_gradient(v)[1].axpby_(1.0, fq.value_and_gradient(v)[1], 1.0, lv)
+    g = grad(x)
+    xo, go = np.zeros(5, dtype), l.copy()
+    for it in range(rv.ACCEL_ITERS):
+        d = acc * g
+        do = acc_o * go
+        if it < 3:  # same directions as the restatement while the (pseudo-inverted) memory is well conditioned
+            assert np.max(np.abs(d.numpy() - do)) <= (2e-3 if dtype == np.float32 else 1e-9) * max(1.0, np.max(np.abs(do))), it
+        x.axpby_(1.0, x, -1.0, d)
+        g_prev, g = g, grad(x)
+        md = d.similar().axpby_(-1.0, d)
+        acc.update_(md, g.similar().axpby_(1.0, g, -1.0, g_prev))
+        xo = xo - do
+        go_prev, go = go, H @ xo + l
+        acc_o.update(-do, go - go_prev)
+    assert f(x.numpy()) <= f_star + (1 + abs(f_star)) * np.sqrt(np.finfo(dtype).eps)
+    acc.reset_()
+    assert np.array_equal((acc * x).numpy(), x.numpy())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rank1_update_kernel(pa, dtype):
+    import ctypes as C
+
+    from proximalalgorithms.jl_amd import _lib
+
+    rng = np.random.default_rng(2)
+    for m, n in ((1, 1), (5, 5), (257, 33), (1000, 70)):
+        A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype))
+        u, w = rng.standard_normal(m).astype(dtype), rng.standard_normal(n).astype(dtype)
+        Ad = pa.HIPMatrix.from_numpy(A)
+        ud, wd = pa.HIPVector.from_numpy(u), pa.HIPVector.from_numpy(w)
+        _lib.call("pg_mat_rank1_update", Ad.handle, 0.37, ud.vp, wd.vp)
+        ref = A + (dtype(0.37) * w)[None, :] * u[:, None]
+        assert np.max(np.abs(Ad.numpy() - ref)) <= 2 * np.finfo(dtype).eps * np.max(np.abs(ref))
+        # padding rows stay zero: a product with the adjoint still matches
+        r = rng.standard_normal(m).astype(dtype)
+        g = Ad.mul_adjoint(pa.HIPVector.from_numpy(r)).numpy()
+        assert np.max(np.abs(g - ref.T.astype(np.float64) @ r)) <= 1e-4 * max(1.0, np.max(np.abs(g)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["broyden", "anderson"])
+def test_drls_and_panoc_with_broyden_and_anderson(pa, dtype, kind):
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    tag = lambda: pa.Broyden() if kind == "broyden" else pa.AndersonAcceleration(5)
+    z, it = pa.DRLS(tol=10 * rv.LASSO_SMALL_TOL, directions=tag())(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), Lf=Lf)
+    assert np.max(np.abs(z - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= 10 * rv.LASSO_SMALL_TOL
+    assert it < rv.LASSO_SMALL_BOUNDS_EXT["drls_" + kind]
+    _, ito = ox.drls(tol=10 * rv.LASSO_SMALL_TOL, directions=kind, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=Lf)
+    assert it == ito if dtype == np.float64 else abs(it - ito) <= 3
+    # the same operators plug into PANOC / ZeroFPR (QuasiNewtonStyle, panoc.jl:114-126)
+    for solver in (pa.PANOC, pa.ZeroFPR):
+        x, it = solver(tol=rv.LASSO_SMALL_TOL, directions=tag())(x0=x0, f=pa.SquaredDistance(b), A=A, g=pa.NormL1(lam), Lf=Lf)
+        assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL and it < 40

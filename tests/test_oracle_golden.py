@@ -525,3 +525,36 @@ def test_lilin_nonconvex_qp_tiny():
     z = np.minimum(1.0, np.maximum(-1.0, x - gamma * (Q @ x + q)))
     assert np.max(np.abs(x - z)) / gamma <= rv.NCQP_TOL
     assert np.all(x0 == 0) and it_obj.monitor_branch_taken == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["anderson", "broyden"])
+def test_anderson_and_broyden_operators(dtype, kind):
+    """test/accel/test_anderson.jl:6-49, test/accel/test_broyden.jl:5-48"""
+    R = np.dtype(dtype).type
+    H, l = rv.ACCEL_H.astype(dtype), rv.ACCEL_L.astype(dtype)
+    f = lambda x: R(np.dot(x, H @ x) / R(2) + np.dot(x, l))
+    x_star = -np.linalg.solve(H, l)
+    f_star = f(x_star)
+    x = np.zeros(5, dtype)
+    acc = ox.AndersonAccelerationOperator(5, x) if kind == "anderson" else ox.BroydenOperator(x)
+    g = H @ x + l
+    for _ in range(rv.ACCEL_ITERS):
+        d = acc * g
+        x = x - d
+        g_prev, g = g, H @ x + l
+        acc.update(-d, g - g_prev)
+    assert f(x) <= f_star + (1 + abs(f_star)) * np.sqrt(np.finfo(dtype).eps)
+    acc.reset()
+    assert np.array_equal(acc * x, x)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["broyden", "anderson"])
+def test_drls_with_broyden_and_anderson(dtype, kind):
+    """test/problems/test_lasso_small.jl:216-231, rows (Broyden(), 19) and (AndersonAcceleration(5), 12)"""
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    z, it = ox.drls(tol=10 * rv.LASSO_SMALL_TOL, directions=kind, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=Lf)
+    assert np.max(np.abs(z - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= 10 * rv.LASSO_SMALL_TOL
+    assert it < rv.LASSO_SMALL_BOUNDS_EXT["drls_" + kind]
