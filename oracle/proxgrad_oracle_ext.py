@@ -98,6 +98,72 @@ def convex_conjugate(f):
     return Conjugate(f)
 
 
+class Linear:
+    """f(x) = <c, x> (ProximalOperators.Linear; the closure `x -> dot(c, x)` of test_linear_programs.jl:107):
+    gradient c, prox = x - gamma c."""
+
+    def __init__(self, c):
+        self.c = c
+
+    def value_and_gradient(self, x):
+        return _R(x)(_dot(self.c.astype(x.dtype), x)), self.c.astype(x.dtype).copy()
+
+    def prox(self, x, gamma):
+        y = (x - _R(x)(gamma) * self.c.astype(x.dtype)).astype(x.dtype)
+        return y, _R(x)(_dot(self.c.astype(x.dtype), y))
+
+    def __call__(self, x):
+        return self.value_and_gradient(x)[0]
+
+
+class IndNonnegative:
+    """indicator of {x >= 0} (ProximalOperators.IndNonnegative): prox = max.(0, x)"""
+
+    def prox(self, x, gamma):
+        return np.maximum(x, _R(x)(0)), _R(x)(0)
+
+    def __call__(self, x):
+        return _R(x)(0) if np.all(x >= 0) else _R(x)(np.inf)
+
+
+class IndPoint:
+    """indicator of {b} (ProximalOperators.IndPoint): prox = b"""
+
+    def __init__(self, b):
+        self.b = b
+
+    def prox(self, x, gamma):
+        return self.b.astype(x.dtype).copy(), _R(x)(0)
+
+
+class IndAffine:
+    """indicator of {x : A x = b} (ProximalOperators.IndAffine, A with full row rank):
+    prox = x - A' (A A')^{-1} (A x - b)"""
+
+    def __init__(self, A, b):
+        self.A, self.b = np.asarray(A), np.asarray(b)
+
+    def prox(self, x, gamma):
+        A = self.A.astype(x.dtype)
+        res = A @ x - self.b.astype(x.dtype)
+        return (x - A.T @ np.linalg.solve(A @ A.T, res)).astype(x.dtype), _R(x)(0)
+
+
+class SlicedSeparableSum:
+    """ProximalOperators.SlicedSeparableSum for contiguous index ranges: h(y) = sum_k h_k(y[lo_k:hi_k])"""
+
+    def __init__(self, fs, ranges):
+        self.fs, self.ranges = fs, ranges
+
+    def prox(self, x, gamma):
+        y = np.empty_like(x)
+        v = _R(x)(0)
+        for f, (lo, hi) in zip(self.fs, self.ranges):
+            y[lo:hi], vk = prox(f, x[lo:hi], gamma)
+            v = _R(x)(v + vk)
+        return y, v
+
+
 def _isapprox(a, b, R):
     """Julia isapprox for reals: |a - b| <= sqrt(eps(R)) * max(|a|, |b|)"""
     return abs(a - b) <= math.sqrt(np.finfo(R).eps) * max(abs(a), abs(b))

@@ -17,7 +17,8 @@ from .forward_backward import (ForwardBackward, ForwardBackwardIteration, Forwar
 from .lbfgs import LBFGS, LBFGSOperator
 from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, FixedNesterovSequence,
                        NesterovExtrapolation, SimpleNesterovSequence, next_)
-from .operators import (Composed, Conjugate, IndBox, IndZero, LeastSquares, LogisticLoss, NormL1, Quadratic,
+from .operators import (Composed, Conjugate, IndAffine, IndBox, IndNonnegative, IndPoint, IndZero, LeastSquares, Linear,
+                        LogisticLoss, NormL1, Quadratic, SlicedSeparableSum,
                         SeparableQuadratic, SqrNormL2, SquaredDistance, Zero, convex_conjugate, gradient_, is_convex,
                         is_generalized_quadratic, prox, prox_, value_and_gradient)
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
@@ -35,6 +36,7 @@ from .primal_dual import (AFBA, AFBAIteration, ChambollePock, ChambollePockItera
                           AFBA_default_stepsizes)
 
 __all__ = [
+    "IndAffine", "IndNonnegative", "IndPoint", "Linear", "SlicedSeparableSum",
     "AndersonAcceleration", "AndersonAccelerationOperator", "Broyden", "BroydenOperator",
     "SFISTA", "SFISTAIteration", "DavisYin", "DavisYinIteration", "LiLin", "LiLinIteration", "DRLS", "DRLSIteration",
     "AFBA", "AFBAIteration", "VuCondat", "VuCondatIteration", "ChambollePock", "ChambollePockIteration",

@@ -337,6 +337,97 @@ class Quadratic:
         return R(x.dot(self._Qx) / R(2) + self.q.dot(x))
 
 
+class Linear:
+    """f(x) = <c, x> (ProximalOperators.Linear(c); the closure `x -> dot(c, x)` of test_linear_programs.jl:107):
+    gradient c, prox = x - gamma c."""
+
+    is_convex = True
+    is_generalized_quadratic = True
+
+    def __init__(self, c, ctx=None):
+        self.c = as_hipvector(c, ctx)
+
+    def value_and_gradient(self, x, out=None):
+        g = out if out is not None else x.similar()
+        g.copy_from(self.c)
+        return self.c.dot(x), g
+
+    def prox_(self, y, x, gamma):
+        y.axpby_(1.0, x, -float(gamma), self.c)
+        return self.c.dot(y)
+
+    def __call__(self, x):
+        return self.c.dot(x)
+
+
+class IndNonnegative(IndBox):
+    """indicator of {x >= 0} (ProximalOperators.IndNonnegative): prox = max.(0, x) -- the box kernel with hi = +Inf"""
+
+    def __init__(self):
+        super().__init__(0.0, float("inf"))
+
+
+class IndPoint:
+    """indicator of {p} (ProximalOperators.IndPoint(p)): prox = p"""
+
+    is_convex = True
+
+    def __init__(self, p, ctx=None):
+        self.p = as_hipvector(p, ctx)
+
+    def prox_(self, y, x, gamma):
+        y.copy_from(self.p)
+        return x.dtype.type(0)
+
+
+class IndAffine:
+    """indicator of {x : A x = b}, A with full row rank (ProximalOperators.IndAffine(A, b)):
+    prox = x - A' (A A')^{-1} (A x - b).  The m x m system is inverted once on the host (float64), every application
+    is three GEMV passes and two AXPBYs on the device."""
+
+    is_convex = True
+
+    def __init__(self, A, b, ctx=None):
+        self.A = A if isinstance(A, HIPMatrix) else HIPMatrix.from_numpy(np.asfortranarray(A), ctx)
+        self.ctx = self.A.ctx
+        self.b = as_hipvector(b, self.ctx)
+        A64 = self.A.numpy().astype(np.float64)
+        S = np.linalg.inv(A64 @ A64.T)
+        self._S = HIPMatrix.from_numpy(np.asfortranarray(S.astype(self.A.dtype)), self.ctx)
+        self._t = HIPVector.empty(self.A.m, self.A.dtype, self.ctx)
+        self._t2 = HIPVector.empty(self.A.m, self.A.dtype, self.ctx)
+        self._w = HIPVector.empty(self.A.n, self.A.dtype, self.ctx)
+
+    def prox_(self, y, x, gamma):
+        self.A.mul(x, self._t)
+        self._t.axpby_(1.0, self._t, -1.0, self.b)
+        self._S.mul(self._t, self._t2)
+        self.A.mul_adjoint(self._t2, self._w)
+        y.axpby_(1.0, x, -1.0, self._w)
+        return x.dtype.type(0)
+
+
+class SlicedSeparableSum:
+    """ProximalOperators.SlicedSeparableSum for contiguous ranges: h(y) = sum_k h_k(y[lo_k:hi_k]); the prox acts on
+    device views of the slices (0-based half-open ranges; element offsets must keep 16-byte alignment)."""
+
+    def __init__(self, fs, ranges):
+        self.fs, self.ranges = tuple(fs), tuple((int(lo), int(hi)) for lo, hi in ranges)
+
+    @staticmethod
+    def _view(v, lo, hi):
+        if (lo * v.dtype.itemsize) % 16:
+            raise ValueError("slice offsets must be multiples of 16 bytes")
+        return HIPVector(v.ctx, v.ptr + lo * v.dtype.itemsize, hi - lo, v.dtype, owner=v)
+
+    def prox_(self, y, x, gamma):
+        R = x.dtype.type
+        total = R(0)
+        for f, (lo, hi) in zip(self.fs, self.ranges):
+            total = R(total + f.prox_(self._view(y, lo, hi), self._view(x, lo, hi), gamma))
+        return total
+
+
 class IndZero:
     """ProximalCore.IndZero: indicator of {0}.  Its conjugate is Zero (primal_dual.jl:187 evaluates
     value_and_gradient(convex_conjugate(l), y))."""

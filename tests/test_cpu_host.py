@@ -107,3 +107,40 @@ def test_world_size_2_gloo_sharded_path():
 def test_bench_cli_parses_without_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+def test_iteration_tools():
+    """test/utilities/test_iteration_tools.jl (host logic, no device)"""
+    import itertools
+    import time
+
+    from proximalalgorithms.jl_amd import iteration_tools as IterationTools
+
+    rng = np.random.default_rng(0)
+    seq = list(rng.random(10))
+    assert IterationTools.loop(seq) == seq[-1]  # :17-21
+    fib = [0, 1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987, 1597, 2584, 4181, 6765]
+    truncated = IterationTools.halt(fib, lambda x: x >= 1000)  # :23-52
+    assert len(truncated) == len(fib) and IterationTools.loop(truncated) == 1597
+
+    def fibonacci(s0, s1):
+        while True:
+            yield s0
+            s0, s1 = s1, s0 + s1
+
+    seen = []
+    teed = IterationTools.tee(fibonacci(0, 1), seen.append)  # :54-64
+    assert list(itertools.islice(teed, 10)) == fib[:10] == seen
+    data = list(rng.standard_normal(147))
+    sampled = IterationTools.sample(data, 10)  # :66-77
+    assert len(sampled) == 15
+    for k, x in enumerate(sampled):
+        assert x == data[min(147, (k + 1) * 10) - 1]
+    assert k == 14
+    timed = IterationTools.stopwatch(seq[:4])  # :79-93
+    assert len(timed) == 4
+    for k, (t, x) in enumerate(timed):
+        assert x == seq[k] and t >= k * 2e7 * 0.9
+        time.sleep(0.02)
+    with pytest.raises(TypeError):
+        IterationTools.loop([])

@@ -455,3 +455,47 @@ def test_drls_and_panoc_with_broyden_and_anderson(pa, dtype, kind):
     for solver in (pa.PANOC, pa.ZeroFPR):
         x, it = solver(tol=rv.LASSO_SMALL_TOL, directions=tag())(x0=x0, f=pa.SquaredDistance(b), A=A, g=pa.NormL1(lam), Lf=Lf)
         assert np.max(np.abs(x - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= rv.LASSO_SMALL_TOL and it < 40
+
+
+# ------------------------------------------------------------------------------------------------
+# linear programs (test/problems/test_linear_programs.jl): Linear, IndNonnegative, IndPoint, IndAffine, SlicedSeparableSum
+# ------------------------------------------------------------------------------------------------
+
+
+def lp_problem(dtype):
+    A = np.asfortranarray(rv.LP_A.astype(dtype))
+    b = A @ rv.LP_XSTAR.astype(dtype)
+    c = A.T @ rv.LP_YSTAR.astype(dtype) + rv.LP_SSTAR.astype(dtype)
+    return A, b, c, 100 * np.finfo(dtype).eps
+
+
+def assert_lp_solution(c, A, b, x, y, tol):
+    assert -min(0.0, float(x.min())) <= tol
+    assert np.linalg.norm(A @ x - b) <= tol
+    assert max(0.0, float((-A.T @ y - c).max())) <= tol
+    assert abs(float(np.dot(c + A.T @ y, x))) <= tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_programs_on_device(pa, dtype):
+    A, b, c, tol = lp_problem(dtype)
+    n, m = 10, 8
+    x0 = np.zeros(n, dtype)
+    for solver, osolver in ((pa.AFBA, ox.afba), (pa.VuCondat, ox.vu_condat)):
+        (x, y), it = solver(tol=tol, maxit=rv.LP_MAXIT)(x0=x0, y0=np.zeros(m, dtype), f=pa.Linear(c), g=pa.IndNonnegative(),
+                                                        h=pa.IndPoint(b), L=A, beta_f=0)
+        assert x.dtype == dtype and y.dtype == dtype and it <= rv.LP_MAXIT and np.all(x0 == 0)
+        assert_lp_solution(c, A, b, x, y, 1000 * tol)
+        _, ito = osolver(tol=tol, maxit=rv.LP_MAXIT, x0=x0, y0=np.zeros(m, dtype), f=ox.Linear(c), g=ox.IndNonnegative(),
+                         h=ox.IndPoint(b), L=A, beta_f=0)
+        assert abs(it - ito) <= max(3, ito // 5)  # the rule fires at 100 eps: rounding-floor territory in both precisions
+    xf, it = pa.DavisYin(gamma=dtype(1), tol=tol, maxit=rv.LP_MAXIT)(x0=x0, f=pa.Linear(c), g=pa.IndNonnegative(),
+                                                                    h=pa.IndAffine(A, b))
+    assert xf.dtype == dtype and it <= rv.LP_MAXIT
+    assert np.linalg.norm(xf - rv.LP_XSTAR.astype(dtype)) <= 100 * tol
+    if dtype == np.float32:  # ChambollePock needs ~20k iterations in Float32, ~80k in Float64 (oracle-pinned on the CPU)
+        h = pa.SlicedSeparableSum((pa.IndPoint(b), pa.IndNonnegative()), ((0, m), (m, m + n)))
+        (x, y), it = pa.ChambollePock(tol=tol, maxit=rv.LP_MAXIT)(x0=x0, y0=np.zeros(m + n, dtype), g=pa.Linear(c), h=h,
+                                                                  L=np.vstack([A, np.eye(n, dtype=dtype)]))
+        assert it <= rv.LP_MAXIT
+        assert_lp_solution(c, A, b, x, y[:m], 1000 * tol)

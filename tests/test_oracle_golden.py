@@ -558,3 +558,37 @@ def test_drls_with_broyden_and_anderson(dtype, kind):
     z, it = ox.drls(tol=10 * rv.LASSO_SMALL_TOL, directions=kind, x0=x0, f=o.LeastSquares(A, b), g=o.NormL1(lam), Lf=Lf)
     assert np.max(np.abs(z - rv.LASSO_SMALL_XSTAR.astype(dtype))) <= 10 * rv.LASSO_SMALL_TOL
     assert it < rv.LASSO_SMALL_BOUNDS_EXT["drls_" + kind]
+
+
+def lp_problem(dtype):
+    A = np.asfortranarray(rv.LP_A.astype(dtype))
+    b = A @ rv.LP_XSTAR.astype(dtype)
+    c = A.T @ rv.LP_YSTAR.astype(dtype) + rv.LP_SSTAR.astype(dtype)
+    return A, b, c, 100 * np.finfo(dtype).eps
+
+
+def assert_lp_solution(c, A, b, x, y, tol):
+    """test_linear_programs.jl:7-22 (the returned dual iterate is the negative of the LP's dual variable)"""
+    assert -min(0.0, float(x.min())) <= tol
+    assert np.linalg.norm(A @ x - b) <= tol
+    assert max(0.0, float((-A.T @ y - c).max())) <= tol
+    assert abs(float(np.dot(c + A.T @ y, x))) <= tol
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_linear_programs(dtype):
+    """test/problems/test_linear_programs.jl:105-193: AFBA, VuCondat, ChambollePock, DavisYin on the LP fixture"""
+    A, b, c, tol = lp_problem(dtype)
+    n, m = 10, 8
+    kw = dict(tol=tol, maxit=rv.LP_MAXIT, x0=np.zeros(n, dtype))
+    for solver in (ox.afba, ox.vu_condat):
+        (x, y), it = solver(y0=np.zeros(m, dtype), f=ox.Linear(c), g=ox.IndNonnegative(), h=ox.IndPoint(b), L=A, beta_f=0, **kw)
+        assert x.dtype == dtype and y.dtype == dtype and it <= rv.LP_MAXIT
+        assert_lp_solution(c, A, b, x, y, 1000 * tol)
+    h = ox.SlicedSeparableSum((ox.IndPoint(b), ox.IndNonnegative()), ((0, m), (m, m + n)))
+    (x, y), it = ox.chambolle_pock(y0=np.zeros(m + n, dtype), g=ox.Linear(c), h=h, L=np.vstack([A, np.eye(n, dtype=dtype)]), **kw)
+    assert it <= rv.LP_MAXIT
+    assert_lp_solution(c, A, b, x, y[:m], 1000 * tol)
+    xf, it = ox.davis_yin(gamma=dtype(1), f=ox.Linear(c), g=ox.IndNonnegative(), h=ox.IndAffine(A, b), **kw)
+    assert xf.dtype == dtype and it <= rv.LP_MAXIT
+    assert np.linalg.norm(xf - rv.LP_XSTAR.astype(dtype)) <= 100 * tol
