@@ -499,3 +499,24 @@ def test_linear_programs_on_device(pa, dtype):
                                                                   L=np.vstack([A, np.eye(n, dtype=dtype)]))
         assert it <= rv.LP_MAXIT
         assert_lp_solution(c, A, b, x, y[:m], 1000 * tol)
+
+
+def test_verbose_display_second_group(pa, capsys):
+    """test/problems/test_verbose.jl: the display path of every solver runs and does not change the answer"""
+    dtype = np.float64
+    A, b, lam, Lf = lasso_small(dtype)
+    x0 = np.zeros(5, dtype)
+    xs = rv.LASSO_SMALL_XSTAR
+    f, g = pa.LeastSquares(A, b), pa.NormL1(lam)
+    y, _ = pa.SFISTA(tol=1e-4, verbose=True, freq=5)(x0=x0, f=f, g=g, Lf=Lf)
+    assert np.max(np.abs(y - xs)) <= 1e-3
+    z, _ = pa.DRLS(tol=1e-4, verbose=True, freq=1)(x0=x0, f=f, g=g, Lf=Lf)
+    assert np.max(np.abs(z - xs)) <= 1e-3
+    z, _ = pa.LiLin(tol=1e-4, verbose=True, freq=20)(x0=x0, f=f, g=g, Lf=Lf)
+    assert np.max(np.abs(z - xs)) <= 1e-3
+    x, _ = pa.DavisYin(tol=1e-6, verbose=True, freq=20)(x0=x0, f=f, g=pa.NormL1(1.0), h=pa.SqrNormL2(1.0), Lf=Lf)
+    assert np.max(np.abs(x - rv.ELASTICNET_XSTAR)) <= 1e-3
+    (x, _), _ = pa.AFBA(tol=1e-6, verbose=True, freq=20)(x0=x0, y0=np.zeros(5), f=f, g=g, beta_f=Lf)
+    assert np.max(np.abs(x - xs)) <= 1e-4
+    out = capsys.readouterr().out
+    assert out.count("\n") >= 10 and "|" in out
