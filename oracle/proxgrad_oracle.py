@@ -97,14 +97,26 @@ class LeastSquares:
         return self.value_and_gradient(x)[0]
 
     def prox(self, x, gamma):
-        """ProximalOperators.LeastSquares prox (direct solve): argmin_z lam/2 ||Az - b||^2 + ||z - x||^2 / (2 gamma)
-        = (A'A + I / (lam gamma)) \\ (A'b + x / (lam gamma)).  Used only to pin the DouglasRachford restatement
-        against test/problems/test_lasso_small.jl:205-214 (prox of LeastSquares is not on the GPU path)."""
+        """ProximalOperators.LeastSquares prox (direct solver): argmin_z lam/2 ||Az - b||^2 + ||z - x||^2 / (2 gamma)
+        = (A'A + I / (lam gamma)) \\ (A'b + x / (lam gamma)).  Like the reference's operator, the Cholesky factor is
+        cached per gamma, and a wide A (m < n) goes through the m x m system (matrix inversion lemma).  Pins the
+        DouglasRachford / DRLS restatements against test/problems/test_lasso_small.jl:205-231."""
+        import scipy.linalg as sla
+
         R = _R(x)
         c = R(1) / (R(self.lam) * R(gamma))
-        n = self.A.shape[1]
-        M = (self.A.T @ self.A + c * np.eye(n, dtype=x.dtype)).astype(x.dtype)
-        y = np.linalg.solve(M, self.A.T @ self.b + c * x).astype(x.dtype)
+        m, n = self.A.shape
+        cache = getattr(self, "_chol", None)
+        if cache is None or cache[0] != c:
+            S = (self.A.T @ self.A if m >= n else self.A @ self.A.T) + c * np.eye(min(m, n), dtype=x.dtype)
+            cache = (c, sla.cho_factor(S.astype(x.dtype)), (self.A.T @ self.b).astype(x.dtype))
+            self._chol = cache
+        q = cache[2] + c * x
+        if m >= n:
+            y = sla.cho_solve(cache[1], q)
+        else:  # (A'A + c I)^-1 q = (q - A' (A A' + c I)^-1 A q) / c
+            y = (q - self.A.T @ sla.cho_solve(cache[1], self.A @ q)) / c
+        y = y.astype(x.dtype)
         return y, self(y)
 
 
