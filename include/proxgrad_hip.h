@@ -117,6 +117,18 @@ pg_status pg_ctx_comm_destroy(pg_ctx* ctx);
  * every rank (fixed step, or FastForwardBackward's adaptive step with reuse_residual).  nranks = 0: row sharding. */
 pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
 pg_status pg_ctx_sync(pg_ctx* ctx);
+/* Stream capture for launch-bound iteration bodies ("capture launch-bound inner loops in hipGraphs"): between _begin and
+ * _end every entry point of this library called on the context RECORDS its kernels into a graph instead of running
+ * them; scalar outputs (double* ..._out) are not meaningful for calls made during the capture.  The recorded body --
+ * e.g. one Base.iterate of AFBA / DavisYin / DouglasRachford (primal_dual.jl:176-209, davis_yin.jl:73-83,
+ * douglas_rachford.jl:57-63), whose step sizes are constants -- is then replayed with ONE launch per iteration.
+ * Requirements: the context owns a non-default stream, no collective attached, every workspace the body needs was
+ * allocated by a previous (uncaptured) run of the same body.  _end with out == NULL aborts and discards the capture. */
+typedef struct pg_graph pg_graph;
+pg_status pg_ctx_capture_begin(pg_ctx* ctx);
+pg_status pg_ctx_capture_end(pg_ctx* ctx, pg_graph** graph_out);
+pg_status pg_graph_launch(pg_graph* graph);
+pg_status pg_graph_destroy(pg_graph* graph);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every
  * launch of the kernels below is bracketed by an event pair; pg_ctx_profile_read synchronises the stream and

@@ -7,7 +7,7 @@ include/proxgrad_hip.h).  There is no CPU fallback: without the library or a gfx
 """
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
-from .device import Context, HIPMatrix, HIPVector, as_hipvector, get_context
+from .device import Context, Graph, HIPMatrix, HIPVector, as_hipvector, get_context, set_default_context
 from .douglas_rachford import DouglasRachford, DouglasRachfordIteration, DouglasRachfordState
 from .fast_forward_backward import (FastForwardBackward, FastForwardBackwardIteration, FastForwardBackwardState,
                                     FastProximalGradient, FastProximalGradientIteration)
@@ -20,7 +20,7 @@ from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, Fixed
 from .operators import (Composed, Conjugate, IndAffine, IndBox, IndNonnegative, IndPoint, IndZero, LeastSquares, Linear,
                         LogisticLoss, NormL1, Quadratic, SlicedSeparableSum,
                         SeparableQuadratic, SqrNormL2, SquaredDistance, Zero, convex_conjugate, gradient_, is_convex,
-                        is_generalized_quadratic, prox, prox_, value_and_gradient)
+                        is_generalized_quadratic, prox, prox_, value_and_gradient, value_and_gradient_)
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
 from .panocplus import PANOCplus, PANOCplusIteration
 from .sharding import NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce_sum_, shard_cols, shard_rows

@@ -60,6 +60,10 @@ SIGNATURES = {
     "pg_ctx_comm_init": [_vp, _vp, _i32, _i32, _i32],
     "pg_ctx_comm_destroy": [_vp],
     "pg_ctx_sync": [_vp],
+    "pg_ctx_capture_begin": [_vp],
+    "pg_ctx_capture_end": [_vp, C.POINTER(_vp)],
+    "pg_graph_launch": [_vp],
+    "pg_graph_destroy": [_vp],
     "pg_ctx_device_info": [_vp, C.POINTER(pg_device_info)],
     "pg_ctx_profile_enable": [_vp, _i32],
     "pg_ctx_profile_select": [_vp, C.c_uint32],

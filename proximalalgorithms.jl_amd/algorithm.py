@@ -9,17 +9,52 @@ def _like_x0(sol, host_x0):
     return sol.numpy() if (host_x0 and isinstance(sol, HIPVector)) else sol
 
 
+def graph_iterate(it):
+    """Iterate a graph-safe iteration (``init_state`` / ``body``; constant coefficients, no buffer swaps): two plain
+    iterations (they allocate every workspace), then the body is RECORDED into a hipGraph and each further iteration
+    is one graph launch.  Scalar fields of the state that the body reads back (prox values) are not refreshed in graph
+    mode.  Falls back to plain stepping when the context cannot capture (default stream, collective attached) or the
+    body turns out to allocate."""
+    from ._lib import ProxGradError
+
+    s = it.init_state()
+    ctx = it.x0.ctx
+    for _ in range(2):
+        it.body(s)
+        yield s
+    graph = None
+    try:
+        ctx.capture_begin()
+        try:
+            it.body(s)
+        except BaseException:
+            ctx.capture_end(abort=True)
+            raise
+        graph = ctx.capture_end()
+    except ProxGradError:
+        graph = None
+    it.graph = graph  # introspection: None = fell back
+    while True:
+        if graph is not None:
+            graph.launch()
+        else:
+            it.body(s)
+        yield s
+
+
 class IterativeAlgorithm:
     """Wrapper for an iterator type adding termination and verbosity options
     (src/ProximalAlgorithms.jl:58-112).  Calling it merges the keyword arguments, builds the iterator
     and loops: ``for (k, state) in enumerate(iter)`` -> returns ``(solution, k)`` when
     ``k >= maxit or stop(iter, state)`` (:114-123)."""
 
-    def __init__(self, iterator_type, *, maxit, stop, solution, verbose, freq, display, device_loop=None, **kwargs):
+    def __init__(self, iterator_type, *, maxit, stop, solution, verbose, freq, display, device_loop=None, graph=False,
+                 **kwargs):
         # device_loop = (tol, check_every): run the loop with the DEFAULT stopping rule inside the library instead of
         # stepping from the host (fused engines only): one launch for launch-bound sizes (pg_iter_run_small /
         # pg_iter_run_coop), else the in-library loop (pg_iter_run / pg_iter_run_batched)
         self.device_loop = device_loop
+        self.graph = bool(graph)  # record the iteration body into a hipGraph (graph-safe iterations only)
         self.iterator_type = iterator_type
         self.maxit = int(maxit)
         self.stop = stop
@@ -63,7 +98,8 @@ class IterativeAlgorithm:
                 k, _ = fused.run(1, self.maxit, tol)
             state._invalidate()
             return _like_x0(self.solution(it, state), host_x0), k
-        for k, state in enumerate(it, start=1):
+        steps = graph_iterate(it) if (self.graph and getattr(it, "graph_safe", False)) else it
+        for k, state in enumerate(steps, start=1):
             if k >= self.maxit or self.stop(it, state):
                 if self.verbose:
                     self.display(k, it, state)

@@ -103,6 +103,63 @@ pg_status pg_ctx_sync(pg_ctx* c) {
   return PG_OK;
 }
 
+// ---- stream capture: a launch-bound iteration body recorded once, replayed as ONE graph launch --------------------
+pg_status pg_ctx_capture_begin(pg_ctx* c) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  PG_REQUIRE(!c->capturing, "a capture is already in progress");
+  PG_REQUIRE(c->stream != nullptr, "the default (null) stream cannot be captured: create the context on its own stream");
+  PG_REQUIRE(c->allreduce == nullptr && c->allreduce_begin == nullptr && c->comm == nullptr,
+             "capture is not available on a context with a collective attached");
+  PG_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  c->capturing = true;
+  return PG_OK;
+}
+
+pg_status pg_ctx_capture_end(pg_ctx* c, pg_graph** out) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  PG_REQUIRE(c->capturing, "no capture in progress");
+  c->capturing = false;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (e != hipSuccess || graph == nullptr) {
+    (void)hipGetLastError();
+    pg_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    return PG_ERR_HIP;
+  }
+  if (out == nullptr) {  // abort: drop what was recorded
+    (void)hipGraphDestroy(graph);
+    return PG_OK;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    pg_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return PG_ERR_HIP;
+  }
+  pg_graph* g = new pg_graph();
+  g->ctx = c;
+  g->graph = graph;
+  g->exec = exec;
+  *out = g;
+  return PG_OK;
+}
+
+pg_status pg_graph_launch(pg_graph* g) {
+  PG_REQUIRE(g != nullptr && g->exec != nullptr, "graph is null");
+  PG_REQUIRE(!g->ctx->capturing, "cannot launch a graph while capturing");
+  PG_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+  return PG_OK;
+}
+
+pg_status pg_graph_destroy(pg_graph* g) {
+  if (!g) return PG_OK;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return PG_OK;
+}
+
 pg_status pg_ctx_profile_enable(pg_ctx* c, int32_t enable) {
   PG_REQUIRE(c != nullptr, "ctx is null");
   c->profiling = enable != 0;
@@ -233,7 +290,7 @@ static hipEvent_t prof_get_event(pg_ctx* c) {
 }
 
 pg_prof_scope::pg_prof_scope(pg_ctx* ctx, int k) : c(ctx), kind(k) {
-  if (!c->profiling || !((c->prof_mask >> k) & 1u)) return;
+  if (!c->profiling || c->capturing || !((c->prof_mask >> k) & 1u)) return;
   start = prof_get_event(c);
   stop = prof_get_event(c);
   if (start && stop) (void)hipEventRecord(start, c->stream);
@@ -250,6 +307,7 @@ pg_status pg_read_scalars(pg_ctx* c, int first, int count) {
   // is one stream synchronisation (no copy kernel, no extra launch)
   (void)first;
   (void)count;
+  if (c->capturing) return PG_OK;  // recorded, not run: the caller's scalars are placeholders
   PG_HIP(hipStreamSynchronize(c->stream));
   return PG_OK;
 }

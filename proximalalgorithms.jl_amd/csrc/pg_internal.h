@@ -101,6 +101,9 @@ struct pg_ctx {
   double* small_out_host = nullptr;  //   ... mapped pinned host memory
   void* coop_ws = nullptr;           // workspace of the cooperative solver (barrier counter, partials)
   size_t coop_ws_bytes = 0;
+  // stream capture (pg_ctx_capture_begin / _end): launches are recorded into a hipGraph instead of executed; scalar
+  // read-backs are skipped (their host values are not meaningful until the graph has run)
+  bool capturing = false;
   // event-pair kernel timing (pg_ctx_profile_*)
   bool profiling = false;
   uint32_t prof_mask = 0xFFFFFFFFu;  // kernel kinds that get an event pair while profiling (pg_ctx_profile_select)
@@ -115,6 +118,12 @@ struct pg_prof_scope {
   hipEvent_t start = nullptr, stop = nullptr;
   pg_prof_scope(pg_ctx* ctx, int k);
   ~pg_prof_scope();
+};
+
+struct pg_graph {
+  pg_ctx* ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
 };
 
 struct pg_mat {

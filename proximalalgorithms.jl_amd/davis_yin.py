@@ -4,7 +4,7 @@ minimize f(x) + g(x) + h(x), f smooth: per iteration prox_g, one gradient of f, 
 """
 from .algorithm import IterativeAlgorithm
 from .device import as_hipvector
-from .operators import Zero, prox_, value_and_gradient
+from .operators import Zero, prox_, value_and_gradient_
 
 
 class DavisYinState:
@@ -32,18 +32,26 @@ class DavisYinIteration:
             gamma = R(1) / R(Lf)
         self.gamma, self.lam = R(gamma), R(lam)
 
-    def __iter__(self):
-        s = DavisYinState(self.x0.copy())
+    graph_safe = True  # constant gamma / lambda, no buffer swaps
+
+    def init_state(self):
+        return DavisYinState(self.x0.copy())
+
+    def body(self, s):
+        """one Base.iterate (davis_yin.jl:73-83), allocation-free"""
         gamma = self.gamma
+        prox_(s.xg, self.g, s.z, gamma)  # :74
+        value_and_gradient_(s.grad_f_xg, self.f, s.xg)  # :75-76
+        s.z_half.axpby_(2.0, s.xg, -1.0, s.z)  # :77  2 xg - z - gamma grad
+        s.z_half.axpby_(1.0, s.z_half, -float(gamma), s.grad_f_xg)
+        prox_(s.xh, self.h, s.z_half, gamma)  # :78
+        s.res.axpby_(1.0, s.xh, -1.0, s.xg)  # :79
+        s.z.axpby_(1.0, s.z, float(self.lam), s.res)  # :80
+
+    def __iter__(self):
+        s = self.init_state()
         while True:
-            prox_(s.xg, self.g, s.z, gamma)  # :74
-            _, g = value_and_gradient(self.f, s.xg)  # :75
-            s.grad_f_xg.copy_from(g)
-            s.z_half.axpby_(2.0, s.xg, -1.0, s.z)  # :77  2 xg - z - gamma grad
-            s.z_half.axpby_(1.0, s.z_half, -float(gamma), s.grad_f_xg)
-            prox_(s.xh, self.h, s.z_half, gamma)  # :78
-            s.res.axpby_(1.0, s.xh, -1.0, s.xg)  # :79
-            s.z.axpby_(1.0, s.z, float(self.lam), s.res)  # :80
+            self.body(s)
             yield s
 
 
@@ -62,9 +70,10 @@ def default_display(it, iteration, state):
 
 
 def DavisYin(*, maxit=10_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
-             display=default_display, **kwargs):
-    """davis_yin.jl:114-132"""
+             display=default_display, graph=False, **kwargs):
+    """davis_yin.jl:114-132.  graph=True: the iteration body is recorded into a hipGraph after two plain iterations and
+    replayed with one launch per iteration."""
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
     return IterativeAlgorithm(DavisYinIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose, freq=freq,
-                              display=display, **kwargs)
+                              display=display, graph=graph, **kwargs)

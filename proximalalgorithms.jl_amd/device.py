@@ -41,7 +41,22 @@ class Context:
         call("pg_ctx_create", self.device, C.c_void_p(self.stream), C.byref(h))
         self._h = h
         self._allreduce_cb = None
+        self._stream_owner = None
+        self.capturing = False
         self._finalizer = weakref.finalize(self, _lib.load().pg_ctx_destroy, h)
+
+    @classmethod
+    def on_new_stream(cls, device=None):
+        """A context on its own (non-default) HIP stream -- what stream capture needs (the null stream cannot be
+        captured).  The torch stream object is kept alive by the context."""
+        import torch
+
+        if device is None:
+            device = torch.cuda.current_device()
+        st = torch.cuda.Stream(device=torch.device("cuda", int(device)))
+        ctx = cls(device, st.cuda_stream)
+        ctx._stream_owner = st
+        return ctx
 
     @property
     def handle(self):
@@ -49,6 +64,23 @@ class Context:
 
     def sync(self):
         call("pg_ctx_sync", self._h)
+
+    # ---- stream capture: record a launch-bound iteration body once, replay it with one launch ----
+    def capture_begin(self):
+        """Start recording: library calls on this context are captured into a hipGraph instead of executed; device
+        allocations through HIPVector.empty are refused until capture_end (their addresses would be baked in)."""
+        call("pg_ctx_capture_begin", self._h)
+        self.capturing = True
+
+    def capture_end(self, abort=False):
+        """Stop recording; returns the instantiated :class:`Graph` (None when aborting)."""
+        self.capturing = False
+        if abort:
+            call("pg_ctx_capture_end", self._h, None)
+            return None
+        g = C.c_void_p()
+        call("pg_ctx_capture_end", self._h, C.byref(g))
+        return Graph(self, g)
 
     def device_info(self):
         info = _lib.pg_device_info()
@@ -138,7 +170,27 @@ class Context:
         call("pg_ctx_set_allreduce_async", self._h, self._allreduce_async_cbs[0], self._allreduce_async_cbs[1], None)
 
 
+class Graph:
+    """An instantiated hipGraph of recorded library calls (pg_graph); ``launch()`` replays it on the context's stream."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._h = handle
+        self._finalizer = weakref.finalize(self, _lib.load().pg_graph_destroy, handle)
+
+    def launch(self):
+        call("pg_graph_launch", self._h)
+
+
 _default_ctx = {}
+
+
+def set_default_context(ctx):
+    """Make ``ctx`` the process-wide default of its device (vectors / operators created without an explicit context
+    use it).  Returns the previous default (or None)."""
+    prev = _default_ctx.get(ctx.device)
+    _default_ctx[ctx.device] = ctx
+    return prev
 
 
 def get_context(device=None):
@@ -185,6 +237,9 @@ class HIPVector:
         import torch
 
         ctx = ctx or get_context()
+        if ctx.capturing:
+            raise _lib.ProxGradError("device allocation during stream capture: the recorded body must reuse buffers "
+                                     "allocated by an earlier, uncaptured run")
         tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
         pg_dtype(dtype)
         t = torch.empty(max(int(n), 1), dtype=tdt, device=ctx.torch_device)
@@ -294,7 +349,7 @@ class HIPVector:
     def norm(self):
         out = C.c_double()
         call("pg_nrm2sq", self.ctx.handle, self.pg_dtype, self.n, self.vp, C.byref(out))
-        return self.dtype.type(np.sqrt(self.dtype.type(out.value)))
+        return self.dtype.type(np.sqrt(self.dtype.type(max(out.value, 0.0))))
 
     def norm_inf(self):
         out = C.c_double()

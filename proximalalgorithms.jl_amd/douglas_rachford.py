@@ -81,13 +81,24 @@ class DouglasRachfordIteration:
                 yield s
         else:
             while True:
-                s.f_y = prox_(s.y, self.f, s.x, self.gamma)  # :58
-                s.r.axpby_(2.0, s.y, -1.0, s.x)  # :59
-                s.g_z = prox_(s.z, self.g, s.r, self.gamma)  # :60
-                s.res.axpby_(1.0, s.y, -1.0, s.z)  # :61
-                s.x.axpby_(1.0, s.x, -1.0, s.res)  # :62
-                s.res_inf = None
+                self.body(s)
                 yield s
+
+    @property
+    def graph_safe(self):
+        return self.engine == "generic"  # the fused engine already is one kernel per iteration / has its own loop
+
+    def init_state(self):
+        return DouglasRachfordState(self.x0.copy())
+
+    def body(self, s):
+        """generic engine: the five statements of douglas_rachford.jl:58-62 as library calls (allocation-free)"""
+        s.f_y = prox_(s.y, self.f, s.x, self.gamma)  # :58
+        s.r.axpby_(2.0, s.y, -1.0, s.x)  # :59
+        s.g_z = prox_(s.z, self.g, s.r, self.gamma)  # :60
+        s.res.axpby_(1.0, s.y, -1.0, s.z)  # :61
+        s.x.axpby_(1.0, s.x, -1.0, s.res)  # :62
+        s.res_inf = None
 
 
 def default_stopping_criterion(tol, iteration, state):
@@ -109,11 +120,11 @@ def default_display(it, iteration, state):
 
 
 def DouglasRachford(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
-                    display=default_display, device_loop=False, check_every=16, **kwargs):
+                    display=default_display, device_loop=False, check_every=16, graph=False, **kwargs):
     """douglas_rachford.jl:101-119.  device_loop=True (default stop rule, fused engine): the driver loop runs inside
     the library, ``check_every`` (1, 8 or 16) iterations per HBM sweep; same iterates, same iteration count."""
     dl = (tol, int(check_every)) if (device_loop and stop is None) else None
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
     return IterativeAlgorithm(DouglasRachfordIteration, maxit=maxit, stop=stop, solution=solution, verbose=verbose,
-                              freq=freq, display=display, device_loop=dl, **kwargs)
+                              freq=freq, display=display, device_loop=dl, graph=graph, **kwargs)

@@ -257,7 +257,9 @@ class _Loss:
         return u.dtype.type(f.value), grad
 
     def __call__(self, u):
-        return self.value_and_gradient(u)[0]
+        if getattr(self, "_scratch", None) is None or self._scratch.n != u.n:
+            self._scratch = u.similar()
+        return self.value_and_gradient(u, out=self._scratch)[0]
 
 
 class SquaredDistance(_Loss):
@@ -523,6 +525,17 @@ class Zero:
 def value_and_gradient(f, x):
     """ProximalAlgorithms.value_and_gradient(f, x) -> (f(x), grad f(x))"""
     return f.value_and_gradient(x)
+
+
+def value_and_gradient_(out, f, x):
+    """value_and_gradient with the gradient written into ``out`` (the `state.grad .= grad` pattern of the reference's
+    iterators without the intermediate array): returns f(x)."""
+    try:
+        return f.value_and_gradient(x, out=out)[0]
+    except TypeError:  # custom operator without the `out` keyword
+        v, g = f.value_and_gradient(x)
+        out.copy_from(g)
+        return v
 
 
 def gradient_(y, f, x):

@@ -12,7 +12,7 @@ import numpy as np
 
 from .algorithm import IterativeAlgorithm
 from .device import HIPMatrix, as_hipvector
-from .operators import IndZero, Zero, convex_conjugate, prox_, value_and_gradient
+from .operators import IndZero, Zero, convex_conjugate, prox_, value_and_gradient_
 
 
 def _isapprox(a, b, R):
@@ -143,36 +143,44 @@ class AFBAIteration:
             return out.fill_(0.0)
         return out.copy_from(y) if self.L is None else self.L.mul_adjoint(y, out)
 
-    def __iter__(self):
+    graph_safe = True  # constant step sizes, no buffer swaps: the body can be recorded once and replayed (hipGraph)
+
+    def init_state(self):
+        s = AFBAState(self.x0.copy(), self.y0.copy())
+        s.hc, s.lc = convex_conjugate(self.h), convex_conjugate(self.l)
+        return s
+
+    def body(self, s):
+        """one Base.iterate (primal_dual.jl:176-209), allocation-free"""
         R = self.x0.dtype.type
         g1, g2 = self.gamma
-        s = AFBAState(self.x0.copy(), self.y0.copy())
-        hc, lc = convex_conjugate(self.h), convex_conjugate(self.l)
         theta, mu, lam = self.theta, self.mu, self.lam
+        value_and_gradient_(s.gradf, self.f, s.x)  # :180
+        self._mul_adjoint(s.temp_x, s.y)  # :182-185   x - gamma1 (L'y + grad f)
+        s.temp_x.axpby_(1.0, s.temp_x, 1.0, s.gradf)
+        s.temp_x.axpby_(-float(g1), s.temp_x, 1.0, s.x)
+        prox_(s.xbar, self.g, s.temp_x, g1)  # :186
+        value_and_gradient_(s.gradl, s.lc, s.y)  # :187
+        s.temp_x.axpby_(float(theta), s.xbar, float(R(1) - theta), s.x)  # :189
+        self._mul(s.temp_y, s.temp_x)  # :190-193   y + gamma2 (L t - grad l*)
+        s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)
+        s.temp_y.axpby_(float(g2), s.temp_y, 1.0, s.y)
+        prox_(s.ybar, s.hc, s.temp_y, g2)  # :194
+        s.FPR_x.axpby_(1.0, s.xbar, -1.0, s.x)  # :196-197
+        s.FPR_y.axpby_(1.0, s.ybar, -1.0, s.y)
+        s.temp_y.axpby_(float(R(mu * (R(2) - theta) * g1)), s.FPR_y)  # :199-201
+        self._mul_adjoint(s.temp_x, s.temp_y)
+        s.temp_x.axpby_(1.0, s.FPR_x, -1.0, s.temp_x)
+        s.x.axpby_(1.0, s.x, float(lam), s.temp_x)
+        s.temp_x.axpby_(float(R((R(1) - mu) * (R(2) - theta) * g2)), s.FPR_x)  # :203-205
+        self._mul(s.temp_y, s.temp_x)
+        s.temp_y.axpby_(1.0, s.FPR_y, 1.0, s.temp_y)
+        s.y.axpby_(1.0, s.y, float(lam), s.temp_y)
+
+    def __iter__(self):
+        s = self.init_state()
         while True:
-            _, gf = value_and_gradient(self.f, s.x)  # :180
-            s.gradf.copy_from(gf)
-            self._mul_adjoint(s.temp_x, s.y)  # :182-185   x - gamma1 (L'y + grad f)
-            s.temp_x.axpby_(1.0, s.temp_x, 1.0, s.gradf)
-            s.temp_x.axpby_(-float(g1), s.temp_x, 1.0, s.x)
-            prox_(s.xbar, self.g, s.temp_x, g1)  # :186
-            _, gl = value_and_gradient(lc, s.y)  # :187
-            s.gradl.copy_from(gl)
-            s.temp_x.axpby_(float(theta), s.xbar, float(R(1) - theta), s.x)  # :189
-            self._mul(s.temp_y, s.temp_x)  # :190-193   y + gamma2 (L t - grad l*)
-            s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)
-            s.temp_y.axpby_(float(g2), s.temp_y, 1.0, s.y)
-            prox_(s.ybar, hc, s.temp_y, g2)  # :194
-            s.FPR_x.axpby_(1.0, s.xbar, -1.0, s.x)  # :196-197
-            s.FPR_y.axpby_(1.0, s.ybar, -1.0, s.y)
-            s.temp_y.axpby_(float(R(mu * (R(2) - theta) * g1)), s.FPR_y)  # :199-201
-            self._mul_adjoint(s.temp_x, s.temp_y)
-            s.temp_x.axpby_(1.0, s.FPR_x, -1.0, s.temp_x)
-            s.x.axpby_(1.0, s.x, float(lam), s.temp_x)
-            s.temp_x.axpby_(float(R((R(1) - mu) * (R(2) - theta) * g2)), s.FPR_x)  # :203-205
-            self._mul(s.temp_y, s.temp_x)
-            s.temp_y.axpby_(1.0, s.FPR_y, 1.0, s.temp_y)
-            s.y.axpby_(1.0, s.y, float(lam), s.temp_y)
+            self.body(s)
             yield s
 
 
@@ -203,26 +211,27 @@ def default_display(it, iteration, state):
     print("%6d | %.3e" % (it, state.FPR_x.norm_inf() + state.FPR_y.norm_inf()))
 
 
-def _make(iterator_type, maxit, tol, stop, solution, verbose, freq, display, kwargs):
+def _make(iterator_type, maxit, tol, stop, solution, verbose, freq, display, graph, kwargs):
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)
     return IterativeAlgorithm(iterator_type, maxit=maxit, stop=stop, solution=solution, verbose=verbose, freq=freq,
-                              display=display, **kwargs)
+                              display=display, graph=graph, **kwargs)
 
 
-def AFBA(*, maxit=10_000, tol=1e-5, stop=None, solution=default_solution, verbose=False, freq=100,
+def AFBA(*, maxit=10_000, tol=1e-5, stop=None, solution=default_solution, verbose=False, freq=100, graph=False,
          display=default_display, **kwargs):
-    """primal_dual.jl:250-268"""
-    return _make(AFBAIteration, maxit, tol, stop, solution, verbose, freq, display, kwargs)
+    """primal_dual.jl:250-268.  graph=True: after two plain iterations the body is recorded into a hipGraph and every
+    further iteration is ONE graph launch plus the stop test (same arithmetic, same iterates)."""
+    return _make(AFBAIteration, maxit, tol, stop, solution, verbose, freq, display, graph, kwargs)
 
 
-def VuCondat(*, maxit=10_000, tol=1e-5, stop=None, solution=default_solution, verbose=False, freq=100,
+def VuCondat(*, maxit=10_000, tol=1e-5, stop=None, solution=default_solution, verbose=False, freq=100, graph=False,
              display=default_display, **kwargs):
     """primal_dual.jl:297-298: AFBA with theta = 2"""
-    return _make(VuCondatIteration, maxit, tol, stop, solution, verbose, freq, display, kwargs)
+    return _make(VuCondatIteration, maxit, tol, stop, solution, verbose, freq, display, graph, kwargs)
 
 
-def ChambollePock(*, maxit=10_000, tol=1e-5, stop=None, solution=default_solution, verbose=False, freq=100,
+def ChambollePock(*, maxit=10_000, tol=1e-5, stop=None, solution=default_solution, verbose=False, freq=100, graph=False,
                   display=default_display, **kwargs):
     """primal_dual.jl:328-329: AFBA with theta = 2, f = Zero, l = IndZero"""
-    return _make(ChambollePockIteration, maxit, tol, stop, solution, verbose, freq, display, kwargs)
+    return _make(ChambollePockIteration, maxit, tol, stop, solution, verbose, freq, display, graph, kwargs)

@@ -58,6 +58,11 @@ def suite(A, b, lam):
          lambda: dict(y0=np.zeros(m, T), h=pa.SquaredDistance(b), L=A, g=pa.NormL1(lam)),
          lambda: ox.afba(theta=1, mu=1, tol=1e-6, x0=x0, y0=np.zeros(m, T), h=ox.SqrDistance(b), L=A, g=o.NormL1(lam))),
         ("SFISTA", pa.SFISTA(tol=1e-3), lambda: dict(Lf=opn2, **ls()), lambda: ox.sfista(tol=1e-3, x0=x0, Lf=opn2, **ols())),
+        # the same calls with the iteration body replayed as a hipGraph (one launch per iteration + the stop test)
+        ("DouglasRachford[graph]", pa.DouglasRachford(tol=1e-6, graph=True), lambda: dict(gamma=1.0, **ls()), None),
+        ("AFBA-1[graph]", pa.AFBA(theta=1, mu=1, tol=1e-6, graph=True), lambda: dict(y0=np.zeros(n, T), beta_f=opn2, **ls()), None),
+        ("AFBA-2[graph]", pa.AFBA(theta=1, mu=1, tol=1e-6, graph=True),
+         lambda: dict(y0=np.zeros(m, T), h=pa.SquaredDistance(b), L=A, g=pa.NormL1(lam)), None),
     ]
     return [(name, dev(solver, kw), cpu) for name, solver, kw, cpu in rows]
 
@@ -80,13 +85,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--instances", default="tiny,small,medium")
+    ap.add_argument("--only", default="", help="substring filter on the solver name")
     args = ap.parse_args()
-    pa.get_context()
+    pa.set_default_context(pa.Context.on_new_stream())  # a capturable (non-default) stream for the [graph] rows
     for inst in args.instances.split(","):
         d = np.load(os.path.join(GOLDEN, f"lasso_{inst}.npz"))
         A, b, lam = np.asfortranarray(d["A"].astype(np.float64)), d["b"].astype(np.float64), float(d["lam"])
         f_star = objective(A, b, lam, d["xstar"])
         for name, dev_call, cpu_call in suite(A, b, lam):
+            if args.only and args.only not in name:
+                continue
             dev_call()  # warm-up (code objects, workspaces)
             ms_dev, (xd, it_dev) = timed(dev_call, args.repeat)
             rec = {"instance": f"lasso_{inst} {A.shape[0]}x{A.shape[1]} f64", "solver": name, "iterations": int(it_dev),
