@@ -95,6 +95,8 @@ def convex_conjugate(f):
         return Zero()
     if isinstance(f, Conjugate):
         return f.f
+    if isinstance(f, SqrNormL2) and f.lam > 0:
+        return SqrNormL2(1.0 / f.lam)  # exact conjugate of lam/2 ||.||^2
     return Conjugate(f)
 
 

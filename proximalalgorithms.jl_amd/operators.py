@@ -464,6 +464,8 @@ def convex_conjugate(f):
         return Zero()
     if isinstance(f, Conjugate):
         return f.f
+    if isinstance(f, SqrNormL2) and f.lam > 0:
+        return SqrNormL2(1.0 / f.lam)  # (lam/2 ||.||^2)* = 1/(2 lam) ||.||^2: smooth, so AFBA's `l` term can use it
     return Conjugate(f)
 
 

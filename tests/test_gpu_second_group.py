@@ -608,3 +608,29 @@ def test_graph_falls_back_on_default_stream_and_refuses_allocation(pa, stream_ct
     finally:
         pa.set_default_context(prev)
     assert device.get_context() is stream_ctx
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_afba_with_infimal_convolution_term(pa, dtype):
+    """the full template f + g + (h [] l)(L x) with a strongly convex l (primal_dual.jl:187: gradient of l*):
+    h = lam ||.||_1, l = beta/2 ||.||^2  ->  h [] l is the Huber function; checked against the restatement and
+    against the stationarity of the smoothed problem."""
+    rng = np.random.default_rng(31)
+    m, n = 40, 25
+    L = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+    c = rng.standard_normal(n).astype(dtype)
+    R = np.dtype(dtype).type
+    lam, beta = R(0.3), R(2.0)
+    x0, y0 = np.zeros(n, dtype), np.zeros(m, dtype)
+    tol = R(1e-4 if dtype == np.float32 else 1e-9)
+    kw = dict(x0=x0, y0=y0, beta_f=1, beta_l=float(1 / beta))
+    for theta, mu in ((2, 0), (1, 1), (0, 1), (0, 0.5), (1, 0), (0, 0)):
+        (x, y), it = pa.AFBA(theta=theta, mu=mu, tol=tol)(f=pa.SquaredDistance(c), h=pa.NormL1(lam), l=pa.SqrNormL2(beta), L=L, **kw)
+        (xo, yo), ito = ox.afba(theta=theta, mu=mu, tol=tol, f=ox.SqrDistance(c), h=o.NormL1(lam), l=ox.SqrNormL2(beta), L=L, **kw)
+        assert abs(it - ito) <= (max(3, ito // 10) if dtype == np.float32 else 0), (theta, mu)
+        assert close(x, xo, dtype, 5) and close(y, yo, dtype, 5), (theta, mu)
+        # stationarity: x - c + L' huber'(L x) = 0 with huber'(z) = clip(beta z, -lam, lam)
+        x64 = x.astype(np.float64)
+        z = L.astype(np.float64) @ x64
+        grad = x64 - c + L.astype(np.float64).T @ np.clip(float(beta) * z, -float(lam), float(lam))
+        assert np.max(np.abs(grad)) <= (2e-3 if dtype == np.float32 else 1e-7), (theta, mu)
