@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the second group of iterations (SFISTA, DavisYin, LiLin, DRLS, AFBA family,
+DouglasRachford with LeastSquares) against the CPU restatement: random shapes (incl. m < n, m > n, sizes that are not
+multiples of the kernels' vector widths), random operator pairs, Float64, a fixed number of iterations compared iterate
+by iterate.  Usage: python tests/tools/fuzz_second_group.py [cases] [first_seed].  Prints one line per failing case
+and a summary; exit code 1 on failures."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import proximalalgorithms.jl_amd as pa  # noqa: E402
+from oracle import proxgrad_oracle as o  # noqa: E402
+from oracle import proxgrad_oracle_ext as ox  # noqa: E402
+
+TOL = 2e-9  # Float64 iterates, relative to max(1, ||.||_inf): same operations in a different rounding order
+
+
+def pick_g(rng, n):
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        lam = float(rng.uniform(0.01, 0.5))
+        return pa.NormL1(lam), o.NormL1(lam)
+    if kind == 1:
+        lo, hi = -float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.1, 1.0))
+        return pa.IndBox(lo, hi), o.IndBox(lo, hi)
+    return pa.Zero(), o.Zero()
+
+
+def case(seed):
+    rng = np.random.default_rng(seed)
+    m, n = int(rng.integers(1, 120)), int(rng.integers(1, 160))
+    A = np.asfortranarray(rng.standard_normal((m, n)) / np.sqrt(m))
+    b = rng.standard_normal(m)
+    Lf = float(np.linalg.norm(A, 2) ** 2) + 1e-3
+    x0 = 0.1 * rng.standard_normal(n)
+    gd, go = pick_g(rng, n)
+    algo = ["sfista", "davis_yin", "lilin", "drls", "afba", "dr", "chambolle_pock"][int(rng.integers(0, 7))]
+    iters = int(rng.integers(5, 25))
+    desc = f"seed={seed} {algo} m={m} n={n} g={type(go).__name__} iters={iters}"
+    if algo == "sfista":
+        mf = float(rng.choice([0.0, 0.05]))
+        dev = pa.SFISTAIteration(x0=x0, f=pa.LeastSquares(A, b), g=gd, Lf=Lf, mf=mf)
+        ora = ox.SFISTAIteration(x0=x0, f=o.LeastSquares(A, b), g=go, Lf=Lf, mf=mf)
+        fields = ("y", "x")
+    elif algo == "davis_yin":
+        lam2, rel = float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.5, 1.5))
+        dev = pa.DavisYinIteration(x0=x0, f=pa.LeastSquares(A, b), g=gd, h=pa.SqrNormL2(lam2), Lf=Lf, lam=rel)
+        ora = ox.DavisYinIteration(x0=x0, f=o.LeastSquares(A, b), g=go, h=ox.SqrNormL2(lam2), Lf=Lf, lam=rel)
+        fields = ("z", "xh")
+    elif algo == "lilin":
+        if isinstance(go, o.IndBox):
+            x0 = np.clip(x0, go.lo, go.hi)  # the initial point must be feasible (li_lin.jl:75)
+        delta = float(rng.choice([1e-3, 5.0]))
+        dev = pa.LiLinIteration(x0=x0, f=pa.LeastSquares(A, b), g=gd, gamma=0.9 / Lf, delta=delta)
+        ora = ox.LiLinIteration(x0=x0, f=o.LeastSquares(A, b), g=go, gamma=0.9 / Lf, delta=delta)
+        fields = ("z", "y")
+    elif algo == "drls":
+        kind = ["none", "nesterov_simple", "nesterov_fixed"][int(rng.integers(0, 3))]
+        tag = {"none": pa.NoAcceleration(), "nesterov_simple": pa.NesterovExtrapolation(pa.SimpleNesterovSequence),
+               "nesterov_fixed": pa.NesterovExtrapolation(pa.FixedNesterovSequence)}[kind]
+        desc += f" directions={kind}"
+        dev = pa.DRLSIteration(x0=x0, f=pa.LeastSquares(A, b), g=gd, Lf=Lf, directions=tag)
+        ora = ox.DRLSIteration(x0=x0, f=o.LeastSquares(A, b), g=go, Lf=Lf, directions=kind)
+        fields = ("x", "v")
+    elif algo == "afba":
+        theta, mu = [(2, 0), (1, 1), (0, 1), (0, 0), (1, 0), (0, 0.5)][int(rng.integers(0, 6))]
+        lam2 = float(rng.uniform(0.2, 2.0))
+        desc += f" theta={theta} mu={mu}"
+        y0 = 0.1 * rng.standard_normal(m)
+        dev = pa.AFBAIteration(x0=x0, y0=y0, f=pa.SqrNormL2(lam2), beta_f=lam2, g=gd, h=pa.SquaredDistance(b), L=A, theta=theta, mu=mu)
+        ora = ox.AFBAIteration(x0=x0, y0=y0, f=ox.SqrNormL2(lam2), beta_f=lam2, g=go, h=ox.SqrDistance(b), L=A, theta=theta, mu=mu)
+        fields = ("x", "y")
+    elif algo == "chambolle_pock":
+        y0 = np.zeros(m)
+        dev = pa.ChambollePockIteration(x0=x0, y0=y0, g=gd, h=pa.SquaredDistance(b), L=A)
+        ora = ox.AFBAIteration(x0=x0, y0=y0, g=go, h=ox.SqrDistance(b), L=A, theta=2)
+        fields = ("x", "y")
+    else:
+        gamma = float(rng.uniform(0.2, 5.0)) / Lf
+        dev = pa.DouglasRachfordIteration(x0=x0, f=pa.LeastSquares(A, b), g=gd, gamma=gamma)
+        ora = o.DouglasRachfordIteration(x0=x0, f=o.LeastSquares(A, b), g=go, gamma=gamma)
+        fields = ("x", "y")
+    di, oi = iter(dev), iter(ora)
+    for k in range(iters):
+        sd, so = next(di), next(oi)
+        for fld in fields:
+            got, ref = getattr(sd, fld).numpy(), np.asarray(getattr(so, fld))
+            err = np.max(np.abs(got - ref)) if got.size else 0.0
+            if not err <= TOL * max(1.0, float(np.max(np.abs(ref))) if ref.size else 1.0) * (k + 1):
+                return desc, f"iteration {k + 1}: {fld} differs by {err:.3e}"
+    return desc, None
+
+
+def run(cases, first_seed=0, verbose=False):
+    bad = []
+    for seed in range(first_seed, first_seed + cases):
+        desc, err = case(seed)
+        if err:
+            bad.append((desc, err))
+            print("FAIL", desc, err, flush=True)
+        elif verbose:
+            print("ok  ", desc, flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    failures = run(n_cases, first)
+    print(f"{n_cases - len(failures)} / {n_cases} cases agree with the CPU restatement")
+    sys.exit(1 if failures else 0)
