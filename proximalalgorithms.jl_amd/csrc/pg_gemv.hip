@@ -743,7 +743,10 @@ template <typename T, int U, int C, int WAVES>
 pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   const int64_t ncg = (A->n + C - 1) / C;
-  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", ((WAVES == 4 && U >= 8) || (WAVES == 8 && U == 4)) ? 1 : 2);
+  // workgroups per CU (measured, scripts/tune_tn.py): one for the big double-buffered tiles, two for 4-wave short
+  // columns, four / eight for the 2- and 1-wave workgroups of very short columns
+  const int bpc_default = WAVES == 1 ? 8 : WAVES == 2 ? 4 : (((WAVES == 4 && U >= 8) || (WAVES == 8 && U == 4)) ? 1 : 2);
+  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", bpc_default);
   if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
   if (blocks > ncg) blocks = ncg;
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
@@ -752,7 +755,7 @@ pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.partials = (T*)A->partials;
   *blocks_out = (int)blocks;
   pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES, WAVES == 4>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
+  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES, (WAVES <= 4)>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -770,7 +773,11 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int nrg = a.nrg;
   // 17..32 row groups (m = 8192 in Float32): eight waves of U = 4 with C = 8 columns per step measured 4 % faster than four
   // waves of U = 8 (775 vs 742 it/s on 8192 x 262144, profiles/r1_tune_tn_geometry.log); 33..64 stay on four waves
-  const int W = env_int("PG_TN_WAVES", (nrg <= 16 || (nrg > 32 && nrg <= 64)) ? 4 : 8) == 8 ? 8 : 4;
+  // very short columns (profiles/r1_tune_tn_short_columns.log): the fewer waves share a column, the fewer cross-wave
+  // exchanges per byte -- one wave per column up to 2 row groups (512 rows f32: 2.6 -> 4.6 TB/s), two waves up to 8
+  // (1024 rows: 4.5 -> 5.3 TB/s, 2048 rows: 6.1 -> 6.3 TB/s); from 9 row groups on, four waves
+  int W = env_int("PG_TN_WAVES", nrg <= 2 ? 1 : nrg <= 8 ? 2 : (nrg <= 16 || (nrg > 32 && nrg <= 64)) ? 4 : 8);
+  if (W != 1 && W != 2 && W != 8) W = 4;
   int U = 1;
   while (U * W < nrg) U *= 2;
   // two register tiles of C * U KiB per wave (one in flight, one being consumed), one workgroup per CU: the measured
@@ -779,6 +786,7 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   int C = env_int("PG_TN_C", U >= 8 ? 32 / U : 16 / U);
   if (W == 8 && U == 16) C = 1;
   if (W == 8 && U == 4 && env_int("PG_TN_C", 0) == 0) C = 8;
+  if (W <= 2 && env_int("PG_TN_C", 0) == 0) C = (W == 2 && U == 4) ? 4 : (U == 1 ? 16 : 8);  // (2,4,4) (2,2,8) (1,2,8) (1,1,16)
   if (sizeof(T) == 8 && U == 1 && C > 16) C = 16;  // <f64, 1, 32> would spill
 #define PG_TN_CASE(UU, CC, WW) \
   if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)
@@ -797,6 +805,26 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TN_CASE(8, 4, 8);
   PG_TN_CASE(4, 4, 8);
   PG_TN_CASE(4, 8, 8);
+  // experiments for short columns (PG_TN_WAVES = 1 | 2): fewer waves per column, hence fewer / no cross-wave exchanges
+  PG_TN_CASE(8, 2, 2);
+  PG_TN_CASE(8, 4, 2);
+  PG_TN_CASE(4, 4, 2);
+  PG_TN_CASE(4, 8, 2);
+  PG_TN_CASE(2, 8, 2);
+  PG_TN_CASE(2, 16, 2);
+  PG_TN_CASE(16, 1, 1);
+  PG_TN_CASE(16, 2, 1);
+  PG_TN_CASE(8, 2, 1);
+  PG_TN_CASE(8, 4, 1);
+  PG_TN_CASE(4, 4, 1);
+  PG_TN_CASE(4, 8, 1);
+  PG_TN_CASE(2, 8, 1);
+  PG_TN_CASE(2, 16, 1);
+  PG_TN_CASE(1, 8, 1);
+  PG_TN_CASE(1, 16, 1);
+  PG_TN_CASE(1, 32, 1);
+  PG_TN_CASE(1, 8, 2);
+  PG_TN_CASE(1, 16, 2);
 #undef PG_TN_CASE
   pg_set_error("no gemv_tn instantiation for U=%d C=%d WAVES=%d", U, C, W);
   return PG_ERR_UNSUPPORTED;

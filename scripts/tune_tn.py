@@ -22,11 +22,11 @@ def main():
         g = pa.NormL1(0.3)
         res = []
         nrg = m * 4 // 1024
-        for W in (4, 8):
+        for W in (1, 2, 4, 8):
             U = 1
             while U * W < nrg: U *= 2
             for C in sorted({max(1, 8 // U), max(1, 16 // U), max(1, 32 // U)}):
-                for bpc in (1, 2, 3, 4):
+                for bpc in ((1, 2, 3, 4) if W >= 4 else (2, 4, 8, 16)):
                     os.environ.update(PG_TN_WAVES=str(W), PG_TN_C=str(C), PG_TN_BLOCKS_PER_CU=str(bpc))
                     try:
                         for _ in range(2): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
@@ -36,7 +36,7 @@ def main():
                         res.append((m * n * 4 / (ms / cnt * 1e-3) / 1e9, W, U, C, bpc))
                     except Exception as e:
                         ctx.profile(False)
-                        if bpc == 1: print(f"  W={W} U={U} C={C}: not instantiated")
+                        if bpc == (1 if W >= 4 else 2): print(f"  W={W} U={U} C={C}: not instantiated")
                         break
         for k in KNOBS: os.environ.pop(k, None)
         for _ in range(2): f.fused_pass(x, x, 0.01, 0.5, g, *vs)
