@@ -82,8 +82,19 @@ class PANOCIteration:
         self.counters["A_passes"] += 1
         return self.A.mul_adjoint(r, out)
 
-    def _model(self, s):  # :84-85
-        return _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / s.gamma)
+    def _model(self, s, gamma=None):  # :84-85
+        """f_model at the current (At_grad_f_Ax, res) pair.  When the pair comes out of the single sweep, the sweep's own
+        reductions <At_grad, res> and ||res||^2 are reused (no further kernels, no host round trips)."""
+        gamma = s.gamma if gamma is None else gamma
+        st = getattr(s, "res_stats", None)
+        if st is not None:
+            R = s.x.dtype.type
+            return R(R(s.f_Ax) - st[1] + (R(self.alpha / gamma) / R(2)) * st[2])
+        return _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)
+
+    def _res_sq(self, s):
+        st = getattr(s, "res_stats", None)
+        return st[2] if st is not None else s.res.norm() ** 2
 
     def _lower_bound_smoothness_constant(self, x, grad_f_Ax):
         """fb_tools.jl:7-12"""
@@ -100,7 +111,7 @@ class PANOCIteration:
         R = s.x.dtype.type
         eps = R(np.finfo(R).eps)
         gamma, reduce_gamma = R(s.gamma), R(0.5)
-        f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)  # :42
+        f_Az_upp = self._model(s, gamma)  # :42
         if getattr(s, "Az_next_valid", False) and getattr(s, "Az_next_of", None) is z:
             Az.copy_from(s.Az_next)  # :43 -- the last sweep already formed A z
             s.Az_next_valid = False
@@ -114,6 +125,7 @@ class PANOCIteration:
             s.y.axpby_(1.0, s.x, -gamma, s.At_grad_f_Ax)
             g_z = prox_(z, self.g, s.y, gamma)
             s.res.axpby_(1.0, s.x, -1.0, z)
+            s.res_stats = s.res_inf = None
             f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)
             self._mul(Az, z)
             f_Az, _ = value_and_gradient_into(self.f, Az, grad_f_Az)
@@ -175,7 +187,7 @@ class PANOCIteration:
         s.f_Ax_d, _ = value_and_gradient_into(self.f, s.Ax_d, s.grad_f_Ax_d)  # :182-183
         sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :193
         tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))  # :194
-        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :195 (the residual of the CURRENT point)
+        threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :195 (the residual of the CURRENT point)
         fused = False
         if self._fused_tn:
             # :184 and :197-199 in one read of A, which also leaves A z for the next iteration's line search
@@ -185,7 +197,8 @@ class PANOCIteration:
             s.z_curr.copy_from(s.z)
             s.f_Ax = s.f_Ax_d
             try:
-                s.g_z = self.A.fused_tn(s.grad_f_Ax_d, s.x, s.gamma, self.g, s.At_grad_f_Ax_d, s.y, s.z, s.res, s.Az_next)[0]
+                sc = self.A.fused_tn(s.grad_f_Ax_d, s.x, s.gamma, self.g, s.At_grad_f_Ax_d, s.y, s.z, s.res, s.Az_next)
+                s.g_z = sc[0]
                 fused = True
             except ProxGradError:
                 self._fused_tn = False  # shape outside the kernel's range: separate sweeps from now on
@@ -193,7 +206,9 @@ class PANOCIteration:
             self.counters["A_passes"] += 1
             s.At_grad_f_Ax.copy_from(s.At_grad_f_Ax_d)
             s.Az_next_valid, s.Az_next_of = True, s.z
+            s.res_stats, s.res_inf = (sc[1], sc[2], sc[3]), sc[1]  # norm(res, Inf), <At_grad, res>, ||res||^2 of this pair
         else:
+            s.res_stats = s.res_inf = None
             self._mul_adj(s.At_grad_f_Ax_d, s.grad_f_Ax_d)  # :184
             s.x.copy_from(s.x_d)  # :186-191
             s.Ax.copy_from(s.Ax_d)
@@ -232,6 +247,7 @@ class PANOCIteration:
             s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :246
             s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :247
             s.res.axpby_(1.0, s.x, -1.0, s.z)  # :248
+            s.res_stats = s.res_inf = None
             FBE_x_new = R(self._model(s) + s.g_z)  # :249
         if s.H is not None:  # :252 (update_direction_state! :122-126)
             s.x_prev.axpby_(1.0, s.x, -1.0, s.x_prev)
@@ -260,7 +276,8 @@ def value_and_gradient_into(f, u, grad_out):
 def default_stopping_criterion(tol, iteration, state):
     """panoc.jl:256-257"""
     R = state.res.dtype.type
-    return R(state.res.norm_inf()) / R(state.gamma) <= R(tol)
+    res_inf = state.res_inf if getattr(state, "res_inf", None) is not None else state.res.norm_inf()
+    return R(res_inf) / R(state.gamma) <= R(tol)
 
 
 def default_solution(iteration, state):

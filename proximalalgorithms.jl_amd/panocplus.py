@@ -55,7 +55,7 @@ class PANOCplusIteration(PANOCIteration):
         FBE_x = R(self._model(s) + s.g_z)  # :174
         sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :176
         tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
-        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :178
+        threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :178
         tau_backtracks = 0
         can_update_direction = True
         while True:  # :183-235
@@ -77,7 +77,9 @@ class PANOCplusIteration(PANOCIteration):
             fused = False
             if self._fused_tn:  # :202-206 and :210 in one read of A (pg_mat_fused_tn)
                 try:
-                    s.g_z = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res, s.Az)[0]
+                    sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res, s.Az)
+                    s.g_z = sc[0]
+                    s.res_stats = (sc[1], sc[2], sc[3])  # the sweep's own reductions of this (At_grad, res) pair
                     fused = True
                     self.counters["A_passes"] += 1
                 except ProxGradError:
@@ -87,6 +89,7 @@ class PANOCplusIteration(PANOCIteration):
                 s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :204
                 s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :205
                 s.res.axpby_(1.0, s.x, -1.0, s.z)  # :206
+                s.res_stats = None
             f_Az_upp = self._model(s)  # :208
             if not fused:
                 self._mul(s.Az, s.z)  # :210

@@ -80,7 +80,7 @@ class ZeroFPRIteration(PANOCIteration):
         self._mul(s.Ad, s.d)  # :193
         sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :195
         tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
-        threshold = R(FBE_x - sigma * s.res.norm() ** 2 + tol)  # :197
+        threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :197
         for k in range(1, self.max_backtracks + 1):  # :199-217
             s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :200
             s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :201
@@ -88,14 +88,17 @@ class ZeroFPRIteration(PANOCIteration):
             fused = False
             if self._fused_tn:  # :205-208 and the A xbar of the next iteration (:43 / :166) in one read of A
                 try:
-                    s.g_xbar = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)[0]
+                    sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)
+                    s.g_xbar = sc[0]
                     fused = True
                 except ProxGradError:
                     self._fused_tn = False
             if fused:
                 self.counters["A_passes"] += 1
                 s.Az_next_valid, s.Az_next_of = True, s.xbar
+                s.res_stats, s.res_inf = (sc[1], sc[2], sc[3]), sc[1]  # the sweep's own reductions of (At_grad, res)
             else:
+                s.res_stats = s.res_inf = None
                 self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :205
                 s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :206
                 s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :207
@@ -111,7 +114,8 @@ class ZeroFPRIteration(PANOCIteration):
 def default_stopping_criterion(tol, iteration, state):
     """zerofpr.jl:222-223"""
     R = state.res.dtype.type
-    return R(state.res.norm_inf()) / R(state.gamma) <= R(tol)
+    res_inf = state.res_inf if getattr(state, "res_inf", None) is not None else state.res.norm_inf()
+    return R(res_inf) / R(state.gamma) <= R(tol)
 
 
 def default_solution(iteration, state):
