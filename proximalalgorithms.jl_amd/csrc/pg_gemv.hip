@@ -805,19 +805,11 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TN_CASE(8, 4, 8);
   PG_TN_CASE(4, 4, 8);
   PG_TN_CASE(4, 8, 8);
-  // experiments for short columns (PG_TN_WAVES = 1 | 2): fewer waves per column, hence fewer / no cross-wave exchanges
-  PG_TN_CASE(8, 2, 2);
-  PG_TN_CASE(8, 4, 2);
+  // very short columns: two waves (3..8 row groups) or one wave (1..2) per column -- defaults and their tuner neighbours
   PG_TN_CASE(4, 4, 2);
   PG_TN_CASE(4, 8, 2);
   PG_TN_CASE(2, 8, 2);
   PG_TN_CASE(2, 16, 2);
-  PG_TN_CASE(16, 1, 1);
-  PG_TN_CASE(16, 2, 1);
-  PG_TN_CASE(8, 2, 1);
-  PG_TN_CASE(8, 4, 1);
-  PG_TN_CASE(4, 4, 1);
-  PG_TN_CASE(4, 8, 1);
   PG_TN_CASE(2, 8, 1);
   PG_TN_CASE(2, 16, 1);
   PG_TN_CASE(1, 8, 1);
