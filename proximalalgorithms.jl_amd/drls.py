@@ -62,10 +62,14 @@ class DRLSIteration:
         self.directions = directions if directions is not None else LBFGS(5)
 
     def DRE(self, s):
-        """drls.jl:105-111: f(u) + g(v) - <x - u, res> / gamma + ||res||^2 / (2 gamma)"""
+        """drls.jl:105-111: f(u) + g(v) - <x - u, res> / gamma + ||res||^2 / (2 gamma).  The value (and ||res||^2) of the
+        state the line search accepted is kept: the next iteration starts from exactly that state (:161-163), so its
+        envelope and threshold cost no further reductions."""
         R = s.x.dtype.type
         dot_product = R(s.x.dot(s.res) - s.u.dot(s.res))
-        return R(s.f_u + s.g_v - dot_product / self.gamma + R(1) / (R(2) * self.gamma) * s.res.norm() ** 2)
+        s.res_sq = R(s.res.norm() ** 2)
+        s.dre = R(s.f_u + s.g_v - dot_product / self.gamma + R(1) / (R(2) * self.gamma) * s.res_sq)
+        return s.dre
 
     def _dr_tail(self, s):
         s.w.axpby_(2.0, s.u, -1.0, s.x)
@@ -80,6 +84,7 @@ class DRLSIteration:
         for name in ("u", "v", "w", "res", "res_prev", "xbar", "d", "x_d", "u0", "u1", "temp_x1", "temp_x2"):
             setattr(s, name, s.x.similar())
         s.gamma, s.tau = self.gamma, R(0)
+        s.dre = s.res_sq = None
         s.f_u = prox_(s.u, self.f, s.x, self.gamma)
         self._dr_tail(s)
         s.xbar_prev = s.xbar.copy()
@@ -89,8 +94,8 @@ class DRLSIteration:
         quadratic = is_generalized_quadratic(self.f)
         yield s
         while True:
-            dre_curr = self.DRE(s)
-            threshold = R(self.dre_sign * dre_curr - self.c / self.gamma * s.res.norm() ** 2)  # :163
+            dre_curr = s.dre if s.dre is not None else self.DRE(s)
+            threshold = R(self.dre_sign * dre_curr - self.c / self.gamma * s.res_sq)  # :163
             if quasi_newton:  # :137-140
                 s.H.mul_(s.d, s.res)
                 s.d.axpby_(-1.0, s.d)
@@ -111,9 +116,11 @@ class DRLSIteration:
                 s.res_prev.axpby_(1.0, s.res, -1.0, s.res_prev)
                 s.H.update_(s.d, s.res_prev)
             a = b = c = R(0)
+            s.dre = None  # the state moved; the loop below re-evaluates the envelope at every candidate
             for k in range(1, self.max_backtracks + 1):  # :183-195
                 if self.dre_sign * self.DRE(s) <= threshold:
                     break
+                s.dre = None
                 s.tau = R(0) if k == self.max_backtracks else R(s.tau / R(2))
                 s.x.axpby_(float(s.tau), s.x_d, float(R(1) - s.tau), s.xbar_prev)
                 if quadratic:
