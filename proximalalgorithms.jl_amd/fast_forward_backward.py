@@ -10,6 +10,8 @@ from .forward_backward import _LazyVectors, _res_inf
 from .nesterov import (AdaptiveNesterovSequence, ConstantNesterovSequence, FixedNesterovSequence,
                        SimpleNesterovSequence)
 from .operators import Zero, fused_supported, prox_, value_and_gradient
+from . import _composed
+from ._composed import composed_supported
 from ._fused import FusedIteration
 
 
@@ -49,7 +51,10 @@ class FastForwardBackwardIteration:
         # fused engine: ONE read of A per iteration where the operator allows it (pg_ls_fused_pass); False = two sweeps
         self.single_sweep = bool(single_sweep)
         if engine is None:
-            engine = "fused" if fused_supported(self.f, self.g) else "generic"
+            engine = "fused" if fused_supported(self.f, self.g) else (
+                "composed" if (composed_supported(self.f, self.g) and self.single_sweep) else "generic")
+        if engine == "composed" and not composed_supported(self.f, self.g):
+            raise TypeError("engine='composed' needs f = Composed(loss, device matrix) and g in {NormL1, IndBox(scalar bounds), Zero}")
         if engine == "fused" and not fused_supported(self.f, self.g):
             raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox(scalar bounds), Zero}")
         self.engine = engine
@@ -139,7 +144,14 @@ class FastForwardBackwardIteration:
             yield s
 
     def __iter__(self):
-        return self._iter_fused() if self.engine == "fused" else self._iter_generic()
+        if self.engine == "fused":
+            return self._iter_fused()
+        if self.engine == "composed":  # x -> loss(A x): one read of A per iteration (_composed.py)
+            gen = _composed.try_iter(self, FastForwardBackwardState, fast=True)
+            if gen is not None:
+                return gen
+            self.engine = "generic"  # the sweep kernel does not cover this matrix
+        return self._iter_generic()
 
 
 def call_extrapolate(x, z, z_prev, beta):

@@ -10,6 +10,8 @@ from .algorithm import IterativeAlgorithm
 from .device import as_hipvector
 from .fb_tools import backtrack_stepsize_, lower_bound_smoothness_constant
 from .operators import Zero, fused_supported, prox_, value_and_gradient
+from . import _composed
+from ._composed import composed_supported
 from ._fused import FusedIteration
 
 
@@ -72,7 +74,10 @@ class ForwardBackwardIteration:
         self.reduce_gamma = R(reduce_gamma)
         self.increase_gamma = R(increase_gamma)
         if engine is None:
-            engine = "fused" if fused_supported(self.f, self.g) else "generic"
+            engine = "fused" if fused_supported(self.f, self.g) else (
+                "composed" if (composed_supported(self.f, self.g) and single_sweep) else "generic")
+        if engine == "composed" and not composed_supported(self.f, self.g):
+            raise TypeError("engine='composed' needs f = Composed(loss, device matrix) and g in {NormL1, IndBox(scalar bounds), Zero}")
         if engine == "fused" and not fused_supported(self.f, self.g):
             raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox(scalar bounds), Zero}")
         self.engine = engine
@@ -139,7 +144,14 @@ class ForwardBackwardIteration:
             yield s
 
     def __iter__(self):
-        return self._iter_fused() if self.engine == "fused" else self._iter_generic()
+        if self.engine == "fused":
+            return self._iter_fused()
+        if self.engine == "composed":  # x -> loss(A x): one read of A per iteration (_composed.py)
+            gen = _composed.try_iter(self, ForwardBackwardState, fast=False)
+            if gen is not None:
+                return gen
+            self.engine = "generic"  # the sweep kernel does not cover this matrix
+        return self._iter_generic()
 
 
 def _res_inf(state):

@@ -1461,3 +1461,64 @@ def test_panoc_single_sweep_equals_separate_sweeps(pa, dtype):
         assert np.max(np.abs(Az.numpy() - A64 @ z.numpy().astype(np.float64))) <= tol * max(1.0, float(np.max(np.abs(A64 @ z_ref))))
         assert float(res_inf) == pytest.approx(float(np.max(np.abs(x - z.numpy()))), rel=1e-5, abs=1e-6)
         assert float(gz) == pytest.approx(0.3 * float(np.sum(np.abs(z.numpy().astype(np.float64)))), rel=1e-4, abs=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# engine "composed": FB / FFB on x -> loss(A x) with ONE read of A per iteration (_composed.py)
+# ------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("loss", ["logistic", "sqdist"])
+def test_composed_single_sweep_matches_generic_engine_and_oracle(pa, dtype, fast, adaptive, loss):
+    m, n = 300, 700
+    A, b, lam = synthetic_problem(m, n, dtype, seed=23)
+    R = np.dtype(dtype).type
+    if loss == "logistic":
+        lam = R(0.02)
+    L, Lo = (pa.LogisticLoss, o.LogisticLoss) if loss == "logistic" else (pa.SquaredDistance, o.SquaredDistance)
+    Lf = R(np.linalg.norm(A.astype(np.float64), 2) ** 2) * (R(0.25) if loss == "logistic" else R(1))
+    It, Io = (pa.FastForwardBackwardIteration, o.FastForwardBackwardIteration) if fast else \
+        (pa.ForwardBackwardIteration, o.ForwardBackwardIteration)
+    x0 = np.zeros(n, dtype)
+    kw = {} if adaptive else {"Lf": Lf}
+    Ad = pa.HIPMatrix.from_numpy(A)
+    it_c = It(f=pa.Composed(L(b), Ad), g=pa.NormL1(lam), x0=x0, **kw)
+    it_g = It(f=pa.Composed(L(b), Ad), g=pa.NormL1(lam), x0=x0, engine="generic", **kw)
+    it_o = Io(f=o.Composed(Lo(b), A), g=o.NormL1(lam), x0=x0, **kw)
+    assert it_c.engine == "composed" and it_g.engine == "generic"
+    K = 25
+    tol = 2e-4 if dtype == np.float32 else 1e-10
+    for k, (sc, sg, so) in enumerate(itertools.islice(zip(it_c, it_g, it_o), K)):
+        if dtype == np.float64:
+            assert float(sc.gamma) == pytest.approx(float(so.gamma), rel=1e-12), k
+        scale = max(1.0, float(np.max(np.abs(so.z))))
+        assert np.max(np.abs(sc.z.numpy() - so.z)) <= tol * scale, k
+        assert np.max(np.abs(sc.z.numpy() - sg.z.numpy())) <= tol * scale, k
+        assert float(sc.f_x) == pytest.approx(float(so.f_x), rel=1e-4 if dtype == np.float32 else 1e-10), k
+    # one read of A per iteration: init (A x0 + sweep [+ 3 for the step-size estimate]) + one sweep per step
+    # (+ one pass per rejected line-search trial)
+    expect = 2 + (3 if adaptive else 0) + (K - 1) + it_c.counters.get("backtracks", 0)
+    assert it_c.counters["a_passes"] == expect
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_composed_engine_sparse_logistic_known_answer_and_fallback(pa, dtype):
+    """test_sparse_logistic_small.jl (FB / FFB rows) through the composed engine; shapes / operators outside the sweep
+    kernel fall back to the generic engine"""
+    A = np.asfortranarray(rv.LASSO_SMALL_A.astype(dtype))
+    b = rv.LASSO_SMALL_B.astype(dtype)
+    R = np.dtype(dtype).type
+    x0 = np.zeros(5, dtype)
+    f = lambda: pa.Composed(pa.LogisticLoss(b), A)
+    for solver, key in ((pa.ForwardBackward, "fb_adaptive"), (pa.FastForwardBackward, "ffb_adaptive")):
+        s = solver(tol=R(rv.LOGISTIC_TOL), adaptive=True)
+        x, it = s(x0=x0, f=f(), g=pa.NormL1(R(rv.LOGISTIC_LAM)))
+        assert np.max(np.abs(x - rv.LOGISTIC_XSTAR.astype(dtype))) <= 1e-4
+        assert it < rv.LOGISTIC_BOUNDS[key]
+    it_v = pa.FastForwardBackwardIteration(f=f(), g=pa.IndBox(np.full(5, -1.0, dtype), np.full(5, 1.0, dtype)), x0=x0, Lf=R(10))
+    assert it_v.engine == "generic"  # vector bounds: not a sweep prox kind
+    it_off = pa.FastForwardBackwardIteration(f=f(), g=pa.NormL1(R(0.1)), x0=x0, Lf=R(10), single_sweep=False)
+    assert it_off.engine == "generic"
