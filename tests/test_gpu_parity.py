@@ -1522,3 +1522,14 @@ def test_composed_engine_sparse_logistic_known_answer_and_fallback(pa, dtype):
     assert it_v.engine == "generic"  # vector bounds: not a sweep prox kind
     it_off = pa.FastForwardBackwardIteration(f=f(), g=pa.NormL1(R(0.1)), x0=x0, Lf=R(10), single_sweep=False)
     assert it_off.engine == "generic"
+    # more rows than the sweep kernel keeps in registers: the iteration starts composed, finds the kernel unsupported and
+    # continues on the generic engine with the same answer as the restatement
+    rng = np.random.default_rng(4)
+    m, n = 40000, 6
+    At = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+    bt = rng.standard_normal(m).astype(dtype)
+    it_tall = pa.FastForwardBackwardIteration(f=pa.Composed(pa.LogisticLoss(bt), At), g=pa.NormL1(R(0.01)), x0=np.zeros(n, dtype), Lf=R(1))
+    it_ora = o.FastForwardBackwardIteration(f=o.Composed(o.LogisticLoss(bt), At), g=o.NormL1(R(0.01)), x0=np.zeros(n, dtype), Lf=R(1))
+    for sd, so in itertools.islice(zip(it_tall, it_ora), 5):
+        assert np.max(np.abs(sd.z.numpy() - so.z)) <= (2e-4 if dtype == np.float32 else 1e-10)
+    assert it_tall.engine == "generic"
