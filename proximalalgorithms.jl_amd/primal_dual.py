@@ -148,6 +148,10 @@ class AFBAIteration:
     def init_state(self):
         s = AFBAState(self.x0.copy(), self.y0.copy())
         s.hc, s.lc = convex_conjugate(self.h), convex_conjugate(self.l)
+        # gradients of a Zero term stay zero: written once here instead of once per iteration
+        s.f_zero, s.lc_zero = isinstance(self.f, Zero), isinstance(s.lc, Zero)
+        s.gradf.fill_(0.0)
+        s.gradl.fill_(0.0)
         return s
 
     def body(self, s):
@@ -155,12 +159,14 @@ class AFBAIteration:
         R = self.x0.dtype.type
         g1, g2 = self.gamma
         theta, mu, lam = self.theta, self.mu, self.lam
-        value_and_gradient_(s.gradf, self.f, s.x)  # :180
+        if not s.f_zero:
+            value_and_gradient_(s.gradf, self.f, s.x)  # :180
         self._mul_adjoint(s.temp_x, s.y)  # :182-185   x - gamma1 (L'y + grad f)
         s.temp_x.axpby_(1.0, s.temp_x, 1.0, s.gradf)
         s.temp_x.axpby_(-float(g1), s.temp_x, 1.0, s.x)
         prox_(s.xbar, self.g, s.temp_x, g1)  # :186
-        value_and_gradient_(s.gradl, s.lc, s.y)  # :187
+        if not s.lc_zero:
+            value_and_gradient_(s.gradl, s.lc, s.y)  # :187
         s.temp_x.axpby_(float(theta), s.xbar, float(R(1) - theta), s.x)  # :189
         self._mul(s.temp_y, s.temp_x)  # :190-193   y + gamma2 (L t - grad l*)
         s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)
@@ -168,14 +174,25 @@ class AFBAIteration:
         prox_(s.ybar, s.hc, s.temp_y, g2)  # :194
         s.FPR_x.axpby_(1.0, s.xbar, -1.0, s.x)  # :196-197
         s.FPR_y.axpby_(1.0, s.ybar, -1.0, s.y)
-        s.temp_y.axpby_(float(R(mu * (R(2) - theta) * g1)), s.FPR_y)  # :199-201
-        self._mul_adjoint(s.temp_x, s.temp_y)
-        s.temp_x.axpby_(1.0, s.FPR_x, -1.0, s.temp_x)
-        s.x.axpby_(1.0, s.x, float(lam), s.temp_x)
-        s.temp_x.axpby_(float(R((R(1) - mu) * (R(2) - theta) * g2)), s.FPR_x)  # :203-205
-        self._mul(s.temp_y, s.temp_x)
-        s.temp_y.axpby_(1.0, s.FPR_y, 1.0, s.temp_y)
-        s.y.axpby_(1.0, s.y, float(lam), s.temp_y)
+        # :199-205.  The correction terms L'(c1 FPR_y) and L(c2 FPR_x) carry the factors mu (2 - theta) gamma1 and
+        # (1 - mu)(2 - theta) gamma2: exactly zero for Vu-Condat / Chambolle-Pock (theta = 2) and, one each, for mu = 0 or 1 --
+        # the product with L is skipped then (the reference multiplies a zero vector): 2 or 3 reads of L instead of 4
+        c1 = R(mu * (R(2) - theta) * g1)
+        if c1 != 0:
+            s.temp_y.axpby_(float(c1), s.FPR_y)
+            self._mul_adjoint(s.temp_x, s.temp_y)
+            s.temp_x.axpby_(1.0, s.FPR_x, -1.0, s.temp_x)
+            s.x.axpby_(1.0, s.x, float(lam), s.temp_x)
+        else:
+            s.x.axpby_(1.0, s.x, float(lam), s.FPR_x)
+        c2 = R((R(1) - mu) * (R(2) - theta) * g2)
+        if c2 != 0:
+            s.temp_x.axpby_(float(c2), s.FPR_x)
+            self._mul(s.temp_y, s.temp_x)
+            s.temp_y.axpby_(1.0, s.FPR_y, 1.0, s.temp_y)
+            s.y.axpby_(1.0, s.y, float(lam), s.temp_y)
+        else:
+            s.y.axpby_(1.0, s.y, float(lam), s.FPR_y)
 
     def __iter__(self):
         s = self.init_state()
