@@ -102,7 +102,7 @@ class AFBAIteration:
     identity (0 * I when h is Zero, :87-91)."""
 
     def __init__(self, *, x0, y0, f=None, g=None, h=None, l=None, L=None, beta_f=None, beta_l=None, theta=1.0, mu=1.0,
-                 lam=1.0, gamma=None, opnorm_L=None, **kw):
+                 lam=1.0, gamma=None, opnorm_L=None, single_sweep=True, **kw):
         if "lambda_" in kw:
             lam = kw.pop("lambda_")
         if kw:
@@ -132,16 +132,27 @@ class AFBAIteration:
                 opnorm_L = 0.0 if self._zero_L else (1.0 if L is None else _opnorm(L))
             gamma = AFBA_default_stepsizes(opnorm_L, self.h, theta, mu, beta_f, beta_l, R)
         self.gamma = (R(gamma[0]), R(gamma[1]))
+        # Vu-Condat / Chambolle-Pock with a device matrix L and an in-kernel prox kind for g: ONE read of L per iteration
+        # (see _body_single_sweep)
+        self.single_sweep = bool(single_sweep) and self.theta == 2 and self.lam == 1 and isinstance(self.L, HIPMatrix) \
+            and hasattr(self.g, "g_kind") and not (hasattr(self.g, "_scalar") and not self.g._scalar)
+        self.counters = {"L_passes": 0}
 
     def _mul(self, out, x):
         if self._zero_L:
             return out.fill_(0.0)
-        return out.copy_from(x) if self.L is None else self.L.mul(x, out)
+        if self.L is None:
+            return out.copy_from(x)
+        self.counters["L_passes"] += 1
+        return self.L.mul(x, out)
 
     def _mul_adjoint(self, out, y):
         if self._zero_L:
             return out.fill_(0.0)
-        return out.copy_from(y) if self.L is None else self.L.mul_adjoint(y, out)
+        if self.L is None:
+            return out.copy_from(y)
+        self.counters["L_passes"] += 1
+        return self.L.mul_adjoint(y, out)
 
     graph_safe = True  # constant step sizes, no buffer swaps: the body can be recorded once and replayed (hipGraph)
 
@@ -154,8 +165,54 @@ class AFBAIteration:
         s.gradl.fill_(0.0)
         return s
 
+    def _body_single_sweep(self, s):
+        """theta = 2, lambda = 1 (Vu-Condat / Chambolle-Pock), L a device matrix: one read of L per iteration.
+        The sweep pg_mat_fused_tn takes the dual iterate y as its m-vector and returns  L'y,  xbar = prox_{g1 g}(x - g1
+        (L'y + grad f))  (the smooth term enters by shifting the sweep's x) and  L xbar;  with lambda = 1 the next primal
+        iterate IS xbar, so  L (2 xbar - x) = 2 L xbar - L x  needs no product: L x is the previous sweep's L xbar.  The
+        two correction products of primal_dual.jl:199-205 carry the factor (2 - theta) = 0.  Returns False (nothing
+        written) when the sweep kernel does not cover this matrix."""
+        from ._lib import ProxGradError
+
+        g1, g2 = self.gamma
+        if getattr(s, "Lx", None) is None:  # first use: workspaces and L x0
+            s.Lx, s.Lxbar = s.y.similar(), s.y.similar()
+            s.sw_y, s.sw_res, s.sw_x = s.x.similar(), s.x.similar(), s.x.similar()
+            s.Lx_valid = False
+        if not s.f_zero:
+            value_and_gradient_(s.gradf, self.f, s.x)  # :180
+            xs = s.sw_x.axpby_(1.0, s.x, -float(g1), s.gradf)
+        else:
+            xs = s.x
+        try:
+            self.L.fused_tn(s.y, xs, g1, self.g, s.temp_x, s.sw_y, s.xbar, s.sw_res, s.Lxbar)  # :182-186 (+ L xbar)
+        except ProxGradError as e:
+            if "error -4" in str(e):
+                return False
+            raise
+        self.counters["L_passes"] += 1
+        if not s.Lx_valid:
+            self._mul(s.Lx, s.x)  # once: L x0
+            s.Lx_valid = True
+        if not s.lc_zero:
+            value_and_gradient_(s.gradl, s.lc, s.y)  # :187
+        s.temp_y.axpby_(2.0, s.Lxbar, -1.0, s.Lx)  # :189-190  L (2 xbar - x)
+        s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)  # :191
+        s.temp_y.axpby_(float(g2), s.temp_y, 1.0, s.y)  # :192-193
+        prox_(s.ybar, s.hc, s.temp_y, g2)  # :194
+        s.FPR_x.axpby_(1.0, s.xbar, -1.0, s.x)  # :196-197
+        s.FPR_y.axpby_(1.0, s.ybar, -1.0, s.y)
+        s.x.axpby_(1.0, s.x, 1.0, s.FPR_x)  # :201 with a zero correction, lambda = 1
+        s.Lx.copy_from(s.Lxbar)  # L x of the new x (= xbar up to the rounding of x + (xbar - x))
+        s.y.axpby_(1.0, s.y, 1.0, s.FPR_y)  # :205
+        return True
+
     def body(self, s):
         """one Base.iterate (primal_dual.jl:176-209), allocation-free"""
+        if self.single_sweep:
+            if self._body_single_sweep(s):
+                return
+            self.single_sweep = False  # outside the sweep kernel's range: the plain statement order from now on
         R = self.x0.dtype.type
         g1, g2 = self.gamma
         theta, mu, lam = self.theta, self.mu, self.lam

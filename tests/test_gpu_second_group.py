@@ -649,3 +649,45 @@ def test_fuzz_second_group_against_oracle(pa):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert not mod.run(150, first_seed=5000)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vu_condat_single_sweep_one_read_of_L_per_iteration(pa, dtype):
+    """theta = 2: the sweep gives L'y, the primal prox and L xbar; L (2 xbar - x) follows by linearity -> ONE read of L
+    per iteration (four products in the reference's statement order), same iterates."""
+    rng = np.random.default_rng(41)
+    m, n = 90, 260
+    A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+    b = rng.standard_normal(m).astype(dtype)
+    R = np.dtype(dtype).type
+    lam = R(0.1) * R(np.max(np.abs(A.T @ b)))
+    x0, y0 = (0.1 * rng.standard_normal(n)).astype(dtype), (0.1 * rng.standard_normal(m)).astype(dtype)
+    Ad = pa.HIPMatrix.from_numpy(A)
+    cases = {
+        "chambolle_pock": (dict(g=pa.NormL1(lam), h=pa.SquaredDistance(b)), dict(g=o.NormL1(lam), h=ox.SqrDistance(b))),
+        "vu_condat_f": (dict(f=pa.SqrNormL2(R(0.5)), beta_f=0.5, g=pa.IndBox(-0.3, 0.4), h=pa.SquaredDistance(b)),
+                        dict(f=ox.SqrNormL2(R(0.5)), beta_f=0.5, g=o.IndBox(-0.3, 0.4), h=ox.SqrDistance(b))),
+        "vu_condat_l": (dict(f=pa.SqrNormL2(R(0.5)), beta_f=0.5, g=pa.NormL1(lam), h=pa.NormL1(R(0.2)), l=pa.SqrNormL2(R(2.0)), beta_l=0.5),
+                        dict(f=ox.SqrNormL2(R(0.5)), beta_f=0.5, g=o.NormL1(lam), h=o.NormL1(R(0.2)), l=ox.SqrNormL2(R(2.0)), beta_l=0.5)),
+    }
+    K = 30
+    for name, (kd, ko) in cases.items():
+        one = pa.AFBAIteration(x0=x0, y0=y0, L=Ad, theta=2, **kd)
+        four = pa.AFBAIteration(x0=x0, y0=y0, L=Ad, theta=2, single_sweep=False, **kd)
+        ora = ox.AFBAIteration(x0=x0, y0=y0, L=A, theta=2, **ko)
+        assert one.single_sweep and not four.single_sweep
+        for k, (s1, s4, so) in enumerate(zip(one, four, ora)):
+            if k >= K:
+                break
+            for fld in ("x", "y", "xbar", "ybar"):
+                ref = getattr(so, fld)
+                tol = (2e-4 if dtype == np.float32 else 1e-10) * max(1.0, float(np.max(np.abs(ref))))
+                assert np.max(np.abs(getattr(s1, fld).numpy() - ref)) <= tol, (name, k, fld)
+                assert np.max(np.abs(getattr(s1, fld).numpy() - getattr(s4, fld).numpy())) <= tol, (name, k, fld)
+        assert one.counters["L_passes"] == K + 2, name  # one sweep per iteration + L x0 (the (K+1)-th body ran in zip)
+        assert four.counters["L_passes"] == 2 * (K + 1), name  # L'y and L(2 xbar - x); the zero-factor products are skipped
+    # the driver, with and without the hipGraph, gives the same answer
+    tol = R(1e-4 if dtype == np.float32 else 1e-8)
+    (xa, ya), ita = pa.ChambollePock(tol=tol)(x0=x0, y0=y0, g=pa.NormL1(lam), h=pa.SquaredDistance(b), L=Ad)
+    (xo, yo), ito = ox.chambolle_pock(tol=tol, x0=x0, y0=y0, g=o.NormL1(lam), h=ox.SqrDistance(b), L=A)
+    assert abs(ita - ito) <= (max(3, ito // 10) if dtype == np.float32 else 1) and close(xa, xo, dtype, 5)
