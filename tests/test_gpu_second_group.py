@@ -560,6 +560,7 @@ def test_graph_replay_matches_plain_stepping(pa, stream_ctx, dtype):
         "afba": lambda: pa.AFBAIteration(x0=x0, y0=y0, f=pa.SqrNormL2(R(0.5)), beta_f=0.5, g=pa.NormL1(lam),
                                          h=pa.SquaredDistance(b), L=A),
         "afba_ls": lambda: pa.AFBAIteration(x0=x0, y0=np.zeros(n, dtype), f=pa.LeastSquares(A, b), g=pa.NormL1(lam), beta_f=Lf),
+        "chambolle_pock_single_sweep": lambda: pa.ChambollePockIteration(x0=x0, y0=y0, g=pa.NormL1(lam), h=pa.SquaredDistance(b), L=A),
         "davis_yin": lambda: pa.DavisYinIteration(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), h=pa.IndBox(-0.5, 0.5), Lf=Lf),
         "dr": lambda: pa.DouglasRachfordIteration(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), gamma=R(1) / Lf),
     }
