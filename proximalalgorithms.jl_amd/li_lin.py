@@ -20,7 +20,7 @@ class LiLinIteration:
     li_lin.jl:108 reads an unbound name ``x`` in the monitor branch (UndefVarError in the reference); this mirror
     evaluates the gradient at ``state.x`` as Algorithm 2 prescribes and counts the visits in ``monitor_branch_taken``."""
 
-    def __init__(self, *, x0, f=None, g=None, Lf=None, gamma=None, adaptive=False, delta=1e-3, eta=0.8):
+    def __init__(self, *, x0, f=None, g=None, Lf=None, gamma=None, adaptive=False, delta=1e-3, eta=0.8, single_sweep=True):
         self.x0 = as_hipvector(x0)
         R = self.x0.dtype.type
         self.f = f if f is not None else Zero()
@@ -32,8 +32,98 @@ class LiLinIteration:
         self.gamma = R(gamma)
         self.adaptive, self.delta, self.eta = bool(adaptive), R(delta), R(eta)
         self.monitor_branch_taken = 0
+        self.counters = {"a_passes": 0}
+        # f = LeastSquares(A, b) or Composed(loss, A) on a device matrix, g an in-kernel prox kind: one read of A per
+        # iteration (two when the monitor branch runs), see _iter_single_sweep
+        self._loss_A = _loss_and_matrix(self.f) if single_sweep else None
+        if self._loss_A is not None and not (hasattr(self.g, "g_kind") and not (hasattr(self.g, "_scalar") and not self.g._scalar)):
+            self._loss_A = None
 
     def __iter__(self):
+        if self._loss_A is not None:
+            from ._lib import ProxGradError
+
+            gen = self._iter_single_sweep(*self._loss_A)
+            try:
+                first = next(gen)
+            except ProxGradError as e:
+                if "error -4" not in str(e):  # anything but "shape outside the sweep kernel's range"
+                    raise
+                self._loss_A = None
+                return self._iter_plain()
+
+            def chain():
+                yield first
+                yield from gen
+
+            return chain()
+        return self._iter_plain()
+
+    def _iter_single_sweep(self, loss, A):
+        """The same iteration with every product with A folded into the single sweep (pg_mat_fused_tn): the sweep at y gives
+        A' grad loss(A y), the prox and A z; f(z) = loss(A z) is an m-vector kernel; A y of the next extrapolated point
+        follows by linearity from A z, A x (and A v).  The monitor branch costs one more sweep (at x)."""
+        R = self.x0.dtype.type
+        s = LiLinState()
+        s.y = self.x0.copy()
+        s.x = self.x0.copy()
+        s.gamma = self.gamma
+        n_like, dt, ctx = s.y, s.y.dtype, s.y.ctx
+        s.grad_f_y, s.y_forward, s.z, s.res = (n_like.similar() for _ in range(4))
+        v, xf, gtmp, rtmp = (n_like.similar() for _ in range(4))
+        Ay = A.mul(s.y)
+        self.counters["a_passes"] += 1
+        Ax = Ay.similar().copy_from(Ay)
+        Az, Av, u = Ay.similar(), Ay.similar(), Ay.similar()
+
+        def sweep_at_y():
+            s.f_y = R(loss.value_and_gradient(Ay, out=u)[0])
+            sc = A.fused_tn(u, s.y, s.gamma, self.g, s.grad_f_y, s.y_forward, s.z, s.res, Az)
+            self.counters["a_passes"] += 1
+            s.g_z, s.res_inf, s.res_sq = sc[0], sc[1], sc[3]
+
+        sweep_at_y()
+        Fy = R(s.f_y + self.g(s.y))
+        if not np.isfinite(Fy):
+            raise AssertionError("initial point must be feasible")  # :75
+        s.theta, s.F_average, s.q = R(1), Fy, R(1)
+        yield s
+        while True:
+            Fz = R(loss(Az) + s.g_z)  # :103
+            theta1 = R((R(1) + R(np.sqrt(R(R(1) + R(4) * s.theta * s.theta)))) / R(2))  # :104
+            if Fz <= s.F_average - self.delta * s.res_sq:  # :106
+                case = 1
+            else:
+                self.monitor_branch_taken += 1
+                loss.value_and_gradient(Ax, out=u)
+                sc = A.fused_tn(u, s.x, s.gamma, self.g, gtmp, xf, v, rtmp, Av)  # :108-110 and A v
+                self.counters["a_passes"] += 1
+                Fv = R(loss(Av) + sc[0])
+                case = 1 if Fz <= Fv else 2
+            if case == 1:
+                c = R((s.theta - R(1)) / theta1)
+                s.y.axpby_(R(R(1) + c), s.z, -float(c), s.x)  # :116
+                Ay.axpby_(R(R(1) + c), Az, -float(c), Ax)
+                s.x, s.z = s.z, s.x
+                Ax, Az = Az, Ax
+                Fx = Fz
+            else:
+                c1, c2 = R(s.theta / theta1), R((s.theta - R(1)) / theta1)
+                s.y.axpby_(R(R(1) + c1), s.z, R(c2 - c1), v)  # :120-122
+                s.y.axpby_(1.0, s.y, -float(c2), s.x)
+                Ay.axpby_(R(R(1) + c1), Az, R(c2 - c1), Av)
+                Ay.axpby_(1.0, Ay, -float(c2), Ax)
+                s.x.copy_from(v)
+                Ax.copy_from(Av)
+                Fx = Fv
+            sweep_at_y()  # :128-135
+            s.theta = theta1
+            q1 = R(self.eta * s.q + R(1))  # :139-141
+            s.F_average = R((self.eta * s.q * s.F_average + Fx) / q1)
+            s.q = q1
+            yield s
+
+    def _iter_plain(self):
         R = self.x0.dtype.type
         s = LiLinState()
         s.y = self.x0.copy()
@@ -86,10 +176,23 @@ class LiLinIteration:
             yield s
 
 
+def _loss_and_matrix(f):
+    """(loss on m-vectors, device matrix) when f(x) = loss(A x) with A a HIPMatrix, else None"""
+    from .device import HIPMatrix
+    from .operators import Composed, LeastSquares, SquaredDistance
+
+    if isinstance(f, Composed) and isinstance(f.A, HIPMatrix):
+        return f.f, f.A
+    if isinstance(f, LeastSquares) and f.comm is None:
+        return SquaredDistance(f.b, lam=f.lam), f.A
+    return None
+
+
 def default_stopping_criterion(tol, iteration, state):
     """norm(state.res, Inf) / state.gamma <= tol  (li_lin.jl:146-147)"""
     R = state.res.dtype.type
-    return state.res.norm_inf() / state.gamma <= R(tol)
+    res_inf = state.res_inf if getattr(state, "res_inf", None) is not None else state.res.norm_inf()
+    return R(res_inf) / state.gamma <= R(tol)
 
 
 def default_solution(iteration, state):

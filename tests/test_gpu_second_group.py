@@ -227,6 +227,13 @@ def test_lilin_monitor_branch_matches_oracle(pa, dtype):
         sd, so = next(dev), next(ora)
         assert close(sd.z.numpy(), so.z, dtype, 5) and close(sd.y.numpy(), so.y, dtype, 5), k
     assert di.monitor_branch_taken == oi.monitor_branch_taken > 0
+    # f = LeastSquares on a device matrix: one read of A per iteration, one more whenever the monitor branch runs
+    assert di.counters["a_passes"] == 2 + 24 + di.monitor_branch_taken
+    dp = pa.LiLinIteration(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), single_sweep=False, **kw)
+    for k, (s1, s2) in enumerate(zip(pa.LiLinIteration(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), **kw), dp)):
+        if k >= 25:
+            break
+        assert close(s1.z.numpy(), s2.z.numpy(), dtype, 5), k
 
 
 # ------------------------------------------------------------------------------------------------
