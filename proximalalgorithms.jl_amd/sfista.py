@@ -32,14 +32,87 @@ class SFISTAState:
 class SFISTAIteration:
     """sfista.jl:37-47 (x0, f, g, Lf, mf = 0) and Base.iterate :65-92"""
 
-    def __init__(self, *, x0, f=None, g=None, Lf, mf=0.0):
+    REFRESH = 64  # single sweep: A x is carried by its linear recurrence and recomputed exactly every REFRESH iterations
+
+    def __init__(self, *, x0, f=None, g=None, Lf, mf=0.0, single_sweep=True):
         self.x0 = as_hipvector(x0)
         R = self.x0.dtype.type
         self.f = f if f is not None else Zero()
         self.g = g if g is not None else Zero()
         self.Lf, self.mf = R(Lf), R(mf)
+        self.counters = {"a_passes": 0}
+        # f = LeastSquares(A, b) / Composed(loss, A) on a device matrix, g an in-kernel prox kind: the gradient at xt, the
+        # prox and A y in ONE read of A (+ one for the default stop rule's gradient at y): 2 reads per iteration, not 4
+        from .li_lin import _loss_and_matrix
+
+        self._loss_A = _loss_and_matrix(self.f) if single_sweep else None
+        if self._loss_A is not None and not (hasattr(self.g, "g_kind") and not (hasattr(self.g, "_scalar") and not self.g._scalar)):
+            self._loss_A = None
 
     def __iter__(self):
+        if self._loss_A is not None:
+            from ._lib import ProxGradError
+
+            gen = self._iter_single_sweep(*self._loss_A)
+            try:
+                first = next(gen)
+            except ProxGradError as e:
+                if "error -4" not in str(e):  # anything but "shape outside the sweep kernel's range"
+                    raise
+                self._loss_A = None
+                return self._iter_plain()
+
+            def chain():
+                yield first
+                yield from gen
+
+            return chain()
+        return self._iter_plain()
+
+    def _iter_single_sweep(self, loss, A):
+        """sfista.jl:65-92 with the products folded into the sweep pg_mat_fused_tn: at xt it returns A' grad loss(A xt), the
+        prox point y and A y; A xt and A x follow from the (linear) recurrences of xt and x -- A y enters fresh from every
+        sweep, A x is recomputed exactly every REFRESH iterations so rounding cannot accumulate."""
+        R = self.x0.dtype.type
+        s = SFISTAState(R(1) / self.Lf, self.x0.copy())
+        mf = self.mf
+        AyPrev = A.mul(s.yPrev)
+        self.counters["a_passes"] += 1
+        AxPrev = AyPrev.similar().copy_from(AyPrev)
+        Ax, Axt, u = AyPrev.similar(), AyPrev.similar(), AyPrev.similar()
+        s.Ay, s.u_tmp, s.loss_A = AyPrev.similar(), AyPrev.similar(), (loss, A)
+        fwd, rtmp, s.g_tmp = s.x.similar(), s.x.similar(), s.x.similar()
+        k = 0
+        while True:
+            s.tau = R(s.lam * (R(1) + mf * s.APrev))  # :70
+            s.a = R((s.tau + R(np.sqrt(R(s.tau * s.tau + R(4) * s.tau * s.APrev)))) / R(2))  # :71
+            s.A = R(s.APrev + s.a)  # :72
+            cy, cx = R(s.APrev / s.A), R(s.a / s.A)
+            s.xt.axpby_(cy, s.yPrev, cx, s.xPrev)  # :73
+            Axt.axpby_(cy, AyPrev, cx, AxPrev)
+            loss.value_and_gradient(Axt, out=u)  # :74 (grad loss at A xt)
+            lam2 = R(s.lam / (R(1) + s.lam * mf))  # :76
+            A.fused_tn(u, s.xt, lam2, self.g, s.gradf_xt, fwd, s.y, rtmp, s.Ay)  # :74-78 and A y
+            self.counters["a_passes"] += 1
+            c = R(s.a / (R(1) + s.A * mf))
+            c0, c1, c2 = R(R(1) - c * mf), R(c * (R(1) / s.lam + mf)), R(c / s.lam)
+            s.x.axpby_(c0, s.xPrev, c1, s.y)  # :79-82
+            s.x.axpby_(1.0, s.x, -float(c2), s.xt)
+            k += 1
+            if k % self.REFRESH == 0:
+                A.mul(s.x, Ax)
+                self.counters["a_passes"] += 1
+            else:
+                Ax.axpby_(c0, AxPrev, c1, s.Ay)
+                Ax.axpby_(1.0, Ax, -float(c2), Axt)
+            s.yPrev.copy_from(s.y)  # :84-86
+            s.xPrev.copy_from(s.x)
+            AyPrev.copy_from(s.Ay)
+            AxPrev.copy_from(Ax)
+            s.APrev = s.A
+            yield s
+
+    def _iter_plain(self):
         R = self.x0.dtype.type
         s = SFISTAState(R(1) / self.Lf, self.x0.copy())
         mf = self.mf
@@ -70,7 +143,13 @@ def check_sc(state, iteration, tol, termination_type=""):
         raise AttributeError("SFISTAIteration has no field y0 (sfista.jl:98-100)")
     R = state.y.dtype.type
     lam2 = R(state.lam / (R(1) + state.lam * iteration.mf))
-    _, gy = value_and_gradient(iteration.f, state.y)
+    if getattr(state, "Ay", None) is not None:  # single sweep: A y is known, the gradient at y costs one read of A
+        loss, A = state.loss_A
+        loss.value_and_gradient(state.Ay, out=state.u_tmp)
+        gy = A.mul_adjoint(state.u_tmp, state.g_tmp)
+        iteration.counters["a_passes"] += 1
+    else:
+        _, gy = value_and_gradient(iteration.f, state.y)
     r = state.tmp
     r.axpby_(1.0, gy, -1.0, state.gradf_xt)  # grad f(y) - grad f(xt)
     r.axpby_(1.0, r, float(R(1) / lam2), state.xt)

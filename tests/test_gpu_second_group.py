@@ -699,3 +699,34 @@ def test_vu_condat_single_sweep_one_read_of_L_per_iteration(pa, dtype):
     (xa, ya), ita = pa.ChambollePock(tol=tol)(x0=x0, y0=y0, g=pa.NormL1(lam), h=pa.SquaredDistance(b), L=Ad)
     (xo, yo), ito = ox.chambolle_pock(tol=tol, x0=x0, y0=y0, g=o.NormL1(lam), h=ox.SqrDistance(b), L=A)
     assert abs(ita - ito) <= (max(3, ito // 10) if dtype == np.float32 else 1) and close(xa, xo, dtype, 5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sfista_single_sweep_pass_counts_and_refresh(pa, dtype):
+    """f = LeastSquares on a device matrix: 1 read of A per iteration + 1 for the default stop rule (4 in the reference's
+    statement order); A x rides its linear recurrence and is recomputed every 64 iterations -- 200 iterations stay on the
+    plain path's iterates."""
+    rng = np.random.default_rng(8)
+    m, n = 150, 400
+    A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+    b = rng.standard_normal(m).astype(dtype)
+    R = np.dtype(dtype).type
+    lam = R(0.05) * R(np.max(np.abs(A.T @ b)))
+    Lf = R(np.linalg.norm(A, 2) ** 2)
+    x0 = np.zeros(n, dtype)
+    Ad = pa.HIPMatrix.from_numpy(A)
+    one = pa.SFISTAIteration(x0=x0, f=pa.LeastSquares(Ad, b), g=pa.NormL1(lam), Lf=Lf, mf=R(0.01))
+    two = pa.SFISTAIteration(x0=x0, f=pa.LeastSquares(Ad, b), g=pa.NormL1(lam), Lf=Lf, mf=R(0.01), single_sweep=False)
+    K = 200
+    for k, (s1, s2) in enumerate(zip(one, two)):
+        if k >= K:
+            break
+        tol = (5e-4 if dtype == np.float32 else 1e-9) * max(1.0, float(np.max(np.abs(s2.y.numpy()))))
+        assert np.max(np.abs(s1.y.numpy() - s2.y.numpy())) <= tol, k
+    assert one.counters["a_passes"] == 1 + (K + 1) + (K + 1) // 64
+    from proximalalgorithms.jl_amd.sfista import check_sc
+
+    r1, _ = check_sc(s1, one, 1e-3)
+    r2, _ = check_sc(s2, two, 1e-3)
+    assert float(r1) == pytest.approx(float(r2), rel=1e-2 if dtype == np.float32 else 1e-6, abs=1e-6)
+    assert one.counters["a_passes"] == 1 + (K + 1) + (K + 1) // 64 + 1
