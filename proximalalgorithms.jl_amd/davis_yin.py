@@ -40,11 +40,11 @@ class DavisYinIteration:
     def body(self, s):
         """one Base.iterate (davis_yin.jl:73-83), allocation-free"""
         gamma = self.gamma
-        prox_(s.xg, self.g, s.z, gamma)  # :74
+        prox_(s.xg, self.g, s.z, gamma, want_value=False)  # :74
         value_and_gradient_(s.grad_f_xg, self.f, s.xg)  # :75-76
         s.z_half.axpby_(2.0, s.xg, -1.0, s.z)  # :77  2 xg - z - gamma grad
         s.z_half.axpby_(1.0, s.z_half, -float(gamma), s.grad_f_xg)
-        prox_(s.xh, self.h, s.z_half, gamma)  # :78
+        prox_(s.xh, self.h, s.z_half, gamma, want_value=False)  # :78
         s.res.axpby_(1.0, s.xh, -1.0, s.xg)  # :79
         s.z.axpby_(1.0, s.z, float(self.lam), s.res)  # :80
 

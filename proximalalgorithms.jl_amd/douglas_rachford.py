@@ -93,9 +93,9 @@ class DouglasRachfordIteration:
 
     def body(self, s):
         """generic engine: the five statements of douglas_rachford.jl:58-62 as library calls (allocation-free)"""
-        s.f_y = prox_(s.y, self.f, s.x, self.gamma)  # :58
+        prox_(s.y, self.f, s.x, self.gamma, want_value=False)  # :58 (the reference discards the values)
         s.r.axpby_(2.0, s.y, -1.0, s.x)  # :59
-        s.g_z = prox_(s.z, self.g, s.r, self.gamma)  # :60
+        prox_(s.z, self.g, s.r, self.gamma, want_value=False)  # :60
         s.res.axpby_(1.0, s.y, -1.0, s.z)  # :61
         s.x.axpby_(1.0, s.x, -1.0, s.res)  # :62
         s.res_inf = None

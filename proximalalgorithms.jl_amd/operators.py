@@ -99,7 +99,7 @@ class LeastSquares:
         R = self.dtype.type
         return tuple(R(v) for v in sc)
 
-    def prox_(self, y, x, gamma):
+    def prox_(self, y, x, gamma, want_value=True):
         """ProximalCore.prox!(y, f, x, gamma) -> f(y): y = argmin lam/2 ||A z - b||^2 + ||z - x||^2 / (2 gamma)
         = (lam A'A + I/gamma) \\ (lam A'b + x/gamma)  (ProximalOperators.LeastSquares, direct solver).
 
@@ -135,7 +135,7 @@ class LeastSquares:
             cache["S"].mul(cache["t"], cache["t2"])
             self.A.mul_adjoint(cache["t2"], cache["w"])
             y.axpby_(gamma, q, -gamma * gamma * self.lam, cache["w"])
-        return self(y)
+        return self(y) if want_value else None
 
     def residual(self):
         """A x - b of the last evaluation (view of the library-owned m-vector)."""
@@ -158,7 +158,10 @@ class NormL1:
     def g_params(self):
         return self.lam, 0.0
 
-    def prox_(self, y, x, gamma):
+    def prox_(self, y, x, gamma, want_value=True):
+        if not want_value:  # no reduction read-back: the call stays asynchronous
+            call("pg_prox_norml1", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, self.lam, float(gamma), None)
+            return None
         out = C.c_double()
         call("pg_prox_norml1", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, self.lam, float(gamma), C.byref(out))
         return x.dtype.type(out.value)
@@ -229,8 +232,11 @@ class SeparableQuadratic:
         return (None if self._d_scalar else self.d.vp, self.d if self._d_scalar else 0.0,
                 None if self._q_scalar else self.q.vp, self.q if self._q_scalar else 0.0)
 
-    def prox_(self, y, x, gamma):
+    def prox_(self, y, x, gamma, want_value=True):
         dv, d, qv, q = self.c_params()
+        if not want_value:
+            call("pg_prox_sepquad", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, dv, d, qv, q, float(gamma), None)
+            return None
         out = C.c_double()
         call("pg_prox_sepquad", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, dv, d, qv, q, float(gamma), C.byref(out))
         return x.dtype.type(out.value)
@@ -281,12 +287,12 @@ class SquaredDistance(_Loss):
             v = u.dtype.type(self.lam) * v
         return v, g
 
-    def prox_(self, y, x, gamma):
+    def prox_(self, y, x, gamma, want_value=True):
         """Translate(SqrNormL2(lam), -b) (test_lasso_small.jl:38, test_elasticnet.jl:24):
         prox = (x + lam gamma b) / (1 + lam gamma); returns f(y)"""
         lg = self.lam * float(gamma)
         y.axpby_(1.0 / (1.0 + lg), x, lg / (1.0 + lg), self.b)
-        return self(y)
+        return self(y) if want_value else None
 
 
 class SqrNormL2:
@@ -305,9 +311,9 @@ class SqrNormL2:
         R = x.dtype.type
         return R(R(self.lam) / R(2) * x.norm() ** 2)
 
-    def prox_(self, y, x, gamma):
+    def prox_(self, y, x, gamma, want_value=True):
         y.axpby_(1.0 / (1.0 + self.lam * float(gamma)), x)
-        return self(y)
+        return self(y) if want_value else None
 
     def value_and_gradient(self, x, out=None):
         g = out if out is not None else x.similar()
@@ -354,9 +360,9 @@ class Linear:
         g.copy_from(self.c)
         return self.c.dot(x), g
 
-    def prox_(self, y, x, gamma):
+    def prox_(self, y, x, gamma, want_value=True):
         y.axpby_(1.0, x, -float(gamma), self.c)
-        return self.c.dot(y)
+        return self.c.dot(y) if want_value else None
 
     def __call__(self, x):
         return self.c.dot(x)
@@ -447,15 +453,15 @@ class Conjugate:
         self.f = f
         self._p = self._xs = None
 
-    def prox_(self, y, x, gamma):
+    def prox_(self, y, x, gamma, want_value=True):
         R = x.dtype.type
         if self._p is None or self._p.n != x.n:
             self._p, self._xs = x.similar(), x.similar()
         gamma = float(gamma)
         self._xs.axpby_(1.0 / gamma, x)
-        fp = self.f.prox_(self._p, self._xs, 1.0 / gamma)
+        fp = prox_(self._p, self.f, self._xs, 1.0 / gamma, want_value=want_value)
         y.axpby_(1.0, x, -gamma, self._p)
-        return R(y.dot(self._p) - fp)
+        return R(y.dot(self._p) - fp) if want_value else None
 
 
 def convex_conjugate(f):
@@ -549,8 +555,16 @@ def gradient_(y, f, x):
     return fx
 
 
-def prox_(y, g, x, gamma):
-    """ProximalCore.prox!(y, g, x, gamma) -> g(y)"""
+def prox_(y, g, x, gamma, want_value=True):
+    """ProximalCore.prox!(y, g, x, gamma) -> g(y).  ``want_value=False`` (callers that discard the return value, like
+    douglas_rachford.jl:58-60 or primal_dual.jl:186,194) skips the value's reduction and its host read-back where the
+    operator supports it; the returned value is then None."""
+    if not want_value:
+        fn = getattr(g.prox_, "__func__", g.prox_)
+        if "want_value" in getattr(getattr(fn, "__code__", None), "co_varnames", ()):
+            return g.prox_(y, x, gamma, want_value=False)
+        g.prox_(y, x, gamma)  # operator without the keyword: compute the value and drop it
+        return None
     return g.prox_(y, x, gamma)
 
 

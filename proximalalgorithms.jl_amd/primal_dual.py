@@ -199,7 +199,7 @@ class AFBAIteration:
         s.temp_y.axpby_(2.0, s.Lxbar, -1.0, s.Lx)  # :189-190  L (2 xbar - x)
         s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)  # :191
         s.temp_y.axpby_(float(g2), s.temp_y, 1.0, s.y)  # :192-193
-        prox_(s.ybar, s.hc, s.temp_y, g2)  # :194
+        prox_(s.ybar, s.hc, s.temp_y, g2, want_value=False)  # :194
         s.FPR_x.axpby_(1.0, s.xbar, -1.0, s.x)  # :196-197
         s.FPR_y.axpby_(1.0, s.ybar, -1.0, s.y)
         s.x.axpby_(1.0, s.x, 1.0, s.FPR_x)  # :201 with a zero correction, lambda = 1
@@ -221,14 +221,14 @@ class AFBAIteration:
         self._mul_adjoint(s.temp_x, s.y)  # :182-185   x - gamma1 (L'y + grad f)
         s.temp_x.axpby_(1.0, s.temp_x, 1.0, s.gradf)
         s.temp_x.axpby_(-float(g1), s.temp_x, 1.0, s.x)
-        prox_(s.xbar, self.g, s.temp_x, g1)  # :186
+        prox_(s.xbar, self.g, s.temp_x, g1, want_value=False)  # :186
         if not s.lc_zero:
             value_and_gradient_(s.gradl, s.lc, s.y)  # :187
         s.temp_x.axpby_(float(theta), s.xbar, float(R(1) - theta), s.x)  # :189
         self._mul(s.temp_y, s.temp_x)  # :190-193   y + gamma2 (L t - grad l*)
         s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)
         s.temp_y.axpby_(float(g2), s.temp_y, 1.0, s.y)
-        prox_(s.ybar, s.hc, s.temp_y, g2)  # :194
+        prox_(s.ybar, s.hc, s.temp_y, g2, want_value=False)  # :194
         s.FPR_x.axpby_(1.0, s.xbar, -1.0, s.x)  # :196-197
         s.FPR_y.axpby_(1.0, s.ybar, -1.0, s.y)
         # :199-205.  The correction terms L'(c1 FPR_y) and L(c2 FPR_x) carry the factors mu (2 - theta) gamma1 and

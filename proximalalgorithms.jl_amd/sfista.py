@@ -125,7 +125,7 @@ class SFISTAIteration:
             s.gradf_xt.copy_from(g)
             lam2 = R(s.lam / (R(1) + s.lam * mf))  # :76
             s.tmp.axpby_(1.0, s.xt, -float(lam2), s.gradf_xt)
-            prox_(s.y, self.g, s.tmp, lam2)  # :78
+            prox_(s.y, self.g, s.tmp, lam2, want_value=False)  # :78
             # x = xPrev + c ((y - xt) / lam + mf (y - xPrev))   (:79-82), regrouped per vector
             c = R(s.a / (R(1) + s.A * mf))
             s.x.axpby_(R(R(1) - c * mf), s.xPrev, R(c * (R(1) / s.lam + mf)), s.y)
