@@ -23,6 +23,33 @@ from ._lib import PG_G_INDBOX, PG_G_NORML1, PG_G_ZERO, call
 from .device import HIPMatrix, HIPVector, as_hipvector
 
 
+def _few_blas_threads():
+    """context manager: cap the host BLAS pool for the small setup factorisations (waking a 64-thread pool costs more
+    than a 500 x 500 Cholesky; measured 60-140 ms stalls on the GPU boxes)"""
+    try:
+        from threadpoolctl import threadpool_limits
+
+        return threadpool_limits(limits=8)
+    except Exception:  # threadpoolctl missing: run with the pool as it is
+        import contextlib
+
+        return contextlib.nullcontext()
+
+
+def _gram(A64, left):
+    """A A' (left) or A' A in float64 on the host (setup only)"""
+    with _few_blas_threads():
+        return A64 @ A64.T if left else A64.T @ A64
+
+
+def _spd_inverse(G):
+    """inverse of a symmetric positive definite matrix through its Cholesky factor (float64, host; setup only)"""
+    import scipy.linalg as sla
+
+    with _few_blas_threads():
+        return sla.cho_solve(sla.cho_factor(G, lower=True, check_finite=False), np.eye(G.shape[0]), check_finite=False)
+
+
 def is_convex(f):
     """ProximalCore.is_convex(typeof(f)) (trait; operators of this package declare it as a class attribute)"""
     return bool(getattr(f, "is_convex", False))
@@ -118,10 +145,10 @@ class LeastSquares:
             cache = {"gamma": gamma, "q": x.similar(), "c0": self.A.mul_adjoint(self.b)}
             cache["c0"].axpby_(self.lam, cache["c0"])  # lam A'b
             if m >= n:
-                M = np.linalg.inv(self.lam * (A64.T @ A64) + np.eye(n) / gamma)
+                M = _spd_inverse(self.lam * _gram(A64, False) + np.eye(n) / gamma)
                 cache["M"] = HIPMatrix.from_numpy(np.asfortranarray(M.astype(self.dtype)), self.ctx)
             else:
-                S = np.linalg.inv(np.eye(m) + gamma * self.lam * (A64 @ A64.T))
+                S = _spd_inverse(np.eye(m) + gamma * self.lam * _gram(A64, True))
                 cache["S"] = HIPMatrix.from_numpy(np.asfortranarray(S.astype(self.dtype)), self.ctx)
                 cache["t"] = HIPVector.empty(m, self.dtype, self.ctx)
                 cache["t2"] = HIPVector.empty(m, self.dtype, self.ctx)
@@ -400,7 +427,7 @@ class IndAffine:
         self.ctx = self.A.ctx
         self.b = as_hipvector(b, self.ctx)
         A64 = self.A.numpy().astype(np.float64)
-        S = np.linalg.inv(A64 @ A64.T)
+        S = _spd_inverse(_gram(A64, True))
         self._S = HIPMatrix.from_numpy(np.asfortranarray(S.astype(self.A.dtype)), self.ctx)
         self._t = HIPVector.empty(self.A.m, self.A.dtype, self.ctx)
         self._t2 = HIPVector.empty(self.A.m, self.A.dtype, self.ctx)

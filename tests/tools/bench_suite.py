@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The reference's own benchmark suite (benchmark/benchmarks.jl:30-135) on the device: for each shipped instance
 (lasso tiny 5x10, small 50x100, medium 500x1000, Float64) the eleven solver calls of the suite, timed like
-BenchmarkTools does (operators built in the setup, the solver call timed; median of ``--repeat`` runs), next to the CPU
+BenchmarkTools does (operators built in an untimed setup before every repetition, the solver call timed; median of
+``--repeat`` runs), next to the CPU
 restatement (oracle/, numpy) running the same call on this box's host cores.  Prints one JSON line per (instance,
 solver): iterations, device ms, CPU ms, objective of both answers.
 
@@ -35,7 +36,10 @@ def suite(A, b, lam):
     x0 = np.zeros(n, T)
 
     def dev(solver, kw):
-        return lambda: solver(x0=x0, **kw())
+        # (setup, call) like BenchmarkTools' `setup` / timed expression: the operators (device upload of A, b) are built
+        # outside the timed region, every repetition gets fresh ones (a cached prox factorisation is then rebuilt inside
+        # the timed call, as the reference's LeastSquares does on its first prox!)
+        return (kw, lambda built: solver(x0=x0, **built))
 
     ls = lambda: dict(f=pa.LeastSquares(A, b), g=pa.NormL1(lam))
     sq = lambda: dict(f=pa.SquaredDistance(b), A=A, g=pa.NormL1(lam))
@@ -73,10 +77,13 @@ def objective(A, b, lam, x):
 
 
 def timed(call, repeat):
+    """call: a zero-argument function, or a (setup, fn) pair -- setup() runs untimed before every repetition"""
+    setup, fn = call if isinstance(call, tuple) else (None, call)
     ts, out = [], None
     for _ in range(repeat):
+        built = setup() if setup is not None else None
         t0 = time.perf_counter()
-        out = call()
+        out = fn(built) if setup is not None else fn()
         ts.append(time.perf_counter() - t0)
     return statistics.median(ts) * 1e3, out
 
@@ -86,6 +93,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--instances", default="tiny,small,medium")
     ap.add_argument("--only", default="", help="substring filter on the solver name")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="BLAS threads for the CPU restatement's runs")
     args = ap.parse_args()
     pa.set_default_context(pa.Context.on_new_stream())  # a capturable (non-default) stream for the [graph] rows
     for inst in args.instances.split(","):
@@ -95,13 +103,19 @@ def main():
         for name, dev_call, cpu_call in suite(A, b, lam):
             if args.only and args.only not in name:
                 continue
-            dev_call()  # warm-up (code objects, workspaces)
+            dev_call[1](dev_call[0]())  # warm-up (code objects, workspaces)
             ms_dev, (xd, it_dev) = timed(dev_call, args.repeat)
             rec = {"instance": f"lasso_{inst} {A.shape[0]}x{A.shape[1]} f64", "solver": name, "iterations": int(it_dev),
                    "device_ms": round(ms_dev, 3), "device_us_per_iteration": round(1e3 * ms_dev / max(it_dev, 1), 2),
                    "objective_gap_device": objective(A, b, lam, xd) - f_star}
             if cpu_call is not None:
-                ms_cpu, (xc, it_cpu) = timed(cpu_call, max(1, args.repeat - 1))
+                # the CPU restatement with a BLAS pool sized for these matrices (64 threads on a 500 x 1000 GEMV are
+                # slower than 8: the pool's wake-ups dominate)
+                from threadpoolctl import threadpool_limits
+
+                with threadpool_limits(limits=args.cpu_threads):
+                    ms_cpu, (xc, it_cpu) = timed(cpu_call, max(1, args.repeat - 1))
+                rec["cpu_threads"] = args.cpu_threads
                 rec.update(cpu_iterations=int(it_cpu), cpu_ms=round(ms_cpu, 3),
                            objective_gap_cpu=objective(A, b, lam, xc) - f_star)
             print(json.dumps(rec), flush=True)
