@@ -26,9 +26,21 @@ from .nesterov import AdaptiveNesterovSequence
 from .operators import Composed, prox_
 
 
+def loss_and_matrix(f):
+    """(loss on m-vectors, device matrix) when f(x) = loss(A x) with A a HIPMatrix -- Composed(loss, A), or an unsharded
+    LeastSquares(A, b, lam) read as lam/2 ||. - b||^2 after A -- else None"""
+    from .operators import LeastSquares, SquaredDistance
+
+    if isinstance(f, Composed) and isinstance(f.A, HIPMatrix):
+        return f.f, f.A
+    if isinstance(f, LeastSquares) and f.comm is None:
+        return SquaredDistance(f.b, lam=f.lam), f.A
+    return None
+
+
 def composed_supported(f, g):
-    """f = Composed(loss, device matrix), g one of the prox kinds the sweep applies in-kernel"""
-    if not isinstance(f, Composed) or not isinstance(f.A, HIPMatrix) or not hasattr(g, "g_kind"):
+    """f(x) = loss(A x) on a device matrix, g one of the prox kinds the sweep applies in-kernel"""
+    if loss_and_matrix(f) is None or not hasattr(g, "g_kind"):
         return False
     return not (hasattr(g, "_scalar") and not g._scalar)
 
@@ -39,7 +51,8 @@ class _Sweep:
     def __init__(self, it, state_cls, with_prev):
         self.it = it
         f, R = it.f, it.x0.dtype.type
-        self.A, self.loss, self.g = f.A, f.f, it.g
+        self.loss, self.A = loss_and_matrix(f)
+        self.g = it.g
         ctx, dt = it.x0.ctx, it.x0.dtype
         m = self.A.m
         x = it.x0.copy()

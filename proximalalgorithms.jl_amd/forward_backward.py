@@ -73,11 +73,19 @@ class ForwardBackwardIteration:
         self.minimum_gamma = R(minimum_gamma)
         self.reduce_gamma = R(reduce_gamma)
         self.increase_gamma = R(increase_gamma)
+        auto = engine is None
         if engine is None:
             engine = "fused" if fused_supported(self.f, self.g) else (
                 "composed" if (composed_supported(self.f, self.g) and single_sweep) else "generic")
+        # f = LeastSquares with the adaptive step: the library's fused iteration needs two sweeps there (the accepted
+        # trial's gradient is a second product), the composed re-association one -- taken once A is large enough for the
+        # sweeps to dominate the extra host calls (64 MiB)
+        if (auto and engine == "fused" and self.adaptive and single_sweep and getattr(self.f, "comm", 1) is None
+                and self.f.A.m * self.f.A.n * self.f.A.dtype.itemsize >= (64 << 20) and composed_supported(self.f, self.g)):
+            engine = "composed"
         if engine == "composed" and not composed_supported(self.f, self.g):
-            raise TypeError("engine='composed' needs f = Composed(loss, device matrix) and g in {NormL1, IndBox(scalar bounds), Zero}")
+            raise TypeError("engine='composed' needs f = Composed(loss, device matrix) or an unsharded LeastSquares, and g in "
+                            "{NormL1, IndBox(scalar bounds), Zero}")
         if engine == "fused" and not fused_supported(self.f, self.g):
             raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox(scalar bounds), Zero}")
         self.engine = engine

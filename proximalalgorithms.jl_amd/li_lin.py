@@ -176,16 +176,7 @@ class LiLinIteration:
             yield s
 
 
-def _loss_and_matrix(f):
-    """(loss on m-vectors, device matrix) when f(x) = loss(A x) with A a HIPMatrix, else None"""
-    from .device import HIPMatrix
-    from .operators import Composed, LeastSquares, SquaredDistance
-
-    if isinstance(f, Composed) and isinstance(f.A, HIPMatrix):
-        return f.f, f.A
-    if isinstance(f, LeastSquares) and f.comm is None:
-        return SquaredDistance(f.b, lam=f.lam), f.A
-    return None
+from ._composed import loss_and_matrix as _loss_and_matrix  # noqa: E402
 
 
 def default_stopping_criterion(tol, iteration, state):

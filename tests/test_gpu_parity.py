@@ -1533,3 +1533,30 @@ def test_composed_engine_sparse_logistic_known_answer_and_fallback(pa, dtype):
     for sd, so in itertools.islice(zip(it_tall, it_ora), 5):
         assert np.max(np.abs(sd.z.numpy() - so.z)) <= (2e-4 if dtype == np.float32 else 1e-10)
     assert it_tall.engine == "generic"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fb_adaptive_least_squares_through_the_composed_sweep(pa, dtype):
+    """ForwardBackward with the adaptive step on LeastSquares: the composed re-association reads A once per iteration
+    (the library's fused iteration needs two sweeps there); same gamma sequence and iterates as the fused engine and
+    the restatement.  (Picked automatically from 64 MiB of A; forced here on a small instance.)"""
+    A, b, lam = synthetic_problem(300, 900, dtype, seed=31)
+    x0 = np.zeros(900, dtype)
+    Ad = pa.HIPMatrix.from_numpy(A)
+    it_c = pa.ForwardBackwardIteration(f=pa.LeastSquares(Ad, b), g=pa.NormL1(lam), x0=x0, engine="composed")
+    it_f = pa.ForwardBackwardIteration(f=pa.LeastSquares(Ad, b), g=pa.NormL1(lam), x0=x0)
+    it_o = o.ForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0)
+    assert it_c.engine == "composed" and it_f.engine == "fused" and it_c.adaptive
+    K = 30
+    for k, (sc, sf, so) in enumerate(itertools.islice(zip(it_c, it_f, it_o), K)):
+        if dtype == np.float64:
+            assert float(sc.gamma) == pytest.approx(float(so.gamma), rel=1e-12), k
+        tol = (2e-4 if dtype == np.float32 else 1e-10) * max(1.0, float(np.max(np.abs(so.z))))
+        assert np.max(np.abs(sc.z.numpy() - so.z)) <= tol, k
+        assert np.max(np.abs(sc.z.numpy() - sf.z.numpy())) <= tol, k
+    assert it_c.counters["a_passes"] == 2 + 3 + (K - 1) + it_c.counters.get("backtracks", 0)
+    # the Lf-less LeastSquares case with lam != 1 as well
+    it_c = pa.ForwardBackwardIteration(f=pa.LeastSquares(Ad, b, lam=0.7), g=pa.IndBox(-0.2, 0.3), x0=x0, engine="composed")
+    it_o = o.ForwardBackwardIteration(f=o.LeastSquares(A, b, 0.7), g=o.IndBox(-0.2, 0.3), x0=x0)
+    for k, (sc, so) in enumerate(itertools.islice(zip(it_c, it_o), 15)):
+        assert np.max(np.abs(sc.z.numpy() - so.z)) <= (2e-4 if dtype == np.float32 else 1e-10), k
