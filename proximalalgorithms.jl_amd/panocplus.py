@@ -50,12 +50,14 @@ class PANOCplusIteration(PANOCIteration):
 
     def _step(self, s):
         R = s.x.dtype.type
-        s.x_prev.copy_from(s.x)  # :170-171
-        s.res_prev.copy_from(s.res)
         FBE_x = R(self._model(s) + s.g_z)  # :174
         sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :176
         tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
         threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :178
+        # :170-171 as reference swaps: x_prev / res_prev take the current buffers, x and res are rewritten in full below
+        s.x_prev, s.x = s.x, s.x_prev
+        s.res_prev, s.res = s.res, s.res_prev
+        s.res_stats = None
         tau_backtracks = 0
         can_update_direction = True
         while True:  # :183-235
