@@ -203,7 +203,10 @@ def get_context(device=None):
         device = torch.cuda.current_device()
     device = int(device)
     if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
+        # PROXGRAD_SIDE_STREAM=1: the default context runs on its own (capturable) stream instead of torch's current one
+        import os
+
+        _default_ctx[device] = Context.on_new_stream(device) if os.environ.get("PROXGRAD_SIDE_STREAM") == "1" else Context(device)
     return _default_ctx[device]
 
 

@@ -71,10 +71,22 @@ class TorchDistributedComm:
     def attach(self, ctx):
         import torch.distributed as dist
 
+        import torch
+
+        def on_ctx_stream():
+            """the collective must be ordered with the library's kernels: when the context runs on its own stream (not
+            torch's current one), make that stream current for the call"""
+            if ctx.stream and ctx.stream != torch.cuda.current_stream(ctx.torch_device).cuda_stream:
+                return torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream, device=ctx.torch_device))
+            import contextlib
+
+            return contextlib.nullcontext()
+
         def fn(ptr, count, pg_dtype, stream):
             self.calls += 1
             self.elements += count
-            allreduce_sum_(self._view(ctx, ptr, count, pg_dtype), self.group)
+            with on_ctx_stream():
+                allreduce_sum_(self._view(ctx, ptr, count, pg_dtype), self.group)
 
         pending = []
 
@@ -83,12 +95,14 @@ class TorchDistributedComm:
             # stream; the current stream is NOT made to wait until wait() -> the next pass-T chunk overlaps it
             self.calls += 1
             self.elements += count
-            pending.append(dist.all_reduce(self._view(ctx, ptr, count, pg_dtype), op=dist.ReduceOp.SUM,
-                                           group=self.group, async_op=True))
+            with on_ctx_stream():
+                pending.append(dist.all_reduce(self._view(ctx, ptr, count, pg_dtype), op=dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True))
 
         def wait(stream):
-            for w in pending:
-                w.wait()
+            with on_ctx_stream():
+                for w in pending:
+                    w.wait()
             pending.clear()
 
         ctx.set_allreduce(fn)
