@@ -730,3 +730,41 @@ def test_sfista_single_sweep_pass_counts_and_refresh(pa, dtype):
     r2, _ = check_sc(s2, two, 1e-3)
     assert float(r1) == pytest.approx(float(r2), rel=1e-2 if dtype == np.float32 else 1e-6, abs=1e-6)
     assert one.counters["a_passes"] == 1 + (K + 1) + (K + 1) // 64 + 1
+
+
+def test_custom_operators_plug_into_the_second_group(pa, stream_ctx):
+    """docs/src/guide/custom_objectives.jl: any object with prox_ / value_and_gradient methods works; operators without
+    the `want_value` / `out` keywords and operators that allocate still run (value computed and dropped, gradient copied,
+    hipGraph capture refused -> plain stepping)."""
+    dtype = np.float64
+    A, b, lam, Lf = lasso_small(dtype)
+
+    class MyL1:  # no want_value keyword, allocates a temporary on every call
+        def __init__(self, lam):
+            self.inner = pa.NormL1(lam)
+
+        def prox_(self, y, x, gamma):
+            tmp = x.similar().copy_from(x)
+            return self.inner.prox_(y, tmp, gamma)
+
+    class MyLeastSquares:  # no `out` keyword
+        def __init__(self):
+            self.inner = pa.LeastSquares(A, b)
+
+        def value_and_gradient(self, x):
+            return self.inner.value_and_gradient(x)
+
+        def __call__(self, x):  # li_lin.jl:103 evaluates iter.f(z)
+            return self.inner(x)
+
+    x0 = np.zeros(5, dtype)
+    xs = rv.LASSO_SMALL_XSTAR
+    (x, _), it = pa.AFBA(theta=1, mu=1, tol=1e-6, graph=True)(x0=x0, y0=np.zeros(5), f=MyLeastSquares(), g=MyL1(lam), beta_f=Lf)
+    (xr, _), itr = pa.AFBA(theta=1, mu=1, tol=1e-6)(x0=x0, y0=np.zeros(5), f=pa.LeastSquares(A, b), g=pa.NormL1(lam), beta_f=Lf)
+    assert it == itr and np.max(np.abs(x - xr)) <= 1e-12 and np.max(np.abs(x - xs)) <= 1e-4
+    y, it = pa.SFISTA(tol=1e-4)(x0=x0, f=MyLeastSquares(), g=MyL1(lam), Lf=Lf)
+    assert np.max(np.abs(y - xs)) <= 1e-3
+    x, it = pa.DavisYin(tol=1e-7, graph=True)(x0=x0, f=MyLeastSquares(), g=MyL1(lam), h=pa.Zero(), Lf=Lf)
+    assert np.max(np.abs(x - xs)) <= 1e-4
+    z, it = pa.LiLin(tol=1e-5)(x0=x0, f=MyLeastSquares(), g=pa.NormL1(lam), Lf=Lf)
+    assert np.max(np.abs(z - xs)) <= 1e-4
