@@ -274,8 +274,11 @@ class LiLinIteration:
     """li_lin.jl:40-49 (options f, g, x0, Lf | gamma, adaptive, delta = 1e-3, eta = 0.8), init :69-97, step :99-144.
 
     NOTE li_lin.jl:108 evaluates ``value_and_gradient(iter.f, x)`` with an unbound name ``x`` -- the monitor branch
-    (``Fz`` above the moving average) raises UndefVarError in the reference.  The restatement uses ``state.x``, the
-    point Algorithm 2 of Li & Lin prescribes; on the reference's own pins the branch is never taken."""
+    (``Fz`` above the moving average) raises UndefVarError in the reference, so nothing it contains is executable there;
+    on the reference's own pins the branch is never taken.  The restatement follows Algorithm 2 of Li & Lin (2015) in
+    that branch: the gradient at ``state.x``, and for the case x+ = v the extrapolation
+    y = v + (t/t+)(z - v) + ((t - 1)/t+)(v - x)  (li_lin.jl:120-122 writes ``z +`` where the paper has ``v +``; taken
+    literally that line makes the iteration diverge on a convex LASSO as soon as the branch fires, for every step size)."""
 
     def __init__(self, *, x0, f=None, g=None, Lf=None, gamma=None, adaptive=False, delta=1e-3, eta=0.8):
         self.x0, self.f, self.g = x0, f if f is not None else Zero(), g if g is not None else Zero()
@@ -314,7 +317,7 @@ class LiLinIteration:
                 s.x, s.z = s.z, s.x
                 Fx = Fz
             else:
-                s.y = (s.z + R(s.theta / theta1) * (s.z - v) + R((s.theta - R(1)) / theta1) * (v - s.x)).astype(s.z.dtype)
+                s.y = (v + R(s.theta / theta1) * (s.z - v) + R((s.theta - R(1)) / theta1) * (v - s.x)).astype(s.z.dtype)  # see the class note
                 s.x = v
                 Fx = Fv
             s.f_y, g = value_and_gradient(self.f, s.y)  # :128

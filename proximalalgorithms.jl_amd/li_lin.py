@@ -17,8 +17,10 @@ class LiLinState:
 class LiLinIteration:
     """li_lin.jl:40-49 (f, g, x0, Lf | gamma, adaptive, delta = 1e-3, eta = 0.8); init :69-97; step :99-144.
 
-    li_lin.jl:108 reads an unbound name ``x`` in the monitor branch (UndefVarError in the reference); this mirror
-    evaluates the gradient at ``state.x`` as Algorithm 2 prescribes and counts the visits in ``monitor_branch_taken``."""
+    li_lin.jl:108 reads an unbound name ``x`` in the monitor branch (UndefVarError in the reference: nothing in that
+    branch is executable there).  This mirror follows Algorithm 2 of Li & Lin (2015) in it -- gradient at ``state.x``, and
+    for x+ = v the extrapolation y = v + (t/t+)(z - v) + ((t - 1)/t+)(v - x) (li_lin.jl:120-122 has ``z +`` for the paper's
+    ``v +``, which diverges on convex problems once the branch fires) -- and counts the visits in ``monitor_branch_taken``."""
 
     def __init__(self, *, x0, f=None, g=None, Lf=None, gamma=None, adaptive=False, delta=1e-3, eta=0.8, single_sweep=True):
         self.x0 = as_hipvector(x0)
@@ -109,9 +111,9 @@ class LiLinIteration:
                 Fx = Fz
             else:
                 c1, c2 = R(s.theta / theta1), R((s.theta - R(1)) / theta1)
-                s.y.axpby_(R(R(1) + c1), s.z, R(c2 - c1), v)  # :120-122
+                s.y.axpby_(c1, s.z, R(R(1) - c1 + c2), v)  # v + c1 (z - v) + c2 (v - x)   (:120-122, see the class note)
                 s.y.axpby_(1.0, s.y, -float(c2), s.x)
-                Ay.axpby_(R(R(1) + c1), Az, R(c2 - c1), Av)
+                Ay.axpby_(c1, Az, R(R(1) - c1 + c2), Av)
                 Ay.axpby_(1.0, Ay, -float(c2), Ax)
                 s.x.copy_from(v)
                 Ax.copy_from(Av)
@@ -160,7 +162,7 @@ class LiLinIteration:
                 Fx = Fz
             else:
                 c1, c2 = R(s.theta / theta1), R((s.theta - R(1)) / theta1)
-                s.y.axpby_(R(R(1) + c1), s.z, R(c2 - c1), v)  # z + c1 (z - v) + c2 (v - x)   (:120-122)
+                s.y.axpby_(c1, s.z, R(R(1) - c1 + c2), v)  # v + c1 (z - v) + c2 (v - x)   (:120-122, see the class note)
                 s.y.axpby_(1.0, s.y, -float(c2), s.x)
                 s.x.copy_from(v)
                 Fx = Fv
