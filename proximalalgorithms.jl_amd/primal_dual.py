@@ -134,7 +134,8 @@ class AFBAIteration:
         self.gamma = (R(gamma[0]), R(gamma[1]))
         # Vu-Condat / Chambolle-Pock with a device matrix L and an in-kernel prox kind for g: ONE read of L per iteration
         # (see _body_single_sweep)
-        self.single_sweep = bool(single_sweep) and self.theta == 2 and self.lam == 1 and isinstance(self.L, HIPMatrix) \
+        self.single_sweep = bool(single_sweep) and isinstance(self.L, HIPMatrix) \
+            and ((self.theta == 2 and self.lam == 1) or (self.theta == 1 and self.mu == 1)) \
             and hasattr(self.g, "g_kind") and not (hasattr(self.g, "_scalar") and not self.g._scalar)
         self.counters = {"L_passes": 0}
 
@@ -166,7 +167,8 @@ class AFBAIteration:
         return s
 
     def _body_single_sweep(self, s):
-        """theta = 2, lambda = 1 (Vu-Condat / Chambolle-Pock), L a device matrix: one read of L per iteration.
+        """theta = 2, lambda = 1 (Vu-Condat / Chambolle-Pock), L a device matrix: one read of L per iteration (theta = 1,
+        mu = 1 -- the default AFBA -- two: the sweep and the primal correction L'(gamma1 FPR_y)).
         The sweep pg_mat_fused_tn takes the dual iterate y as its m-vector and returns  L'y,  xbar = prox_{g1 g}(x - g1
         (L'y + grad f))  (the smooth term enters by shifting the sweep's x) and  L xbar;  with lambda = 1 the next primal
         iterate IS xbar, so  L (2 xbar - x) = 2 L xbar - L x  needs no product: L x is the previous sweep's L xbar.  The
@@ -191,20 +193,30 @@ class AFBAIteration:
                 return False
             raise
         self.counters["L_passes"] += 1
-        if not s.Lx_valid:
+        if self.theta == 2 and not s.Lx_valid:
             self._mul(s.Lx, s.x)  # once: L x0
             s.Lx_valid = True
         if not s.lc_zero:
             value_and_gradient_(s.gradl, s.lc, s.y)  # :187
-        s.temp_y.axpby_(2.0, s.Lxbar, -1.0, s.Lx)  # :189-190  L (2 xbar - x)
-        s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)  # :191
+        if self.theta == 2:
+            s.temp_y.axpby_(2.0, s.Lxbar, -1.0, s.Lx)  # :189-190  L (2 xbar - x)
+            s.temp_y.axpby_(1.0, s.temp_y, -1.0, s.gradl)  # :191
+        else:  # theta = 1: L (theta xbar + (1 - theta) x) = L xbar, straight out of the sweep
+            s.temp_y.axpby_(1.0, s.Lxbar, -1.0, s.gradl)
         s.temp_y.axpby_(float(g2), s.temp_y, 1.0, s.y)  # :192-193
         prox_(s.ybar, s.hc, s.temp_y, g2, want_value=False)  # :194
         s.FPR_x.axpby_(1.0, s.xbar, -1.0, s.x)  # :196-197
         s.FPR_y.axpby_(1.0, s.ybar, -1.0, s.y)
-        s.x.axpby_(1.0, s.x, 1.0, s.FPR_x)  # :201 with a zero correction, lambda = 1
-        s.Lx.copy_from(s.Lxbar)  # L x of the new x (= xbar up to the rounding of x + (xbar - x))
-        s.y.axpby_(1.0, s.y, 1.0, s.FPR_y)  # :205
+        if self.theta == 2:
+            s.x.axpby_(1.0, s.x, 1.0, s.FPR_x)  # :201 with a zero correction, lambda = 1
+            s.Lx.copy_from(s.Lxbar)  # L x of the new x (= xbar up to the rounding of x + (xbar - x))
+            s.y.axpby_(1.0, s.y, 1.0, s.FPR_y)  # :205
+        else:  # theta = 1, mu = 1: the primal correction L'(gamma1 FPR_y) is a real product (:199-201), the dual one vanishes
+            s.temp_y.axpby_(float(g1), s.FPR_y)
+            self._mul_adjoint(s.temp_x, s.temp_y)
+            s.temp_x.axpby_(1.0, s.FPR_x, -1.0, s.temp_x)
+            s.x.axpby_(1.0, s.x, float(self.lam), s.temp_x)
+            s.y.axpby_(1.0, s.y, float(self.lam), s.FPR_y)  # :205
         return True
 
     def body(self, s):

@@ -768,3 +768,33 @@ def test_custom_operators_plug_into_the_second_group(pa, stream_ctx):
     assert np.max(np.abs(x - xs)) <= 1e-4
     z, it = pa.LiLin(tol=1e-5)(x0=x0, f=MyLeastSquares(), g=pa.NormL1(lam), Lf=Lf)
     assert np.max(np.abs(z - xs)) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_afba_default_two_reads_of_L_per_iteration(pa, dtype):
+    """theta = 1, mu = 1 with a device matrix L: the sweep (L'y, prox, L xbar) plus the primal correction -- two reads of L per
+    iteration instead of three, same iterates as the plain statement order and the restatement"""
+    rng = np.random.default_rng(43)
+    m, n = 70, 210
+    A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+    b = rng.standard_normal(m).astype(dtype)
+    R = np.dtype(dtype).type
+    lam = R(0.1) * R(np.max(np.abs(A.T @ b)))
+    x0, y0 = (0.1 * rng.standard_normal(n)).astype(dtype), (0.1 * rng.standard_normal(m)).astype(dtype)
+    Ad = pa.HIPMatrix.from_numpy(A)
+    kd = dict(f=pa.SqrNormL2(R(0.3)), beta_f=0.3, g=pa.NormL1(lam), h=pa.SquaredDistance(b), lam=R(0.9), gamma=(R(0.2), R(0.3)))
+    ko = dict(f=ox.SqrNormL2(R(0.3)), beta_f=0.3, g=o.NormL1(lam), h=ox.SqrDistance(b), lam=R(0.9), gamma=(R(0.2), R(0.3)))
+    two = pa.AFBAIteration(x0=x0, y0=y0, L=Ad, **kd)
+    three = pa.AFBAIteration(x0=x0, y0=y0, L=Ad, single_sweep=False, **kd)
+    ora = ox.AFBAIteration(x0=x0, y0=y0, L=A, **ko)
+    assert two.single_sweep and not three.single_sweep
+    K = 30
+    for k, (s2, s3, so) in enumerate(zip(two, three, ora)):
+        if k >= K:
+            break
+        for fld in ("x", "y", "xbar", "ybar"):
+            ref = getattr(so, fld)
+            tol = (2e-4 if dtype == np.float32 else 1e-10) * max(1.0, float(np.max(np.abs(ref))))
+            assert np.max(np.abs(getattr(s2, fld).numpy() - ref)) <= tol, (k, fld)
+            assert np.max(np.abs(getattr(s2, fld).numpy() - getattr(s3, fld).numpy())) <= tol, (k, fld)
+    assert two.counters["L_passes"] == 2 * (K + 1) and three.counters["L_passes"] == 3 * (K + 1)
