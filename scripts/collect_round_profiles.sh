@@ -15,3 +15,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof_write -- python3 be
 for d in prof_headline prof_fetch prof_write; do python scripts/rocpd_summary.py gpurun_out/$d/*/*_results.db > gpurun_out/$d.md 2>&1; done
 python scripts/bench_panoc.py > gpurun_out/bench_panoc.json 2>/dev/null
 python tests/tools/bench_dr.py > gpurun_out/bench_dr.json 2>/dev/null
+for a in ffb ffb-generic; do python scripts/bench_panoc.py --algo $a 2>/dev/null; done > gpurun_out/bench_logistic_ffb.json
+python scripts/bench_primal_dual.py > gpurun_out/bench_primal_dual.json 2>/dev/null
+python tests/tools/bench_suite.py > gpurun_out/bench_suite.log 2>/dev/null
