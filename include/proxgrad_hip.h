@@ -51,7 +51,7 @@ enum {
 enum { PG_F32 = 0, PG_F64 = 1 };
 
 /* proximable term g -- ProximalOperators.{NormL1, IndBox}, ProximalCore.Zero               */
-enum { PG_G_ZERO = 0, PG_G_NORML1 = 1, PG_G_INDBOX = 2 };
+enum { PG_G_ZERO = 0, PG_G_NORML1 = 1, PG_G_INDBOX = 2, PG_G_SQRNORML2 = 3 /* lam/2 ||.||^2: pg_mat_fused_dys only */ };
 
 /* extrapolation sequences -- src/accel/nesterov.jl                                          */
 enum {
@@ -180,6 +180,16 @@ pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
  * Unsharded matrices with m <= 32768 (f32) / 16384 (f64) rows; PG_ERR_UNSUPPORTED otherwise. */
 pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
                           void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out);
+/* One Davis-Yin iteration (davis_yin.jl:73-83: prox!(xg, g, z); grad f(xg); z_half = 2 xg - z - gamma grad; prox!(xh, h,
+ * z_half); res = xh - xg; z += lambda res) for f = loss o A in ONE read of A.  Input: r = grad loss(A xg) (m-vector), xg, z.
+ * Output per column: grad = A' r, z_half, xh = prox_{gamma h}(z_half), res, z_next = z + relax * res, and already the NEXT
+ * iteration's xg_next = prox_{gamma g}(z_next) with its image A_xg_next = A xg_next.  g_kind / h_kind in {PG_G_ZERO,
+ * PG_G_NORML1 (p0 = lam), PG_G_INDBOX (p0 = lo, p1 = hi), PG_G_SQRNORML2 (p0 = lam)}.  scalars_out (host, may be NULL) =
+ * { 0, norm(res, Inf), dot(grad, res), norm(res)^2 }.  Same shape limits as pg_mat_fused_tn. */
+pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void* z, double gamma, double relax,
+                           int32_t g_kind, double g_p0, double g_p1, int32_t h_kind, double h_p0, double h_p1, void* grad,
+                           void* z_half, void* xh, void* res, void* z_next, void* xg_next, void* A_xg_next,
+                           double* scalars_out);
 
 /* ------------------------------------------------------------------ LeastSquares -------- */
 /* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the

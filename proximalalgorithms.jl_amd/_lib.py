@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libproxgrad_hip.so")
 
 PG_F32, PG_F64 = 0, 1
-PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX = 0, 1, 2
+PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX, PG_G_SQRNORML2 = 0, 1, 2, 3
 PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST = 0, 1, 2, 3, 4
 PG_FLAG_GAMMA_TOO_SMALL = 1
 PG_K_GEMV_N, PG_K_GEMV_N_FINISH, PG_K_GEMV_T, PG_K_EPILOGUE, PG_K_EXTRAPOLATE, PG_K_DR_STEP = range(6)
@@ -88,6 +88,8 @@ SIGNATURES = {
     "pg_mat_mul": [_vp, _vp, _vp],
     "pg_mat_mul_adjoint": [_vp, _vp, _vp],
     "pg_mat_fused_tn": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
+    "pg_mat_fused_dys": [_vp, _vp, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                         _pf64],
     "pg_ls_create": [_vp, _vp, _vp, _f64, C.POINTER(_vp)],
     "pg_ls_destroy": [_vp],
     "pg_ls_value_and_gradient": [_vp, _vp, _vp, _pf64],

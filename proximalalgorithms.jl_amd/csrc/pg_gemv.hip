@@ -281,7 +281,23 @@ struct TNArgs {
   double* red_partials;
   unsigned* red_counter;
   double* scal_out;  // 4 doubles: g(z), ||res||_inf, <g, res>, ||res||^2
+  // Davis-Yin mode (MODE = 1): x = xg (the prox_g point the gradient was taken at), z_old = the splitting variable z;
+  // per column  z_half = 2 xg - z - gamma g ; xh = prox_{gamma h}(z_half) ; res = xh - xg ; z+ = z + relax res ;
+  // xg+ = prox_{gamma g}(z+)  -- outputs y = z_half, xh_out = xh, res, v_out = z+, z_new = xg+ ; A xg+ is accumulated
+  int h_kind = 0;
+  T h_p0 = T(0), h_p1 = T(0), relax = T(1);  // h_p0 = gamma * lam (NormL1) | lo (IndBox) | 1 / (1 + lam gamma) (SqrNormL2)
+  T* xh_out = nullptr;
 };
+
+// in-kernel prox kinds: PG_G_ZERO / PG_G_NORML1 / PG_G_INDBOX and, for the second operator of the Davis-Yin mode,
+// PG_G_SQRNORML2 (p0 = the scaling 1 / (1 + lam gamma))
+template <typename T>
+__device__ __forceinline__ T tn_prox(int kind, T y, T p0, T p1) {
+  if (kind == PG_G_NORML1) return y <= -p0 ? y + p0 : (y >= p0 ? y - p0 : T(0));
+  if (kind == PG_G_INDBOX) return fmin(p1, fmax(p0, y));
+  if (kind == PG_G_SQRNORML2) return y * p0;
+  return y;
+}
 
 template <typename T, int U, int C, int WAVES>
 struct TNTile {
@@ -310,7 +326,7 @@ struct TNTile {
   }
 };
 
-template <typename T, int U, int C, int WAVES, bool DOUBLE_BUFFER>
+template <typename T, int U, int C, int WAVES, bool DOUBLE_BUFFER, int MODE = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -371,26 +387,47 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
       const bool valid = j < a.n;
       if (a.lam_ls != T(1)) g = a.lam_ls * g;
       const T xj = xs[c], zo = zos[c];
-      const T yj = xj - a.gamma * g;
-      T zj;
-      if (a.g_kind == PG_G_NORML1)
-        zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-      else if (a.g_kind == PG_G_INDBOX)
-        zj = fmin(a.p1, fmax(a.p0, yj));
-      else
-        zj = yj;
-      const T rj = xj - zj;
-      const T vj = valid ? zj + a.beta * (zj - zo) : T(0);
-      if ((int)threadIdx.x == c && valid) {
-        a.g_out[j] = g;
-        a.y[j] = yj;
-        a.z_new[j] = zj;
-        a.res[j] = rj;
-        if (a.v_out != nullptr) a.v_out[j] = vj;
-        if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
-        acc[1] = fmax(acc[1], fabs((double)rj));
-        acc[2] += (double)g * (double)rj;
-        acc[3] += (double)rj * (double)rj;
+      T vj;
+      if constexpr (MODE == 1) {  // Davis-Yin: davis_yin.jl:74-80 for column j, then the next prox_g point
+        const T zh = T(2) * xj - zo - a.gamma * g;
+        const T xh = tn_prox<T>(a.h_kind, zh, a.h_p0, a.h_p1);
+        const T rj = xh - xj;
+        const T zs = zo + a.relax * rj;
+        const T xg = tn_prox<T>(a.g_kind, zs, a.p0, a.p1);
+        vj = valid ? xg : T(0);
+        if ((int)threadIdx.x == c && valid) {
+          a.g_out[j] = g;
+          a.y[j] = zh;
+          a.xh_out[j] = xh;
+          a.res[j] = rj;
+          a.v_out[j] = zs;
+          a.z_new[j] = xg;
+          acc[1] = fmax(acc[1], fabs((double)rj));
+          acc[2] += (double)g * (double)rj;
+          acc[3] += (double)rj * (double)rj;
+        }
+      } else {
+        const T yj = xj - a.gamma * g;
+        T zj;
+        if (a.g_kind == PG_G_NORML1)
+          zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
+        else if (a.g_kind == PG_G_INDBOX)
+          zj = fmin(a.p1, fmax(a.p0, yj));
+        else
+          zj = yj;
+        const T rj = xj - zj;
+        vj = valid ? zj + a.beta * (zj - zo) : T(0);
+        if ((int)threadIdx.x == c && valid) {
+          a.g_out[j] = g;
+          a.y[j] = yj;
+          a.z_new[j] = zj;
+          a.res[j] = rj;
+          if (a.v_out != nullptr) a.v_out[j] = vj;
+          if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
+          acc[1] = fmax(acc[1], fabs((double)rj));
+          acc[2] += (double)g * (double)rj;
+          acc[3] += (double)rj * (double)rj;
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -739,7 +776,7 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
 
 // ---- pass TN launcher ------------------------------------------------------------------------------------------
 // Tunables (environment, for experiments): PG_TN_C (columns per step), PG_TN_BLOCKS_PER_CU, PG_TN_BLOCKS.
-template <typename T, int U, int C, int WAVES>
+template <typename T, int U, int C, int WAVES, int MODE = 0>
 pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   const int64_t ncg = (A->n + C - 1) / C;
@@ -755,7 +792,8 @@ pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.partials = (T*)A->partials;
   *blocks_out = (int)blocks;
   pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES, (WAVES <= 4)>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
+  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES, (WAVES <= 4), MODE>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
+                     c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -768,7 +806,7 @@ bool tn_supported(const pg_mat* A) {
   return A->m > 0 && A->n > 0 && nrg <= 16 * 8;
 }
 
-template <typename T>
+template <typename T, int MODE = 0>
 pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int nrg = a.nrg;
   // 17..32 row groups (m = 8192 in Float32): eight waves of U = 4 with C = 8 columns per step measured 4 % faster than four
@@ -788,6 +826,21 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   if (W == 8 && U == 4 && env_int("PG_TN_C", 0) == 0) C = 8;
   if (W <= 2 && env_int("PG_TN_C", 0) == 0) C = (W == 2 && U == 4) ? 4 : (U == 1 ? 16 : 8);  // (2,4,4) (2,2,8) (1,2,8) (1,1,16)
   if (sizeof(T) == 8 && U == 1 && C > 16) C = 16;  // <f64, 1, 32> would spill
+  if constexpr (MODE == 1) {  // Davis-Yin mode: the default geometries only (no tuner variants)
+#define PG_TN_DYS(UU, CC, WW) \
+  if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW, 1>(A, a, blocks_out)
+    PG_TN_DYS(16, 2, 4);
+    PG_TN_DYS(16, 1, 8);
+    PG_TN_DYS(4, 8, 8);
+    PG_TN_DYS(4, 4, 4);
+    PG_TN_DYS(4, 4, 2);
+    PG_TN_DYS(2, 8, 2);
+    PG_TN_DYS(2, 8, 1);
+    PG_TN_DYS(1, 16, 1);
+#undef PG_TN_DYS
+    pg_set_error("no Davis-Yin sweep for U=%d C=%d WAVES=%d (launch-geometry overrides are not available in this mode)", U, C, W);
+    return PG_ERR_UNSUPPORTED;
+  }
 #define PG_TN_CASE(UU, CC, WW) \
   if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)
   PG_TN_CASE(16, 1, 4);
@@ -1064,6 +1117,70 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
   return PG_OK;
 }
 
+// One Davis-Yin iteration (davis_yin.jl:73-83) for f = loss o A in ONE read of A: given r = grad loss(A xg), the sweep forms
+// grad = A' r, z_half, xh = prox_{gamma h}, res, z+ = z + relax res, the NEXT xg+ = prox_{gamma g}(z+) and A xg+.
+template <typename T>
+pg_status mat_fused_dys_t(pg_mat* A, const T* r, const T* xg, const T* z, double gamma, double relax, int g_kind, double g_p0,
+                          double g_p1, int h_kind, double h_p0, double h_p1, T* grad, T* z_half, T* xh, T* res, T* z_next,
+                          T* xg_next, T* A_xg_next) {
+  pg_ctx* c = A->ctx;
+  if (pg_row_sharded(c) || pg_col_sharded(c) || !tn_supported<T>(A)) {
+    pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(128 * 1024 / sizeof(T)));
+    return PG_ERR_UNSUPPORTED;
+  }
+  if (A->rpad == nullptr) {
+    PG_HIP(hipMalloc(&A->rpad, (size_t)A->ld * sizeof(T)));
+    PG_HIP(hipMemsetAsync(A->rpad, 0, (size_t)A->ld * sizeof(T), c->stream));
+  }
+  PG_HIP(hipMemcpyAsync(A->rpad, r, (size_t)A->m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  const T gm = (T)gamma;
+  auto scaled = [&](int kind, double p0) -> T {
+    if (kind == PG_G_NORML1) return (T)(gm * (T)p0);
+    if (kind == PG_G_SQRNORML2) return T(1) / (T(1) + (T)p0 * gm);
+    return (T)p0;
+  };
+  TNArgs<T> a;
+  a.A = (const T*)A->data;
+  a.ld = A->ld;
+  a.n = A->n;
+  a.m = A->m;
+  a.nrg = (int)(A->ld / (1024 / (int64_t)sizeof(T)));
+  a.r = (const T*)A->rpad;
+  a.x = xg;
+  a.z_old = z;
+  a.gamma = gm;
+  a.beta = T(0);
+  a.p0 = scaled(g_kind, g_p0);
+  a.p1 = (T)g_p1;
+  a.lam_ls = T(1);
+  a.g_kind = g_kind;
+  a.gscale = 0.0;
+  a.h_kind = h_kind;
+  a.h_p0 = scaled(h_kind, h_p0);
+  a.h_p1 = (T)h_p1;
+  a.relax = (T)relax;
+  a.g_out = grad;
+  a.y = z_half;
+  a.xh_out = xh;
+  a.res = res;
+  a.v_out = z_next;
+  a.z_new = xg_next;
+  a.partials = nullptr;
+  a.red_partials = c->red_partials;
+  a.red_counter = c->red_counter;
+  a.scal_out = c->dscal + PG_S_GZ;
+  int blocks = 0;
+  PG_TRY((launch_tn<T, 1>(A, a, &blocks)));
+  int64_t fb = (A->ld + 63) / 64;
+  if (fb > 1024) fb = 1024;
+  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+  hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
+                     (const T*)A->partials, A->ld, A->m, blocks, (const T*)nullptr, A_xg_next, A->m, 0.0, (double*)nullptr,
+                     (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ v, int64_t n, T a) {
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) v[j] *= a;
@@ -1258,6 +1375,28 @@ pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma,
                                                     (float*)At_r, (float*)y, (float*)z, (float*)res, (float*)Az)
                             : mat_fused_tn_t<double>(A, (const double*)r, (const double*)x, gamma, g_kind, g_p0, g_p1,
                                                      (double*)At_r, (double*)y, (double*)z, (double*)res, (double*)Az));
+  if (scalars_out) {
+    PG_TRY(pg_read_scalars(A->ctx, PG_S_GZ, 4));
+    for (int k = 0; k < 4; ++k) scalars_out[k] = A->ctx->hscal[PG_S_GZ + k];
+  }
+  return PG_OK;
+}
+
+pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void* z, double gamma, double relax,
+                           int32_t g_kind, double g_p0, double g_p1, int32_t h_kind, double h_p0, double h_p1, void* grad,
+                           void* z_half, void* xh, void* res, void* z_next, void* xg_next, void* A_xg_next,
+                           double* scalars_out) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  PG_REQUIRE(r && xg && z && grad && z_half && xh && res && z_next && xg_next && A_xg_next, "null vector");
+  PG_REQUIRE(g_kind >= PG_G_ZERO && g_kind <= PG_G_SQRNORML2 && h_kind >= PG_G_ZERO && h_kind <= PG_G_SQRNORML2, "unknown prox kind");
+  PG_REQUIRE(gamma > 0, "gamma must be positive");
+  PG_TRY(A->dtype == PG_F32
+             ? mat_fused_dys_t<float>(A, (const float*)r, (const float*)xg, (const float*)z, gamma, relax, g_kind, g_p0, g_p1,
+                                      h_kind, h_p0, h_p1, (float*)grad, (float*)z_half, (float*)xh, (float*)res,
+                                      (float*)z_next, (float*)xg_next, (float*)A_xg_next)
+             : mat_fused_dys_t<double>(A, (const double*)r, (const double*)xg, (const double*)z, gamma, relax, g_kind, g_p0,
+                                       g_p1, h_kind, h_p0, h_p1, (double*)grad, (double*)z_half, (double*)xh, (double*)res,
+                                       (double*)z_next, (double*)xg_next, (double*)A_xg_next));
   if (scalars_out) {
     PG_TRY(pg_read_scalars(A->ctx, PG_S_GZ, 4));
     for (int k = 0; k < 4; ++k) scalars_out[k] = A->ctx->hscal[PG_S_GZ + k];

@@ -452,6 +452,16 @@ class HIPMatrix:
         R = self.dtype.type
         return tuple(R(v) for v in sc)
 
+    def fused_dys(self, r, xg, z, gamma, relax, g_spec, h_spec, grad, z_half, xh, res, z_next, xg_next, A_xg_next):
+        """ONE read of A for a Davis-Yin iteration (pg_mat_fused_dys); g_spec / h_spec = (kind, p0, p1).
+        Returns (norm(res, Inf), dot(grad, res), norm(res)^2)."""
+        sc = (C.c_double * 4)()
+        call("pg_mat_fused_dys", self._h, r.vp, xg.vp, z.vp, float(gamma), float(relax), g_spec[0], float(g_spec[1]),
+             float(g_spec[2]), h_spec[0], float(h_spec[1]), float(h_spec[2]), grad.vp, z_half.vp, xh.vp, res.vp, z_next.vp,
+             xg_next.vp, A_xg_next.vp, sc)
+        R = self.dtype.type
+        return R(sc[1]), R(sc[2]), R(sc[3])
+
     def mul_adjoint(self, r, out=None):
         """mul!(out, A', r)"""
         out = out if out is not None else HIPVector.empty(self.n, self.dtype, self.ctx)

@@ -568,7 +568,8 @@ def test_graph_replay_matches_plain_stepping(pa, stream_ctx, dtype):
                                          h=pa.SquaredDistance(b), L=A),
         "afba_ls": lambda: pa.AFBAIteration(x0=x0, y0=np.zeros(n, dtype), f=pa.LeastSquares(A, b), g=pa.NormL1(lam), beta_f=Lf),
         "chambolle_pock_single_sweep": lambda: pa.ChambollePockIteration(x0=x0, y0=y0, g=pa.NormL1(lam), h=pa.SquaredDistance(b), L=A),
-        "davis_yin": lambda: pa.DavisYinIteration(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), h=pa.IndBox(-0.5, 0.5), Lf=Lf),
+        "davis_yin": lambda: pa.DavisYinIteration(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), h=pa.IndBox(-0.5, 0.5), Lf=Lf,
+                                                  single_sweep=False),  # the plain body (the sweep form swaps buffers)
         "dr": lambda: pa.DouglasRachfordIteration(x0=x0, f=pa.LeastSquares(A, b), g=pa.NormL1(lam), gamma=R(1) / Lf),
     }
     for name, make in makers.items():
@@ -798,3 +799,41 @@ def test_afba_default_two_reads_of_L_per_iteration(pa, dtype):
             assert np.max(np.abs(getattr(s2, fld).numpy() - ref)) <= tol, (k, fld)
             assert np.max(np.abs(getattr(s2, fld).numpy() - getattr(s3, fld).numpy())) <= tol, (k, fld)
     assert two.counters["L_passes"] == 2 * (K + 1) and three.counters["L_passes"] == 3 * (K + 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_davis_yin_single_sweep_one_read_of_A_per_iteration(pa, dtype):
+    """f = LeastSquares / Composed on a device matrix, g and h in-kernel prox kinds: the whole Davis-Yin iteration (and the
+    next prox_g point with its image) in ONE read of A (pg_mat_fused_dys); same iterates as the plain statement order
+    (two reads) and the restatement."""
+    rng = np.random.default_rng(47)
+    R = np.dtype(dtype).type
+    for (m, n) in ((60, 200), (300, 90), (1100, 40)):
+        A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+        b = rng.standard_normal(m).astype(dtype)
+        lam = R(0.1) * R(np.max(np.abs(A.T @ b)))
+        Lf = R(np.linalg.norm(A, 2) ** 2)
+        x0 = (0.1 * rng.standard_normal(n)).astype(dtype)
+        Ad = pa.HIPMatrix.from_numpy(A)
+        cases = [
+            (dict(f=pa.LeastSquares(Ad, b), g=pa.NormL1(lam), h=pa.SqrNormL2(R(0.7))), dict(f=o.LeastSquares(A, b), g=o.NormL1(lam), h=ox.SqrNormL2(R(0.7)))),
+            (dict(f=pa.Composed(pa.LogisticLoss(b), Ad), g=pa.IndBox(-0.4, 0.3), h=pa.NormL1(R(0.01))),
+             dict(f=o.Composed(o.LogisticLoss(b), A), g=o.IndBox(-0.4, 0.3), h=o.NormL1(R(0.01)))),
+            (dict(f=pa.LeastSquares(Ad, b, lam=0.5), g=pa.Zero(), h=pa.IndBox(-0.2, 0.2)), dict(f=o.LeastSquares(A, b, 0.5), g=o.Zero(), h=o.IndBox(-0.2, 0.2))),
+        ]
+        K = 25
+        for kd, ko in cases:
+            one = pa.DavisYinIteration(x0=x0, Lf=Lf, lam=R(1.2), **kd)
+            two = pa.DavisYinIteration(x0=x0, Lf=Lf, lam=R(1.2), single_sweep=False, **kd)
+            ora = ox.DavisYinIteration(x0=x0, Lf=Lf, lam=R(1.2), **ko)
+            assert one._sweep is not None and two._sweep is None and not one.graph_safe and two.graph_safe
+            for k, (s1, s2, so) in enumerate(zip(one, two, ora)):
+                if k >= K:
+                    break
+                for fld in ("z", "xg", "xh", "res", "z_half", "grad_f_xg"):
+                    ref = getattr(so, fld)
+                    tol = (3e-4 if dtype == np.float32 else 1e-10) * max(1.0, float(np.max(np.abs(ref))))
+                    assert np.max(np.abs(getattr(s1, fld).numpy() - ref)) <= tol, (m, n, k, fld)
+                    assert np.max(np.abs(getattr(s1, fld).numpy() - getattr(s2, fld).numpy())) <= tol, (m, n, k, fld)
+                assert float(s1.res_inf) == pytest.approx(float(np.max(np.abs(so.res))), rel=1e-3, abs=1e-6)
+            assert one.counters["a_passes"] == 1 + (K + 1)
