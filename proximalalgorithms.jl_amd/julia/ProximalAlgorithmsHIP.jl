@@ -119,6 +119,36 @@ function HIPMatrix(A::Matrix{T}; ctx = default_ctx()) where {T}
     M
 end
 
+# mul!(y, A, x) / mul!(g, A', r) on the device matrix (panoc.jl:178,184 ...)
+function LinearAlgebra.mul!(y::HIPVector{T}, A::HIPMatrix{T}, x::HIPVector{T}) where {T}
+    check(ccall((:pg_mat_mul, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), A.handle, x.ptr, y.ptr)); y
+end
+function LinearAlgebra.mul!(g::HIPVector{T}, At::Adjoint{T,HIPMatrix{T}}, r::HIPVector{T}) where {T}
+    check(ccall((:pg_mat_mul_adjoint, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), parent(At).handle, r.ptr, g.ptr)); g
+end
+
+# The single sweep for x -> loss(A x) terms: At_r = A'r, y = x - gamma At_r, z = prox_{gamma g}(y), res = x - z and Az = A z in
+# ONE read of A (g_kind: 0 Zero, 1 NormL1(p0 = lam), 2 IndBox(p0 = lo, p1 = hi)); returns (g(z), norm(res, Inf), dot(At_r, res),
+# norm(res)^2).  This is what lets FB / FFB / Vu-Condat / LiLin on such terms run at one read of A per iteration.
+function fused_tn!(A::HIPMatrix{T}, r, x, gamma, g_kind, p0, p1, At_r, y, z, res, Az) where {T}
+    sc = zeros(Float64, 4)
+    check(ccall((:pg_mat_fused_tn, libpg), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),
+                A.handle, r.ptr, x.ptr, gamma, g_kind, p0, p1, At_r.ptr, y.ptr, z.ptr, res.ptr, Az.ptr, sc))
+    (sc[1], sc[2], sc[3], sc[4])
+end
+
+# One Davis-Yin iteration (davis_yin.jl:73-83) in ONE read of A; prox kinds as above plus 3 = SqrNormL2(p0 = lam)
+function fused_dys!(A::HIPMatrix{T}, r, xg, z, gamma, relax, g_spec, h_spec, grad, z_half, xh, res, z_next, xg_next, A_xg_next) where {T}
+    sc = zeros(Float64, 4)
+    check(ccall((:pg_mat_fused_dys, libpg), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int32, Float64, Float64, Int32, Float64, Float64,
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),
+                A.handle, r.ptr, xg.ptr, z.ptr, gamma, relax, g_spec[1], g_spec[2], g_spec[3], h_spec[1], h_spec[2], h_spec[3],
+                grad.ptr, z_half.ptr, xh.ptr, res.ptr, z_next.ptr, xg_next.ptr, A_xg_next.ptr, sc))
+    (sc[2], sc[3], sc[4])
+end
+
 # f(x) = lam/2 ||A x - b||^2 : replaces ProximalOperators.LeastSquares + benchmark/benchmarks.jl:11-17
 mutable struct HIPLeastSquares{T}
     A::HIPMatrix{T}
@@ -297,6 +327,7 @@ function hip_douglas_rachford(d, q, g, x0::Vector{T}; gamma, maxit = 1_000, tol 
 end
 
 export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
-       HIPForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve, hip_douglas_rachford
+       HIPForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve, hip_douglas_rachford,
+       fused_tn!, fused_dys!
 
 end # module
