@@ -384,6 +384,15 @@ pg_status pg_lbfgs_destroy(pg_lbfgs* L);
 pg_status pg_lbfgs_update(pg_lbfgs* L, const void* s, const void* y); /* update!  lbfgs.jl:30-50 */
 pg_status pg_lbfgs_reset(pg_lbfgs* L);                               /* reset!   lbfgs.jl:52-55 */
 pg_status pg_lbfgs_apply(pg_lbfgs* L, void* d, const void* v);       /* mul!     lbfgs.jl:64-95 */
+/* Images of the stored pairs under a linear map A (m rows): with A s_i and A y_i kept next to s_i, y_i, the image of the
+ * quasi-Newton direction, A (H v), follows from A v and the two-loop coefficients of the LAST pg_lbfgs_apply without
+ * reading A:  A d = H0 (A v - sum alpha_i A y_i) + sum (alpha_i - beta_i) A s_i.  This removes the `mul!(Ad, A, d)` of
+ * panoc.jl:178 (PANOC then reads A once per accepted step).  _enable(m) allocates the image slab; _update(As, Ay) must
+ * follow every pg_lbfgs_update with the images of the same pair (ignored when the pair was rejected, <s, y> <= 0);
+ * _apply(Ad, Av) must follow the pg_lbfgs_apply whose direction it maps. */
+pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m);
+pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay);
+pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av);
 
 #ifdef __cplusplus
 }

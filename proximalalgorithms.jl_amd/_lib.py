@@ -128,6 +128,9 @@ SIGNATURES = {
     "pg_lbfgs_update": [_vp, _vp, _vp],
     "pg_lbfgs_reset": [_vp],
     "pg_lbfgs_apply": [_vp, _vp, _vp],
+    "pg_lbfgs_images_enable": [_vp, _i64],
+    "pg_lbfgs_images_update": [_vp, _vp, _vp],
+    "pg_lbfgs_images_apply": [_vp, _vp, _vp],
 }
 _SPECIAL = {"pg_abi_version": ([], C.c_int32), "pg_last_error": ([], C.c_char_p)}
 

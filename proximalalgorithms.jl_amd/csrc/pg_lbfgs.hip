@@ -17,8 +17,17 @@ struct pg_lbfgs {
   void** s_M = nullptr;
   void** y_M = nullptr;
   double* ys_M = nullptr;   // host copy (lbfgs.jl:11)
-  double* dcoef = nullptr;  // device: alphas[M] ++ beta ++ scratch[2]
+  double* dcoef = nullptr;  // device: alphas[M] ++ betas[M] ++ scratch[4]
   double H = 1.0;
+  // images under a linear map A (pg_lbfgs_images_*): A s_i, A y_i of the stored pairs, so that A (H v) follows from A v
+  // and the two-loop coefficients without reading A -- d = H0 (v - sum alpha_i y_i) + sum (alpha_i - beta_i) s_i
+  int64_t img_m = 0;
+  void* img_slab = nullptr;  // As_M[M], Ay_M[M]
+  size_t img_vb = 0;
+  bool last_update_accepted = false;
+  int last_k = 0;        // currmem of the last apply
+  int last_idx[64];      // its loop order (newest -> oldest, 1-based slots)
+  double last_H = 1.0;
 };
 
 namespace {
@@ -90,7 +99,7 @@ pg_status axpy_dot(pg_lbfgs* L, void* d_out, const void* d_in, int mode, int a_i
 template <typename T>
 pg_status lbfgs_apply_t(pg_lbfgs* L, void* d, const void* v) {
   const int M = L->M, k = L->currmem;
-  const int BETA = M;
+  const int BETA = M;  // betas[M] follow alphas[M] in dcoef
   const double H = (double)(T)L->H;
   if (k == 0)  // d .= v ; d .*= H
     return axpy_dot<T>(L, d, v, 0, 0, 0, nullptr, H, nullptr, 0, 1.0);
@@ -113,21 +122,60 @@ pg_status lbfgs_apply_t(pg_lbfgs* L, void* d, const void* v) {
       const int nx = idx[t + 1] - 1;
       PG_TRY((axpy_dot<T>(L, d, din, 1, i, 0, L->y_M[i], 1.0, L->s_M[nx], nx, L->ys_M[nx])));
     } else {  // last of loop1: d -= alpha_i y_i ; d *= H (:67) ; beta = <y_i, d> / ys_i (first of loop2 :85-95)
-      PG_TRY((axpy_dot<T>(L, d, din, 1, i, 0, L->y_M[i], H, L->y_M[i], BETA, L->ys_M[i])));
+      PG_TRY((axpy_dot<T>(L, d, din, 1, i, 0, L->y_M[i], H, L->y_M[i], BETA + i, L->ys_M[i])));
     }
   }
   for (int t = k - 1; t >= 0; --t) {  // loop2 oldest -> newest
     const int i = idx[t] - 1;
-    if (t > 0) {  // d += (alpha_i - beta) s_i ; beta' = <y_next, d> / ys_next
+    // every step's beta has its own slot (betas[slot of the pair]): nothing is overwritten while a kernel still reads it,
+    // and the whole coefficient set survives the recursion (pg_lbfgs_images_apply reuses it)
+    if (t > 0) {  // d += (alpha_i - beta_i) s_i ; beta_next = <y_next, d> / ys_next
       const int nx = idx[t - 1] - 1;
-      // beta' must not overwrite beta while this kernel still reads it: alternate two slots
-      const int bslot_in = BETA + ((k - 1 - t) & 1), bslot_out = BETA + (((k - 1 - t) + 1) & 1);
-      PG_TRY((axpy_dot<T>(L, d, d, 2, i, bslot_in, L->s_M[i], 1.0, L->y_M[nx], bslot_out, L->ys_M[nx])));
+      PG_TRY((axpy_dot<T>(L, d, d, 2, i, BETA + i, L->s_M[i], 1.0, L->y_M[nx], BETA + nx, L->ys_M[nx])));
     } else {
-      const int bslot_in = BETA + ((k - 1 - t) & 1);
-      PG_TRY((axpy_dot<T>(L, d, d, 2, i, bslot_in, L->s_M[i], 1.0, nullptr, 0, 1.0)));
+      PG_TRY((axpy_dot<T>(L, d, d, 2, i, BETA + i, L->s_M[i], 1.0, nullptr, 0, 1.0)));
     }
   }
+  L->last_k = k;
+  for (int t = 0; t < k; ++t) L->last_idx[t] = idx[t];
+  L->last_H = H;
+  return PG_OK;
+}
+
+// Ad[i] = H (Av[i] - sum_t alpha_t Ay_t[i]) + sum_t (alpha_t - beta_t) As_t[i] with the coefficients the last apply left
+// on the device: the image of d = H v under the linear map the stored images belong to
+struct ImgOrder {
+  int k;
+  int idx[64];  // 0-based slots, newest -> oldest
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void lbfgs_image_kernel(T* __restrict__ Ad, const T* __restrict__ Av, const T* __restrict__ As,
+                                                         const T* __restrict__ Ay, int64_t stride, int64_t m, int M,
+                                                         const double* __restrict__ coef, T H, ImgOrder ord) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+    T acc = Av[i];
+    for (int t = 0; t < ord.k; ++t) acc -= (T)coef[ord.idx[t]] * Ay[(int64_t)ord.idx[t] * stride + i];
+    acc *= H;
+    for (int t = ord.k - 1; t >= 0; --t)
+      acc += ((T)coef[ord.idx[t]] - (T)coef[M + ord.idx[t]]) * As[(int64_t)ord.idx[t] * stride + i];
+    Ad[i] = acc;
+  }
+}
+
+template <typename T>
+pg_status lbfgs_images_apply_t(pg_lbfgs* L, void* Ad, const void* Av) {
+  ImgOrder ord;
+  ord.k = L->last_k;
+  for (int t = 0; t < ord.k; ++t) ord.idx[t] = L->last_idx[t] - 1;
+  const int64_t stride = (int64_t)(L->img_vb / sizeof(T));
+  int64_t blocks = (L->img_m + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(lbfgs_image_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, L->ctx->stream, (T*)Ad, (const T*)Av,
+                     (const T*)L->img_slab, (const T*)((char*)L->img_slab + (size_t)L->M * L->img_vb), stride, L->img_m, L->M,
+                     (const double*)L->dcoef, (T)L->last_H, ord);
+  PG_LAUNCH_CHECK();
   return PG_OK;
 }
 
@@ -143,6 +191,7 @@ pg_status lbfgs_update_t(pg_lbfgs* L, const void* s, const void* y) {
   PG_TRY((launch_ew<T, Dot2F<T>, 2, 0u>(c, L->n, true, f, c->dscal + PG_S_MISC)));
   PG_TRY(pg_read_scalars(c, PG_S_MISC, 2));
   const T ys = (T)c->hscal[PG_S_MISC], yty = (T)c->hscal[PG_S_MISC + 1];
+  L->last_update_accepted = ys > T(0);
   if (ys > T(0)) {  // :34-49
     L->curridx += 1;
     if (L->curridx > L->M) L->curridx = 1;
@@ -176,13 +225,13 @@ pg_status pg_lbfgs_create(pg_ctx* c, int32_t dtype, int32_t M, int64_t n, pg_lbf
   const size_t vb = (size_t)pg_round_up((int64_t)((size_t)(n > 0 ? n : 1) * pg_sizeof(dtype)), 256);
   PG_HIP(hipSetDevice(c->device));
   if (hipMalloc(&L->slab, vb * (2 + 2 * (size_t)M)) != hipSuccess ||
-      hipMalloc((void**)&L->dcoef, sizeof(double) * (M + 4)) != hipSuccess) {
+      hipMalloc((void**)&L->dcoef, sizeof(double) * (2 * M + 4)) != hipSuccess) {
     pg_set_error("L-BFGS memory allocation failed (M=%d, n=%lld)", M, (long long)n);
     pg_lbfgs_destroy(L);
     return PG_ERR_ALLOC;
   }
   PG_HIP(hipMemsetAsync(L->slab, 0, vb * (2 + 2 * (size_t)M), c->stream));
-  PG_HIP(hipMemsetAsync(L->dcoef, 0, sizeof(double) * (M + 4), c->stream));
+  PG_HIP(hipMemsetAsync(L->dcoef, 0, sizeof(double) * (2 * M + 4), c->stream));
   char* base = (char*)L->slab;
   L->s = base;
   L->y = base + vb;
@@ -202,6 +251,7 @@ pg_status pg_lbfgs_destroy(pg_lbfgs* L) {
   if (L->slab || L->dcoef) (void)hipStreamSynchronize(L->ctx->stream);
   if (L->slab) (void)hipFree(L->slab);
   if (L->dcoef) (void)hipFree(L->dcoef);
+  if (L->img_slab) (void)hipFree(L->img_slab);
   delete[] L->s_M;
   delete[] L->y_M;
   delete[] L->ys_M;
@@ -220,7 +270,46 @@ pg_status pg_lbfgs_reset(pg_lbfgs* L) {  // lbfgs.jl:52-55
   L->currmem = 0;
   L->curridx = 0;
   L->H = 1.0;
+  L->last_k = 0;
+  L->last_H = 1.0;
   return PG_OK;
+}
+
+pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m) {
+  PG_REQUIRE(L != nullptr && m >= 0, "bad argument");
+  if (L->img_slab != nullptr && L->img_m == m) return PG_OK;
+  if (L->img_slab) {
+    (void)hipStreamSynchronize(L->ctx->stream);
+    (void)hipFree(L->img_slab);
+    L->img_slab = nullptr;
+  }
+  L->img_m = m;
+  L->img_vb = (size_t)pg_round_up((int64_t)((size_t)(m > 0 ? m : 1) * pg_sizeof(L->dtype)), 256);
+  if (hipMalloc(&L->img_slab, L->img_vb * 2 * (size_t)L->M) != hipSuccess) {
+    pg_set_error("L-BFGS image allocation failed (M=%d, m=%lld)", L->M, (long long)m);
+    return PG_ERR_ALLOC;
+  }
+  PG_HIP(hipMemsetAsync(L->img_slab, 0, L->img_vb * 2 * (size_t)L->M, L->ctx->stream));
+  return PG_OK;
+}
+
+pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay) {
+  PG_REQUIRE(L != nullptr && L->img_slab != nullptr, "images are not enabled");
+  PG_REQUIRE(L->img_m == 0 || (As != nullptr && Ay != nullptr), "null vector");
+  if (!L->last_update_accepted || L->curridx == 0 || L->img_m == 0) return PG_OK;  // the pair was not stored (<s, y> <= 0)
+  const size_t nb = (size_t)L->img_m * pg_sizeof(L->dtype);
+  char* base = (char*)L->img_slab;
+  PG_HIP(hipMemcpyAsync(base + (size_t)(L->curridx - 1) * L->img_vb, As, nb, hipMemcpyDeviceToDevice, L->ctx->stream));
+  PG_HIP(hipMemcpyAsync(base + ((size_t)L->M + (size_t)(L->curridx - 1)) * L->img_vb, Ay, nb, hipMemcpyDeviceToDevice,
+                        L->ctx->stream));
+  return PG_OK;
+}
+
+pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av) {
+  PG_REQUIRE(L != nullptr && L->img_slab != nullptr, "images are not enabled");
+  PG_REQUIRE(L->img_m == 0 || (Ad != nullptr && Av != nullptr), "null vector");
+  if (L->img_m == 0) return PG_OK;
+  return L->dtype == PG_F32 ? lbfgs_images_apply_t<float>(L, Ad, Av) : lbfgs_images_apply_t<double>(L, Ad, Av);
 }
 
 pg_status pg_lbfgs_apply(pg_lbfgs* L, void* d, const void* v) {

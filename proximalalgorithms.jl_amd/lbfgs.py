@@ -33,6 +33,21 @@ class LBFGSOperator:
         call("pg_lbfgs_apply", self._h, d.vp, v.vp)
         return d
 
+    # ---- images under a linear map (see include/proxgrad_hip.h: pg_lbfgs_images_*) ----
+    def images_enable(self, m):
+        call("pg_lbfgs_images_enable", self._h, int(m))
+        return self
+
+    def images_update_(self, As, Ay):
+        """to be called right after update_(s, y) with A s, A y"""
+        call("pg_lbfgs_images_update", self._h, As.vp, Ay.vp)
+        return self
+
+    def images_mul_(self, Ad, Av):
+        """to be called right after mul_(d, v): Ad = A d from A v"""
+        call("pg_lbfgs_images_apply", self._h, Ad.vp, Av.vp)
+        return Ad
+
     def __mul__(self, v):
         """L * v  lbfgs.jl:57-60"""
         return self.mul_(v.similar(), v)

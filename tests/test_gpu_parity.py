@@ -1560,3 +1560,34 @@ def test_fb_adaptive_least_squares_through_the_composed_sweep(pa, dtype):
     it_o = o.ForwardBackwardIteration(f=o.LeastSquares(A, b, 0.7), g=o.IndBox(-0.2, 0.3), x0=x0)
     for k, (sc, so) in enumerate(itertools.islice(zip(it_c, it_o), 15)):
         assert np.max(np.abs(sc.z.numpy() - so.z)) <= (2e-4 if dtype == np.float32 else 1e-10), k
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lbfgs_images_give_the_image_of_the_direction_without_reading_A(pa, dtype):
+    """pg_lbfgs_images_*: with A s_i, A y_i stored next to the pairs, A (H v) follows from A v and the two-loop coefficients
+    of the last apply -- checked against A.mul(H v), through memory wrap-around, a rejected pair and a reset."""
+    rng = np.random.default_rng(5)
+    m, n, M = 70, 300, 4
+    A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+    Ad = pa.HIPMatrix.from_numpy(A)
+    H = pa.LBFGSOperator(M, pa.HIPVector.zeros(n, dtype)).images_enable(m)
+    tol = 2e-4 if dtype == np.float32 else 1e-11
+
+    def check():
+        v = rng.standard_normal(n).astype(dtype)
+        vd = pa.HIPVector.from_numpy(v)
+        d = H.mul_(vd.similar(), vd)
+        img = H.images_mul_(pa.HIPVector.empty(m, dtype), Ad.mul(vd))
+        ref = Ad.mul(d).numpy()
+        assert np.max(np.abs(img.numpy() - ref)) <= tol * max(1.0, np.max(np.abs(ref)))
+
+    check()  # empty memory: d = v
+    for k in range(9):  # wraps around M = 4 twice
+        s = rng.standard_normal(n).astype(dtype)
+        y = (s + 0.3 * rng.standard_normal(n)).astype(dtype) if k != 5 else (-s).astype(dtype)  # k = 5: <s, y> < 0, rejected
+        sd, yd = pa.HIPVector.from_numpy(s), pa.HIPVector.from_numpy(y)
+        H.update_(sd, yd)
+        H.images_update_(Ad.mul(sd), Ad.mul(yd))
+        check()
+    H.reset_()
+    check()
