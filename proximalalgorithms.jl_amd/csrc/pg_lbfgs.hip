@@ -101,8 +101,11 @@ pg_status lbfgs_apply_t(pg_lbfgs* L, void* d, const void* v) {
   const int M = L->M, k = L->currmem;
   const int BETA = M;  // betas[M] follow alphas[M] in dcoef
   const double H = (double)(T)L->H;
-  if (k == 0)  // d .= v ; d .*= H
+  if (k == 0) {  // d .= v ; d .*= H
+    L->last_k = 0;
+    L->last_H = H;
     return axpy_dot<T>(L, d, v, 0, 0, 0, nullptr, H, nullptr, 0, 1.0);
+  }
   // order of loop1 (newest -> oldest): idx_t, t = 0..k-1   lbfgs.jl:72-83
   int idx[64];
   {
