@@ -177,7 +177,8 @@ pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
  * search, fb_tools.jl:43): for a caller-supplied m-vector r (= grad f(A x)),
  *   At_r = A' r ; y = x - gamma At_r ; z = prox_{gamma g}(y) ; res = x - z ; Az = A z
  * in ONE read of A.  scalars_out (host, may be NULL) = { g(z), norm(res, Inf), dot(At_r, res), norm(res)^2 }.
- * Unsharded matrices with m <= 32768 (f32) / 16384 (f64) rows; PG_ERR_UNSUPPORTED otherwise. */
+ * Unsharded matrices with m <= 262144 (f32) / 131072 (f64) rows (columns longer than 32768 / 16384 rows are split over
+ * teams of workgroups); PG_ERR_UNSUPPORTED otherwise. */
 pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
                           void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out);
 /* One Davis-Yin iteration (davis_yin.jl:73-83: prox!(xg, g, z); grad f(xg); z_half = 2 xg - z - gamma grad; prox!(xh, h,
@@ -212,7 +213,7 @@ pg_status pg_ls_residual_ptr(pg_ls* f, const void** r_out);
  *   grad = lam A' r ; y = x - gamma grad ; z_new = prox_{gamma g}(y) ; res = x - z_new ;
  *   v_next = z_new + beta (z_new - z_old) ; f's residual := A v_next - b.
  * A column's contribution to A v_next is accumulated while the column is still in registers, so A is read once.
- * Unsharded operators with m <= 32768 (f32) / 16384 (f64) rows; PG_ERR_UNSUPPORTED otherwise.
+ * Unsharded or column-sharded operators with m <= 262144 (f32) / 131072 (f64) rows; PG_ERR_UNSUPPORTED otherwise.
  * scalars_out (host, may be NULL) = { f(v_next), g(z_new), norm(res, Inf), dot(grad, res), norm(res)^2 }. */
 pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,
                            double g_p0, double g_p1, void* grad, void* y, void* z_new, void* res, void* v_next,
@@ -307,7 +308,7 @@ typedef struct pg_iter_opts {
                           * the line search already holds, (1+beta)(A z - b) - beta (A z_prev - b): 2 passes over A per
                           * iteration instead of 3 (the reference does 4); 0 = recompute A x like the reference */
   int32_t single_sweep;  /* 1 (default) = iterate with ONE read of A per iteration where the operator allows it
-                          * (pg_ls_fused_pass: unsharded, m <= 32768 f32 / 16384 f64 rows; FB / FFB with a fixed step, FFB
+                          * (pg_ls_fused_pass: unsharded, m <= 262144 f32 / 131072 f64 rows; FB / FFB with a fixed step, FFB
                           * with the adaptive step and reuse_residual): the sweep that forms A' r also applies the prox
                           * to each finished column and accumulates the NEXT residual from it while it is in registers.
                           * Same iterates up to summation order.  0 = two sweeps (A x, then A' r) like the reference. */

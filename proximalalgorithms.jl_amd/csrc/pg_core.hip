@@ -309,6 +309,11 @@ pg_status pg_read_scalars(pg_ctx* c, int first, int count) {
   (void)count;
   if (c->capturing) return PG_OK;  // recorded, not run: the caller's scalars are placeholders
   PG_HIP(hipStreamSynchronize(c->stream));
+  if (c->hscal[PG_S_TEAMERR] != 0.0) {  // a workgroup team of the long-column sweep gave up waiting (pg_gemv_tn2.hip)
+    c->hscal[PG_S_TEAMERR] = 0.0;
+    pg_set_error("single-sweep pass: a workgroup team timed out waiting for a member (device shared with another job?)");
+    return PG_ERR_HIP;
+  }
   return PG_OK;
 }
 
@@ -432,6 +437,7 @@ pg_status pg_mat_destroy(pg_mat* A) {
   if (A->data) (void)hipFree(A->data);
   if (A->partials) (void)hipFree(A->partials);
   if (A->rpad) (void)hipFree(A->rpad);
+  if (A->xch) (void)hipFree(A->xch);
   delete A;
   return PG_OK;
 }

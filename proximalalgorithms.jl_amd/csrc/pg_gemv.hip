@@ -12,33 +12,14 @@
 //   pass TN (single sweep): g = A' r, then per finished column the prox step and the column's contribution to the
 //                          NEXT residual while it is still in registers -- A read once per iteration
 //                          (pg_ls_fused_pass / pg_mat_fused_tn; column shards: one all-reduce of m + 4 N elements).
-#include <cstdlib>
+//                          (pg_ls_fused_pass / pg_mat_fused_tn; column shards: one all-reduce of m + 4 N elements).
+//                          Three geometries by column length: gemv_tnw (short), gemv_tn (pg_gemv_tn.h), gemv_tnt
+//                          (long: teams of workgroups) -- see launch_tn.
+#include "pg_gemv_tn.h"
 
-#include "pg_internal.h"
+using namespace pgtn;
 
 namespace {
-
-constexpr int WAVE = 64;
-
-template <typename V>
-__device__ __forceinline__ V nt_load(const V* p) {
-  return __builtin_nontemporal_load(p);
-}
-
-// Wave-wide sum in every lane.  The four intra-row steps are DPP moves (no LDS round trip): quad_perm xor 1 and
-// xor 2, then row_half_mirror / row_mirror (lane i <-> 7-i / 15-i: after the quad steps every lane of a quad holds
-// the quad sum, so the mirrored partner contributes exactly the other quad / the other half-row); the two
-// cross-row steps (xor 16, xor 32) go through ds_bpermute.  Fixed order => deterministic.
-template <typename T>
-__device__ __forceinline__ T wave_allsum(T v) {
-  v += pg_dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  (xor 1)
-  v += pg_dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  (xor 2)
-  v += pg_dpp_mov<0x141>(v);  // row_half_mirror
-  v += pg_dpp_mov<0x140>(v);  // row_mirror
-  v += pg_shfl_xor(v, 16);
-  v += pg_shfl_xor(v, 32);
-  return v;
-}
 
 // -------------------------------------------------------------------------------------------------
 // pass N, stage 1: partials[slot][i] = sum_{j in columns of slot} A[i, j] * x[j]
@@ -116,55 +97,6 @@ __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const T* __restrict
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (r < r_eff) *reinterpret_cast<V*>(p + r * (WAVE * VEC)) = acc[r];
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// pass N, stage 2: y[i] = sum_s partials[s][i] - b[i]   (i < m; fixed summation order, fp64), optional
-// f = f_scale * sum_i y[i]^2 -> f_out (+ typed copy for the all-reduce payload).
-// 1024 threads = 64 rows x 16 slot groups; row groups are grid-strided.
-// -------------------------------------------------------------------------------------------------
-template <typename T, bool WITH_F>
-__global__ __launch_bounds__(1024) void gemv_n_finish_kernel(const T* __restrict__ partials, int64_t ld, int64_t m,
-                                                             int S, const T* __restrict__ b, T* __restrict__ y,
-                                                             int64_t y_len, double f_scale,
-                                                             double* __restrict__ red_partials,
-                                                             unsigned* __restrict__ red_counter,
-                                                             double* __restrict__ f_out, T* __restrict__ f_out_typed) {
-  __shared__ double sm_rows[16][64];
-  const int rx = threadIdx.x & 63;
-  const int sg = threadIdx.x >> 6;
-  double sq = 0.0;
-  for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < ld; row0 += (int64_t)gridDim.x * 64) {
-    const int64_t i = row0 + rx;
-    double acc = 0.0;
-    if (i < ld) {
-      for (int s = sg; s < S; s += 16) acc += (double)partials[(int64_t)s * ld + i];
-    }
-    sm_rows[sg][rx] = acc;
-    __syncthreads();
-    if (sg == 0) {
-      double v = sm_rows[0][rx];
-#pragma unroll
-      for (int k = 1; k < 16; ++k) v += sm_rows[k][rx];
-      T out = T(0);
-      if (i < m) {
-        if (b != nullptr) v -= (double)b[i];
-        out = (T)v;
-        sq += (double)out * (double)out;
-      }
-      if (i < y_len) y[i] = out;
-    }
-    __syncthreads();
-  }
-  if constexpr (WITH_F) {
-    // wave 0 holds the row contributions; all 16 waves take part in the grid reduction
-    double v[1] = {sg == 0 ? sq : 0.0};
-    const double ps[1] = {f_scale};
-    double fin[1];
-    const bool last = grid_reduce_finalize<1, 0u, 16>(v, red_partials, red_counter, f_out, ps, fin);
-    // mirror f in working precision (slot n of the all-reduce payload)
-    if (last && threadIdx.x == 0 && f_out_typed != nullptr) *f_out_typed = (T)fin[0];
   }
 }
 
@@ -249,233 +181,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict_
   }
 }
 
-// -------------------------------------------------------------------------------------------------
-// pass TN: ONE sweep over A for BOTH orientations of a proximal-gradient iteration (unsharded operator).
-// For a column j everything the next residual needs from it is known as soon as g_j = A_j' r is:
-//     g_j -> y_j = x_j - gamma g_j -> z_j = prox(y_j) -> res_j = x_j - z_j -> v_j = z_j + beta (z_j - zold_j)
-// (forward_backward.jl:117-120 / fast_forward_backward.jl:140-142 followed by :135 of the NEXT iteration), so
-// A_j v_j is accumulated while the column is still in registers and A is read once per iteration instead of twice.
-// A workgroup's WAVES waves share every column: wave w owns the 1 KiB row groups w * U + u (u < U) -- its slice
-// of r and of the next residual live in registers for the whole kernel (no LDS staging) -- and the C column dot
-// products of a step meet in LDS (one workgroup barrier per step, fixed summation order).  Each workgroup leaves
-// a partial of A v in partials[blockIdx.x], reduced by gemv_n_finish_kernel like pass N's slots; thread c of the
-// workgroup writes column c's outputs and accumulates the epilogue scalars for the grid reduction.
-// -------------------------------------------------------------------------------------------------
-// row group owned by (wave, u): every wave streams a CONTIGUOUS run of U KiB of each column (measured +1.3 % over
-// interleaving the waves' row groups: longer bursts per wave)
-#define TN_RG(u, wave, U, WAVES) ((wave) * (U) + (u))
-
-template <typename T>
-struct TNArgs {
-  const T* A;
-  int64_t ld, n, m;
-  int nrg;  // 1 KiB row groups of a column
-  const T* r;      // [ld] A x - b (lam not applied)
-  const T* x;      // [n]
-  const T* z_old;  // [n] the prox output of the previous iteration (for v); may alias nothing written here
-  T gamma, beta, p0, p1, lam_ls;  // p0 = gamma * lam (NormL1) | lo (IndBox) ; p1 = hi
-  int g_kind;
-  double gscale;  // lam for NormL1 else 0
-  T *g_out, *y, *z_new, *res, *v_out;  // [n] each
-  T* partials;                         // [gridDim.x][ld]
-  double* red_partials;
-  unsigned* red_counter;
-  double* scal_out;  // 4 doubles: g(z), ||res||_inf, <g, res>, ||res||^2
-  // Davis-Yin mode (MODE = 1): x = xg (the prox_g point the gradient was taken at), z_old = the splitting variable z;
-  // per column  z_half = 2 xg - z - gamma g ; xh = prox_{gamma h}(z_half) ; res = xh - xg ; z+ = z + relax res ;
-  // xg+ = prox_{gamma g}(z+)  -- outputs y = z_half, xh_out = xh, res, v_out = z+, z_new = xg+ ; A xg+ is accumulated
-  int h_kind = 0;
-  T h_p0 = T(0), h_p1 = T(0), relax = T(1);  // h_p0 = gamma * lam (NormL1) | lo (IndBox) | 1 / (1 + lam gamma) (SqrNormL2)
-  T* xh_out = nullptr;
-};
-
-// in-kernel prox kinds: PG_G_ZERO / PG_G_NORML1 / PG_G_INDBOX and, for the second operator of the Davis-Yin mode,
-// PG_G_SQRNORML2 (p0 = the scaling 1 / (1 + lam gamma))
-template <typename T>
-__device__ __forceinline__ T tn_prox(int kind, T y, T p0, T p1) {
-  if (kind == PG_G_NORML1) return y <= -p0 ? y + p0 : (y >= p0 ? y - p0 : T(0));
-  if (kind == PG_G_INDBOX) return fmin(p1, fmax(p0, y));
-  if (kind == PG_G_SQRNORML2) return y * p0;
-  return y;
-}
-
-template <typename T, int U, int C, int WAVES>
-struct TNTile {
-  using V = typename VecOf<T>::type;
-  static constexpr int VEC = VecOf<T>::N;
-  V col[C][U];
-
-  // this wave's row groups wave * U + u of the C columns of group cg
-  __device__ __forceinline__ void load(const TNArgs<T>& a, int64_t cg, int wave, int lane) {
-    const int64_t j0 = cg * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
-      const T* __restrict__ p = a.A + j * a.ld + lane * VEC;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int rg = TN_RG(u, wave, U, WAVES);
-        if (rg < a.nrg) {
-          col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rg * (WAVE * VEC)));
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) col[c][u][e] = T(0);
-        }
-      }
-    }
-  }
-};
-
-template <typename T, int U, int C, int WAVES, bool DOUBLE_BUFFER, int MODE = 0>
-__global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
-  using V = typename VecOf<T>::type;
-  constexpr int VEC = VecOf<T>::N;
-  __shared__ T sm_dot[2][C][WAVES];
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t ncg = (a.n + C - 1) / C;
-
-  // this wave's rows: row groups rg(u) = wave * U + u
-  V rk[U], racc[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int rg = TN_RG(u, wave, U, WAVES);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
-    if (rg < a.nrg) {
-      rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)rg * (WAVE * VEC) + lane * VEC);
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) rk[u][e] = T(0);
-    }
-  }
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-
-  // one column group: dot products -> workgroup totals (fixed wave order) -> epilogue -> next-residual accumulation
-  auto process = [&](const TNTile<T, U, C, WAVES>& t, int64_t cg, int buf) {
-    const int64_t j0 = cg * C;
-    // the per-column scalars are fetched before the barrier so that their latency hides behind the dot products
-    T xs[C], zos[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
-      xs[c] = a.x[jc];
-      zos[c] = a.z_old[jc];
-    }
-    T dot[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      T d = T(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) d = fma(t.col[c][u][e], rk[u][e], d);
-      }
-      dot[c] = wave_allsum(d);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) sm_dot[buf][c][wave] = dot[c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      T g = sm_dot[buf][c][0];
-#pragma unroll
-      for (int w = 1; w < WAVES; ++w) g += sm_dot[buf][c][w];
-      const int64_t j = j0 + c;
-      const bool valid = j < a.n;
-      if (a.lam_ls != T(1)) g = a.lam_ls * g;
-      const T xj = xs[c], zo = zos[c];
-      T vj;
-      if constexpr (MODE == 1) {  // Davis-Yin: davis_yin.jl:74-80 for column j, then the next prox_g point
-        const T zh = T(2) * xj - zo - a.gamma * g;
-        const T xh = tn_prox<T>(a.h_kind, zh, a.h_p0, a.h_p1);
-        const T rj = xh - xj;
-        const T zs = zo + a.relax * rj;
-        const T xg = tn_prox<T>(a.g_kind, zs, a.p0, a.p1);
-        vj = valid ? xg : T(0);
-        if ((int)threadIdx.x == c && valid) {
-          a.g_out[j] = g;
-          a.y[j] = zh;
-          a.xh_out[j] = xh;
-          a.res[j] = rj;
-          a.v_out[j] = zs;
-          a.z_new[j] = xg;
-          acc[1] = fmax(acc[1], fabs((double)rj));
-          acc[2] += (double)g * (double)rj;
-          acc[3] += (double)rj * (double)rj;
-        }
-      } else {
-        const T yj = xj - a.gamma * g;
-        T zj;
-        if (a.g_kind == PG_G_NORML1)
-          zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-        else if (a.g_kind == PG_G_INDBOX)
-          zj = fmin(a.p1, fmax(a.p0, yj));
-        else
-          zj = yj;
-        const T rj = xj - zj;
-        vj = valid ? zj + a.beta * (zj - zo) : T(0);
-        if ((int)threadIdx.x == c && valid) {
-          a.g_out[j] = g;
-          a.y[j] = yj;
-          a.z_new[j] = zj;
-          a.res[j] = rj;
-          if (a.v_out != nullptr) a.v_out[j] = vj;
-          if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
-          acc[1] = fmax(acc[1], fabs((double)rj));
-          acc[2] += (double)g * (double)rj;
-          acc[3] += (double)rj * (double)rj;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) racc[u][e] = fma(t.col[c][u][e], vj, racc[u][e]);
-      }
-    }
-  };
-
-  // two register tiles: the loads of the next column group are in flight while the current one is reduced, exchanged
-  // through LDS and folded into the next residual (the kernel would otherwise idle the memory system at every barrier)
-  if constexpr (DOUBLE_BUFFER) {
-    TNTile<T, U, C, WAVES> ta, tb;
-    // column groups are strided across the grid: all workgroups sweep one moving window of A.  (A blocked assignment --
-    // every workgroup streaming its own contiguous region -- measured 3 % faster on a freshly booted device and 3-10 %
-    // slower, alternating from process to process, on others: 256 far-apart streams depend on how the 64 GiB
-    // allocation happens to be mapped.  The strided form is stable to 0.5 %.)
-    const int64_t cnt = ncg > (int64_t)blockIdx.x ? (ncg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    auto at = [&](int64_t i) { return (int64_t)blockIdx.x + i * (int64_t)gridDim.x; };
-    int64_t i = 0;
-    if (i < cnt) ta.load(a, at(i), wave, lane);
-    while (i < cnt) {
-      if (i + 1 < cnt) tb.load(a, at(i + 1), wave, lane);
-      process(ta, at(i), 0);
-      if (i + 1 >= cnt) break;
-      if (i + 2 < cnt) ta.load(a, at(i + 2), wave, lane);
-      process(tb, at(i + 1), 1);
-      i += 2;
-    }
-  } else {  // 8-wave workgroups have half the registers per wave: one tile, two workgroups per CU overlap instead
-    TNTile<T, U, C, WAVES> t;
-    int buf = 0;
-    for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
-      t.load(a, cg, wave, lane);
-      process(t, cg, buf);
-      buf ^= 1;
-    }
-  }
-  T* part = a.partials + (int64_t)blockIdx.x * a.ld + lane * VEC;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int rg = TN_RG(u, wave, U, WAVES);
-    if (rg < a.nrg) *reinterpret_cast<V*>(part + (int64_t)rg * (WAVE * VEC)) = racc[u];
-  }
-  const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
-  grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
-}
-
 // g[j] = sum_k chunks[k][j]
 template <typename T>
 __global__ __launch_bounds__(256) void sum_chunks_kernel(const T* __restrict__ chunks, int nchunks, int64_t n,
@@ -498,6 +203,10 @@ __global__ void cast_scalar_kernel(const T* __restrict__ in, double* __restrict_
 constexpr int64_t LDS_R_BYTES = 128 * 1024;
 constexpr int64_t LDS_DEFAULT_LIMIT = 64 * 1024;
 
+// columns of up to this many 1 KiB row groups take the one-wave-per-column-group sweep (gemv_tnw_kernel); 0 = never.
+// Set from the sweeps in profiles/r2_tune_tn_short_columns.log
+constexpr int PG_TN_WAVE_MAX_RG = 8;
+
 // ----------------------------------------------------------------------------------------------
 // host-side launch planning
 // ----------------------------------------------------------------------------------------------
@@ -505,10 +214,6 @@ struct PlanN {
   int R, U, TW, n_rowgroups, n_tiles, n_tile_groups, S, S_eff;
 };
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 // Launch geometry of pass N.  Tunables (environment, for experiments): PG_N_R, PG_N_U, PG_N_TW, PG_N_WAVES_PER_CU.
 PlanN plan_n(const pg_mat* A) {
@@ -553,22 +258,6 @@ PlanN plan_n(const pg_mat* A) {
   return p;
 }
 
-pg_status ensure_partials(pg_mat* A, int S) {
-  if (A->partials && A->partials_slots >= S) return PG_OK;
-  if (A->partials) {
-    PG_HIP(hipStreamSynchronize(A->ctx->stream));
-    PG_HIP(hipFree(A->partials));
-    A->partials = nullptr;
-  }
-  const size_t bytes = (size_t)S * (size_t)A->ld * pg_sizeof(A->dtype);
-  hipError_t e = hipMalloc(&A->partials, bytes);
-  if (e != hipSuccess) {
-    pg_set_error("hipMalloc(%zu) for GEMV partial sums failed: %s", bytes, hipGetErrorString(e));
-    return PG_ERR_ALLOC;
-  }
-  A->partials_slots = S;
-  return PG_OK;
-}
 
 template <typename T, int R, int U>
 pg_status launch_n_ru(pg_mat* A, const PlanN& p, const T* x) {
@@ -774,41 +463,30 @@ pg_status gemv_t(pg_mat* A, const T* r, T* g, T** gchunks_ws) {
   return PG_OK;
 }
 
-// ---- pass TN launcher ------------------------------------------------------------------------------------------
-// Tunables (environment, for experiments): PG_TN_C (columns per step), PG_TN_BLOCKS_PER_CU, PG_TN_BLOCKS.
-template <typename T, int U, int C, int WAVES, int MODE = 0>
-pg_status launch_tn_ucw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
-  pg_ctx* c = A->ctx;
-  const int64_t ncg = (A->n + C - 1) / C;
-  // workgroups per CU (measured, scripts/tune_tn.py): one for the big double-buffered tiles, two for 4-wave short
-  // columns, four / eight for the 2- and 1-wave workgroups of very short columns
-  const int bpc_default = WAVES == 1 ? 8 : WAVES == 2 ? 4 : (((WAVES == 4 && U >= 8) || (WAVES == 8 && U == 4)) ? 1 : 2);
-  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TN_BLOCKS_PER_CU", bpc_default);
-  if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
-  if (blocks > ncg) blocks = ncg;
-  if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
-  if (blocks < 1) blocks = 1;
-  PG_TRY(ensure_partials(A, (int)blocks));
-  a.partials = (T*)A->partials;
-  *blocks_out = (int)blocks;
-  pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES, (WAVES <= 4), MODE>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
-                     c->stream, a);
-  PG_LAUNCH_CHECK();
-  return PG_OK;
-}
 
-// true when the shape is covered: every wave keeps U <= 16 row groups of r and of the next residual in registers
+// true when a single-sweep geometry covers the shape: one wave per column group (<= 8 row groups), one workgroup (<= 128)
+// or a team of up to 16 workgroups (<= 1024 row groups: 262144 rows in Float32, 131072 in Float64)
 template <typename T>
 bool tn_supported(const pg_mat* A) {
   const int64_t rows_per_rg = 1024 / (int64_t)sizeof(T);
   const int64_t nrg = A->ld / rows_per_rg;
-  return A->m > 0 && A->n > 0 && nrg <= 16 * 8;
+  return A->m > 0 && A->n > 0 && (tn_single_wg_supported<T>(A) || tn_team_covers((int)nrg));
 }
 
-template <typename T, int MODE = 0>
+// Geometry of the single sweep by column length.  PG_TN_KERNEL = wave | wg | team forces one (experiments, tests).
+template <typename T>
 pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int nrg = a.nrg;
+  const char* force = getenv("PG_TN_KERNEL");
+  const bool single_ok = tn_single_wg_supported<T>(A);
+  if (force != nullptr && *force) {
+    if (force[0] == 'w' && force[1] == 'a' && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
+    if (force[0] == 't' && tn_team_covers(nrg)) return launch_tn_team<T>(A, a, blocks_out);
+  } else {
+    if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
+    if (nrg <= PG_TN_WAVE_MAX_RG && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
+  }
+  if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
   // 17..32 row groups (m = 8192 in Float32): eight waves of U = 4 with C = 8 columns per step measured 4 % faster than four
   // waves of U = 8 (775 vs 742 it/s on 8192 x 262144, profiles/r1_tune_tn_geometry.log); 33..64 stay on four waves
   // very short columns (profiles/r1_tune_tn_short_columns.log): the fewer waves share a column, the fewer cross-wave
@@ -826,21 +504,6 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   if (W == 8 && U == 4 && env_int("PG_TN_C", 0) == 0) C = 8;
   if (W <= 2 && env_int("PG_TN_C", 0) == 0) C = (W == 2 && U == 4) ? 4 : (U == 1 ? 16 : 8);  // (2,4,4) (2,2,8) (1,2,8) (1,1,16)
   if (sizeof(T) == 8 && U == 1 && C > 16) C = 16;  // <f64, 1, 32> would spill
-  if constexpr (MODE == 1) {  // Davis-Yin mode: the default geometries only (no tuner variants)
-#define PG_TN_DYS(UU, CC, WW) \
-  if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW, 1>(A, a, blocks_out)
-    PG_TN_DYS(16, 2, 4);
-    PG_TN_DYS(16, 1, 8);
-    PG_TN_DYS(4, 8, 8);
-    PG_TN_DYS(4, 4, 4);
-    PG_TN_DYS(4, 4, 2);
-    PG_TN_DYS(2, 8, 2);
-    PG_TN_DYS(2, 8, 1);
-    PG_TN_DYS(1, 16, 1);
-#undef PG_TN_DYS
-    pg_set_error("no Davis-Yin sweep for U=%d C=%d WAVES=%d (launch-geometry overrides are not available in this mode)", U, C, W);
-    return PG_ERR_UNSUPPORTED;
-  }
 #define PG_TN_CASE(UU, CC, WW) \
   if (U == UU && C == CC && W == WW) return launch_tn_ucw<T, UU, CC, WW>(A, a, blocks_out)
   PG_TN_CASE(16, 1, 4);
@@ -1117,70 +780,6 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
   return PG_OK;
 }
 
-// One Davis-Yin iteration (davis_yin.jl:73-83) for f = loss o A in ONE read of A: given r = grad loss(A xg), the sweep forms
-// grad = A' r, z_half, xh = prox_{gamma h}, res, z+ = z + relax res, the NEXT xg+ = prox_{gamma g}(z+) and A xg+.
-template <typename T>
-pg_status mat_fused_dys_t(pg_mat* A, const T* r, const T* xg, const T* z, double gamma, double relax, int g_kind, double g_p0,
-                          double g_p1, int h_kind, double h_p0, double h_p1, T* grad, T* z_half, T* xh, T* res, T* z_next,
-                          T* xg_next, T* A_xg_next) {
-  pg_ctx* c = A->ctx;
-  if (pg_row_sharded(c) || pg_col_sharded(c) || !tn_supported<T>(A)) {
-    pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(128 * 1024 / sizeof(T)));
-    return PG_ERR_UNSUPPORTED;
-  }
-  if (A->rpad == nullptr) {
-    PG_HIP(hipMalloc(&A->rpad, (size_t)A->ld * sizeof(T)));
-    PG_HIP(hipMemsetAsync(A->rpad, 0, (size_t)A->ld * sizeof(T), c->stream));
-  }
-  PG_HIP(hipMemcpyAsync(A->rpad, r, (size_t)A->m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-  const T gm = (T)gamma;
-  auto scaled = [&](int kind, double p0) -> T {
-    if (kind == PG_G_NORML1) return (T)(gm * (T)p0);
-    if (kind == PG_G_SQRNORML2) return T(1) / (T(1) + (T)p0 * gm);
-    return (T)p0;
-  };
-  TNArgs<T> a;
-  a.A = (const T*)A->data;
-  a.ld = A->ld;
-  a.n = A->n;
-  a.m = A->m;
-  a.nrg = (int)(A->ld / (1024 / (int64_t)sizeof(T)));
-  a.r = (const T*)A->rpad;
-  a.x = xg;
-  a.z_old = z;
-  a.gamma = gm;
-  a.beta = T(0);
-  a.p0 = scaled(g_kind, g_p0);
-  a.p1 = (T)g_p1;
-  a.lam_ls = T(1);
-  a.g_kind = g_kind;
-  a.gscale = 0.0;
-  a.h_kind = h_kind;
-  a.h_p0 = scaled(h_kind, h_p0);
-  a.h_p1 = (T)h_p1;
-  a.relax = (T)relax;
-  a.g_out = grad;
-  a.y = z_half;
-  a.xh_out = xh;
-  a.res = res;
-  a.v_out = z_next;
-  a.z_new = xg_next;
-  a.partials = nullptr;
-  a.red_partials = c->red_partials;
-  a.red_counter = c->red_counter;
-  a.scal_out = c->dscal + PG_S_GZ;
-  int blocks = 0;
-  PG_TRY((launch_tn<T, 1>(A, a, &blocks)));
-  int64_t fb = (A->ld + 63) / 64;
-  if (fb > 1024) fb = 1024;
-  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
-  hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
-                     (const T*)A->partials, A->ld, A->m, blocks, (const T*)nullptr, A_xg_next, A->m, 0.0, (double*)nullptr,
-                     (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
-  PG_LAUNCH_CHECK();
-  return PG_OK;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ v, int64_t n, T a) {
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) v[j] *= a;
@@ -1375,28 +974,6 @@ pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma,
                                                     (float*)At_r, (float*)y, (float*)z, (float*)res, (float*)Az)
                             : mat_fused_tn_t<double>(A, (const double*)r, (const double*)x, gamma, g_kind, g_p0, g_p1,
                                                      (double*)At_r, (double*)y, (double*)z, (double*)res, (double*)Az));
-  if (scalars_out) {
-    PG_TRY(pg_read_scalars(A->ctx, PG_S_GZ, 4));
-    for (int k = 0; k < 4; ++k) scalars_out[k] = A->ctx->hscal[PG_S_GZ + k];
-  }
-  return PG_OK;
-}
-
-pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void* z, double gamma, double relax,
-                           int32_t g_kind, double g_p0, double g_p1, int32_t h_kind, double h_p0, double h_p1, void* grad,
-                           void* z_half, void* xh, void* res, void* z_next, void* xg_next, void* A_xg_next,
-                           double* scalars_out) {
-  PG_REQUIRE(A != nullptr, "matrix is null");
-  PG_REQUIRE(r && xg && z && grad && z_half && xh && res && z_next && xg_next && A_xg_next, "null vector");
-  PG_REQUIRE(g_kind >= PG_G_ZERO && g_kind <= PG_G_SQRNORML2 && h_kind >= PG_G_ZERO && h_kind <= PG_G_SQRNORML2, "unknown prox kind");
-  PG_REQUIRE(gamma > 0, "gamma must be positive");
-  PG_TRY(A->dtype == PG_F32
-             ? mat_fused_dys_t<float>(A, (const float*)r, (const float*)xg, (const float*)z, gamma, relax, g_kind, g_p0, g_p1,
-                                      h_kind, h_p0, h_p1, (float*)grad, (float*)z_half, (float*)xh, (float*)res,
-                                      (float*)z_next, (float*)xg_next, (float*)A_xg_next)
-             : mat_fused_dys_t<double>(A, (const double*)r, (const double*)xg, (const double*)z, gamma, relax, g_kind, g_p0,
-                                       g_p1, h_kind, h_p0, h_p1, (double*)grad, (double*)z_half, (double*)xh, (double*)res,
-                                       (double*)z_next, (double*)xg_next, (double*)A_xg_next));
   if (scalars_out) {
     PG_TRY(pg_read_scalars(A->ctx, PG_S_GZ, 4));
     for (int k = 0; k < 4; ++k) scalars_out[k] = A->ctx->hscal[PG_S_GZ + k];

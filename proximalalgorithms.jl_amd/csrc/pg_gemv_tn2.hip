@@ -1,0 +1,695 @@
+// Two more geometries of the single-sweep pass (pass TN, see pg_gemv_tn.h), for the column lengths the
+// one-workgroup-per-column-group kernel serves badly or not at all:
+//
+//   gemv_tnw_kernel  SHORT columns (a column fits one wave's registers, <= 8 row groups): every wave works on its own
+//                    column groups -- no LDS exchange, no workgroup barrier in the loop.  The C per-column dot products
+//                    of a step are reduced ACROSS columns at once (a halving butterfly: v_permlane32_swap /
+//                    v_permlane16_swap / DPP row steps; ~C + 6 lane exchanges instead of 6 C), which leaves column c's
+//                    total in lane group c, so the forward-backward epilogue (fast_forward_backward.jl:140-142 and :135
+//                    of the next iteration) runs ONCE per column, lane-parallel, with coalesced loads / stores of the
+//                    n-vectors; v_j returns to the whole wave through v_readlane for the A v accumulation.
+//   gemv_tnt_kernel  LONG columns (more row groups than one workgroup's registers hold: m > 32768 in Float32): a TEAM of
+//                    workgroups splits the rows of every column.  Each member keeps its slice of r and of the next
+//                    residual in registers exactly like the one-workgroup kernel; the members' partial dots of a column
+//                    meet through a ring of tagged 8-byte granules in global memory (agent-scope stores / loads, one
+//                    granule = {value bits, step tag} so no fence is needed), every member forms the same total in the
+//                    same order, applies the prox and accumulates A v on its rows.  With LAG > 0 the exchange is taken
+//                    off the critical path: step i posts its partials and consumes the totals of step i - LAG, whose
+//                    column tile waited in LDS (128 KiB of the CU's 160 KiB).
+//
+// Same arithmetic as the reference's statement order up to summation order (benchmark/benchmarks.jl:15-16,
+// fast_forward_backward.jl:135-142); both are reached through launch_tn in pg_gemv.hip.
+#include <type_traits>
+
+#include "pg_gemv_tn.h"
+
+namespace pgtn {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// column-parallel wave reduction: d[0..C) per lane in, the total of column (lane / (64 / C)) in every lane out
+// ---------------------------------------------------------------------------------------------------------------
+// v_permlane32_swap: vdst[32:63] <-> vsrc[0:31] ; v_permlane16_swap: odd rows of vdst <-> even rows of vsrc (gfx950).
+// Inline assembly, not __builtin_amdgcn_permlane{32,16}_swap: with ROCm 7.2's compiler `r[0] + r[1]` on the builtin's
+// result pair compiles to `v_add_f32 v1, v1, v1` (the second output is lost) -- seen in the disassembly and as wrong Float32
+// results on the device.  The s_nop covers the VALU-write -> permlane-swap-read hazard the compiler would otherwise handle.
+__device__ __forceinline__ void lane_swap32(unsigned& x, unsigned& y) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(x), "+v"(y));
+}
+__device__ __forceinline__ void lane_swap16(unsigned& x, unsigned& y) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1" : "+v"(x), "+v"(y));
+}
+// lanes < 32: a(l) + a(l + 32) ; lanes >= 32: b(l - 32) + b(l)
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+  lane_swap32(x, y);
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+// rows 0, 2: a(row) + a(row + 1) ; rows 1, 3: b(row - 1) + b(row)
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+  lane_swap16(x, y);
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ double swap32_add(double a, double b) {
+  const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
+  unsigned xl = (unsigned)ab, yl = (unsigned)bb, xh = (unsigned)(ab >> 32), yh = (unsigned)(bb >> 32);
+  lane_swap32(xl, yl);
+  lane_swap32(xh, yh);
+  return __builtin_bit_cast(double, ((unsigned long long)xh << 32) | xl) +
+         __builtin_bit_cast(double, ((unsigned long long)yh << 32) | yl);
+}
+__device__ __forceinline__ double swap16_add(double a, double b) {
+  const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
+  unsigned xl = (unsigned)ab, yl = (unsigned)bb, xh = (unsigned)(ab >> 32), yh = (unsigned)(bb >> 32);
+  lane_swap16(xl, yl);
+  lane_swap16(xh, yh);
+  return __builtin_bit_cast(double, ((unsigned long long)xh << 32) | xl) +
+         __builtin_bit_cast(double, ((unsigned long long)yh << 32) | yl);
+}
+
+// One butterfly stage.  Stage s pairs lanes that differ in bit 5 - s (and, for the DPP mirrors, in lower bits as well):
+// a lane whose bit is 0 keeps `a` and receives its partner's `a`; a lane whose bit is 1 keeps `b` and receives `b`.
+// With a == b this is one step of a plain all-reduce.  Fixed pairing, commutative adds: deterministic, and all lanes
+// that end up with the same column hold the same bits.
+template <int STAGE, typename T>
+__device__ __forceinline__ T cr_combine(T a, T b, int lane) {
+  if constexpr (STAGE == 0) {
+    return swap32_add(a, b);
+  } else if constexpr (STAGE == 1) {
+    return swap16_add(a, b);
+  } else {
+    constexpr int BIT = 5 - STAGE;
+    const bool upper = ((lane >> BIT) & 1) != 0;
+    const T send = upper ? a : b, keep = upper ? b : a;
+    if constexpr (STAGE == 2) return keep + pg_dpp_mov<0x140>(send);       // row_mirror: lane ^ 15
+    else if constexpr (STAGE == 3) return keep + pg_dpp_mov<0x141>(send);  // row_half_mirror: lane ^ 7
+    else if constexpr (STAGE == 4) return keep + pg_dpp_mov<0x4E>(send);   // quad_perm [2,3,0,1]: lane ^ 2
+    else return keep + pg_dpp_mov<0xB1>(send);                             // quad_perm [1,0,3,2]: lane ^ 1
+  }
+}
+
+template <typename T, int CNT, int STAGE>
+__device__ __forceinline__ void cr_stage(T* d, int lane) {
+  if constexpr (STAGE < 6) {
+    if constexpr (CNT > 1) {
+#pragma unroll
+      for (int k = 0; k < CNT / 2; ++k) d[k] = cr_combine<STAGE>(d[k], d[k + CNT / 2], lane);
+      cr_stage<T, CNT / 2, STAGE + 1>(d, lane);
+    } else {
+      d[0] = cr_combine<STAGE>(d[0], d[0], lane);
+      cr_stage<T, 1, STAGE + 1>(d, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SHORT columns: one wave per column group
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int U, int C>
+struct WTile {
+  using V = typename VecOf<T>::type;
+  static constexpr int VEC = VecOf<T>::N;
+  V col[C][U];
+  __device__ __forceinline__ void load(const TNArgs<T>& a, int64_t cg, int lane) {
+    const int64_t j0 = cg * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
+      const T* __restrict__ p = a.A + j * a.ld + lane * VEC;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (u < a.nrg) {
+          col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)u * (WAVE * VEC)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) col[c][u][e] = T(0);
+        }
+      }
+    }
+  }
+};
+
+template <typename T, int U, int C, int WPB, bool DOUBLE_BUFFER>
+__global__ __launch_bounds__(WPB * 64) void gemv_tnw_kernel(TNArgs<T> a) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int G = 64 / C;  // lanes that hold the same column after the reduction
+  static_assert(C >= 2 && C <= 32 && (C & (C - 1)) == 0, "C must be a power of two in 2..32");
+  __shared__ V sm_acc[WPB > 1 ? WPB * U * WAVE : 1];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ncg = (a.n + C - 1) / C;
+  const int c_own = lane / G;
+  const bool lead = (lane % G) == 0;
+
+  V rk[U], racc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
+    if (u < a.nrg) {
+      rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)u * (WAVE * VEC) + lane * VEC);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rk[u][e] = T(0);
+    }
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+
+  auto process = [&](const WTile<T, U, C>& t, int64_t cg) {
+    const int64_t j = cg * C + c_own;
+    const bool valid = j < a.n;
+    const int64_t jc = valid ? j : (a.n - 1);
+    const T xj = a.x[jc], zo = a.z_old[jc];  // in flight during the dot products
+    T d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      T s = T(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s = fma(t.col[c][u][e], rk[u][e], s);
+      }
+      d[c] = s;
+    }
+    cr_stage<T, C, 0>(d, lane);
+    T g = d[0];  // = A_j' r for column j = cg * C + lane / G
+    if (a.lam_ls != T(1)) g = a.lam_ls * g;
+    const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
+    T zj;                            // :118 / :141
+    if (a.g_kind == PG_G_NORML1)
+      zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
+    else if (a.g_kind == PG_G_INDBOX)
+      zj = fmin(a.p1, fmax(a.p0, yj));
+    else
+      zj = yj;
+    const T rj = xj - zj;                                     // :120 / :142
+    const T vj = valid ? zj + a.beta * (zj - zo) : T(0);      // fast_forward_backward.jl:135 of the next iteration
+    if (lead && valid) {
+      a.g_out[j] = g;
+      a.y[j] = yj;
+      a.z_new[j] = zj;
+      a.res[j] = rj;
+      if (a.v_out != nullptr) a.v_out[j] = vj;
+      if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
+      acc[1] = fmax(acc[1], fabs((double)rj));
+      acc[2] += (double)g * (double)rj;
+      acc[3] += (double)rj * (double)rj;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const T vc = pg_readlane(vj, c * G);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) racc[u][e] = fma(t.col[c][u][e], vc, racc[u][e]);
+      }
+    }
+  };
+
+  // column groups are strided across all waves of the grid (one moving window over A, see gemv_tn_kernel)
+  const int64_t gw = (int64_t)blockIdx.x * WPB + wave, nw = (int64_t)gridDim.x * WPB;
+  const int64_t cnt = ncg > gw ? (ncg - gw + nw - 1) / nw : 0;
+  auto at = [&](int64_t i) { return gw + i * nw; };
+  if constexpr (DOUBLE_BUFFER) {
+    WTile<T, U, C> ta, tb;
+    int64_t i = 0;
+    if (i < cnt) ta.load(a, at(i), lane);
+    while (i < cnt) {
+      if (i + 1 < cnt) tb.load(a, at(i + 1), lane);
+      process(ta, at(i));
+      if (i + 1 >= cnt) break;
+      if (i + 2 < cnt) ta.load(a, at(i + 2), lane);
+      process(tb, at(i + 1));
+      i += 2;
+    }
+  } else {
+    WTile<T, U, C> t;
+    for (int64_t i = 0; i < cnt; ++i) {
+      t.load(a, at(i), lane);
+      process(t, at(i));
+    }
+  }
+  // this workgroup's partial of A v: the waves' accumulators are combined in wave order
+  T* part = a.partials + (int64_t)blockIdx.x * a.ld + lane * VEC;
+  if constexpr (WPB == 1) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)u * (WAVE * VEC)) = racc[u];
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) sm_acc[(wave * U + u) * WAVE + lane] = racc[u];
+    __syncthreads();
+    for (int u = wave; u < U; u += WPB) {
+      V s = sm_acc[u * WAVE + lane];
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) {
+        const V o = sm_acc[(w * U + u) * WAVE + lane];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += o[e];
+      }
+      if (u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)u * (WAVE * VEC)) = s;
+    }
+  }
+  const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
+  grid_reduce_finalize<4, 0x2u, WPB>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
+}
+
+template <typename T, int U, int C, int WPB, bool DB>
+pg_status launch_tnw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  pg_ctx* c = A->ctx;
+  const int64_t ncg = (A->n + C - 1) / C;
+  // waves per CU: every wave keeps one (two when double-buffered) C * U KiB tile in flight
+  const int wpc = env_int("PG_TNW_WAVES_PER_CU", DB ? 16 : 4);
+  int64_t blocks = ((int64_t)c->num_cu * wpc + WPB - 1) / WPB;
+  if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
+  if (blocks > (ncg + WPB - 1) / WPB) blocks = (ncg + WPB - 1) / WPB;
+  if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  PG_TRY(ensure_partials(A, (int)blocks));
+  a.partials = (T*)A->partials;
+  *blocks_out = (int)blocks;
+  pg_prof_scope prof(c, PG_K_GEMV_TN);
+  hipLaunchKernelGGL((gemv_tnw_kernel<T, U, C, WPB, DB>), dim3((unsigned)blocks), dim3(WPB * 64), 0, c->stream, a);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LONG columns: teams of workgroups
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TEAM_WAVES = 8;                   // a member holds 8 U row groups of every column (U = 8: 16384 rows in Float32)
+constexpr int TEAM_MAX = 16;                    // members per team: up to 1024 row groups at U = 8 (262144 rows f32, 131072 f64)
+constexpr int TEAM_RING = 8;                    // granule ring slots per team (>= 2 LAG + 2, see the protocol note)
+constexpr long long TEAM_SPIN_LIMIT = 1 << 21;  // polls before a member gives up (~ seconds): bounded, never a hang
+
+template <typename T, int C>
+struct Pending {
+  unsigned long long w;  // this lane's granule of the awaited step
+  T xs[C], zos[C];       // the columns' x_j and z_old_j, fetched together with the poll
+};
+
+// Protocol.  Step i of a team = column group cg = team + i * nteams.  Member p writes its C partial dots of step i as
+// granules {value bits (32 per granule; an f64 takes two), tag = i + 1} into ring slot i % TEAM_RING at offset
+// (p * C + c) * G + h with ONE 8-byte agent-scope store each, so a reader that sees the tag sees the value.  Every wave
+// of every member polls the team_size * C * G granules of a step (one lane per granule), then sums the values in member
+// order.  A member posts step i only after it has consumed step i - LAG - 1, i.e. after ALL members have posted step
+// i - LAG - 1, which each of them did after consuming step i - 2 LAG - 2: a ring of 2 LAG + 2 slots is never
+// overwritten before everyone has read it.  The ring is zeroed before every launch (tags start at 1).
+//
+// Where the column tiles live.  Two register tiles alternate (one being loaded, one being dotted), as in
+// gemv_tn_kernel.  A tile whose totals are still travelling (LAG > 0) is parked in LDS -- LAG slots of
+// WAVES * C * U KiB, 128 KiB of the CU's 160 KiB at the default geometry -- and read back, 16 bytes per lane at a time,
+// for the A v accumulation: every wave touches only its own region of a slot (no barrier), reads the slot of step
+// i - LAG and then parks step i in the same slot.  (Keeping the waiting tiles in registers was tried first: the kernel
+// then needs ~340 VGPRs and spills whole tiles to scratch.)
+//
+// What the loop body may not contain (each cost a factor on the device, all seen in the disassembly): a branch around any
+// of the streaming loads, taken or not -- the compiler then no longer counts the loads in flight and waits for ALL of them
+// (s_waitcnt vmcnt(0)) before every dot product; a load inside the retry loop of the poll without a first look outside
+// it -- same effect at the loop header; the small loads (poll, x_j, z_old_j) issued AFTER the tile loads -- they return
+// in order, so reading them waits for the tile too.  Hence: a branch-free steady-state loop (ALL = true) between a
+// conditional head and tail, row groups past the end of a column clamped (masked through r = 0) instead of skipped.
+template <typename T, int U, int C, int WAVES, int LAG>
+__global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int G = (int)sizeof(T) / 4;  // granules per value
+  static_assert(2 * LAG + 2 <= TEAM_RING, "granule ring too short for this lag");
+  static_assert(TEAM_MAX * C * G <= 64, "one lane per granule of a step");
+  __shared__ T sm_dot[2][C][WAVES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
+  V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][WAVES][C][U][64]
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int team = (int)(blockIdx.x % (unsigned)a.nteams);
+  const int member = (int)(blockIdx.x / (unsigned)a.nteams);
+  const int TM = a.team_size;
+  const int npoll = TM * C * G;
+  const int64_t ncg = (a.n + C - 1) / C;
+  const int64_t cnt = ncg > team ? (ncg - team + a.nteams - 1) / a.nteams : 0;
+  const int rg0 = (member * WAVES + wave) * U;  // this wave's first row group: a contiguous run of U KiB of each column
+  unsigned long long* const ring = a.xch + (size_t)team * TEAM_RING * (size_t)(TEAM_MAX * C * G);
+
+  V rk[U], racc[U];
+  int rgc[U];  // row groups past the end of the column are clamped to the last one; their r is zero
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    rgc[u] = min(rg0 + u, a.nrg - 1);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
+    if (rg0 + u < a.nrg) {
+      rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)(rg0 + u) * (WAVE * VEC) + lane * VEC);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rk[u][e] = T(0);
+    }
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  bool dead = false;  // wave-uniform: a poll timed out, stop waiting (the launch is reported as failed)
+
+  struct Tile {
+    V col[C][U];
+  };
+  auto load = [&](Tile& t, int64_t i) {
+    const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
+      // wave-uniform base (scalar registers) + one shared per-lane offset: no 64-bit vector address per load
+      const T* __restrict__ p = a.A + j * a.ld;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        t.col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rgc[u] * (WAVE * VEC)) + lane);
+    }
+  };
+  // this member's partial dots of step i -> ring
+  auto dot_post = [&](const Tile& t, int64_t i) {
+    const int buf = (int)(i & 1);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      T d = T(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d = fma(t.col[c][u][e], rk[u][e], d);
+      }
+      d = wave_allsum(d);
+      if (lane == 0) sm_dot[buf][c][wave] = d;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < C * G) {
+      T mine = T(0);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        T s = sm_dot[buf][c][0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += sm_dot[buf][c][w];
+        if (lane / G == c) mine = s;
+      }
+      unsigned bits;
+      if constexpr (G == 1) {
+        bits = __builtin_bit_cast(unsigned, mine);
+      } else {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, mine);
+        bits = (lane % G) == 0 ? (unsigned)b : (unsigned)(b >> 32);
+      }
+      const unsigned long long word = ((unsigned long long)(unsigned)(i + 1) << 32) | bits;
+      __hip_atomic_store(ring + (size_t)(i % TEAM_RING) * (TEAM_MAX * C * G) + (size_t)member * (C * G) + lane, word,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  const int poll_lane = lane < npoll ? lane : npoll - 1;  // every lane polls (no exec-masked load): lanes >= npoll repeat the last granule
+  auto poll_word = [&](int64_t i) -> unsigned long long {
+    return __hip_atomic_load(ring + (size_t)(i % TEAM_RING) * (TEAM_MAX * C * G) + poll_lane, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto fetch_xz = [&](Pending<T, C>& pd, int64_t i) {
+    const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
+      pd.xs[c] = a.x[jc];
+      pd.zos[c] = a.z_old[jc];
+    }
+  };
+  // totals of step i (all members have posted, or will shortly) -> epilogue -> v_j (0 for columns past the end)
+  auto totals = [&](int64_t i, Pending<T, C>& pd, T (&vj)[C]) {
+    const unsigned tag = (unsigned)(i + 1);
+    // The first look at the granules stays OUTSIDE the retry loop (see the note above the kernel).
+    if (!dead && __builtin_amdgcn_ballot_w64((unsigned)(pd.w >> 32) == tag) != ~0ull) {
+      long long spins = 0;
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        pd.w = poll_word(i);
+        if (__builtin_amdgcn_ballot_w64((unsigned)(pd.w >> 32) == tag) == ~0ull) break;
+        if (++spins > TEAM_SPIN_LIMIT) {
+          dead = true;
+          if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    const int w_lo = (int)(unsigned)pd.w;
+    const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      T g = T(0);
+      for (int p = 0; p < TM; ++p) {  // member order: every member forms the same bits
+        const int idx = (p * C + c) * G;
+        if constexpr (G == 1) {
+          g += __builtin_bit_cast(float, __builtin_amdgcn_readlane(w_lo, idx));
+        } else {
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane(w_lo, idx);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane(w_lo, idx + 1);
+          g += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        }
+      }
+      const int64_t j = j0 + c;
+      const bool valid = j < a.n;
+      if (a.lam_ls != T(1)) g = a.lam_ls * g;
+      const T xj = pd.xs[c], zo = pd.zos[c];
+      const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
+      T zj;                            // :118 / :141
+      if (a.g_kind == PG_G_NORML1)
+        zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
+      else if (a.g_kind == PG_G_INDBOX)
+        zj = fmin(a.p1, fmax(a.p0, yj));
+      else
+        zj = yj;
+      const T rj = xj - zj;                             // :120 / :142
+      vj[c] = valid ? zj + a.beta * (zj - zo) : T(0);   // fast_forward_backward.jl:135 of the next iteration
+      if (member == 0 && (int)threadIdx.x == c && valid) {
+        a.g_out[j] = g;
+        a.y[j] = yj;
+        a.z_new[j] = zj;
+        a.res[j] = rj;
+        if (a.v_out != nullptr) a.v_out[j] = vj[c];
+        if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
+        acc[1] = fmax(acc[1], fabs((double)rj));
+        acc[2] += (double)g * (double)rj;
+        acc[3] += (double)rj * (double)rj;
+      }
+    }
+  };
+  auto park_slot = [&](int64_t i) { return park + ((size_t)(LAG > 0 ? i % (LAG > 0 ? LAG : 1) : 0) * WAVES + wave) * (C * U * WAVE) + lane; };
+
+  // One step: [poll the totals of step i - LAG, fetch its x_j / z_old_j] [start loading tile i + 1 into `nxt`]
+  // [dot + post tile i = `cur`] [totals of step i - LAG -> v_j ; A v accumulation from the parked tile] [park `cur`].
+  // ALL = steady state: every part runs, no branch.
+  auto step = [&](auto allc, Tile& cur, Tile& nxt, int64_t i) {
+    constexpr bool ALL = decltype(allc)::value;
+    if (!ALL && i >= cnt + LAG) return;
+    const bool has_fma = ALL || i >= LAG;
+    Pending<T, C> pd{};
+    if (has_fma) {
+      if constexpr (LAG > 0) pd.w = poll_word(i - LAG);  // issued BEFORE the next tile's loads: it returns first
+      fetch_xz(pd, i - LAG);
+    }
+    if (ALL || i + 1 < cnt) load(nxt, i + 1);
+    if (ALL || i < cnt) dot_post(cur, i);
+    if constexpr (LAG == 0) {
+      if (has_fma) pd.w = poll_word(i);
+    }
+    if (has_fma) {
+      T vj[C];
+      totals(i - LAG, pd, vj);
+      if constexpr (LAG == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(cur.col[c][u][e], vj[c], racc[u][e]);
+          }
+        }
+      } else {
+        const V* __restrict__ src = park_slot(i - LAG);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const V col = src[(c * U + u) * WAVE];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(col[e], vj[c], racc[u][e]);
+          }
+        }
+      }
+    }
+    if constexpr (LAG > 0) {
+      if (ALL || i < cnt) {  // same slot as the tile just read: this wave's region only, program order suffices
+        V* __restrict__ dst = park_slot(i);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) dst[(c * U + u) * WAVE] = cur.col[c][u];
+        }
+      }
+    }
+  };
+
+  Tile ta, tb;
+  if (cnt > 0) load(ta, 0);
+  constexpr int64_t HEAD = (LAG + 1) / 2 * 2;  // first even step from which every step has totals to consume
+  int64_t base = 0;
+  for (; base < HEAD && base < cnt + LAG; base += 2) {
+    step(std::false_type{}, ta, tb, base);
+    step(std::false_type{}, tb, ta, base + 1);
+  }
+  if (base + 3 <= cnt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the steady loop starts from a state the compiler knows exactly
+    for (; base + 3 <= cnt; base += 2) {
+      step(std::true_type{}, ta, tb, base);
+      step(std::true_type{}, tb, ta, base + 1);
+    }
+  }
+  for (; base < cnt + LAG; base += 2) {
+    step(std::false_type{}, ta, tb, base);
+    step(std::false_type{}, tb, ta, base + 1);
+  }
+  // this member's rows of the team's partial of A v
+  T* part = a.partials + (int64_t)team * a.ld + lane * VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (rg0 + u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)(rg0 + u) * (WAVE * VEC)) = racc[u];
+  const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
+  grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
+}
+
+template <typename T, int U, int C, int LAG>
+pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  pg_ctx* c = A->ctx;
+  constexpr int G = (int)sizeof(T) / 4;
+  const int64_t ncg = (A->n + C - 1) / C;
+  const int per_member = U * TEAM_WAVES;
+  int TM = (a.nrg + per_member - 1) / per_member;
+  if (env_int("PG_TN_TEAM", 0) > TM) TM = env_int("PG_TN_TEAM", 0);  // experiments: more (partly idle) members
+  if (TM < 1) TM = 1;
+  if (TM > TEAM_MAX) {
+    pg_set_error("the single-sweep pass covers columns of at most %d rows", (int)(TEAM_MAX * per_member * 1024 / sizeof(T)));
+    return PG_ERR_UNSUPPORTED;
+  }
+  // every member must be resident at once (they wait for each other): one 512-thread workgroup per CU at most
+  int64_t nteams = c->num_cu / TM;
+  if (env_int("PG_TN_TEAMS", 0) > 0 && env_int("PG_TN_TEAMS", 0) < nteams) nteams = env_int("PG_TN_TEAMS", 0);
+  if (nteams > ncg) nteams = ncg;
+  if (nteams < 1) nteams = 1;
+  if (nteams * TM > c->num_cu) {
+    pg_set_error("a team of %d workgroups does not fit the device's %d compute units", TM, c->num_cu);
+    return PG_ERR_UNSUPPORTED;
+  }
+  const size_t xch_bytes = (size_t)nteams * TEAM_RING * (size_t)(TEAM_MAX * C * G) * sizeof(unsigned long long);
+  if (A->xch == nullptr || A->xch_bytes < xch_bytes) {
+    if (A->xch) {
+      PG_HIP(hipStreamSynchronize(c->stream));
+      PG_HIP(hipFree(A->xch));
+      A->xch = nullptr;
+    }
+    hipError_t e = hipMalloc(&A->xch, xch_bytes);
+    if (e != hipSuccess) {
+      pg_set_error("hipMalloc(%zu) for the team exchange ring failed: %s", xch_bytes, hipGetErrorString(e));
+      return PG_ERR_ALLOC;
+    }
+    A->xch_bytes = xch_bytes;
+  }
+  PG_HIP(hipMemsetAsync(A->xch, 0, xch_bytes, c->stream));
+  PG_TRY(ensure_partials(A, (int)nteams));
+  a.partials = (T*)A->partials;
+  a.team_size = TM;
+  a.nteams = (int)nteams;
+  a.xch = (unsigned long long*)A->xch;
+  a.team_err = c->dscal + PG_S_TEAMERR;
+  *blocks_out = (int)nteams;
+  // LDS for the parked tiles: LAG slots of WAVES * C * U KiB; more than 64 KiB of dynamic LDS is opted into once
+  const size_t lds = (size_t)LAG * TEAM_WAVES * C * U * 1024;
+  if (lds > 64 * 1024) {
+    static bool opted_in[64] = {};
+    const int dev = c->device & 63;
+    if (!opted_in[dev]) {
+      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      opted_in[dev] = true;
+    }
+  }
+  pg_prof_scope prof(c, PG_K_GEMV_TN);
+  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG>), dim3((unsigned)(nteams * TM)), dim3(TEAM_WAVES * 64), lds,
+                     c->stream, a);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+}  // namespace
+
+bool tn_wave_covers(int nrg) { return nrg >= 1 && nrg <= 8; }
+bool tn_team_covers(int nrg) { return nrg >= 1 && nrg <= TEAM_MAX * 8 * TEAM_WAVES; }
+
+// Tunables (environment, for experiments): PG_TNW_C, PG_TNW_WPB (waves per workgroup), PG_TNW_DB (0 / 1),
+// PG_TNW_WAVES_PER_CU.
+template <typename T>
+pg_status launch_tn_wave(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  const int nrg = a.nrg;
+  int U = 1;
+  while (U < nrg) U *= 2;
+  // defaults from the sweeps in profiles/r2_tune_tn_short_columns.log: 32 KiB tiles (C * U = 32), four-wave workgroups;
+  // columns of >= 3 row groups: ONE tile per wave and one workgroup per CU (6.7 / 6.9 TB/s at 1024 / 2048 rows, Float32);
+  // shorter ones: two tiles per wave, four workgroups per CU (6.3 TB/s at 256 and 512 rows)
+  int C = env_int("PG_TNW_C", 32 / U);
+  const int WPB = env_int("PG_TNW_WPB", 4);
+  const int DB = env_int("PG_TNW_DB", U >= 4 ? 0 : 1);
+  if (sizeof(T) == 8 && C > 16) C = 16;
+#define PG_TNW_CASE(UU, CC, WW, DD) \
+  if (U == UU && C == CC && WPB == WW && DB == DD) return launch_tnw<T, UU, CC, WW, (DD != 0)>(A, a, blocks_out)
+#define PG_TNW_UC(UU, CC)   \
+  PG_TNW_CASE(UU, CC, 1, 1); \
+  PG_TNW_CASE(UU, CC, 1, 0); \
+  PG_TNW_CASE(UU, CC, 2, 0); \
+  PG_TNW_CASE(UU, CC, 8, 0); \
+  PG_TNW_CASE(UU, CC, 4, 1); \
+  PG_TNW_CASE(UU, CC, 4, 0)
+  PG_TNW_UC(1, 8);
+  PG_TNW_UC(1, 16);
+  PG_TNW_UC(1, 32);
+  PG_TNW_UC(2, 4);
+  PG_TNW_UC(2, 8);
+  PG_TNW_UC(2, 16);
+  PG_TNW_UC(4, 2);
+  PG_TNW_UC(4, 4);
+  PG_TNW_UC(4, 8);
+  PG_TNW_UC(8, 2);
+  PG_TNW_UC(8, 4);
+#undef PG_TNW_UC
+#undef PG_TNW_CASE
+  pg_set_error("no gemv_tnw instantiation for U=%d C=%d WPB=%d DB=%d", U, C, WPB, DB);
+  return PG_ERR_UNSUPPORTED;
+}
+
+// Tunables (environment, for experiments): PG_TNT_U, PG_TNT_C, PG_TNT_LAG, PG_TN_TEAM (members per team), PG_TN_TEAMS.
+template <typename T>
+pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  // The exchange costs about two step times (the post and the poll each queue behind a step's worth of loads in their
+  // CU's memory pipeline) plus the fabric: the totals of step i are consumed LAG steps later
+  // (profiles/r2_tune_tn_team.log).  LAG * C * U <= 16: the parked tiles fill 128 KiB of LDS.
+  // Measured (Float32, 64 GiB): 131072 rows (8 members of U = 8) 6.57 TB/s; 65536 rows: 8 members of U = 4 with two
+  // columns per step 6.67 TB/s, 4 members of U = 8 6.49 TB/s; LAG = 1: 4.97-5.58, LAG = 0: 4.60-5.52 TB/s.
+  const int U = env_int("PG_TNT_U", a.nrg <= 8 * 4 * TEAM_WAVES ? 4 : 8);
+  const int C = env_int("PG_TNT_C", U == 4 ? 2 : 1), LAG = env_int("PG_TNT_LAG", 2);
+#define PG_TNT_CASE(UU, CC, LL) \
+  if (U == UU && C == CC && LAG == LL) return launch_tnt<T, UU, CC, LL>(A, a, blocks_out)
+  PG_TNT_CASE(8, 1, 2);
+  PG_TNT_CASE(8, 1, 1);
+  PG_TNT_CASE(8, 2, 1);
+  PG_TNT_CASE(8, 1, 0);
+  PG_TNT_CASE(8, 2, 0);
+  PG_TNT_CASE(4, 2, 2);
+#undef PG_TNT_CASE
+  pg_set_error("no gemv_tnt instantiation for U=%d C=%d LAG=%d", U, C, LAG);
+  return PG_ERR_UNSUPPORTED;
+}
+
+template pg_status launch_tn_wave<float>(pg_mat*, TNArgs<float>&, int*);
+template pg_status launch_tn_wave<double>(pg_mat*, TNArgs<double>&, int*);
+template pg_status launch_tn_team<float>(pg_mat*, TNArgs<float>&, int*);
+template pg_status launch_tn_team<double>(pg_mat*, TNArgs<double>&, int*);
+
+}  // namespace pgtn

@@ -63,6 +63,7 @@ enum {
   PG_S_MISC = 5,     // dot / nrm2sq / nrminf / prox value results (2 slots)
   PG_S_DR = 8,       // Douglas-Rachford step: { ||res||_inf, f(y), g(z) }
   PG_S_FNEXT = 34,   // f at the speculative next point of the single-sweep iteration (2 slots, alternating)
+  PG_S_TEAMERR = 36, // set to 1 by a workgroup team of the long-column sweep that gave up waiting for a member
   PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 16 inner iterations, f(y), g(z) }
   PG_S_COUNT = 40
 };
@@ -135,6 +136,8 @@ struct pg_mat {
   void* partials = nullptr;
   int64_t partials_slots = 0;
   void* rpad = nullptr;  // [ld] zero-padded copy of a caller's m-vector (pg_mat_fused_tn)
+  void* xch = nullptr;   // granule ring of the workgroup teams of the long-column sweep (gemv_tnt_kernel)
+  size_t xch_bytes = 0;
 };
 
 struct pg_ls {

@@ -207,14 +207,41 @@ struct SepQuadParams {
   T ds, qs;
 };
 
-// (x - gamma q) / (1 + gamma d) with every product rounded (no FMA contraction): the single-step and the
-// multi-iteration kernels must produce the same bits, and so does an unfused CPU evaluation
+// prox of the separable quadratic, (x - gamma q) / (1 + gamma d), with every product rounded (no FMA contraction) and
+// the quotient CORRECTLY ROUNDED, i.e. the bits of the IEEE division an unfused CPU evaluation performs -- but the divider
+// is paid once per element, not once per application: inv = RN(1 / den) is formed with one IEEE division, and a quotient
+// a / den is then  q0 = RN(a inv) followed by two Markstein corrections  q <- RN(q + RN(a - den q) inv)  (the residual is
+// exact in an FMA).  After the first correction q is within half an ulp + 2 u^2 of a / den, which is the precondition under
+// which the second one returns RN(a / den) (Markstein 1990; Cornea, Harrison & Tang, "Scientific computing on Itanium-based
+// systems", thm. 8.3), barring underflow of the residual (|a| below 2^(emin + p)).  Five multiply-adds against the ~25
+// issue slots of v_div_scale / v_rcp / v_div_fmas / v_div_fixup: this is what took the K-iterations-per-sweep
+// Douglas-Rachford kernel off the divider (profiles/r2_bench_dr.json.log).  The single-step kernel and the operator-level
+// prox use the same function, so all three produce the same bits.
+template <typename T>
+struct SepQuadElem {
+  T gq, den, inv;
+};
+template <typename T>
+__device__ __forceinline__ SepQuadElem<T> sepquad_prepare(T gamma, T de, T qe) {
+#pragma clang fp contract(off)
+  SepQuadElem<T> p;
+  p.gq = gamma * qe;
+  p.den = T(1) + gamma * de;
+  p.inv = T(1) / p.den;
+  return p;
+}
+template <typename T>
+__device__ __forceinline__ T sepquad_apply(const SepQuadElem<T>& p, T x) {
+#pragma clang fp contract(off)
+  const T a = x - p.gq;
+  T q = a * p.inv;
+  q = fma(fma(-p.den, q, a), p.inv, q);
+  q = fma(fma(-p.den, q, a), p.inv, q);
+  return q;
+}
 template <typename T>
 __device__ __forceinline__ T sepquad_prox_elem(T x, T gamma, T de, T qe) {
-#pragma clang fp contract(off)
-  const T gq = gamma * qe;
-  const T den = T(1) + gamma * de;
-  return (x - gq) / den;
+  return sepquad_apply(sepquad_prepare(gamma, de, qe), x);
 }
 
 template <typename T, int N>
@@ -317,10 +344,11 @@ __device__ __forceinline__ void dr_block_apply(const DRBlockArgs<T, GKIND, K>& a
   for (int e = 0; e < N; ++e) {
     const T de = a.f.dv != nullptr ? d.v[e] : a.f.ds;
     const T qe = a.f.qv != nullptr ? q.v[e] : a.f.qs;
+    const SepQuadElem<T> pe = sepquad_prepare(a.gamma, de, qe);  // one division per element per sweep
     T xe = xv.v[e], ye, re, ze, se;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      ye = sepquad_prox_elem(xe, a.gamma, de, qe);
+      ye = sepquad_apply(pe, xe);
       re = T(2) * ye - xe;
       if constexpr (GKIND == PG_G_NORML1)
         ze = soft_threshold(re, a.p0);

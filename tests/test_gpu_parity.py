@@ -1127,8 +1127,8 @@ def test_error_paths_report_messages(pa):
     assert lib.pg_ls_fused_pass(*args(gamma=0.0)) == -1 and b"gamma" in lib.pg_last_error()
     assert lib.pg_ls_fused_pass(*args(kind=9)) == -1 and b"g_kind" in lib.pg_last_error()
     assert lib.pg_ls_fused_pass(*args(z=None)) == -1 and b"null" in lib.pg_last_error()
-    tall = pa.HIPMatrix.from_numpy(np.ones((40000, 2), np.float32))
-    r, xx = pa.HIPVector.zeros(40000, np.float32), pa.HIPVector.zeros(2, np.float32)
+    tall = pa.HIPMatrix.from_numpy(np.ones((300000, 2), np.float32))  # beyond 16 team members x 16384 rows
+    r, xx = pa.HIPVector.zeros(300000, np.float32), pa.HIPVector.zeros(2, np.float32)
     with pytest.raises(pa.ProxGradError):
         tall.fused_tn(r, xx, 0.1, pa.NormL1(0.1), xx.similar(), xx.similar(), xx.similar(), xx.similar(), r.similar())
     with pytest.raises(pa.ProxGradError):
