@@ -3,29 +3,44 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE FastForwardBackward iteration (fast_forward_backward.jl:106-145) of the fused HIP engine on
-the headline workload  m = 16384, n = 2^20, Float32, fixed step gamma = 1/Lf  (BASELINE.json north_star).
-A (64 GiB) is generated on the device and is resident in HBM before the timed region.  By default an iteration
-reads A ONCE (the single-sweep iteration: A' r, prox, next extrapolation and next residual per column while
-it is in registers); --sweeps two runs A x and A' r as separate sweeps like the reference.  For N > 1 the
-driver launches one process per GPU with torch.distributed.run (STRONG scaling: the global problem is fixed):
-column blocks of A are sharded over the N ranks, which keeps the single sweep on every GPU with ONE RCCL
-all-reduce of m + 4 N floats per iteration (--sharding rows: row blocks, two sweeps, n+1 floats per gradient
-evaluation -- north_star's layout, used for the adaptive mode and weak scaling).  Rank 0 prints ONE JSON line.
+A "step" is ONE FastForwardBackward iteration (fast_forward_backward.jl:106-145) of the fused HIP engine on the
+headline workload  m = 16384, n = 2^20, Float32, fixed step gamma = 1/Lf  (BASELINE.json north_star).  A (64 GiB)
+is generated on the device and is resident in HBM before the timed region.  An iteration reads A ONCE (the
+single-sweep iteration: A' r, prox, next extrapolation and next residual per column while it is in registers);
+--sweeps two runs A x and A' r as separate sweeps like the reference.
+
+N > 1: one process per GPU over RCCL (torch.distributed backend "nccl").  Started as plain `python bench.py --gpus N`
+the script launches `python -m torch.distributed.run --nproc-per-node N` itself as a CHILD process (before anything
+touches the GPU), relays the child's JSON line and exits with its code; under torch.distributed.run it is a rank.
+Rank 0 prints ONE JSON line.  Its top-level value is the STRONG-scaled headline problem with COLUMN blocks of A per
+rank (every GPU keeps the single sweep; one all-reduce of m + 8 N floats per iteration); the line also carries
+  rows_strong        the same problem with ROW blocks (north_star's layout: two sweeps, one all-reduce of n + 1 floats
+                     per gradient evaluation),
+  config5_weak_rows  BASELINE config 5 and its smaller twins: 16384 rows PER GPU (131072 x 2^20 at N = 8), row blocks,
+  config5_weak_cols  the same global problem with column blocks (each GPU: m x n/N, the long-column single sweep),
+each with its own roofline, the world size RCCL reports and the all-reduce payload.
+
+N = 1: the line also carries `also`: the reference benchmark's own adaptive mode on the headline matrix
+(benchmark/benchmarks.jl:55-61) and BASELINE configs 2, 3 and 4, each with its roofline (--no-also skips them).
 
 Extra legs in the same line:
   roofline      HBM roofline of the dominant kernel (the slowest sweep over A), timed live with HIP event pairs
                 on the launch stream (pg_ctx_profile_*), algorithmic bytes = one full read of the local A block +
                 its vectors; whole_iteration reports the SURVEY 8(d) two-pass figure and the bytes actually moved.
+                traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes, quoted only while the
+                kernel sources still hash to what the passes were taken on (else null + traffic_stale).
   cpu_baseline  the CPU restatement (oracle/, numpy + OpenBLAS, same unfused op order as the reference) timed on
                 this host on the SAME workload (the device matrix copied to host memory) when memory allows, else
                 on a bounded column sample scaled to it/s of the full workload.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,9 +56,11 @@ WORKLOADS = {
     "config2": (8192, 262144),  # configs[1]
     "small": (2048, 16384),  # quick functional check
 }
+# the sources the sweep kernels are built from: the PMC passes in profiles/pmc_traffic.json are tied to their hash
+KERNEL_SOURCES = ("pg_gemv_tn.h", "pg_gemv.hip", "pg_gemv_tn2.hip")
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
@@ -55,11 +72,14 @@ def parse_args():
     p.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="working precision (BASELINE metric: f32)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--sweeps", choices=["one", "two"], default="one",
-                   help="one: the single-sweep iteration (A read once per iteration; single GPU) -- two: A x and A' r as "
+                   help="one: the single-sweep iteration (A read once per iteration) -- two: A x and A' r as "
                         "separate sweeps like the reference (always the case when rows are sharded)")
     p.add_argument("--sharding", choices=["auto", "rows", "cols"], default="auto",
-                   help="N > 1: how A is distributed (auto: column blocks for the fixed-step single-sweep run, row blocks "
-                        "otherwise)")
+                   help="N > 1: layout of the TOP-LEVEL record (auto: column blocks for the fixed-step single-sweep run, row "
+                        "blocks otherwise); the other layout is reported as a sub-record")
+    p.add_argument("--no-also", action="store_true",
+                   help="skip the extra records (N = 1: adaptive headline + configs 2 / 3 / 4; N > 1: the other layouts)")
+    p.add_argument("--also-budget", type=float, default=60.0, help="seconds the extra records may take in total (N = 1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel-events", choices=["gemv", "all", "none"], default="gemv",
                    help="which kernels are bracketed by HIP event pairs in the timed region (none: no roofline object)")
@@ -70,21 +90,57 @@ def parse_args():
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
     p.add_argument("--scaling", choices=["strong", "weak"], default="strong",
-                   help="strong: the global problem is fixed and its rows are split over the ranks (default); weak: every "
-                        "rank holds --m rows (BASELINE config 5 = --scaling weak --m 16384 on 8 GPUs: 131072 x 2^20)")
+                   help="TOP-LEVEL record: strong = the global problem is fixed and split over the ranks (default); weak = "
+                        "every rank holds --m rows (BASELINE config 5 = --scaling weak --m 16384 on 8 GPUs)")
     p.add_argument("--collective", choices=["torch", "native"], default="torch",
                    help="N > 1: all-reduce through torch.distributed (default) or the library's own RCCL communicator")
     p.add_argument("--overlap", action="store_true",
-                   help="pipeline the [grad ; f] all-reduce with pass T in column chunks (N > 1). Off by default: at the "
-                        "headline shard shape the chunking costs ~60 us/step, about what it can hide (DESIGN.md section 6)")
+                   help="pipeline the [grad ; f] all-reduce with pass T in column chunks (N > 1, row blocks). Off by default: at "
+                        "the headline shard shape the chunking costs ~60 us/step, about what it can hide (DESIGN.md section 6)")
     p.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     p.add_argument("--force-comm", action="store_true",
                    help="diagnostic: attach the collective even with one rank (measures the cost of the sharded code path)")
     p.add_argument("--share-device", action="store_true",
                    help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 from a plain shell: start the ranks as a child process (never exec: see the module docstring)
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child, relay its JSON line, return its exit code.  Nothing in this process has touched the GPU."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                if "metric" in json.loads(ln):
+                    line = ln
+            except ValueError:
+                pass
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif proc.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
+        return 1
+    return proc.returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU leg
+# ---------------------------------------------------------------------------------------------------------------
 def _host_memory_limit():
     """Bytes this process may use: the cgroup limit when there is one, else MemAvailable."""
     lim = None
@@ -104,9 +160,20 @@ def _host_memory_limit():
     return lim
 
 
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+
+        return max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
     """The SAME workload on the host cores: the device matrix is copied to host memory (a few seconds over PCIe) and the
-    oracle (numpy/OpenBLAS restatement of the reference's op sequence) steps on it for at most `budget_s` seconds."""
+    oracle (numpy/OpenBLAS restatement of the reference's op sequence) steps on it for at most `budget_s` seconds with
+    every BLAS thread, then ONE iteration with a single BLAS thread (the reference's runbenchmarks.jl pins BLAS to one
+    thread) -- measured on the full matrix, not extrapolated."""
     import numpy as np
 
     from oracle import proxgrad_oracle as o
@@ -123,21 +190,26 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
         next(it)
         steps += 1
     dt = time.perf_counter() - t0
-    one_thread = None
+    one_thread, note1 = None, ""
     try:
-        from threadpoolctl import threadpool_info, threadpool_limits
+        from threadpoolctl import threadpool_limits
 
-        cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+        with threadpool_limits(limits=1, user_api="blas"):
+            t1 = time.perf_counter()
+            next(it)
+            d1 = time.perf_counter() - t1
+        one_thread = 1.0 / d1
+        note1 = f"; 1 BLAS thread: 1 iteration on the same matrix in {d1:.1f} s"
     except Exception:
-        cores = os.cpu_count() or 1
+        pass
     return {
         "value": steps / dt,
         "value_1thread": one_thread,
         "unit": "it/s",
-        "cores": int(cores),
+        "cores": int(_blas_threads()),
         "kind": "port",
         "sample": f"the full workload: oracle FFB fixed-step on the downloaded {m}x{n} {A.dtype.name} matrix "
-                  f"({A.nbytes / 2**30:.1f} GiB, copied to the host in {t_dl:.1f} s), {steps} iterations in {dt:.1f} s",
+                  f"({A.nbytes / 2**30:.1f} GiB, copied to the host in {t_dl:.1f} s), {steps} iterations in {dt:.1f} s{note1}",
     }
 
 
@@ -170,10 +242,8 @@ def cpu_baseline(m, n, sample_cols, steps, seed):
     its_sample = steps / dt
     one_thread = None
     try:
-        from threadpoolctl import threadpool_info, threadpool_limits
+        from threadpoolctl import threadpool_limits
 
-        cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
-        # the single-thread figure (the reference's runbenchmarks.jl pins BLAS to one thread)
         with threadpool_limits(limits=1, user_api="blas"):
             s1 = max(2, steps // 5)
             t0 = time.perf_counter()
@@ -181,20 +251,369 @@ def cpu_baseline(m, n, sample_cols, steps, seed):
                 next(it)
             one_thread = s1 / (time.perf_counter() - t0) * ns / n
     except Exception:
-        cores = os.cpu_count() or 1
+        pass
     return {
         "value": its_sample * ns / n,
         "value_1thread": one_thread,
         "unit": "it/s",
-        "cores": int(cores),
+        "cores": int(_blas_threads()),
         "kind": "port",
         "sample": f"oracle FFB fixed-step, m={m} n={ns} f32 ({steps} it, {dt:.2f} s, {its_sample:.2f} it/s on the sample; "
-                  f"scaled linearly in n to n={n})",
+                  f"scaled linearly in n to n={n}; the host cannot hold the full matrix)",
     }
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# PMC traffic tied to the kernel sources
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(workload, kernel):
+    """(traffic bytes per launch | None, source | None, stale flag) from profiles/pmc_traffic.json"""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        rec = pmc.get(workload)
+        if not rec or kernel not in rec.get("kernels", {}):
+            return None, None, False
+        if rec.get("kernel_source_sha256") != kernel_source_hash():
+            return None, rec.get("source"), True
+        return rec["kernels"][kernel]["hbm_bytes"], rec.get("source"), False
+    except Exception:
+        return None, None, False
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one FastForwardBackward record
+# ---------------------------------------------------------------------------------------------------------------
+class Dist:
+    """what the records need to know about the job"""
+
+    def __init__(self, world, rank, local_rank, backend, collective, overlap, force_comm):
+        self.world, self.rank, self.local_rank = world, rank, local_rank
+        self.backend, self.collective, self.overlap, self.force_comm = backend, collective, overlap, force_comm
+        self.sharded = world > 1 or force_comm
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, v):
+        if self.world == 1:
+            return float(v)
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_scalar(self, v, op):
+        if self.world == 1:
+            return float(v)
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def ranks_seen(self):
+        if not self.sharded:
+            return 1
+        import torch.distributed as dist
+
+        return dist.get_world_size()
+
+
+def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
+    """A resident in HBM (this rank's block), b, lam = 0.1 ||A'b||_inf (test_lasso_small.jl:29), Lf (fixed step) -- untimed."""
+    import numpy as np
+    import torch.distributed as dist
+
+    t0 = time.perf_counter()
+    cols = layout == "cols"
+    if cols:
+        row_off, m_loc = 0, m_glob
+        col_off, n_loc = pa.shard_cols(n, D.world, D.rank)
+    elif layout == "rows":
+        row_off, m_loc = pa.shard_rows(m_glob, D.world, D.rank)
+        col_off, n_loc = 0, n
+    else:
+        row_off, m_loc, col_off, n_loc = 0, m_glob, 0, n
+    A = pa.HIPMatrix.synthetic(m_loc, n_loc, dtype, seed=seed, row_offset=row_off, col_offset=col_off, m_global=m_glob,
+                               ctx=ctx)
+    rng = np.random.default_rng(seed + 12345)
+    k = max(1, n // 1000)
+    x_true = np.zeros(n, dtype)
+    x_true[rng.choice(n, size=k, replace=False)] = rng.standard_normal(k).astype(dtype)
+    noise = np.random.default_rng(seed + 54321).standard_normal(m_glob).astype(dtype)[row_off:row_off + m_loc]
+    b = A.mul(pa.HIPVector.from_numpy(x_true[col_off:col_off + n_loc], ctx))  # row blocks: rows are independent
+    if cols and D.world > 1:
+        pa.allreduce_sum_(b.torch())  # column blocks: b = sum_p A[:, J_p] x_true[J_p]
+    b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
+    comm = None
+    if layout != "none":
+        shard = "cols" if cols else "rows"
+        comm = (pa.NativeRcclComm(overlap=D.overlap, shard=shard) if D.collective == "native"
+                else pa.TorchDistributedComm(overlap=D.overlap, shard=shard))
+    f = pa.LeastSquares(A, b, comm=comm)
+    zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)
+    _, g0 = f.value_and_gradient(zero_n)  # = -A'b (row blocks: all-reduced; column blocks: this rank's columns)
+    g0_inf = float(g0.norm_inf())
+    if cols:
+        g0_inf = D.reduce_scalar(g0_inf, dist.ReduceOp.MAX)
+    lam = dtype(0.1) * dtype(g0_inf)
+    Lf = None
+    if mode == "fixed":
+        f0 = pa.LeastSquares(A, pa.HIPVector.zeros(m_loc, dtype, ctx), comm=comm)  # x -> A'A x
+        v = pa.HIPVector.zeros(n_loc, dtype, ctx).fill_(1.0 / math.sqrt(n))
+        w = v.similar()
+        nrm = dtype(1)
+        for _ in range(30):
+            f0.value_and_gradient(v, out=w)
+            nrm2 = float(w.norm()) ** 2
+            if cols:
+                nrm2 = D.reduce_scalar(nrm2, dist.ReduceOp.SUM)
+            nrm = dtype(math.sqrt(nrm2))
+            v.axpby_(1.0 / float(nrm), w)
+        Lf = dtype(1.1) * nrm  # ||A||^2 estimate (+10 % margin: power iteration under-estimates)
+        del f0
+    ctx.sync()
+    return {"A": A, "b": b, "f": f, "comm": comm, "lam": lam, "Lf": Lf, "zero_n": zero_n, "m_glob": m_glob, "n": n,
+            "m_loc": m_loc, "n_loc": n_loc, "layout": layout, "dtype": dtype, "setup_s": time.perf_counter() - t0, "seed": seed}
+
+
+def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_name=None, scaling="strong"):
+    """W untimed + K timed FastForwardBackward iterations on a prepared problem; returns the record (every rank) with
+    value = K / max-over-ranks(elapsed), the HIP-event roofline of the dominant sweep kernel and the problem's config."""
+    import numpy as np
+
+    dtype, n, m_glob, m_loc, n_loc, layout = P["dtype"], P["n"], P["m_glob"], P["m_loc"], P["n_loc"], P["layout"]
+    cols = layout == "cols"
+    es = np.dtype(dtype).itemsize
+    Lf = P["Lf"] if mode == "fixed" else None
+    iteration = pa.FastForwardBackwardIteration(f=P["f"], g=pa.NormL1(P["lam"]), x0=P["zero_n"], Lf=Lf,
+                                                single_sweep=sweeps == "one")
+    it = iter(iteration)
+    state = next(it)  # init (k = 1)
+    stop_rule = lambda s: float(s.res_inf) / float(s.gamma) <= 1e-6  # benchmarks.jl:57 (evaluated, not acted on)
+    for _ in range(warmup):
+        state = next(it)
+        stop_rule(state)
+    passes0 = iteration.counters.get("a_passes", 0)
+    comm = P["comm"]
+    calls0, elems0 = (getattr(comm, "calls", 0), getattr(comm, "elements", 0)) if comm is not None else (0, 0)
+    ctx.profile(kernel_events != "none", kernels=None if kernel_events == "all" else ("gemv_n_partial", "gemv_t", "gemv_tn"))
+    ctx.profile_reset()
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        state = next(it)
+        stop_rule(state)
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    a_passes = iteration.counters.get("a_passes", 0) - passes0
+    elapsed = D.max_over_ranks(elapsed)
+    its = steps / elapsed
+    sweeps_done = a_passes / max(steps, 1)  # reads of A per iteration actually executed
+    # SURVEY 8(d): the algorithmic figure counts the passes the mode REQUIRES when A x and A' r are separate sweeps (2 for
+    # fixed-step FB / FFB and for adaptive FFB with the residual pair); the single-sweep iteration moves fewer bytes --
+    # both are reported, labelled
+    passes_alg = max(2.0, sweeps_done) if sweeps == "two" or layout == "rows" else 2.0
+    bytes_iter_local = passes_alg * m_loc * n_loc * es + 10 * n_loc * es + 3 * m_loc * es
+    bytes_moved_local = sweeps_done * m_loc * n_loc * es + 10 * n_loc * es + 3 * m_loc * es
+    kern = {}
+    n_cnt = prof["gemv_n_partial"][0]
+    for name, vec_bytes in (("gemv_n_partial", n_loc * es), ("gemv_t", m_loc * es + n_loc * es),
+                            ("gemv_tn", (m_loc + 7 * n_loc) * es)):
+        cnt, ms = prof[name]
+        if cnt:
+            avg_ms = ms / cnt
+            # with a collective attached pass T may run as several column-chunk launches per evaluation
+            evals = max(a_passes - n_cnt - prof["gemv_tn"][0], 1) if name == "gemv_t" else cnt
+            launch_bytes = (m_loc * n_loc * es + vec_bytes) * evals / cnt
+            kern[name] = {"launches": cnt, "avg_ms": avg_ms, "bytes": launch_bytes, "launches_per_pass": cnt / evals,
+                          "GBps": launch_bytes / (avg_ms * 1e-3) / 1e9}
+    dom = max(kern, key=lambda k_: kern[k_]["avg_ms"]) if kern else None
+    roofline = None
+    if dom:
+        traffic, traffic_src, stale = (None, None, False)
+        if workload_name and D.world == 1 and layout == "none" and dtype == np.float32:
+            traffic, traffic_src, stale = pmc_traffic(workload_name, dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(kern[dom]["GBps"], 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src, "traffic_stale": stale,
+                    "avg_launch_ms": round(kern[dom]["avg_ms"], 4), "launches": kern[dom]["launches"],
+                    "algorithmic_bytes_per_launch": int(kern[dom]["bytes"]),
+                    "per_kernel": {k_: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1), "launches": v["launches"],
+                                        "launches_per_pass": round(v["launches_per_pass"], 2)} for k_, v in kern.items()},
+                    "whole_iteration": {"algorithmic_bytes_per_gpu": int(bytes_iter_local),
+                                        "GBps_per_gpu": round(bytes_iter_local * its / 1e9, 1),
+                                        "frac": round(bytes_iter_local * its / 1e9 / HBM_PEAK_GBS, 4),
+                                        "sweeps_of_A_per_iteration": round(sweeps_done, 3),
+                                        "hbm_bytes_moved_per_gpu": int(bytes_moved_local),
+                                        "hbm_GBps_moved_per_gpu": round(bytes_moved_local * its / 1e9, 1),
+                                        "frac_of_bytes_moved": round(bytes_moved_local * its / 1e9 / HBM_PEAK_GBS, 4),
+                                        "note": "algorithmic_bytes = SURVEY 8(d): A x and A' r as separate passes (2 m n s "
+                                                "+ vectors); frac > 1 means the iteration moves fewer bytes than that (the "
+                                                "single sweep reads A once); *_moved = bytes actually read/written"}}
+    dname = "Float32" if dtype == np.float32 else "Float64"
+    rec = {
+        "value": round(its, 4), "unit": "it/s", "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 4),
+        "scaling": scaling,
+        "config": {"workload": "FFB LASSO m=%d n=%d %s, %s step, %s" % (
+            m_glob, n, dname, mode, "one GPU" if layout == "none" else
+            "%s of A sharded over %d GPU(s)" % ("columns" if cols else "rows", D.world)),
+            "m": m_glob, "n": n, "mode": mode, "sharding": layout, "shards": D.world if layout != "none" else 1,
+            "m_per_gpu": m_loc, "n_per_gpu": n_loc, "lambda": float(P["lam"]), "Lf": float(Lf) if Lf is not None else None,
+            "seed": P["seed"], "a_passes_per_step": a_passes / max(steps, 1),
+            "sweeps": sweeps if layout != "rows" else "two", "setup_s": round(P["setup_s"], 2),
+            "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
+                      "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
+        "roofline": roofline,
+    }
+    if layout != "none":
+        calls = getattr(comm, "calls", 0) - calls0
+        elems = getattr(comm, "elements", 0) - elems0
+        rec["ranks_seen_by_rccl"] = D.ranks_seen()
+        rec["collective"] = {"backend": "rccl" if D.backend == "nccl" else D.backend, "through": D.collective,
+                             "allreduce_calls_per_step": round(calls / max(steps, 1), 3) if calls else None,
+                             "allreduce_payload_bytes_per_call": int(elems / calls * es) if calls else None,
+                             "layout_payload": ("[A v partial (m) ; 8 N scalar slots]" if cols else "[grad (n) ; f]")}
+    del it, iteration
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 4 (N = 1 `also` records)
+# ---------------------------------------------------------------------------------------------------------------
+def run_config3(pa, ctx, n=10_000_000, steps=200):
+    """DouglasRachford on a box-constrained QP with diagonal Hessian (douglas_rachford.jl:53-70), n = 10^7, Float32:
+    stepping from the host (one fused sweep per iteration) and the in-library loop (16 iterations per sweep)."""
+    import numpy as np
+
+    dtype = np.float32
+    rng = np.random.default_rng(0)
+    d = (0.1 + rng.random(n, dtype=np.float32)).astype(dtype)
+    q = rng.standard_normal(n, dtype=np.float32)
+    x0 = np.zeros(n, dtype)
+    lo, hi, gamma = dtype(-0.5), dtype(0.25), dtype(1.0)
+    out = {"label": "config3", "unit": "it/s",
+           "config": {"workload": "DouglasRachford box-constrained QP n=%d Float32 (SeparableQuadratic + IndBox)" % n}}
+    it = iter(pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma,
+                                          materialize=False))
+    for _ in range(20):
+        s = next(it)
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s = next(it)
+        float(s.res_inf) / float(gamma) <= 1e-8  # the stop rule, evaluated every iteration like the driver loop
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    cnt, ms = ctx.profile_read()["dr_step"]
+    ctx.profile(False)
+    b5 = 5 * n * 4  # x, d, q in; x, y out
+    out["stepping"] = {"value": round(steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 5), "steps": steps,
+                       "roofline": {"bound": "hbm", "kernel": "dr_step", "avg_launch_ms": round(ms / cnt, 5),
+                                    "algorithmic_bytes_per_launch": b5, "achieved": round(b5 / (ms / cnt * 1e-3) / 1e9, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b5 / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    block = 16
+    nst = max(steps, 10 * block) // block * block
+    itn = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
+    itn.device_run(2 * block, 0.0, block)
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    s, k = itn.device_run(nst, 0.0, block)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    cnt, ms = ctx.profile_read()["dr_step"]
+    ctx.profile(False)
+    out["device_loop"] = {"value": round(nst / dt, 1), "ms_per_step": round(1e3 * dt / nst, 6), "steps": nst,
+                          "iterations_per_launch": block,
+                          "roofline": {"bound": "valu (exact division) / hbm", "kernel": "dr_block<%d>" % block,
+                                       "avg_launch_ms": round(ms / cnt, 5), "algorithmic_bytes_per_launch": b5,
+                                       "achieved": round(b5 / (ms / cnt * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(b5 / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    out["value"] = out["device_loop"]["value"]
+    out["ms_per_step"] = out["device_loop"]["ms_per_step"]
+    out["steps"] = nst
+    out["roofline"] = out["stepping"]["roofline"]
+    return out
+
+
+def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3):
+    """PANOC (panoc.jl:138-255; L-BFGS memory 5, adaptive step) on logistic loss + L1, m = 16384, n = 10^6, Float32."""
+    import numpy as np
+
+    dtype = np.float32
+    A = pa.HIPMatrix.synthetic(m, n, dtype, seed=0, ctx=ctx)
+    rng = np.random.default_rng(12345)
+    k = max(1, n // 1000)
+    x_true = np.zeros(n, dtype)
+    x_true[rng.choice(n, size=k, replace=False)] = rng.standard_normal(k).astype(dtype)
+    b = A.mul(pa.HIPVector.from_numpy(x_true, ctx))
+    b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(rng.standard_normal(m).astype(dtype), ctx))
+    f = pa.LogisticLoss(b)
+    _, g0 = f.value_and_gradient(pa.HIPVector.zeros(m, dtype, ctx))
+    lam = dtype(0.1) * A.mul_adjoint(g0).norm_inf()
+    iteration = pa.PANOCIteration(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype))
+    it = iter(iteration)
+    s = next(it)
+    for _ in range(warmup):
+        s = next(it)
+    p0 = iteration.counters.get("A_passes", 0)
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s = next(it)
+        float(s.res.norm_inf()) / float(s.gamma) <= 1e-8
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    passes = iteration.counters.get("A_passes", 0) - p0
+    per = {k_: {"launches": prof[k_][0], "avg_ms": round(prof[k_][1] / prof[k_][0], 4),
+                "GBps": round(m * n * 4 / (prof[k_][1] / prof[k_][0] * 1e-3) / 1e9, 1)}
+           for k_ in ("gemv_n_partial", "gemv_t", "gemv_tn") if prof[k_][0]}
+    dom = max(per, key=lambda k_: per[k_]["avg_ms"])
+    gemv_ms = sum(prof[k_][1] for k_ in per)
+    return {"label": "config4", "value": round(steps / dt, 3), "unit": "it/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / steps, 4),
+            "config": {"workload": "PANOC logistic + L1, m=%d n=%d Float32, LBFGS(5), adaptive step" % (m, n),
+                       "A_passes_per_step": passes / steps, "lambda": float(lam),
+                       "final": {"gamma": float(s.gamma), "res_inf_over_gamma": float(s.res.norm_inf()) / float(s.gamma)}},
+            "roofline": {"bound": "hbm", "kernel": dom, "avg_launch_ms": per[dom]["avg_ms"],
+                         "algorithmic_bytes_per_launch": m * n * 4, "achieved": per[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(per[dom]["GBps"] / HBM_PEAK_GBS, 4), "per_kernel": per,
+                         "gemv_time_fraction_of_step": round(gemv_ms * 1e-3 / dt, 4)}}
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(self_launch(args))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -207,12 +626,10 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if args.share_device:
         local_rank = 0
@@ -227,211 +644,85 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    D = Dist(world, rank, local_rank, args.backend, args.collective, args.overlap, args.force_comm)
 
-    m_glob, n = WORKLOADS[args.workload]
-    m_glob = args.m or m_glob
-    if args.scaling == "weak":
-        m_glob *= world
+    m_base, n = WORKLOADS[args.workload]
+    m_base = args.m or m_base
     n = args.n or n
+    m_glob = m_base * world if args.scaling == "weak" else m_base
     dtype = np.float32 if args.dtype == "f32" else np.float64
     ctx = pa.get_context(local_rank)
-    # N > 1: column shards keep the single-sweep iteration on every GPU (one all-reduce of m + 4 N elements per
-    # iteration); row shards (north_star's layout) iterate with two sweeps and all-reduce [grad ; f] (n + 1 elements)
-    sharding = args.sharding
-    if sharding == "auto":
-        sharding = "cols" if (world > 1 or args.force_comm) and args.sweeps == "one" and args.scaling == "strong" else "rows"
-    if world == 1 and not args.force_comm:
-        sharding = "none"
-    cols = sharding == "cols"
-    if cols:
-        row_off, m_loc = 0, m_glob
-        col_off, n_loc = pa.shard_cols(n, world, rank)
-    else:
-        row_off, m_loc = pa.shard_rows(m_glob, world, rank)
-        col_off, n_loc = 0, n
+    # N > 1: column blocks keep the single-sweep iteration on every GPU (one all-reduce of m + 8 N elements per
+    # iteration); row blocks (north_star's layout) iterate with two sweeps and all-reduce [grad ; f] (n + 1 elements)
+    layout = args.sharding
+    if layout == "auto":
+        layout = "cols" if D.sharded and args.sweeps == "one" and args.scaling == "strong" else "rows"
+    if not D.sharded:
+        layout = "none"
+    named = args.workload if (args.m is None and args.n is None) else None
 
-    def allreduce_scalar(v, op):
-        """a Python scalar reduced over the ranks (setup only)"""
-        if world == 1:
-            return float(v)
-        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=op)
-        return float(t.item())
+    P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode)
+    main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
+                       workload_name=named, scaling=args.scaling)
+    extra = {}
+    sub_steps = max(4, min(args.steps, 20))
+    if args.no_also:
+        pass
+    elif world == 1 and not args.force_comm and args.workload == "headline" and named and args.mode == "fixed":
+        also = []
+        # the reference benchmark's own mode: adaptive step (benchmark/benchmarks.jl:55-61), same matrix
+        r = run_ffb(pa, ctx, D, P, "adaptive", args.sweeps, sub_steps, 3, args.kernel_events)
+        r["label"] = "headline_adaptive"
+        also.append(r)
+        # the CPU leg needs the headline matrix: take it before the other configs claim the memory
+        if rank == 0 and not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
+            args.no_cpu_baseline = True
+        P = None  # release the 64 GiB matrix
+        t_also = time.perf_counter()  # time box of the remaining records (the CPU leg is not part of it)
+        within = lambda: time.perf_counter() - t_also < args.also_budget
+        if within():
+            P2 = setup_lasso(pa, ctx, D, *WORKLOADS["config2"], dtype, args.seed, "none", "fixed")
+            r = run_ffb(pa, ctx, D, P2, "fixed", "one", max(sub_steps, 50), 5, args.kernel_events)
+            r["label"] = "config2"
+            also.append(r)
+            P2 = None
+        if within():
+            also.append(run_config3(pa, ctx))
+        if within():
+            also.append(run_config4(pa, ctx))
+        extra["also"] = also
+    elif world > 1:
+        P = None
+        other = "rows" if layout == "cols" else "cols"
+        if args.scaling == "strong":
+            # the same global problem in the other layout (row blocks = north_star's contract)
+            P2 = setup_lasso(pa, ctx, D, m_base, n, dtype, args.seed, other, "fixed")
+            extra["%s_strong" % other] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events)
+            P2 = None
+        # BASELINE config 5 and its twins: m_base rows PER GPU (131072 x 2^20 at N = 8), both layouts
+        for lay in ("rows", "cols"):
+            if args.scaling == "weak" and lay == layout:
+                continue
+            P2 = setup_lasso(pa, ctx, D, m_base * world, n, dtype, args.seed, lay, "fixed")
+            extra["config5_weak_%s" % lay] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events,
+                                                     scaling="weak")
+            P2 = None
 
-    # ---------------- problem setup (untimed): A resident in HBM, b, lam, Lf ----------------
-    t_setup = time.perf_counter()
-    A = pa.HIPMatrix.synthetic(m_loc, n_loc, dtype, seed=args.seed, row_offset=row_off, col_offset=col_off, m_global=m_glob,
-                               ctx=ctx)
-    rng = np.random.default_rng(args.seed + 12345)
-    k = max(1, n // 1000)
-    x_true = np.zeros(n, dtype)
-    x_true[rng.choice(n, size=k, replace=False)] = rng.standard_normal(k).astype(dtype)
-    noise = np.random.default_rng(args.seed + 54321).standard_normal(m_glob).astype(dtype)[row_off:row_off + m_loc]
-    b = A.mul(pa.HIPVector.from_numpy(x_true[col_off:col_off + n_loc], ctx))  # row shards: rows are independent
-    if cols and world > 1:
-        pa.allreduce_sum_(b.torch())  # column shards: b = sum_p A[:, J_p] x_true[J_p]
-    b.axpby_(1.0, b, 0.01, pa.HIPVector.from_numpy(noise, ctx))
-    comm = None
-    if world > 1 or args.force_comm:
-        comm = (pa.NativeRcclComm(overlap=args.overlap, shard="cols" if cols else "rows") if args.collective == "native"
-                else pa.TorchDistributedComm(overlap=args.overlap, shard="cols" if cols else "rows"))
-    f = pa.LeastSquares(A, b, comm=comm)
-    zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)
-    _, g0 = f.value_and_gradient(zero_n)  # = -A'b (row shards: all-reduced; column shards: this rank's columns)
-    g0_inf = float(g0.norm_inf())
-    if cols:
-        g0_inf = allreduce_scalar(g0_inf, dist.ReduceOp.MAX)
-    lam = dtype(0.1) * dtype(g0_inf)  # test_lasso_small.jl:29
-    Lf = None
-    if args.mode == "fixed":
-        f0 = pa.LeastSquares(A, pa.HIPVector.zeros(m_loc, dtype, ctx), comm=comm)  # x -> A'A x
-        v = pa.HIPVector.zeros(n_loc, dtype, ctx).fill_(1.0 / math.sqrt(n))
-        w = v.similar()
-        nrm = dtype(1)
-        for _ in range(30):
-            f0.value_and_gradient(v, out=w)
-            nrm2 = float(w.norm()) ** 2
-            if cols:
-                nrm2 = allreduce_scalar(nrm2, dist.ReduceOp.SUM)
-            nrm = dtype(math.sqrt(nrm2))
-            v.axpby_(1.0 / float(nrm), w)
-        Lf = dtype(1.1) * nrm  # ||A||^2 estimate (+10 % margin: power iteration under-estimates)
-        del f0
-    ctx.sync()
-    t_setup = time.perf_counter() - t_setup
-
-    iteration = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=zero_n, Lf=Lf, single_sweep=args.sweeps == "one")
-    it = iter(iteration)
-    state = next(it)  # init (k = 1)
-    stop_rule = lambda s: float(s.res_inf) / float(s.gamma) <= 1e-6  # benchmarks.jl:57 (evaluated, not acted on)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        state = next(it)
-        stop_rule(state)
-    passes0 = iteration.counters.get("a_passes", 0)
-    # HIP event pairs around the two GEMV kernels only: each pair is a marker packet on the stream, and the roofline
-    # leg needs nothing else
-    ctx.profile(args.kernel_events != "none",
-                kernels=None if args.kernel_events == "all" else ("gemv_n_partial", "gemv_t", "gemv_tn"))
-    ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        state = next(it)
-        stop_rule(state)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read()
-    ctx.profile(False)
-    a_passes = iteration.counters.get("a_passes", 0) - passes0
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    its = args.steps / elapsed
-    es = 4 if args.dtype == "f32" else 8
-    sweeps = a_passes / max(args.steps, 1)  # reads of A per iteration actually executed
-    # SURVEY 8(d): the algorithmic figure counts the passes the mode REQUIRES when A x and A' r are separate sweeps (2 for
-    # fixed-step FB / FFB and for adaptive FFB with the residual pair); the single-sweep iteration moves fewer bytes --
-    # both are reported, labelled
-    passes_alg = max(2.0, sweeps) if args.sweeps == "two" or (world > 1 and not cols) else 2.0
-    bytes_iter_local = passes_alg * m_loc * n_loc * es + 10 * n_loc * es + 3 * m_loc * es
-    bytes_moved_local = sweeps * m_loc * n_loc * es + 10 * n_loc * es + 3 * m_loc * es
-    # dominant kernel = the slowest sweep over A; algorithmic bytes of one launch = the local A block + its vectors
-    kern = {}
-    n_cnt = prof["gemv_n_partial"][0]
-    for name, vec_bytes in (("gemv_n_partial", n_loc * es), ("gemv_t", m_loc * es + n_loc * es),
-                            ("gemv_tn", (m_loc + 7 * n_loc) * es)):
-        cnt, ms = prof[name]
-        if cnt:
-            avg_ms = ms / cnt
-            # with a collective attached pass T runs as several column-chunk launches per evaluation
-            # (pg_gemv.hip ls_grad_stage_t): one launch then covers 1/chunks of the local block
-            evals = max(a_passes - n_cnt - prof["gemv_tn"][0], 1) if name == "gemv_t" else cnt
-            launch_bytes = (m_loc * n_loc * es + vec_bytes) * evals / cnt
-            kern[name] = {"launches": cnt, "avg_ms": avg_ms, "bytes": launch_bytes,
-                          "launches_per_pass": cnt / evals, "GBps": launch_bytes / (avg_ms * 1e-3) / 1e9}
-    dom = max(kern, key=lambda k_: kern[k_]["avg_ms"]) if kern else None
-    roofline = None
-    if dom:
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process);
-        # only quoted when they were collected on this exact workload
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            rec = pmc.get(args.workload)
-            if rec and world == 1 and args.m is None and args.n is None and args.dtype == "f32":
-                traffic = rec["kernels"][dom]["hbm_bytes"]
-                traffic_src = rec["source"]
-        except Exception:
-            pass
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(kern[dom]["GBps"], 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "avg_launch_ms": round(kern[dom]["avg_ms"], 4), "launches": kern[dom]["launches"],
-                    "algorithmic_bytes_per_launch": int(kern[dom]["bytes"]),
-                    "per_kernel": {k_: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["GBps"], 1),
-                                        "launches": v["launches"], "launches_per_pass": round(v["launches_per_pass"], 2)}
-                                   for k_, v in kern.items()},
-                    "whole_iteration": {"algorithmic_bytes_per_gpu": int(bytes_iter_local),
-                                        "GBps_per_gpu": round(bytes_iter_local * its / 1e9, 1),
-                                        "frac": round(bytes_iter_local * its / 1e9 / HBM_PEAK_GBS, 4),
-                                        "sweeps_of_A_per_iteration": round(sweeps, 3),
-                                        "hbm_bytes_moved_per_gpu": int(bytes_moved_local),
-                                        "hbm_GBps_moved_per_gpu": round(bytes_moved_local * its / 1e9, 1),
-                                        "frac_of_bytes_moved": round(bytes_moved_local * its / 1e9 / HBM_PEAK_GBS, 4),
-                                        "note": "algorithmic_bytes = SURVEY 8(d): A x and A' r as separate passes (2 m n s "
-                                                "+ vectors); frac > 1 means the iteration moves fewer bytes than that (the "
-                                                "single sweep reads A once); *_moved = bytes actually read/written"}}
-
+    line = None
     if rank == 0:
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            # the whole matrix when the host can hold it (3x headroom), else a column sample scaled linearly in n
-            need = 3 * m_glob * n * es
-            lim = _host_memory_limit()
-            if args.cpu_baseline == "full" or (args.cpu_baseline == "auto" and lim is not None and lim >= need):
-                cpu = cpu_baseline_full(A, b, lam, Lf)
-                # single-thread figure from the column sample (a one-thread pass over the whole matrix takes too long)
-                cpu["value_1thread"] = cpu_baseline(m_glob, n, args.cpu_sample_cols, max(2, args.cpu_steps // 2),
-                                                    args.seed)["value_1thread"]
-            else:
-                cpu = cpu_baseline(m_glob, n, args.cpu_sample_cols, args.cpu_steps, args.seed)
-        line = {
-            "metric": "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, %s)" % (m_glob, n, args.dtype),
-            "value": round(its, 4),
-            "unit": "it/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": "FFB LASSO m=%d n=%d %s, %s step, %s of A sharded over %d GPU(s)"
-                                   % (m_glob, n, "Float32" if args.dtype == "f32" else "Float64", args.mode,
-                                      "columns" if cols else "rows", world),
-                       "m": m_glob, "n": n, "mode": args.mode, "sharding": sharding, "shards": world,
-                       "row_shards": 1 if cols else world, "m_per_gpu": m_loc, "n_per_gpu": n_loc,
-                       "lambda": float(lam), "Lf": float(Lf) if Lf is not None else None, "seed": args.seed,
-                       "a_passes_per_step": a_passes / max(args.steps, 1), "sweeps": args.sweeps if (world == 1 or cols) else "two",
-                       "setup_s": round(t_setup, 2),
-                       "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
-                                 "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-    else:
-        line = None
+        cpu = extra.pop("cpu_baseline", None)
+        if cpu is None and world == 1 and not args.no_cpu_baseline and P is not None:
+            cpu = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
+        line = {"metric": "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, %s)" % (m_glob, n, args.dtype),
+                "value": main_rec["value"], "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": main_rec["config"],
+                "roofline": main_rec["roofline"], "cpu_baseline": cpu}
+        for k_ in ("ranks_seen_by_rccl", "collective"):
+            if k_ in main_rec:
+                line[k_] = main_rec[k_]
+        line.update(extra)
     if world > 1 or args.force_comm:
         dist.barrier()
         dist.destroy_process_group()
@@ -440,6 +731,15 @@ def main():
     if line is not None:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
+
+
+def cpu_leg(args, P, m_glob, n, es):
+    # the whole matrix when the host can hold it (3x headroom), else a column sample scaled linearly in n
+    need = 3 * m_glob * n * es
+    lim = _host_memory_limit()
+    if args.cpu_baseline == "full" or (args.cpu_baseline == "auto" and lim is not None and lim >= need):
+        return cpu_baseline_full(P["A"], P["b"], P["lam"], P["Lf"])
+    return cpu_baseline(m_glob, n, args.cpu_sample_cols, args.cpu_steps, args.seed)
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ __device__ __forceinline__ void ew_on_final(const F&, const double*) {}
 // Generic elementwise driver: F is a functor with
 //   template<int N> __device__ void operator()(int64_t i0, /*lane-private*/ Acc&) processing N consecutive
 // elements starting at i0 (N = VEC for the vector body, 1 for tails / unaligned operands).
-template <typename T, typename F, int NS, unsigned MAXMASK, int BS>
+template <typename T, typename F, int NS, unsigned MAXMASK, int BS, int UNR = 2>
 __global__ __launch_bounds__(BS) void ew_kernel(int64_t n, bool vec_ok, F f, double* __restrict__ red_partials,
                                                  unsigned* __restrict__ red_counter, double* __restrict__ out) {
   constexpr int VEC = VecOf<T>::N;
@@ -44,11 +44,11 @@ __global__ __launch_bounds__(BS) void ew_kernel(int64_t n, bool vec_ok, F f, dou
   if (vec_ok) {
     const int64_t nvec = n / VEC;
     int64_t v = tid;
-    for (; v + nthreads < nvec; v += 2 * nthreads) {  // two independent vectors per trip: more loads in flight
-      f.template apply<VEC>(v * VEC, acc);
-      f.template apply<VEC>((v + nthreads) * VEC, acc);
+    for (; v + (UNR - 1) * nthreads < nvec; v += UNR * nthreads) {  // UNR independent vectors per trip: more loads in flight
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) f.template apply<VEC>((v + k * nthreads) * VEC, acc);
     }
-    if (v < nvec) f.template apply<VEC>(v * VEC, acc);
+    for (; v < nvec; v += nthreads) f.template apply<VEC>(v * VEC, acc);
     for (int64_t i = nvec * VEC + tid; i < n; i += nthreads) f.template apply<1>(i, acc);
   } else {
     for (int64_t i = tid; i < n; i += nthreads) f.template apply<1>(i, acc);
@@ -111,12 +111,19 @@ __device__ __forceinline__ void st_nt(T* __restrict__ p, int64_t i, const Pack<T
 }
 
 
-template <typename T, typename F, int NS, unsigned MAXMASK>
-pg_status launch_ew(pg_ctx* c, int64_t n, bool vec_ok, const F& f, double* out_dev) {
+// BSR: workgroup size of a reducing kernel (default EW_BS_REDUCE); UNR: independent vectors per loop trip
+template <typename T, typename F, int NS, unsigned MAXMASK, int BSR = EW_BS_REDUCE, int UNR = 2>
+pg_status launch_ew(pg_ctx* c, int64_t n, bool vec_ok, const F& f, double* out_dev, int blocks_per_cu = 0) {
   if (n <= 0 && NS == 0) return PG_OK;
-  constexpr int BS = NS > 0 ? EW_BS_REDUCE : EW_BS_STREAM;
-  const unsigned blocks = grid_for(n / VecOf<T>::N + 1, c->num_cu, NS > 0);
-  hipLaunchKernelGGL((ew_kernel<T, F, NS, MAXMASK, BS>), dim3(blocks), dim3(BS), 0, c->stream, n, vec_ok, f,
+  constexpr int BS = NS > 0 ? BSR : EW_BS_STREAM;
+  unsigned blocks = grid_for(n / VecOf<T>::N + 1, c->num_cu, NS > 0);
+  if (blocks_per_cu > 0) {
+    int64_t b = (n / VecOf<T>::N + BS) / BS;
+    if (b > (int64_t)c->num_cu * blocks_per_cu) b = (int64_t)c->num_cu * blocks_per_cu;
+    if (b > PG_RED_MAX_BLOCKS) b = PG_RED_MAX_BLOCKS;
+    blocks = (unsigned)(b < 1 ? 1 : b);
+  }
+  hipLaunchKernelGGL((ew_kernel<T, F, NS, MAXMASK, BS, UNR>), dim3(blocks), dim3(BS), 0, c->stream, n, vec_ok, f,
                      c->red_partials, c->red_counter, out_dev);
   PG_LAUNCH_CHECK();
   return PG_OK;

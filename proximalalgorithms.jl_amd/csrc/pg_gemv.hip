@@ -11,8 +11,7 @@
 //                          top to bottom; per-column DPP/shuffle wave reduction; no cross-wave traffic.
 //   pass TN (single sweep): g = A' r, then per finished column the prox step and the column's contribution to the
 //                          NEXT residual while it is still in registers -- A read once per iteration
-//                          (pg_ls_fused_pass / pg_mat_fused_tn; column shards: one all-reduce of m + 4 N elements).
-//                          (pg_ls_fused_pass / pg_mat_fused_tn; column shards: one all-reduce of m + 4 N elements).
+//                          (pg_ls_fused_pass / pg_mat_fused_tn; column shards: one all-reduce of m + 8 N elements).
 //                          Three geometries by column length: gemv_tnw (short), gemv_tn (pg_gemv_tn.h), gemv_tnt
 //                          (long: teams of workgroups) -- see launch_tn.
 #include "pg_gemv_tn.h"
@@ -563,14 +562,27 @@ pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
 // This rank holds A[:, J_p] and the J_p slices of every n-vector; m-vectors are replicated.  What crosses ranks:
 //   * A x: every rank's partial A[:, J_p] x[J_p] (m elements), SUM all-reduce, then - b and the norm locally;
 //   * the four epilogue scalars { g(z), ||res||_inf, <g, res>, ||res||^2 }: each rank writes its values into its own
-//     group of four slots of a zeroed 4 * nranks vector; the SUM all-reduce then acts as an all-gather and every rank
+//     group of slots (four scalars, each as a hi / lo pair) of a zeroed vector; the SUM all-reduce then acts as an all-gather and every rank
 //     combines the groups in rank order (sum, max, sum, sum) -- one collective, deterministic, no MAX reduction needed.
 // A' r needs no collective at all (the columns are local), which is what lets the single-sweep iteration run with ONE
-// all-reduce of m + 4 * nranks elements per iteration.
+// all-reduce of m + 8 * nranks elements per iteration.
+// Every scalar travels as a (hi, lo) pair of working-precision values, hi = (T) d, lo = (T)(d - hi): the slots of a rank
+// are zero on every other rank, so the SUM passes both through exactly and d = hi + lo arrives with the ~48 (Float32) / 106
+// (Float64) bits the unsharded path keeps in its fp64 scalar block -- the line search compares f(z) against the model with a
+// tolerance of 10 eps, and a length n_global > 2^24 must survive the trip.
+constexpr int COL_SLOTS = 8;  // working-precision words per rank: 4 scalars x (hi, lo)
+
 template <typename T>
 __global__ void col_pack_scalars_kernel(T* __restrict__ slots, int nranks, int rank, const double* __restrict__ s4) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < 4 * nranks) slots[t] = (t >> 2) == rank ? (T)s4[t & 3] : T(0);
+  if (t >= COL_SLOTS * nranks) return;
+  T v = T(0);
+  if (t / COL_SLOTS == rank) {
+    const double d = s4[(t % COL_SLOTS) >> 1];
+    const T hi = (T)d;
+    v = (t & 1) ? (T)(d - (double)hi) : hi;
+  }
+  slots[t] = v;
 }
 
 template <typename T>
@@ -578,10 +590,11 @@ __global__ void col_unpack_scalars_kernel(const T* __restrict__ slots, int nrank
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double gz = 0.0, ri = 0.0, dg = 0.0, rs = 0.0;
   for (int p = 0; p < nranks; ++p) {
-    gz += (double)slots[4 * p + 0];
-    ri = fmax(ri, (double)slots[4 * p + 1]);
-    dg += (double)slots[4 * p + 2];
-    rs += (double)slots[4 * p + 3];
+    const T* q = slots + COL_SLOTS * p;
+    gz += (double)q[0] + (double)q[1];
+    ri = fmax(ri, (double)q[2] + (double)q[3]);
+    dg += (double)q[4] + (double)q[5];
+    rs += (double)q[6] + (double)q[7];
   }
   s4[0] = gz;
   s4[1] = ri;
@@ -592,7 +605,7 @@ __global__ void col_unpack_scalars_kernel(const T* __restrict__ slots, int nrank
 template <typename T>
 pg_status col_ensure_cbuf(pg_ls* f) {
   if (f->cbuf) return PG_OK;
-  const size_t bytes = ((size_t)f->A->ld + 4 * (size_t)f->ctx->shard_nranks + 64) * sizeof(T);
+  const size_t bytes = ((size_t)f->A->ld + COL_SLOTS * (size_t)f->ctx->shard_nranks + 64) * sizeof(T);
   hipError_t e = hipMalloc(&f->cbuf, bytes);
   if (e != hipSuccess) {
     pg_set_error("hipMalloc for the column-sharding payload failed: %s", hipGetErrorString(e));
@@ -608,10 +621,10 @@ pg_status col_allreduce_scalars_t(pg_ls* f) {
   PG_TRY(col_ensure_cbuf<T>(f));
   T* slots = (T*)f->cbuf + f->A->ld;
   const int nr = c->shard_nranks;
-  hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((4 * nr + 63) / 64), dim3(64), 0, c->stream, slots, nr, c->shard_rank,
-                     (const double*)(c->dscal + PG_S_GZ));
+  hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((COL_SLOTS * nr + 63) / 64), dim3(64), 0, c->stream, slots, nr,
+                     c->shard_rank, (const double*)(c->dscal + PG_S_GZ));
   PG_LAUNCH_CHECK();
-  PG_TRY(do_allreduce(c, slots, 4 * nr, f->A->dtype));
+  PG_TRY(do_allreduce(c, slots, COL_SLOTS * nr, f->A->dtype));
   hipLaunchKernelGGL(col_unpack_scalars_kernel<T>, dim3(1), dim3(64), 0, c->stream, (const T*)slots, nr, c->dscal + PG_S_GZ);
   PG_LAUNCH_CHECK();
   return PG_OK;
@@ -705,10 +718,10 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
                          (double*)nullptr, (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
       PG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((4 * nr + 63) / 64), dim3(64), 0, c->stream, payload + A->ld, nr,
-                       c->shard_rank, (const double*)(c->dscal + PG_S_GZ));
+    hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((COL_SLOTS * nr + 63) / 64), dim3(64), 0, c->stream, payload + A->ld,
+                       nr, c->shard_rank, (const double*)(c->dscal + PG_S_GZ));
     PG_LAUNCH_CHECK();
-    PG_TRY(do_allreduce(c, payload, A->ld + 4 * nr, A->dtype));
+    PG_TRY(do_allreduce(c, payload, A->ld + COL_SLOTS * nr, A->dtype));
     PG_TRY(pg_residual_combo_async(c, A->dtype, A->m, r_dst, 1.0, payload, -1.0, f->b, 0.5 * f->lam, nullptr, f_dst));
     hipLaunchKernelGGL(col_unpack_scalars_kernel<T>, dim3(1), dim3(64), 0, c->stream, (const T*)(payload + A->ld), nr,
                        c->dscal + PG_S_GZ);

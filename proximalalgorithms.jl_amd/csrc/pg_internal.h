@@ -62,14 +62,14 @@ enum {
   PG_S_RESSQ = 4,    // ||res||^2
   PG_S_MISC = 5,     // dot / nrm2sq / nrminf / prox value results (2 slots)
   PG_S_DR = 8,       // Douglas-Rachford step: { ||res||_inf, f(y), g(z) }
-  PG_S_FNEXT = 34,   // f at the speculative next point of the single-sweep iteration (2 slots, alternating)
-  PG_S_TEAMERR = 36, // set to 1 by a workgroup team of the long-column sweep that gave up waiting for a member
-  PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 16 inner iterations, f(y), g(z) }
-  PG_S_COUNT = 40
+  PG_S_FNEXT = 12,   // f at the speculative next point of the single-sweep iteration (2 slots, alternating)
+  PG_S_TEAMERR = 14, // set to 1 by a workgroup team of the long-column sweep that gave up waiting for a member
+  PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 32 inner iterations, f(y), g(z) }
+  PG_S_COUNT = 56
 };
 
 constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize
-constexpr int PG_RED_MAX_NS = 18;
+constexpr int PG_RED_MAX_NS = 34;
 
 // RCCL communicator bound by pg_ctx_comm_init (csrc/pg_comm.hip)
 struct pg_comm {
@@ -266,7 +266,9 @@ __device__ __forceinline__ T pg_wave_allreduce(T v) {
 // write-through agent-scope stores; the last block to arrive (ticket counter) combines all partials in a
 // fixed order and writes out[k] * post_scale[k].  The counter is reset for the next launch.  Returns true
 // (to all its threads) in the finalizing block only; out[] is then visible to that block's thread 0.
-template <int NS, unsigned MAXMASK, int NW = 4>
+// WAVE_REDUCED: v[] already holds the wave's values in lane 0 (the caller reduced within the wave, e.g. in working precision
+// with DPP moves); the fp64 shuffle stage is skipped.
+template <int NS, unsigned long long MAXMASK, int NW = 4, bool WAVE_REDUCED = false>
 __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __restrict__ partials,
                                                      unsigned* __restrict__ counter, double* __restrict__ out,
                                                      const double (&post_scale)[NS], double* final_vals = nullptr) {
@@ -274,12 +276,14 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
   __shared__ int sm_last;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  if constexpr (!WAVE_REDUCED) {
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
+    for (int k = 0; k < NS; ++k) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      double o = pg_shfl_down(v[k], off);
-      v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
+      for (int off = 32; off >= 1; off >>= 1) {
+        double o = pg_shfl_down(v[k], off);
+        v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
+      }
     }
   }
   if (lane == 0) {

@@ -334,33 +334,142 @@ struct DRBlockArgs {
   double gscale;
 };
 
+// two elements side by side: on gfx950 the multiply-adds of a Float32 pair issue as ONE v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 (Float64 pairs are two instructions; same source)
+template <typename T>
+struct Pair2 {
+  typedef T type __attribute__((ext_vector_type(2)));
+};
+__device__ __forceinline__ float pg_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double pg_med3(double x, double lo, double hi) { return fmin(hi, fmax(lo, x)); }
+
+template <typename T, int N>
+struct DRBlockIn {
+  Pack<T, N> x, d, q;
+};
+// BOTH: d and q are known to be vectors -- three unconditional loads (no branch for the compiler to trip over)
+template <typename T, int GKIND, int K, int N, bool BOTH = false>
+__device__ __forceinline__ DRBlockIn<T, N> dr_block_load(const DRBlockArgs<T, GKIND, K>& a, int64_t i) {
+  DRBlockIn<T, N> in;
+  in.x = ld<T, N>(a.x_in, i);
+  if (BOTH || a.f.dv != nullptr) in.d = ld<T, N>(a.f.dv, i);
+  if (BOTH || a.f.qv != nullptr) in.q = ld<T, N>(a.f.qv, i);
+  return in;
+}
+
 template <typename T, int GKIND, int K, int N>
-__device__ __forceinline__ void dr_block_apply(const DRBlockArgs<T, GKIND, K>& a, int64_t i, T (&mx)[K], double& fy,
-                                               double& gz) {
-  Pack<T, N> xv = ld<T, N>(a.x_in, i), yv, rv, zv, sv, d, q;
-  if (a.f.dv != nullptr) d = ld<T, N>(a.f.dv, i);
-  if (a.f.qv != nullptr) q = ld<T, N>(a.f.qv, i);
+__device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>& a, int64_t i, const DRBlockIn<T, N>& in,
+                                                 T (&mx)[K], double& fy, double& gz) {
+#pragma clang fp contract(off)
+  Pack<T, N> xv = in.x, yv, rv, zv, sv, d = in.d, q = in.q;
+  if constexpr (N >= 2) {
+    using P = typename Pair2<T>::type;
+    constexpr int NP = N / 2;
+    const P two = {T(2), T(2)}, gam = {a.gamma, a.gamma};
+    // sepquad_prepare / sepquad_apply on pairs: same operations, same rounding, per lane.  The NP pairs of a vector advance
+    // in lockstep (pair loop INSIDE the iteration loop): consecutive instructions then belong to different dependency
+    // chains, which is what the packed-Float32 pipeline wants (a dependent v_pk_* needs a wait state; written pair by
+    // pair the compiler filled those with s_nop, 276 of them against 358 arithmetic instructions).
+    // Float32 quotient a / den = RN32(RN64(a * RN64(1 / den))): the double product is within 2^-52 of a / den, and the
+    // quotient of two 24-bit significands is never closer than 2^-49 (relative) to a rounding boundary of the 24-bit
+    // format, so the final rounding lands on RN32(a / den) -- the bits of the IEEE division, for three full-rate
+    // instructions (convert, multiply, convert) instead of the five of the Markstein sequence.  Float64 keeps Markstein.
+    constexpr bool VIA64 = false;  // measured: 67.3 us per 16 iterations against 65.1 us for the Markstein form (the conversions are not full rate)
+    P de[NP], qe[NP], gq[NP], inv[NP], nden[NP], xe[NP], ye[NP], re[NP], ze[NP], se[NP];
+    double inv64[NP][2];
 #pragma unroll
-  for (int e = 0; e < N; ++e) {
-    const T de = a.f.dv != nullptr ? d.v[e] : a.f.ds;
-    const T qe = a.f.qv != nullptr ? q.v[e] : a.f.qs;
-    const SepQuadElem<T> pe = sepquad_prepare(a.gamma, de, qe);  // one division per element per sweep
-    T xe = xv.v[e], ye, re, ze, se;
+    for (int p = 0; p < NP; ++p) {
+      de[p] = (P){a.f.dv != nullptr ? d.v[2 * p] : a.f.ds, a.f.dv != nullptr ? d.v[2 * p + 1] : a.f.ds};
+      qe[p] = (P){a.f.qv != nullptr ? q.v[2 * p] : a.f.qs, a.f.qv != nullptr ? q.v[2 * p + 1] : a.f.qs};
+      gq[p] = gam * qe[p];
+      const P den = (P){T(1), T(1)} + gam * de[p];
+      if constexpr (VIA64) {
+        inv64[p][0] = 1.0 / (double)den[0], inv64[p][1] = 1.0 / (double)den[1];  // one division per element per sweep
+      } else {
+        inv[p] = (P){T(1) / den[0], T(1) / den[1]};
+        nden[p] = -den;
+      }
+      xe[p] = (P){xv.v[2 * p], xv.v[2 * p + 1]};
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      P aa[NP], qq[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) aa[p] = xe[p] - gq[p];
+      if constexpr (VIA64) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) qq[p] = (P){(T)((double)aa[p][0] * inv64[p][0]), (T)((double)aa[p][1] * inv64[p][1])};
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) qq[p] = aa[p] * inv[p];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {  // two Markstein corrections
+          P rr[NP];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) rr[p] = __builtin_elementwise_fma(nden[p], qq[p], aa[p]);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) qq[p] = __builtin_elementwise_fma(rr[p], inv[p], qq[p]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        ye[p] = qq[p];
+        re[p] = __builtin_elementwise_fma(two, ye[p], -xe[p]);  // 2 y - x: the product is exact, so this is the unfused value
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          if constexpr (GKIND == PG_G_NORML1)
+            ze[p][l] = soft_threshold(re[p][l], a.p0);
+          else if constexpr (GKIND == PG_G_INDBOX)
+            ze[p][l] = pg_med3(re[p][l], a.p0, a.p1);  // = min(hi, max(lo, .)) for lo <= hi (checked by the entry point)
+          else
+            ze[p][l] = re[p][l];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) se[p] = ye[p] - ze[p];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) xe[p] = xe[p] - se[p];
+      T m = mx[j];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) m = fmax(m, fmax(fabs(se[p][0]), fabs(se[p][1])));
+      mx[j] = m;
+      // one iteration at a time: left alone the scheduler postpones the K running maxima to the end of the sweep and keeps
+      // every iteration's residual alive for them (209 registers at K = 32)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int e = 2 * p + l;
+        xv.v[e] = xe[p][l], yv.v[e] = ye[p][l], rv.v[e] = re[p][l], zv.v[e] = ze[p][l], sv.v[e] = se[p][l];
+        fy += 0.5 * (double)de[p][l] * (double)ye[p][l] * (double)ye[p][l] + (double)qe[p][l] * (double)ye[p][l];
+        if constexpr (GKIND == PG_G_NORML1) gz += fabs((double)ze[p][l]);
+      }
+    }
+  } else {
+    const T de = a.f.dv != nullptr ? d.v[0] : a.f.ds;
+    const T qe = a.f.qv != nullptr ? q.v[0] : a.f.qs;
+    const SepQuadElem<T> pe = sepquad_prepare(a.gamma, de, qe);
+    T xe = xv.v[0], ye, re, ze, se;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       ye = sepquad_apply(pe, xe);
-      re = T(2) * ye - xe;
+      re = fma(T(2), ye, -xe);
       if constexpr (GKIND == PG_G_NORML1)
         ze = soft_threshold(re, a.p0);
       else if constexpr (GKIND == PG_G_INDBOX)
-        ze = fmin(a.p1, fmax(a.p0, re));
+        ze = pg_med3(re, a.p0, a.p1);
       else
         ze = re;
       se = ye - ze;
       xe = xe - se;
       mx[j] = fmax(mx[j], fabs(se));
     }
-    xv.v[e] = xe, yv.v[e] = ye, rv.v[e] = re, zv.v[e] = ze, sv.v[e] = se;
+    xv.v[0] = xe, yv.v[0] = ye, rv.v[0] = re, zv.v[0] = ze, sv.v[0] = se;
     fy += 0.5 * (double)de * (double)ye * (double)ye + (double)qe * (double)ye;
     if constexpr (GKIND == PG_G_NORML1) gz += fabs((double)ze);
   }
@@ -373,10 +482,11 @@ __device__ __forceinline__ void dr_block_apply(const DRBlockArgs<T, GKIND, K>& a
 
 // 512-thread workgroups, two per CU: the K running maxima live in T registers over the whole sweep (they only become
 // doubles for the grid reduction), which keeps the K = 16 body free of scratch spills
-constexpr int DR_BLOCK_BS = 512;
+template <int K>
+constexpr int dr_block_bs() { return K <= 16 ? 512 : 256; }  // K = 32: 32 running maxima per thread; 256-thread workgroups keep three per CU
 
 template <typename T, int GKIND, int K>
-__global__ __launch_bounds__(DR_BLOCK_BS) void dr_block_kernel(int64_t n, bool vec_ok, DRBlockArgs<T, GKIND, K> a,
+__global__ __launch_bounds__(dr_block_bs<K>()) void dr_block_kernel(int64_t n, bool vec_ok, DRBlockArgs<T, GKIND, K> a,
                                                                double* __restrict__ red_partials,
                                                                unsigned* __restrict__ red_counter,
                                                                double* __restrict__ out) {
@@ -385,21 +495,45 @@ __global__ __launch_bounds__(DR_BLOCK_BS) void dr_block_kernel(int64_t n, bool v
 #pragma unroll
   for (int j = 0; j < K; ++j) mx[j] = T(0);
   double fy = 0.0, gz = 0.0;
+  constexpr int DR_BLOCK_BS = dr_block_bs<K>();
   const int64_t tid = (int64_t)blockIdx.x * DR_BLOCK_BS + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * DR_BLOCK_BS;
   if (vec_ok) {
     const int64_t nvec = n / VEC;
-    for (int64_t v = tid; v < nvec; v += nthreads) dr_block_apply<T, GKIND, K, VEC>(a, v * VEC, mx, fy, gz);
-    for (int64_t i = nvec * VEC + tid; i < n; i += nthreads) dr_block_apply<T, GKIND, K, 1>(a, i, mx, fy, gz);
+    // Software pipeline: the next vector's x, d, q are requested BEFORE the K iterations on the current one, so the
+    // memory phase of a trip hides behind the arithmetic of the previous one (all waves of the grid start together and
+    // would otherwise alternate between loading and computing in step: 21 us + 16 x 2.8 us per sweep at n = 10^7).
+    // The prefetch is unconditional -- past the end it re-reads the thread's last vector -- because a branch around it
+    // makes the compiler wait for it (vmcnt(0)) before the arithmetic, which undoes the overlap.
+    if (a.f.dv != nullptr && a.f.qv != nullptr) {
+      if (tid < nvec) {
+        DRBlockIn<T, VEC> cur = dr_block_load<T, GKIND, K, VEC, true>(a, tid * VEC);
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+          const int64_t vn = v + nthreads < nvec ? v + nthreads : v;
+          const DRBlockIn<T, VEC> nxt = dr_block_load<T, GKIND, K, VEC, true>(a, vn * VEC);
+          __builtin_amdgcn_sched_barrier(0);  // keep the loads up here (the scheduler sinks them below the arithmetic)
+          dr_block_compute<T, GKIND, K, VEC>(a, v * VEC, cur, mx, fy, gz);
+          cur = nxt;
+        }
+      }
+    } else {  // scalar d or q: nothing worth prefetching beyond x
+      for (int64_t v = tid; v < nvec; v += nthreads)
+        dr_block_compute<T, GKIND, K, VEC>(a, v * VEC, dr_block_load<T, GKIND, K, VEC>(a, v * VEC), mx, fy, gz);
+    }
+    for (int64_t i = nvec * VEC + tid; i < n; i += nthreads)
+      dr_block_compute<T, GKIND, K, 1>(a, i, dr_block_load<T, GKIND, K, 1>(a, i), mx, fy, gz);
   } else {
-    for (int64_t i = tid; i < n; i += nthreads) dr_block_apply<T, GKIND, K, 1>(a, i, mx, fy, gz);
+    for (int64_t i = tid; i < n; i += nthreads)
+      dr_block_compute<T, GKIND, K, 1>(a, i, dr_block_load<T, GKIND, K, 1>(a, i), mx, fy, gz);
   }
+  // the K maxima are reduced within the wave in working precision (DPP row steps + v_readlane: ~11 instructions each
+  // against ~36 for an fp64 shuffle chain -- the end of the kernel was a fifth of its instruction count)
   double v[K + 2], ps[K + 2];
 #pragma unroll
-  for (int j = 0; j < K; ++j) v[j] = (double)mx[j], ps[j] = 1.0;
-  v[K] = fy, ps[K] = 1.0;
-  v[K + 1] = gz, ps[K + 1] = a.gscale;
-  grid_reduce_finalize<K + 2, (1u << K) - 1u, DR_BLOCK_BS / 64>(v, red_partials, red_counter, out, ps);
+  for (int j = 0; j < K; ++j) v[j] = (double)pg_wave_allreduce<true, T>(mx[j]), ps[j] = 1.0;
+  v[K] = pg_wave_allreduce<false, double>(fy), ps[K] = 1.0;
+  v[K + 1] = pg_wave_allreduce<false, double>(gz), ps[K + 1] = a.gscale;
+  grid_reduce_finalize<K + 2, (1ull << K) - 1ull, DR_BLOCK_BS / 64, true>(v, red_partials, red_counter, out, ps);
 }
 
 // smooth losses on m-vectors (the `f` of PANOC's f(Ax)); acc[0] = f(u), grad written elementwise
@@ -543,6 +677,28 @@ pg_status prox_sepquad_t(pg_ctx* c, int64_t n, void* y, const void* x, const voi
   return launch_ew<T, ProxSepQuadF<T>, 1, 0u>(c, n, v, f, c->dscal + PG_S_MISC);
 }
 
+// launch geometry of the stepping kernel; PG_DR_STEP_GEOM = "<threads>x<blocks per CU>x<vectors per trip>" for experiments
+template <typename T, typename F>
+pg_status dr_step_launch(pg_ctx* c, int64_t n, bool v, const F& f) {
+  static const char* geom = getenv("PG_DR_STEP_GEOM");
+  int bs = 1024, bpc = 1, unr = 2;
+  if (geom != nullptr && *geom) sscanf(geom, "%dx%dx%d", &bs, &bpc, &unr);
+#define PG_DR_GEOM(BB, UU) \
+  if (bs == BB && unr == UU) return launch_ew<T, F, 3, 0x1u, BB, UU>(c, n, v, f, c->dscal + PG_S_DR, bpc)
+  PG_DR_GEOM(1024, 2);
+  PG_DR_GEOM(1024, 1);
+  PG_DR_GEOM(1024, 4);
+  PG_DR_GEOM(512, 1);
+  PG_DR_GEOM(512, 2);
+  PG_DR_GEOM(512, 4);
+  PG_DR_GEOM(256, 1);
+  PG_DR_GEOM(256, 2);
+  PG_DR_GEOM(256, 4);
+#undef PG_DR_GEOM
+  pg_set_error("PG_DR_STEP_GEOM: unsupported geometry %dx%dx%d", bs, bpc, unr);
+  return PG_ERR_INVALID;
+}
+
 template <typename T>
 pg_status dr_step_t(pg_ctx* c, int64_t n, void* x, void* y, void* r, void* z, void* res, const void* dv, double ds,
                     const void* qv, double qs, int g_kind, double g_p0, double g_p1, double gamma) {
@@ -553,15 +709,15 @@ pg_status dr_step_t(pg_ctx* c, int64_t n, void* x, void* y, void* r, void* z, vo
   pg_prof_scope prof(c, PG_K_DR_STEP);
   if (g_kind == PG_G_NORML1) {
     DRStepF<T, PG_G_NORML1> f{(T*)x, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)(gm * (T)g_p0), T(0), (double)(T)g_p0};
-    return launch_ew<T, decltype(f), 3, 0x1u>(c, n, v, f, c->dscal + PG_S_DR);
+    return dr_step_launch<T>(c, n, v, f);
   }
   if (g_kind == PG_G_INDBOX) {
     DRStepF<T, PG_G_INDBOX> f{(T*)x, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)g_p0, (T)g_p1, 0.0};
-    return launch_ew<T, decltype(f), 3, 0x1u>(c, n, v, f, c->dscal + PG_S_DR);
+    return dr_step_launch<T>(c, n, v, f);
   }
   if (g_kind == PG_G_ZERO) {
     DRStepF<T, PG_G_ZERO> f{(T*)x, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, T(0), T(0), 0.0};
-    return launch_ew<T, decltype(f), 3, 0x1u>(c, n, v, f, c->dscal + PG_S_DR);
+    return dr_step_launch<T>(c, n, v, f);
   }
   pg_set_error("unknown g_kind %d", g_kind);
   return PG_ERR_INVALID;
@@ -569,8 +725,9 @@ pg_status dr_step_t(pg_ctx* c, int64_t n, void* x, void* y, void* r, void* z, vo
 
 template <typename T, int GKIND, int K>
 pg_status dr_block_launch(pg_ctx* c, int64_t n, bool vec_ok, const DRBlockArgs<T, GKIND, K>& a) {
+  constexpr int DR_BLOCK_BS = dr_block_bs<K>();
   int64_t blocks = (n / VecOf<T>::N + DR_BLOCK_BS) / DR_BLOCK_BS;
-  if (blocks > (int64_t)c->num_cu * 2) blocks = (int64_t)c->num_cu * 2;
+  if (blocks > (int64_t)c->num_cu * (1024 / DR_BLOCK_BS)) blocks = (int64_t)c->num_cu * (1024 / DR_BLOCK_BS);
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
   hipLaunchKernelGGL((dr_block_kernel<T, GKIND, K>), dim3((unsigned)blocks), dim3(DR_BLOCK_BS), 0, c->stream, n, vec_ok, a,
                      c->red_partials, c->red_counter, c->dscal + PG_S_DRRUN);
@@ -618,8 +775,9 @@ pg_status dr_run_t(pg_ctx* c, int64_t n, void* x, void* x_alt, void* y, void* r,
   bool done = false;
   while (!done && k < maxit) {
     if (K > 1 && maxit - k >= K) {
-      PG_TRY(K == 16 ? (dr_block_t<T, 16>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma))
-                     : (dr_block_t<T, 8>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma)));
+      PG_TRY(K == 32   ? (dr_block_t<T, 32>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma))
+             : K == 16 ? (dr_block_t<T, 16>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma))
+                       : (dr_block_t<T, 8>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma)));
       PG_TRY(pg_read_scalars(c, PG_S_DRRUN, K + 2));
       int hit = -1;
       for (int j = 0; j < K && hit < 0; ++j)
@@ -830,10 +988,12 @@ pg_status pg_dr_run(pg_ctx* c, int32_t dtype, int64_t n, void* x, void* x_alt, v
   PG_VEC_ARGS_OK(c, n);
   PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
   PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
-  PG_REQUIRE(block == 1 || block == 8 || block == 16, "block must be 1, 8 or 16");
+  PG_REQUIRE(block == 1 || block == 8 || block == 16 || block == 32, "block must be 1, 8, 16 or 32");
   PG_REQUIRE(block == 1 || (x_alt != nullptr && x_alt != x) || n == 0, "x_alt (a second n-vector) is required when block > 1");
   PG_REQUIRE(maxit >= 1, "maxit must be >= 1");
   PG_REQUIRE(gamma > 0, "gamma must be positive");
+  // ProximalOperators.IndBox refuses lb > ub at construction; the blocked kernel clamps with v_med3_f32 on that premise
+  PG_REQUIRE(g_kind != PG_G_INDBOX || g_p0 <= g_p1, "IndBox needs lo <= hi");
   return dtype == PG_F32 ? dr_run_t<float>(c, n, x, x_alt, y, r, z, res, d_vec, d, q_vec, q, g_kind, g_p0, g_p1, gamma,
                                            tol, maxit, block, k_out, scalars_out)
                          : dr_run_t<double>(c, n, x, x_alt, y, r, z, res, d_vec, d, q_vec, q, g_kind, g_p0, g_p1, gamma,

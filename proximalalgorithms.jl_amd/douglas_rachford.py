@@ -122,7 +122,7 @@ def default_display(it, iteration, state):
 def DouglasRachford(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
                     display=default_display, device_loop=False, check_every=16, graph=False, **kwargs):
     """douglas_rachford.jl:101-119.  device_loop=True (default stop rule, fused engine): the driver loop runs inside
-    the library, ``check_every`` (1, 8 or 16) iterations per HBM sweep; same iterates, same iteration count."""
+    the library, ``check_every`` (1, 8, 16 or 32) iterations per HBM sweep; same iterates, same iteration count."""
     dl = (tol, int(check_every)) if (device_loop and stop is None) else None
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)

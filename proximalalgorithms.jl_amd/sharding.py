@@ -5,7 +5,7 @@ with ONE sum all-reduce of [grad ; f] (n+1 elements) over RCCL/xGMI, every f-onl
 all-reduce.  All n-vectors are replicated, so the elementwise epilogue and its reductions need no communication.
 
 Column sharding (``shard="cols"``): every rank holds a column block of A and the matching slices of the n-vectors; b and
-the residual are replicated.  A' r is then local and what crosses ranks is A x (m elements) plus 4 * world scalar slots
+the residual are replicated.  A' r is then local and what crosses ranks is A x (m elements) plus 8 * world scalar slots (four scalars per rank, each as a hi / lo pair)
 -- ONE all-reduce per iteration, 64x smaller than the row-sharded payload at the headline shape -- so every rank keeps
 the single-sweep iteration (A read once per iteration).
 """

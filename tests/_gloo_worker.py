@@ -61,7 +61,7 @@ def main():
         assert torch.equal(gathered[0], gathered[1])
     # ---- column shards: the single-sweep protocol of csrc/pg_gemv.hip (ls_fused_pass_t, column mode) on the CPU ----
     # every rank holds A[:, J_p] and the J_p slices of the n-vectors; per iteration ONE all-reduce of
-    # [partial of A v (m) ; 4 * world scalar slots]; the slots turn the SUM into an all-gather (sum, max, sum, sum)
+    # [partial of A v (m) ; 8 * world scalar slots (hi / lo pairs)]; the slots turn the SUM into an all-gather (sum, max, sum, sum)
     for dtype in (np.float32, np.float64):
         A, b, _ = o.synthetic_lasso(m, n, seed=0, dtype=dtype)
         lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
@@ -73,12 +73,16 @@ def main():
         s_ref = next(ref)
 
         def exchange(part, scal):
-            slots = np.zeros(4 * world, dtype)
-            slots[4 * rank:4 * rank + 4] = scal
+            # every scalar as a (hi, lo) pair of the working precision: hi = T(d), lo = T(d - hi) (col_pack_scalars_kernel)
+            d = np.asarray(scal, np.float64)
+            hi = d.astype(dtype)
+            lo = (d - hi.astype(np.float64)).astype(dtype)
+            slots = np.zeros(8 * world, dtype)
+            slots[8 * rank:8 * rank + 8] = np.stack([hi, lo], axis=1).ravel()
             buf = torch.from_numpy(np.concatenate([part, slots]))
             pa.allreduce_sum_(buf)
             out = buf.numpy()
-            sl = out[m:].reshape(world, 4)
+            sl = out[m:].astype(np.float64).reshape(world, 4, 2).sum(axis=2)
             return out[:m].copy(), (sl[:, 0].sum(), sl[:, 1].max(), sl[:, 2].sum(), sl[:, 3].sum())
 
         # init (state 1): x = x0, z = prox(x - gamma grad), z_prev = x   -- local slices

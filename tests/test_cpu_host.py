@@ -109,6 +109,78 @@ def test_bench_cli_parses_without_gpu():
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
 
 
+def test_bench_self_launches_ranks_as_a_child(monkeypatch, capsys):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): before anything touches the GPU the script starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (subprocess, never exec), relays the
+    child's single JSON line and returns its exit code."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class Done:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+
+    def fake_run(cmd, stdout=None, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done(seen["rc"], seen["out"])
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    line = json.dumps({"metric": "m", "value": 1.0, "n_gpus": 4})
+    seen["rc"], seen["out"] = 0, ("NCCL banner\n" + line + "\n").encode()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    assert capsys.readouterr().out.strip() == line  # exactly the child's JSON line
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a failing child: its exit code comes back, nothing is printed
+    seen["rc"], seen["out"] = 3, b"Traceback ...\n"
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3 and capsys.readouterr().out == ""
+    # a child that exits 0 without a line is an error, not a silent success
+    seen["rc"], seen["out"] = 0, b""
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 1
+
+
+def test_pmc_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic is only quoted while the sweep-kernel sources hash to what the rocprofv3 --pmc passes were taken
+    on; otherwise bench.py reports traffic = null with traffic_stale = true."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h = bench.kernel_source_hash()
+    assert len(h) == 64 and h == bench.kernel_source_hash()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert "kernel_source_sha256" in committed["headline"]
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: h)
+    rec = {"headline": {"source": "profiles/x.md", "kernel_source_sha256": h, "kernels": {"gemv_tn": {"hbm_bytes": 123.0}}}}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec))
+    assert bench.pmc_traffic("headline", "gemv_tn") == (123.0, "profiles/x.md", False)
+    assert bench.pmc_traffic("config2", "gemv_tn") == (None, None, False)  # never measured there
+    rec["headline"]["kernel_source_sha256"] = "0" * 64
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec))
+    assert bench.pmc_traffic("headline", "gemv_tn") == (None, "profiles/x.md", True)
+
+
 def test_iteration_tools():
     """test/utilities/test_iteration_tools.jl (host logic, no device)"""
     import itertools
