@@ -59,7 +59,9 @@ enum {
   PG_SEQ_FIXED = 1,    /* FixedNesterovSequence          nesterov.jl:14-17                   */
   PG_SEQ_SIMPLE = 2,   /* SimpleNesterovSequence         nesterov.jl:36                      */
   PG_SEQ_CONSTANT = 3, /* ConstantNesterovSequence(m, s) nesterov.jl:51-54                   */
-  PG_SEQ_HOST = 4      /* coefficient supplied by the host each step (custom iterators)      */
+  PG_SEQ_HOST = 4,     /* coefficient supplied by the host each step (custom iterators)      */
+  PG_SEQ_REPEATED = 5  /* the constant seq_p0 every step: Iterators.repeated(beta), which is what
+                        * ConstantNesterovSequence returns (nesterov.jl:51-54)               */
 };
 
 /* flags reported in pg_iter_scalars.flags */
@@ -301,7 +303,7 @@ typedef struct pg_iter_opts {
   double increase_gamma; /* 1.0   */
   double mf;             /* FFB: convexity modulus (0)                                           */
   int32_t seq_kind;      /* FFB: PG_SEQ_*                                                        */
-  double seq_p0, seq_p1; /* PG_SEQ_CONSTANT: (m, stepsize)                                       */
+  double seq_p0, seq_p1; /* PG_SEQ_CONSTANT: (m, stepsize) ; PG_SEQ_REPEATED: seq_p0 = the coefficient    */
   int32_t g_kind;        /* PG_G_*                                                               */
   double g_p0, g_p1;     /* NormL1: lam | IndBox: lo, hi                                         */
   int32_t reuse_residual; /* FFB adaptive: 1 (default) = form A x - b at the extrapolated point from the residuals

@@ -19,6 +19,7 @@ import warnings
 
 import numpy as np
 
+from . import _lib
 from ._lib import ProxGradError
 from .device import HIPMatrix, HIPVector
 from .fb_tools import f_model, lower_bound_smoothness_constant
@@ -176,7 +177,7 @@ def try_iter(it, state_cls, fast):
         gen = (iter_ffb if fast else iter_fb)(it, state_cls)
         first = next(gen)
     except ProxGradError as e:
-        if "error -4" in str(e):  # PG_ERR_UNSUPPORTED: fall back to the generic engine
+        if e.code == _lib.PG_ERR_UNSUPPORTED:  # fall back to the generic engine (any other failure propagates)
             return None
         raise
 

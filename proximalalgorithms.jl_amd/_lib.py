@@ -8,14 +8,23 @@ LIB_PATH = os.path.join(HERE, "libproxgrad_hip.so")
 
 PG_F32, PG_F64 = 0, 1
 PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX, PG_G_SQRNORML2 = 0, 1, 2, 3
-PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST = 0, 1, 2, 3, 4
+PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST, PG_SEQ_REPEATED = 0, 1, 2, 3, 4, 5
 PG_FLAG_GAMMA_TOO_SMALL = 1
 PG_K_GEMV_N, PG_K_GEMV_N_FINISH, PG_K_GEMV_T, PG_K_EPILOGUE, PG_K_EXTRAPOLATE, PG_K_DR_STEP = range(6)
 KERNEL_NAMES = ["gemv_n_partial", "gemv_n_finish", "gemv_t", "fb_epilogue", "extrapolate", "dr_step", "gemv_tn"]
 
 
+PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_ALLOC, PG_ERR_UNSUPPORTED, PG_ERR_COLLECTIVE = -1, -2, -3, -4, -5
+
+
 class ProxGradError(RuntimeError):
-    pass
+    """A failed library call; ``code`` is the pg_status (PG_ERR_*; None for errors raised on the Python side).  Callers
+    that fall back to another path do so on ``e.code == PG_ERR_UNSUPPORTED`` only -- a HIP or allocation failure
+    propagates."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 class pg_device_info(C.Structure):
@@ -169,7 +178,7 @@ def exported_symbols():
 def check(status):
     if status != 0:
         msg = load().pg_last_error()
-        raise ProxGradError(f"libproxgrad_hip error {status}: {msg.decode() if msg else '?'}")
+        raise ProxGradError(f"libproxgrad_hip error {status}: {msg.decode() if msg else '?'}", code=int(status))
 
 
 def call(name, *args):

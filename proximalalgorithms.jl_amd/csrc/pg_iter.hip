@@ -383,7 +383,7 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   PG_REQUIRE(c != nullptr && f != nullptr && o != nullptr && out != nullptr, "null argument");
   PG_REQUIRE(f->ctx == c, "f belongs to another context");
   PG_REQUIRE(o->g_kind == PG_G_ZERO || o->g_kind == PG_G_NORML1 || o->g_kind == PG_G_INDBOX, "unknown g_kind");
-  PG_REQUIRE(o->seq_kind >= PG_SEQ_ADAPTIVE && o->seq_kind <= PG_SEQ_HOST, "unknown seq_kind");
+  PG_REQUIRE(o->seq_kind >= PG_SEQ_ADAPTIVE && o->seq_kind <= PG_SEQ_REPEATED, "unknown seq_kind");
   *out = nullptr;
   pg_iter* it = new pg_iter();
   it->ctx = c;

@@ -72,6 +72,8 @@ __host__ __device__ inline T seq_next_hd(int kind, T mf, T p0, T p1, SeqState<T>
     }
     case PG_SEQ_HOST:
       return host_beta;
+    case PG_SEQ_REPEATED:  // Iterators.repeated(beta)
+      return p0;
     case PG_SEQ_ADAPTIVE:
     default: {  // nesterov.jl:89-103
       const T m = mf;

@@ -25,6 +25,8 @@ struct pg_lbfgs {
   void* img_slab = nullptr;  // As_M[M], Ay_M[M]
   size_t img_vb = 0;
   bool last_update_accepted = false;
+  bool img_valid[64] = {};  // slot holds the images of the pair currently stored in it (set by images_update, cleared when
+                            // update overwrites the slot, when images are (re-)enabled and on reset)
   int last_k = 0;        // currmem of the last apply
   int last_idx[64];      // its loop order (newest -> oldest, 1-based slots)
   double last_H = 1.0;
@@ -201,6 +203,7 @@ pg_status lbfgs_update_t(pg_lbfgs* L, const void* s, const void* y) {
     L->currmem += 1;
     if (L->currmem > L->M) L->currmem = L->M;
     L->ys_M[L->curridx - 1] = (double)ys;
+    L->img_valid[L->curridx - 1] = false;  // the slot's images (if any) belonged to the pair just overwritten
     if (L->n > 0) {
       PG_HIP(hipMemcpyAsync(L->s_M[L->curridx - 1], L->s, nb, hipMemcpyDeviceToDevice, c->stream));
       PG_HIP(hipMemcpyAsync(L->y_M[L->curridx - 1], L->y, nb, hipMemcpyDeviceToDevice, c->stream));
@@ -275,6 +278,7 @@ pg_status pg_lbfgs_reset(pg_lbfgs* L) {  // lbfgs.jl:52-55
   L->H = 1.0;
   L->last_k = 0;
   L->last_H = 1.0;
+  for (bool& v : L->img_valid) v = false;
   return PG_OK;
 }
 
@@ -293,6 +297,7 @@ pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m) {
     return PG_ERR_ALLOC;
   }
   PG_HIP(hipMemsetAsync(L->img_slab, 0, L->img_vb * 2 * (size_t)L->M, L->ctx->stream));
+  for (bool& v : L->img_valid) v = false;  // pairs already stored have no image: images_apply refuses them
   return PG_OK;
 }
 
@@ -305,6 +310,7 @@ pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay) {
   PG_HIP(hipMemcpyAsync(base + (size_t)(L->curridx - 1) * L->img_vb, As, nb, hipMemcpyDeviceToDevice, L->ctx->stream));
   PG_HIP(hipMemcpyAsync(base + ((size_t)L->M + (size_t)(L->curridx - 1)) * L->img_vb, Ay, nb, hipMemcpyDeviceToDevice,
                         L->ctx->stream));
+  L->img_valid[L->curridx - 1] = true;
   return PG_OK;
 }
 
@@ -312,6 +318,16 @@ pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av) {
   PG_REQUIRE(L != nullptr && L->img_slab != nullptr, "images are not enabled");
   PG_REQUIRE(L->img_m == 0 || (Ad != nullptr && Av != nullptr), "null vector");
   if (L->img_m == 0) return PG_OK;
+  // every pair the last apply used needs the image of the pair it holds NOW: enabled after pairs were stored, or an
+  // accepted update without its images_update, would otherwise combine stale / zero images into a wrong A d silently
+  for (int t = 0; t < L->last_k; ++t) {
+    const int slot = L->last_idx[t] - 1;
+    if (slot < 0 || slot >= L->M || !L->img_valid[slot]) {
+      pg_set_error("L-BFGS images: slot %d used by the last apply has no current image (call pg_lbfgs_images_update after every "
+                   "accepted pg_lbfgs_update; enable images on an empty operator)", slot + 1);
+      return PG_ERR_INVALID;
+    }
+  }
   return L->dtype == PG_F32 ? lbfgs_images_apply_t<float>(L, Ad, Av) : lbfgs_images_apply_t<double>(L, Ad, Av);
 }
 

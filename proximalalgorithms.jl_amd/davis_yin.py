@@ -98,13 +98,14 @@ class DavisYinIteration:
 
     def __iter__(self):
         if self._sweep is not None:
+            from . import _lib
             from ._lib import ProxGradError
 
             gen = self._iter_single_sweep(*self._sweep)
             try:
                 first = next(gen)
             except ProxGradError as e:
-                if "error -4" not in str(e):  # anything but "shape outside the sweep kernel's range"
+                if e.code != _lib.PG_ERR_UNSUPPORTED:  # anything but "shape outside the sweep kernel's range"
                     raise
                 self._sweep = None
             else:

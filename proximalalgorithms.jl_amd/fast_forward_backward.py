@@ -1,5 +1,7 @@
 """FastForwardBackward (accelerated proximal gradient / FISTA) -- mirror of
 src/algorithms/fast_forward_backward.jl.  Engines as in forward_backward.py."""
+import itertools
+
 import numpy as np
 
 from . import _lib
@@ -72,6 +74,10 @@ class FastForwardBackwardIteration:
             return _lib.PG_SEQ_SIMPLE, 0.0, 0.0, None
         if isinstance(s, ConstantNesterovSequence) and np.dtype(s.R) == R:
             return _lib.PG_SEQ_CONSTANT, float(s.m), float(s.stepsize), None
+        if isinstance(s, itertools.repeat):  # Iterators.repeated(beta): the library repeats the value itself
+            beta = next(iter(s))
+            if isinstance(beta, (float, np.floating)) and float(R.type(beta)) == float(beta):
+                return _lib.PG_SEQ_REPEATED, float(beta), 0.0, None
         return _lib.PG_SEQ_HOST, 0.0, 0.0, iter(s)  # Iterators.Stateful(seq)  (:90-92)
 
     def _iter_fused(self):

@@ -7,6 +7,7 @@
 #     using ProximalAlgorithms, ProximalAlgorithmsHIP
 #     f = HIPLeastSquares(A, b); g = HIPNormL1(lam)
 #     x, it = HIPFastForwardBackward(tol = 1e-6)(x0 = zeros(Float32, n), f = f, g = g)
+#     x, it = HIPFastForwardBackward(tol = 1e-6)(x0 = x0, f = f, g = g, Lf = Lf, extrapolation_sequence = FixedNesterovSequence(Float32))
 #
 module ProximalAlgorithmsHIP
 
@@ -219,13 +220,26 @@ end
 g_spec(g::HIPNormL1) = (Int32(1), Float64(g.lambda), 0.0)
 g_spec(g::HIPIndBox) = (Int32(2), Float64(g.lo), Float64(g.hi))
 
-# keyword constructor mirrors ForwardBackwardIteration / FastForwardBackwardIteration (forward_backward.jl:38-48)
+# extrapolation sequences (src/accel/nesterov.jl) -> (seq_kind, seq_p0, seq_p1, host-side iterator or nothing)
+const PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST, PG_SEQ_REPEATED =
+    Int32(0), Int32(1), Int32(2), Int32(3), Int32(4), Int32(5)
+# (R = real(eltype(x0)): the library evaluates the recurrences in the working precision, like a sequence of type R)
+seq_spec(::Nothing, R) = (PG_SEQ_ADAPTIVE, 0.0, 0.0, nothing)   # AdaptiveNesterovSequence(mf), fast_forward_backward.jl:94-95
+seq_spec(::ProximalAlgorithms.FixedNesterovSequence{R}, ::Type{R}) where {R} = (PG_SEQ_FIXED, 0.0, 0.0, nothing)    # nesterov.jl:14-17
+seq_spec(::ProximalAlgorithms.SimpleNesterovSequence{R}, ::Type{R}) where {R} = (PG_SEQ_SIMPLE, 0.0, 0.0, nothing)  # nesterov.jl:36
+# ConstantNesterovSequence(m, stepsize) IS `repeated(beta)` (nesterov.jl:51-54): the library repeats the same value
+seq_spec(s::Base.Iterators.Repeated{R}, ::Type{R}) where {R} = (PG_SEQ_REPEATED, Float64(s.x), 0.0, nothing)
+# any other iterator (or a sequence of another precision): the coefficient of each step is drawn on the host
+# (fast_forward_backward.jl:91-93,99-101) and passed to pg_iter_step; the library then iterates with two sweeps over A
+# (the single sweep needs the NEXT coefficient one step early)
+seq_spec(s, R) = (PG_SEQ_HOST, 0.0, 0.0, Iterators.Stateful(s))
+
+# keyword constructors mirror ForwardBackwardIteration (forward_backward.jl:38-48) and FastForwardBackwardIteration
+# (fast_forward_backward.jl:44-56): same names, same defaults
 Base.@kwdef struct HIPForwardBackwardIteration{R,Tf,Tg,Tx}
     f::Tf
     g::Tg
     x0::Tx
-    fast::Bool = false
-    mf::R = real(eltype(x0))(0)
     Lf::Union{Nothing,R} = nothing
     gamma::Union{Nothing,R} = Lf === nothing ? nothing : (1 / Lf)
     adaptive::Bool = gamma === nothing
@@ -233,12 +247,34 @@ Base.@kwdef struct HIPForwardBackwardIteration{R,Tf,Tg,Tx}
     reduce_gamma::R = real(eltype(x0))(0.5)
     increase_gamma::R = real(eltype(x0))(1.0)
 end
-Base.IteratorSize(::Type{<:HIPForwardBackwardIteration}) = Base.IsInfinite()
+Base.@kwdef struct HIPFastForwardBackwardIteration{R,Tf,Tg,Tx,Textr}
+    f::Tf
+    g::Tg
+    x0::Tx
+    mf::R = real(eltype(x0))(0)
+    Lf::Union{Nothing,R} = nothing
+    gamma::Union{Nothing,R} = Lf === nothing ? nothing : (1 / Lf)
+    adaptive::Bool = gamma === nothing
+    minimum_gamma::R = real(eltype(x0))(1e-7)
+    reduce_gamma::R = real(eltype(x0))(0.5)
+    increase_gamma::R = real(eltype(x0))(1.0)
+    extrapolation_sequence::Textr = nothing
+end
+const HIPIteration = Union{HIPForwardBackwardIteration,HIPFastForwardBackwardIteration}
+Base.IteratorSize(::Type{<:HIPForwardBackwardIteration}) = Base.IsInfinite()       # forward_backward.jl:50
+Base.IteratorSize(::Type{<:HIPFastForwardBackwardIteration}) = Base.IsInfinite()   # fast_forward_backward.jl:58
+is_fast(::HIPForwardBackwardIteration) = false
+is_fast(::HIPFastForwardBackwardIteration) = true
 
+# ForwardBackwardState (forward_backward.jl:52-63) / FastForwardBackwardState (fast_forward_backward.jl:60-71): the same
+# field names; the vectors are non-owning views of the library's state slab and follow its pointer swaps.  z_prev and
+# extrapolation_sequence exist for the fast iteration only (z_prev === nothing, extrapolation_sequence === nothing else).
 mutable struct HIPIterState{R,T}
     handle::Ptr{Cvoid}
-    x::HIPVector{T}; grad_f_x::HIPVector{T}; y::HIPVector{T}; z::HIPVector{T}; res::HIPVector{T}
-    f_x::R; gamma::R; g_z::R; res_inf::R
+    x::HIPVector{T}; f_x::R; grad_f_x::HIPVector{T}; gamma::R; y::HIPVector{T}; z::HIPVector{T}; g_z::R; res::HIPVector{T}
+    z_prev::Union{Nothing,HIPVector{T}}
+    extrapolation_sequence::Any   # Iterators.Stateful for host-drawn coefficients, else the (kind, p0, p1) the library runs
+    res_inf::R
 end
 
 function refresh!(st::HIPIterState{R,T}, sc::PgIterScalars, ctx, n) where {R,T}
@@ -246,49 +282,59 @@ function refresh!(st::HIPIterState{R,T}, sc::PgIterScalars, ctx, n) where {R,T}
     check(ccall((:pg_iter_state_view, libpg), Int32, (Ptr{Cvoid}, Ref{PgIterState}), st.handle, v))
     mk(p) = HIPVector{T}(ctx, p, n, st)   # non-owning views, pointers follow the library's swaps
     st.x, st.grad_f_x, st.y, st.z, st.res = mk(v[].x), mk(v[].grad_f_x), mk(v[].y), mk(v[].z), mk(v[].res)
+    st.z_prev = v[].z_prev == C_NULL ? nothing : mk(v[].z_prev)
     st.f_x, st.gamma, st.g_z, st.res_inf = R(sc.f_x), R(sc.gamma), R(sc.g_z), R(sc.res_inf)
     st
 end
 
-function Base.iterate(iter::HIPForwardBackwardIteration{R}) where {R}
+function Base.iterate(iter::HIPIteration)
     T = eltype(iter.x0)
+    R = real(T)
     x0 = iter.x0 isa HIPVector ? iter.x0 : HIPVector(iter.x0; ctx = iter.f.A.ctx)   # x0 is copied, never mutated
     kind, p0, p1 = g_spec(iter.g)
-    opts = Ref(PgIterOpts(iter.fast, iter.adaptive, something(iter.Lf, -1.0), something(iter.gamma, -1.0),
-                          iter.minimum_gamma, iter.reduce_gamma, iter.increase_gamma, iter.mf, 0, 0.0, 0.0, kind, p0, p1, 1, 1))
+    fast = is_fast(iter)
+    skind, sp0, sp1, host_seq = fast ? seq_spec(iter.extrapolation_sequence, R) : (PG_SEQ_ADAPTIVE, 0.0, 0.0, nothing)
+    opts = Ref(PgIterOpts(fast, iter.adaptive, something(iter.Lf, -1.0), something(iter.gamma, -1.0),
+                          iter.minimum_gamma, iter.reduce_gamma, iter.increase_gamma, fast ? iter.mf : 0.0,
+                          skind, sp0, sp1, kind, p0, p1, 1, 1))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:pg_iter_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterOpts}, Ref{Ptr{Cvoid}}),
                 iter.f.A.ctx.handle, iter.f.handle, opts, h))
     sc = Ref{PgIterScalars}()
     check(ccall((:pg_iter_init, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterScalars}), h[], x0.ptr, sc))
-    st = HIPIterState{R,T}(h[], x0, x0, x0, x0, x0, R(0), R(0), R(0), R(0))
+    st = HIPIterState{R,T}(h[], x0, R(0), x0, R(0), x0, x0, R(0), x0, nothing,
+                           host_seq === nothing ? (skind, sp0, sp1) : host_seq, R(0))
     finalizer(s -> ccall((:pg_iter_destroy, libpg), Int32, (Ptr{Cvoid},), s.handle), st)
     refresh!(st, sc[], iter.f.A.ctx, length(x0))
     return st, st
 end
-function Base.iterate(iter::HIPForwardBackwardIteration, st::HIPIterState)
+function Base.iterate(iter::HIPIteration, st::HIPIterState)
+    # get_next_extrapolation_coefficient! (fast_forward_backward.jl:99-104) for host-side sequences
+    beta = st.extrapolation_sequence isa Iterators.Stateful ? Float64(first(st.extrapolation_sequence)) : 0.0
     sc = Ref{PgIterScalars}()
-    check(ccall((:pg_iter_step, libpg), Int32, (Ptr{Cvoid}, Float64, Ref{PgIterScalars}), st.handle, 0.0, sc))
+    check(ccall((:pg_iter_step, libpg), Int32, (Ptr{Cvoid}, Float64, Ref{PgIterScalars}), st.handle, beta, sc))
     (sc[].flags & 1) != 0 && @warn "stepsize `gamma` became too small ($(sc[].gamma))"   # fb_tools.jl:59-61
     refresh!(st, sc[], iter.f.A.ctx, st.x.n)
     return st, st
 end
 
-default_stopping_criterion(tol, ::HIPForwardBackwardIteration, st::HIPIterState) = st.res_inf / st.gamma <= tol
-default_solution(::HIPForwardBackwardIteration, st::HIPIterState) = Array(st.z)
-default_display(it, ::HIPForwardBackwardIteration, st::HIPIterState) =
+default_stopping_criterion(tol, ::HIPIteration, st::HIPIterState) = st.res_inf / st.gamma <= tol
+default_solution(::HIPIteration, st::HIPIterState) = Array(st.z)
+default_display(it, ::HIPIteration, st::HIPIterState) =
     @printf("%5d | %.3e | %.3e\n", it, st.gamma, st.res_inf / st.gamma)
 
 HIPForwardBackward(; maxit = 10_000, tol = 1e-8, stop = (iter, state) -> default_stopping_criterion(tol, iter, state),
                    solution = default_solution, verbose = false, freq = 100, display = default_display, kwargs...) =
     ProximalAlgorithms.IterativeAlgorithm(HIPForwardBackwardIteration; maxit, stop, solution, verbose, freq, display, kwargs...)
-HIPFastForwardBackward(; kwargs...) = HIPForwardBackward(; fast = true, kwargs...)
+HIPFastForwardBackward(; maxit = 10_000, tol = 1e-8, stop = (iter, state) -> default_stopping_criterion(tol, iter, state),
+                       solution = default_solution, verbose = false, freq = 100, display = default_display, kwargs...) =
+    ProximalAlgorithms.IterativeAlgorithm(HIPFastForwardBackwardIteration; maxit, stop, solution, verbose, freq, display, kwargs...)
 
 # The driver loop of ProximalAlgorithms.jl:114-123 with the default stopping rule, inside the library: no host round
 # trip per iteration.  Launch-bound sizes run as ONE kernel launch (pg_iter_run_small: one workgroup;
 # pg_iter_run_coop: cooperating workgroups with grid barriers while A is cache-resident); larger problems use the
 # streaming kernels (pg_iter_run).  Returns (solution, k) like IterativeAlgorithm.
-function hip_solve(iter::HIPForwardBackwardIteration{R}; maxit = 10_000, tol = 1e-8) where {R}
+function hip_solve(iter::HIPIteration; maxit = 10_000, tol = 1e-8)
     st, _ = iterate(iter)                                  # k = 1 (the state after init)
     A = iter.f.A
     T = eltype(iter.x0)
@@ -327,7 +373,8 @@ function hip_douglas_rachford(d, q, g, x0::Vector{T}; gamma, maxit = 1_000, tol 
 end
 
 export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
-       HIPForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve, hip_douglas_rachford,
+       HIPForwardBackwardIteration, HIPFastForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve,
+       hip_douglas_rachford,
        fused_tn!, fused_dys!
 
 end # module

@@ -43,13 +43,14 @@ class LiLinIteration:
 
     def __iter__(self):
         if self._loss_A is not None:
+            from . import _lib
             from ._lib import ProxGradError
 
             gen = self._iter_single_sweep(*self._loss_A)
             try:
                 first = next(gen)
             except ProxGradError as e:
-                if "error -4" not in str(e):  # anything but "shape outside the sweep kernel's range"
+                if e.code != _lib.PG_ERR_UNSUPPORTED:  # anything but "shape outside the sweep kernel's range"
                     raise
                 self._loss_A = None
                 return self._iter_plain()

@@ -9,6 +9,7 @@ import warnings
 
 import numpy as np
 
+from . import _lib
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .device import HIPMatrix, as_hipvector
@@ -203,7 +204,9 @@ class PANOCIteration:
                 sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res, s.Az_next)
                 s.g_z = sc[0]
                 fused = True
-            except ProxGradError:
+            except ProxGradError as e:
+                if e.code != _lib.PG_ERR_UNSUPPORTED:
+                    raise  # a HIP / allocation / argument failure is not a reason to change path
                 self._fused_tn = False  # shape outside the kernel's range: separate sweeps from now on
         if fused:
             self.counters["A_passes"] += 1

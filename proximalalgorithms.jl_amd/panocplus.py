@@ -3,6 +3,7 @@ import warnings
 
 import numpy as np
 
+from . import _lib
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .operators import prox_
@@ -84,7 +85,9 @@ class PANOCplusIteration(PANOCIteration):
                     s.res_stats = (sc[1], sc[2], sc[3])  # the sweep's own reductions of this (At_grad, res) pair
                     fused = True
                     self.counters["A_passes"] += 1
-                except ProxGradError:
+                except ProxGradError as e:
+                    if e.code != _lib.PG_ERR_UNSUPPORTED:
+                        raise
                     self._fused_tn = False
             if not fused:
                 self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :202

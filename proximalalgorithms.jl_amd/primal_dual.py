@@ -174,6 +174,7 @@ class AFBAIteration:
         iterate IS xbar, so  L (2 xbar - x) = 2 L xbar - L x  needs no product: L x is the previous sweep's L xbar.  The
         two correction products of primal_dual.jl:199-205 carry the factor (2 - theta) = 0.  Returns False (nothing
         written) when the sweep kernel does not cover this matrix."""
+        from . import _lib
         from ._lib import ProxGradError
 
         g1, g2 = self.gamma
@@ -189,7 +190,7 @@ class AFBAIteration:
         try:
             self.L.fused_tn(s.y, xs, g1, self.g, s.temp_x, s.sw_y, s.xbar, s.sw_res, s.Lxbar)  # :182-186 (+ L xbar)
         except ProxGradError as e:
-            if "error -4" in str(e):
+            if e.code == _lib.PG_ERR_UNSUPPORTED:
                 return False
             raise
         self.counters["L_passes"] += 1

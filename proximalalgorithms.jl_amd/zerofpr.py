@@ -3,6 +3,7 @@ direction on the forward-backward residual and a line search on the forward-back
 primitives as PANOC (panoc.py); every array statement is a kernel of libproxgrad_hip."""
 import numpy as np
 
+from . import _lib
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .operators import prox_
@@ -91,7 +92,9 @@ class ZeroFPRIteration(PANOCIteration):
                     sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)
                     s.g_xbar = sc[0]
                     fused = True
-                except ProxGradError:
+                except ProxGradError as e:
+                    if e.code != _lib.PG_ERR_UNSUPPORTED:
+                        raise
                     self._fused_tn = False
             if fused:
                 self.counters["A_passes"] += 1

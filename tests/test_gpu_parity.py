@@ -1771,5 +1771,22 @@ def test_lbfgs_images_give_the_image_of_the_direction_without_reading_A(pa, dtyp
         H.update_(sd, yd)
         H.images_update_(Ad.mul(sd), Ad.mul(yd))
         check()
+    # an accepted update WITHOUT its images_update leaves a slot whose image belongs to the overwritten pair: refused
+    s = rng.standard_normal(n).astype(dtype)
+    sd, yd = pa.HIPVector.from_numpy(s), pa.HIPVector.from_numpy((s + 0.3 * rng.standard_normal(n)).astype(dtype))
+    H.update_(sd, yd)
+    v = pa.HIPVector.from_numpy(rng.standard_normal(n).astype(dtype))
+    H.mul_(v.similar(), v)
+    with pytest.raises(pa.ProxGradError, match="no current image"):
+        H.images_mul_(pa.HIPVector.empty(m, dtype), Ad.mul(v))
+    H.images_update_(Ad.mul(sd), Ad.mul(yd))  # ... and accepted again once the image is supplied
+    check()
     H.reset_()
     check()
+    # images enabled on an operator that already holds pairs: those pairs have no image
+    H2 = pa.LBFGSOperator(M, pa.HIPVector.zeros(n, dtype))
+    H2.update_(sd, yd)
+    H2.images_enable(m)
+    H2.mul_(v.similar(), v)
+    with pytest.raises(pa.ProxGradError, match="no current image"):
+        H2.images_mul_(pa.HIPVector.empty(m, dtype), Ad.mul(v))
