@@ -205,6 +205,8 @@ constexpr int64_t LDS_DEFAULT_LIMIT = 64 * 1024;
 // columns of up to this many 1 KiB row groups take the one-wave-per-column-group sweep (gemv_tnw_kernel); 0 = never.
 // Set from the sweeps in profiles/r2_tune_tn_short_columns.log
 constexpr int PG_TN_WAVE_MAX_RG = 8;
+// ... up to this many: the workgroup-shared sweep with the lane-parallel epilogue (gemv_tnc_kernel); beyond: gemv_tn_kernel
+constexpr int PG_TN_COOP_MAX_RG = 16;
 
 // ----------------------------------------------------------------------------------------------
 // host-side launch planning
@@ -481,9 +483,11 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   if (force != nullptr && *force) {
     if (force[0] == 'w' && force[1] == 'a' && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
     if (force[0] == 't' && tn_team_covers(nrg)) return launch_tn_team<T>(A, a, blocks_out);
+    if (force[0] == 'c' && tn_coop_covers(nrg)) return launch_tn_coop<T>(A, a, blocks_out);
   } else {
     if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
     if (nrg <= PG_TN_WAVE_MAX_RG && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
+    if (nrg > PG_TN_WAVE_MAX_RG && nrg <= PG_TN_COOP_MAX_RG && tn_coop_covers(nrg)) return launch_tn_coop<T>(A, a, blocks_out);
   }
   if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
   // 17..32 row groups (m = 8192 in Float32): eight waves of U = 4 with C = 8 columns per step measured 4 % faster than four

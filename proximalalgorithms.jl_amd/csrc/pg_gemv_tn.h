@@ -370,9 +370,12 @@ bool tn_single_wg_supported(const pg_mat* A) {
 // workgroups for columns longer than one workgroup's registers
 bool tn_wave_covers(int nrg);
 bool tn_team_covers(int nrg);
+bool tn_coop_covers(int nrg);
 template <typename T>
 pg_status launch_tn_wave(pg_mat* A, TNArgs<T>& a, int* blocks_out);
 template <typename T>
 pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out);
+template <typename T>
+pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out);
 
 }  // namespace pgtn

@@ -277,6 +277,147 @@ pg_status launch_tnw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// MEDIUM columns (9..32 row groups): the waves of a workgroup SHARE every column group like gemv_tn_kernel, with the
+// column-parallel reduction and the lane-parallel epilogue of gemv_tnw_kernel: per step each wave reduces its C partial
+// dots across columns (C + 6 lane exchanges), the lane groups' leaders leave them in LDS, and after the one workgroup
+// barrier of the step every lane sums the WAVES partials of ITS column, applies the prox once and hands v_j back through
+// v_readlane.  (gemv_tn_kernel: 6 C shuffles per wave and the epilogue of all C columns in every lane.)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int U, int C, int WAVES, bool DOUBLE_BUFFER>
+__global__ __launch_bounds__(WAVES * 64) void gemv_tnc_kernel(TNArgs<T> a) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int G = 64 / C;
+  static_assert(C >= 2 && C <= 32 && (C & (C - 1)) == 0, "C must be a power of two in 2..32");
+  __shared__ T sm_part[2][WAVES][C];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ncg = (a.n + C - 1) / C;
+  const int c_own = lane / G;
+  const bool lead = (lane % G) == 0;
+
+  V rk[U], racc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int rg = TN_RG(u, wave, U, WAVES);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
+    if (rg < a.nrg) {
+      rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)rg * (WAVE * VEC) + lane * VEC);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rk[u][e] = T(0);
+    }
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+
+  auto process = [&](const TNTile<T, U, C, WAVES>& t, int64_t cg, int buf) {
+    const int64_t j = cg * C + c_own;
+    const bool valid = j < a.n;
+    const int64_t jc = valid ? j : (a.n - 1);
+    const T xj = a.x[jc], zo = a.z_old[jc];  // in flight during the dot products
+    T d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      T s = T(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s = fma(t.col[c][u][e], rk[u][e], s);
+      }
+      d[c] = s;
+    }
+    cr_stage<T, C, 0>(d, lane);
+    if (lead) sm_part[buf][wave][c_own] = d[0];
+    __syncthreads();
+    T g = sm_part[buf][0][c_own];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) g += sm_part[buf][w][c_own];  // wave order: every wave forms the same bits
+    if (a.lam_ls != T(1)) g = a.lam_ls * g;
+    const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
+    T zj;                            // :118 / :141
+    if (a.g_kind == PG_G_NORML1)
+      zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
+    else if (a.g_kind == PG_G_INDBOX)
+      zj = fmin(a.p1, fmax(a.p0, yj));
+    else
+      zj = yj;
+    const T rj = xj - zj;                                 // :120 / :142
+    const T vj = valid ? zj + a.beta * (zj - zo) : T(0);  // fast_forward_backward.jl:135 of the next iteration
+    if (wave == 0 && lead && valid) {
+      a.g_out[j] = g;
+      a.y[j] = yj;
+      a.z_new[j] = zj;
+      a.res[j] = rj;
+      if (a.v_out != nullptr) a.v_out[j] = vj;
+      if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
+      acc[1] = fmax(acc[1], fabs((double)rj));
+      acc[2] += (double)g * (double)rj;
+      acc[3] += (double)rj * (double)rj;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const T vc = pg_readlane(vj, c * G);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) racc[u][e] = fma(t.col[c][u][e], vc, racc[u][e]);
+      }
+    }
+  };
+
+  if constexpr (DOUBLE_BUFFER) {
+    TNTile<T, U, C, WAVES> ta, tb;
+    const int64_t cnt = ncg > (int64_t)blockIdx.x ? (ncg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    auto at = [&](int64_t i) { return (int64_t)blockIdx.x + i * (int64_t)gridDim.x; };
+    int64_t i = 0;
+    if (i < cnt) ta.load(a, at(i), wave, lane);
+    while (i < cnt) {
+      if (i + 1 < cnt) tb.load(a, at(i + 1), wave, lane);
+      process(ta, at(i), 0);
+      if (i + 1 >= cnt) break;
+      if (i + 2 < cnt) ta.load(a, at(i + 2), wave, lane);
+      process(tb, at(i + 1), 1);
+      i += 2;
+    }
+  } else {
+    TNTile<T, U, C, WAVES> t;
+    int buf = 0;
+    for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
+      t.load(a, cg, wave, lane);
+      process(t, cg, buf);
+      buf ^= 1;
+    }
+  }
+  T* part = a.partials + (int64_t)blockIdx.x * a.ld + lane * VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int rg = TN_RG(u, wave, U, WAVES);
+    if (rg < a.nrg) *reinterpret_cast<V*>(part + (int64_t)rg * (WAVE * VEC)) = racc[u];
+  }
+  const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
+  grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
+}
+
+template <typename T, int U, int C, int WAVES, bool DB>
+pg_status launch_tnc(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  pg_ctx* c = A->ctx;
+  const int64_t ncg = (A->n + C - 1) / C;
+  int64_t blocks = (int64_t)c->num_cu * env_int("PG_TNC_BLOCKS_PER_CU", DB ? (WAVES >= 8 ? 1 : 2) : (WAVES >= 8 ? 1 : (WAVES == 4 ? 1 : 2)));
+  if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
+  if (blocks > ncg) blocks = ncg;
+  if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  PG_TRY(ensure_partials(A, (int)blocks));
+  a.partials = (T*)A->partials;
+  *blocks_out = (int)blocks;
+  pg_prof_scope prof(c, PG_K_GEMV_TN);
+  hipLaunchKernelGGL((gemv_tnc_kernel<T, U, C, WAVES, DB>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LONG columns: teams of workgroups
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TEAM_WAVES = 8;                   // a member holds 8 U row groups of every column (U = 8: 16384 rows in Float32)
@@ -664,6 +805,43 @@ pg_status launch_tn_wave(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   return PG_ERR_UNSUPPORTED;
 }
 
+bool tn_coop_covers(int nrg) { return nrg >= 3 && nrg <= 32; }
+
+// Tunables (environment, for experiments): PG_TNC_WAVES, PG_TNC_C, PG_TNC_DB, PG_TNC_BLOCKS_PER_CU.
+template <typename T>
+pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  const int nrg = a.nrg;
+  // measured (profiles/r2_tune_tn_mid_columns.log): eight waves of U = 2 with C = 16 columns per step, one tile, one workgroup
+  // per CU -- 4096 x 2^19: 6.68 TB/s against 6.37 for gemv_tn's four waves of U = 4; 3072 rows: 6.62 against 6.03;
+  // from 17 row groups on the two kernels are level (8192 x 2^18: 6.68 / 6.67) and gemv_tn stays
+  const int W = env_int("PG_TNC_WAVES", 8);
+  int U = 1;
+  while (U * W < nrg) U *= 2;
+  const int C = env_int("PG_TNC_C", 32 / U);
+  const int DB = env_int("PG_TNC_DB", 0);
+#define PG_TNC_CASE(UU, CC, WW, DD) \
+  if (U == UU && C == CC && W == WW && DB == DD) return launch_tnc<T, UU, CC, WW, (DD != 0)>(A, a, blocks_out)
+#define PG_TNC_UCW(UU, CC, WW) \
+  PG_TNC_CASE(UU, CC, WW, 0); \
+  PG_TNC_CASE(UU, CC, WW, 1)
+  PG_TNC_UCW(4, 8, 4);
+  PG_TNC_UCW(4, 4, 4);
+  PG_TNC_UCW(8, 4, 2);
+  PG_TNC_UCW(8, 2, 2);
+  PG_TNC_UCW(2, 16, 8);
+  PG_TNC_UCW(2, 8, 8);
+  PG_TNC_UCW(4, 8, 8);
+  PG_TNC_UCW(4, 4, 8);
+  PG_TNC_UCW(8, 4, 4);
+  PG_TNC_UCW(8, 2, 4);
+  PG_TNC_UCW(2, 16, 4);
+  PG_TNC_UCW(2, 8, 4);
+#undef PG_TNC_UCW
+#undef PG_TNC_CASE
+  pg_set_error("no gemv_tnc instantiation for U=%d C=%d WAVES=%d DB=%d", U, C, W, DB);
+  return PG_ERR_UNSUPPORTED;
+}
+
 // Tunables (environment, for experiments): PG_TNT_U, PG_TNT_C, PG_TNT_LAG, PG_TN_TEAM (members per team), PG_TN_TEAMS.
 template <typename T>
 pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
@@ -689,6 +867,8 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 
 template pg_status launch_tn_wave<float>(pg_mat*, TNArgs<float>&, int*);
 template pg_status launch_tn_wave<double>(pg_mat*, TNArgs<double>&, int*);
+template pg_status launch_tn_coop<float>(pg_mat*, TNArgs<float>&, int*);
+template pg_status launch_tn_coop<double>(pg_mat*, TNArgs<double>&, int*);
 template pg_status launch_tn_team<float>(pg_mat*, TNArgs<float>&, int*);
 template pg_status launch_tn_team<double>(pg_mat*, TNArgs<double>&, int*);
 

@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import proximalalgorithms.jl_amd as pa  # noqa: E402
 
 KNOBS = ("PG_TN_KERNEL", "PG_TNW_C", "PG_TNW_WPB", "PG_TNW_DB", "PG_TNW_WAVES_PER_CU", "PG_TNT_C", "PG_TNT_LAG", "PG_TNT_PF", "PG_TNT_U", "PG_TN_TEAM",
-         "PG_TN_TEAMS", "PG_TN_WAVES", "PG_TN_C", "PG_TN_BLOCKS_PER_CU")
+         "PG_TN_TEAMS", "PG_TN_WAVES", "PG_TN_C", "PG_TN_BLOCKS_PER_CU", "PG_TNC_WAVES", "PG_TNC_C", "PG_TNC_DB",
+         "PG_TNC_BLOCKS_PER_CU")
 
 
 def clear():
@@ -90,6 +91,16 @@ def cmd_check():
                           (256 * rpg, 333, {"PG_TNT_U": "8", "PG_TNT_C": "2", "PG_TNT_LAG": "0"}),
                           (300 * rpg + 17, 700, {}), (512 * rpg, 24, {}), (1024 * rpg, 9, {})):
             ok &= check_one(m, n, dtype, env)
+        # medium columns: waves share the column group, lane-parallel epilogue (gemv_tnc)
+        for m in (3 * rpg, 9 * rpg + 1, 16 * rpg, 17 * rpg, 32 * rpg):
+            for n in (1, 37, 1000):
+                nrg = (m + rpg - 1) // rpg
+                for env in ({"PG_TN_KERNEL": "coop"}, {"PG_TN_KERNEL": "coop", "PG_TNC_DB": "1", "PG_TNC_C": str(16 // max(1, (nrg + 7) // 8 if nrg > 16 else (nrg + 3) // 4) or 2)}):
+                    try:
+                        ok &= check_one(m, n, dtype, env)
+                    except pa.ProxGradError as e:
+                        print("  skip", env, str(e)[:80])
+                        clear()
         # the one-workgroup kernel still answers (regression of the split into translation units)
         for m, n in ((16 * rpg, 100), (64 * rpg, 30), (128 * rpg, 20)):
             ok &= check_one(m, n, dtype, {"PG_TN_KERNEL": "wg"})
@@ -155,6 +166,40 @@ def cmd_short(shapes):
         del f, A
 
 
+def cmd_mid(shapes):
+    ctx = pa.get_context()
+    g = pa.NormL1(0.3)
+    for (m, n) in shapes:
+        A, f, x, vs = setup(m, n)
+        nbytes = m * n * 4
+        nrg = (m * 4 + 1023) // 1024
+        clear()
+        os.environ["PG_TN_KERNEL"] = "wg"
+        base = nbytes / (time_pass(f, x, vs, g, ctx) * 1e-3) / 1e9
+        res = []
+        for W in (2, 4, 8):
+            U = 1
+            while U * W < nrg:
+                U *= 2
+            for C in (2, 4, 8, 16):
+                for db in (0, 1):
+                    for bpc in (1, 2, 3, 4):
+                        clear()
+                        os.environ.update(PG_TN_KERNEL="coop", PG_TNC_WAVES=str(W), PG_TNC_C=str(C), PG_TNC_DB=str(db),
+                                          PG_TNC_BLOCKS_PER_CU=str(bpc))
+                        try:
+                            res.append((nbytes / (time_pass(f, x, vs, g, ctx) * 1e-3) / 1e9, W, U, C, db, bpc))
+                        except pa.ProxGradError:
+                            break
+        clear()
+        dflt = nbytes / (time_pass(f, x, vs, g, ctx) * 1e-3) / 1e9
+        res.sort(reverse=True)
+        print(f"=== {m}x{n} f32 ({nrg} row groups) ===  gemv_tn (round 1 geometry) {base:6.0f} GB/s ; default dispatch {dflt:6.0f} GB/s")
+        for gb, W, U, C, db, bpc in res[:8]:
+            print(f"   gemv_tnc waves={W} U={U} C={C:2d} double_buffer={db} workgroups/CU={bpc}: {gb:6.0f} GB/s")
+        del f, A
+
+
 def cmd_team(shapes):
     ctx = pa.get_context()
     g = pa.NormL1(0.3)
@@ -193,5 +238,7 @@ if __name__ == "__main__":
         sys.exit(cmd_check())
     if cmd == "short":
         cmd_short(shapes or [(512, 1 << 22), (1024, 1 << 21), (2048, 1 << 20)])
+    if cmd == "mid":
+        cmd_mid(shapes or [(4096, 1 << 19), (8192, 1 << 18), (3072, 1 << 19), (6144, 1 << 18)])
     if cmd == "team":
         cmd_team(shapes or [(131072, 131072), (65536, 262144)])
