@@ -501,7 +501,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
 # ---------------------------------------------------------------------------------------------------------------
 def run_config3(pa, ctx, n=10_000_000, steps=200):
     """DouglasRachford on a box-constrained QP with diagonal Hessian (douglas_rachford.jl:53-70), n = 10^7, Float32:
-    stepping from the host (one fused sweep per iteration) and the in-library loop (16 iterations per sweep)."""
+    stepping from the host (one fused sweep per iteration) and the in-library loop (32 iterations per sweep, two sweeps in flight)."""
     import numpy as np
 
     dtype = np.float32
@@ -532,22 +532,24 @@ def run_config3(pa, ctx, n=10_000_000, steps=200):
                        "roofline": {"bound": "hbm", "kernel": "dr_step", "avg_launch_ms": round(ms / cnt, 5),
                                     "algorithmic_bytes_per_launch": b5, "achieved": round(b5 / (ms / cnt * 1e-3) / 1e9, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b5 / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-    block = 16
-    nst = max(steps, 10 * block) // block * block
+    block = 32
+    nst = max(steps, 20 * block) // block * block
     itn = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
     itn.device_run(2 * block, 0.0, block)
-    ctx.profile(True)
-    ctx.profile_reset()
     ctx.sync()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()  # timed without event pairs: two sweeps are in flight and a marker packet between them costs ~5 us
     s, k = itn.device_run(nst, 0.0, block)
     ctx.sync()
     dt = time.perf_counter() - t0
+    ctx.profile(True)
+    ctx.profile_reset()
+    itn.device_run(4 * block, 0.0, block)  # the kernel's own duration, from a second (bracketed) run
+    ctx.sync()
     cnt, ms = ctx.profile_read()["dr_step"]
     ctx.profile(False)
     out["device_loop"] = {"value": round(nst / dt, 1), "ms_per_step": round(1e3 * dt / nst, 6), "steps": nst,
                           "iterations_per_launch": block,
-                          "roofline": {"bound": "valu (exact division) / hbm", "kernel": "dr_block<%d>" % block,
+                          "roofline": {"bound": "valu (the prox's division, evaluated exactly) / hbm", "kernel": "dr_block<%d>" % block,
                                        "avg_launch_ms": round(ms / cnt, 5), "algorithmic_bytes_per_launch": b5,
                                        "achieved": round(b5 / (ms / cnt * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(b5 / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}

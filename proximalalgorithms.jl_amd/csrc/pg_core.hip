@@ -63,6 +63,9 @@ pg_status pg_ctx_destroy(pg_ctx* c) {
   if (c->red_partials) (void)hipFree(c->red_partials);
   if (c->red_counter) (void)hipFree(c->red_counter);
   if (c->hscal) (void)hipHostFree(c->hscal);
+  if (c->dr_ws) (void)hipFree(c->dr_ws);
+  for (hipEvent_t e : c->dr_ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->small_out_host) (void)hipHostFree(c->small_out_host);
   if (c->coop_ws) (void)hipFree(c->coop_ws);
   for (int k = 0; k < PG_K_COUNT; ++k)

@@ -65,7 +65,8 @@ enum {
   PG_S_FNEXT = 12,   // f at the speculative next point of the single-sweep iteration (2 slots, alternating)
   PG_S_TEAMERR = 14, // set to 1 by a workgroup team of the long-column sweep that gave up waiting for a member
   PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 32 inner iterations, f(y), g(z) }
-  PG_S_COUNT = 56
+  PG_S_DRRUN2 = 52,  // second set of the same (two blocks of pg_dr_run are in flight)
+  PG_S_COUNT = 88
 };
 
 constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize
@@ -101,6 +102,9 @@ struct pg_ctx {
   double* small_out = nullptr;       // result block of the single-workgroup solver (device address)
   double* small_out_host = nullptr;  //   ... mapped pinned host memory
   void* coop_ws = nullptr;           // workspace of the cooperative solver (barrier counter, partials)
+  void* dr_ws = nullptr;             // third x buffer of pg_dr_run's two-blocks-in-flight loop
+  size_t dr_ws_bytes = 0;
+  hipEvent_t dr_ev[2] = {nullptr, nullptr};
   size_t coop_ws_bytes = 0;
   // stream capture (pg_ctx_capture_begin / _end): launches are recorded into a hipGraph instead of executed; scalar
   // read-backs are skipped (their host values are not meaningful until the graph has run)

@@ -435,10 +435,10 @@ __device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>&
       T m = mx[j];
 #pragma unroll
       for (int p = 0; p < NP; ++p) m = fmax(m, fmax(fabs(se[p][0]), fabs(se[p][1])));
+      // the empty asm pins the maximum HERE: left alone the compiler sinks the K max operations to the end of the sweep
+      // (their only use) and keeps every iteration's residuals alive for them -- 4 registers per iteration, 209 at K = 32
+      asm volatile("" : "+v"(m));
       mx[j] = m;
-      // one iteration at a time: left alone the scheduler postpones the K running maxima to the end of the sweep and keeps
-      // every iteration's residual alive for them (209 registers at K = 32)
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -724,13 +724,13 @@ pg_status dr_step_t(pg_ctx* c, int64_t n, void* x, void* y, void* r, void* z, vo
 }
 
 template <typename T, int GKIND, int K>
-pg_status dr_block_launch(pg_ctx* c, int64_t n, bool vec_ok, const DRBlockArgs<T, GKIND, K>& a) {
+pg_status dr_block_launch(pg_ctx* c, int64_t n, bool vec_ok, const DRBlockArgs<T, GKIND, K>& a, int slot_base) {
   constexpr int DR_BLOCK_BS = dr_block_bs<K>();
   int64_t blocks = (n / VecOf<T>::N + DR_BLOCK_BS) / DR_BLOCK_BS;
   if (blocks > (int64_t)c->num_cu * (1024 / DR_BLOCK_BS)) blocks = (int64_t)c->num_cu * (1024 / DR_BLOCK_BS);
   if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
   hipLaunchKernelGGL((dr_block_kernel<T, GKIND, K>), dim3((unsigned)blocks), dim3(DR_BLOCK_BS), 0, c->stream, n, vec_ok, a,
-                     c->red_partials, c->red_counter, c->dscal + PG_S_DRRUN);
+                     c->red_partials, c->red_counter, c->dscal + slot_base);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -738,7 +738,7 @@ pg_status dr_block_launch(pg_ctx* c, int64_t n, bool vec_ok, const DRBlockArgs<T
 template <typename T, int K>
 pg_status dr_block_t(pg_ctx* c, int64_t n, const void* x_in, void* x_out, void* y, void* r, void* z, void* res,
                      const void* dv, double ds, const void* qv, double qs, int g_kind, double g_p0, double g_p1,
-                     double gamma) {
+                     double gamma, int slot_base) {
   const bool v = aligned16(x_in) && aligned16(x_out) && aligned16(y) && (!r || aligned16(r)) && (!z || aligned16(z)) &&
                  (!res || aligned16(res)) && (!dv || aligned16(dv)) && (!qv || aligned16(qv));
   const T gm = (T)gamma;
@@ -747,70 +747,115 @@ pg_status dr_block_t(pg_ctx* c, int64_t n, const void* x_in, void* x_out, void* 
   if (g_kind == PG_G_NORML1) {
     DRBlockArgs<T, PG_G_NORML1, K> a{(const T*)x_in, (T*)x_out, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)(gm * (T)g_p0),
                                      T(0), (double)(T)g_p0};
-    return dr_block_launch(c, n, v, a);
+    return dr_block_launch(c, n, v, a, slot_base);
   }
   if (g_kind == PG_G_INDBOX) {
     DRBlockArgs<T, PG_G_INDBOX, K> a{(const T*)x_in, (T*)x_out, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, (T)g_p0, (T)g_p1, 0.0};
-    return dr_block_launch(c, n, v, a);
+    return dr_block_launch(c, n, v, a, slot_base);
   }
   if (g_kind == PG_G_ZERO) {
     DRBlockArgs<T, PG_G_ZERO, K> a{(const T*)x_in, (T*)x_out, (T*)y, (T*)r, (T*)z, (T*)res, fp, gm, T(0), T(0), 0.0};
-    return dr_block_launch(c, n, v, a);
+    return dr_block_launch(c, n, v, a, slot_base);
   }
   pg_set_error("unknown g_kind %d", g_kind);
   return PG_ERR_INVALID;
 }
 
 // DouglasRachford driver loop (ProximalAlgorithms.jl:114-123 with the stop rule of douglas_rachford.jl:65-69) in
-// blocks of K iterations per sweep; returns the number of iterations k and leaves exactly the state of iteration k
+// blocks of K iterations per sweep; returns the number of iterations k and leaves exactly the state of iteration k.
+//
+// Two blocks are kept in flight: while the host waits for block b's K residual norms (an event, not a stream
+// synchronisation) block b + 1 is already queued behind it, so the device does not idle for the ~12 us of a launch +
+// read-back per block (a fifth of a 16-iteration sweep at n = 10^7).  x rotates through three buffers (x, x_alt and a
+// context-owned workspace): block b + 1 must not overwrite the INPUT of block b, from which the state is replayed with
+// single steps when one of b's inner iterations satisfies the stop rule (block b + 1 has by then overwritten y / r / z /
+// res with a state past the stop).  No successor is queued behind a block that reaches maxit.
 template <typename T>
 pg_status dr_run_t(pg_ctx* c, int64_t n, void* x, void* x_alt, void* y, void* r, void* z, void* res, const void* dv,
                    double ds, const void* qv, double qs, int g_kind, double g_p0, double g_p1, double gamma, double tol,
                    int64_t maxit, int K, int64_t* k_out, double* scalars_out) {
   const T gm = (T)gamma, tl = (T)tol;
   auto stop = [&](double res_inf) { return (T)res_inf / gm <= tl; };  // norm(res, Inf) / gamma <= tol  in T
-  void *cur = x, *alt = x_alt;
+  auto step = [&](void* xx) { return dr_step_t<T>(c, n, xx, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma); };
+  void* cur = x;
   int64_t k = 0;
   double sc[3] = {0, 0, 0};
   bool done = false;
-  while (!done && k < maxit) {
-    if (K > 1 && maxit - k >= K) {
-      PG_TRY(K == 32   ? (dr_block_t<T, 32>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma))
-             : K == 16 ? (dr_block_t<T, 16>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma))
-                       : (dr_block_t<T, 8>(c, n, cur, alt, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma)));
-      PG_TRY(pg_read_scalars(c, PG_S_DRRUN, K + 2));
+  if (K > 1 && maxit >= K) {
+    const size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(T);
+    if (c->dr_ws_bytes < nb) {
+      if (c->dr_ws) {
+        PG_HIP(hipStreamSynchronize(c->stream));
+        PG_HIP(hipFree(c->dr_ws));
+        c->dr_ws = nullptr;
+      }
+      PG_HIP(hipMalloc(&c->dr_ws, nb));
+      c->dr_ws_bytes = nb;
+    }
+    for (int e = 0; e < 2; ++e)
+      if (c->dr_ev[e] == nullptr) PG_HIP(hipEventCreateWithFlags(&c->dr_ev[e], hipEventDisableTiming));
+    void* bufs[3] = {x, x_alt, c->dr_ws};
+    const int slot_base[2] = {PG_S_DRRUN, PG_S_DRRUN2};
+    struct Blk {
+      int in = 0, set = 0;
+      bool live = false;
+    } A, B;
+    auto launch = [&](Blk& b, int in, int set) -> pg_status {
+      b.in = in, b.set = set, b.live = true;
+      void *xi = bufs[in], *xo = bufs[(in + 1) % 3];
+      PG_TRY(K == 32   ? (dr_block_t<T, 32>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
+             : K == 16 ? (dr_block_t<T, 16>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
+                       : (dr_block_t<T, 8>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set])));
+      PG_HIP(hipEventRecord(c->dr_ev[set], c->stream));
+      return PG_OK;
+    };
+    int in = 0;
+    while (!done && maxit - k >= K) {
+      if (!A.live) PG_TRY(launch(A, in, 0));
+      // a successor only if block A cannot be the last one (it reaches maxit exactly when k + K >= maxit)
+      if (!B.live && maxit - (k + K) >= K) PG_TRY(launch(B, (A.in + 1) % 3, 1 - A.set));
+      PG_HIP(hipEventSynchronize(c->dr_ev[A.set]));
+      const double* hs = c->hscal + slot_base[A.set];
       int hit = -1;
       for (int j = 0; j < K && hit < 0; ++j)
-        if (k + j + 1 >= maxit || stop(c->hscal[PG_S_DRRUN + j])) hit = j;
-      if (hit < 0 || hit == K - 1) {
+        if (k + j + 1 >= maxit || stop(hs[j])) hit = j;
+      if (hit < 0) {  // no stop inside A: its output is the next input; B (if queued) becomes the block to wait for
         k += K;
-        std::swap(cur, alt);
-        sc[0] = c->hscal[PG_S_DRRUN + K - 1], sc[1] = c->hscal[PG_S_DRRUN + K], sc[2] = c->hscal[PG_S_DRRUN + K + 1];
-        done = hit >= 0;
+        in = (A.in + 1) % 3;
+        A = B;
+        B.live = false;
+      } else if (hit == K - 1 && !B.live) {  // stopped exactly at the end of A and nothing ran past it: the state is A's
+        k += K;
+        in = (A.in + 1) % 3;
+        sc[0] = hs[K - 1], sc[1] = hs[K], sc[2] = hs[K + 1];
+        done = true;
       } else {
-        // an inner iteration stopped: replay hit+1 single steps from the block's input (same arithmetic, same bits)
-        for (int j = 0; j <= hit; ++j)
-          PG_TRY(dr_step_t<T>(c, n, cur, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma));
+        // an inner iteration stopped (or a successor has overwritten y / r / z / res): replay hit + 1 single steps from
+        // A's input -- same arithmetic, same bits; stream order puts them behind the queued successor
+        in = A.in;
+        for (int j = 0; j <= hit; ++j) PG_TRY(step(bufs[in]));
         PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
         for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
         k += hit + 1;
         done = true;
       }
-    } else {
-      PG_TRY(dr_step_t<T>(c, n, cur, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma));
-      PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
-      for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
-      ++k;
-      done = k >= maxit || stop(sc[0]);
     }
+    cur = bufs[in];
+  }
+  while (!done && k < maxit) {  // fewer than K iterations left (or block = 1): step by step
+    PG_TRY(step(cur));
+    PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
+    for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
+    ++k;
+    done = k >= maxit || stop(sc[0]);
   }
   if (cur != x && n > 0) {
     if (hipMemcpyAsync(x, cur, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
       pg_set_error("hipMemcpyAsync failed");
       return PG_ERR_HIP;
     }
-    PG_TRY(pg_ctx_sync(c));
   }
+  PG_TRY(pg_ctx_sync(c));
   if (k_out) *k_out = k;
   if (scalars_out)
     for (int q3 = 0; q3 < 3; ++q3) scalars_out[q3] = sc[q3];
