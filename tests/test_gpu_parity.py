@@ -1057,6 +1057,80 @@ def test_panoc_against_oracle_synthetic(pa, dtype, loss):
     assert kg <= max(ko + 10, int(1.5 * ko))
 
 
+def test_panoc_at_config4_column_length_against_oracle(pa):
+    """BASELINE config 4's kernels in their steady state: PANOC on logistic + L1 with the headline
+    column length (m = 16384 -> gemv_n / gemv_t / the pg_mat_fused_tn sweep in the geometries the 16384 x 10^6 run uses)
+    and n = 65536 (4 GiB: the oracle holds it), adaptive step, L-BFGS(5).  Float32 quasi-Newton trajectories separate
+    with the summation order, so the iteration is compared the way SURVEY 8(c) prescribes: identical gamma while the
+    backtracking decisions agree, and the objective after every iteration to 1e-4 relative / 1e-6 at the end."""
+    m, n, dtype = 16384, 65536, np.float32
+    ctx = pa.get_context()
+    A_d = pa.HIPMatrix.synthetic(m, n, dtype, seed=5, ctx=ctx)
+    rng = np.random.default_rng(12345)
+    x_true = np.zeros(n, dtype)
+    x_true[rng.choice(n, size=n // 1000, replace=False)] = rng.standard_normal(n // 1000).astype(dtype)
+    b_d = A_d.mul(pa.HIPVector.from_numpy(x_true, ctx))
+    b_d.axpby_(1.0, b_d, 0.01, pa.HIPVector.from_numpy(rng.standard_normal(m).astype(dtype), ctx))
+    A, b = A_d.numpy(), b_d.numpy()
+    _, g0 = pa.LogisticLoss(b_d).value_and_gradient(pa.HIPVector.zeros(m, dtype, ctx))
+    lam = dtype(0.1) * A_d.mul_adjoint(g0).norm_inf()
+    x0 = np.zeros(n, dtype)
+    it_g = pa.PANOCIteration(f=pa.LogisticLoss(b_d), A=A_d, g=pa.NormL1(lam), x0=x0)
+    it_o = o.PANOCIteration(f=o.LogisticLoss(b), A=A, g=o.NormL1(lam), x0=x0)
+    b64 = b.astype(np.float64)
+
+    def obj(z):
+        nz = np.flatnonzero(z)
+        t = A[:, nz].astype(np.float64) @ z[nz].astype(np.float64) - b64
+        return float(np.sum(np.log1p(np.exp(-t)))) + float(lam) * float(np.sum(np.abs(z.astype(np.float64))))
+
+    same_gamma = True
+    for k, (sg, so) in enumerate(itertools.islice(zip(it_g, it_o), 10)):
+        if same_gamma and float(sg.gamma) != pytest.approx(float(so.gamma), rel=1e-5):
+            same_gamma = False
+            assert k >= 3, (k, float(sg.gamma), float(so.gamma))  # the step-size estimate and the first decisions agree
+        Fg, Fo = obj(sg.z.numpy()), obj(so.z)
+        assert abs(Fg - Fo) <= 1e-4 * abs(Fo), (k, Fg, Fo)
+    assert abs(Fg - Fo) <= 1e-6 * abs(Fo) or not same_gamma
+    assert it_g.counters["A_passes"] <= 2.6 * 10 + 4  # about two reads of A per iteration (three before the fused sweep)
+
+
+def test_douglas_rachford_at_config3_size_against_oracle(pa):
+    """BASELINE config 3 at its own size (n = 10^7, Float32): the fused Douglas-Rachford step against
+    the oracle's unfused statements of douglas_rachford.jl:58-62 -- bit for bit, the prox's division included -- and the
+    in-library loop (32 iterations per sweep, two sweeps in flight) against stepping, bit for bit as well."""
+    n, dtype = 10_000_000, np.float32
+    rng = np.random.default_rng(0)
+    d = (0.1 + rng.random(n, dtype=np.float32)).astype(dtype)
+    q = rng.standard_normal(n, dtype=np.float32)
+    x0 = rng.standard_normal(n, dtype=np.float32)
+    lo, hi, gamma = dtype(-0.5), dtype(0.25), dtype(0.9)
+    it_g = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma)
+    it_o = o.DouglasRachfordIteration(f=o.SeparableQuadratic(d, q), g=o.IndBox(lo, hi), x0=x0, gamma=gamma)
+    for k, (sg, so) in enumerate(itertools.islice(zip(it_g, it_o), 6)):
+        for name in ("y", "z", "x"):
+            assert np.array_equal(getattr(sg, name).numpy(), getattr(so, name)), (name, k)
+        assert float(sg.res_inf) == float(np.max(np.abs(so.res)))
+    step = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
+    for k, s_ref in enumerate(step, start=1):
+        if k == 70:
+            break
+    loop = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
+    s_dev, k_dev = loop.device_run(70, 0.0, 32)  # two blocks of 32 + 6 single steps
+    assert k_dev == 70
+    assert np.array_equal(s_dev.x.numpy(), s_ref.x.numpy()) and np.array_equal(s_dev.y.numpy(), s_ref.y.numpy())
+    assert float(s_dev.res_inf) == float(s_ref.res_inf)
+    # a stop INSIDE a block while its successor is already queued: the state is replayed from the block's input
+    tol = float(dtype(s_ref.res_inf) / gamma) * 1.0000001
+    loop2 = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
+    s2, k2 = loop2.device_run(1000, tol, 32)
+    step2 = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
+    for k, s in enumerate(step2, start=1):
+        if dtype(s.res_inf) / gamma <= dtype(tol):
+            break
+    assert k2 == k and np.array_equal(s2.y.numpy(), s.y.numpy()) and np.array_equal(s2.x.numpy(), s.x.numpy())
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_ffb_adaptive_residual_reuse(pa, dtype):
     """Adaptive FFB forms A x - b at the extrapolated point from the line search's residuals
