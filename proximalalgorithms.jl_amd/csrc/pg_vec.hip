@@ -307,12 +307,20 @@ struct DRStepF {
       if constexpr (GKIND == PG_G_NORML1) acc[2] += fabs((double)zv.v[e]);
     }
     st<T, N>(x, i, xv);  // re-read by the next iteration: regular store
-    st_nt<T, N>(y, i, yv);
-    if (r != nullptr) st_nt<T, N>(r, i, rv);
-    if (z != nullptr) st_nt<T, N>(z, i, zv);
-    if (res != nullptr) st_nt<T, N>(res, i, sv);
+    if (nt_out) {
+      st_nt<T, N>(y, i, yv);
+      if (r != nullptr) st_nt<T, N>(r, i, rv);
+      if (z != nullptr) st_nt<T, N>(z, i, zv);
+      if (res != nullptr) st_nt<T, N>(res, i, sv);
+    } else {
+      st<T, N>(y, i, yv);
+      if (r != nullptr) st<T, N>(r, i, rv);
+      if (z != nullptr) st<T, N>(z, i, zv);
+      if (res != nullptr) st<T, N>(res, i, sv);
+    }
   }
   __device__ double post_scale(int k) const { return k == 2 ? gscale : 1.0; }
+  bool nt_out = true;  // non-temporal stores for the streams the next iteration does not read (experiments: PG_DR_NT=0)
 };
 
 // K Douglas-Rachford iterations per HBM sweep (temporal blocking): f and g are separable, so an element's K updates
@@ -679,8 +687,11 @@ pg_status prox_sepquad_t(pg_ctx* c, int64_t n, void* y, const void* x, const voi
 
 // launch geometry of the stepping kernel; PG_DR_STEP_GEOM = "<threads>x<blocks per CU>x<vectors per trip>" for experiments
 template <typename T, typename F>
-pg_status dr_step_launch(pg_ctx* c, int64_t n, bool v, const F& f) {
+pg_status dr_step_launch(pg_ctx* c, int64_t n, bool v, const F& f_in) {
   static const char* geom = getenv("PG_DR_STEP_GEOM");
+  static const bool nt_out = !(getenv("PG_DR_NT") && atoi(getenv("PG_DR_NT")) == 0);
+  F f = f_in;
+  f.nt_out = nt_out;
   int bs = 1024, bpc = 1, unr = 2;
   if (geom != nullptr && *geom) sscanf(geom, "%dx%dx%d", &bs, &bpc, &unr);
 #define PG_DR_GEOM(BB, UU) \

@@ -9,6 +9,11 @@ mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 # per-kernel durations of the same command (HIP-event timing in the line must agree)
 rocprofv3 --kernel-trace --stats -d $O/prof_default -- python3 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_default.log 2>&1
+# the headline alone (kernel averages of this run are directly comparable with roofline.avg_launch_ms in its line)
+rocprofv3 --kernel-trace --stats -d $O/prof_headline -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-also > $O/prof_headline.log 2>&1
+python bench.py --workload config2 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_config2.json 2>/dev/null
+python bench.py --m 8192 --n $((1<<20)) --dtype f64 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_f64_8192.json 2>/dev/null
+python bench.py --m 65536 --n 131072 --dtype f64 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_f64_long_65536.json 2>/dev/null
 # HBM traffic of the headline sweep kernel
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/prof_write.log 2>&1
@@ -30,7 +35,7 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_dr_fetch -- python3 tests/tools/bench_dr.py --no-cpu-baseline --steps 64 > $O/prof_dr_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_dr_write -- python3 tests/tools/bench_dr.py --no-cpu-baseline --steps 64 > $O/prof_dr_write.log 2>&1
 python scripts/bench_panoc.py > $O/bench_panoc.json 2>/dev/null
-for d in prof_default prof_fetch prof_write prof_long prof_long_fetch prof_long_write prof_dr_valu prof_dr_fetch prof_dr_write; do python scripts/rocpd_summary.py $O/$d/*/*_results.db > $O/$d.md 2>&1; done
+for d in prof_default prof_headline prof_fetch prof_write prof_long prof_long_fetch prof_long_write prof_dr_valu prof_dr_fetch prof_dr_write; do python scripts/rocpd_summary.py $O/$d/*/*_results.db > $O/$d.md 2>&1; done
 cp $O/prof_fetch/*/*_results.db $O/fetch.db; cp $O/prof_write/*/*_results.db $O/write.db
 cp $O/prof_long_fetch/*/*_results.db $O/long_fetch.db; cp $O/prof_long_write/*/*_results.db $O/long_write.db
 ls -la $O
