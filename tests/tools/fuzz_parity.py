@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential test: the GPU engine (every form of the driver loop) against the CPU restatement on random
-small / mid-size LASSO-type problems.  Usage: python tests/tools/fuzz_parity.py [cases] [first_seed].  Prints one line per
-failing case and a summary; exit code 1 if anything failed."""
+small / mid-size LASSO-type problems.  Usage: python tests/tools/fuzz_parity.py [cases] [first_seed] [tall].  Prints one
+line per failing case and a summary; exit code 1 if anything failed.  `tall`: column lengths from 600 to 140000 rows with few
+columns, so that every geometry of the single sweep is drawn (one wave per column group, shared workgroups, teams of
+workgroups -- csrc/pg_gemv_tn2.hip); the persistent small-problem kernels are skipped there."""
 import os
 import sys
 import time
@@ -20,11 +22,17 @@ def objective(A, b, g_o, z):
     return 0.5 * float(r @ r) + gz
 
 
+TALL = False
+
+
 def one_case(seed):
     rng = np.random.default_rng(seed)
     dtype = np.float32 if rng.random() < 0.5 else np.float64
     m = int(rng.choice([1, 2, 5, 63, 64, 65, 200, 511])) if rng.random() < 0.4 else int(rng.integers(1, 600))
     n = int(rng.choice([1, 3, 16, 17, 255, 500, 1025])) if rng.random() < 0.4 else int(rng.integers(1, 900))
+    if TALL:
+        m = int(rng.choice([600, 1025, 2048, 2305, 4096, 4100, 8192, 16384, 20000, 32768, 32769, 40000, 65536, 70001, 131072, 140000]))
+        n = int(rng.choice([1, 2, 7, 33, 64, 130]))
     fast = bool(rng.random() < 0.6)
     mode = rng.choice(["fixed", "adaptive", "adaptive_regret"])
     gname = rng.choice(["l1", "box", "zero"], p=[0.6, 0.25, 0.15])
@@ -55,10 +63,10 @@ def one_case(seed):
     F_start = 0.5 * float(b.astype(np.float64) @ b.astype(np.float64))
     It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
     f_g = pa.LeastSquares(A, b)
-    solvers = ["step", "run", "small", "coop"] + (["batched"] if mode == "fixed" else [])
+    solvers = (["step", "run"] if TALL else ["step", "run", "small", "coop"]) + (["batched"] if mode == "fixed" else [])
     fails = []
     for solver in solvers:
-        it = It(f=f_g, g=g_g, x0=x0, **kw)
+        it = It(f=f_g, g=g_g, x0=x0, engine="fused", **kw)
         gen = iter(it)
         st = next(gen)
         try:
@@ -114,6 +122,8 @@ def one_case(seed):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    global TALL
+    TALL = len(sys.argv) > 3 and sys.argv[3] == "tall"
     pa.get_context()
     bad = 0
     t0 = time.perf_counter()
