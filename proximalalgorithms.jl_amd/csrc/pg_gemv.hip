@@ -205,8 +205,10 @@ constexpr int64_t LDS_DEFAULT_LIMIT = 64 * 1024;
 // columns of up to this many 1 KiB row groups take the one-wave-per-column-group sweep (gemv_tnw_kernel); 0 = never.
 // Set from the sweeps in profiles/r2_tune_tn_short_columns.log
 constexpr int PG_TN_WAVE_MAX_RG = 8;
-// ... up to this many: the workgroup-shared sweep with the lane-parallel epilogue (gemv_tnc_kernel); beyond: gemv_tn_kernel
-constexpr int PG_TN_COOP_MAX_RG = 16;
+// ... up to this many: the workgroup-shared sweep with the lane-parallel epilogue (gemv_tnc_kernel); beyond: gemv_tn_kernel.
+// Interleaved A/B, five rounds (profiles/r2_tune_tn_mid_columns.log): 17 / 20 / 24 row groups 7.03 / 6.83 / 6.96 TB/s against
+// 6.27 / 6.53 / 6.88 for gemv_tn; level at 28 and 32 (the same shape re-allocated moves by 3 %: no finer cut than this)
+constexpr int PG_TN_COOP_MAX_RG = 24;
 
 // ----------------------------------------------------------------------------------------------
 // host-side launch planning

@@ -73,6 +73,9 @@ struct TNArgs {
   int team_size = 1, nteams = 0;
   unsigned long long* xch = nullptr;  // [nteams][ring][team_size * C * granules-per-value]
   double* team_err = nullptr;         // set to 1 when a team member gave up waiting (bounded spin)
+#ifdef PG_TNT_EXPERIMENT
+  int dbg = 0;  // timing experiments of the team kernel (wrong results): see pg_gemv_tn2.hip
+#endif
 };
 
 // in-kernel prox kinds: PG_G_ZERO / PG_G_NORML1 / PG_G_INDBOX and, for the second operator of the Davis-Yin mode,
@@ -221,6 +224,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
         for (int e = 0; e < VEC; ++e) racc[u][e] = fma(t.col[c][u][e], vj, racc[u][e]);
       }
     }
+    // Pin the accumulators here: their only use is at the end of the kernel, and the compiler otherwise sinks this
+    // group's multiply-adds into the next group's code, keeping this tile alive across it (found on the team kernel,
+    // pg_gemv_tn2.hip: whole tiles spilled; here: the <16,2,4> instantiation filled all 512 registers)
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(racc[u]));
   };
 
   // two register tiles: the loads of the next column group are in flight while the current one is reduced, exchanged

@@ -452,7 +452,7 @@ struct Pending {
 // it -- same effect at the loop header; the small loads (poll, x_j, z_old_j) issued AFTER the tile loads -- they return
 // in order, so reading them waits for the tile too.  Hence: a branch-free steady-state loop (ALL = true) between a
 // conditional head and tail, row groups past the end of a column clamped (masked through r = 0) instead of skipped.
-template <typename T, int U, int C, int WAVES, int LAG>
+template <typename T, int U, int C, int WAVES, int LAG, int PF = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   struct Tile {
     V col[C][U];
   };
-  auto load = [&](Tile& t, int64_t i) {
+  auto load = [&](Tile& t, int64_t i) __attribute__((always_inline)) {
     const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     }
   };
   // this member's partial dots of step i -> ring
-  auto dot_post = [&](const Tile& t, int64_t i) {
+  auto dot_post = [&](const Tile& t, int64_t i) __attribute__((always_inline)) {
     const int buf = (int)(i & 1);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -542,11 +542,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     }
   };
   const int poll_lane = lane < npoll ? lane : npoll - 1;  // every lane polls (no exec-masked load): lanes >= npoll repeat the last granule
-  auto poll_word = [&](int64_t i) -> unsigned long long {
+  auto poll_word = [&](int64_t i) __attribute__((always_inline)) -> unsigned long long {
     return __hip_atomic_load(ring + (size_t)(i % TEAM_RING) * (TEAM_MAX * C * G) + poll_lane, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
   };
-  auto fetch_xz = [&](Pending<T, C>& pd, int64_t i) {
+  auto fetch_xz = [&](Pending<T, C>& pd, int64_t i) __attribute__((always_inline)) {
     const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -556,8 +556,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     }
   };
   // totals of step i (all members have posted, or will shortly) -> epilogue -> v_j (0 for columns past the end)
-  auto totals = [&](int64_t i, Pending<T, C>& pd, T (&vj)[C]) {
+  auto totals = [&](int64_t i, Pending<T, C>& pd, T (&vj)[C]) __attribute__((always_inline)) {
     const unsigned tag = (unsigned)(i + 1);
+#ifdef PG_TNT_EXPERIMENT
+    if (a.dbg & 1) dead = true;  // timing experiment: never wait (totals are then wrong)
+#endif
     // The first look at the granules stays OUTSIDE the retry loop (see the note above the kernel).
     if (!dead && __builtin_amdgcn_ballot_w64((unsigned)(pd.w >> 32) == tag) != ~0ull) {
       long long spins = 0;
@@ -619,16 +622,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   // One step: [poll the totals of step i - LAG, fetch its x_j / z_old_j] [start loading tile i + 1 into `nxt`]
   // [dot + post tile i = `cur`] [totals of step i - LAG -> v_j ; A v accumulation from the parked tile] [park `cur`].
   // ALL = steady state: every part runs, no branch.
-  auto step = [&](auto allc, Tile& cur, Tile& nxt, int64_t i) {
+  auto step = [&](auto allc, Tile& cur, Tile& nxt, int64_t i) __attribute__((always_inline)) {
     constexpr bool ALL = decltype(allc)::value;
     if (!ALL && i >= cnt + LAG) return;
     const bool has_fma = ALL || i >= LAG;
     Pending<T, C> pd{};
+    // scheduling fences around the load issue: `nxt` is the register tile the previous step read last; without them the
+    // scheduler hoists these loads above that step's multiply-adds into fresh registers and the kernel spills
+    __builtin_amdgcn_sched_barrier(0);
     if (has_fma) {
       if constexpr (LAG > 0) pd.w = poll_word(i - LAG);  // issued BEFORE the next tile's loads: it returns first
       fetch_xz(pd, i - LAG);
     }
-    if (ALL || i + 1 < cnt) load(nxt, i + 1);
+    if (ALL || i + PF < cnt) load(nxt, i + PF);
+    __builtin_amdgcn_sched_barrier(0);
     if (ALL || i < cnt) dot_post(cur, i);
     if constexpr (LAG == 0) {
       if (has_fma) pd.w = poll_word(i);
@@ -645,20 +652,53 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
             for (int e = 0; e < VEC; ++e) racc[u][e] = fma(cur.col[c][u][e], vj[c], racc[u][e]);
           }
         }
-      } else {
-        const V* __restrict__ src = park_slot(i - LAG);
+#ifdef PG_TNT_EXPERIMENT
+      } else if (a.dbg & 2) {  // timing experiment: no LDS read-back (wrong tile)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const V col = src[(c * U + u) * WAVE];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(col[e], vj[c], racc[u][e]);
+            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(cur.col[c][u][e], vj[c], racc[u][e]);
+          }
+        }
+#endif
+      } else {
+        // Four 16-byte reads at a time.  Left alone the compiler issues all C * U reads up front (C * U * 4 registers) and,
+        // for two columns per step, makes room by spilling the tile that is in flight.  The address of every chunk depends
+        // (through an opaque v_mov that always yields 0) on an accumulator of the previous chunk, which pins the order
+        // read 4 -> multiply-add 4 -> read 4 ...
+        const V* __restrict__ src = park_slot(i - LAG);
+        int dep = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u0 = 0; u0 < U; u0 += 4) {
+            const V* __restrict__ sp = src + dep;
+            V col[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (u0 + k < U) col[k] = sp[(c * U + u0 + k) * WAVE];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (u0 + k < U) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) racc[u0 + k][e] = fma(col[k][e], vj[c], racc[u0 + k][e]);
+              }
+            }
+            asm volatile("v_mov_b32 %0, 0" : "=v"(dep) : "v"(racc[u0][0]));
           }
         }
       }
     }
+    // Pin the accumulators HERE.  Their only use is at the end of the kernel, so the compiler is free to sink this step's
+    // multiply-adds into the next step (keeping this step's tile alive across it: +C * U * 4 registers, whole tiles spilled).
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(racc[u]));
     if constexpr (LAG > 0) {
+#ifdef PG_TNT_EXPERIMENT
+      if (!(a.dbg & 4))
+#endif
       if (ALL || i < cnt) {  // same slot as the tile just read: this wave's region only, program order suffices
         V* __restrict__ dst = park_slot(i);
 #pragma unroll
@@ -670,25 +710,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     }
   };
 
-  Tile ta, tb;
+  // PF + 1 register tiles rotate: tile i is dotted while tiles i + 1 .. i + PF are in flight.  Named variables, not an
+  // array: an array of tiles handed to the step by reference ends up in scratch memory.
+  constexpr int NR = PF + 1;
+  static_assert(NR == 2 || NR == 3, "two or three register tiles");
+  Tile ta, tb, tc;
   if (cnt > 0) load(ta, 0);
-  constexpr int64_t HEAD = (LAG + 1) / 2 * 2;  // first even step from which every step has totals to consume
-  int64_t base = 0;
-  for (; base < HEAD && base < cnt + LAG; base += 2) {
-    step(std::false_type{}, ta, tb, base);
-    step(std::false_type{}, tb, ta, base + 1);
+  if constexpr (PF > 1) {
+    if (cnt > 1) load(tb, 1);
   }
-  if (base + 3 <= cnt) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the steady loop starts from a state the compiler knows exactly
-    for (; base + 3 <= cnt; base += 2) {
-      step(std::true_type{}, ta, tb, base);
-      step(std::true_type{}, tb, ta, base + 1);
+  auto round = [&](auto allc, int64_t base) __attribute__((always_inline)) {
+    if constexpr (NR == 2) {
+      step(allc, ta, tb, base);
+      step(allc, tb, ta, base + 1);
+    } else {  // tile i in t[i % 3], loading tile i + 2 into t[(i + 2) % 3]
+      step(allc, ta, tc, base);
+      step(allc, tb, ta, base + 1);
+      step(allc, tc, tb, base + 2);
     }
+  };
+  constexpr int64_t HEAD = (LAG + NR - 1) / NR * NR;  // first round boundary from which every step has totals to consume
+  int64_t base = 0;
+  for (; base < HEAD && base < cnt + LAG; base += NR) round(std::false_type{}, base);
+  if (base + NR + PF <= cnt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the steady loop starts from a state the compiler knows exactly
+    for (; base + NR + PF <= cnt; base += NR) round(std::true_type{}, base);
   }
-  for (; base < cnt + LAG; base += 2) {
-    step(std::false_type{}, ta, tb, base);
-    step(std::false_type{}, tb, ta, base + 1);
-  }
+  for (; base < cnt + LAG; base += NR) round(std::false_type{}, base);
   // this member's rows of the team's partial of A v
   T* part = a.partials + (int64_t)team * a.ld + lane * VEC;
 #pragma unroll
@@ -698,7 +746,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
 }
 
-template <typename T, int U, int C, int LAG>
+template <typename T, int U, int C, int LAG, int PF = 1>
 pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   constexpr int G = (int)sizeof(T) / 4;
@@ -741,6 +789,9 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.nteams = (int)nteams;
   a.xch = (unsigned long long*)A->xch;
   a.team_err = c->dscal + PG_S_TEAMERR;
+#ifdef PG_TNT_EXPERIMENT
+  a.dbg = env_int("PG_TNT_DBG", 0);
+#endif
   *blocks_out = (int)nteams;
   // LDS for the parked tiles: LAG slots of WAVES * C * U KiB; more than 64 KiB of dynamic LDS is opted into once
   const size_t lds = (size_t)LAG * TEAM_WAVES * C * U * 1024;
@@ -748,13 +799,13 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     static bool opted_in[64] = {};
     const int dev = c->device & 63;
     if (!opted_in[dev]) {
-      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG>),
+      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG, PF>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       opted_in[dev] = true;
     }
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG>), dim3((unsigned)(nteams * TM)), dim3(TEAM_WAVES * 64), lds,
+  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG, PF>), dim3((unsigned)(nteams * TM)), dim3(TEAM_WAVES * 64), lds,
                      c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
@@ -813,7 +864,8 @@ pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int nrg = a.nrg;
   // measured (profiles/r2_tune_tn_mid_columns.log): eight waves of U = 2 with C = 16 columns per step, one tile, one workgroup
   // per CU -- 4096 x 2^19: 6.68 TB/s against 6.37 for gemv_tn's four waves of U = 4; 3072 rows: 6.62 against 6.03;
-  // from 17 row groups on the two kernels are level (8192 x 2^18: 6.68 / 6.67) and gemv_tn stays
+  // 17..24 row groups: eight waves of U = 4, C = 8: 7.03 / 6.83 / 6.96 TB/s against gemv_tn's 6.27 / 6.53 / 6.88; from 28
+  // row groups on the two kernels are level (8192 x 2^18: 6.85 / 6.88) and gemv_tn stays
   const int W = env_int("PG_TNC_WAVES", 8);
   int U = 1;
   while (U * W < nrg) U *= 2;
@@ -852,6 +904,13 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // columns per step 6.67 TB/s, 4 members of U = 8 6.49 TB/s; LAG = 1: 4.97-5.58, LAG = 0: 4.60-5.52 TB/s.
   const int U = env_int("PG_TNT_U", a.nrg <= 8 * 4 * TEAM_WAVES ? 4 : 8);
   const int C = env_int("PG_TNT_C", U == 4 ? 2 : 1), LAG = env_int("PG_TNT_LAG", 2);
+  // Tiles in flight ahead of the one being consumed: two for the U = 8 geometry (131072 rows: 6.68 vs 6.52 TB/s with
+  // one), no difference for U = 4 (65536 rows: 6.81 / 6.82) -- profiles/r2_tune_tn_team.log
+  if (env_int("PG_TNT_PF", U == 8 ? 2 : 1) == 2) {
+    if (U == 8 && C == 1 && LAG == 2) return launch_tnt<T, 8, 1, 2, 2>(A, a, blocks_out);
+    if (U == 4 && C == 2 && LAG == 2) return launch_tnt<T, 4, 2, 2, 2>(A, a, blocks_out);
+    if (U == 8 && C == 1 && LAG == 1) return launch_tnt<T, 8, 1, 1, 2>(A, a, blocks_out);
+  }
 #define PG_TNT_CASE(UU, CC, LL) \
   if (U == UU && C == CC && LAG == LL) return launch_tnt<T, UU, CC, LL>(A, a, blocks_out)
   PG_TNT_CASE(8, 1, 2);

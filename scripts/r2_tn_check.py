@@ -200,6 +200,27 @@ def cmd_mid(shapes):
         del f, A
 
 
+def cmd_ab(shapes):
+    """Interleaved A/B of the candidate geometries for 9..32 row groups (median of five rounds each)."""
+    ctx = pa.get_context()
+    g = pa.NormL1(0.3)
+    for (m, n) in shapes:
+        A, f, x, vs = setup(m, n)
+        nbytes = m * n * 4
+        nrg = (m * 4 + 1023) // 1024
+        coop = lambda C, db: dict(PG_TN_KERNEL="coop", PG_TNC_WAVES="8", PG_TNC_C=str(C), PG_TNC_DB=str(db))
+        cands = [("default", {}), ("wg", dict(PG_TN_KERNEL="wg"))]
+        cands += [(f"coop C={C} db={db}", coop(C, db)) for C in ((8, 16) if nrg <= 16 else (4, 8)) for db in (0, 1)]
+        got = {k: [] for k, _ in cands}
+        for _ in range(5):
+            for k, env in cands:
+                clear()
+                os.environ.update(env)
+                got[k].append(nbytes / (time_pass(f, x, vs, g, ctx) * 1e-3) / 1e9)
+        print(f"=== {m}x{n} f32 ({nrg} row groups) === " + " ; ".join(f"{k}: {np.median(v):5.0f}" for k, v in got.items()))
+        del f, A
+
+
 def cmd_team(shapes):
     ctx = pa.get_context()
     g = pa.NormL1(0.3)
@@ -238,6 +259,8 @@ if __name__ == "__main__":
         sys.exit(cmd_check())
     if cmd == "short":
         cmd_short(shapes or [(512, 1 << 22), (1024, 1 << 21), (2048, 1 << 20)])
+    if cmd == "ab":
+        cmd_ab(shapes or [(256 * k, (1 << 23) // k // 8 * 8) for k in (9, 10, 12, 14, 16, 17, 20, 24, 28, 32)] + [(8192, 1 << 18)])
     if cmd == "mid":
         cmd_mid(shapes or [(4096, 1 << 19), (8192, 1 << 18), (3072, 1 << 19), (6144, 1 << 18)])
     if cmd == "team":

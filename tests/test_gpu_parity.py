@@ -764,6 +764,7 @@ def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol):
 @pytest.mark.parametrize("m,n,what", [
     (16384, 65536, "gemv_tn<16,2,4> double-buffered: the headline kernel, 128 column groups per workgroup"),
     (8192, 32768, "gemv_tn<4,8,8>: BASELINE config 2's kernel, 16 column groups per workgroup"),
+    (5120, 65536, "gemv_tnc<4,8,8>: 17..24 row groups, partly filled last wave (20 of 32 row groups)"),
     (4096, 131072, "gemv_tnc<2,16,8>: waves share the column group, lane-parallel epilogue, 32 groups per workgroup"),
     (2048, 262144, "gemv_tnw<8,4>: one wave per column group, 64 groups per wave"),
     (512, 1 << 20, "gemv_tnw<2,16>: short columns, double-buffered waves"),
