@@ -420,8 +420,8 @@ pg_status launch_tnc(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 // ---------------------------------------------------------------------------------------------------------------
 // LONG columns: teams of workgroups
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int TEAM_WAVES = 8;                   // a member holds 8 U row groups of every column (U = 8: 16384 rows in Float32)
-constexpr int TEAM_MAX = 16;                    // members per team: up to 1024 row groups at U = 8 (262144 rows f32, 131072 f64)
+constexpr int TEAM_MEMBER_RG = 64;              // a member holds WAVES * U = 64 row groups of every column (16384 rows in Float32)
+constexpr int TEAM_MAX = 16;                    // members per team: up to 1024 row groups (262144 rows f32, 131072 f64)
 constexpr int TEAM_RING = 8;                    // granule ring slots per team (>= 2 LAG + 2, see the protocol note)
 constexpr long long TEAM_SPIN_LIMIT = 1 << 21;  // polls before a member gives up (~ seconds): bounded, never a hang
 
@@ -439,7 +439,7 @@ struct Pending {
 // i - LAG - 1, which each of them did after consuming step i - 2 LAG - 2: a ring of 2 LAG + 2 slots is never
 // overwritten before everyone has read it.  The ring is zeroed before every launch (tags start at 1).
 //
-// Where the column tiles live.  Two register tiles alternate (one being loaded, one being dotted), as in
+// Where the column tiles live.  PF + 1 register tiles rotate (one being dotted, PF being loaded), as in
 // gemv_tn_kernel.  A tile whose totals are still travelling (LAG > 0) is parked in LDS -- LAG slots of
 // WAVES * C * U KiB, 128 KiB of the CU's 160 KiB at the default geometry -- and read back, 16 bytes per lane at a time,
 // for the A v accumulation: every wave touches only its own region of a slot (no barrier), reads the slot of step
@@ -746,12 +746,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
 }
 
-template <typename T, int U, int C, int LAG, int PF = 1>
+template <typename T, int U, int C, int LAG, int PF, int WAVES>
 pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   constexpr int G = (int)sizeof(T) / 4;
   const int64_t ncg = (A->n + C - 1) / C;
-  const int per_member = U * TEAM_WAVES;
+  const int per_member = U * WAVES;
   int TM = (a.nrg + per_member - 1) / per_member;
   if (env_int("PG_TN_TEAM", 0) > TM) TM = env_int("PG_TN_TEAM", 0);  // experiments: more (partly idle) members
   if (TM < 1) TM = 1;
@@ -759,7 +759,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     pg_set_error("the single-sweep pass covers columns of at most %d rows", (int)(TEAM_MAX * per_member * 1024 / sizeof(T)));
     return PG_ERR_UNSUPPORTED;
   }
-  // every member must be resident at once (they wait for each other): one 512-thread workgroup per CU at most
+  // every member must be resident at once (they wait for each other): one workgroup per CU at most
   int64_t nteams = c->num_cu / TM;
   if (env_int("PG_TN_TEAMS", 0) > 0 && env_int("PG_TN_TEAMS", 0) < nteams) nteams = env_int("PG_TN_TEAMS", 0);
   if (nteams > ncg) nteams = ncg;
@@ -794,18 +794,18 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 #endif
   *blocks_out = (int)nteams;
   // LDS for the parked tiles: LAG slots of WAVES * C * U KiB; more than 64 KiB of dynamic LDS is opted into once
-  const size_t lds = (size_t)LAG * TEAM_WAVES * C * U * 1024;
+  const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
   if (lds > 64 * 1024) {
     static bool opted_in[64] = {};
     const int dev = c->device & 63;
     if (!opted_in[dev]) {
-      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG, PF>),
+      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       opted_in[dev] = true;
     }
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, TEAM_WAVES, LAG, PF>), dim3((unsigned)(nteams * TM)), dim3(TEAM_WAVES * 64), lds,
+  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>), dim3((unsigned)(nteams * TM)), dim3(WAVES * 64), lds,
                      c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
@@ -814,7 +814,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 }  // namespace
 
 bool tn_wave_covers(int nrg) { return nrg >= 1 && nrg <= 8; }
-bool tn_team_covers(int nrg) { return nrg >= 1 && nrg <= TEAM_MAX * 8 * TEAM_WAVES; }
+bool tn_team_covers(int nrg) { return nrg >= 1 && nrg <= TEAM_MAX * TEAM_MEMBER_RG; }
 
 // Tunables (environment, for experiments): PG_TNW_C, PG_TNW_WPB (waves per workgroup), PG_TNW_DB (0 / 1),
 // PG_TNW_WAVES_PER_CU.
@@ -894,33 +894,32 @@ pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   return PG_ERR_UNSUPPORTED;
 }
 
-// Tunables (environment, for experiments): PG_TNT_U, PG_TNT_C, PG_TNT_LAG, PG_TN_TEAM (members per team), PG_TN_TEAMS.
+// Tunables (environment, for experiments): PG_TNT_WAVES, PG_TNT_U, PG_TNT_C, PG_TNT_LAG, PG_TNT_PF, PG_TN_TEAM (members per
+// team), PG_TN_TEAMS.
 template <typename T>
 pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // The exchange costs about two step times (the post and the poll each queue behind a step's worth of loads in their
-  // CU's memory pipeline) plus the fabric: the totals of step i are consumed LAG steps later
-  // (profiles/r2_tune_tn_team.log).  LAG * C * U <= 16: the parked tiles fill 128 KiB of LDS.
-  // Measured (Float32, 64 GiB): 131072 rows (8 members of U = 8) 6.57 TB/s; 65536 rows: 8 members of U = 4 with two
-  // columns per step 6.67 TB/s, 4 members of U = 8 6.49 TB/s; LAG = 1: 4.97-5.58, LAG = 0: 4.60-5.52 TB/s.
-  const int U = env_int("PG_TNT_U", a.nrg <= 8 * 4 * TEAM_WAVES ? 4 : 8);
+  // CU's memory pipeline) plus the fabric: the totals of step i are consumed LAG steps later.  LAG * C * U * WAVES <= 128:
+  // the parked tiles fill 128 KiB of LDS.  A member is FOUR waves of U = 16 row groups (one wave per SIMD, 16 KiB of a
+  // column per wave and step, the full 512 registers): 131072 rows 7.01-7.05 TB/s, 65536 rows 7.03-7.06; eight waves of
+  // U = 8 (the same rows per member, half the bytes per wave and step): 6.73-6.75 / 6.41-6.56; eight waves of U = 4 with
+  // two columns per step: 6.20 / 6.79-6.81; LAG = 1: 5.05-5.61, LAG = 0: 4.62-5.49 TB/s (profiles/r2_tune_tn_team.log).
+  const int W = env_int("PG_TNT_WAVES", 4);
+  const int U = env_int("PG_TNT_U", W == 4 ? 16 : 8);
   const int C = env_int("PG_TNT_C", U == 4 ? 2 : 1), LAG = env_int("PG_TNT_LAG", 2);
-  // Tiles in flight ahead of the one being consumed: two for the U = 8 geometry (131072 rows: 6.68 vs 6.52 TB/s with
-  // one), no difference for U = 4 (65536 rows: 6.81 / 6.82) -- profiles/r2_tune_tn_team.log
-  if (env_int("PG_TNT_PF", U == 8 ? 2 : 1) == 2) {
-    if (U == 8 && C == 1 && LAG == 2) return launch_tnt<T, 8, 1, 2, 2>(A, a, blocks_out);
-    if (U == 4 && C == 2 && LAG == 2) return launch_tnt<T, 4, 2, 2, 2>(A, a, blocks_out);
-    if (U == 8 && C == 1 && LAG == 1) return launch_tnt<T, 8, 1, 1, 2>(A, a, blocks_out);
-  }
-#define PG_TNT_CASE(UU, CC, LL) \
-  if (U == UU && C == CC && LAG == LL) return launch_tnt<T, UU, CC, LL>(A, a, blocks_out)
-  PG_TNT_CASE(8, 1, 2);
-  PG_TNT_CASE(8, 1, 1);
-  PG_TNT_CASE(8, 2, 1);
-  PG_TNT_CASE(8, 1, 0);
-  PG_TNT_CASE(8, 2, 0);
-  PG_TNT_CASE(4, 2, 2);
+  // tiles in flight ahead of the one being consumed
+  const int PF = env_int("PG_TNT_PF", U == 4 ? 1 : 2);
+#define PG_TNT_CASE(UU, CC, LL, PP, WW) \
+  if (U == UU && C == CC && LAG == LL && PF == PP && W == WW) return launch_tnt<T, UU, CC, LL, PP, WW>(A, a, blocks_out)
+  PG_TNT_CASE(16, 1, 2, 2, 4);
+  PG_TNT_CASE(16, 1, 2, 1, 4);
+  PG_TNT_CASE(16, 1, 1, 2, 4);
+  PG_TNT_CASE(16, 1, 0, 2, 4);
+  PG_TNT_CASE(8, 1, 2, 2, 8);
+  PG_TNT_CASE(8, 1, 2, 1, 8);
+  PG_TNT_CASE(4, 2, 2, 1, 8);
 #undef PG_TNT_CASE
-  pg_set_error("no gemv_tnt instantiation for U=%d C=%d LAG=%d", U, C, LAG);
+  pg_set_error("no gemv_tnt instantiation for WAVES=%d U=%d C=%d LAG=%d PF=%d", W, U, C, LAG, PF);
   return PG_ERR_UNSUPPORTED;
 }
 

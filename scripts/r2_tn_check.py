@@ -13,7 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import proximalalgorithms.jl_amd as pa  # noqa: E402
 
-KNOBS = ("PG_TN_KERNEL", "PG_TNW_C", "PG_TNW_WPB", "PG_TNW_DB", "PG_TNW_WAVES_PER_CU", "PG_TNT_C", "PG_TNT_LAG", "PG_TNT_PF", "PG_TNT_U", "PG_TN_TEAM",
+KNOBS = ("PG_TN_KERNEL", "PG_TNW_C", "PG_TNW_WPB", "PG_TNW_DB", "PG_TNW_WAVES_PER_CU", "PG_TNT_C", "PG_TNT_LAG", "PG_TNT_PF", "PG_TNT_WAVES", "PG_TNT_U", "PG_TN_TEAM",
          "PG_TN_TEAMS", "PG_TN_WAVES", "PG_TN_C", "PG_TN_BLOCKS_PER_CU", "PG_TNC_WAVES", "PG_TNC_C", "PG_TNC_DB",
          "PG_TNC_BLOCKS_PER_CU")
 
@@ -84,11 +84,11 @@ def cmd_check():
         for m, n, env in ((3 * rpg, 50, {"PG_TN_KERNEL": "team", "PG_TN_TEAM": "3"}),
                           (100 * rpg, 77, {"PG_TN_KERNEL": "team"}),
                           (130 * rpg + 5, 40, {}),
-                          (256 * rpg, 40, {}), (256 * rpg, 333, {"PG_TNT_U": "4", "PG_TNT_C": "2", "PG_TNT_LAG": "2"}),
-                          (256 * rpg, 333, {"PG_TNT_U": "8", "PG_TNT_C": "1", "PG_TNT_LAG": "1"}),
-                          (256 * rpg, 333, {"PG_TNT_U": "8", "PG_TNT_C": "2", "PG_TNT_LAG": "1"}),
-                          (256 * rpg, 333, {"PG_TNT_U": "8", "PG_TNT_C": "1", "PG_TNT_LAG": "0"}),
-                          (256 * rpg, 333, {"PG_TNT_U": "8", "PG_TNT_C": "2", "PG_TNT_LAG": "0"}),
+                          (256 * rpg, 40, {}), (256 * rpg, 333, {"PG_TNT_PF": "1"}),
+                          (256 * rpg, 333, {"PG_TNT_LAG": "1"}), (256 * rpg, 333, {"PG_TNT_LAG": "0"}),
+                          (256 * rpg, 333, {"PG_TNT_WAVES": "8", "PG_TNT_U": "8"}),
+                          (256 * rpg, 333, {"PG_TNT_WAVES": "8", "PG_TNT_U": "8", "PG_TNT_PF": "1"}),
+                          (256 * rpg, 333, {"PG_TNT_WAVES": "8", "PG_TNT_U": "4"}),
                           (300 * rpg + 17, 700, {}), (512 * rpg, 24, {}), (1024 * rpg, 9, {})):
             ok &= check_one(m, n, dtype, env)
         # medium columns: waves share the column group, lane-parallel epilogue (gemv_tnc)
@@ -221,16 +221,19 @@ def cmd_ab(shapes):
         del f, A
 
 
-def cmd_team(shapes):
+W8 = {"PG_TNT_WAVES": "8"}
+TEAM_ENVS = ({}, {"PG_TNT_PF": "1"}, {"PG_TNT_LAG": "1"}, {"PG_TNT_LAG": "0"}, dict(W8, PG_TNT_U="8"), dict(W8, PG_TNT_U="8", PG_TNT_PF="1"),
+             dict(W8, PG_TNT_U="4"), {})
+
+
+def cmd_team(shapes, envs=TEAM_ENVS):
     ctx = pa.get_context()
     g = pa.NormL1(0.3)
     for (m, n) in shapes:
         A, f, x, vs = setup(m, n)
         nbytes = m * n * 4
         print(f"=== {m}x{n} f32 ({nbytes / 2**30:.1f} GiB) ===")
-        for env in ({}, {"PG_TNT_U": "8", "PG_TNT_C": "1", "PG_TNT_LAG": "1"}, {"PG_TNT_U": "8", "PG_TNT_C": "2", "PG_TNT_LAG": "1"},
-                    {"PG_TNT_U": "8", "PG_TNT_C": "1", "PG_TNT_LAG": "0"}, {"PG_TNT_U": "8", "PG_TNT_C": "2", "PG_TNT_LAG": "0"},
-                    {"PG_TNT_U": "4", "PG_TNT_C": "2", "PG_TNT_LAG": "2"}):
+        for env in envs:
             clear()
             if m * 4 <= 128 * 1024 and "PG_TN_TEAM" not in env:
                 env = dict(env, PG_TN_KERNEL="team")

@@ -768,15 +768,16 @@ def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol):
     (4096, 131072, "gemv_tnc<2,16,8>: waves share the column group, lane-parallel epilogue, 32 groups per workgroup"),
     (2048, 262144, "gemv_tnw<8,4>: one wave per column group, 64 groups per wave"),
     (512, 1 << 20, "gemv_tnw<2,16>: short columns, double-buffered waves"),
-    (65536, 8192, "gemv_tnt: teams of 8 workgroups (U = 4), 128 steps per team with the two-step lag"),
-    (131072, 4096, "gemv_tnt: teams of 8 workgroups (U = 8), BASELINE config 5's per-GPU column length"),
+    (65536, 8192, "gemv_tnt: teams of 4 workgroups, 128 steps per team with the two-step lag"),
+    (131072, 4096, "gemv_tnt: teams of 8 workgroups, BASELINE config 5's per-GPU column length"),
 ])
 def test_sweep_kernels_steady_state_iterates_match_oracle(pa, m, n, what):
     _ffb_device_vs_oracle(pa, m, n, np.float32, fixed_its=20, adaptive_its=8, z_tol=1e-5)
 
 
 def test_sweep_kernels_steady_state_float64(pa):
-    for (m, n) in ((8192, 16384), (1024, 131072), (32768, 4096)):  # one workgroup / one wave / teams
+    # one workgroup / one wave / teams / waves sharing the column group with the lane-parallel epilogue (U = 2 and U = 4)
+    for (m, n) in ((8192, 16384), (1024, 131072), (32768, 4096), (2048, 65536), (2560, 32768)):
         _ffb_device_vs_oracle(pa, m, n, np.float64, fixed_its=12, adaptive_its=6, z_tol=1e-11)
 
 
@@ -1628,8 +1629,9 @@ def test_fused_single_sweep_pass_matches_separate_kernels(pa, dtype, gname):
     rng = np.random.default_rng(11)
     shapes = [(1, 1), (5, 3), (200, 500), (256, 64), (257, 65), (1000, 33), (4096, 40), (4097, 130), (8192, 70), (16384, 24), (20000, 9)]
     # one wave per column group (<= 8 row groups), one workgroup (<= 128), teams of workgroups beyond (pg_gemv_tn2.hip)
-    shapes += [(511, 700), (2048, 333), (32768, 5), (32769, 7), (65536, 40), (131072, 24)] if dtype == np.float32 else \
-        [(1024, 333), (16385, 4), (40000, 11), (65536, 24)]
+    # (the last two of each list: ragged and full teams of 16, the longest columns the sweep takes)
+    shapes += [(511, 700), (2048, 333), (5000, 77), (32768, 5), (32769, 7), (65536, 40), (131072, 24), (200000, 5), (262144, 6)] \
+        if dtype == np.float32 else [(1024, 333), (2500, 77), (16385, 4), (40000, 11), (65536, 24), (100000, 5), (131072, 6)]
     for (m, n) in shapes:
         A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
         b = rng.standard_normal(m).astype(dtype)
