@@ -21,7 +21,8 @@ rank (every GPU keeps the single sweep; one all-reduce of m + 8 N floats per ite
 each with its own roofline, the world size RCCL reports and the all-reduce payload.
 
 N = 1: the line also carries `also`: the reference benchmark's own adaptive mode on the headline matrix
-(benchmark/benchmarks.jl:55-61) and BASELINE configs 2, 3 and 4, each with its roofline (--no-also skips them).
+(benchmark/benchmarks.jl:55-61), BASELINE configs 2, 3 and 4 and two per-GPU block shapes at N = 8 (long and short columns), each with
+its roofline (--no-also skips them).
 
 Extra legs in the same line:
   roofline      HBM roofline of the dominant kernel (the slowest sweep over A), timed live with HIP event pairs
@@ -662,6 +663,8 @@ def main():
     if not D.sharded:
         layout = "none"
     named = args.workload if (args.m is None and args.n is None) else None
+    if (m_glob, n) == (131072, 131072) and world == 1:
+        named = "long_columns"  # the shape the PMC passes of the team sweep were taken on (profiles/pmc_traffic.json)
 
     P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode)
     main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
@@ -670,7 +673,7 @@ def main():
     sub_steps = max(4, min(args.steps, 20))
     if args.no_also:
         pass
-    elif world == 1 and not args.force_comm and args.workload == "headline" and named and args.mode == "fixed":
+    elif world == 1 and not args.force_comm and named == "headline" and args.mode == "fixed":
         also = []
         # the reference benchmark's own mode: adaptive step (benchmark/benchmarks.jl:55-61), same matrix
         r = run_ffb(pa, ctx, D, P, "adaptive", args.sweeps, sub_steps, 3, args.kernel_events)
@@ -693,6 +696,18 @@ def main():
             also.append(run_config3(pa, ctx))
         if within():
             also.append(run_config4(pa, ctx))
+        # per-GPU block shapes at N = 8, run as problems of their own on one GPU: BASELINE config 5 under the column layout
+        # (131072 x 131072: one team sweep per iteration) and the headline under north_star's row layout (2048 x 2^20: the
+        # short-column sweep, one wave per column group)
+        for label, (mm, nn) in (("config5_column_block", (131072, 131072)), ("headline_row_block_n8", (2048, 1 << 20))):
+            if within():
+                P2 = setup_lasso(pa, ctx, D, mm, nn, dtype, args.seed, "none", "fixed")
+                # the PMC passes of the long-column sweep were taken on exactly this shape (profiles/pmc_traffic.json)
+                r = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events,
+                            workload_name="long_columns" if mm == 131072 and dtype == np.float32 else None)
+                r["label"] = label
+                also.append(r)
+                P2 = None
         extra["also"] = also
     elif world > 1:
         P = None

@@ -628,7 +628,8 @@ def test_bench_self_launched_two_ranks_reports_every_layout(pa):
 def test_bench_default_line_carries_every_single_gpu_config(pa):
     """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`): the top-level record is the fixed-step headline
     run; `also` holds the reference benchmark's adaptive mode on the same matrix and BASELINE configs 2, 3, 4, each with its
-    own roofline."""
+    own roofline, then the long-column and short-column per-GPU block shapes at N = 8 (next-round 4 and 6:
+    one read of A per iteration at >= 0.8 of peak on 131072 x 131072)."""
     import json
     import subprocess
     import sys
@@ -648,8 +649,10 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
     assert d["roofline"]["kernel"] == "gemv_tn" and d["roofline"]["frac"] > 0.6  # north_star: >= 60 % of the HBM roofline
     assert "traffic_stale" in d["roofline"]
     labels = [r["label"] for r in d["also"]]
-    assert labels == ["headline_adaptive", "config2", "config3", "config4"], labels
-    ad, c2, c3, c4 = d["also"]
+    assert labels == ["headline_adaptive", "config2", "config3", "config4", "config5_column_block", "headline_row_block_n8"], labels
+    ad, c2, c3, c4, c5c, c5r = d["also"]
+    assert c5c["config"]["m"] == 131072 and c5c["config"]["a_passes_per_step"] == 1.0 and c5c["roofline"]["frac"] > 0.8
+    assert c5r["config"]["m"] == 2048 and c5r["config"]["a_passes_per_step"] == 1.0 and c5r["roofline"]["frac"] > 0.75
     assert ad["config"]["mode"] == "adaptive" and ad["config"]["a_passes_per_step"] <= 1.5 and ad["roofline"]["frac"] > 0.6
     assert c2["config"]["m"] == 8192 and c2["config"]["n"] == 262144 and c2["roofline"]["frac"] > 0.6
     assert c3["stepping"]["roofline"]["kernel"] == "dr_step" and c3["device_loop"]["value"] > c3["stepping"]["value"]
