@@ -27,6 +27,42 @@ __global__ void read_kernel(const f4* __restrict__ p, size_t n4, float* out) {
   if (s == 1.2345e-30f) out[0] = s;  // keep the loads alive
 }
 
+// The access pattern of the GEMV sweeps: every wave streams contiguous runs of U KiB (U loads of 64 lanes x 16 B), two
+// runs in flight (the second is issued before the first is consumed), runs dealt round-robin over all waves of the grid.
+template <int U>
+__global__ void read_runs_kernel(const f4* __restrict__ p, size_t n4, float* out) {
+  const size_t run = (size_t)U * 64;  // f4 elements per run
+  const size_t nruns = n4 / run;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64, nwaves = (size_t)gridDim.x * blockDim.x / 64;
+  const int lane = threadIdx.x & 63;
+  f4 acc = {0, 0, 0, 0};
+  f4 a[U], b[U];
+  size_t r = wave;
+  if (r < nruns) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(p + r * run + u * 64 + lane);
+  }
+  for (; r < nruns; r += 2 * nwaves) {
+    const size_t r1 = r + nwaves, r2 = r + 2 * nwaves;
+    if (r1 < nruns) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) b[u] = __builtin_nontemporal_load(p + r1 * run + u * 64 + lane);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += a[u];
+    if (r2 < nruns) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(p + r2 * run + u * 64 + lane);
+    }
+    if (r1 < nruns) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += b[u];
+    }
+  }
+  float s = acc.x + acc.y + acc.z + acc.w;
+  if (s == 1.2345e-30f) out[0] = s;
+}
+
 template <int U>
 __global__ void copy_kernel(const f4* __restrict__ p, f4* __restrict__ q, size_t n4) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,6 +116,15 @@ int main(int argc, char** argv) {
         double g = 2.0 * bytes / ms / 1e6; if (g > best_c) best_c = g; printf("copy %d %d %d 1 %.3f %.1f\n", threads, blocks, U, ms, g); }
       RUN_C(1) RUN_C(4)
     }
-  printf("# best read-only %.1f GB/s, best copy (read+write) %.1f GB/s\n", best_r, best_c);
+  double best_w = 0;
+  for (int threads : {256, 512})
+    for (int bpc : {1, 2, 4}) {
+      const int blocks = cu * bpc;
+#define RUN_W(U) { double ms = time_ms([&] { hipLaunchKernelGGL((read_runs_kernel<U>), dim3(blocks), dim3(threads), 0, 0, p, n4, out); }, 3); \
+        double g = bytes / ms / 1e6; if (g > best_w) best_w = g; printf("read_runs %d %d %d 1 %.3f %.1f\n", threads, blocks, U, ms, g); }
+      RUN_W(4) RUN_W(8)
+    }
+  printf("# best read-only %.1f GB/s, best read-only in wave-contiguous runs (the sweeps' pattern) %.1f GB/s, best copy (read+write) %.1f GB/s\n",
+         best_r, best_w, best_c);
   return 0;
 }
