@@ -35,6 +35,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_dr_fetch -- python3 tests/tools/bench_dr.py --no-cpu-baseline --steps 64 > $O/prof_dr_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_dr_write -- python3 tests/tools/bench_dr.py --no-cpu-baseline --steps 64 > $O/prof_dr_write.log 2>&1
 python scripts/bench_panoc.py > $O/bench_panoc.json 2>/dev/null
+# the device's streaming-read ceiling on the same box (grid-stride and the sweeps' wave-contiguous runs), 64 GiB
+hipcc -O3 --offload-arch=gfx950 scripts/stream_ceiling.hip -o /tmp/stream_ceiling && /tmp/stream_ceiling 64 > $O/stream_ceiling.log 2>&1
 for d in prof_default prof_headline prof_fetch prof_write prof_long prof_long_fetch prof_long_write prof_dr_valu prof_dr_fetch prof_dr_write; do python scripts/rocpd_summary.py $O/$d/*/*_results.db > $O/$d.md 2>&1; done
 cp $O/prof_fetch/*/*_results.db $O/fetch.db; cp $O/prof_write/*/*_results.db $O/write.db
 cp $O/prof_long_fetch/*/*_results.db $O/long_fetch.db; cp $O/prof_long_write/*/*_results.db $O/long_write.db

@@ -32,6 +32,7 @@ done
   echo "# Douglas-Rachford kernels (tests/tools/bench_dr.py --no-cpu-baseline --steps 64): rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES, then FETCH_SIZE and WRITE_SIZE passes"
   cat $O/prof_dr_valu.md $O/prof_dr_fetch.md $O/prof_dr_write.md
 } > $P/r2_dr_counters.md
+grep -v amdgpu.ids $O/stream_ceiling.log > $P/r2_stream_ceiling.log
 python scripts/pmc_to_traffic.py headline $O/fetch.db $O/write.db profiles/r2_headline_pmc_fetch_write.md > /dev/null
 python scripts/pmc_to_traffic.py long_columns $O/long_fetch.db $O/long_write.db profiles/r2_long_columns_stats_and_pmc.md > /dev/null
 python - <<'EOF'
