@@ -25,6 +25,8 @@ N = 1: the line also carries `also`: the reference benchmark's own adaptive mode
 its roofline (--no-also skips them).
 
 Extra legs in the same line:
+  sustained     the main record's iteration kept running for --sustain seconds (one-GPU headline: 5) after the K timed steps:
+                it/s over that window (a burst check, and a window long enough for an outside GPU-busy sampler)
   roofline      HBM roofline of the dominant kernel (the slowest sweep over A), timed live with HIP event pairs
                 on the launch stream (pg_ctx_profile_*), algorithmic bytes = one full read of the local A block +
                 its vectors; whole_iteration reports the SURVEY 8(d) two-pass figure and the bytes actually moved.
@@ -80,6 +82,9 @@ def parse_args(argv=None):
                         "blocks otherwise); the other layout is reported as a sub-record")
     p.add_argument("--no-also", action="store_true",
                    help="skip the extra records (N = 1: adaptive headline + configs 2 / 3 / 4; N > 1: the other layouts)")
+    p.add_argument("--sustain", type=float, default=None,
+                   help="seconds the main record's iteration keeps running after the K timed steps (reported as `sustained`); "
+                        "default: 5 for the one-GPU headline line, 0 otherwise")
     p.add_argument("--also-budget", type=float, default=60.0, help="seconds the extra records may take in total (N = 1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel-events", choices=["gemv", "all", "none"], default="gemv",
@@ -394,7 +399,7 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
             "m_loc": m_loc, "n_loc": n_loc, "layout": layout, "dtype": dtype, "setup_s": time.perf_counter() - t0, "seed": seed}
 
 
-def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_name=None, scaling="strong"):
+def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_name=None, scaling="strong", sustain=0.0):
     """W untimed + K timed FastForwardBackward iterations on a prepared problem; returns the record (every rank) with
     value = K / max-over-ranks(elapsed), the HIP-event roofline of the dominant sweep kernel and the problem's config."""
     import numpy as np
@@ -426,6 +431,18 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
     prof = ctx.profile_read()
     ctx.profile(False)
     a_passes = iteration.counters.get("a_passes", 0) - passes0
+    sustained = None
+    if sustain > 0:  # the same iteration kept going for `sustain` seconds of wall clock (no event pairs): a window long enough
+        D.barrier()   # for an outside sampler to see, and a check that the K-step figure is not a burst
+        t1, k1 = time.perf_counter(), 0
+        while time.perf_counter() - t1 < sustain:
+            for _ in range(10):
+                state = next(it)
+                stop_rule(state)
+            k1 += 10
+        D.barrier()
+        dt1 = time.perf_counter() - t1
+        sustained = {"seconds": round(dt1, 2), "steps": k1, "value": round(k1 / dt1, 4), "ms_per_step": round(1e3 * dt1 / k1, 4)}
     elapsed = D.max_over_ranks(elapsed)
     its = steps / elapsed
     sweeps_done = a_passes / max(steps, 1)  # reads of A per iteration actually executed
@@ -494,6 +511,8 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
                              "allreduce_payload_bytes_per_call": int(elems / calls * es) if calls else None,
                              "layout_payload": ("[A v partial (m) ; 8 N scalar slots]" if cols else "[grad (n) ; f]")}
     del it, iteration
+    if sustained is not None:
+        rec["sustained"] = sustained
     return rec
 
 
@@ -666,9 +685,11 @@ def main():
     if (m_glob, n) == (131072, 131072) and world == 1:
         named = "long_columns"  # the shape the PMC passes of the team sweep were taken on (profiles/pmc_traffic.json)
 
+    if args.sustain is None:
+        args.sustain = 5.0 if (named == "headline" and world == 1 and not args.force_comm) else 0.0
     P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode)
     main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
-                       workload_name=named, scaling=args.scaling)
+                       workload_name=named, scaling=args.scaling, sustain=args.sustain)
     extra = {}
     sub_steps = max(4, min(args.steps, 20))
     if args.no_also:
@@ -736,7 +757,7 @@ def main():
                 "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": main_rec["config"],
                 "roofline": main_rec["roofline"], "cpu_baseline": cpu}
-        for k_ in ("ranks_seen_by_rccl", "collective"):
+        for k_ in ("ranks_seen_by_rccl", "collective", "sustained"):
             if k_ in main_rec:
                 line[k_] = main_rec[k_]
         line.update(extra)

@@ -648,6 +648,8 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
     assert d["config"]["m"] == 16384 and d["config"]["n"] == 1 << 20 and d["config"]["mode"] == "fixed" and d["steps"] == 6
     assert d["roofline"]["kernel"] == "gemv_tn" and d["roofline"]["frac"] > 0.6  # north_star: >= 60 % of the HBM roofline
     assert "traffic_stale" in d["roofline"]
+    # the same iteration kept going for 5 s: the K-step figure is not a burst
+    assert d["sustained"]["seconds"] >= 4.5 and abs(d["sustained"]["value"] / d["value"] - 1.0) < 0.05, (d["sustained"], d["value"])
     labels = [r["label"] for r in d["also"]]
     assert labels == ["headline_adaptive", "config2", "config3", "config4", "config5_column_block", "headline_row_block_n8"], labels
     ad, c2, c3, c4, c5c, c5r = d["also"]
