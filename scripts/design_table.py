@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Print the rows of DESIGN.md's "Measured (round 2)" table from the bench lines under profiles/ (run after
-scripts/publish_round_profiles.sh), so that the table is transcribed by a program and not by hand."""
+"""Write the "Measured (round 2)" table of DESIGN.md from the bench lines under profiles/ (run after
+scripts/publish_round_profiles.sh): the table is transcribed by a program, not by hand.
+    python scripts/design_table.py           print the table
+    python scripts/design_table.py --apply   replace the block between the <!-- measured:begin/end --> markers of DESIGN.md"""
 import json
 import os
+import re
+import sys
 
-P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
 
 
 def line(name):
@@ -14,25 +19,86 @@ def line(name):
     raise SystemExit(name + ": no JSON line")
 
 
-def ffb(d):
+def tb(r):
+    return r["achieved"] / 1e3
+
+
+def main():
+    d = line("r2_bench_default.json")
+    also = {a["label"]: a for a in d["also"]}
     r = d["roofline"]
-    return f"{d['value']:.1f} it/s, {d['ms_per_step']:.3f} ms/step, kernel {r['avg_launch_ms']:.3f} ms, {r['achieved'] / 1e3:.2f} TB/s, frac {r['frac']:.3f}"
-
-
-d = line("r2_bench_default.json")
-print("headline fixed      :", ffb(d), "| traffic", d["roofline"]["traffic"], "| cpu", round(d["cpu_baseline"]["value"], 2), round(d["cpu_baseline"]["value_1thread"], 2))
-for a in d["also"]:
-    if a["label"] == "config3":
-        s, l = a["stepping"], a["device_loop"]
-        print(f"also config3        : stepping {s['value']:.0f} it/s, dr_step {s['roofline']['avg_launch_ms'] * 1e3:.1f} us, {s['roofline']['achieved'] / 1e3:.2f} TB/s, frac {s['roofline']['frac']:.3f};"
-              f" loop {l['value']:.0f} it/s, dr_block {l['roofline']['avg_launch_ms'] * 1e3:.0f} us")
-    elif a["label"] == "config4":
-        pk = a["roofline"]["per_kernel"]
-        print(f"also config4        : {a['value']:.1f} it/s, " + ", ".join(f"{k} {v['avg_ms']:.2f} ms {v['GBps'] / 1e3:.2f} TB/s" for k, v in pk.items()))
+    ceiling = None
+    for l in open(os.path.join(P, "r2_stream_ceiling.log")):
+        m = re.search(r"wave-contiguous runs \(the sweeps' pattern\) ([0-9.]+) GB/s", l)
+        if m:
+            ceiling = float(m.group(1)) / 1e3
+    rows = []
+    add = lambda *c: rows.append("| " + " | ".join(c) + " |")
+    add("workload (Float32 unless noted)", "it/s", "dominant kernel: avg launch", "A bytes ÷ kernel time", "of 8 TB/s", "source")
+    add("---", "---", "---", "---", "---", "---")
+    sus = d.get("sustained")
+    add("headline 16384 × 2^20, fixed step (the driver's line)",
+        f"**{d['value']:.1f}** ({d['ms_per_step']:.2f} ms/step" + (f"; kept running for {sus['seconds']:.0f} s: {sus['value']:.1f}" if sus else "") + ")",
+        f"`gemv_tn<16,2,4>` {r['avg_launch_ms']:.2f} ms", f"{tb(r):.2f} TB/s", f"**{r['frac']:.3f}**", "`r2_bench_default.json`")
+    a = also["headline_adaptive"]
+    add("the same, adaptive step (`benchmarks.jl:55-61`)", f"{a['value']:.1f}", f"{a['roofline']['avg_launch_ms']:.2f} ms", f"{tb(a['roofline']):.2f} TB/s",
+        f"{a['roofline']['frac']:.3f}", "`also[0]` of the same line")
+    c2, a2 = line("r2_bench_config2.json"), also["config2"]
+    add("config 2, 8192 × 262144", f"{c2['value']:.0f} ({a2['value']:.0f} inside `also`)", f"`gemv_tn<4,8,8>` {c2['roofline']['avg_launch_ms']:.3f} ms",
+        f"{tb(c2['roofline']):.2f} TB/s", f"{c2['roofline']['frac']:.3f} ({a2['roofline']['frac']:.3f})", "`r2_bench_config2.json`, `also[1]`")
+    c3 = also["config3"]
+    s3, l3 = c3["stepping"], c3["device_loop"]
+    add("config 3, DouglasRachford n = 10^7: stepping", f"{s3['value'] / 1e3:.1f} k", f"`dr_step` {s3['roofline']['avg_launch_ms'] * 1e3:.1f} µs (200 MB)",
+        f"{tb(s3['roofline']):.2f} TB/s", f"{s3['roofline']['frac']:.3f}", "`also[2]`, `r2_bench_dr.json`")
+    add("config 3: in-library loop, 32 iterations per sweep, two sweeps in flight", f"**{l3['value'] / 1e3:.1f} k** (round 1: 129 k)",
+        f"`dr_block<32>` {l3['roofline']['avg_launch_ms'] * 1e3:.0f} µs", "VALU-bound, see below", "—", "`also[2].device_loop`")
+    c4 = also["config4"]
+    pk = c4["roofline"]["per_kernel"]
+    add("config 4, PANOC logistic + L1 16384 × 10^6, L-BFGS(5), adaptive", f"{c4['value']:.1f} (2.0 reads of A per iteration)",
+        f"`gemv_tn<16,2,4>` {pk['gemv_tn']['avg_ms']:.2f} ms, `gemv_n_partial` {pk['gemv_n_partial']['avg_ms']:.2f} ms",
+        f"{pk['gemv_tn']['GBps'] / 1e3:.2f} / {pk['gemv_n_partial']['GBps'] / 1e3:.2f} TB/s",
+        f"{pk['gemv_tn']['GBps'] / 8e3:.3f} / {pk['gemv_n_partial']['GBps'] / 8e3:.3f}", "`also[3]`, `r2_bench_panoc.json`")
+    lf, la, l6 = line("r2_bench_long_131072.json"), line("r2_bench_long_131072_adaptive.json"), line("r2_bench_long_65536.json")
+    add("long columns 131072 × 131072 (config 5's per-GPU block under column shards), fixed / adaptive",
+        f"**{lf['value']:.1f} / {la['value']:.1f}** with ONE read of A (round 1: two sweeps, 19.5 ms per iteration ≈ 51 it/s)",
+        f"`gemv_tnt<16,1,4,2,2>` {lf['roofline']['avg_launch_ms']:.2f} ms", f"{tb(lf['roofline']):.2f} TB/s", f"**{lf['roofline']['frac']:.3f}**",
+        "`r2_bench_long_131072*.json`, `also[4]`")
+    add("long columns 65536 × 262144", f"{l6['value']:.1f}", f"`gemv_tnt<16,1,4,2,2>` {l6['roofline']['avg_launch_ms']:.2f} ms", f"{tb(l6['roofline']):.2f} TB/s",
+        f"{l6['roofline']['frac']:.3f}", "`r2_bench_long_65536.json`")
+    sh = [line(f"r2_bench_short_{k}.json") for k in ("2048", "1024", "512x4M", "512")]
+    add("short columns 2048 × 2^20 / 1024 × 2^20 / 512 × 2^22 / 512 × 2^20 (row-shard shapes of N = 8 and below)",
+        " / ".join(f"{x['value']:.0f}" for x in sh), "`gemv_tnw` " + " / ".join(f"{x['roofline']['avg_launch_ms']:.3f}" for x in sh) + " ms",
+        " / ".join(f"{tb(x['roofline']):.2f}" for x in sh) + " TB/s",
+        "**" + " / ".join(f"{x['roofline']['frac']:.3f}" for x in sh) + "** (round 1: 0.77 / 0.67 / 0.59 / —)", "`r2_bench_short_*.json`, `also[5]`")
+    s4 = line("r2_bench_short_4096.json")
+    add("4096 × 2^20", f"{s4['value']:.0f}", f"`gemv_tnc<2,16,8>` {s4['roofline']['avg_launch_ms']:.2f} ms", f"{tb(s4['roofline']):.2f} TB/s",
+        f"{s4['roofline']['frac']:.3f}", "`r2_bench_short_4096.json`")
+    cs = [line(f"r2_bench_colshard_n{k}.json") for k in ("524288", "262144", "131072")]
+    add("column-shard shapes with the collective attached (one rank): n = 2^19 / 2^18 / 2^17",
+        " / ".join(f"{x['value']:.1f}" for x in cs) + " (" + " / ".join(f"{x['value'] / d['value']:.2f}×" for x in cs) +
+        " this box's one-GPU rate before the 64 KiB all-reduce)",
+        "`gemv_tn` " + " / ".join(f"{x['roofline']['avg_launch_ms']:.2f}" for x in cs) + " ms", "",
+        " / ".join(f"{x['roofline']['frac']:.3f}" for x in cs), "`r2_bench_colshard_n*.json`")
+    f8, fl = line("r2_bench_f64_8192.json"), line("r2_bench_f64_long_65536.json")
+    add("Float64: 8192 × 2^20 / long columns 65536 × 131072", f"{f8['value']:.1f} / {fl['value']:.1f}",
+        f"{f8['roofline']['avg_launch_ms']:.2f} / {fl['roofline']['avg_launch_ms']:.2f} ms", f"{tb(f8['roofline']):.2f} / {tb(fl['roofline']):.2f} TB/s",
+        f"{f8['roofline']['frac']:.3f} / {fl['roofline']['frac']:.3f}", "`r2_bench_f64_*.json`")
+    cb = d["cpu_baseline"]
+    add("CPU restatement, same 64 GiB matrix on the box's 64 cores / one BLAS thread (measured on the full matrix)",
+        f"{cb['value']:.2f} / {cb['value_1thread']:.2f}", "", "", "", "`cpu_baseline` of the line")
+    head = (f"streaming-read ceiling of the same box (`r2_stream_ceiling.log`): {ceiling:.2f} TB/s — the headline sweep is at "
+            f"{tb(r) / ceiling:.2f} of it, long columns {tb(lf['roofline']) / ceiling:.2f}, 2048-row columns {tb(sh[0]['roofline']) / ceiling:.2f}, "
+            f"config 2 {tb(c2['roofline']) / ceiling:.2f}" if ceiling else "")
+    text = head + "\n\n" + "\n".join(rows) + "\n"
+    if "--apply" in sys.argv:
+        path = os.path.join(ROOT, "DESIGN.md")
+        s = open(path).read()
+        b, e = "<!-- measured:begin -->\n", "<!-- measured:end -->\n"
+        i, j = s.index(b) + len(b), s.index(e)
+        open(path, "w").write(s[:i] + text + s[j:])
     else:
-        print(f"also {a['label']:15s}:", ffb(a))
-for f in ("config2", "long_131072", "long_131072_adaptive", "long_65536", "short_4096", "short_2048", "short_1024", "short_512x4M",
-          "short_512", "colshard_n524288", "colshard_n262144", "colshard_n131072", "f64_8192", "f64_long_65536"):
-    print(f"{f:20s}:", ffb(line(f"r2_bench_{f}.json")))
-p = line("r2_bench_panoc.json")
-print("panoc standalone    :", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items() if not isinstance(v, (dict, list))})
+        print(text)
+
+
+if __name__ == "__main__":
+    main()
