@@ -8,22 +8,22 @@ mkdir -p $O
 # the driver's command: headline + also[] (adaptive, configs 2 / 3 / 4) + CPU leg
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 # per-kernel durations of the same command (HIP-event timing in the line must agree)
-rocprofv3 --kernel-trace --stats -d $O/prof_default -- python3 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_default.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_default -- python3 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 > $O/prof_default.log 2>&1
 # the headline alone (kernel averages of this run are directly comparable with roofline.avg_launch_ms in its line)
-rocprofv3 --kernel-trace --stats -d $O/prof_headline -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-also > $O/prof_headline.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_headline -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --sustain 0 --no-also > $O/prof_headline.log 2>&1
 python bench.py --workload config2 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_config2.json 2>/dev/null
 python bench.py --m 8192 --n $((1<<20)) --dtype f64 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_f64_8192.json 2>/dev/null
 python bench.py --m 65536 --n 131072 --dtype f64 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_f64_long_65536.json 2>/dev/null
 # HBM traffic of the headline sweep kernel
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/prof_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/prof_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_write.log 2>&1
 # long columns (teams of workgroups): BASELINE config 5's per-GPU block under column shards, and 65536 rows
 python bench.py --m 131072 --n 131072 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_long_131072.json 2>/dev/null
 python bench.py --m 65536 --n 262144 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_long_65536.json 2>/dev/null
 python bench.py --m 131072 --n 131072 --mode adaptive --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_long_131072_adaptive.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d $O/prof_long -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/prof_long.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_long_fetch -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/prof_long_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_long_write -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --no-also > $O/prof_long_write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_long -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_long_fetch -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_long_write -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long_write.log 2>&1
 # short columns (one wave per column group): the per-GPU shapes of north_star's row layout at N = 8 and below
 for m in 4096 2048 1024 512; do python bench.py --m $m --n $((1<<20)) --steps 30 --warmup 5 --no-cpu-baseline --no-also > $O/bench_short_$m.json 2>/dev/null; done
 python bench.py --m 512 --n $((1<<22)) --steps 30 --warmup 5 --no-cpu-baseline --no-also > $O/bench_short_512x4M.json 2>/dev/null

@@ -9,22 +9,22 @@ for f in default config2 long_131072 long_131072_adaptive long_65536 short_4096 
   cp $O/bench_$f.json $P/r2_bench_$f.json
 done
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline: the driver's command incl. also[] (headline fixed + adaptive: gemv_tn<16,2,4>; config 2: gemv_tn<4,8,8>; config 3: DRStepF / dr_block_kernel; config 4: gemv_n_partial + gemv_tn + AxpyDotF)"
+  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0: the driver's command incl. also[] (headline fixed + adaptive: gemv_tn<16,2,4>; config 2: gemv_tn<4,8,8>; config 3: DRStepF / dr_block_kernel; config 4: gemv_n_partial + gemv_tn + AxpyDotF)"
   line $O/prof_default.log; echo
   cat $O/prof_default.md
 } > $P/r2_default_kernel_stats.md
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-also (headline only)"
+  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --sustain 0 --no-also (headline only)"
   echo "# the run's own JSON line (HIP-event timing, to compare with the gemv_tn row below):"
   line $O/prof_headline.log; echo
   cat $O/prof_headline.md
 } > $P/r2_headline_kernel_stats.md
 {
-  echo "# headline 16384 x 2^20 f32, gemv_tn<16,2,4>: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also"
+  echo "# headline 16384 x 2^20 f32, gemv_tn<16,2,4>: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also"
   cat $O/prof_fetch.md $O/prof_write.md
 } > $P/r2_headline_pmc_fetch_write.md
 {
-  echo "# 131072 x 131072 f32 (teams of workgroups, gemv_tnt): rocprofv3 --kernel-trace --stats, then separate --pmc FETCH_SIZE / WRITE_SIZE passes; bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --no-also"
+  echo "# 131072 x 131072 f32 (teams of workgroups, gemv_tnt): rocprofv3 --kernel-trace --stats, then separate --pmc FETCH_SIZE / WRITE_SIZE passes; bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also"
   line $O/prof_long.log; echo
   cat $O/prof_long.md $O/prof_long_fetch.md $O/prof_long_write.md
 } > $P/r2_long_columns_stats_and_pmc.md
