@@ -706,7 +706,7 @@ def _host_can_hold(nbytes):
         return False
 
 
-def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol):
+def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol, g="l1"):
     """FastForwardBackward on the device (single-sweep engine) against oracle.FastForwardBackwardIteration
     (fast_forward_backward.jl:73-145 restated) on the SAME matrix -- generated on the device, downloaded for the oracle.
     SURVEY 8(c): fixed step: ||z_k^gpu - z_k^cpu||_inf <= z_tol max(1, ||z_k||_inf) for every k, f_x and gamma equal to
@@ -735,27 +735,37 @@ def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol):
     A, b = A_d.numpy(), b_d.numpy()
     x0 = np.zeros(n, dtype)
     eps = np.finfo(dtype).eps
+    f_at_zero = 0.5 * float(b.astype(np.float64) @ b.astype(np.float64))
+
+    if g == "box":  # IndBox (forward_backward.jl:118 with the clamp of test_nonconvex_qp.jl:33-34): most entries end on a bound
+        bound = dtype(0.5) * dtype(np.max(np.abs(x_true)))
+        g_d, g_o, gscale = pa.IndBox(-bound, bound), o.IndBox(-bound, bound), 0.0
+    else:
+        g_d, g_o, gscale = pa.NormL1(lam), o.NormL1(lam), float(lam)
 
     def objective64(z):
         nz = np.flatnonzero(z)
         r = A[:, nz].astype(np.float64) @ z[nz].astype(np.float64) - b.astype(np.float64)
-        return 0.5 * float(r @ r) + float(lam) * float(np.sum(np.abs(z.astype(np.float64))))
+        return 0.5 * float(r @ r) + gscale * float(np.sum(np.abs(z.astype(np.float64))))
 
-    it_g = pa.FastForwardBackwardIteration(f=f_d, g=pa.NormL1(lam), x0=x0, Lf=Lf)
-    it_c = o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0, Lf=Lf)
+    it_g = pa.FastForwardBackwardIteration(f=f_d, g=g_d, x0=x0, Lf=Lf)
+    it_c = o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=g_o, x0=x0, Lf=Lf)
     for kk, (sg, sc) in enumerate(itertools.islice(zip(it_g, it_c), fixed_its), start=1):
         zg, zc = sg.z.numpy(), sc.z
         assert np.max(np.abs(zg - zc)) <= z_tol * max(1.0, float(np.max(np.abs(zc)))), (m, n, kk)
         assert float(sg.gamma) == float(sc.gamma)
-        assert float(sg.f_x) == pytest.approx(float(sc.f_x), rel=200 * eps), (m, n, kk)
+        # f = ||A x - b||^2 / 2 carries the rounding of A x (relative to ||b||) through the residual: to first order
+        # |df| <= ||r|| ||dr|| ~ eps sqrt(2 f) sqrt(2 f0), which is eps f when the fit is loose and more when A x ~ b (IndBox)
+        f_c = float(sc.f_x)
+        assert abs(float(sg.f_x) - f_c) <= 200 * eps * max(f_c, np.sqrt(f_c * f_at_zero)), (m, n, kk, float(sg.f_x), f_c)
         assert float(sg.res_inf) == pytest.approx(float(np.max(np.abs(sc.res))), rel=1e-3, abs=z_tol), (m, n, kk)
     assert it_g.counters["a_passes"] <= fixed_its + 3  # one read of A per iteration (+ init)
     Fg, Fc = objective64(zg), objective64(zc)
-    assert abs(Fg - Fc) <= 1e-6 * abs(Fc), (Fg, Fc)
+    assert abs(Fg - Fc) <= 1e-6 * max(abs(Fc), 1e-3 * f_at_zero), (Fg, Fc)  # (an objective driven to ~0 is compared on the scale of F(0))
     assert np.array_equal(zg != 0, zc != 0) or np.count_nonzero((zg != 0) != (zc != 0)) <= max(2, n // 100000)
     if adaptive_its:
-        it_g = pa.FastForwardBackwardIteration(f=f_d, g=pa.NormL1(lam), x0=x0)
-        it_c = o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0)
+        it_g = pa.FastForwardBackwardIteration(f=f_d, g=g_d, x0=x0)
+        it_c = o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=g_o, x0=x0)
         gam_g, gam_c = [], []
         for sg, sc in itertools.islice(zip(it_g, it_c), adaptive_its):
             gam_g.append(float(sg.gamma))
@@ -763,7 +773,7 @@ def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol):
         # identical backtracking decisions (the initial estimate may differ in the last bits: it is a norm)
         assert np.allclose(gam_g, gam_c, rtol=50 * eps, atol=0), (gam_g, gam_c)
         Fg, Fc = objective64(sg.z.numpy()), objective64(sc.z)
-        assert abs(Fg - Fc) <= 1e-6 * abs(Fc), (Fg, Fc)
+        assert abs(Fg - Fc) <= 1e-6 * max(abs(Fc), 1e-3 * f_at_zero), (Fg, Fc)  # (an objective driven to ~0 is compared on the scale of F(0))
 
 
 @pytest.mark.parametrize("m,n,what", [
@@ -778,6 +788,13 @@ def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol):
 ])
 def test_sweep_kernels_steady_state_iterates_match_oracle(pa, m, n, what):
     _ffb_device_vs_oracle(pa, m, n, np.float32, fixed_its=20, adaptive_its=8, z_tol=1e-5)
+
+
+@pytest.mark.parametrize("m,n", [(16384, 65536), (2048, 262144), (131072, 4096)])
+def test_sweep_kernels_steady_state_indbox(pa, m, n):
+    """The same comparison with g = IndBox (the other prox of the path): one workgroup, one wave and the
+    team kernel."""
+    _ffb_device_vs_oracle(pa, m, n, np.float32, fixed_its=20, adaptive_its=8, z_tol=1e-5, g="box")
 
 
 def test_sweep_kernels_steady_state_float64(pa):
