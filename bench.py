@@ -682,8 +682,8 @@ def main():
     if not D.sharded:
         layout = "none"
     named = args.workload if (args.m is None and args.n is None) else None
-    if (m_glob, n) == (131072, 131072) and world == 1:
-        named = "long_columns"  # the shape the PMC passes of the team sweep were taken on (profiles/pmc_traffic.json)
+    if world == 1:  # the shapes further PMC passes were taken on (profiles/pmc_traffic.json)
+        named = {(131072, 131072): "long_columns", (2048, 1 << 20): "short_columns"}.get((m_glob, n), named)
 
     if args.sustain is None:
         args.sustain = 5.0 if (named == "headline" and world == 1 and not args.force_comm) else 0.0
@@ -709,7 +709,7 @@ def main():
         within = lambda: time.perf_counter() - t_also < args.also_budget
         if within():
             P2 = setup_lasso(pa, ctx, D, *WORKLOADS["config2"], dtype, args.seed, "none", "fixed")
-            r = run_ffb(pa, ctx, D, P2, "fixed", "one", max(sub_steps, 50), 5, args.kernel_events)
+            r = run_ffb(pa, ctx, D, P2, "fixed", "one", max(sub_steps, 50), 5, args.kernel_events, workload_name="config2")
             r["label"] = "config2"
             also.append(r)
             P2 = None
@@ -723,9 +723,9 @@ def main():
         for label, (mm, nn) in (("config5_column_block", (131072, 131072)), ("headline_row_block_n8", (2048, 1 << 20))):
             if within():
                 P2 = setup_lasso(pa, ctx, D, mm, nn, dtype, args.seed, "none", "fixed")
-                # the PMC passes of the long-column sweep were taken on exactly this shape (profiles/pmc_traffic.json)
+                # the PMC passes of these two sweeps were taken on exactly these shapes (profiles/pmc_traffic.json)
                 r = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events,
-                            workload_name="long_columns" if mm == 131072 and dtype == np.float32 else None)
+                            workload_name="long_columns" if mm == 131072 else "short_columns")
                 r["label"] = label
                 also.append(r)
                 P2 = None

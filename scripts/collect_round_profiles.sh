@@ -24,6 +24,11 @@ python bench.py --m 131072 --n 131072 --mode adaptive --steps 20 --warmup 3 --no
 rocprofv3 --kernel-trace --stats -d $O/prof_long -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_long_fetch -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_long_write -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long_write.log 2>&1
+# HBM traffic of config 2's sweep (gemv_tn<4,8,8>) and of the short-column sweep (gemv_tnw, 2048 x 2^20)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_c2_fetch -- python3 bench.py --workload config2 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_c2_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_c2_write -- python3 bench.py --workload config2 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_c2_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_short_fetch -- python3 bench.py --m 2048 --n 1048576 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_short_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_short_write -- python3 bench.py --m 2048 --n 1048576 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_short_write.log 2>&1
 # short columns (one wave per column group): the per-GPU shapes of north_star's row layout at N = 8 and below
 for m in 4096 2048 1024 512; do python bench.py --m $m --n $((1<<20)) --steps 30 --warmup 5 --no-cpu-baseline --no-also > $O/bench_short_$m.json 2>/dev/null; done
 python bench.py --m 512 --n $((1<<22)) --steps 30 --warmup 5 --no-cpu-baseline --no-also > $O/bench_short_512x4M.json 2>/dev/null
@@ -37,7 +42,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_dr_write -- python3 tests/t
 python scripts/bench_panoc.py > $O/bench_panoc.json 2>/dev/null
 # the device's streaming-read ceiling on the same box (grid-stride and the sweeps' wave-contiguous runs), 64 GiB
 hipcc -O3 --offload-arch=gfx950 scripts/stream_ceiling.hip -o /tmp/stream_ceiling && /tmp/stream_ceiling 64 > $O/stream_ceiling.log 2>&1
-for d in prof_default prof_headline prof_fetch prof_write prof_long prof_long_fetch prof_long_write prof_dr_valu prof_dr_fetch prof_dr_write; do python scripts/rocpd_summary.py $O/$d/*/*_results.db > $O/$d.md 2>&1; done
+for d in prof_default prof_headline prof_fetch prof_write prof_long prof_long_fetch prof_long_write prof_dr_valu prof_dr_fetch prof_dr_write prof_c2_fetch prof_c2_write prof_short_fetch prof_short_write; do python scripts/rocpd_summary.py $O/$d/*/*_results.db > $O/$d.md 2>&1; done
 cp $O/prof_fetch/*/*_results.db $O/fetch.db; cp $O/prof_write/*/*_results.db $O/write.db
 cp $O/prof_long_fetch/*/*_results.db $O/long_fetch.db; cp $O/prof_long_write/*/*_results.db $O/long_write.db
+cp $O/prof_c2_fetch/*/*_results.db $O/c2_fetch.db; cp $O/prof_c2_write/*/*_results.db $O/c2_write.db
+cp $O/prof_short_fetch/*/*_results.db $O/short_fetch.db; cp $O/prof_short_write/*/*_results.db $O/short_write.db
 ls -la $O

@@ -32,6 +32,12 @@ done
   echo "# Douglas-Rachford kernels (tests/tools/bench_dr.py --no-cpu-baseline --steps 64): rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES, then FETCH_SIZE and WRITE_SIZE passes"
   cat $O/prof_dr_valu.md $O/prof_dr_fetch.md $O/prof_dr_write.md
 } > $P/r2_dr_counters.md
+{
+  echo "# config 2 (8192 x 262144, gemv_tn<4,8,8>) and short columns (2048 x 2^20, gemv_tnw): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bench.py --workload config2 | --m 2048 --n 1048576, --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also"
+  cat $O/prof_c2_fetch.md $O/prof_c2_write.md $O/prof_short_fetch.md $O/prof_short_write.md
+} > $P/r2_config2_short_columns_pmc.md
+python scripts/pmc_to_traffic.py config2 $O/c2_fetch.db $O/c2_write.db profiles/r2_config2_short_columns_pmc.md > /dev/null
+python scripts/pmc_to_traffic.py short_columns $O/short_fetch.db $O/short_write.db profiles/r2_config2_short_columns_pmc.md > /dev/null
 grep -v amdgpu.ids $O/stream_ceiling.log > $P/r2_stream_ceiling.log
 python scripts/pmc_to_traffic.py headline $O/fetch.db $O/write.db profiles/r2_headline_pmc_fetch_write.md > /dev/null
 python scripts/pmc_to_traffic.py long_columns $O/long_fetch.db $O/long_write.db profiles/r2_long_columns_stats_and_pmc.md > /dev/null
