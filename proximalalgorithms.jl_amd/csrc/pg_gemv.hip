@@ -209,6 +209,8 @@ constexpr int PG_TN_WAVE_MAX_RG = 8;
 // Interleaved A/B, five rounds (profiles/r2_tune_tn_mid_columns.log): 17 / 20 / 24 row groups 7.03 / 6.83 / 6.96 TB/s against
 // 6.27 / 6.53 / 6.88 for gemv_tn; level at 28 and 32 (the same shape re-allocated moves by 3 %: no finer cut than this)
 constexpr int PG_TN_COOP_MAX_RG = 24;
+// 33 .. this many: one four-wave "team" member per column group with U instantiated exactly (gemv_tnt_kernel, TM = 1)
+constexpr int PG_TN_TEAM1_MAX_RG = 44;
 
 // ----------------------------------------------------------------------------------------------
 // host-side launch planning
@@ -490,6 +492,10 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
     if (nrg <= PG_TN_WAVE_MAX_RG && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
     if (nrg > PG_TN_WAVE_MAX_RG && nrg <= PG_TN_COOP_MAX_RG && tn_coop_covers(nrg)) return launch_tn_coop<T>(A, a, blocks_out);
+    // 33..44 row groups (8448..11264 rows f32) fill the four-wave U = 16 geometry to 52-69 %: a single-member "team"
+    // instantiated for U = ceil(nrg / 4) exactly (9..11) wastes nothing -- 9000 / 10000 rows 6.05 / 6.10 TB/s against
+    // 5.50 / 5.92; level from 47 row groups on (profiles/r2_tune_tn_odd_rows.log)
+    if (nrg > 32 && nrg <= PG_TN_TEAM1_MAX_RG) return launch_tn_team<T>(A, a, blocks_out);
   }
   if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
   // 17..32 row groups (m = 8192 in Float32): eight waves of U = 4 with C = 8 columns per step measured 4 % faster than four

@@ -470,17 +470,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   const int npoll = TM * C * G;
   const int64_t ncg = (a.n + C - 1) / C;
   const int64_t cnt = ncg > team ? (ncg - team + a.nteams - 1) / a.nteams : 0;
-  const int rg0 = (member * WAVES + wave) * U;  // this wave's first row group: a contiguous run of U KiB of each column
+  const int rg0 = (member * WAVES + wave) * a.ueff;  // this wave's first row group: a contiguous run of ueff <= U KiB of each column
   unsigned long long* const ring = a.xch + (size_t)team * TEAM_RING * (size_t)(TEAM_MAX * C * G);
 
   V rk[U], racc[U];
   int rgc[U];  // row groups past the end of the column are clamped to the last one; their r is zero
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    rgc[u] = min(rg0 + u, a.nrg - 1);
+    rgc[u] = min(rg0 + min(u, a.ueff - 1), a.nrg - 1);  // past the run: the wave's own last row group again (a cached load)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
-    if (rg0 + u < a.nrg) {
+    if (u < a.ueff && rg0 + u < a.nrg) {
       rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)(rg0 + u) * (WAVE * VEC) + lane * VEC);
     } else {
 #pragma unroll
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   T* part = a.partials + (int64_t)team * a.ld + lane * VEC;
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    if (rg0 + u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)(rg0 + u) * (WAVE * VEC)) = racc[u];
+    if (u < a.ueff && rg0 + u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)(rg0 + u) * (WAVE * VEC)) = racc[u];
   const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
   grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
 }
@@ -751,7 +751,11 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   constexpr int G = (int)sizeof(T) / 4;
   const int64_t ncg = (A->n + C - 1) / C;
-  const int per_member = U * WAVES;
+  // Four-wave members hold up to 64 row groups; the rows are dealt evenly over the team's waves (ueff each) and the kernel
+  // is instantiated for U = ueff exactly (9..16), so that a column length that only partly fills the last member costs
+  // neither idle workgroups nor repeated loads: 50000 rows are 4 members x 4 waves x 13 row groups, not 3 full members + 4
+  // row groups.  (Eight-wave geometries, kept for the tuning sweeps: U row groups per wave, filled in order.)
+  const int per_member = WAVES == 4 ? TEAM_MEMBER_RG : U * WAVES;
   int TM = (a.nrg + per_member - 1) / per_member;
   if (env_int("PG_TN_TEAM", 0) > TM) TM = env_int("PG_TN_TEAM", 0);  // experiments: more (partly idle) members
   if (TM < 1) TM = 1;
@@ -786,6 +790,11 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TRY(ensure_partials(A, (int)nteams));
   a.partials = (T*)A->partials;
   a.team_size = TM;
+  a.ueff = WAVES == 4 ? (a.nrg + TM * WAVES - 1) / (TM * WAVES) : U;
+  if (a.ueff > U) {
+    pg_set_error("gemv_tnt<U = %d> launched for %d row groups per wave", U, a.ueff);
+    return PG_ERR_INVALID;
+  }
   a.nteams = (int)nteams;
   a.xch = (unsigned long long*)A->xch;
   a.team_err = c->dscal + PG_S_TEAMERR;
@@ -905,13 +914,28 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // U = 8 (the same rows per member, half the bytes per wave and step): 6.73-6.75 / 6.41-6.56; eight waves of U = 4 with
   // two columns per step: 6.20 / 6.79-6.81; LAG = 1: 5.05-5.61, LAG = 0: 4.62-5.49 TB/s (profiles/r2_tune_tn_team.log).
   const int W = env_int("PG_TNT_WAVES", 4);
-  const int U = env_int("PG_TNT_U", W == 4 ? 16 : 8);
+  int U = env_int("PG_TNT_U", W == 4 ? 0 : 8);
+  if (U == 0) {  // four-wave members: the smallest instantiation that holds the even deal
+    int TM = (a.nrg + TEAM_MEMBER_RG - 1) / TEAM_MEMBER_RG;
+    if (env_int("PG_TN_TEAM", 0) > TM) TM = env_int("PG_TN_TEAM", 0);
+    U = (a.nrg + TM * 4 - 1) / (TM * 4);
+    if (U < 8) U = 8;
+    if (U > 16) U = 16;  // (more than 16 members' worth of rows: launch_tnt reports it)
+  }
   const int C = env_int("PG_TNT_C", U == 4 ? 2 : 1), LAG = env_int("PG_TNT_LAG", 2);
   // tiles in flight ahead of the one being consumed
   const int PF = env_int("PG_TNT_PF", U == 4 ? 1 : 2);
 #define PG_TNT_CASE(UU, CC, LL, PP, WW) \
   if (U == UU && C == CC && LAG == LL && PF == PP && W == WW) return launch_tnt<T, UU, CC, LL, PP, WW>(A, a, blocks_out)
   PG_TNT_CASE(16, 1, 2, 2, 4);
+  PG_TNT_CASE(15, 1, 2, 2, 4);
+  PG_TNT_CASE(14, 1, 2, 2, 4);
+  PG_TNT_CASE(13, 1, 2, 2, 4);
+  PG_TNT_CASE(12, 1, 2, 2, 4);
+  PG_TNT_CASE(11, 1, 2, 2, 4);
+  PG_TNT_CASE(10, 1, 2, 2, 4);
+  PG_TNT_CASE(9, 1, 2, 2, 4);
+  PG_TNT_CASE(8, 1, 2, 2, 4);
   PG_TNT_CASE(16, 1, 2, 1, 4);
   PG_TNT_CASE(16, 1, 1, 2, 4);
   PG_TNT_CASE(16, 1, 0, 2, 4);

@@ -214,8 +214,10 @@ def cmd_ab(shapes):
             cands += [(f"coop C={C} db={db}", coop(C, db)) for C in ((8, 16) if nrg <= 16 else (4, 8)) for db in (0, 1)]
         if 17 <= nrg <= 32:
             cands += [(f"wg W=4 C={C}", dict(PG_TN_KERNEL="wg", PG_TN_WAVES="4", PG_TN_C=str(C))) for C in (2, 4)]
-        if nrg > 64:
-            cands += [("team", dict(PG_TN_KERNEL="team")), ("team PF=1", dict(PG_TN_KERNEL="team", PG_TNT_PF="1"))]
+        if nrg > 32:
+            cands += [("team", dict(PG_TN_KERNEL="team"))]
+        if nrg > 64 and nrg % 64 == 0:
+            cands += [("team PF=1", dict(PG_TN_KERNEL="team", PG_TNT_PF="1"))]
         got = {k: [] for k, _ in cands}
         for _ in range(5):
             for k, env in cands:

@@ -785,6 +785,8 @@ def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol, g="l1
     (512, 1 << 20, "gemv_tnw<2,16>: short columns, double-buffered waves"),
     (65536, 8192, "gemv_tnt: teams of 4 workgroups, 128 steps per team with the two-step lag"),
     (131072, 4096, "gemv_tnt: teams of 8 workgroups, BASELINE config 5's per-GPU column length"),
+    (50000, 8192, "gemv_tnt<U = 13>: 196 row groups dealt evenly over 4 members x 4 waves (a column length that fills no power of two)"),
+    (10000, 32768, "gemv_tnt<U = 10>, one member per column group: 40 row groups"),
 ])
 def test_sweep_kernels_steady_state_iterates_match_oracle(pa, m, n, what):
     _ffb_device_vs_oracle(pa, m, n, np.float32, fixed_its=20, adaptive_its=8, z_tol=1e-5)
@@ -799,7 +801,8 @@ def test_sweep_kernels_steady_state_indbox(pa, m, n):
 
 def test_sweep_kernels_steady_state_float64(pa):
     # one workgroup / one wave / teams / waves sharing the column group with the lane-parallel epilogue (U = 2 and U = 4)
-    for (m, n) in ((8192, 16384), (1024, 131072), (32768, 4096), (2048, 65536), (2560, 32768)):
+    # ... and an odd team length (25000 rows = 196 row groups: U = 13)
+    for (m, n) in ((8192, 16384), (1024, 131072), (32768, 4096), (2048, 65536), (2560, 32768), (25000, 4096)):
         _ffb_device_vs_oracle(pa, m, n, np.float64, fixed_its=12, adaptive_its=6, z_tol=1e-11)
 
 
@@ -1684,8 +1687,10 @@ def test_fused_single_sweep_pass_matches_separate_kernels(pa, dtype, gname):
     shapes = [(1, 1), (5, 3), (200, 500), (256, 64), (257, 65), (1000, 33), (4096, 40), (4097, 130), (8192, 70), (16384, 24), (20000, 9)]
     # one wave per column group (<= 8 row groups), one workgroup (<= 128), teams of workgroups beyond (pg_gemv_tn2.hip)
     # (the last two of each list: ragged and full teams of 16, the longest columns the sweep takes)
-    shapes += [(511, 700), (2048, 333), (5000, 77), (32768, 5), (32769, 7), (65536, 40), (131072, 24), (200000, 5), (262144, 6)] \
-        if dtype == np.float32 else [(1024, 333), (2500, 77), (16385, 4), (40000, 11), (65536, 24), (100000, 5), (131072, 6)]
+    # (9000 / 10000 f32 rows, 4500 f64 rows: 33..44 row groups, the single-member team with U instantiated exactly)
+    shapes += [(511, 700), (2048, 333), (5000, 77), (9000, 50), (10000, 300), (32768, 5), (32769, 7), (65536, 40), (131072, 24),
+               (200000, 5), (262144, 6)] \
+        if dtype == np.float32 else [(1024, 333), (2500, 77), (4500, 50), (16385, 4), (40000, 11), (65536, 24), (100000, 5), (131072, 6)]
     for (m, n) in shapes:
         A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
         b = rng.standard_normal(m).astype(dtype)
