@@ -20,6 +20,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write -- python3 bench.py -
 # long columns (teams of workgroups): BASELINE config 5's per-GPU block under column shards, and 65536 rows
 python bench.py --m 131072 --n 131072 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_long_131072.json 2>/dev/null
 python bench.py --m 65536 --n 262144 --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_long_65536.json 2>/dev/null
+# column lengths that fill no power of two: exact-U team members (50000, 100000 rows) and the single-member team (10000 rows)
+python bench.py --m 50000 --n 84000 --steps 30 --warmup 5 --no-cpu-baseline --no-also > $O/bench_odd_50000.json 2>/dev/null
+python bench.py --m 100000 --n 84000 --steps 30 --warmup 5 --no-cpu-baseline --no-also > $O/bench_odd_100000.json 2>/dev/null
+python bench.py --m 10000 --n 420000 --steps 30 --warmup 5 --no-cpu-baseline --no-also > $O/bench_odd_10000.json 2>/dev/null
 python bench.py --m 131072 --n 131072 --mode adaptive --steps 20 --warmup 3 --no-cpu-baseline --no-also > $O/bench_long_131072_adaptive.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $O/prof_long -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_long_fetch -- python3 bench.py --m 131072 --n 131072 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also > $O/prof_long_fetch.log 2>&1

@@ -65,6 +65,11 @@ def main():
         "`r2_bench_long_131072*.json`, `also[4]`")
     add("long columns 65536 × 262144", f"{l6['value']:.1f}", f"`gemv_tnt<16,1,4,2,2>` {l6['roofline']['avg_launch_ms']:.2f} ms", f"{tb(l6['roofline']):.2f} TB/s",
         f"{l6['roofline']['frac']:.3f}", "`r2_bench_long_65536.json`")
+    od = [line(f"r2_bench_odd_{k}.json") for k in ("50000", "100000", "10000")]
+    add("column lengths that fill no power of two: 50000 × 84000 / 100000 × 84000 (exact-`U` team members) / 10000 × 420000 (single-member team)",
+        " / ".join(f"{x['value']:.0f}" for x in od), "`gemv_tnt<13 | 13 | 10,…>` " + " / ".join(f"{x['roofline']['avg_launch_ms']:.2f}" for x in od) + " ms",
+        " / ".join(f"{tb(x['roofline']):.2f}" for x in od) + " TB/s", " / ".join(f"{x['roofline']['frac']:.3f}" for x in od) + " (before: 0.74 / 0.79 / 0.74)",
+        "`r2_bench_odd_*.json`, `r2_tune_tn_odd_rows.log`")
     sh = [line(f"r2_bench_short_{k}.json") for k in ("2048", "1024", "512x4M", "512")]
     add("short columns 2048 × 2^20 / 1024 × 2^20 / 512 × 2^22 / 512 × 2^20 (row-shard shapes of N = 8 and below)",
         " / ".join(f"{x['value']:.0f}" for x in sh), "`gemv_tnw` " + " / ".join(f"{x['roofline']['avg_launch_ms']:.3f}" for x in sh) + " ms",
