@@ -67,7 +67,7 @@ def main():
         f"{l6['roofline']['frac']:.3f}", "`r2_bench_long_65536.json`")
     od = [line(f"r2_bench_odd_{k}.json") for k in ("50000", "100000", "10000")]
     add("column lengths that fill no power of two: 50000 × 84000 / 100000 × 84000 (exact-`U` team members) / 10000 × 420000 (single-member team)",
-        " / ".join(f"{x['value']:.0f}" for x in od), "`gemv_tnt<13 | 13 | 10,…>` " + " / ".join(f"{x['roofline']['avg_launch_ms']:.2f}" for x in od) + " ms",
+        " / ".join(f"{x['value']:.0f}" for x in od), "`gemv_tnt`, `U` = 13 / 14 / 10: " + " / ".join(f"{x['roofline']['avg_launch_ms']:.2f}" for x in od) + " ms",
         " / ".join(f"{tb(x['roofline']):.2f}" for x in od) + " TB/s", " / ".join(f"{x['roofline']['frac']:.3f}" for x in od) + " (before: 0.74 / 0.79 / 0.74)",
         "`r2_bench_odd_*.json`, `r2_tune_tn_odd_rows.log`")
     sh = [line(f"r2_bench_short_{k}.json") for k in ("2048", "1024", "512x4M", "512")]
