@@ -216,3 +216,17 @@ def test_iteration_tools():
         time.sleep(0.02)
     with pytest.raises(TypeError):
         IterationTools.loop([])
+
+
+def test_design_table_matches_the_committed_bench_lines():
+    """DESIGN.md's "Measured (round 2)" block is generated from the bench lines under profiles/ (scripts/design_table.py):
+    the committed block must be what the committed lines produce."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_table.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    b, e = "<!-- measured:begin -->\n", "<!-- measured:end -->\n"
+    block = text[text.index(b) + len(b):text.index(e)]
+    assert block.strip() == out.stdout.strip()
