@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test: the GPU engine (every form of the driver loop) against the CPU restatement on random
 small / mid-size LASSO-type problems.  Usage: python tests/tools/fuzz_parity.py [cases] [first_seed] [tall].  Prints one
-line per failing case and a summary; exit code 1 if anything failed.  `tall`: column lengths from 600 to 140000 rows with few
+line per failing case and a summary; exit code 1 if anything failed.  `tall`: column lengths from 600 to 150000 rows (a fixed list of boundary lengths, or uniformly drawn) with few
 columns, so that every geometry of the single sweep is drawn (one wave per column group, shared workgroups, teams of
 workgroups -- csrc/pg_gemv_tn2.hip); the persistent small-problem kernels are skipped there."""
 import os
@@ -32,6 +32,8 @@ def one_case(seed):
     n = int(rng.choice([1, 3, 16, 17, 255, 500, 1025])) if rng.random() < 0.4 else int(rng.integers(1, 900))
     if TALL:
         m = int(rng.choice([600, 1025, 2048, 2305, 4096, 4100, 8192, 16384, 20000, 32768, 32769, 40000, 65536, 70001, 131072, 140000]))
+        if rng.random() < 0.5:  # any column length: every U = 8..16 of the team kernel, single-member teams, ragged last row groups
+            m = int(rng.integers(2049, 150000))
         n = int(rng.choice([1, 2, 7, 33, 64, 130]))
     fast = bool(rng.random() < 0.6)
     mode = rng.choice(["fixed", "adaptive", "adaptive_regret"])
