@@ -552,7 +552,7 @@ def run_config3(pa, ctx, n=10_000_000, steps=200):
                        "roofline": {"bound": "hbm", "kernel": "dr_step", "avg_launch_ms": round(ms / cnt, 5),
                                     "algorithmic_bytes_per_launch": b5, "achieved": round(b5 / (ms / cnt * 1e-3) / 1e9, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b5 / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-    block = 32
+    block = 64
     nst = max(steps, 20 * block) // block * block
     itn = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
     itn.device_run(2 * block, 0.0, block)

@@ -279,7 +279,7 @@ pg_status pg_dr_step(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, void* y, vo
                      double g_p1, double gamma, double* scalars_out /* host, 3 doubles; NULL = no sync */);
 
 /* The DouglasRachford driver loop (src/ProximalAlgorithms.jl:114-123 with the default stop rule
- * norm(res, Inf) / gamma <= tol, douglas_rachford.jl:65-69, evaluated in T) inside the library.  With block = 8, 16 or 32
+ * norm(res, Inf) / gamma <= tol, douglas_rachford.jl:65-69, evaluated in T) inside the library.  With block = 8, 16, 32 or 64
  * that many iterations run per HBM sweep (f and g are separable, so the iterates of an element stay in registers;
  * the stop rule of every inner iteration is still evaluated and, when one of them fires, the block is replayed up to
  * it, so the state left behind is bit-identical to stepping with pg_dr_step).  block = 1 steps one by one.

@@ -64,13 +64,13 @@ enum {
   PG_S_DR = 8,       // Douglas-Rachford step: { ||res||_inf, f(y), g(z) }
   PG_S_FNEXT = 12,   // f at the speculative next point of the single-sweep iteration (2 slots, alternating)
   PG_S_TEAMERR = 14, // set to 1 by a workgroup team of the long-column sweep that gave up waiting for a member
-  PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 32 inner iterations, f(y), g(z) }
-  PG_S_DRRUN2 = 52,  // second set of the same (two blocks of pg_dr_run are in flight)
-  PG_S_COUNT = 88
+  PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 64 inner iterations, f(y), g(z) }
+  PG_S_DRRUN2 = 82,  // second set of the same (two blocks of pg_dr_run are in flight)
+  PG_S_COUNT = 148
 };
 
 constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize
-constexpr int PG_RED_MAX_NS = 34;
+constexpr int PG_RED_MAX_NS = 66;
 
 // RCCL communicator bound by pg_ctx_comm_init (csrc/pg_comm.hip)
 struct pg_comm {
@@ -272,6 +272,9 @@ __device__ __forceinline__ T pg_wave_allreduce(T v) {
 // (to all its threads) in the finalizing block only; out[] is then visible to that block's thread 0.
 // WAVE_REDUCED: v[] already holds the wave's values in lane 0 (the caller reduced within the wave, e.g. in working precision
 // with DPP moves); the fp64 shuffle stage is skipped.
+// slot k is a max when bit k of the mask is set; slots from 64 on are sums (the 64-iteration Douglas-Rachford block: 64 maxima + 2 sums)
+__host__ __device__ constexpr bool pg_red_is_max(unsigned long long mask, int k) { return k < 64 && ((mask >> k) & 1ull) != 0; }
+
 template <int NS, unsigned long long MAXMASK, int NW = 4, bool WAVE_REDUCED = false>
 __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __restrict__ partials,
                                                      unsigned* __restrict__ counter, double* __restrict__ out,
@@ -286,7 +289,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
         double o = pg_shfl_down(v[k], off);
-        v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
+        v[k] = pg_red_is_max(MAXMASK, k) ? fmax(v[k], o) : (v[k] + o);
       }
     }
   }
@@ -303,7 +306,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double a = sm[k];
-      for (int w = 1; w < NW; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      for (int w = 1; w < NW; ++w) a = pg_red_is_max(MAXMASK, k) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
       __hip_atomic_store(&partials[(size_t)blockIdx.x * NS + k], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -314,12 +317,12 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
   if (!sm_last) return false;
   double acc[NS];
 #pragma unroll
-  for (int k = 0; k < NS; ++k) acc[k] = ((MAXMASK >> k) & 1u) ? -INFINITY : 0.0;
+  for (int k = 0; k < NS; ++k) acc[k] = pg_red_is_max(MAXMASK, k) ? -INFINITY : 0.0;
   for (unsigned b = threadIdx.x; b < gridDim.x; b += NW * 64) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double p = __hip_atomic_load(&partials[(size_t)b * NS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      acc[k] = ((MAXMASK >> k) & 1u) ? fmax(acc[k], p) : (acc[k] + p);
+      acc[k] = pg_red_is_max(MAXMASK, k) ? fmax(acc[k], p) : (acc[k] + p);
     }
   }
 #pragma unroll
@@ -327,7 +330,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       double o = pg_shfl_down(acc[k], off);
-      acc[k] = ((MAXMASK >> k) & 1u) ? fmax(acc[k], o) : (acc[k] + o);
+      acc[k] = pg_red_is_max(MAXMASK, k) ? fmax(acc[k], o) : (acc[k] + o);
     }
   }
   __syncthreads();  // sm reuse
@@ -340,12 +343,85 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double a = sm[k];
-      for (int w = 1; w < NW; ++w) a = ((MAXMASK >> k) & 1u) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      for (int w = 1; w < NW; ++w) a = pg_red_is_max(MAXMASK, k) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
       out[k] = a * post_scale[k];
       if (final_vals != nullptr) final_vals[k] = a * post_scale[k];  // valid on thread 0 of the finalizing block
     }
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return true;  // every thread of the finalizing block
+}
+
+// The same protocol for MANY slots (the 32- and 64-iteration Douglas-Rachford blocks: K maxima + 2 sums) without holding
+// NS doubles per thread: grid_reduce_finalize keeps v[NS] and acc[NS] live (4 NS registers -- 270 at NS = 66, one wave per
+// SIMD for the whole kernel).  Here the caller hands over a functor that produces slot k's WAVE-reduced value (valid in lane
+// 0) on demand, and the finalizing block combines the partials eight slots at a time.  Same layout of `partials`, same ticket.
+template <int NS, unsigned long long MAXMASK, int NW, typename WaveVal>
+__device__ __forceinline__ bool grid_reduce_finalize_streamed(WaveVal wave_val, double* __restrict__ partials,
+                                                              unsigned* __restrict__ counter, double* __restrict__ out,
+                                                              double scale_last) {
+  constexpr int CH = 8;
+  __shared__ double sm[NW * NS];
+  __shared__ int sm_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double v = wave_val(k);
+    if (lane == 0) sm[wave * NS + k] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < NS; k += NW * 64) {  // one slot per thread: publish this workgroup's partial
+    const bool is_max = pg_red_is_max(MAXMASK, k);
+    double a = sm[k];
+    for (int w = 1; w < NW; ++w) a = is_max ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+    __hip_atomic_store(&partials[(size_t)blockIdx.x * NS + k], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // every publishing thread has drained its stores before the ticket is taken
+  if (threadIdx.x == 0) {
+    unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sm_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!sm_last) return false;
+  for (int k0 = 0; k0 < NS; k0 += CH) {
+    double acc[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) acc[q] = pg_red_is_max(MAXMASK, k0 + q) ? -INFINITY : 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += NW * 64) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        if (k0 + q < NS) {
+          const double p = __hip_atomic_load(&partials[(size_t)b * NS + k0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[q] = pg_red_is_max(MAXMASK, k0 + q) ? fmax(acc[q], p) : (acc[q] + p);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double o = pg_shfl_down(acc[q], off);
+        acc[q] = pg_red_is_max(MAXMASK, k0 + q) ? fmax(acc[q], o) : (acc[q] + o);
+      }
+    }
+    __syncthreads();  // sm reuse
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) sm[wave * CH + q] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < CH && k0 + (int)threadIdx.x < NS) {
+      const int k = k0 + threadIdx.x;
+      const bool is_max = pg_red_is_max(MAXMASK, k);
+      double a = sm[threadIdx.x];
+      for (int w = 1; w < NW; ++w) a = is_max ? fmax(a, sm[w * CH + threadIdx.x]) : (a + sm[w * CH + threadIdx.x]);
+      out[k] = k == NS - 1 ? a * scale_last : a;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
 }
 #endif  // __HIPCC__

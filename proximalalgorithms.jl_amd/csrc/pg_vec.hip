@@ -365,9 +365,27 @@ __device__ __forceinline__ DRBlockIn<T, N> dr_block_load(const DRBlockArgs<T, GK
   return in;
 }
 
-template <typename T, int GKIND, int K, int N>
+// The K running maxima of a thread: one working-precision register per inner iteration.
+template <typename T, int K>
+struct DRMaxRegs {
+  T mx[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < K; ++j) mx[j] = T(0);
+  }
+  __device__ __forceinline__ void fold(int j, T m) {
+    T v = fmax(mx[j], m);
+    // the empty asm pins the maximum HERE: left alone the compiler sinks the K max operations to the end of the sweep
+    // (their only use) and keeps every iteration's residuals alive for them -- 4 registers per iteration, 209 at K = 32
+    asm volatile("" : "+v"(v));
+    mx[j] = v;
+  }
+  __device__ __forceinline__ T get(int j) const { return mx[j]; }
+};
+
+template <typename T, int GKIND, int K, int N, typename MX>
 __device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>& a, int64_t i, const DRBlockIn<T, N>& in,
-                                                 T (&mx)[K], double& fy, double& gz) {
+                                                 MX& mx, double& fy, double& gz) {
 #pragma clang fp contract(off)
   Pack<T, N> xv = in.x, yv, rv, zv, sv, d = in.d, q = in.q;
   if constexpr (N >= 2) {
@@ -440,13 +458,10 @@ __device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>&
       for (int p = 0; p < NP; ++p) se[p] = ye[p] - ze[p];
 #pragma unroll
       for (int p = 0; p < NP; ++p) xe[p] = xe[p] - se[p];
-      T m = mx[j];
+      T m = fmax(fabs(se[0][0]), fabs(se[0][1]));
 #pragma unroll
-      for (int p = 0; p < NP; ++p) m = fmax(m, fmax(fabs(se[p][0]), fabs(se[p][1])));
-      // the empty asm pins the maximum HERE: left alone the compiler sinks the K max operations to the end of the sweep
-      // (their only use) and keeps every iteration's residuals alive for them -- 4 registers per iteration, 209 at K = 32
-      asm volatile("" : "+v"(m));
-      mx[j] = m;
+      for (int p = 1; p < NP; ++p) m = fmax(m, fmax(fabs(se[p][0]), fabs(se[p][1])));
+      mx.fold(j, m);
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -475,7 +490,7 @@ __device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>&
         ze = re;
       se = ye - ze;
       xe = xe - se;
-      mx[j] = fmax(mx[j], fabs(se));
+      mx.fold(j, fabs(se));
     }
     xv.v[0] = xe, yv.v[0] = ye, rv.v[0] = re, zv.v[0] = ze, sv.v[0] = se;
     fy += 0.5 * (double)de * (double)ye * (double)ye + (double)qe * (double)ye;
@@ -488,10 +503,14 @@ __device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>&
   if (a.res != nullptr) st_nt<T, N>(a.res, i, sv);
 }
 
-// 512-thread workgroups, two per CU: the K running maxima live in T registers over the whole sweep (they only become
-// doubles for the grid reduction), which keeps the K = 16 body free of scratch spills
+// 512-thread workgroups, two per CU, for every K: the K running maxima live in T registers over the whole sweep and are handed
+// to the grid reduction one at a time (grid_reduce_finalize_streamed; the array form kept 4 (K + 2) registers live at the end of
+// the kernel and forced 256-thread workgroups at K = 32: 125 us per block against 118 us now, K = 64: 218 us)
+#ifndef DR_BS
+#define DR_BS 512
+#endif
 template <int K>
-constexpr int dr_block_bs() { return K <= 16 ? 512 : 256; }  // K = 32: 32 running maxima per thread; 256-thread workgroups keep three per CU
+constexpr int dr_block_bs() { return DR_BS; }
 
 template <typename T, int GKIND, int K>
 __global__ __launch_bounds__(dr_block_bs<K>()) void dr_block_kernel(int64_t n, bool vec_ok, DRBlockArgs<T, GKIND, K> a,
@@ -499,11 +518,10 @@ __global__ __launch_bounds__(dr_block_bs<K>()) void dr_block_kernel(int64_t n, b
                                                                unsigned* __restrict__ red_counter,
                                                                double* __restrict__ out) {
   constexpr int VEC = VecOf<T>::N;
-  T mx[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) mx[j] = T(0);
-  double fy = 0.0, gz = 0.0;
   constexpr int DR_BLOCK_BS = dr_block_bs<K>();
+  DRMaxRegs<T, K> mx;
+  mx.init();
+  double fy = 0.0, gz = 0.0;
   const int64_t tid = (int64_t)blockIdx.x * DR_BLOCK_BS + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * DR_BLOCK_BS;
   if (vec_ok) {
@@ -536,12 +554,24 @@ __global__ __launch_bounds__(dr_block_bs<K>()) void dr_block_kernel(int64_t n, b
   }
   // the K maxima are reduced within the wave in working precision (DPP row steps + v_readlane: ~11 instructions each
   // against ~36 for an fp64 shuffle chain -- the end of the kernel was a fifth of its instruction count)
-  double v[K + 2], ps[K + 2];
+  if constexpr (K >= 32) {
+    // one slot at a time, nothing held per thread (grid_reduce_finalize would keep 4 (K + 2) registers live: one wave per
+    // SIMD at K = 64); summation / maximum order over waves and workgroups is the same
+    const double fyw = pg_wave_allreduce<false, double>(fy), gzw = pg_wave_allreduce<false, double>(gz);
+    auto wave_val = [&](int k) -> double {
+      if (k < K) return (double)pg_wave_allreduce<true, T>((T)mx.get(k));
+      return k == K ? fyw : gzw;
+    };
+    grid_reduce_finalize_streamed<K + 2, (K >= 64 ? ~0ull : ((1ull << (K & 63)) - 1ull)), DR_BLOCK_BS / 64>(
+        wave_val, red_partials, red_counter, out, a.gscale);
+  } else {
+    double v[K + 2], ps[K + 2];
 #pragma unroll
-  for (int j = 0; j < K; ++j) v[j] = (double)pg_wave_allreduce<true, T>(mx[j]), ps[j] = 1.0;
-  v[K] = pg_wave_allreduce<false, double>(fy), ps[K] = 1.0;
-  v[K + 1] = pg_wave_allreduce<false, double>(gz), ps[K + 1] = a.gscale;
-  grid_reduce_finalize<K + 2, (1ull << K) - 1ull, DR_BLOCK_BS / 64, true>(v, red_partials, red_counter, out, ps);
+    for (int j = 0; j < K; ++j) v[j] = (double)pg_wave_allreduce<true, T>((T)mx.get(j)), ps[j] = 1.0;
+    v[K] = pg_wave_allreduce<false, double>(fy), ps[K] = 1.0;
+    v[K + 1] = pg_wave_allreduce<false, double>(gz), ps[K + 1] = a.gscale;
+    grid_reduce_finalize<K + 2, (1ull << K) - 1ull, DR_BLOCK_BS / 64, true>(v, red_partials, red_counter, out, ps);
+  }
 }
 
 // smooth losses on m-vectors (the `f` of PANOC's f(Ax)); acc[0] = f(u), grad written elementwise
@@ -814,7 +844,8 @@ pg_status dr_run_t(pg_ctx* c, int64_t n, void* x, void* x_alt, void* y, void* r,
     auto launch = [&](Blk& b, int in, int set) -> pg_status {
       b.in = in, b.set = set, b.live = true;
       void *xi = bufs[in], *xo = bufs[(in + 1) % 3];
-      PG_TRY(K == 32   ? (dr_block_t<T, 32>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
+      PG_TRY(K == 64   ? (dr_block_t<T, 64>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
+             : K == 32 ? (dr_block_t<T, 32>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
              : K == 16 ? (dr_block_t<T, 16>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
                        : (dr_block_t<T, 8>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set])));
       PG_HIP(hipEventRecord(c->dr_ev[set], c->stream));
@@ -1044,7 +1075,7 @@ pg_status pg_dr_run(pg_ctx* c, int32_t dtype, int64_t n, void* x, void* x_alt, v
   PG_VEC_ARGS_OK(c, n);
   PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
   PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
-  PG_REQUIRE(block == 1 || block == 8 || block == 16 || block == 32, "block must be 1, 8, 16 or 32");
+  PG_REQUIRE(block == 1 || block == 8 || block == 16 || block == 32 || block == 64, "block must be 1, 8, 16, 32 or 64");
   PG_REQUIRE(block == 1 || (x_alt != nullptr && x_alt != x) || n == 0, "x_alt (a second n-vector) is required when block > 1");
   PG_REQUIRE(maxit >= 1, "maxit must be >= 1");
   PG_REQUIRE(gamma > 0, "gamma must be positive");

@@ -47,7 +47,7 @@ class DouglasRachfordIteration:
         self.engine = engine
         self.materialize = bool(materialize)
 
-    def device_run(self, maxit, tol, block=32):
+    def device_run(self, maxit, tol, block=64):
         """The driver loop of ProximalAlgorithms.jl:114-123 with the default stop rule, inside the library
         (pg_dr_run): ``block`` iterations per HBM sweep.  Returns ``(state, k)``; the state is bit-identical to the one
         the step-by-step loop stops at."""
@@ -120,9 +120,9 @@ def default_display(it, iteration, state):
 
 
 def DouglasRachford(*, maxit=1_000, tol=1e-8, stop=None, solution=default_solution, verbose=False, freq=100,
-                    display=default_display, device_loop=False, check_every=32, graph=False, **kwargs):
+                    display=default_display, device_loop=False, check_every=64, graph=False, **kwargs):
     """douglas_rachford.jl:101-119.  device_loop=True (default stop rule, fused engine): the driver loop runs inside
-    the library, ``check_every`` (1, 8, 16 or 32) iterations per HBM sweep; same iterates, same iteration count."""
+    the library, ``check_every`` (1, 8, 16, 32 or 64) iterations per HBM sweep; same iterates, same iteration count."""
     dl = (tol, int(check_every)) if (device_loop and stop is None) else None
     if stop is None:
         stop = lambda iteration, state: default_stopping_criterion(tol, iteration, state)

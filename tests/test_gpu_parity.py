@@ -924,7 +924,7 @@ def test_douglas_rachford_box_qp(pa, dtype, engine, materialize, gname):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("gname", ["box", "l1", "zero"])
-@pytest.mark.parametrize("block", [8, 16, 32])
+@pytest.mark.parametrize("block", [8, 16, 32, 64])
 def test_douglas_rachford_device_loop_is_bit_identical(pa, dtype, gname, block):
     """pg_dr_run (K iterations per HBM sweep, stop rule evaluated for every inner iteration) leaves exactly the state
     the step-by-step loop stops at: same k, same bits -- when the rule fires mid-block, at a block end, at maxit
@@ -1157,7 +1157,7 @@ def test_config2_iterates_match_oracle(pa):
 def test_douglas_rachford_at_config3_size_against_oracle(pa):
     """BASELINE config 3 at its own size (n = 10^7, Float32): the fused Douglas-Rachford step against
     the oracle's unfused statements of douglas_rachford.jl:58-62 -- bit for bit, the prox's division included -- and the
-    in-library loop (32 iterations per sweep, two sweeps in flight) against stepping, bit for bit as well."""
+    in-library loop (32 and 64 iterations per sweep, two sweeps in flight) against stepping, bit for bit as well."""
     n, dtype = 10_000_000, np.float32
     rng = np.random.default_rng(0)
     d = (0.1 + rng.random(n, dtype=np.float32)).astype(dtype)
@@ -1175,14 +1175,16 @@ def test_douglas_rachford_at_config3_size_against_oracle(pa):
         if k == 70:
             break
     loop = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
-    s_dev, k_dev = loop.device_run(70, 0.0, 32)  # two blocks of 32 + 6 single steps
-    assert k_dev == 70
-    assert np.array_equal(s_dev.x.numpy(), s_ref.x.numpy()) and np.array_equal(s_dev.y.numpy(), s_ref.y.numpy())
-    assert float(s_dev.res_inf) == float(s_ref.res_inf)
+    for block in (32, 64):  # two blocks of 32 + 6 single steps; one block of 64 + 6 single steps
+        s_dev, k_dev = loop.device_run(70, 0.0, block)
+        assert k_dev == 70
+        assert np.array_equal(s_dev.x.numpy(), s_ref.x.numpy()) and np.array_equal(s_dev.y.numpy(), s_ref.y.numpy())
+        assert float(s_dev.res_inf) == float(s_ref.res_inf)
+        loop = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
     # a stop INSIDE a block while its successor is already queued: the state is replayed from the block's input
     tol = float(dtype(s_ref.res_inf) / gamma) * 1.0000001
     loop2 = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
-    s2, k2 = loop2.device_run(1000, tol, 32)
+    s2, k2 = loop2.device_run(1000, tol, 64)
     step2 = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
     for k, s in enumerate(step2, start=1):
         if dtype(s.res_inf) / gamma <= dtype(tol):

@@ -57,7 +57,7 @@ def main():
                               "whole_iteration_GBps": bytes_iter * args.steps / dt / 1e9,
                               "res_inf": float(s.res_inf)}
     # driver loop inside the library, K iterations per HBM sweep (pg_dr_run); tol = 0 so that exactly `steps` run
-    for block in (8, 16, 32):
+    for block in (8, 16, 32, 64):
         steps = max(args.steps, 10 * block) // block * block
         itn = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma,
                                           materialize=False)

@@ -31,7 +31,7 @@ def one_case(seed):
         tol = 1e-4 if dtype == np.float32 else float(rng.choice([1e-6, 1e-10]))
         maxit = int(rng.choice([7, 40, 500]))
         y_o, k_o = o.douglas_rachford(tol=tol, maxit=maxit, x0=x0, f=o.SeparableQuadratic(d, q), g=g_o, gamma=gamma)
-        for loop, blk in (("host", 1), ("device", 8), ("device", 16), ("device", 1)):
+        for loop, blk in (("host", 1), ("device", 8), ("device", 16), ("device", 64), ("device", 1)):
             y, k = pa.DouglasRachford(tol=tol, maxit=maxit, device_loop=(loop == "device"), check_every=blk)(
                 x0=x0, f=pa.SeparableQuadratic(d, q), g=g_g, gamma=gamma)
             if k != k_o or not np.array_equal(y, y_o):  # the separable prox is evaluated without contraction: same bits
