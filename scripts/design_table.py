@@ -50,8 +50,9 @@ def main():
     s3, l3 = c3["stepping"], c3["device_loop"]
     add("config 3, DouglasRachford n = 10^7: stepping", f"{s3['value'] / 1e3:.1f} k", f"`dr_step` {s3['roofline']['avg_launch_ms'] * 1e3:.1f} µs (200 MB)",
         f"{tb(s3['roofline']):.2f} TB/s", f"{s3['roofline']['frac']:.3f}", "`also[2]`, `r2_bench_dr.json`")
-    add("config 3: in-library loop, 32 iterations per sweep, two sweeps in flight", f"**{l3['value'] / 1e3:.1f} k** (round 1: 129 k)",
-        f"`dr_block<32>` {l3['roofline']['avg_launch_ms'] * 1e3:.0f} µs", "VALU-bound, see below", "—", "`also[2].device_loop`")
+    kk = l3["iterations_per_launch"]
+    add(f"config 3: in-library loop, {kk} iterations per sweep, two sweeps in flight", f"**{l3['value'] / 1e3:.1f} k** (round 1: 129 k)",
+        f"`dr_block<{kk}>` {l3['roofline']['avg_launch_ms'] * 1e3:.0f} µs", "VALU-bound, see below", "—", "`also[2].device_loop`")
     c4 = also["config4"]
     pk = c4["roofline"]["per_kernel"]
     add("config 4, PANOC logistic + L1 16384 × 10^6, L-BFGS(5), adaptive", f"{c4['value']:.1f} (2.0 reads of A per iteration)",
