@@ -380,6 +380,11 @@ struct DRMaxRegs {
     asm volatile("" : "+v"(v));
     mx[j] = v;
   }
+  __device__ __forceinline__ void fold2(int j, T a, T b) {  // max(mx, |a|, |b|): one v_max3 with abs modifiers
+    T v = fmax(fmax(mx[j], fabs(a)), fabs(b));
+    asm volatile("" : "+v"(v));
+    mx[j] = v;
+  }
   __device__ __forceinline__ T get(int j) const { return mx[j]; }
 };
 
@@ -426,15 +431,22 @@ __device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>&
 #pragma unroll
         for (int p = 0; p < NP; ++p) qq[p] = (P){(T)((double)aa[p][0] * inv64[p][0]), (T)((double)aa[p][1] * inv64[p][1])};
       } else {
+        // The scheduling fences keep the pairs in lockstep in the EMITTED code too: in the prefetching loop the scheduler
+        // otherwise runs one pair's whole chain after the other's and pads every dependent v_pk_* with s_nop (four per
+        // iteration, ~8 % of the loop's issue cycles)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < NP; ++p) qq[p] = aa[p] * inv[p];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {  // two Markstein corrections
           P rr[NP];
 #pragma unroll
           for (int p = 0; p < NP; ++p) rr[p] = __builtin_elementwise_fma(nden[p], qq[p], aa[p]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int p = 0; p < NP; ++p) qq[p] = __builtin_elementwise_fma(rr[p], inv[p], qq[p]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
@@ -458,10 +470,8 @@ __device__ __forceinline__ void dr_block_compute(const DRBlockArgs<T, GKIND, K>&
       for (int p = 0; p < NP; ++p) se[p] = ye[p] - ze[p];
 #pragma unroll
       for (int p = 0; p < NP; ++p) xe[p] = xe[p] - se[p];
-      T m = fmax(fabs(se[0][0]), fabs(se[0][1]));
 #pragma unroll
-      for (int p = 1; p < NP; ++p) m = fmax(m, fmax(fabs(se[p][0]), fabs(se[p][1])));
-      mx.fold(j, m);
+      for (int p = 0; p < NP; ++p) mx.fold2(j, se[p][0], se[p][1]);  // one v_max3_f32 per pair
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
