@@ -567,8 +567,17 @@ def run_config3(pa, ctx, n=10_000_000, steps=200):
     ctx.sync()
     cnt, ms = ctx.profile_read()["dr_step"]
     ctx.profile(False)
+    # the bound that applies to the blocked kernel: VALU issue.  Per 4 elements and iteration 18 v_pk_*_f32 (half rate on
+    # gfx950: 2 issue slots each), 4 v_med3 and 2 v_max3 = 42 slots = 10.5 per element; a CU issues 64 lane-slots per clock
+    info = ctx.device_info()
+    slots = 10.5
+    valu_floor_ms = block * n * slots / (info["compute_units"] * 64.0 * info["clock_khz"] * 1e3) * 1e3
     out["device_loop"] = {"value": round(nst / dt, 1), "ms_per_step": round(1e3 * dt / nst, 6), "steps": nst,
                           "iterations_per_launch": block,
+                          "valu": {"issue_slots_per_element_iteration": slots, "compute_units": info["compute_units"],
+                                   "clock_khz": info["clock_khz"], "floor_ms_per_launch": round(valu_floor_ms, 5),
+                                   "frac": round(valu_floor_ms / (ms / cnt), 4),
+                                   "note": "floor = the K iterations' VALU issue time alone (loads, stores and the reduction excluded)"},
                           "roofline": {"bound": "valu (the prox's division, evaluated exactly) / hbm", "kernel": "dr_block<%d>" % block,
                                        "avg_launch_ms": round(ms / cnt, 5), "algorithmic_bytes_per_launch": b5,
                                        "achieved": round(b5 / (ms / cnt * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

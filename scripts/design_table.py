@@ -52,7 +52,9 @@ def main():
         f"{tb(s3['roofline']):.2f} TB/s", f"{s3['roofline']['frac']:.3f}", "`also[2]`, `r2_bench_dr.json`")
     kk = l3["iterations_per_launch"]
     add(f"config 3: in-library loop, {kk} iterations per sweep, two sweeps in flight", f"**{l3['value'] / 1e3:.1f} k** (round 1: 129 k)",
-        f"`dr_block<{kk}>` {l3['roofline']['avg_launch_ms'] * 1e3:.0f} µs", "VALU-bound, see below", "—", "`also[2].device_loop`")
+        f"`dr_block<{kk}>` {l3['roofline']['avg_launch_ms'] * 1e3:.0f} µs",
+        "VALU-bound, see below" + (f": {l3['valu']['frac']:.2f} of the loop's VALU issue floor ({l3['valu']['floor_ms_per_launch'] * 1e3:.0f} µs)" if "valu" in l3 else ""),
+        "—", "`also[2].device_loop`")
     c4 = also["config4"]
     pk = c4["roofline"]["per_kernel"]
     add("config 4, PANOC logistic + L1 16384 × 10^6, L-BFGS(5), adaptive", f"{c4['value']:.1f} (2.0 reads of A per iteration)",
