@@ -42,10 +42,13 @@ import hashlib
 import json
 import math
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -98,8 +101,9 @@ def parse_args(argv=None):
     p.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                    help="TOP-LEVEL record: strong = the global problem is fixed and split over the ranks (default); weak = "
                         "every rank holds --m rows (BASELINE config 5 = --scaling weak --m 16384 on 8 GPUs)")
-    p.add_argument("--collective", choices=["torch", "native"], default="torch",
-                   help="N > 1: all-reduce through torch.distributed (default) or the library's own RCCL communicator")
+    p.add_argument("--collective", choices=["auto", "torch", "native"], default="auto",
+                   help="N > 1: all-reduce through the library's own RCCL communicator (native: no Python in the collective path; the "
+                        "default when librccl loads and the backend is nccl) or through torch.distributed (torch)")
     p.add_argument("--overlap", action="store_true",
                    help="pipeline the [grad ; f] all-reduce with pass T in column chunks (N > 1, row blocks). Off by default: at "
                         "the headline shard shape the chunking costs ~60 us/step, about what it can hide (DESIGN.md section 6)")
@@ -108,26 +112,49 @@ def parse_args(argv=None):
                    help="diagnostic: attach the collective even with one rank (measures the cost of the sharded code path)")
     p.add_argument("--share-device", action="store_true",
                    help="functional test mode: every rank uses cuda:0 (e.g. 2 ranks on a 1-GPU box, with --backend gloo)")
+    p.add_argument("--launch-timeout", type=float, default=900.0,
+                   help="`python bench.py --gpus N` without a launcher: wall-clock limit of the child job; on expiry its process "
+                        "group is ended and an error JSON line is printed (exit code 124)")
+    p.add_argument("--record-timeout", type=float, default=300.0,
+                   help="deadline of the top-level record (setup + warm-up + timed steps), seconds; on expiry rank 0 prints the "
+                        "line it has (with `error` and `stage`) and every rank exits")
+    p.add_argument("--sub-record-timeout", type=float, default=240.0, help="deadline of each further record, seconds")
+    p.add_argument("--stall-timeout", type=float, default=90.0,
+                   help="a record that makes no progress (no iteration, no setup phase finished) for this long is treated like an "
+                        "expired deadline; kept below --init-timeout so that this script, not the collective's own watchdog, ends the job")
+    p.add_argument("--init-timeout", type=float, default=120.0, help="torch.distributed.init_process_group timeout, seconds")
+    p.add_argument("--inject-fault", default=None, metavar="RANK:STAGE:KIND",
+                   help="test hook: when RANK enters the record STAGE it hangs (KIND = hang) or exits with code 1 (KIND = exit)")
     return p.parse_args(argv)
+
+
+def metric_name(args, world=None):
+    m_base, n = WORKLOADS[args.workload]
+    m_base, n = args.m or m_base, args.n or n
+    world = world or args.gpus
+    return "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, %s)" % (m_base * world if args.scaling == "weak" else m_base, n, args.dtype)
+
+
+def error_line(args, error, stage, **more):
+    """the ONE JSON line of a run that could not measure its top-level record"""
+    d = {"metric": metric_name(args), "value": None, "unit": "it/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+         "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
+         "data": "synthetic", "error": error, "stage": stage}
+    d.update(more)
+    return d
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # N > 1 from a plain shell: start the ranks as a child process (never exec: see the module docstring)
 # ---------------------------------------------------------------------------------------------------------------
-def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
-    as a child, relay its JSON line, return its exit code.  Nothing in this process has touched the GPU."""
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+def launch_command(args, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+
+
+def _find_line(text):
     line = None
-    for ln in proc.stdout.decode(errors="replace").splitlines():
+    for ln in text.splitlines():
         ln = ln.strip()
         if ln.startswith("{") and ln.endswith("}"):
             try:
@@ -135,13 +162,154 @@ def self_launch(args):
                     line = ln
             except ValueError:
                 pass
-    if line is not None:
-        sys.stdout.write(line + "\n")
-        sys.stdout.flush()
-    elif proc.returncode == 0:
-        sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
-        return 1
-    return proc.returncode
+    return line
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a CHILD in its own process group (never exec: nothing in this process has touched the GPU), relay its JSON line and
+    return its exit code.  The child gets --launch-timeout seconds of wall clock: on expiry the group gets SIGTERM (rank 0
+    then prints the line it has), 10 s later SIGKILL.  Whatever happens, stdout carries ONE JSON line: the ranks' own, or
+    an error line {"metric", "value": null, "error", "stage", "stderr_tail"} built here."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = launch_command(args, port)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True)
+    out_chunks, err_tail = [], []
+
+    def pump_out():
+        for chunk in iter(lambda: proc.stdout.read(65536), b""):
+            out_chunks.append(chunk)
+
+    def pump_err():  # relayed as it comes; the last lines are kept for the error line
+        for raw in iter(proc.stderr.readline, b""):
+            sys.stderr.buffer.write(raw)
+            sys.stderr.flush()
+            err_tail.append(raw.decode(errors="replace").rstrip())
+            del err_tail[:-60]
+
+    threads = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
+    for t in threads:
+        t.start()
+    timed_out = False
+    try:
+        rc = proc.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    for t in threads:
+        t.join(timeout=5.0)
+    line = _find_line(b"".join(out_chunks).decode(errors="replace"))
+    tail = [ln for ln in err_tail if ln.strip()][-12:]
+    if line is None:
+        if timed_out:
+            d = error_line(args, "timeout", "launch: no line from the ranks within %.0f s" % args.launch_timeout, stderr_tail=tail)
+        elif rc != 0:
+            d = error_line(args, "the ranks exited with code %d without a line" % rc, "launch", stderr_tail=tail)
+        else:
+            d = error_line(args, "the ranks exited without a JSON line", "launch", stderr_tail=tail)
+            rc = 1
+        line = json.dumps(d)
+    elif timed_out:
+        d = json.loads(line)
+        d.setdefault("error", "timeout")
+        d.setdefault("stage", "launch: ended after %.0f s" % args.launch_timeout)
+        line = json.dumps(d)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deadlines inside a rank: a hang in one record must not cost the records already measured
+# ---------------------------------------------------------------------------------------------------------------
+class Watchdog:
+    """Every record runs under a deadline and a stall detector.  A daemon thread watches both; when one expires rank 0
+    writes the line it has -- the records measured so far, `error` and `stage` -- and every rank leaves with os._exit
+    (0 when the top-level record was measured, else 3; ranks > 0 wait `grace` seconds so that rank 0's line is out before
+    the launcher reacts to the first exit).  SIGTERM (the launcher ending the job because another rank died) takes the
+    same path through a sigwait thread, which works while the main thread is stuck inside a collective."""
+
+    def __init__(self, rank, stall_s, write_line, grace=3.0, inject=None):
+        self.rank, self.stall_s, self.write_line, self.grace = rank, stall_s, write_line, grace
+        self.lock = threading.Lock()
+        self.stage, self.deadline_s = "startup", float("inf")
+        self.t_stage = self.t_beat = time.monotonic()
+        self.main_done = False
+        self.closed = False
+        self.inject = None
+        if inject:
+            r, st, kind = inject.split(":")
+            if int(r) == rank:
+                self.inject = (st, kind)
+        threading.Thread(target=self._watch, daemon=True).start()
+        threading.Thread(target=self._sigwait, daemon=True).start()
+
+    def enter(self, stage, deadline_s, stall=True):
+        self.stage, self.deadline_s = stage, deadline_s
+        self.stall_on = stall
+        self.t_stage = self.t_beat = time.monotonic()
+        if self.inject and self.inject[0] == stage:
+            if self.inject[1] == "exit":
+                sys.stderr.write("bench.py: injected fault: rank %d exits in stage %s\n" % (self.rank, stage))
+                sys.stderr.flush()
+                os._exit(1)
+            while True:  # "hang": the main thread never comes back (the watchdog thread ends the process)
+                time.sleep(1.0)
+
+    def beat(self):
+        self.t_beat = time.monotonic()
+
+    def close(self):
+        """the normal end: from here on the main thread owns the line"""
+        with self.lock:
+            if self.closed:  # a watchdog exit is under way
+                time.sleep(3600)
+            self.closed = True
+
+    def _fire(self, error):
+        with self.lock:
+            if self.closed:
+                return
+            self.closed = True
+        code = 0 if self.main_done else 3
+        sys.stderr.write("bench.py: rank %d: %s in stage %s -> exit %d\n" % (self.rank, error, self.stage, code))
+        sys.stderr.flush()
+        if self.rank == 0:
+            try:
+                self.write_line(error, self.stage)
+            except Exception:
+                traceback.print_exc()
+        else:
+            time.sleep(self.grace)
+        os._exit(code)
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            now = time.monotonic()
+            if now - self.t_stage > self.deadline_s:
+                self._fire("timeout: record deadline of %.0f s expired" % self.deadline_s)
+            if getattr(self, "stall_on", True) and now - self.t_beat > self.stall_s:
+                self._fire("timeout: no progress for %.0f s" % self.stall_s)
+
+    def _sigwait(self):
+        signal.sigwait({signal.SIGTERM})
+        self._fire("terminated by the launcher (SIGTERM: another rank failed or the job ran out of time)")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -173,6 +341,49 @@ def _blas_threads():
         return max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
     except Exception:
         return os.cpu_count() or 1
+
+
+def host_stream_gbps(threads=None, mib_per_array=1024, reps=3):
+    """The host's own streaming rate, so that the CPU leg's it/s can be read as a fraction of what this host can move:
+    STREAM "add" (a = b + c, Float32, 12 bytes per element by STREAM's count) with numpy kernels on `threads` Python threads
+    (numpy releases the GIL inside the loop), each on its own contiguous chunk; best of `reps`.  Returns (GB/s with all
+    threads, GB/s with one thread, threads)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads = threads or min(os.cpu_count() or 1, 64)
+    n = mib_per_array * (1 << 20) // 4
+    b, c_, a = np.ones(n, np.float32), np.ones(n, np.float32), np.empty(n, np.float32)
+    a[:] = 0  # touch every page before timing
+
+    def rate(T):
+        cuts = [n * k // T for k in range(T + 1)]
+        best = float("inf")
+        with ThreadPoolExecutor(T) as ex:
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                list(ex.map(lambda k: np.add(b[cuts[k]:cuts[k + 1]], c_[cuts[k]:cuts[k + 1]], out=a[cuts[k]:cuts[k + 1]]), range(T)))
+                best = min(best, time.perf_counter() - t0)
+        return 3 * n * 4 / best / 1e9
+
+    return rate(threads), rate(1), threads
+
+
+def _cpu_bandwidth_fields(rec, m, n, es):
+    """what the it/s of the CPU leg means in bytes: the oracle streams A twice per iteration (A x, then A' r)"""
+    rec["achieved_GBps"] = round(2.0 * m * n * es * rec["value"] / 1e9, 1)
+    if rec.get("value_1thread"):
+        rec["achieved_GBps_1thread"] = round(2.0 * m * n * es * rec["value_1thread"] / 1e9, 1)
+    try:
+        g_all, g_one, T = host_stream_gbps()
+        rec["host_stream_GBps"] = round(g_all, 1)
+        rec["host_stream_GBps_1thread"] = round(g_one, 1)
+        rec["host_stream_note"] = "STREAM add (Float32, numpy kernels on %d threads, 3 x 1 GiB arrays): what this host streams; " \
+                                  "achieved_GBps / host_stream_GBps is the CPU leg's own roofline fraction" % T
+    except Exception as e:  # never let the side measurement cost the line
+        rec["host_stream_GBps"] = None
+        rec["host_stream_note"] = "not measured: %s" % str(e)[:120]
+    return rec
 
 
 def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
@@ -208,7 +419,7 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
         note1 = f"; 1 BLAS thread: 1 iteration on the same matrix in {d1:.1f} s"
     except Exception:
         pass
-    return {
+    rec = {
         "value": steps / dt,
         "value_1thread": one_thread,
         "unit": "it/s",
@@ -217,6 +428,9 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
         "sample": f"the full workload: oracle FFB fixed-step on the downloaded {m}x{n} {A.dtype.name} matrix "
                   f"({A.nbytes / 2**30:.1f} GiB, copied to the host in {t_dl:.1f} s), {steps} iterations in {dt:.1f} s{note1}",
     }
+    es = A.dtype.itemsize
+    del it, A, b
+    return _cpu_bandwidth_fields(rec, m, n, es)
 
 
 def cpu_baseline(m, n, sample_cols, steps, seed):
@@ -258,7 +472,7 @@ def cpu_baseline(m, n, sample_cols, steps, seed):
             one_thread = s1 / (time.perf_counter() - t0) * ns / n
     except Exception:
         pass
-    return {
+    rec = {
         "value": its_sample * ns / n,
         "value_1thread": one_thread,
         "unit": "it/s",
@@ -267,6 +481,8 @@ def cpu_baseline(m, n, sample_cols, steps, seed):
         "sample": f"oracle FFB fixed-step, m={m} n={ns} f32 ({steps} it, {dt:.2f} s, {its_sample:.2f} it/s on the sample; "
                   f"scaled linearly in n to n={n}; the host cannot hold the full matrix)",
     }
+    del it, A
+    return _cpu_bandwidth_fields(rec, m, n, 4)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -304,6 +520,7 @@ class Dist:
         self.world, self.rank, self.local_rank = world, rank, local_rank
         self.backend, self.collective, self.overlap, self.force_comm = backend, collective, overlap, force_comm
         self.sharded = world > 1 or force_comm
+        self.beat = lambda: None  # progress mark for the watchdog's stall detector
 
     def barrier(self):
         import torch
@@ -358,6 +575,8 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
         row_off, m_loc, col_off, n_loc = 0, m_glob, 0, n
     A = pa.HIPMatrix.synthetic(m_loc, n_loc, dtype, seed=seed, row_offset=row_off, col_offset=col_off, m_global=m_glob,
                                ctx=ctx)
+    ctx.sync()
+    D.beat()
     rng = np.random.default_rng(seed + 12345)
     k = max(1, n // 1000)
     x_true = np.zeros(n, dtype)
@@ -372,6 +591,7 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
         shard = "cols" if cols else "rows"
         comm = (pa.NativeRcclComm(overlap=D.overlap, shard=shard) if D.collective == "native"
                 else pa.TorchDistributedComm(overlap=D.overlap, shard=shard))
+    D.beat()
     f = pa.LeastSquares(A, b, comm=comm)
     zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)
     _, g0 = f.value_and_gradient(zero_n)  # = -A'b (row blocks: all-reduced; column blocks: this rank's columns)
@@ -386,6 +606,7 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
         w = v.similar()
         nrm = dtype(1)
         for _ in range(30):
+            D.beat()
             f0.value_and_gradient(v, out=w)
             nrm2 = float(w.norm()) ** 2
             if cols:
@@ -412,10 +633,12 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
                                                 single_sweep=sweeps == "one")
     it = iter(iteration)
     state = next(it)  # init (k = 1)
+    D.beat()
     stop_rule = lambda s: float(s.res_inf) / float(s.gamma) <= 1e-6  # benchmarks.jl:57 (evaluated, not acted on)
     for _ in range(warmup):
         state = next(it)
         stop_rule(state)
+        D.beat()
     passes0 = iteration.counters.get("a_passes", 0)
     comm = P["comm"]
     calls0, elems0 = (getattr(comm, "calls", 0), getattr(comm, "elements", 0)) if comm is not None else (0, 0)
@@ -428,6 +651,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
         stop_rule(state)
     D.barrier()
     elapsed = time.perf_counter() - t0
+    D.beat()
     prof = ctx.profile_read()
     ctx.profile(False)
     a_passes = iteration.counters.get("a_passes", 0) - passes0
@@ -440,6 +664,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
                 state = next(it)
                 stop_rule(state)
             k1 += 10
+            D.beat()
         D.barrier()
         dt1 = time.perf_counter() - t1
         sustained = {"seconds": round(dt1, 2), "steps": k1, "value": round(k1 / dt1, 4), "ms_per_step": round(1e3 * dt1 / k1, 4)}
@@ -519,9 +744,9 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE configs 3 and 4 (N = 1 `also` records)
 # ---------------------------------------------------------------------------------------------------------------
-def run_config3(pa, ctx, n=10_000_000, steps=200):
+def run_config3(pa, ctx, n=10_000_000, steps=200, beat=lambda: None):
     """DouglasRachford on a box-constrained QP with diagonal Hessian (douglas_rachford.jl:53-70), n = 10^7, Float32:
-    stepping from the host (one fused sweep per iteration) and the in-library loop (32 iterations per sweep, two sweeps in flight)."""
+    stepping from the host (one fused sweep per iteration) and the in-library loop (64 iterations per sweep, two sweeps in flight)."""
     import numpy as np
 
     dtype = np.float32
@@ -536,6 +761,7 @@ def run_config3(pa, ctx, n=10_000_000, steps=200):
                                           materialize=False))
     for _ in range(20):
         s = next(it)
+    beat()
     ctx.profile(True)
     ctx.profile_reset()
     ctx.sync()
@@ -545,6 +771,7 @@ def run_config3(pa, ctx, n=10_000_000, steps=200):
         float(s.res_inf) / float(gamma) <= 1e-8  # the stop rule, evaluated every iteration like the driver loop
     ctx.sync()
     dt = time.perf_counter() - t0
+    beat()
     cnt, ms = ctx.profile_read()["dr_step"]
     ctx.profile(False)
     b5 = 5 * n * 4  # x, d, q in; x, y out
@@ -589,7 +816,7 @@ def run_config3(pa, ctx, n=10_000_000, steps=200):
     return out
 
 
-def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3):
+def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3, beat=lambda: None):
     """PANOC (panoc.jl:138-255; L-BFGS memory 5, adaptive step) on logistic loss + L1, m = 16384, n = 10^6, Float32."""
     import numpy as np
 
@@ -606,9 +833,11 @@ def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3):
     lam = dtype(0.1) * A.mul_adjoint(g0).norm_inf()
     iteration = pa.PANOCIteration(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype))
     it = iter(iteration)
+    beat()
     s = next(it)
     for _ in range(warmup):
         s = next(it)
+        beat()
     p0 = iteration.counters.get("A_passes", 0)
     ctx.profile(True)
     ctx.profile_reset()
@@ -617,6 +846,7 @@ def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3):
     for _ in range(steps):
         s = next(it)
         float(s.res.norm_inf()) / float(s.gamma) <= 1e-8
+        beat()
     ctx.sync()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
@@ -639,43 +869,137 @@ def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def summary_row(r):
+    """[it/s, ms_per_step, dominant kernel, roofline frac] of a record -- the compact form nested under `config`"""
+    if not isinstance(r, dict) or "value" not in r:
+        return {"error": (r or {}).get("error", "not measured")[:120]} if isinstance(r, dict) else None
+    roof = r.get("roofline") or {}
+    return [r.get("value"), r.get("ms_per_step"), roof.get("kernel"), roof.get("frac")]
+
+
+class Job:
+    """what rank 0 needs to print the line at any moment: the records measured so far"""
+
+    def __init__(self, args, world, rank):
+        self.args, self.world, self.rank = args, world, rank
+        self.main_rec, self.extra, self.cpu, self.meta = None, {}, None, {}
+        self.json_fd = None
+
+    def line(self, error=None, stage=None):
+        args = self.args
+        if self.main_rec is None:
+            d = error_line(args, error or "not measured", stage)
+            d["metric"] = metric_name(args, self.world)
+            d["n_gpus"] = self.world
+        else:
+            r = self.main_rec
+            config = dict(r["config"])
+            also = self.extra.get("also")
+            if also is not None:  # the driver keeps `config` whole and drops unknown top-level keys
+                config["also_summary"] = {a.get("label", "?"): summary_row(a) for a in also}
+            subs = {k_: summary_row(v) for k_, v in self.extra.items() if k_ != "also" and isinstance(v, dict) and ("value" in v or "error" in v)}
+            if subs:
+                config["layouts_summary"] = subs
+            if "sustained" in r:
+                config["sustained_it_s"] = r["sustained"]["value"]
+            d = {"metric": metric_name(args, self.world), "value": r["value"], "unit": "it/s", "n_gpus": self.world,
+                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+                 "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": config,
+                 "roofline": r["roofline"], "cpu_baseline": self.cpu}
+            for k_ in ("ranks_seen_by_rccl", "collective", "sustained"):
+                if k_ in r:
+                    d[k_] = r[k_]
+            if error is not None:
+                d["error"], d["stage"] = error, stage
+        d["job"] = self.meta
+        d.update(self.extra)
+        return d
+
+    def write(self, error=None, stage=None):
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.write(self.json_fd, (json.dumps(self.line(error, stage)) + "\n").encode())
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
         sys.exit(self_launch(args))
 
+    # SIGTERM is taken by the watchdog's sigwait thread: block it here, before any library starts a thread of its own
+    signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    # stdout carries exactly ONE line (the JSON, written last by rank 0): RCCL prints a version banner through C
+    # stdio on fd 1 when a communicator is created, so everything else on fd 1 is routed to stderr
+    sys.stdout.flush()
+    job = Job(args, world, rank)
+    job.json_fd = os.dup(1)
+    os.dup2(2, 1)
+    wd = Watchdog(rank, args.stall_timeout, job.write, inject=args.inject_fault)
+    try:
+        rc = run_rank(args, job, wd, world, rank, local_rank)
+    except BaseException as e:  # a rank that raises still leaves a line (rank 0) and a non-zero exit code
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        traceback.print_exc()
+        wd.close()
+        if rank == 0:
+            job.write("%s: %s" % (type(e).__name__, str(e)[:400]), wd.stage)
+        sys.stderr.flush()
+        os._exit(1)  # not sys.exit: a peer stuck in a collective must not keep this process in an atexit handler
+    os.close(job.json_fd)
+    if rc:
+        sys.exit(rc)
+
+
+def run_rank(args, job, wd, world, rank, local_rank):
+    wd.enter("import", 600.0, stall=False)  # the first `import torch` on a fresh box pages the image in: minutes, not a hang
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import proximalalgorithms.jl_amd as pa
 
-    # stdout carries exactly ONE line (the JSON, written last by rank 0): RCCL prints a version banner through C
-    # stdio on fd 1 when a communicator is created, so everything else on fd 1 is routed to stderr
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-
-    world = int(world_env or "1")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    wd.enter("init", args.init_timeout + 30.0, stall=False)
     if args.share_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # before the first library call: the context below is created on this device
+    job.meta = {"HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"),
+                "devices_visible": torch.cuda.device_count(), "device": torch.cuda.get_device_name(local_rank),
+                "local_rank": local_rank, "backend": None, "rccl_version": None, "collective": None}
     if world > 1 or args.force_comm:
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         if world == 1:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        tmo = datetime.timedelta(seconds=args.init_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
+            try:
+                job.meta["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
         else:
-            dist.init_process_group("gloo")
-    D = Dist(world, rank, local_rank, args.backend, args.collective, args.overlap, args.force_comm)
+            dist.init_process_group("gloo", timeout=tmo)
+        job.meta["backend"] = "rccl" if args.backend == "nccl" else args.backend
+        job.meta["ranks_seen_by_rccl"] = dist.get_world_size()
+    collective = args.collective
+    if collective == "auto":  # the library's own RCCL communicator when librccl loads and the job runs on RCCL; else torch.distributed
+        collective = "native" if (args.backend == "nccl" and pa.native_rccl_available()) else "torch"
+    job.meta["collective"] = collective
+    D = Dist(world, rank, local_rank, args.backend, collective, args.overlap, args.force_comm)
+    D.beat = wd.beat
 
     m_base, n = WORKLOADS[args.workload]
     m_base = args.m or m_base
@@ -696,22 +1020,26 @@ def main():
 
     if args.sustain is None:
         args.sustain = 5.0 if (named == "headline" and world == 1 and not args.force_comm) else 0.0
+    wd.enter("main", args.record_timeout + args.sustain)
     P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode)
-    main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
-                       workload_name=named, scaling=args.scaling, sustain=args.sustain)
-    extra = {}
+    job.main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
+                           workload_name=named, scaling=args.scaling, sustain=args.sustain)
+    wd.main_done = True
+    extra = job.extra
     sub_steps = max(4, min(args.steps, 20))
     if args.no_also:
         pass
     elif world == 1 and not args.force_comm and named == "headline" and args.mode == "fixed":
-        also = []
+        also = extra["also"] = []
         # the reference benchmark's own mode: adaptive step (benchmark/benchmarks.jl:55-61), same matrix
+        wd.enter("headline_adaptive", args.sub_record_timeout)
         r = run_ffb(pa, ctx, D, P, "adaptive", args.sweeps, sub_steps, 3, args.kernel_events)
         r["label"] = "headline_adaptive"
         also.append(r)
         # the CPU leg needs the headline matrix: take it before the other configs claim the memory
         if rank == 0 and not args.no_cpu_baseline:
-            extra["cpu_baseline"] = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
+            wd.enter("cpu_baseline", 600.0, stall=False)
+            job.cpu = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
             args.no_cpu_baseline = True
         P = None  # release the 64 GiB matrix
         t_also = time.perf_counter()  # time box of the remaining records (the CPU leg is not part of it)
@@ -721,6 +1049,7 @@ def main():
             # an extra record that fails (out of memory on a smaller device, a refused shape) must not cost the headline line
             if not within():
                 return
+            wd.enter(label, args.sub_record_timeout)
             try:
                 r = fn()
             except (pa.ProxGradError, MemoryError, RuntimeError) as e:
@@ -733,20 +1062,20 @@ def main():
             return run_ffb(pa, ctx, D, P2, "fixed", "one", steps_, warm_, args.kernel_events, workload_name=key)
 
         also_record("config2", lambda: ffb_record(*WORKLOADS["config2"], max(sub_steps, 50), 5, "config2"))
-        also_record("config3", lambda: run_config3(pa, ctx))
-        also_record("config4", lambda: run_config4(pa, ctx))
+        also_record("config3", lambda: run_config3(pa, ctx, beat=wd.beat))
+        also_record("config4", lambda: run_config4(pa, ctx, beat=wd.beat))
         # per-GPU block shapes at N = 8, run as problems of their own on one GPU: BASELINE config 5 under the column layout
         # (131072 x 131072: one team sweep per iteration) and the headline under north_star's row layout (2048 x 2^20: the
         # short-column sweep, one wave per column group); the PMC passes of these sweeps were taken on exactly these shapes
         also_record("config5_column_block", lambda: ffb_record(131072, 131072, sub_steps, 3, "long_columns"))
         also_record("headline_row_block_n8", lambda: ffb_record(2048, 1 << 20, sub_steps, 3, "short_columns"))
-        extra["also"] = also
     elif world > 1:
         P = None
         other = "rows" if layout == "cols" else "cols"
 
         def extra_record(key, m_rec, lay, scaling):
             # an extra record that cannot run (the library refuses the shape on every rank alike) must not cost the line
+            wd.enter(key, args.sub_record_timeout)
             try:
                 P2 = setup_lasso(pa, ctx, D, m_rec, n, dtype, args.seed, lay, "fixed")
                 extra[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events, scaling=scaling)
@@ -762,28 +1091,17 @@ def main():
                 continue
             extra_record("config5_weak_%s" % lay, m_base * world, lay, "weak")
 
-    line = None
-    if rank == 0:
-        cpu = extra.pop("cpu_baseline", None)
-        if cpu is None and world == 1 and not args.no_cpu_baseline and P is not None:
-            cpu = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
-        line = {"metric": "FastForwardBackward iters/sec on LASSO (m=%d, n=%d, %s)" % (m_glob, n, args.dtype),
-                "value": main_rec["value"], "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
-                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": main_rec["config"],
-                "roofline": main_rec["roofline"], "cpu_baseline": cpu}
-        for k_ in ("ranks_seen_by_rccl", "collective", "sustained"):
-            if k_ in main_rec:
-                line[k_] = main_rec[k_]
-        line.update(extra)
+    if rank == 0 and job.cpu is None and world == 1 and not args.no_cpu_baseline and P is not None:
+        wd.enter("cpu_baseline", 600.0, stall=False)
+        job.cpu = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
+    wd.enter("finalize", 60.0)
     if world > 1 or args.force_comm:
         dist.barrier()
         dist.destroy_process_group()
-    sys.stdout.flush()
-    ctypes.CDLL(None).fflush(None)
-    if line is not None:
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
-    os.close(json_fd)
+    wd.close()
+    if rank == 0:
+        job.write()
+    return 0
 
 
 def cpu_leg(args, P, m_glob, n, es):

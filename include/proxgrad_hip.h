@@ -45,7 +45,10 @@ enum {
   PG_ERR_HIP = -2,       /* a HIP runtime call failed; see pg_last_error()                   */
   PG_ERR_ALLOC = -3,     /* device allocation failed                                         */
   PG_ERR_UNSUPPORTED = -4,
-  PG_ERR_COLLECTIVE = -5 /* the registered all-reduce callback reported a failure           */
+  PG_ERR_COLLECTIVE = -5, /* the registered all-reduce callback reported a failure           */
+  PG_ERR_TIMEOUT = -6     /* a bounded wait inside a kernel expired: the workgroup teams of the long-column sweep wait
+                           * for each other and one of them never arrived (see pg_ls_fused_pass).  The outputs of the call
+                           * are undefined, its inputs intact; the iterators (pg_iter_*) recover by themselves           */
 };
 
 enum { PG_F32 = 0, PG_F64 = 1 };
@@ -65,7 +68,12 @@ enum {
 };
 
 /* flags reported in pg_iter_scalars.flags */
-enum { PG_FLAG_GAMMA_TOO_SMALL = 1 /* fb_tools.jl:59-61 (@warn, not an error) */ };
+enum {
+  PG_FLAG_GAMMA_TOO_SMALL = 1, /* fb_tools.jl:59-61 (@warn, not an error) */
+  PG_FLAG_SWEEP_FALLBACK = 2   /* this iteration's single sweep was refused at launch or timed out (PG_ERR_TIMEOUT): its
+                                * uncommitted outputs were discarded and the iteration redone with two sweeps (A x, A' r) --
+                                * same iterate, more reads of A (pg_iter_scalars.a_passes shows them) */
+};
 
 typedef struct pg_ctx pg_ctx;
 typedef struct pg_mat pg_mat;
@@ -109,9 +117,14 @@ pg_status pg_ctx_set_allreduce_async(pg_ctx* ctx, pg_allreduce_fn begin, pg_allr
  * and installs the library's own all-reduce -- blocking form on the context stream, and with overlap != 0 also the
  * asynchronous pair on a side stream behind events (chunked pass T, see pg_ctx_set_allreduce_async). */
 #define PG_COMM_ID_BYTES 128
+int32_t pg_comm_available(void); /* 1 when librccl could be loaded, else 0 (then the two calls below return PG_ERR_UNSUPPORTED) */
 pg_status pg_comm_get_unique_id(void* id_out /* PG_COMM_ID_BYTES */);
+/* One communicator per context for the life of the job: a further call with the same (nranks, rank) keeps it, re-installs the
+ * library's all-reduce and only switches the overlap mode (`id` is then ignored). */
 pg_status pg_ctx_comm_init(pg_ctx* ctx, const void* id, int32_t nranks, int32_t rank, int32_t overlap);
 pg_status pg_ctx_comm_destroy(pg_ctx* ctx);
+/* telemetry of the native path: all-reduces issued so far and the sum of their lengths (elements) */
+pg_status pg_ctx_comm_stats(pg_ctx* ctx, int64_t* calls, int64_t* elements);
 /* Column sharding (the alternative to row sharding named in SURVEY 8(e)): rank `rank` of `nranks` holds the column block
  * A[:, J_rank] and the J_rank slices of all n-vectors; b and the residual are replicated.  The registered collective
  * (pg_ctx_set_allreduce / pg_ctx_comm_init) then carries A x (m elements) plus 8 * nranks scalar slots (four scalars per rank as hi / lo pairs of the working precision) -- ONE all-reduce
@@ -216,7 +229,13 @@ pg_status pg_ls_residual_ptr(pg_ls* f, const void** r_out);
  *   v_next = z_new + beta (z_new - z_old) ; f's residual := A v_next - b.
  * A column's contribution to A v_next is accumulated while the column is still in registers, so A is read once.
  * Unsharded or column-sharded operators with m <= 262144 (f32) / 131072 (f64) rows; PG_ERR_UNSUPPORTED otherwise.
- * scalars_out (host, may be NULL) = { f(v_next), g(z_new), norm(res, Inf), dot(grad, res), norm(res)^2 }. */
+ * scalars_out (host, may be NULL) = { f(v_next), g(z_new), norm(res, Inf), dot(grad, res), norm(res)^2 }.
+ * Columns longer than one workgroup's registers (> 32768 rows f32) are split over TEAMS of workgroups that exchange their
+ * partial dot products while the kernel runs; the launch is cooperative, so either every team member is resident or the
+ * launch is refused (PG_ERR_UNSUPPORTED, nothing written).  One such sweep at a time per device: a member that still has
+ * not heard from its team after a bounded wait gives up, and the call (or, with scalars_out == NULL, the next call that
+ * synchronises) returns PG_ERR_TIMEOUT -- grad, y, z_new, res, v_next and f's residual are then undefined, x and z_old
+ * intact; re-evaluate f at x (pg_ls_value) before trying again, or use pg_ls_value_and_gradient + pg_fb_epilogue. */
 pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,
                            double g_p0, double g_p1, void* grad, void* y, void* z_new, void* res, void* v_next,
                            double* scalars_out);

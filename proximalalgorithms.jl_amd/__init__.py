@@ -23,7 +23,8 @@ from .operators import (Composed, Conjugate, IndAffine, IndBox, IndNonnegative, 
                         is_generalized_quadratic, prox, prox_, value_and_gradient, value_and_gradient_)
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
 from .panocplus import PANOCplus, PANOCplusIteration
-from .sharding import NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce_sum_, shard_cols, shard_rows
+from .sharding import (NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce_sum_, native_rccl_available, shard_cols,
+                       shard_rows)
 
 from .zerofpr import ZeroFPR, ZeroFPRIteration
 from .sfista import SFISTA, SFISTAIteration
@@ -51,6 +52,6 @@ __all__ = [
     "ForwardBackward", "ForwardBackwardIteration", "ForwardBackwardState", "ProximalGradient",
     "ProximalGradientIteration", "LBFGS", "LBFGSOperator", "AdaptiveNesterovSequence", "ConstantNesterovSequence",
     "FixedNesterovSequence", "SimpleNesterovSequence", "next_", "IndBox", "LeastSquares", "NormL1", "Zero",
-    "gradient_", "prox", "prox_", "value_and_gradient", "NativeRcclComm", "ScaleComm", "TorchDistributedComm", "allreduce_sum_",
+    "gradient_", "prox", "prox_", "value_and_gradient", "NativeRcclComm", "native_rccl_available", "ScaleComm", "TorchDistributedComm", "allreduce_sum_",
     "shard_rows", "shard_cols",
 ]

@@ -9,12 +9,12 @@ LIB_PATH = os.path.join(HERE, "libproxgrad_hip.so")
 PG_F32, PG_F64 = 0, 1
 PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX, PG_G_SQRNORML2 = 0, 1, 2, 3
 PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST, PG_SEQ_REPEATED = 0, 1, 2, 3, 4, 5
-PG_FLAG_GAMMA_TOO_SMALL = 1
+PG_FLAG_GAMMA_TOO_SMALL, PG_FLAG_SWEEP_FALLBACK = 1, 2
 PG_K_GEMV_N, PG_K_GEMV_N_FINISH, PG_K_GEMV_T, PG_K_EPILOGUE, PG_K_EXTRAPOLATE, PG_K_DR_STEP = range(6)
 KERNEL_NAMES = ["gemv_n_partial", "gemv_n_finish", "gemv_t", "fb_epilogue", "extrapolate", "dr_step", "gemv_tn"]
 
 
-PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_ALLOC, PG_ERR_UNSUPPORTED, PG_ERR_COLLECTIVE = -1, -2, -3, -4, -5
+PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_ALLOC, PG_ERR_UNSUPPORTED, PG_ERR_COLLECTIVE, PG_ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
 
 
 class ProxGradError(RuntimeError):
@@ -68,6 +68,7 @@ SIGNATURES = {
     "pg_comm_get_unique_id": [_vp],
     "pg_ctx_comm_init": [_vp, _vp, _i32, _i32, _i32],
     "pg_ctx_comm_destroy": [_vp],
+    "pg_ctx_comm_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "pg_ctx_sync": [_vp],
     "pg_ctx_capture_begin": [_vp],
     "pg_ctx_capture_end": [_vp, C.POINTER(_vp)],
@@ -141,7 +142,7 @@ SIGNATURES = {
     "pg_lbfgs_images_update": [_vp, _vp, _vp],
     "pg_lbfgs_images_apply": [_vp, _vp, _vp],
 }
-_SPECIAL = {"pg_abi_version": ([], C.c_int32), "pg_last_error": ([], C.c_char_p)}
+_SPECIAL = {"pg_abi_version": ([], C.c_int32), "pg_last_error": ([], C.c_char_p), "pg_comm_available": ([], C.c_int32)}
 
 _lib = None
 

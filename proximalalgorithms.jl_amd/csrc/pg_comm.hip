@@ -56,6 +56,8 @@ const char* rccl_err(RcclApi* api, int rc) { return api->error_string ? api->err
 int native_allreduce(void* user, void* buf, int64_t count, int32_t dtype, void* stream) {
   pg_ctx* c = (pg_ctx*)user;
   RcclApi* api = rccl_api();
+  c->comm->calls += 1;
+  c->comm->elements += count;
   return api->all_reduce(buf, buf, (size_t)count, dtype == PG_F64 ? 8 : 7, 0, c->comm->comm, (hipStream_t)stream);
 }
 
@@ -63,6 +65,8 @@ int native_allreduce_begin(void* user, void* buf, int64_t count, int32_t dtype, 
   pg_ctx* c = (pg_ctx*)user;
   RcclApi* api = rccl_api();
   pg_comm* k = c->comm;
+  k->calls += 1;
+  k->elements += count;
   if (hipEventRecord(k->ev_ready, (hipStream_t)stream) != hipSuccess) return 1;
   if (hipStreamWaitEvent(k->side, k->ev_ready, 0) != hipSuccess) return 1;
   return api->all_reduce(buf, buf, (size_t)count, dtype == PG_F64 ? 8 : 7, 0, k->comm, k->side);
@@ -76,9 +80,18 @@ int native_allreduce_wait(void* user, void* stream) {
   return 0;
 }
 
+void install(pg_ctx* c, int32_t overlap) {
+  c->allreduce = native_allreduce;
+  c->allreduce_user = c;
+  c->allreduce_begin = overlap ? native_allreduce_begin : nullptr;
+  c->allreduce_wait = overlap ? native_allreduce_wait : nullptr;
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t pg_comm_available(void) { return rccl_api() != nullptr ? 1 : 0; }
 
 pg_status pg_comm_get_unique_id(void* id_out) {
   PG_REQUIRE(id_out != nullptr, "id_out is null");
@@ -100,7 +113,13 @@ pg_status pg_comm_get_unique_id(void* id_out) {
 pg_status pg_ctx_comm_init(pg_ctx* c, const void* id_bytes, int32_t nranks, int32_t rank, int32_t overlap) {
   PG_REQUIRE(c != nullptr && id_bytes != nullptr, "null argument");
   PG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
-  PG_REQUIRE(c->comm == nullptr, "the context already has a communicator");
+  if (c->comm != nullptr) {
+    // one communicator per context for the life of the job: a second call with the same (nranks, rank) re-installs the
+    // library's all-reduce (a host callback may have replaced it meanwhile) and switches the overlap mode; the id is ignored
+    PG_REQUIRE(c->comm->nranks == nranks && c->comm->rank == rank, "the context already has a communicator of another shape");
+    install(c, overlap);
+    return PG_OK;
+  }
   RcclApi* api = rccl_api();
   if (!api) {
     pg_set_error("librccl could not be loaded (dlopen librccl.so.1)");
@@ -127,15 +146,14 @@ pg_status pg_ctx_comm_init(pg_ctx* c, const void* id_bytes, int32_t nranks, int3
   k->nranks = nranks;
   k->rank = rank;
   c->comm = k;
-  c->allreduce = native_allreduce;
-  c->allreduce_user = c;
-  if (overlap) {
-    c->allreduce_begin = native_allreduce_begin;
-    c->allreduce_wait = native_allreduce_wait;
-  } else {
-    c->allreduce_begin = nullptr;
-    c->allreduce_wait = nullptr;
-  }
+  install(c, overlap);
+  return PG_OK;
+}
+
+pg_status pg_ctx_comm_stats(pg_ctx* c, int64_t* calls, int64_t* elements) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  if (calls) *calls = c->comm ? c->comm->calls : 0;
+  if (elements) *elements = c->comm ? c->comm->elements : 0;
   return PG_OK;
 }
 

@@ -1,6 +1,8 @@
 // Context, memory helpers and the dense column-major matrix object (upload / generate / download).
 #include <cstdarg>
 
+#include <cstdlib>
+
 #include "pg_internal.h"
 
 static thread_local std::string g_last_error;
@@ -52,6 +54,8 @@ pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out) {
   }
   PG_HIP(hipMemset(c->red_counter, 0, sizeof(unsigned) * 8));
   memset(c->hscal, 0, sizeof(double) * PG_S_COUNT);
+  if (const char* v = getenv("PG_TEST_TEAM_FAULT")) c->test_team_fault = atoi(v);
+  if (const char* v = getenv("PG_TN_TEAM_PLAIN")) c->team_plain_launch = atoi(v) != 0;
   PG_HIP(hipDeviceSynchronize());
   *out = c;
   return PG_OK;
@@ -314,8 +318,9 @@ pg_status pg_read_scalars(pg_ctx* c, int first, int count) {
   PG_HIP(hipStreamSynchronize(c->stream));
   if (c->hscal[PG_S_TEAMERR] != 0.0) {  // a workgroup team of the long-column sweep gave up waiting (pg_gemv_tn2.hip)
     c->hscal[PG_S_TEAMERR] = 0.0;
+    c->team_timeout = true;
     pg_set_error("single-sweep pass: a workgroup team timed out waiting for a member (device shared with another job?)");
-    return PG_ERR_HIP;
+    return PG_ERR_TIMEOUT;
   }
   return PG_OK;
 }

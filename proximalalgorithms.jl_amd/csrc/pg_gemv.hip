@@ -334,11 +334,11 @@ pg_status gemv_n(pg_mat* A, const T* x, const T* b, T* y, int64_t y_len, bool wi
   if (with_f)
     hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3(blocks), dim3(1024), 0, c->stream,
                        (const T*)A->partials, A->ld, A->m, p.S_eff, b, y, y_len, f_scale, c->red_partials,
-                       c->red_counter, c->dscal + PG_S_F, f_typed);
+                       c->red_counter, c->dscal + PG_S_F, f_typed, ColPack<T>{});
   else
     hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3(blocks), dim3(1024), 0, c->stream,
                        (const T*)A->partials, A->ld, A->m, p.S_eff, b, y, y_len, 0.0, (double*)nullptr,
-                       (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+                       (unsigned*)nullptr, (double*)nullptr, (T*)nullptr, ColPack<T>{});
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -582,24 +582,16 @@ pg_status do_allreduce(pg_ctx* c, void* buf, int64_t count, int dtype) {
 // are zero on every other rank, so the SUM passes both through exactly and d = hi + lo arrives with the ~48 (Float32) / 106
 // (Float64) bits the unsharded path keeps in its fp64 scalar block -- the line search compares f(z) against the model with a
 // tolerance of 10 eps, and a length n_global > 2^24 must survive the trip.
-constexpr int COL_SLOTS = 8;  // working-precision words per rank: 4 scalars x (hi, lo)
-
+// (COL_SLOTS = 8 working-precision words per rank -- 4 scalars x (hi, lo) -- plus one shared group whose first word sums the
+// ranks' team-timeout flags: ColPack in pg_gemv_tn.h)
 template <typename T>
-__global__ void col_pack_scalars_kernel(T* __restrict__ slots, int nranks, int rank, const double* __restrict__ s4) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= COL_SLOTS * nranks) return;
-  T v = T(0);
-  if (t / COL_SLOTS == rank) {
-    const double d = s4[(t % COL_SLOTS) >> 1];
-    const T hi = (T)d;
-    v = (t & 1) ? (T)(d - (double)hi) : hi;
-  }
-  slots[t] = v;
+__global__ void col_pack_scalars_kernel(ColPack<T> p) {
+  col_pack_slot(p, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
+// slots (after the all-reduce) -> the four global scalars, combined in rank order, and the global team-timeout flag
 template <typename T>
-__global__ void col_unpack_scalars_kernel(const T* __restrict__ slots, int nranks, double* __restrict__ s4) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void col_unpack(const T* __restrict__ slots, int nranks, double* __restrict__ s4, double* __restrict__ team_err) {
   double gz = 0.0, ri = 0.0, dg = 0.0, rs = 0.0;
   for (int p = 0; p < nranks; ++p) {
     const T* q = slots + COL_SLOTS * p;
@@ -612,12 +604,39 @@ __global__ void col_unpack_scalars_kernel(const T* __restrict__ slots, int nrank
   s4[1] = ri;
   s4[2] = dg;
   s4[3] = rs;
+  if (team_err != nullptr && slots[COL_SLOTS * nranks] != T(0)) *team_err = 1.0;  // some rank's sweep timed out: every rank falls back
+}
+
+template <typename T>
+__global__ void col_unpack_scalars_kernel(const T* __restrict__ slots, int nranks, double* __restrict__ s4, double* __restrict__ team_err) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  col_unpack(slots, nranks, s4, team_err);
+}
+
+// After the all-reduce of [A v partial sums ; slots]: r = payload - b over the m rows (rows m .. ld of r stay as they are:
+// zero), f = f_scale ||r||^2 -> f_dst (fixed summation order), and -- the same launch -- the scalar slots combined into
+// dscal[PG_S_GZ ..].  One kernel where there were two (residual combination, unpack).
+template <typename T>
+__global__ __launch_bounds__(256) void col_combine_kernel(const T* __restrict__ payload, const T* __restrict__ b, T* __restrict__ r,
+                                                          int64_t m, double f_scale, double* __restrict__ red_partials,
+                                                          unsigned* __restrict__ red_counter, double* __restrict__ f_dst,
+                                                          const T* __restrict__ slots, int nranks, double* __restrict__ s4,
+                                                          double* __restrict__ team_err) {
+  double acc[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+    const T o = payload[i] - b[i];
+    r[i] = o;
+    acc[0] += (double)o * (double)o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) col_unpack(slots, nranks, s4, team_err);
+  const double ps[1] = {f_scale};
+  grid_reduce_finalize<1, 0u, 4>(acc, red_partials, red_counter, f_dst, ps);
 }
 
 template <typename T>
 pg_status col_ensure_cbuf(pg_ls* f) {
   if (f->cbuf) return PG_OK;
-  const size_t bytes = ((size_t)f->A->ld + COL_SLOTS * (size_t)f->ctx->shard_nranks + 64) * sizeof(T);
+  const size_t bytes = ((size_t)f->A->ld + COL_SLOTS * ((size_t)f->ctx->shard_nranks + 1) + 64) * sizeof(T);
   hipError_t e = hipMalloc(&f->cbuf, bytes);
   if (e != hipSuccess) {
     pg_set_error("hipMalloc for the column-sharding payload failed: %s", hipGetErrorString(e));
@@ -633,11 +652,18 @@ pg_status col_allreduce_scalars_t(pg_ls* f) {
   PG_TRY(col_ensure_cbuf<T>(f));
   T* slots = (T*)f->cbuf + f->A->ld;
   const int nr = c->shard_nranks;
-  hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((COL_SLOTS * nr + 63) / 64), dim3(64), 0, c->stream, slots, nr,
-                     c->shard_rank, (const double*)(c->dscal + PG_S_GZ));
+  const int nslots = COL_SLOTS * (nr + 1);
+  ColPack<T> pk;
+  pk.slots = slots;
+  pk.nranks = nr;
+  pk.rank = c->shard_rank;
+  pk.s4 = c->dscal + PG_S_GZ;
+  pk.team_err = nullptr;  // no sweep in flight on this path
+  hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((nslots + 63) / 64), dim3(64), 0, c->stream, pk);
   PG_LAUNCH_CHECK();
-  PG_TRY(do_allreduce(c, slots, COL_SLOTS * nr, f->A->dtype));
-  hipLaunchKernelGGL(col_unpack_scalars_kernel<T>, dim3(1), dim3(64), 0, c->stream, (const T*)slots, nr, c->dscal + PG_S_GZ);
+  PG_TRY(do_allreduce(c, slots, nslots, f->A->dtype));
+  hipLaunchKernelGGL(col_unpack_scalars_kernel<T>, dim3(1), dim3(64), 0, c->stream, (const T*)slots, nr, c->dscal + PG_S_GZ,
+                     (double*)nullptr);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -682,7 +708,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   pg_mat* A = f->A;
   if (pg_row_sharded(c) || !tn_supported<T>(A)) {
     pg_set_error("the single-sweep pass needs an unsharded or column-sharded operator with at most %d rows",
-                 (int)(128 * 1024 / sizeof(T)));
+                 (int)(1024 * (1024 / sizeof(T))));  // 1024 row groups: teams of up to 16 workgroups (pg_gemv_tn2.hip)
     return PG_ERR_UNSUPPORTED;
   }
   const bool cols = pg_col_sharded(c);
@@ -719,24 +745,31 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   int64_t fb = (A->ld + 63) / 64;
   if (fb > 1024) fb = 1024;
   if (cols) {
-    // [sum of the workgroup partials of A[:, J_p] v[J_p] ; this rank's four scalars in its slots] -> ONE all-reduce ->
-    // r = . - b and its norm ; scalars combined in rank order
+    // [sum of the workgroup partials of A[:, J_p] v[J_p] ; this rank's four scalars in its slots ; team-timeout flag] ->
+    // ONE all-reduce -> r = . - b and its norm ; scalars combined in rank order.  Three launches beside the sweep:
+    // finish (+ pack), the collective, combine (+ unpack).
     T* payload = (T*)f->cbuf;
     const int nr = c->shard_nranks;
+    ColPack<T> pk;
+    pk.slots = payload + A->ld;
+    pk.nranks = nr;
+    pk.rank = c->shard_rank;
+    pk.s4 = c->dscal + PG_S_GZ;
+    pk.team_err = c->dscal + PG_S_TEAMERR;
     {
       pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
       hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
                          (const T*)A->partials, A->ld, A->m, blocks, (const T*)nullptr, payload, A->ld, 0.0,
-                         (double*)nullptr, (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+                         (double*)nullptr, (unsigned*)nullptr, (double*)nullptr, (T*)nullptr, pk);
       PG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(col_pack_scalars_kernel<T>, dim3((COL_SLOTS * nr + 63) / 64), dim3(64), 0, c->stream, payload + A->ld,
-                       nr, c->shard_rank, (const double*)(c->dscal + PG_S_GZ));
-    PG_LAUNCH_CHECK();
-    PG_TRY(do_allreduce(c, payload, A->ld + COL_SLOTS * nr, A->dtype));
-    PG_TRY(pg_residual_combo_async(c, A->dtype, A->m, r_dst, 1.0, payload, -1.0, f->b, 0.5 * f->lam, nullptr, f_dst));
-    hipLaunchKernelGGL(col_unpack_scalars_kernel<T>, dim3(1), dim3(64), 0, c->stream, (const T*)(payload + A->ld), nr,
-                       c->dscal + PG_S_GZ);
+    PG_TRY(do_allreduce(c, payload, A->ld + COL_SLOTS * (nr + 1), A->dtype));
+    int64_t cb = (A->m + 1023) / 1024;
+    if (cb > 256) cb = 256;
+    if (cb < 1) cb = 1;
+    hipLaunchKernelGGL(col_combine_kernel<T>, dim3((unsigned)cb), dim3(256), 0, c->stream, (const T*)payload, (const T*)f->b, r_dst,
+                       A->m, 0.5 * f->lam, c->red_partials, c->red_counter, f_dst, (const T*)(payload + A->ld), nr,
+                       c->dscal + PG_S_GZ, c->dscal + PG_S_TEAMERR);
     PG_LAUNCH_CHECK();
     if (r_dst == (T*)f->r) f->r_gen++;
     return PG_OK;
@@ -745,7 +778,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
                      (const T*)A->partials, A->ld, A->m, blocks, (const T*)f->b, r_dst,
                      r_dst == (T*)f->r ? A->ld : A->m /* only f->r is padded to ld */, 0.5 * f->lam,
-                     c->red_partials, c->red_counter, f_dst, (T*)nullptr);
+                     c->red_partials, c->red_counter, f_dst, (T*)nullptr, ColPack<T>{});
   PG_LAUNCH_CHECK();
   if (r_dst == (T*)f->r) f->r_gen++;
   return PG_OK;
@@ -759,7 +792,7 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
                          T* y, T* z_new, T* res, T* Az_out) {
   pg_ctx* c = A->ctx;
   if (pg_row_sharded(c) || pg_col_sharded(c) || !tn_supported<T>(A)) {
-    pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(128 * 1024 / sizeof(T)));
+    pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(1024 * (1024 / sizeof(T))));
     return PG_ERR_UNSUPPORTED;
   }
   if (A->rpad == nullptr) {  // r zero-padded to the leading dimension (the kernel reads whole 1 KiB row groups)
@@ -800,7 +833,7 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
   pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
   hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
                      (const T*)A->partials, A->ld, A->m, blocks, (const T*)nullptr, Az_out, A->m, 0.0, (double*)nullptr,
-                     (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+                     (unsigned*)nullptr, (double*)nullptr, (T*)nullptr, ColPack<T>{});
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

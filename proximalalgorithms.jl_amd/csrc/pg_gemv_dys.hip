@@ -93,7 +93,7 @@ pg_status mat_fused_dys_t(pg_mat* A, const T* r, const T* xg, const T* z, double
   pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
   hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
                      (const T*)A->partials, A->ld, A->m, blocks, (const T*)nullptr, A_xg_next, A->m, 0.0, (double*)nullptr,
-                     (unsigned*)nullptr, (double*)nullptr, (T*)nullptr);
+                     (unsigned*)nullptr, (double*)nullptr, (T*)nullptr, ColPack<T>{});
   PG_LAUNCH_CHECK();
   return PG_OK;
 }

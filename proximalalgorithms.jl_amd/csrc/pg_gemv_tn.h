@@ -72,6 +72,7 @@ struct TNArgs {
   // workgroup teams (gemv_tnt_kernel, columns longer than one workgroup's registers): team_size workgroups split the rows
   // of every column; their per-column partial dots meet in xch, a ring of tagged 8-byte granules per team
   int team_size = 1, nteams = 0;
+  unsigned tag_base = 0;  // launch epoch << 24: the tag of step i is tag_base + i + 1, so granules of earlier launches never match
   unsigned long long* xch = nullptr;  // [nteams][ring][team_size * C * granules-per-value]
   double* team_err = nullptr;         // set to 1 when a team member gave up waiting (bounded spin)
 #ifdef PG_TNT_EXPERIMENT
@@ -276,17 +277,47 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
 // f = f_scale * sum_i y[i]^2 -> f_out (+ typed copy for the all-reduce payload).
 // 1024 threads = 64 rows x 16 slot groups; row groups are grid-strided.
 // -------------------------------------------------------------------------------------------------
+// Column shards: the scalar slots behind the m-vector of the all-reduce payload (pg_gemv.hip, "column sharding").  Every rank
+// owns COL_SLOTS working-precision words -- its four epilogue scalars as (hi, lo) pairs -- that are zero on all other ranks,
+// so the SUM all-reduce acts as an all-gather; one more group of COL_SLOTS words behind them is shared: word 0 carries this
+// rank's team-timeout flag (PG_S_TEAMERR), whose sum tells EVERY rank that some rank's sweep failed (they must fall back
+// together: the two-sweep retry issues a different collective).
+constexpr int COL_SLOTS = 8;
+template <typename T>
+struct ColPack {
+  T* slots = nullptr;  // [COL_SLOTS * nranks + COL_SLOTS]; nullptr: nothing to pack
+  int nranks = 0, rank = 0;
+  const double* s4 = nullptr;        // this rank's { g(z), ||res||_inf, <g, res>, ||res||^2 }
+  const double* team_err = nullptr;  // this rank's PG_S_TEAMERR
+};
+template <typename T>
+__device__ __forceinline__ void col_pack_slot(const ColPack<T>& p, int t) {
+  if (t >= COL_SLOTS * (p.nranks + 1)) return;
+  T v = T(0);
+  if (t / COL_SLOTS == p.rank) {
+    const double d = p.s4[(t % COL_SLOTS) >> 1];
+    const T hi = (T)d;
+    v = (t & 1) ? (T)(d - (double)hi) : hi;
+  } else if (t == COL_SLOTS * p.nranks) {
+    v = (p.team_err != nullptr && *p.team_err != 0.0) ? T(1) : T(0);
+  }
+  p.slots[t] = v;
+}
+
 template <typename T, bool WITH_F>
 __global__ __launch_bounds__(1024) void gemv_n_finish_kernel(const T* __restrict__ partials, int64_t ld, int64_t m,
                                                              int S, const T* __restrict__ b, T* __restrict__ y,
                                                              int64_t y_len, double f_scale,
                                                              double* __restrict__ red_partials,
                                                              unsigned* __restrict__ red_counter,
-                                                             double* __restrict__ f_out, T* __restrict__ f_out_typed) {
+                                                             double* __restrict__ f_out, T* __restrict__ f_out_typed,
+                                                             ColPack<T> pack) {
   __shared__ double sm_rows[16][64];
   const int rx = threadIdx.x & 63;
   const int sg = threadIdx.x >> 6;
   double sq = 0.0;
+  // column shards: the scalar slots of the all-reduce payload ride in this launch (they were their own kernel before)
+  if (pack.slots != nullptr && blockIdx.x == 0) col_pack_slot(pack, (int)threadIdx.x);
   for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < ld; row0 += (int64_t)gridDim.x * 64) {
     const int64_t i = row0 + rx;
     double acc = 0.0;

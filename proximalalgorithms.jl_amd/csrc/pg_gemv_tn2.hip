@@ -21,6 +21,8 @@
 // fast_forward_backward.jl:135-142); both are reached through launch_tn in pg_gemv.hip.
 #include <type_traits>
 
+#include <mutex>
+
 #include "pg_gemv_tn.h"
 
 namespace pgtn {
@@ -437,7 +439,9 @@ struct Pending {
 // of every member polls the team_size * C * G granules of a step (one lane per granule), then sums the values in member
 // order.  A member posts step i only after it has consumed step i - LAG - 1, i.e. after ALL members have posted step
 // i - LAG - 1, which each of them did after consuming step i - 2 LAG - 2: a ring of 2 LAG + 2 slots is never
-// overwritten before everyone has read it.  The ring is zeroed before every launch (tags start at 1).
+// overwritten before everyone has read it.  Tags carry the launch epoch in their high byte (tag = epoch << 24 | i + 1, i + 1
+// < 2^24), so the ring needs no zeroing between launches: every slot is rewritten by every launch (the step count of a
+// matrix is fixed), and a granule left by the launch 256 epochs ago has been overwritten 255 times since.
 //
 // Where the column tiles live.  PF + 1 register tiles rotate (one being dotted, PF being loaded), as in
 // gemv_tn_kernel.  A tile whose totals are still travelling (LAG > 0) is parked in LDS -- LAG slots of
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         const unsigned long long b = __builtin_bit_cast(unsigned long long, mine);
         bits = (lane % G) == 0 ? (unsigned)b : (unsigned)(b >> 32);
       }
-      const unsigned long long word = ((unsigned long long)(unsigned)(i + 1) << 32) | bits;
+      const unsigned long long word = ((unsigned long long)(a.tag_base + (unsigned)(i + 1)) << 32) | bits;
       __hip_atomic_store(ring + (size_t)(i % TEAM_RING) * (TEAM_MAX * C * G) + (size_t)member * (C * G) + lane, word,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   };
   // totals of step i (all members have posted, or will shortly) -> epilogue -> v_j (0 for columns past the end)
   auto totals = [&](int64_t i, Pending<T, C>& pd, T (&vj)[C]) __attribute__((always_inline)) {
-    const unsigned tag = (unsigned)(i + 1);
+    const unsigned tag = a.tag_base + (unsigned)(i + 1);
 #ifdef PG_TNT_EXPERIMENT
     if (a.dbg & 1) dead = true;  // timing experiment: never wait (totals are then wrong)
 #endif
@@ -760,7 +764,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   if (env_int("PG_TN_TEAM", 0) > TM) TM = env_int("PG_TN_TEAM", 0);  // experiments: more (partly idle) members
   if (TM < 1) TM = 1;
   if (TM > TEAM_MAX) {
-    pg_set_error("the single-sweep pass covers columns of at most %d rows", (int)(TEAM_MAX * per_member * 1024 / sizeof(T)));
+    pg_set_error("the single-sweep pass covers columns of at most %d rows", (int)(TEAM_MAX * per_member * (1024 / sizeof(T))));
     return PG_ERR_UNSUPPORTED;
   }
   // every member must be resident at once (they wait for each other): one workgroup per CU at most
@@ -773,7 +777,9 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     return PG_ERR_UNSUPPORTED;
   }
   const size_t xch_bytes = (size_t)nteams * TEAM_RING * (size_t)(TEAM_MAX * C * G) * sizeof(unsigned long long);
+  bool fresh_ring = false;
   if (A->xch == nullptr || A->xch_bytes < xch_bytes) {
+    fresh_ring = true;
     if (A->xch) {
       PG_HIP(hipStreamSynchronize(c->stream));
       PG_HIP(hipFree(A->xch));
@@ -786,7 +792,10 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     }
     A->xch_bytes = xch_bytes;
   }
-  PG_HIP(hipMemsetAsync(A->xch, 0, xch_bytes, c->stream));
+  const long long layout = ((long long)nteams << 20) | ((long long)TM << 8) | (long long)(C * G);
+  if (layout != A->xch_layout) fresh_ring = true;
+  A->xch_layout = layout;
+  if (fresh_ring) PG_HIP(hipMemsetAsync(A->xch, 0, xch_bytes, c->stream));
   PG_TRY(ensure_partials(A, (int)nteams));
   a.partials = (T*)A->partials;
   a.team_size = TM;
@@ -795,28 +804,61 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     pg_set_error("gemv_tnt<U = %d> launched for %d row groups per wave", U, a.ueff);
     return PG_ERR_INVALID;
   }
+  const int64_t steps = (ncg + nteams - 1) / nteams;
+  if (steps + 1 >= (1 << 24)) {
+    pg_set_error("the long-column sweep covers at most 2^24 column groups per team (%lld here)", (long long)steps);
+    return PG_ERR_UNSUPPORTED;
+  }
   a.nteams = (int)nteams;
   a.xch = (unsigned long long*)A->xch;
   a.team_err = c->dscal + PG_S_TEAMERR;
+  A->xch_epoch = (A->xch_epoch % 255u) + 1u;  // 1 .. 255: never the all-zero tag of a fresh ring
+  a.tag_base = A->xch_epoch << 24;
 #ifdef PG_TNT_EXPERIMENT
   a.dbg = env_int("PG_TNT_DBG", 0);
 #endif
   *blocks_out = (int)nteams;
-  // LDS for the parked tiles: LAG slots of WAVES * C * U KiB; more than 64 KiB of dynamic LDS is opted into once
+  // LDS for the parked tiles: LAG slots of WAVES * C * U KiB on top of the kernel's static LDS (the dot exchange and the grid
+  // reduction's scratch); anything beyond the default 64 KiB limit is opted into once per device
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
-  if (lds > 64 * 1024) {
+  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>);
+  if (lds + 4096 > 64 * 1024) {
+    static std::mutex mu;
     static bool opted_in[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
     const int dev = c->device & 63;
     if (!opted_in[dev]) {
-      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      PG_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       opted_in[dev] = true;
     }
   }
+  // Every member of every team must be resident at once (they wait for each other).  A cooperative launch makes that the
+  // runtime's promise instead of this file's assumption: it is refused when the grid cannot be co-resident with this
+  // kernel's registers and LDS, and the cooperative queue keeps a second cooperative grid from interleaving with it.
+  // What it cannot promise is that nothing ELSE holds compute units for the whole duration (another process, a kernel of
+  // another stream that itself waits for this one): the members' waits are bounded for that case (TEAM_SPIN_LIMIT ->
+  // PG_S_TEAMERR -> PG_ERR_TIMEOUT at the next scalar read-back, which the iterations turn into a two-sweep retry).
+  unsigned grid = (unsigned)(nteams * TM);
+  c->team_launches++;
+  if (c->test_team_fault > 0 && c->team_launches == c->test_team_fault && TM > 1)
+    grid -= 1;  // test hook: the last member of the last team is never started, its team-mates time out
   pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>), dim3((unsigned)(nteams * TM)), dim3(WAVES * 64), lds,
-                     c->stream, a);
-  PG_LAUNCH_CHECK();
+  if (c->team_plain_launch || c->capturing) {  // (stream capture records plain launches only)
+    hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+    PG_LAUNCH_CHECK();
+    return PG_OK;
+  }
+  void* args[1] = {(void*)&a};
+  hipError_t e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(WAVES * 64), args, (unsigned)lds, c->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    pg_set_error("cooperative launch of the long-column sweep (%u workgroups of %d threads, %zu bytes of LDS) was refused: %s",
+                 grid, WAVES * 64, lds, hipGetErrorString(e));
+    return e == hipErrorCooperativeLaunchTooLarge || e == hipErrorInvalidConfiguration || e == hipErrorInvalidValue ||
+                   e == hipErrorNotSupported
+               ? PG_ERR_UNSUPPORTED
+               : PG_ERR_HIP;
+  }
   return PG_OK;
 }
 

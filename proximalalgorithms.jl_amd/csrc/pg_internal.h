@@ -78,6 +78,7 @@ struct pg_comm {
   hipStream_t side = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   int nranks = 1, rank = 0;
+  int64_t calls = 0, elements = 0;  // telemetry: all-reduces issued through the native path and their total length
 };
 
 struct pg_ctx {
@@ -106,6 +107,13 @@ struct pg_ctx {
   size_t dr_ws_bytes = 0;
   hipEvent_t dr_ev[2] = {nullptr, nullptr};
   size_t coop_ws_bytes = 0;
+  // long-column sweep (gemv_tnt_kernel, pg_gemv_tn2.hip): a timeout seen by the last scalar read-back, and the test hook
+  // PG_TEST_TEAM_FAULT = k (read once, here): the k-th team launch on this context (1-based) goes out with one workgroup
+  // missing, so that one team times out
+  bool team_timeout = false;
+  int test_team_fault = 0;
+  long team_launches = 0;
+  bool team_plain_launch = false;  // PG_TN_TEAM_PLAIN = 1: plain instead of cooperative launch (A/B measurements)
   // stream capture (pg_ctx_capture_begin / _end): launches are recorded into a hipGraph instead of executed; scalar
   // read-backs are skipped (their host values are not meaningful until the graph has run)
   bool capturing = false;
@@ -142,6 +150,8 @@ struct pg_mat {
   void* rpad = nullptr;  // [ld] zero-padded copy of a caller's m-vector (pg_mat_fused_tn)
   void* xch = nullptr;   // granule ring of the workgroup teams of the long-column sweep (gemv_tnt_kernel)
   size_t xch_bytes = 0;
+  unsigned xch_epoch = 0;     // launch epoch of the ring (1 .. 255, the high byte of every granule tag: no memset per launch)
+  long long xch_layout = -1;  // (nteams, team size, C) the ring was last used with; a change re-zeroes it
 };
 
 struct pg_ls {

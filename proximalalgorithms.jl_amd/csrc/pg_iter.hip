@@ -190,6 +190,31 @@ pg_status read_sweep_scalars(pg_iter* it) {
   return PG_OK;
 }
 
+// The sweep of this iteration could not be used: refused at launch (PG_ERR_UNSUPPORTED: nothing was written; it would be
+// refused again, so the iterator leaves the single-sweep mode) or one of its workgroup teams timed out (PG_ERR_TIMEOUT:
+// grad, y, z, res, x_next and the sweep's residual output are garbage; x, z_prev and, when the sweep wrote its residual
+// elsewhere, f->r are intact).  Nothing of the sweep had been committed -- its outputs only become state when the NEXT
+// step swaps them in -- so the second half of the iteration (fast_forward_backward.jl:138-142 / forward_backward.jl:113-120)
+// is redone here the reference's way, A x then A' r, and the step reports PG_FLAG_SWEEP_FALLBACK.  With column shards every
+// rank gets here in the same step (the timeout flag travels with the all-reduce payload), so the collectives still pair up.
+template <typename T>
+pg_status redo_with_two_sweeps(pg_iter* it, pg_status why, bool residual_intact) {
+  pg_ctx* c = it->ctx;
+  c->team_timeout = false;
+  it->sp_ready = false;
+  it->flags |= PG_FLAG_SWEEP_FALLBACK;
+  if (why == PG_ERR_UNSUPPORTED) it->single_sweep = false;
+  if (residual_intact) {  // f->r = A x - b and dscal[PG_S_F] = f(x) are still those of x: only A' r is missing
+    PG_TRY(pg_ls_grad_stage_async(it->f, it->grad_f_x));
+  } else {
+    PG_TRY(pg_ls_vg_async(it->f, it->x, it->grad_f_x));
+  }
+  if (it->rz_prev != nullptr) it->rz_valid = false;
+  return epilogue_and_read<T>(it, true);
+}
+
+static inline bool sweep_lost(pg_status st) { return st == PG_ERR_UNSUPPORTED || st == PG_ERR_TIMEOUT; }
+
 template <typename T>
 pg_status iter_step_single_sweep(pg_iter* it) {
   pg_ctx* c = it->ctx;
@@ -225,13 +250,16 @@ pg_status iter_step_single_sweep(pg_iter* it) {
       SeqState<T> s2 = seq_load<T>(it);
       const double beta2 = (double)seq_next_hd<T>(o.seq_kind, (T)o.mf, (T)o.seq_p0, (T)o.seq_p1, s2, (T)it->gamma, T(0));
       it->sp_slot ^= 1;
-      PG_TRY(pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev, it->gamma,
-                                    beta2, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, it->x_next));
+      pg_status st = pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev,
+                                            it->gamma, beta2, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res,
+                                            it->x_next);
+      if (st == PG_OK && !it->defer_sync) st = read_sweep_scalars<T>(it);
+      if (sweep_lost(st) && !it->defer_sync) return redo_with_two_sweeps<T>(it, st, false);
+      PG_TRY(st);
       it->sp_beta = beta2;
       it->spec_stepsize = (double)s2.stepsize, it->spec_theta = (double)s2.theta, it->spec_t = (double)s2.t, it->spec_k = s2.k;
       it->sp_gen = f->r_gen;
       it->sp_ready = true;
-      if (!it->defer_sync) PG_TRY(read_sweep_scalars<T>(it));
     } else {
       // ---- ForwardBackward, fixed step: forward_backward.jl:111-120 (the next point is the prox output itself) ----
       const bool fresh_first_half = !(it->sp_ready && it->sp_gen == f->r_gen);
@@ -248,11 +276,13 @@ pg_status iter_step_single_sweep(pg_iter* it) {
         it->fx_src = PG_S_FNEXT + it->sp_slot;
       }
       it->sp_slot ^= 1;
-      PG_TRY(pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->x, it->gamma, 0.0,
-                                    o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr));
+      pg_status st = pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->x, it->gamma,
+                                            0.0, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr);
+      if (st == PG_OK && !it->defer_sync) st = read_sweep_scalars<T>(it);
+      if (sweep_lost(st) && !it->defer_sync) return redo_with_two_sweeps<T>(it, st, false);
+      PG_TRY(st);
       it->sp_gen = f->r_gen;
       it->sp_ready = true;
-      if (!it->defer_sync) PG_TRY(read_sweep_scalars<T>(it));
     }
     return PG_OK;
   }
@@ -296,11 +326,16 @@ pg_status iter_step_single_sweep(pg_iter* it) {
   std::swap(it->rz_prev, it->rz);  // the residual at the new z_prev
   // A' r, prox (:138-142) and the residual of the NEW z for the next line search, one sweep
   it->sp_slot ^= 1;
-  PG_TRY(pg_ls_fused_pass_async(f, f->r, it->rz, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev, it->gamma, 0.0,
-                                o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr));
+  pg_status st = pg_ls_fused_pass_async(f, f->r, it->rz, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev, it->gamma, 0.0,
+                                        o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr);
+  if (st == PG_OK) st = read_sweep_scalars<T>(it);
+  if (sweep_lost(st)) {  // the sweep read f->r and wrote rz: the residual of x and f(x) (PG_S_F) are intact
+    it->rz_valid = false;
+    return redo_with_two_sweeps<T>(it, st, true);
+  }
+  PG_TRY(st);
   it->sp_ready = true;
   it->rz_valid = false;
-  PG_TRY(read_sweep_scalars<T>(it));
   it->f_x = Arith<T>::r(c->hscal[PG_S_F]);  // from the residual combination
   return PG_OK;
 }

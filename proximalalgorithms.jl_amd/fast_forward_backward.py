@@ -1,5 +1,6 @@
 """FastForwardBackward (accelerated proximal gradient / FISTA) -- mirror of
 src/algorithms/fast_forward_backward.jl.  Engines as in forward_backward.py."""
+import copy
 import itertools
 
 import numpy as np
@@ -75,9 +76,15 @@ class FastForwardBackwardIteration:
         if isinstance(s, ConstantNesterovSequence) and np.dtype(s.R) == R:
             return _lib.PG_SEQ_CONSTANT, float(s.m), float(s.stepsize), None
         if isinstance(s, itertools.repeat):  # Iterators.repeated(beta): the library repeats the value itself
-            beta = next(iter(s))
-            if isinstance(beta, (float, np.floating)) and float(R.type(beta)) == float(beta):
-                return _lib.PG_SEQ_REPEATED, float(beta), 0.0, None
+            try:  # only the INFINITE form (a finite repeat(beta, times) is exhausted after `times` draws, like the
+                s.__length_hint__()  # reference's Iterators.Stateful): asking it for a length raises TypeError
+                infinite = False
+            except TypeError:
+                infinite = True
+            if infinite:
+                beta = next(copy.copy(s))  # the caller's iterator is left untouched
+                if isinstance(beta, (float, np.floating)) and float(R.type(beta)) == float(beta):
+                    return _lib.PG_SEQ_REPEATED, float(beta), 0.0, None
         return _lib.PG_SEQ_HOST, 0.0, 0.0, iter(s)  # Iterators.Stateful(seq)  (:90-92)
 
     def _iter_fused(self):
@@ -99,6 +106,9 @@ class FastForwardBackwardIteration:
             state.n_backtracks = sc.n_backtracks
             self.counters["backtracks"] = self.counters.get("backtracks", 0) + sc.n_backtracks
             self.counters["a_passes"] = sc.a_passes
+            state.flags = sc.flags
+            if sc.flags & _lib.PG_FLAG_SWEEP_FALLBACK:  # this step's single sweep was lost and redone with two sweeps
+                self.counters["sweep_fallbacks"] = self.counters.get("sweep_fallbacks", 0) + 1
 
         refresh(fi.init(self.x0))
         yield state

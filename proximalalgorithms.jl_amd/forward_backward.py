@@ -10,7 +10,7 @@ from .algorithm import IterativeAlgorithm
 from .device import as_hipvector
 from .fb_tools import backtrack_stepsize_, lower_bound_smoothness_constant
 from .operators import Zero, fused_supported, prox_, value_and_gradient
-from . import _composed
+from . import _composed, _lib
 from ._composed import composed_supported
 from ._fused import FusedIteration
 
@@ -109,6 +109,9 @@ class ForwardBackwardIteration:
             state.n_backtracks = sc.n_backtracks
             self.counters["backtracks"] = self.counters.get("backtracks", 0) + sc.n_backtracks
             self.counters["a_passes"] = sc.a_passes
+            state.flags = sc.flags
+            if sc.flags & _lib.PG_FLAG_SWEEP_FALLBACK:  # this step's single sweep was lost and redone with two sweeps
+                self.counters["sweep_fallbacks"] = self.counters.get("sweep_fallbacks", 0) + 1
 
         refresh(fi.init(self.x0))
         yield state

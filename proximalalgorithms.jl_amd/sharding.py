@@ -111,9 +111,18 @@ class TorchDistributedComm:
         ctx.set_column_sharding(self.world_size if self.shard == "cols" else 0, self.rank)
 
 
+def native_rccl_available():
+    """True when the library can bind RCCL itself (dlopen librccl): the collective then needs no host callback."""
+    from ._lib import load
+
+    return bool(load().pg_comm_available())
+
+
 class NativeRcclComm:
     """The library's own RCCL communicator (csrc/pg_comm.hip): no Python in the collective path.  The 128-byte
-    ncclUniqueId is created on rank 0 and shipped with torch.distributed (any backend) when world_size > 1."""
+    ncclUniqueId is created on rank 0 and shipped with torch.distributed (any backend) when world_size > 1.  A context
+    keeps ONE communicator for the life of the job: further NativeRcclComm objects attached to it reuse that communicator
+    and only switch the layout (rows / cols) and the overlap mode."""
 
     def __init__(self, world_size=None, rank=None, overlap=False, shard="rows"):
         import torch.distributed as dist
@@ -128,6 +137,27 @@ class NativeRcclComm:
             rank = dist.get_rank() if initialised else 0
         self.world_size, self.rank, self.overlap = int(world_size), int(rank), bool(overlap)
         self._ctx = None
+        self._calls0 = self._elements0 = 0
+
+    def _stats(self):
+        import ctypes as C
+
+        from ._lib import call
+
+        if self._ctx is None:
+            return 0, 0
+        calls, elements = C.c_int64(0), C.c_int64(0)
+        call("pg_ctx_comm_stats", self._ctx.handle, C.byref(calls), C.byref(elements))
+        return calls.value - self._calls0, elements.value - self._elements0
+
+    @property
+    def calls(self):
+        """all-reduces issued through this communicator since it was attached"""
+        return self._stats()[0]
+
+    @property
+    def elements(self):
+        return self._stats()[1]
 
     def attach(self, ctx):
         import ctypes as C
@@ -141,16 +171,23 @@ class NativeRcclComm:
         if self._ctx is not None:
             raise RuntimeError("a NativeRcclComm is bound to one context")
         ident = C.create_string_buffer(128)
-        if self.rank == 0:
-            call("pg_comm_get_unique_id", ident)
-        if self.world_size > 1:
-            box = [bytes(ident.raw) if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ident = C.create_string_buffer(box[0], 128)
+        shape = getattr(ctx, "_native_comm_shape", None)
+        if shape is None:
+            if self.rank == 0:
+                call("pg_comm_get_unique_id", ident)
+            if self.world_size > 1:
+                box = [bytes(ident.raw) if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ident = C.create_string_buffer(box[0], 128)
+        elif shape != (self.world_size, self.rank):
+            raise RuntimeError("the context already has a communicator for world_size=%d rank=%d" % shape)
         call("pg_ctx_comm_init", ctx.handle, ident, self.world_size, self.rank,
              1 if (self.overlap and self.shard == "rows") else 0)
+        ctx._native_comm_shape = (self.world_size, self.rank)
         ctx.set_column_sharding(self.world_size if self.shard == "cols" else 0, self.rank)
         self._ctx = ctx
+        self._calls0, self._elements0 = 0, 0
+        self._calls0, self._elements0 = self._stats()
 
 
 class ScaleComm:

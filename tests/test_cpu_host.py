@@ -109,51 +109,140 @@ def test_bench_cli_parses_without_gpu():
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
 
 
-def test_bench_self_launches_ranks_as_a_child(monkeypatch, capsys):
-    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): before anything touches the GPU the script starts
-    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (subprocess, never exec), relays the
-    child's single JSON line and returns its exit code."""
+def _load_bench(name="bench_mod"):
     import importlib.util
-    import json
 
-    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    seen = {}
+    return bench
 
-    class Done:
-        def __init__(self, rc, out):
-            self.returncode, self.stdout = rc, out
 
-    def fake_run(cmd, stdout=None, env=None, **kw):
-        seen["cmd"], seen["env"] = cmd, env
-        return Done(seen["rc"], seen["out"])
+def test_bench_self_launches_ranks_as_a_child(monkeypatch, capfd):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): before anything touches the GPU the script starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (own process group, never exec), relays the
+    child's single JSON line and returns its exit code.  Whatever the child does -- exits non-zero, prints nothing, never
+    returns -- stdout still carries ONE JSON line naming the error and the stage."""
+    import json
 
-    monkeypatch.setattr(bench.subprocess, "run", fake_run)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    bench = _load_bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2", "--launch-timeout", "4"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    line = json.dumps({"metric": "m", "value": 1.0, "n_gpus": 4})
-    seen["rc"], seen["out"] = 0, ("NCCL banner\n" + line + "\n").encode()
-    with pytest.raises(SystemExit) as e:
-        bench.main()
-    assert e.value.code == 0
-    assert capsys.readouterr().out.strip() == line  # exactly the child's JSON line
-    cmd = seen["cmd"]
+    args = bench.parse_args(sys.argv[1:])
+    cmd = bench.launch_command(args, 29999)
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
     k = cmd.index(os.path.join(ROOT, "bench.py"))
-    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
-    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    # a failing child: its exit code comes back, nothing is printed
-    seen["rc"], seen["out"] = 3, b"Traceback ...\n"
-    with pytest.raises(SystemExit) as e:
-        bench.main()
-    assert e.value.code == 3 and capsys.readouterr().out == ""
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--launch-timeout", "4"]
+
+    def child(code):
+        # the child reports what it was given: its own process group (killpg must not reach pytest) and the IPC setting
+        pre = "import os,sys,time,json; assert os.getpgid(0) == os.getpid(); assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'; "
+        monkeypatch.setattr(bench, "launch_command", lambda a, port: [sys.executable, "-c", pre + code])
+
+    def run():
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        out = capfd.readouterr().out.splitlines()
+        assert len(out) == 1, out  # exactly one line on stdout, always
+        return e.value.code, json.loads(out[0])
+
+    line = {"metric": "m", "value": 1.0, "n_gpus": 4}
+    child("print('NCCL banner'); print(json.dumps(%r))" % line)
+    rc, d = run()
+    assert rc == 0 and d == line  # exactly the child's JSON line
+    # a failing child: its exit code comes back together with an error line that carries the end of its stderr
+    child("sys.stderr.write('Traceback ...\\nRuntimeError: boom\\n'); sys.exit(3)")
+    rc, d = run()
+    assert rc == 3 and d["value"] is None and "code 3" in d["error"] and d["stage"] == "launch" and d["n_gpus"] == 4
+    assert any("boom" in ln for ln in d["stderr_tail"]) and d["metric"].startswith("FastForwardBackward")
+    # a failing child that printed its own (error) line: that line is relayed, the exit code kept
+    child("print(json.dumps({'metric': 'm', 'value': None, 'error': 'timeout', 'stage': 'main'})); sys.exit(3)")
+    rc, d = run()
+    assert rc == 3 and d["error"] == "timeout" and d["stage"] == "main"
     # a child that exits 0 without a line is an error, not a silent success
-    seen["rc"], seen["out"] = 0, b""
-    with pytest.raises(SystemExit) as e:
-        bench.main()
-    assert e.value.code == 1
+    child("pass")
+    rc, d = run()
+    assert rc == 1 and d["value"] is None and "without a JSON line" in d["error"]
+    # a child that never returns: ended after --launch-timeout (SIGTERM to its group, then SIGKILL), exit code 124
+    import time
+
+    t0 = time.time()
+    child("import signal; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(3600)")
+    rc, d = run()
+    assert rc == 124 and d["error"] == "timeout" and d["stage"].startswith("launch") and 4 <= time.time() - t0 < 40
+    # ... and one that prints the line it has when it is told to stop (what rank 0 does on SIGTERM)
+    child("import signal\ndef h(*a):\n print(json.dumps({'metric': 'm', 'value': 2.0, 'error': 'terminated', 'stage': 'rows_strong'}), flush=True); os._exit(0)\n"
+          "signal.signal(signal.SIGTERM, h); time.sleep(3600)")
+    rc, d = run()
+    assert rc == 124 and d["value"] == 2.0 and d["error"] == "terminated" and d["stage"] == "rows_strong"
+
+
+def test_bench_without_a_gpu_still_prints_a_line():
+    """`python3 bench.py --gpus 2` on a box without a GPU: an error JSON line instead of nothing (VERDICT r2 next-round 1 "done" test)."""
+    import json
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the GPU-less container")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "3",
+                          "--warmup", "1", "--launch-timeout", "240"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["error"] and d["stage"] in ("init", "import", "launch")
+
+
+def test_bench_watchdog_prints_the_partial_line(tmp_path):
+    """The per-record deadline inside a rank: when the main thread hangs, rank 0 writes the line it has (`error`, `stage`, the
+    records measured so far) and the process leaves with 0 when the top-level record was measured, else 3; a stalled record
+    (no progress mark) is caught before its deadline; SIGTERM takes the same path while the main thread is blocked."""
+    import json
+    import subprocess
+
+    prog = """
+import json, os, signal, sys, time
+sys.path.insert(0, %r)
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(%r, "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+mode = sys.argv[1]
+signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+args = bench.parse_args(["--workload", "small"])
+job = bench.Job(args, 1, 0)
+job.json_fd = os.dup(1)
+wd = bench.Watchdog(0, 1.0 if mode == "stall" else 30.0, job.write, inject="0:rows_strong:hang" if mode == "inject" else None)
+if mode in ("main_done", "inject", "sigterm"):
+    job.main_rec = {"value": 5.0, "ms_per_step": 200.0, "config": {"workload": "w"}, "roofline": {"kernel": "gemv_tn", "frac": 0.5}}
+    job.extra["config5_weak_cols"] = {"value": 7.0, "ms_per_step": 1.0, "roofline": {"kernel": "gemv_tn", "frac": 0.8}}
+    wd.main_done = True
+if mode == "sigterm":
+    wd.enter("config5_weak_rows", 60.0)
+    os.kill(os.getpid(), signal.SIGTERM)
+    time.sleep(30)
+wd.enter("rows_strong" if mode != "deadline" else "main", 60.0 if mode == "stall" else 1.0)
+time.sleep(30)
+""" % (ROOT, ROOT)
+    script = tmp_path / "wd.py"
+    script.write_text(prog)
+    for mode, rc, stage in (("deadline", 3, "main"), ("stall", 3, "rows_strong"), ("main_done", 0, "rows_strong"),
+                            ("inject", 0, "rows_strong"), ("sigterm", 0, "config5_weak_rows")):
+        out = subprocess.run([sys.executable, str(script), mode], capture_output=True, text=True, timeout=60)
+        assert out.returncode == rc, (mode, out.returncode, out.stderr[-2000:])
+        lines = out.stdout.splitlines()
+        assert len(lines) == 1, (mode, out.stdout)
+        d = json.loads(lines[0])
+        assert d["stage"] == stage and d["error"], (mode, d)
+        assert ("no progress" in d["error"]) == (mode == "stall") and ("SIGTERM" in d["error"]) == (mode == "sigterm")
+        if rc == 0:  # the measured records survive, with the compact summary nested under config
+            assert d["value"] == 5.0 and d["config5_weak_cols"]["value"] == 7.0
+            assert d["config"]["layouts_summary"]["config5_weak_cols"] == [7.0, 1.0, "gemv_tn", 0.8]
+        else:
+            assert d["value"] is None
 
 
 def test_pmc_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):

@@ -625,6 +625,68 @@ def test_bench_self_launched_two_ranks_reports_every_layout(pa):
     assert d["config5_weak_rows"]["config"]["final"]["f_x"] == pytest.approx(d["config5_weak_cols"]["config"]["final"]["f_x"], rel=5e-4)
 
 
+@pytest.mark.parametrize("stage,kind", [("main", "hang"), ("main", "exit"), ("rows_strong", "hang"), ("config5_weak_rows", "exit")])
+def test_bench_rank_failure_still_prints_a_line(pa, stage, kind):
+    """A rank that hangs forever or dies inside a record: stdout still carries ONE JSON line with
+    `error` and `stage`.  While the top-level record is not measured the line says value = null and the exit code is non-zero;
+    once it is, the records measured so far survive in the line and a hang in a later record ends with exit code 0."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--workload", "small",
+           "--steps", "6", "--warmup", "1", "--inject-fault", "1:%s:%s" % (stage, kind), "--record-timeout", "40",
+           "--sub-record-timeout", "25", "--stall-timeout", "12", "--launch-timeout", "240"]
+    t0 = time.time()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    took = time.time() - t0
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["error"] and d["stage"] == stage, d
+    assert took < 200, took  # the job's own deadlines ended it, not --launch-timeout
+    if stage == "main":
+        assert d["value"] is None and out.returncode != 0
+    else:
+        assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["sharding"] == "cols"
+        if stage == "config5_weak_rows":  # rows_strong was measured before the failure and is in the line
+            assert d["rows_strong"]["value"] > 0 and d["config"]["layouts_summary"]["rows_strong"][0] == d["rows_strong"]["value"]
+        if kind == "hang":
+            assert out.returncode == 0 and "timeout" in d["error"]
+    assert d["job"]["backend"] == "gloo" and d["job"]["ranks_seen_by_rccl"] == 2 and d["job"]["collective"] == "torch"
+
+
+@pytest.mark.parametrize("mode,cols", [("fixed", False), ("adaptive", False), ("fixed", True)])
+def test_team_sweep_timeout_falls_back_to_two_sweeps(pa, mode, cols):
+    """65536 x 8192 (teams of four workgroups per column group): the third team launch of the solve goes out with one
+    workgroup missing (PG_TEST_TEAM_FAULT, read at context creation -> own process).  That step's sweep times out, its
+    uncommitted outputs are discarded, the step is redone with two sweeps and flagged; the iterates stay the oracle's
+    (1e-5 max(1, |z|) in Float32), the step size sequence too, and the following steps are back to one read
+    of A per iteration.  cols: the same as the single rank of a column-sharded job, where the
+    timeout flag travels through the all-reduce payload."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "tools", "team_fault.py"), "--mode", mode, "--fault", "3", "--steps", "7"]
+    out = subprocess.run(cmd + (["--cols"] if cols else []), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    steps = d["steps"]
+    flagged = [r["k"] for r in steps if r["flags"] & d["fallback_flag"]]
+    assert flagged == [3] and d["sweep_fallbacks"] == 1, (flagged, steps)
+    for r in steps:
+        assert r["dz"] <= 1e-5 * r["z_scale"], r
+        assert r["gamma"] == pytest.approx(r["gamma_oracle"], rel=1e-6), r
+        assert r["f_x"] == pytest.approx(r["f_x_oracle"], rel=1e-4), r
+    by_k = {r["k"]: r["a_passes"] for r in steps}
+    assert by_k[2] == 1 and by_k[3] >= 2 and by_k[6] == 1 and by_k[7] == 1, by_k  # one read of A per step again after the fallback
+
+
 def test_bench_default_line_carries_every_single_gpu_config(pa):
     """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`): the top-level record is the fixed-step headline
     run; `also` holds the reference benchmark's adaptive mode on the same matrix and BASELINE configs 2, 3, 4, each with its
