@@ -8,6 +8,10 @@
  * INTEGRATION.md for the Julia-side glue).  A Python/ctypes host with the same operator
  * and iterator surface lives in `proximalalgorithms.jl_amd/`.
  *
+ * This file holds the entry points of SURVEY.md section 8 (the hot path and its "next" rows).  Exports that serve
+ * algorithms outside that scope (Davis-Yin's single sweep, the Broyden rank-one update, stream capture / graphs, the
+ * L-BFGS image slab) are declared in proxgrad_hip_ext.h.
+ *
  * Conventions
  *  - plain C, `extern "C"`, opaque handles, plain pointers and sizes; no C++/torch types.
  *  - every function returns a pg_status (0 = ok, negative = error); pg_last_error() gives the
@@ -132,18 +136,6 @@ pg_status pg_ctx_comm_stats(pg_ctx* ctx, int64_t* calls, int64_t* elements);
  * every rank (fixed step, or FastForwardBackward's adaptive step with reuse_residual).  nranks = 0: row sharding. */
 pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
 pg_status pg_ctx_sync(pg_ctx* ctx);
-/* Stream capture for launch-bound iteration bodies ("capture launch-bound inner loops in hipGraphs"): between _begin and
- * _end every entry point of this library called on the context RECORDS its kernels into a graph instead of running
- * them; scalar outputs (double* ..._out) are not meaningful for calls made during the capture.  The recorded body --
- * e.g. one Base.iterate of AFBA / DavisYin / DouglasRachford (primal_dual.jl:176-209, davis_yin.jl:73-83,
- * douglas_rachford.jl:57-63), whose step sizes are constants -- is then replayed with ONE launch per iteration.
- * Requirements: the context owns a non-default stream, no collective attached, every workspace the body needs was
- * allocated by a previous (uncaptured) run of the same body.  _end with out == NULL aborts and discards the capture. */
-typedef struct pg_graph pg_graph;
-pg_status pg_ctx_capture_begin(pg_ctx* ctx);
-pg_status pg_ctx_capture_end(pg_ctx* ctx, pg_graph** graph_out);
-pg_status pg_graph_launch(pg_graph* graph);
-pg_status pg_graph_destroy(pg_graph* graph);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every
  * launch of the kernels below is bracketed by an event pair; pg_ctx_profile_read synchronises the stream and
@@ -181,9 +173,6 @@ pg_status pg_mat_generate(pg_mat* A, uint32_t seed, int64_t row_offset, double s
 /* ... the block at (row_offset, col_offset) of the same global matrix (row shards use the first, column shards the second) */
 pg_status pg_mat_generate_block(pg_mat* A, uint32_t seed, int64_t row_offset, int64_t col_offset, double scale);
 pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int32_t* dtype, void** dptr);
-/* A += alpha * u * w'  (u: m-vector, w: n-vector, device): the `L.H .+= (s - Hy) / dot(...) * sH` rank-one update of
- * the Broyden operator, src/accel/broyden.jl:18-28 */
-pg_status pg_mat_rank1_update(pg_mat* A, double alpha, const void* u, const void* w);
 /* y = A x  (mul!(y, A, x)) and g = A' r  (mul!(g, A', r)) -- the two GEMV orientations on the
  * column-major store; used by LeastSquares and (later) PANOC's `mul!` with A: panoc.jl:150-190 */
 pg_status pg_mat_mul(pg_mat* A, const void* x, void* y);
@@ -196,17 +185,6 @@ pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
  * teams of workgroups); PG_ERR_UNSUPPORTED otherwise. */
 pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
                           void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out);
-/* One Davis-Yin iteration (davis_yin.jl:73-83: prox!(xg, g, z); grad f(xg); z_half = 2 xg - z - gamma grad; prox!(xh, h,
- * z_half); res = xh - xg; z += lambda res) for f = loss o A in ONE read of A.  Input: r = grad loss(A xg) (m-vector), xg, z.
- * Output per column: grad = A' r, z_half, xh = prox_{gamma h}(z_half), res, z_next = z + relax * res, and already the NEXT
- * iteration's xg_next = prox_{gamma g}(z_next) with its image A_xg_next = A xg_next.  g_kind / h_kind in {PG_G_ZERO,
- * PG_G_NORML1 (p0 = lam), PG_G_INDBOX (p0 = lo, p1 = hi), PG_G_SQRNORML2 (p0 = lam)}.  scalars_out (host, may be NULL) =
- * { 0, norm(res, Inf), dot(grad, res), norm(res)^2 }.  Same shape limits as pg_mat_fused_tn. */
-pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void* z, double gamma, double relax,
-                           int32_t g_kind, double g_p0, double g_p1, int32_t h_kind, double h_p0, double h_p1, void* grad,
-                           void* z_half, void* xh, void* res, void* z_next, void* xg_next, void* A_xg_next,
-                           double* scalars_out);
-
 /* ------------------------------------------------------------------ LeastSquares -------- */
 /* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the
  * value_and_gradient method of benchmark/benchmarks.jl:11-17.  `b` is a device m-vector
@@ -406,16 +384,6 @@ pg_status pg_lbfgs_destroy(pg_lbfgs* L);
 pg_status pg_lbfgs_update(pg_lbfgs* L, const void* s, const void* y); /* update!  lbfgs.jl:30-50 */
 pg_status pg_lbfgs_reset(pg_lbfgs* L);                               /* reset!   lbfgs.jl:52-55 */
 pg_status pg_lbfgs_apply(pg_lbfgs* L, void* d, const void* v);       /* mul!     lbfgs.jl:64-95 */
-/* Images of the stored pairs under a linear map A (m rows): with A s_i and A y_i kept next to s_i, y_i, the image of the
- * quasi-Newton direction, A (H v), follows from A v and the two-loop coefficients of the LAST pg_lbfgs_apply without
- * reading A:  A d = H0 (A v - sum alpha_i A y_i) + sum (alpha_i - beta_i) A s_i.  This removes the `mul!(Ad, A, d)` of
- * panoc.jl:178 (PANOC then reads A once per accepted step).  _enable(m) allocates the image slab; _update(As, Ay) must
- * follow every pg_lbfgs_update with the images of the same pair (ignored when the pair was rejected, <s, y> <= 0);
- * _apply(Ad, Av) must follow the pg_lbfgs_apply whose direction it maps. */
-pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m);
-pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay);
-pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,64 @@
+/*
+ * proxgrad_hip_ext.h -- entry points of libproxgrad_hip.so OUTSIDE the hot-path scope of SURVEY.md section 8.
+ *
+ * proxgrad_hip.h is the drop-in boundary for the ForwardBackward / FastForwardBackward path and its "next" rows
+ * (DouglasRachford, PANOC / ZeroFPR / PANOCplus with L-BFGS, the device-resident loops).  What is declared here serves
+ * other algorithms of the reference on the same kernels -- Davis-Yin and AFBA bodies replayed as graphs, the Broyden
+ * operator, PANOC's image slab -- and is kept apart so that the boundary header matches section 8(b)'s table.
+ * Same conventions as proxgrad_hip.h.
+ */
+#ifndef PROXGRAD_HIP_EXT_H
+#define PROXGRAD_HIP_EXT_H
+
+#include "proxgrad_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ stream capture ---- */
+/* Stream capture for launch-bound iteration bodies ("capture launch-bound inner loops in hipGraphs"): between _begin and
+ * _end every entry point of this library called on the context RECORDS its kernels into a graph instead of running
+ * them; scalar outputs (double* ..._out) are not meaningful for calls made during the capture.  The recorded body --
+ * e.g. one Base.iterate of AFBA / DavisYin / DouglasRachford (primal_dual.jl:176-209, davis_yin.jl:73-83,
+ * douglas_rachford.jl:57-63), whose step sizes are constants -- is then replayed with ONE launch per iteration.
+ * Requirements: the context owns a non-default stream, no collective attached, every workspace the body needs was
+ * allocated by a previous (uncaptured) run of the same body.  _end with out == NULL aborts and discards the capture. */
+typedef struct pg_graph pg_graph;
+pg_status pg_ctx_capture_begin(pg_ctx* ctx);
+pg_status pg_ctx_capture_end(pg_ctx* ctx, pg_graph** graph_out);
+pg_status pg_graph_launch(pg_graph* graph);
+pg_status pg_graph_destroy(pg_graph* graph);
+
+/* ------------------------------------------------------------------ Broyden rank-one update ---- */
+/* A += alpha * u * w'  (u: m-vector, w: n-vector, device): the `L.H .+= (s - Hy) / dot(...) * sH` rank-one update of
+ * the Broyden operator, src/accel/broyden.jl:18-28 */
+pg_status pg_mat_rank1_update(pg_mat* A, double alpha, const void* u, const void* w);
+
+/* ------------------------------------------------------------------ Davis-Yin single sweep ---- */
+/* One Davis-Yin iteration (davis_yin.jl:73-83: prox!(xg, g, z); grad f(xg); z_half = 2 xg - z - gamma grad; prox!(xh, h,
+ * z_half); res = xh - xg; z += lambda res) for f = loss o A in ONE read of A.  Input: r = grad loss(A xg) (m-vector), xg, z.
+ * Output per column: grad = A' r, z_half, xh = prox_{gamma h}(z_half), res, z_next = z + relax * res, and already the NEXT
+ * iteration's xg_next = prox_{gamma g}(z_next) with its image A_xg_next = A xg_next.  g_kind / h_kind in {PG_G_ZERO,
+ * PG_G_NORML1 (p0 = lam), PG_G_INDBOX (p0 = lo, p1 = hi), PG_G_SQRNORML2 (p0 = lam)}.  scalars_out (host, may be NULL) =
+ * { 0, norm(res, Inf), dot(grad, res), norm(res)^2 }.  Same shape limits as pg_mat_fused_tn. */
+pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void* z, double gamma, double relax,
+                           int32_t g_kind, double g_p0, double g_p1, int32_t h_kind, double h_p0, double h_p1, void* grad,
+                           void* z_half, void* xh, void* res, void* z_next, void* xg_next, void* A_xg_next,
+                           double* scalars_out);
+
+/* ------------------------------------------------------------------ L-BFGS images ---- */
+/* Images of the stored pairs under a linear map A (m rows): with A s_i and A y_i kept next to s_i, y_i, the image of the
+ * quasi-Newton direction, A (H v), follows from A v and the two-loop coefficients of the LAST pg_lbfgs_apply without
+ * reading A:  A d = H0 (A v - sum alpha_i A y_i) + sum (alpha_i - beta_i) A s_i.  This removes the `mul!(Ad, A, d)` of
+ * panoc.jl:178 (PANOC then reads A once per accepted step).  _enable(m) allocates the image slab; _update(As, Ay) must
+ * follow every pg_lbfgs_update with the images of the same pair (ignored when the pair was rejected, <s, y> <= 0);
+ * _apply(Ad, Av) must follow the pg_lbfgs_apply whose direction it maps. */
+pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m);
+pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay);
+pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROXGRAD_HIP_EXT_H */

@@ -485,6 +485,9 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const char* force = getenv("PG_TN_KERNEL");
   const bool single_ok = tn_single_wg_supported<T>(A);
   if (force != nullptr && *force) {
+    if (force[0] == 'm')  // experiments: an exact-U instantiation of the one-workgroup sweep (pg_gemv_tn3.hip)
+      return launch_tn_mid<T>(A, a, blocks_out, env_int("PG_TN_U", 8), env_int("PG_TN_C", 2), env_int("PG_TN_WAVES", 4),
+                              env_int("PG_TN_DB", 0), env_int("PG_TN_BLOCKS_PER_CU", 1));
     if (force[0] == 'w' && force[1] == 'a' && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
     if (force[0] == 't' && tn_team_covers(nrg)) return launch_tn_team<T>(A, a, blocks_out);
     if (force[0] == 'c' && tn_coop_covers(nrg)) return launch_tn_coop<T>(A, a, blocks_out);

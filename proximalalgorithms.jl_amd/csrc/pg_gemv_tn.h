@@ -427,5 +427,8 @@ template <typename T>
 pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out);
 template <typename T>
 pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out);
+// exact-U instantiations of gemv_tn_kernel for mid-length columns (pg_gemv_tn3.hip)
+template <typename T>
+pg_status launch_tn_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int U, int C, int W, int db, int bpc);
 
 }  // namespace pgtn

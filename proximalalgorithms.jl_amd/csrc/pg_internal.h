@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "proxgrad_hip.h"
+#include "proxgrad_hip_ext.h"
 
 // ---------------------------------------------------------------------------------------------
 // error handling

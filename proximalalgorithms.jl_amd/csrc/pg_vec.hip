@@ -839,6 +839,7 @@ pg_status dr_run_t(pg_ctx* c, int64_t n, void* x, void* x_alt, void* y, void* r,
         PG_HIP(hipStreamSynchronize(c->stream));
         PG_HIP(hipFree(c->dr_ws));
         c->dr_ws = nullptr;
+        c->dr_ws_bytes = 0;  // (a failed hipMalloc below must not leave the old size standing)
       }
       PG_HIP(hipMalloc(&c->dr_ws, nb));
       c->dr_ws_bytes = nb;
