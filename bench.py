@@ -1080,6 +1080,10 @@ def run_rank(args, job, wd, world, rank, local_rank):
                 P2 = setup_lasso(pa, ctx, D, m_rec, n, dtype, args.seed, lay, "fixed")
                 extra[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events, scaling=scaling)
             except pa.ProxGradError as e:
+                # only what every rank sees alike: a refused shape or a failed allocation.  A failed collective or HIP call
+                # leaves the ranks out of step -- that ends the job (with the line measured so far)
+                if e.code not in (pa.PG_ERR_UNSUPPORTED, pa.PG_ERR_ALLOC):
+                    raise
                 extra[key] = {"error": str(e)[:300]}
 
         if args.scaling == "strong":

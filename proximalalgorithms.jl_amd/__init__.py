@@ -5,7 +5,8 @@ Host-side mirror of the reference's interface (same names, keyword arguments and
 all arithmetic runs in hand-written HIP kernels of libproxgrad_hip.so (csrc/, C ABI in
 include/proxgrad_hip.h).  There is no CPU fallback: without the library or a gfx950 device, calls raise.
 """
-from ._lib import ProxGradError
+from ._lib import (PG_ERR_ALLOC, PG_ERR_COLLECTIVE, PG_ERR_HIP, PG_ERR_INVALID, PG_ERR_TIMEOUT, PG_ERR_UNSUPPORTED,
+                   PG_FLAG_GAMMA_TOO_SMALL, PG_FLAG_SWEEP_FALLBACK, ProxGradError)
 from .algorithm import IterativeAlgorithm
 from .device import Context, Graph, HIPMatrix, HIPVector, as_hipvector, get_context, set_default_context
 from .douglas_rachford import DouglasRachford, DouglasRachfordIteration, DouglasRachfordState
@@ -23,7 +24,7 @@ from .operators import (Composed, Conjugate, IndAffine, IndBox, IndNonnegative, 
                         is_generalized_quadratic, prox, prox_, value_and_gradient, value_and_gradient_)
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
 from .panocplus import PANOCplus, PANOCplusIteration
-from .sharding import (NativeRcclComm, ScaleComm, TorchDistributedComm, allreduce_sum_, native_rccl_available, shard_cols,
+from .sharding import (NativeRcclComm, TorchDistributedComm, allreduce_sum_, native_rccl_available, shard_cols,
                        shard_rows)
 
 from .zerofpr import ZeroFPR, ZeroFPRIteration
@@ -44,7 +45,8 @@ __all__ = [
     "AFBA_default_stepsizes", "NesterovExtrapolation", "Conjugate", "IndZero", "Quadratic", "SqrNormL2",
     "convex_conjugate", "is_convex", "is_generalized_quadratic",
     "ZeroFPR", "ZeroFPRIteration", "PANOCplus", "PANOCplusIteration",
-    "ProxGradError", "IterativeAlgorithm", "DouglasRachford", "DouglasRachfordIteration", "DouglasRachfordState",
+    "ProxGradError", "PG_ERR_ALLOC", "PG_ERR_COLLECTIVE", "PG_ERR_HIP", "PG_ERR_INVALID", "PG_ERR_TIMEOUT", "PG_ERR_UNSUPPORTED",
+    "PG_FLAG_GAMMA_TOO_SMALL", "PG_FLAG_SWEEP_FALLBACK", "IterativeAlgorithm", "DouglasRachford", "DouglasRachfordIteration", "DouglasRachfordState",
     "SeparableQuadratic", "PANOC", "PANOCIteration", "PANOCState", "NoAcceleration", "Composed", "LogisticLoss",
     "SquaredDistance", "Context", "HIPMatrix", "HIPVector", "as_hipvector", "get_context",
     "FastForwardBackward", "FastForwardBackwardIteration", "FastForwardBackwardState", "FastProximalGradient",
@@ -52,6 +54,6 @@ __all__ = [
     "ForwardBackward", "ForwardBackwardIteration", "ForwardBackwardState", "ProximalGradient",
     "ProximalGradientIteration", "LBFGS", "LBFGSOperator", "AdaptiveNesterovSequence", "ConstantNesterovSequence",
     "FixedNesterovSequence", "SimpleNesterovSequence", "next_", "IndBox", "LeastSquares", "NormL1", "Zero",
-    "gradient_", "prox", "prox_", "value_and_gradient", "NativeRcclComm", "native_rccl_available", "ScaleComm", "TorchDistributedComm", "allreduce_sum_",
+    "gradient_", "prox", "prox_", "value_and_gradient", "NativeRcclComm", "native_rccl_available", "TorchDistributedComm", "allreduce_sum_",
     "shard_rows", "shard_cols",
 ]

@@ -319,7 +319,10 @@ function Base.iterate(iter::HIPIteration, st::HIPIterState)
 end
 
 default_stopping_criterion(tol, ::HIPIteration, st::HIPIterState) = st.res_inf / st.gamma <= tol
-default_solution(::HIPIteration, st::HIPIterState) = Array(st.z)
+# fast_forward_backward.jl:152 / forward_backward.jl:128 return `state.z` itself (aliased, not copied): so does the glue -- a
+# HIPVector view of the library-owned state, valid until the next step.  `host_solution` is the explicit host copy.
+default_solution(::HIPIteration, st::HIPIterState) = st.z
+host_solution(iter::HIPIteration, st::HIPIterState) = Array(default_solution(iter, st))
 default_display(it, ::HIPIteration, st::HIPIterState) =
     @printf("%5d | %.3e | %.3e\n", it, st.gamma, st.res_inf / st.gamma)
 
@@ -352,7 +355,7 @@ function hip_solve(iter::HIPIteration; maxit = 10_000, tol = 1e-8)
                     st.handle, 1, maxit, tol, k, sc))
     end
     refresh!(st, sc[], A.ctx, st.x.n)
-    return Array(st.z), Int(k[])
+    return st.z, Int(k[])   # the aliased device vector, like IterativeAlgorithm's `solution(iter, state)`; Array(z) copies to the host
 end
 
 # DouglasRachford on a separable quadratic + box / L1 (douglas_rachford.jl:53-70): the whole loop in the library,

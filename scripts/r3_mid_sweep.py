@@ -13,36 +13,37 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import proximalalgorithms.jl_amd as pa  # noqa: E402
 import r2_tn_check as r2  # noqa: E402
 
-r2.KNOBS = r2.KNOBS + ("PG_TN_U", "PG_TN_DB")
+r2.KNOBS = r2.KNOBS + ("PG_TN_U", "PG_TN_DB", "PG_TN_MIDK")
 
 
-def mid(U, C, W, db, bpc=1):
-    return dict(PG_TN_KERNEL="mid", PG_TN_U=str(U), PG_TN_C=str(C), PG_TN_WAVES=str(W), PG_TN_DB=str(db), PG_TN_BLOCKS_PER_CU=str(bpc))
+def mid(U, C, W, db, bpc=1, k=1):
+    return dict(PG_TN_KERNEL="mid", PG_TN_U=str(U), PG_TN_C=str(C), PG_TN_WAVES=str(W), PG_TN_DB=str(db), PG_TN_BLOCKS_PER_CU=str(bpc),
+                PG_TN_MIDK=str(k))
 
 
-def candidates(nrg):
+def candidates(nrg, both=True):
+    """(label, env): the default dispatch, then gemv_tnm (k = 1: branch-free tile loads, scalar x_j / z_old_j loads) and the
+    exact-U instantiations of gemv_tn_kernel (k = 0) in the geometries that fit nrg row groups"""
     c = [("default", {})]
+    geo = []
     if 17 <= nrg <= 32:
         U = (nrg + 3) // 4
-        for C in (4, 2):
-            for db in (0, 1):
-                for bpc in (1, 2):
-                    c.append((f"mid U={U} C={C} W=4 tiles={db + 1} wg/CU={bpc}", mid(U, C, 4, db, bpc)))
+        geo += [(U, 4, 4, db, bpc) for db in (0, 1) for bpc in (1, 2)]
+        if U == 8:
+            geo += [(8, 2, 4, db, bpc) for db in (0, 1) for bpc in (1, 2)] + [(4, 8, 8, 0, 1), (4, 4, 8, 0, 1), (4, 4, 8, 1, 1), (4, 8, 8, 0, 2)]
     if 33 <= nrg <= 64:
         U = (nrg + 3) // 4
-        for C in (2, 4):
-            for db in (0, 1):
-                for bpc in (1, 2):
-                    c.append((f"mid U={U} C={C} W=4 tiles={db + 1} wg/CU={bpc}", mid(U, C, 4, db, bpc)))
-        U8 = (nrg + 7) // 8
-        if U8 >= 5:
-            c.append((f"mid U={U8} C=4 W=8", mid(U8, 4, 8, 0)))
+        geo += [(U, 2, 4, db, bpc) for db in (0, 1) for bpc in (1, 2)]
+        if U in (10, 12):
+            geo += [(U, 4, 4, 0, 1)]
     if 65 <= nrg <= 128:
         U = (nrg + 7) // 8
-        for C in (1, 2):
-            for db in (0, 1):
-                for bpc in (1, 2):
-                    c.append((f"mid U={U} C={C} W=8 tiles={db + 1} wg/CU={bpc}", mid(U, C, 8, db, bpc)))
+        geo += [(U, C, 8, 0, bpc) for C in (1, 2) for bpc in (1, 2)]
+        if U in (9, 10):
+            geo += [(U, 1, 8, 1, 1)]
+    for (U, C, W, db, bpc) in geo:
+        for k in ((1, 0) if both else (1,)):
+            c.append((f"{'tnm' if k else 'tn '} U={U} C={C} W={W} tiles={db + 1} wg/CU={bpc}", mid(U, C, W, db, bpc, k)))
     return c
 
 
@@ -77,7 +78,7 @@ def cmd_check():
         rpg = 1024 // np.dtype(dtype).itemsize
         for nrg in (17, 20, 24, 29, 32, 33, 37, 40, 44, 47, 52, 57, 60, 64, 65, 72, 81, 90, 100, 104, 113, 120, 128):
             for m in (nrg * rpg, nrg * rpg - 3):
-                for name, env in candidates(nrg)[1:]:
+                for name, env in candidates(nrg, both=False)[1:]:
                     if "wg/CU=2" in name:
                         continue
                     for n in (37, 1000):

@@ -447,7 +447,9 @@ def test_sharded_payload_with_emulated_allreduce(pa, dtype, overlap, ls_lam):
     m, n = 300, 700 if not overlap else 20000  # the chunked (pipelined) path needs n >= 4 * 4096
     A, b, lam = synthetic_problem(m, n, dtype, seed=4)
     ctx2 = pa.Context()  # separate context so the callback does not leak into other tests
-    comm = pa.ScaleComm(2, overlap=overlap)
+    from tests._doubles import ScaleComm
+
+    comm = ScaleComm(2, overlap=overlap)
     f_sh = pa.LeastSquares(pa.HIPMatrix.from_numpy(A, ctx2), pa.HIPVector.from_numpy(b, ctx2), lam=ls_lam, comm=comm)
     f_full = pa.LeastSquares(np.vstack([A, A]), np.concatenate([b, b]), lam=ls_lam)
     x = np.random.default_rng(0).standard_normal(n).astype(dtype)

@@ -187,3 +187,6 @@ def test_glue_carries_the_reference_iterator_surface():
     for n_, v in zip(names, vals):
         assert enum[n_] == v, (n_, v, enum[n_])
     assert "Base.IsInfinite()" in text and "default_stopping_criterion" in text and "default_solution" in text and "default_display" in text
+    # fast_forward_backward.jl:152: the solution is the ALIASED state vector, not a host copy (VERDICT r2 missing 3)
+    assert re.search(r"^default_solution\(::HIPIteration, st::HIPIterState\) = st\.z$", text, flags=re.M)
+    assert "host_solution" in text and "Array(st.z)" not in text
