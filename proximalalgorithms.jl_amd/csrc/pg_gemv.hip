@@ -209,8 +209,7 @@ constexpr int PG_TN_WAVE_MAX_RG = 8;
 // Interleaved A/B, five rounds (profiles/r2_tune_tn_mid_columns.log): 17 / 20 / 24 row groups 7.03 / 6.83 / 6.96 TB/s against
 // 6.27 / 6.53 / 6.88 for gemv_tn; level at 28 and 32 (the same shape re-allocated moves by 3 %: no finer cut than this)
 constexpr int PG_TN_COOP_MAX_RG = 24;
-// 33 .. this many: one four-wave "team" member per column group with U instantiated exactly (gemv_tnt_kernel, TM = 1)
-constexpr int PG_TN_TEAM1_MAX_RG = 44;
+// 25 .. 28: gemv_tn_kernel<4, 8, 8>; 29 .. 128: gemv_tnm_kernel (tn_mid_covers, pg_gemv_tn3.hip); beyond: teams of workgroups
 
 // ----------------------------------------------------------------------------------------------
 // host-side launch planning
@@ -485,9 +484,9 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const char* force = getenv("PG_TN_KERNEL");
   const bool single_ok = tn_single_wg_supported<T>(A);
   if (force != nullptr && *force) {
-    if (force[0] == 'm')  // experiments: an exact-U instantiation of the one-workgroup sweep (pg_gemv_tn3.hip)
+    if (force[0] == 'm')  // experiments: a named instantiation of gemv_tnm_kernel (pg_gemv_tn3.hip)
       return launch_tn_mid<T>(A, a, blocks_out, env_int("PG_TN_U", 8), env_int("PG_TN_C", 2), env_int("PG_TN_WAVES", 4),
-                              env_int("PG_TN_DB", 0), env_int("PG_TN_BLOCKS_PER_CU", 1));
+                              env_int("PG_TN_DB", 0) + 1, env_int("PG_TN_BLOCKS_PER_CU", 1));
     if (force[0] == 'w' && force[1] == 'a' && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
     if (force[0] == 't' && tn_team_covers(nrg)) return launch_tn_team<T>(A, a, blocks_out);
     if (force[0] == 'c' && tn_coop_covers(nrg)) return launch_tn_coop<T>(A, a, blocks_out);
@@ -495,10 +494,8 @@ pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
     if (nrg <= PG_TN_WAVE_MAX_RG && tn_wave_covers(nrg)) return launch_tn_wave<T>(A, a, blocks_out);
     if (nrg > PG_TN_WAVE_MAX_RG && nrg <= PG_TN_COOP_MAX_RG && tn_coop_covers(nrg)) return launch_tn_coop<T>(A, a, blocks_out);
-    // 33..44 row groups (8448..11264 rows f32) fill the four-wave U = 16 geometry to 52-69 %: a single-member "team"
-    // instantiated for U = ceil(nrg / 4) exactly (9..11) wastes nothing -- 9000 / 10000 rows 6.05 / 6.10 TB/s against
-    // 5.50 / 5.92; level from 47 row groups on (profiles/r2_tune_tn_odd_rows.log)
-    if (nrg > 32 && nrg <= PG_TN_TEAM1_MAX_RG) return launch_tn_team<T>(A, a, blocks_out);
+    // 29..128 row groups (the headline's 64 among them): gemv_tnm_kernel with U fitted to the column (pg_gemv_tn3.hip)
+    if (single_ok && tn_mid_covers(nrg)) return launch_tn_mid_default<T>(A, a, blocks_out);
   }
   if (!single_ok) return launch_tn_team<T>(A, a, blocks_out);
   // 17..32 row groups (m = 8192 in Float32): eight waves of U = 4 with C = 8 columns per step measured 4 % faster than four
@@ -742,6 +739,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   a.red_partials = c->red_partials;
   a.red_counter = c->red_counter;
   a.scal_out = c->dscal + PG_S_GZ;
+  a.line_cols = env_int("PG_TN_LINE_COLS", 32);  // experiments: 1 = column groups dealt one by one (round 1-2 assignment)
   int blocks = 0;
   PG_TRY(launch_tn<T>(A, a, &blocks));
   f->a_passes += 1;
@@ -829,6 +827,7 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
   a.red_partials = c->red_partials;
   a.red_counter = c->red_counter;
   a.scal_out = c->dscal + PG_S_GZ;
+  a.line_cols = env_int("PG_TN_LINE_COLS", 32);  // experiments: 1 = column groups dealt one by one (round 1-2 assignment)
   int blocks = 0;
   PG_TRY(launch_tn<T>(A, a, &blocks));
   int64_t fb = (A->ld + 63) / 64;

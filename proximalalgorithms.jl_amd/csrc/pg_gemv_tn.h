@@ -72,12 +72,42 @@ struct TNArgs {
   // workgroup teams (gemv_tnt_kernel, columns longer than one workgroup's registers): team_size workgroups split the rows
   // of every column; their per-column partial dots meet in xch, a ring of tagged 8-byte granules per team
   int team_size = 1, nteams = 0;
+  int line_cols = 32;  // columns a workgroup (wave, team) takes in a row before it jumps: see CgMap
   unsigned tag_base = 0;  // launch epoch << 24: the tag of step i is tag_base + i + 1, so granules of earlier launches never match
   unsigned long long* xch = nullptr;  // [nteams][ring][team_size * C * granules-per-value]
   double* team_err = nullptr;         // set to 1 when a team member gave up waiting (bounded spin)
 #ifdef PG_TNT_EXPERIMENT
   int dbg = 0;  // timing experiments of the team kernel (wrong results): see pg_gemv_tn2.hip
 #endif
+};
+
+// Column groups -> units (workgroups; waves in gemv_tnw; teams in gemv_tnt).  A unit produces, per column, five 4-byte
+// outputs (g, y, z, res, v).  With the groups dealt round-robin (unit u takes groups u, u + N, u + 2N ...) every 128-byte
+// line of those vectors is written in 4..16 pieces by as many workgroups on different XCDs: none of their L2s ever holds
+// the whole line, each piece goes to memory as a masked partial write, and the sweep loses 3-8 % of its streaming rate to
+// them (scripts/tile_pattern.hip, profiles/r3_mid_columns_counters.md: the same kernel without the stores, or with the stores
+// going to workgroup-private lines, runs 7.15-7.3 TB/s where it ran 6.7-6.9).  So a unit takes line_cols / C CONSECUTIVE
+// groups -- line_cols = 32 columns: whole lines of every output, written by one workgroup within a few steps -- and then
+// jumps by N such chunks; A is still swept as one moving window (N chunks wide).  The groups left over by the last
+// incomplete round are dealt one by one again, so no unit gets more than one step more than another.
+struct CgMap {
+  int64_t head, cnt;  // steps under the chunked assignment; all steps of this unit
+  int64_t gridK, tail0, unit, nunits;
+  int shift;  // log2 of the chunk length (groups)
+  __device__ __forceinline__ CgMap(int64_t ncg, int C, int line_cols, int64_t unit_, int64_t nunits_) : unit(unit_), nunits(nunits_) {
+    int K = line_cols / C;  // C and line_cols are powers of two
+    if (K < 1) K = 1;
+    shift = 31 - __builtin_clz((unsigned)K);
+    gridK = nunits << shift;
+    const int64_t rounds = ncg / gridK;
+    head = rounds << shift;
+    tail0 = rounds * gridK;
+    const int64_t rem = ncg - tail0;
+    cnt = head + (rem > unit ? (rem - unit + nunits - 1) / nunits : 0);
+  }
+  __device__ __forceinline__ int64_t at(int64_t i) const {
+    return i < head ? (i >> shift) * gridK + (unit << shift) + (i & ((int64_t(1) << shift) - 1)) : tail0 + unit + (i - head) * nunits;
+  }
 };
 
 // in-kernel prox kinds: PG_G_ZERO / PG_G_NORML1 / PG_G_INDBOX and, for the second operator of the Davis-Yin mode,
@@ -235,14 +265,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
 
   // two register tiles: the loads of the next column group are in flight while the current one is reduced, exchanged
   // through LDS and folded into the next residual (the kernel would otherwise idle the memory system at every barrier)
+  // column groups go to workgroups in chunks of whole output lines, the chunks strided across the grid: all workgroups
+  // sweep one moving window of A (CgMap).  (A fully blocked assignment -- every workgroup streaming its own contiguous
+  // region -- measured 3 % faster on a freshly booted device and 3-10 % slower, alternating from process to process, on
+  // others: 256 far-apart streams depend on how the 64 GiB allocation happens to be mapped.)
+  const CgMap map(ncg, C, a.line_cols, blockIdx.x, gridDim.x);
+  const int64_t cnt = map.cnt;
+  auto at = [&](int64_t i) { return map.at(i); };
   if constexpr (DOUBLE_BUFFER) {
     TNTile<T, U, C, WAVES> ta, tb;
-    // column groups are strided across the grid: all workgroups sweep one moving window of A.  (A blocked assignment --
-    // every workgroup streaming its own contiguous region -- measured 3 % faster on a freshly booted device and 3-10 %
-    // slower, alternating from process to process, on others: 256 far-apart streams depend on how the 64 GiB
-    // allocation happens to be mapped.  The strided form is stable to 0.5 %.)
-    const int64_t cnt = ncg > (int64_t)blockIdx.x ? (ncg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    auto at = [&](int64_t i) { return (int64_t)blockIdx.x + i * (int64_t)gridDim.x; };
     int64_t i = 0;
     if (i < cnt) ta.load(a, at(i), wave, lane);
     while (i < cnt) {
@@ -256,7 +287,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
   } else {  // 8-wave workgroups have half the registers per wave: one tile, two workgroups per CU overlap instead
     TNTile<T, U, C, WAVES> t;
     int buf = 0;
-    for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t cg = at(i);
       t.load(a, cg, wave, lane);
       process(t, cg, buf);
       buf ^= 1;
@@ -427,8 +459,11 @@ template <typename T>
 pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out);
 template <typename T>
 pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out);
-// exact-U instantiations of gemv_tn_kernel for mid-length columns (pg_gemv_tn3.hip)
+// gemv_tnm_kernel: 29 .. 128 row groups, the headline's 64 among them (pg_gemv_tn3.hip)
+bool tn_mid_covers(int nrg);
 template <typename T>
-pg_status launch_tn_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int U, int C, int W, int db, int bpc);
+pg_status launch_tn_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int U, int C, int W, int nt, int bpc);
+template <typename T>
+pg_status launch_tn_mid_default(pg_mat* A, TNArgs<T>& a, int* blocks_out);
 
 }  // namespace pgtn

@@ -210,10 +210,12 @@ __global__ __launch_bounds__(WPB * 64) void gemv_tnw_kernel(TNArgs<T> a) {
     }
   };
 
-  // column groups are strided across all waves of the grid (one moving window over A, see gemv_tn_kernel)
-  const int64_t gw = (int64_t)blockIdx.x * WPB + wave, nw = (int64_t)gridDim.x * WPB;
-  const int64_t cnt = ncg > gw ? (ncg - gw + nw - 1) / nw : 0;
-  auto at = [&](int64_t i) { return gw + i * nw; };
+  // The waves of a workgroup take WPB adjacent column groups per step (one contiguous run of A, WPB * C adjacent outputs);
+  // those runs go to the workgroups in chunks of whole output lines (CgMap, pg_gemv_tn.h).  A wave's last step may lie
+  // past the end (ncg not a multiple of WPB): its columns are then all invalid -- clamped loads, nothing stored, v = 0.
+  const CgMap map((ncg + WPB - 1) / WPB, C * WPB, a.line_cols, blockIdx.x, gridDim.x);
+  const int64_t cnt = map.cnt;
+  auto at = [&](int64_t i) { return map.at(i) * WPB + wave; };
   if constexpr (DOUBLE_BUFFER) {
     WTile<T, U, C> ta, tb;
     int64_t i = 0;
@@ -368,10 +370,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnc_kernel(TNArgs<T> a) {
     }
   };
 
+  const CgMap map(ncg, C, a.line_cols, blockIdx.x, gridDim.x);
+  const int64_t cnt = map.cnt;
+  auto at = [&](int64_t i) { return map.at(i); };
   if constexpr (DOUBLE_BUFFER) {
     TNTile<T, U, C, WAVES> ta, tb;
-    const int64_t cnt = ncg > (int64_t)blockIdx.x ? (ncg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    auto at = [&](int64_t i) { return (int64_t)blockIdx.x + i * (int64_t)gridDim.x; };
     int64_t i = 0;
     if (i < cnt) ta.load(a, at(i), wave, lane);
     while (i < cnt) {
@@ -385,7 +388,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnc_kernel(TNArgs<T> a) {
   } else {
     TNTile<T, U, C, WAVES> t;
     int buf = 0;
-    for (int64_t cg = blockIdx.x; cg < ncg; cg += gridDim.x) {
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t cg = at(i);
       t.load(a, cg, wave, lane);
       process(t, cg, buf);
       buf ^= 1;
@@ -433,7 +437,7 @@ struct Pending {
   T xs[C], zos[C];       // the columns' x_j and z_old_j, fetched together with the poll
 };
 
-// Protocol.  Step i of a team = column group cg = team + i * nteams.  Member p writes its C partial dots of step i as
+// Protocol.  Step i of a team = column group map.at(i) (CgMap, pg_gemv_tn.h: chunks of whole output lines per team).  Member p writes its C partial dots of step i as
 // granules {value bits (32 per granule; an f64 takes two), tag = i + 1} into ring slot i % TEAM_RING at offset
 // (p * C + c) * G + h with ONE 8-byte agent-scope store each, so a reader that sees the tag sees the value.  Every wave
 // of every member polls the team_size * C * G granules of a step (one lane per granule), then sums the values in member
@@ -473,7 +477,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   const int TM = a.team_size;
   const int npoll = TM * C * G;
   const int64_t ncg = (a.n + C - 1) / C;
-  const int64_t cnt = ncg > team ? (ncg - team + a.nteams - 1) / a.nteams : 0;
+  const CgMap map(ncg, C, a.line_cols, team, a.nteams);  // step i of this team = column group map.at(i)
+  const int64_t cnt = map.cnt;
   const int rg0 = (member * WAVES + wave) * a.ueff;  // this wave's first row group: a contiguous run of ueff <= U KiB of each column
   unsigned long long* const ring = a.xch + (size_t)team * TEAM_RING * (size_t)(TEAM_MAX * C * G);
 
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     V col[C][U];
   };
   auto load = [&](Tile& t, int64_t i) __attribute__((always_inline)) {
-    const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
+    const int64_t j0 = map.at(i) * C;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
                              __HIP_MEMORY_SCOPE_AGENT);
   };
   auto fetch_xz = [&](Pending<T, C>& pd, int64_t i) __attribute__((always_inline)) {
-    const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
+    const int64_t j0 = map.at(i) * C;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
       }
     }
     const int w_lo = (int)(unsigned)pd.w;
-    const int64_t j0 = ((int64_t)team + i * a.nteams) * C;
+    const int64_t j0 = map.at(i) * C;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       T g = T(0);

@@ -1,9 +1,8 @@
-// Mid-length columns (33 .. 128 row groups: 8448 .. 32768 rows in Float32): instantiations of the one-workgroup sweep
-// (gemv_tn_kernel, pg_gemv_tn.h) for a row-group count per wave U that fits the column exactly (9 .. 16 rather than the
-// next power of two) and with the register-tile count chosen per geometry, compiled in their own translation unit.
-// scripts/tile_pattern.hip (profiles/r3_mid_columns_counters.md) is the measurement behind them: the load pattern of these
-// geometries alone reaches 7.2-7.35 TB/s with the dot / barrier / accumulate structure of the sweep, so what the
-// power-of-two geometries lose at these lengths is repeated or wasted loads, not the memory system.
+// Columns of 29 .. 128 row groups (7424 .. 32768 rows in Float32, the headline's 16384 among them): gemv_tnm_kernel, the
+// one-workgroup sweep with a row-group count per wave U that fits the column exactly (9 .. 16 rather than the next power
+// of two), branch-free tile loads and x_j / z_old_j issued ahead of the tile, compiled in its own translation unit.
+// Measurements behind it: scripts/tile_pattern.hip and scripts/r3_mid_sweep.py (profiles/r3_mid_columns_counters.md,
+// profiles/r3_tune_tn_mid_columns.log).
 #include "pg_gemv_tn.h"
 
 namespace pgtn {
@@ -18,43 +17,13 @@ namespace {
 //   * every tile load sat behind its own scalar compare-and-branch (row group < nrg) with the address arithmetic in
 //     between, ~10 instructions per 1 KiB load.  Here row groups past the end are CLAMPED to the last one (its lines are
 //     in the cache; the matching r entries are zero, so they add nothing) and the C * U loads of a tile go out back to back;
-//   * x_j and z_old_j were vector loads issued AFTER the tile had arrived (s_waitcnt vmcnt(0) in front of them), so every
-//     step paid one more memory round trip between its barrier and its epilogue with nothing in flight.  Here they are
-//     SCALAR loads (constant address space: s_load_dword, its own counter, no in-order queue shared with the tile) issued
-//     before the tile's loads.
+//   * x_j and z_old_j were loaded AFTER the tile had arrived (s_waitcnt vmcnt(0) in front of them), so every step paid
+//     one more memory round trip between its barrier and its epilogue with nothing in flight.  Here they are issued
+//     BEFORE the tile's loads (vector loads return in order: they are back first), between scheduling fences.  (Scalar
+//     loads were tried: through the constant address space the compiler sinks them to the instruction in front of the
+//     barrier, fences or not; as hand-written s_load asm the destination register is reused before the data lands.)
 // NT = 1: one register tile (load, wait, consume); NT = 2: the next tile's loads are in flight while this one is consumed.
 // ---------------------------------------------------------------------------------------------------------------
-// x_j / z_old_j: one scalar load each, issued where the source says (volatile asm; the compiler's own s_load was sunk to
-// the instruction in front of the barrier) and waited for with sload_wait right before the epilogue
-__device__ __forceinline__ unsigned sload_bits(const float* p) {
-  unsigned v;
-  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(p));
-  return v;
-}
-__device__ __forceinline__ unsigned long long sload_bits(const double* p) {
-  unsigned long long v;
-  asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(v) : "s"(p));
-  return v;
-}
-__device__ __forceinline__ float sload_wait(unsigned& b) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b));
-  return __builtin_bit_cast(float, b);
-}
-__device__ __forceinline__ double sload_wait(unsigned long long& b) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b));
-  return __builtin_bit_cast(double, b);
-}
-template <typename T>
-struct BitsOf;
-template <>
-struct BitsOf<float> {
-  using type = unsigned;
-};
-template <>
-struct BitsOf<double> {
-  using type = unsigned long long;
-};
-
 template <typename T, int U, int C, int WAVES, int NT>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
@@ -63,8 +32,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ncg = (a.n + C - 1) / C;
-  using Bits = typename BitsOf<T>::type;
-
   V rk[U], racc[U];
   int rgo[U];  // element offset of this wave's row group u within a column (clamped)
 #pragma unroll
@@ -84,7 +51,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
 
   struct Tile {
     V col[C][U];
-    Bits xs[C], zos[C];
+    T xs[C], zos[C];
   };
   auto load = [&](Tile& t, int64_t cg) __attribute__((always_inline)) {
     const int64_t j0 = cg * C;
@@ -92,8 +59,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
-      t.xs[c] = sload_bits(a.x + jc);
-      t.zos[c] = sload_bits(a.z_old + jc);
+      t.xs[c] = a.x[jc];
+      t.zos[c] = a.z_old[jc];
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -104,7 +71,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto process = [&](Tile& t, int64_t cg, int buf) __attribute__((always_inline)) {
+  auto process = [&](const Tile& t, int64_t cg, int buf) __attribute__((always_inline)) {
     const int64_t j0 = cg * C;
     T dot[C];
 #pragma unroll
@@ -130,7 +97,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
       const int64_t j = j0 + c;
       const bool valid = j < a.n;
       if (a.lam_ls != T(1)) g = a.lam_ls * g;
-      const T xj = sload_wait(t.xs[c]), zo = sload_wait(t.zos[c]);
+      const T xj = t.xs[c], zo = t.zos[c];
       const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
       T zj;                            // :118 / :141
       if (a.g_kind == PG_G_NORML1)
@@ -162,8 +129,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(racc[u]));  // see gemv_tn_kernel: keeps this tile from living on
   };
 
-  const int64_t cnt = ncg > (int64_t)blockIdx.x ? (ncg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-  auto at = [&](int64_t i) { return (int64_t)blockIdx.x + i * (int64_t)gridDim.x; };
+  const CgMap map(ncg, C, a.line_cols, blockIdx.x, gridDim.x);
+  const int64_t cnt = map.cnt;
+  auto at = [&](int64_t i) { return map.at(i); };
   if constexpr (NT == 2) {
     Tile ta, tb;
     int64_t i = 0;
@@ -213,73 +181,47 @@ pg_status launch_tnm(pg_mat* A, TNArgs<T>& a, int* blocks_out, int bpc) {
   return PG_OK;
 }
 
-template <typename T, int U, int C, int WAVES, bool DB>
-pg_status launch_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int bpc) {
-  pg_ctx* c = A->ctx;
-  const int64_t ncg = (A->n + C - 1) / C;
-  int64_t blocks = (int64_t)c->num_cu * bpc;
-  if (env_int("PG_TN_BLOCKS", 0) > 0) blocks = env_int("PG_TN_BLOCKS", 0);
-  if (blocks > ncg) blocks = ncg;
-  if (blocks > PG_RED_MAX_BLOCKS) blocks = PG_RED_MAX_BLOCKS;
-  if (blocks < 1) blocks = 1;
-  PG_TRY(ensure_partials(A, (int)blocks));
-  a.partials = (T*)A->partials;
-  *blocks_out = (int)blocks;
-  pg_prof_scope prof(c, PG_K_GEMV_TN);
-  hipLaunchKernelGGL((gemv_tn_kernel<T, U, C, WAVES, DB, 0>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, c->stream, a);
-  PG_LAUNCH_CHECK();
-  return PG_OK;
-}
-
 }  // namespace
 
-// U row groups per wave, C columns per step, W waves, db register tiles - 1; PG_ERR_UNSUPPORTED when not instantiated
+// The instantiations: U row groups per wave, C columns per step, W waves, NT register tiles.
+//   29 .. 32 row groups   eight waves of U = 4, C = 4, two tiles           (8192 x 2^18: 7.16-7.20 TB/s against 7.04-7.08)
+//   33 .. 64              four waves of U = ceil(nrg / 4), C = 2, two tiles (16384 x 2^20, the headline: 0.914-0.917 of 8 TB/s
+//                         against 0.894-0.896 for gemv_tn_kernel<16, 2, 4>); U = 10: C = 4, one tile
+//   65 .. 128             eight waves of U = ceil(nrg / 8), one tile, C = 2 up to U = 12, C = 1 above
+// (interleaved A/B on one box, medians of five rounds: profiles/r3_tune_tn_mid_columns.log)
 template <typename T>
-pg_status launch_tn_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int U, int C, int W, int db, int bpc) {
-  if (env_int("PG_TN_MIDK", 1) == 1) {
+pg_status launch_tn_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int U, int C, int W, int nt, int bpc) {
 #define PG_TNM(UU, CC, WW, NN) \
-  if (U == UU && C == CC && W == WW && db + 1 == NN) return launch_tnm<T, UU, CC, WW, NN>(A, a, blocks_out, bpc)
-    PG_TNM(5, 4, 4, 1); PG_TNM(6, 4, 4, 1); PG_TNM(7, 4, 4, 1); PG_TNM(8, 4, 4, 1);
-    PG_TNM(5, 4, 4, 2); PG_TNM(6, 4, 4, 2); PG_TNM(7, 4, 4, 2); PG_TNM(8, 4, 4, 2);
-    PG_TNM(8, 2, 4, 1); PG_TNM(8, 2, 4, 2);
-    PG_TNM(4, 8, 8, 1); PG_TNM(4, 4, 8, 1); PG_TNM(4, 4, 8, 2);
-    PG_TNM(9, 2, 4, 1); PG_TNM(10, 2, 4, 1); PG_TNM(11, 2, 4, 1); PG_TNM(12, 2, 4, 1);
-    PG_TNM(13, 2, 4, 1); PG_TNM(14, 2, 4, 1); PG_TNM(15, 2, 4, 1); PG_TNM(16, 2, 4, 1);
-    PG_TNM(9, 2, 4, 2); PG_TNM(10, 2, 4, 2); PG_TNM(11, 2, 4, 2); PG_TNM(12, 2, 4, 2);
-    PG_TNM(13, 2, 4, 2); PG_TNM(14, 2, 4, 2); PG_TNM(15, 2, 4, 2); PG_TNM(16, 2, 4, 2);
-    PG_TNM(10, 4, 4, 1); PG_TNM(12, 4, 4, 1);
-    PG_TNM(9, 1, 8, 1); PG_TNM(10, 1, 8, 1); PG_TNM(11, 1, 8, 1); PG_TNM(12, 1, 8, 1);
-    PG_TNM(13, 1, 8, 1); PG_TNM(14, 1, 8, 1); PG_TNM(15, 1, 8, 1); PG_TNM(16, 1, 8, 1);
-    PG_TNM(9, 2, 8, 1); PG_TNM(10, 2, 8, 1); PG_TNM(11, 2, 8, 1); PG_TNM(12, 2, 8, 1); PG_TNM(13, 2, 8, 1);
-    PG_TNM(9, 1, 8, 2); PG_TNM(10, 1, 8, 2);
+  if (U == UU && C == CC && W == WW && nt == NN) return launch_tnm<T, UU, CC, WW, NN>(A, a, blocks_out, bpc)
+  PG_TNM(4, 4, 8, 2);
+  PG_TNM(9, 2, 4, 2); PG_TNM(10, 2, 4, 2); PG_TNM(11, 2, 4, 2); PG_TNM(12, 2, 4, 2);
+  PG_TNM(13, 2, 4, 2); PG_TNM(14, 2, 4, 2); PG_TNM(15, 2, 4, 2); PG_TNM(16, 2, 4, 2);
+  PG_TNM(10, 4, 4, 1); PG_TNM(16, 2, 4, 1);
+  PG_TNM(9, 2, 8, 1); PG_TNM(10, 2, 8, 1); PG_TNM(11, 2, 8, 1); PG_TNM(12, 2, 8, 1);
+  PG_TNM(13, 1, 8, 1); PG_TNM(14, 1, 8, 1); PG_TNM(15, 1, 8, 1); PG_TNM(16, 1, 8, 1);
 #undef PG_TNM
-    pg_set_error("no gemv_tnm instantiation for U=%d C=%d WAVES=%d tiles=%d", U, C, W, db + 1);
-    return PG_ERR_UNSUPPORTED;
-  }
-#define PG_MID(UU, CC, WW, DD) \
-  if (U == UU && C == CC && W == WW && db == DD) return launch_mid<T, UU, CC, WW, (DD != 0)>(A, a, blocks_out, bpc)
-  // four waves, exact U (33 .. 64 row groups)
-  PG_MID(9, 2, 4, 1); PG_MID(10, 2, 4, 1); PG_MID(11, 2, 4, 1); PG_MID(12, 2, 4, 1);
-  PG_MID(13, 2, 4, 1); PG_MID(14, 2, 4, 1); PG_MID(15, 2, 4, 1);
-  PG_MID(9, 2, 4, 0); PG_MID(10, 2, 4, 0); PG_MID(11, 2, 4, 0); PG_MID(12, 2, 4, 0);
-  PG_MID(13, 2, 4, 0); PG_MID(14, 2, 4, 0); PG_MID(15, 2, 4, 0); PG_MID(16, 2, 4, 0);
-  PG_MID(10, 4, 4, 0); PG_MID(12, 4, 4, 0);
-  // 17 .. 32 row groups on four waves (U = 5 .. 8)
-  PG_MID(8, 4, 4, 0); PG_MID(8, 2, 4, 0); PG_MID(8, 4, 4, 1); PG_MID(8, 2, 4, 1);
-  PG_MID(5, 4, 4, 0); PG_MID(6, 4, 4, 0); PG_MID(7, 4, 4, 0);
-  PG_MID(5, 4, 4, 1); PG_MID(6, 4, 4, 1); PG_MID(7, 4, 4, 1);
-  // eight waves, exact U (65 .. 128 row groups)
-  PG_MID(9, 2, 8, 0); PG_MID(10, 2, 8, 0); PG_MID(11, 2, 8, 0); PG_MID(12, 2, 8, 0);
-  PG_MID(13, 2, 8, 0); PG_MID(14, 2, 8, 0); PG_MID(15, 2, 8, 0); PG_MID(16, 2, 8, 0);
-  PG_MID(9, 1, 8, 0); PG_MID(10, 1, 8, 0); PG_MID(11, 1, 8, 0); PG_MID(12, 1, 8, 0);
-  PG_MID(13, 1, 8, 0); PG_MID(14, 1, 8, 0); PG_MID(15, 1, 8, 0);
-  PG_MID(9, 1, 8, 1); PG_MID(12, 1, 8, 1); PG_MID(16, 1, 8, 1);
-#undef PG_MID
-  pg_set_error("no mid-column gemv_tn instantiation for U=%d C=%d WAVES=%d tiles=%d", U, C, W, db + 1);
+  pg_set_error("no gemv_tnm instantiation for U=%d C=%d WAVES=%d tiles=%d", U, C, W, nt);
   return PG_ERR_UNSUPPORTED;
+}
+
+bool tn_mid_covers(int nrg) { return nrg >= 29 && nrg <= 128; }
+
+// geometry by column length (see the table above)
+template <typename T>
+pg_status launch_tn_mid_default(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  const int nrg = a.nrg;
+  if (nrg <= 32) return launch_tn_mid<T>(A, a, blocks_out, 4, 4, 8, 2, 1);
+  if (nrg <= 64) {
+    const int U = (nrg + 3) / 4;
+    return U == 10 ? launch_tn_mid<T>(A, a, blocks_out, 10, 4, 4, 1, 1) : launch_tn_mid<T>(A, a, blocks_out, U, 2, 4, 2, 1);
+  }
+  const int U = (nrg + 7) / 8;
+  return launch_tn_mid<T>(A, a, blocks_out, U, U <= 12 ? 2 : 1, 8, 1, 1);
 }
 
 template pg_status launch_tn_mid<float>(pg_mat*, TNArgs<float>&, int*, int, int, int, int, int);
 template pg_status launch_tn_mid<double>(pg_mat*, TNArgs<double>&, int*, int, int, int, int, int);
+template pg_status launch_tn_mid_default<float>(pg_mat*, TNArgs<float>&, int*);
+template pg_status launch_tn_mid_default<double>(pg_mat*, TNArgs<double>&, int*);
 
 }  // namespace pgtn

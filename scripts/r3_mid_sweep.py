@@ -24,26 +24,23 @@ def mid(U, C, W, db, bpc=1, k=1):
 def candidates(nrg, both=True):
     """(label, env): the default dispatch, then gemv_tnm (k = 1: branch-free tile loads, scalar x_j / z_old_j loads) and the
     exact-U instantiations of gemv_tn_kernel (k = 0) in the geometries that fit nrg row groups"""
-    c = [("default", {})]
+    c = [("default", {}), ("gemv_tn (round 2)", dict(PG_TN_KERNEL="wg"))]
     geo = []
     if 17 <= nrg <= 32:
         U = (nrg + 3) // 4
-        geo += [(U, 4, 4, db, bpc) for db in (0, 1) for bpc in (1, 2)]
-        if U == 8:
-            geo += [(8, 2, 4, db, bpc) for db in (0, 1) for bpc in (1, 2)] + [(4, 8, 8, 0, 1), (4, 4, 8, 0, 1), (4, 4, 8, 1, 1), (4, 8, 8, 0, 2)]
+        geo += [(U, 4, 4, db, 1) for db in (0, 1)]
+        U8 = (nrg + 7) // 8
+        geo += [(U8, 8, 8, 0, 1), (U8, 4, 8, 0, 1), (U8, 4, 8, 1, 1)]
     if 33 <= nrg <= 64:
         U = (nrg + 3) // 4
-        geo += [(U, 2, 4, db, bpc) for db in (0, 1) for bpc in (1, 2)]
+        geo += [(U, 2, 4, db, 1) for db in (0, 1)]
         if U in (10, 12):
             geo += [(U, 4, 4, 0, 1)]
     if 65 <= nrg <= 128:
         U = (nrg + 7) // 8
-        geo += [(U, C, 8, 0, bpc) for C in (1, 2) for bpc in (1, 2)]
-        if U in (9, 10):
-            geo += [(U, 1, 8, 1, 1)]
+        geo += [(U, C, 8, 0, 1) for C in (1, 2) if not (C == 2 and U > 13)]
     for (U, C, W, db, bpc) in geo:
-        for k in ((1, 0) if both else (1,)):
-            c.append((f"{'tnm' if k else 'tn '} U={U} C={C} W={W} tiles={db + 1} wg/CU={bpc}", mid(U, C, W, db, bpc, k)))
+        c.append((f"tnm U={U} C={C} W={W} tiles={db + 1} wg/CU={bpc}", mid(U, C, W, db, bpc, 1)))
     return c
 
 
@@ -97,5 +94,6 @@ if __name__ == "__main__":
     shapes = [(rest[i], rest[i + 1]) for i in range(0, len(rest) - 1, 2)]
     if cmd == "check":
         sys.exit(cmd_check())
-    cmd_ab(shapes or [(8192, 262144), (6144, 349520), (5120, 419424), (10240, 209712), (9000, 238608), (12288, 174760),
-                      (14336, 149796), (16384, 131072), (20480, 104856), (24576, 87380), (28672, 74896), (32768, 65536)])
+    total = 8192 * 262144  # elements: 8 GiB of Float32 per shape
+    cmd_ab(shapes or [(256 * g, total // (256 * g)) for g in (17, 20, 24, 28, 32, 33, 36, 40, 44, 48, 52, 56, 60, 64, 65, 72, 80, 88, 96,
+                                                                104, 112, 120, 128)])
