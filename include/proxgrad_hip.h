@@ -343,6 +343,12 @@ pg_status pg_iter_opts_default(pg_iter_opts* opts);
 /* ForwardBackwardIteration(; f, g, x0, ...) / FastForwardBackwardIteration(; ...) */
 pg_status pg_iter_create(pg_ctx* ctx, pg_ls* f, const pg_iter_opts* opts, pg_iter** out);
 pg_status pg_iter_destroy(pg_iter* it);
+/* g = IndBox with PER-ELEMENT bounds (ProximalOperators.IndBox(lo::AbstractArray, hi::AbstractArray)): lo / hi are
+ * device n-vectors (this rank's slices under column sharding), borrowed for the life of the iterator; call after
+ * pg_iter_create (g_kind = PG_G_INDBOX; g_p0 / g_p1 are then ignored) and before pg_iter_init.  NULL, NULL: the scalars again.
+ * The single sweep reads them as two more n-vector streams next to x and z_old.  pg_iter_run_small / _coop take scalar
+ * bounds only (PG_ERR_UNSUPPORTED). */
+pg_status pg_iter_set_g_vectors(pg_iter* it, const void* lo, const void* hi);
 /* Base.iterate(iter): forward_backward.jl:65-84 / fast_forward_backward.jl:73-97.
  * x0 is a DEVICE n-vector; it is copied, never mutated (test_lasso_small.jl:54). */
 pg_status pg_iter_init(pg_iter* it, const void* x0, pg_iter_scalars* out);

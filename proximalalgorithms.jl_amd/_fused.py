@@ -37,8 +37,16 @@ class FusedIteration:
         self.scalars = _lib.pg_iter_scalars()
         self.n = f.A.n
         self.dtype = f.A.dtype
+        self._g_vectors = None
 
     def init(self, x0):
+        if hasattr(self.g, "g_vectors") and self._g_vectors is None:  # IndBox with per-element bounds
+            lo, hi = self.g.g_vectors(x0)
+            if lo is not None:
+                if lo.n != self.n or hi.n != self.n:
+                    raise ValueError("IndBox bounds must have one entry per variable")
+                call("pg_iter_set_g_vectors", self._h, lo.vp, hi.vp)
+                self._g_vectors = (lo, hi)  # keep the device vectors alive as long as the iterator
         call("pg_iter_init", self._h, x0.vp, C.byref(self.scalars))
         return self.scalars
 

@@ -126,6 +126,7 @@ SIGNATURES = {
     "pg_iter_opts_default": [C.POINTER(pg_iter_opts)],
     "pg_iter_create": [_vp, _vp, C.POINTER(pg_iter_opts), C.POINTER(_vp)],
     "pg_iter_destroy": [_vp],
+    "pg_iter_set_g_vectors": [_vp, _vp, _vp],
     "pg_iter_init": [_vp, _vp, C.POINTER(pg_iter_scalars)],
     "pg_iter_step": [_vp, _f64, C.POINTER(pg_iter_scalars)],
     "pg_iter_run": [_vp, _i64, _i64, _f64, C.POINTER(_i64), C.POINTER(pg_iter_scalars)],

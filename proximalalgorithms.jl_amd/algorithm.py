@@ -82,7 +82,8 @@ class IterativeAlgorithm:
             A = it.f.A
             adaptive = bool(it.adaptive)
             nbytes = A.m * A.n * A.dtype.itemsize
-            unsharded = A.m > 0 and A.n > 0 and it.f.comm is None
+            # (the one-launch solvers take scalar IndBox bounds only)
+            unsharded = A.m > 0 and A.n > 0 and it.f.comm is None and fused._g_vectors is None
             # measured crossovers (tests/tools/bench_small.py, profiles/): one workgroup up to ~8k elements; the cooperative
             # multi-workgroup kernel while A is a few MiB (its barriers beat launches + host round trips: up to ~10 MiB
             # with the adaptive step, ~8 MiB against per-iteration syncs, ~3 MiB against the batched fixed-step loop);

@@ -703,7 +703,8 @@ pg_status ls_value_t(pg_ls* f, const T* x) {
 // then f->r = A v - b and dscal[PG_S_F] = lam/2 ||A v - b||^2; epilogue scalars -> dscal[PG_S_GZ..PG_S_RESSQ]
 template <typename T>
 pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, const T* x, const T* z_old, double gamma,
-                          double beta, int g_kind, double g_p0, double g_p1, T* g_out, T* y, T* z_new, T* res, T* v_out) {
+                          double beta, int g_kind, double g_p0, double g_p1, T* g_out, T* y, T* z_new, T* res, T* v_out,
+                          const T* g_v0, const T* g_v1) {
   pg_ctx* c = f->ctx;
   pg_mat* A = f->A;
   if (pg_row_sharded(c) || !tn_supported<T>(A)) {
@@ -729,6 +730,8 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   a.p1 = (T)g_p1;
   a.lam_ls = (T)f->lam;
   a.g_kind = g_kind;
+  a.p0v = g_kind == PG_G_INDBOX ? g_v0 : nullptr;
+  a.p1v = g_kind == PG_G_INDBOX ? g_v1 : nullptr;
   a.gscale = g_kind == PG_G_NORML1 ? (double)(T)g_p0 : 0.0;
   a.g_out = g_out;
   a.y = y;
@@ -921,17 +924,17 @@ pg_status ls_vg_t(pg_ls* f, const T* x, T* grad_out) {
 
 pg_status pg_ls_fused_pass_async(pg_ls* f, const void* r_src, void* r_dst, double* f_dst, const void* x, const void* z_old,
                                  double gamma, double beta, int g_kind, double g_p0, double g_p1, void* grad, void* y,
-                                 void* z_new, void* res, void* v_next) {
+                                 void* z_new, void* res, void* v_next, const void* g_v0, const void* g_v1) {
   if (r_src == nullptr) r_src = f->r;
   if (r_dst == nullptr) r_dst = f->r;
   if (f_dst == nullptr) f_dst = f->ctx->dscal + PG_S_F;
   return f->A->dtype == PG_F32
              ? ls_fused_pass_t<float>(f, (const float*)r_src, (float*)r_dst, f_dst, (const float*)x, (const float*)z_old, gamma,
                                       beta, g_kind, g_p0, g_p1, (float*)grad, (float*)y, (float*)z_new, (float*)res,
-                                      (float*)v_next)
+                                      (float*)v_next, (const float*)g_v0, (const float*)g_v1)
              : ls_fused_pass_t<double>(f, (const double*)r_src, (double*)r_dst, f_dst, (const double*)x, (const double*)z_old,
                                        gamma, beta, g_kind, g_p0, g_p1, (double*)grad, (double*)y, (double*)z_new,
-                                       (double*)res, (double*)v_next);
+                                       (double*)res, (double*)v_next, (const double*)g_v0, (const double*)g_v1);
 }
 
 pg_status pg_ls_allreduce_epilogue_scalars(pg_ls* f) {

@@ -57,6 +57,10 @@ struct TNArgs {
   const T* z_old;  // [n] the prox output of the previous iteration (for v); may alias nothing written here
   T gamma, beta, p0, p1, lam_ls;  // p0 = gamma * lam (NormL1) | lo (IndBox) ; p1 = hi
   int g_kind;
+  // IndBox with PER-ELEMENT bounds (ProximalOperators.IndBox(lo::AbstractArray, hi::AbstractArray)): lo_j = p0v[j], hi_j = p1v[j];
+  // nullptr: the scalars p0 / p1.  Two more n-vector streams next to x and z_old (< 0.1 % of the sweep's bytes).
+  const T* p0v = nullptr;
+  const T* p1v = nullptr;
   double gscale;  // lam for NormL1 else 0
   T *g_out, *y, *z_new, *res, *v_out;  // [n] each
   T* partials;                         // [gridDim.x][ld]
@@ -232,9 +236,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
         T zj;
         if (a.g_kind == PG_G_NORML1)
           zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-        else if (a.g_kind == PG_G_INDBOX)
-          zj = fmin(a.p1, fmax(a.p0, yj));
-        else
+        else if (a.g_kind == PG_G_INDBOX) {
+          T lo = a.p0, hi = a.p1;
+          if (a.p0v != nullptr) lo = a.p0v[valid ? j : a.n - 1], hi = a.p1v[valid ? j : a.n - 1];
+          zj = fmin(hi, fmax(lo, yj));
+        } else
           zj = yj;
         const T rj = xj - zj;
         vj = valid ? zj + a.beta * (zj - zo) : T(0);

@@ -182,9 +182,11 @@ __global__ __launch_bounds__(WPB * 64) void gemv_tnw_kernel(TNArgs<T> a) {
     T zj;                            // :118 / :141
     if (a.g_kind == PG_G_NORML1)
       zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-    else if (a.g_kind == PG_G_INDBOX)
-      zj = fmin(a.p1, fmax(a.p0, yj));
-    else
+    else if (a.g_kind == PG_G_INDBOX) {
+      T lo = a.p0, hi = a.p1;
+      if (a.p0v != nullptr) lo = a.p0v[jc], hi = a.p1v[jc];  // per-element bounds
+      zj = fmin(hi, fmax(lo, yj));
+    } else
       zj = yj;
     const T rj = xj - zj;                                     // :120 / :142
     const T vj = valid ? zj + a.beta * (zj - zo) : T(0);      // fast_forward_backward.jl:135 of the next iteration
@@ -342,9 +344,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnc_kernel(TNArgs<T> a) {
     T zj;                            // :118 / :141
     if (a.g_kind == PG_G_NORML1)
       zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-    else if (a.g_kind == PG_G_INDBOX)
-      zj = fmin(a.p1, fmax(a.p0, yj));
-    else
+    else if (a.g_kind == PG_G_INDBOX) {
+      T lo = a.p0, hi = a.p1;
+      if (a.p0v != nullptr) lo = a.p0v[jc], hi = a.p1v[jc];  // per-element bounds
+      zj = fmin(hi, fmax(lo, yj));
+    } else
       zj = yj;
     const T rj = xj - zj;                                 // :120 / :142
     const T vj = valid ? zj + a.beta * (zj - zo) : T(0);  // fast_forward_backward.jl:135 of the next iteration
@@ -607,9 +611,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
       T zj;                            // :118 / :141
       if (a.g_kind == PG_G_NORML1)
         zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-      else if (a.g_kind == PG_G_INDBOX)
-        zj = fmin(a.p1, fmax(a.p0, yj));
-      else
+      else if (a.g_kind == PG_G_INDBOX) {
+        T lo = a.p0, hi = a.p1;
+        if (a.p0v != nullptr) lo = a.p0v[valid ? j : a.n - 1], hi = a.p1v[valid ? j : a.n - 1];  // per-element bounds
+        zj = fmin(hi, fmax(lo, yj));
+      } else
         zj = yj;
       const T rj = xj - zj;                             // :120 / :142
       vj[c] = valid ? zj + a.beta * (zj - zo) : T(0);   // fast_forward_backward.jl:135 of the next iteration

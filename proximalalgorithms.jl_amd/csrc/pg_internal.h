@@ -193,7 +193,9 @@ pg_status pg_ls_value_async(pg_ls* f, const void* x);
 pg_status pg_ls_fused_pass_async(pg_ls* f, const void* r_src /* null: f->r */, void* r_dst /* null: f->r */,
                                  double* f_dst /* device scalar; null: dscal[PG_S_F] */, const void* x, const void* z_old,
                                  double gamma, double beta, int g_kind, double g_p0, double g_p1, void* grad, void* y,
-                                 void* z_new, void* res, void* v_next /* nullable */);
+                                 void* z_new, void* res, void* v_next /* nullable */,
+                                 const void* g_v0 = nullptr /* IndBox: per-element lo, hi (else the scalars g_p0, g_p1) */,
+                                 const void* g_v1 = nullptr);
 bool pg_ls_fused_pass_supported(const pg_ls* f);
 // g = lam A' r (+ all-reduce) from the residual currently held in f->r; f must already be in dscal[PG_S_F]
 pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out);
@@ -203,7 +205,8 @@ pg_status pg_residual_combo_async(pg_ctx* ctx, int dtype, int64_t m, void* r_out
 // column sharding: global sums / max of the four epilogue scalars in dscal[PG_S_GZ..PG_S_RESSQ] (one small all-reduce)
 pg_status pg_ls_allreduce_epilogue_scalars(pg_ls* f);
 pg_status pg_fb_epilogue_async(pg_ctx* ctx, int dtype, int64_t n, const void* x, const void* grad, double gamma,
-                               int g_kind, double g_p0, double g_p1, void* y, void* z, void* res);
+                               int g_kind, double g_p0, double g_p1, void* y, void* z, void* res, const void* g_v0 = nullptr,
+                               const void* g_v1 = nullptr);
 
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------------------------

@@ -45,7 +45,7 @@ template <typename T>
 pg_status epilogue_and_read(pg_iter* it, bool read_f) {
   pg_ctx* c = it->ctx;
   PG_TRY(pg_fb_epilogue_async(c, it->dtype, it->n, it->x, it->grad_f_x, it->gamma, it->o.g_kind, it->o.g_p0,
-                              it->o.g_p1, it->y, it->z, it->res));
+                              it->o.g_p1, it->y, it->z, it->res, it->g_v0, it->g_v1));
   PG_TRY(pg_ls_allreduce_epilogue_scalars(it->f));  // column shards: the kernel's sums cover this rank's columns only
   if (it->defer_sync) return PG_OK;  // scalars stay on the device side until the batch is synchronised
   PG_TRY(pg_read_scalars(c, PG_S_F, 5));
@@ -252,7 +252,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
       it->sp_slot ^= 1;
       pg_status st = pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev,
                                             it->gamma, beta2, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res,
-                                            it->x_next);
+                                            it->x_next, it->g_v0, it->g_v1);
       if (st == PG_OK && !it->defer_sync) st = read_sweep_scalars<T>(it);
       if (sweep_lost(st) && !it->defer_sync) return redo_with_two_sweeps<T>(it, st, false);
       PG_TRY(st);
@@ -277,7 +277,8 @@ pg_status iter_step_single_sweep(pg_iter* it) {
       }
       it->sp_slot ^= 1;
       pg_status st = pg_ls_fused_pass_async(f, nullptr, nullptr, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->x, it->gamma,
-                                            0.0, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr);
+                                            0.0, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr, it->g_v0,
+                                            it->g_v1);
       if (st == PG_OK && !it->defer_sync) st = read_sweep_scalars<T>(it);
       if (sweep_lost(st) && !it->defer_sync) return redo_with_two_sweeps<T>(it, st, false);
       PG_TRY(st);
@@ -327,7 +328,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
   // A' r, prox (:138-142) and the residual of the NEW z for the next line search, one sweep
   it->sp_slot ^= 1;
   pg_status st = pg_ls_fused_pass_async(f, f->r, it->rz, c->dscal + PG_S_FNEXT + it->sp_slot, it->x, it->z_prev, it->gamma, 0.0,
-                                        o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr);
+                                        o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr, it->g_v0, it->g_v1);
   if (st == PG_OK) st = read_sweep_scalars<T>(it);
   if (sweep_lost(st)) {  // the sweep read f->r and wrote rz: the residual of x and f(x) (PG_S_F) are intact
     it->rz_valid = false;
@@ -472,6 +473,15 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
     it->rz_prev = base + nvec * vb + mb;
   }
   *out = it;
+  return PG_OK;
+}
+
+pg_status pg_iter_set_g_vectors(pg_iter* it, const void* lo, const void* hi) {
+  PG_REQUIRE(it != nullptr, "iterator is null");
+  PG_REQUIRE((lo == nullptr) == (hi == nullptr), "lo and hi must both be vectors or both be null");
+  PG_REQUIRE(lo == nullptr || it->o.g_kind == PG_G_INDBOX, "per-element parameters are for g = IndBox");
+  it->g_v0 = lo;
+  it->g_v1 = hi;
   return PG_OK;
 }
 

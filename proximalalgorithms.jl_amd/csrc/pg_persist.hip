@@ -998,6 +998,10 @@ pg_status pg_iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double 
   PG_REQUIRE(it->o.seq_kind != PG_SEQ_HOST || !it->o.fast, "PG_SEQ_HOST needs per-step coefficients");
   PG_REQUIRE(it->ctx->allreduce == nullptr && it->ctx->allreduce_begin == nullptr,
              "the single-workgroup solver does not support row-sharded operators");
+  if (it->g_v0 != nullptr) {
+    pg_set_error("the single-workgroup solver takes scalar IndBox bounds only (per-element bounds: pg_iter_run)");
+    return PG_ERR_UNSUPPORTED;
+  }
   pg_mat* A = it->f->A;
   if (A->m * A->n > ((int64_t)1 << 20) || A->m >= ((int64_t)1 << 31) || A->n >= ((int64_t)1 << 31) || A->m == 0 || A->n == 0) {
     pg_set_error("pg_iter_run_small is for launch-bound sizes (0 < m * n <= 2^20 elements); use pg_iter_run");
@@ -1018,6 +1022,10 @@ pg_status pg_iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double t
   PG_REQUIRE(it->o.seq_kind != PG_SEQ_HOST || !it->o.fast, "PG_SEQ_HOST needs per-step coefficients");
   PG_REQUIRE(it->ctx->allreduce == nullptr && it->ctx->allreduce_begin == nullptr,
              "the cooperative solver does not support row-sharded operators");
+  if (it->g_v0 != nullptr) {
+    pg_set_error("the cooperative solver takes scalar IndBox bounds only (per-element bounds: pg_iter_run)");
+    return PG_ERR_UNSUPPORTED;
+  }
   pg_mat* A = it->f->A;
   const int64_t es = (int64_t)pg_sizeof(it->dtype);
   if (A->m == 0 || A->n == 0 || A->n >= ((int64_t)1 << 31) || 3 * pg_round_up(A->m, 64) * es > COOP_MAX_LDS * 3 / 4 ||

@@ -172,16 +172,21 @@ struct EpilogueF {
   T* grad_copy;  // nullable: also materialise grad here (sharded path keeps it in the all-reduce buffer)
   T gamma, p0, p1;  // p0 = gamma*lam (NormL1) | lo (IndBox) ; p1 = hi
   double gscale;    // lam for NormL1 else 0
+  const T* p0v = nullptr;  // IndBox: per-element bounds (nullptr: the scalars)
+  const T* p1v = nullptr;
   template <int N>
   __device__ __forceinline__ void apply(int64_t i, double* acc) const {
-    Pack<T, N> xv = ld<T, N>(x, i), gv = ld<T, N>(grad, i), yv, zv, rv;
+    Pack<T, N> xv = ld<T, N>(x, i), gv = ld<T, N>(grad, i), yv, zv, rv, lov, hiv;
+    if constexpr (GKIND == PG_G_INDBOX) {
+      if (p0v != nullptr) lov = ld<T, N>(p0v, i), hiv = ld<T, N>(p1v, i);
+    }
 #pragma unroll
     for (int e = 0; e < N; ++e) {
       yv.v[e] = xv.v[e] - gamma * gv.v[e];
       if constexpr (GKIND == PG_G_NORML1)
         zv.v[e] = soft_threshold(yv.v[e], p0);
       else if constexpr (GKIND == PG_G_INDBOX)
-        zv.v[e] = fmin(p1, fmax(p0, yv.v[e]));
+        zv.v[e] = p0v != nullptr ? fmin(hiv.v[e], fmax(lov.v[e], yv.v[e])) : fmin(p1, fmax(p0, yv.v[e]));
       else
         zv.v[e] = yv.v[e];
       rv.v[e] = xv.v[e] - zv.v[e];
@@ -641,9 +646,9 @@ __device__ __forceinline__ void ew_on_final(const ResidualComboF<T>& f, const do
 
 template <typename T>
 pg_status epilogue_t(pg_ctx* c, int64_t n, const T* x, const T* grad, double gamma, int g_kind, double g_p0,
-                     double g_p1, T* y, T* z, T* res, T* grad_copy) {
+                     double g_p1, T* y, T* z, T* res, T* grad_copy, const T* g_v0 = nullptr, const T* g_v1 = nullptr) {
   const bool v = aligned16(x) && aligned16(grad) && aligned16(y) && aligned16(z) && aligned16(res) &&
-                 (grad_copy == nullptr || aligned16(grad_copy));
+                 (grad_copy == nullptr || aligned16(grad_copy)) && (g_v0 == nullptr || (aligned16(g_v0) && aligned16(g_v1)));
   const T gm = (T)gamma;
   pg_prof_scope prof(c, PG_K_EPILOGUE);
   if (g_kind == PG_G_NORML1) {
@@ -651,7 +656,7 @@ pg_status epilogue_t(pg_ctx* c, int64_t n, const T* x, const T* grad, double gam
     return launch_ew<T, decltype(f), 4, 0x2u>(c, n, v, f, c->dscal + PG_S_GZ);
   }
   if (g_kind == PG_G_INDBOX) {
-    EpilogueF<T, PG_G_INDBOX> f{x, grad, y, z, res, grad_copy, gm, (T)g_p0, (T)g_p1, 0.0};
+    EpilogueF<T, PG_G_INDBOX> f{x, grad, y, z, res, grad_copy, gm, (T)g_p0, (T)g_p1, 0.0, g_v0, g_v1};
     return launch_ew<T, decltype(f), 4, 0x2u>(c, n, v, f, c->dscal + PG_S_GZ);
   }
   if (g_kind == PG_G_ZERO) {
@@ -948,12 +953,13 @@ pg_status pg_residual_combo_async(pg_ctx* c, int dtype, int64_t m, void* r_out, 
 }
 
 pg_status pg_fb_epilogue_async(pg_ctx* c, int dtype, int64_t n, const void* x, const void* grad, double gamma,
-                               int g_kind, double g_p0, double g_p1, void* y, void* z, void* res) {
+                               int g_kind, double g_p0, double g_p1, void* y, void* z, void* res, const void* g_v0,
+                               const void* g_v1) {
   PG_DISPATCH(dtype,
               epilogue_t<float>(c, n, (const float*)x, (const float*)grad, gamma, g_kind, g_p0, g_p1, (float*)y,
-                                (float*)z, (float*)res, nullptr),
+                                (float*)z, (float*)res, nullptr, (const float*)g_v0, (const float*)g_v1),
               epilogue_t<double>(c, n, (const double*)x, (const double*)grad, gamma, g_kind, g_p0, g_p1,
-                                 (double*)y, (double*)z, (double*)res, nullptr));
+                                 (double*)y, (double*)z, (double*)res, nullptr, (const double*)g_v0, (const double*)g_v1));
 }
 
 extern "C" {

@@ -59,7 +59,7 @@ class FastForwardBackwardIteration:
         if engine == "composed" and not composed_supported(self.f, self.g):
             raise TypeError("engine='composed' needs f = Composed(loss, device matrix) and g in {NormL1, IndBox(scalar bounds), Zero}")
         if engine == "fused" and not fused_supported(self.f, self.g):
-            raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox(scalar bounds), Zero}")
+            raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox, Zero}")
         self.engine = engine
         self.counters = {}
 

@@ -87,7 +87,7 @@ class ForwardBackwardIteration:
             raise TypeError("engine='composed' needs f = Composed(loss, device matrix) or an unsharded LeastSquares, and g in "
                             "{NormL1, IndBox(scalar bounds), Zero}")
         if engine == "fused" and not fused_supported(self.f, self.g):
-            raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox(scalar bounds), Zero}")
+            raise TypeError("engine='fused' needs f = LeastSquares and g in {NormL1, IndBox, Zero}")
         self.engine = engine
         self.counters = {}
 

@@ -188,15 +188,18 @@ function ProximalCore.prox!(y::HIPVector{T}, g::HIPNormL1, x::HIPVector{T}, gamm
                 x.ctx.handle, pg_dtype(T), x.n, y.ptr, x.ptr, g.lambda, gamma, gy))
     T(gy[])
 end
+# IndBox(lo, hi): scalar bounds or per-element bounds (HIPVectors), like ProximalOperators.IndBox
 struct HIPIndBox{R}
     lo::R
     hi::R
 end
+box_scalar(v) = v isa HIPVector ? 0.0 : Float64(v)
+box_vector(v) = v isa HIPVector ? v.ptr : C_NULL
 function ProximalCore.prox!(y::HIPVector{T}, g::HIPIndBox, x::HIPVector{T}, gamma) where {T}
     gy = Ref{Float64}(0)
     check(ccall((:pg_prox_indbox, libpg), Int32,
                 (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}),
-                x.ctx.handle, pg_dtype(T), x.n, y.ptr, x.ptr, g.lo, g.hi, C_NULL, C_NULL, gy))
+                x.ctx.handle, pg_dtype(T), x.n, y.ptr, x.ptr, box_scalar(g.lo), box_scalar(g.hi), box_vector(g.lo), box_vector(g.hi), gy))
     T(0)
 end
 ProximalCore.prox(g::Union{HIPNormL1,HIPIndBox}, x::HIPVector, gamma) = (y = similar(x); (y, ProximalCore.prox!(y, g, x, gamma)))
@@ -218,7 +221,11 @@ struct PgIterState
     x::Ptr{Cvoid}; grad_f_x::Ptr{Cvoid}; y::Ptr{Cvoid}; z::Ptr{Cvoid}; res::Ptr{Cvoid}; z_prev::Ptr{Cvoid}; grad_f_z::Ptr{Cvoid}
 end
 g_spec(g::HIPNormL1) = (Int32(1), Float64(g.lambda), 0.0)
-g_spec(g::HIPIndBox) = (Int32(2), Float64(g.lo), Float64(g.hi))
+g_spec(g::HIPIndBox) = (Int32(2), box_scalar(g.lo), box_scalar(g.hi))
+# per-element bounds reach the fused iteration through pg_iter_set_g_vectors (after create, before init)
+set_g_vectors!(h, g) = nothing
+set_g_vectors!(h, g::HIPIndBox{<:HIPVector}) =
+    check(ccall((:pg_iter_set_g_vectors, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, g.lo.ptr, g.hi.ptr))
 
 # extrapolation sequences (src/accel/nesterov.jl) -> (seq_kind, seq_p0, seq_p1, host-side iterator or nothing)
 const PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST, PG_SEQ_REPEATED =
@@ -300,6 +307,7 @@ function Base.iterate(iter::HIPIteration)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:pg_iter_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterOpts}, Ref{Ptr{Cvoid}}),
                 iter.f.A.ctx.handle, iter.f.handle, opts, h))
+    set_g_vectors!(h[], iter.g)
     sc = Ref{PgIterScalars}()
     check(ccall((:pg_iter_init, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterScalars}), h[], x0.ptr, sc))
     st = HIPIterState{R,T}(h[], x0, R(0), x0, R(0), x0, x0, R(0), x0, nothing,

@@ -214,9 +214,15 @@ class IndBox:
         self._lov = self._hiv = None
 
     def g_params(self):
+        """(lo, hi) as the scalars of the C ABI; with per-element bounds the fused iteration takes them through
+        ``g_vectors`` (pg_iter_set_g_vectors) and ignores these"""
         if not self._scalar:
-            raise TypeError("vector bounds are not supported by the fused iteration; use engine='generic'")
+            return 0.0, 0.0
         return float(self.lo), float(self.hi)
+
+    def g_vectors(self, x):
+        """per-element bounds as device vectors shaped like ``x`` (None, None for scalar bounds)"""
+        return self._vectors(x)
 
     def _vectors(self, x):
         if self._scalar:
@@ -603,8 +609,4 @@ def prox(g, x, gamma):
 
 def fused_supported(f, g):
     """True when (f, g) is the pair the fused HIP iteration is specialised for."""
-    if not isinstance(f, LeastSquares) or not isinstance(g, (NormL1, IndBox, Zero)):
-        return False
-    if isinstance(g, IndBox) and not g._scalar:
-        return False
-    return True
+    return isinstance(f, LeastSquares) and isinstance(g, (NormL1, IndBox, Zero))

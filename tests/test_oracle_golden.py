@@ -592,3 +592,25 @@ def test_linear_programs(dtype):
     xf, it = ox.davis_yin(gamma=dtype(1), f=ox.Linear(c), g=ox.IndNonnegative(), h=ox.IndAffine(A, b), **kw)
     assert xf.dtype == dtype and it <= rv.LP_MAXIT
     assert np.linalg.norm(xf - rv.LP_XSTAR.astype(dtype)) <= 100 * tol
+
+
+def test_cpu_twin_matches_the_numpy_oracle():
+    """oracle/csrc/cpu_twin.c -- the C / OpenMP restatement bench.py times as its CPU leg -- against the numpy oracle
+    (fast_forward_backward.jl:73-145 restated, itself pinned to the reference's known answers above): same iterates after
+    25 fixed-step iterations up to summation order, for every thread count (the partial sums of A x are combined in thread
+    order)."""
+    from oracle import cpu_twin
+
+    m, n = 300, 900
+    A, b, _ = o.synthetic_lasso(m, n, seed=2, dtype=np.float32)
+    A = np.asfortranarray(A)
+    lam = np.float32(0.1) * np.float32(np.max(np.abs(A.T @ b)))
+    Lf = np.float32(1.05) * np.float32(np.linalg.norm(A.astype(np.float64), 2) ** 2)
+    it = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(n, np.float32), Lf=Lf))
+    for _ in range(26):
+        s = next(it)
+    for threads in (1, 3, None):
+        z, fx, sec, thr = cpu_twin.ffb(A, b, lam, Lf, 25, threads=threads)
+        assert np.max(np.abs(z - s.z)) <= 1e-5 * max(1.0, float(np.max(np.abs(s.z))))
+        assert abs(fx - float(s.f_x)) <= 1e-5 * abs(float(s.f_x)) and sec > 0 and thr >= 1
+        assert np.array_equal(z != 0, s.z != 0) or np.count_nonzero((z != 0) != (s.z != 0)) <= 2
