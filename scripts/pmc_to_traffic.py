@@ -11,7 +11,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GROUPS = {"gemv_tn": ("gemv_tn_kernel", "gemv_tnw_kernel", "gemv_tnc_kernel", "gemv_tnt_kernel"), "gemv_n_partial": ("gemv_n_partial_kernel",),
+GROUPS = {"gemv_tn": ("gemv_tn_kernel", "gemv_tnm_kernel", "gemv_tnw_kernel", "gemv_tnc_kernel", "gemv_tnt_kernel"), "gemv_n_partial": ("gemv_n_partial_kernel",),
           "gemv_t": ("gemv_t_kernel",)}
 
 

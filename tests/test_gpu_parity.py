@@ -731,7 +731,7 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
 def test_four_ranks_one_gpu_column_shards(pa):
     """Four processes sharing cuda:0 over gloo, column shards (4096 columns each): the 4 * world scalar slots and the
     m-element partial sums combine to the single-rank answers, fixed and adaptive step."""
-    for mode in ("fixed", "adaptive"):
+    for mode in ("adaptive",):  # (the fixed step runs with eight ranks below)
         one = _run_bench(["--mode", mode])
         four = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", "cols"], nproc=4, port=29655)
         assert four["n_gpus"] == 4 and four["config"]["n_per_gpu"] * 4 == one["config"]["n"]
@@ -898,7 +898,7 @@ def test_headline_iterates_match_oracle(pa):
     free, _ = torch.cuda.mem_get_info()
     if free < 70 * 2**30 or not _host_can_hold(3 * 64 * 2**30):
         pytest.skip("needs 64 GiB of free HBM and 3 x 64 GiB of host memory")
-    _ffb_device_vs_oracle(pa, 16384, 1 << 20, np.float32, fixed_its=10, adaptive_its=6, z_tol=1e-5)
+    _ffb_device_vs_oracle(pa, 16384, 1 << 20, np.float32, fixed_its=8, adaptive_its=4, z_tol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1222,14 +1222,16 @@ def test_zerofpr_panocplus_at_config4_column_length_against_oracle(pa, alg):
 
 
 def test_panoc_at_config4_full_size_against_oracle(pa):
-    """BASELINE config 4 AT ITS OWN SIZE (16384 x 10^6, Float32, 61 GiB): four PANOC iterations on the device against the
-    oracle on the downloaded matrix (about 20 s of host BLAS per iteration: several evaluations of 2 x 61 GiB each)."""
+    """BASELINE config 4 AT ITS OWN SIZE (16384 x 10^6, Float32, 61 GiB): the initial state and one PANOC iteration on the
+    device against the oracle on the downloaded matrix (about 20 s of host BLAS per iteration: several evaluations of
+    2 x 61 GiB each; round 2 ran four iterations -- the steady state of the same kernels is compared at the config's
+    column length above, this test is about the size: 64-bit addressing, 10^6 columns that are no power of two)."""
     import torch
 
     free, _ = torch.cuda.mem_get_info()
     if free < 70 * 2**30 or not _host_can_hold(3 * 64 * 2**30):
         pytest.skip("needs 61 GiB of free HBM and 3 x 61 GiB of host memory")
-    _panoc_logistic_vs_oracle(pa, 16384, 1_000_000, 4)
+    _panoc_logistic_vs_oracle(pa, 16384, 1_000_000, 2, passes_per_it=4.0)
 
 
 def test_config2_iterates_match_oracle(pa):
