@@ -334,6 +334,20 @@ def _host_memory_limit():
     return lim
 
 
+def _effective_cpus():
+    """CPUs this process can actually keep busy: the affinity mask capped by the cgroup's CPU quota (cpu.max = quota period).
+    The GPU box shows 256 hardware threads but grants 16 CPUs' worth of time; more runnable threads than that are throttled
+    and a streaming loop gets SLOWER (measured there: 16 threads 140-160 GB/s, 64 threads 70, 128 threads 43)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(float(quota) / float(period)))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -346,25 +360,29 @@ def _blas_threads():
 def host_stream_gbps(threads=None, mib_per_array=1024, reps=3):
     """The host's own streaming rate, so that the CPU leg's it/s can be read as a fraction of what this host can move:
     STREAM "add" (a = b + c, Float32, 12 bytes per element by STREAM's count) with numpy kernels on `threads` Python threads
-    (numpy releases the GIL inside the loop), each on its own contiguous chunk; best of `reps`.  Returns (GB/s with all
-    threads, GB/s with one thread, threads)."""
+    (numpy releases the GIL inside the loop), each on its own contiguous chunk, sustained over at least one second.  `threads`
+    defaults to the CPUs the cgroup grants (_effective_cpus).  Returns (GB/s with all threads, GB/s with one thread, threads)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
 
-    threads = threads or min(os.cpu_count() or 1, 64)
+    threads = threads or min(_effective_cpus(), 64)
     n = mib_per_array * (1 << 20) // 4
     b, c_, a = np.ones(n, np.float32), np.ones(n, np.float32), np.empty(n, np.float32)
     a[:] = 0  # touch every page before timing
 
     def rate(T):
+        # sustained, not a burst: passes back to back for at least a second (a CPU quota refills per 100 ms period, so a
+        # single 15 ms pass on many threads would show a rate the cgroup does not sustain)
         cuts = [n * k // T for k in range(T + 1)]
-        best = float("inf")
         with ThreadPoolExecutor(T) as ex:
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                list(ex.map(lambda k: np.add(b[cuts[k]:cuts[k + 1]], c_[cuts[k]:cuts[k + 1]], out=a[cuts[k]:cuts[k + 1]]), range(T)))
-                best = min(best, time.perf_counter() - t0)
-        return 3 * n * 4 / best / 1e9
+            one = lambda: list(ex.map(lambda k: np.add(b[cuts[k]:cuts[k + 1]], c_[cuts[k]:cuts[k + 1]], out=a[cuts[k]:cuts[k + 1]]), range(T)))
+            one()
+            passes, t0 = 0, time.perf_counter()
+            while passes < reps or time.perf_counter() - t0 < 1.0:
+                one()
+                passes += 1
+            dt = time.perf_counter() - t0
+        return 3 * n * 4 * passes / dt / 1e9
 
     return rate(threads), rate(1), threads
 
@@ -378,8 +396,10 @@ def _cpu_bandwidth_fields(rec, m, n, es):
         g_all, g_one, T = host_stream_gbps()
         rec["host_stream_GBps"] = round(g_all, 1)
         rec["host_stream_GBps_1thread"] = round(g_one, 1)
-        rec["host_stream_note"] = "STREAM add (Float32, numpy kernels on %d threads, 3 x 1 GiB arrays): what this host streams; " \
-                                  "achieved_GBps / host_stream_GBps is the CPU leg's own roofline fraction" % T
+        rec["host_cpus_granted"] = _effective_cpus()
+        rec["host_stream_note"] = "STREAM add (Float32, numpy kernels on %d threads = the CPUs the cgroup grants, 3 x 1 GiB arrays, sustained " \
+                                  "over >= 1 s): what this host streams for this job; achieved_GBps / host_stream_GBps is the CPU " \
+                                  "leg's own roofline fraction" % T
     except Exception as e:  # never let the side measurement cost the line
         rec["host_stream_GBps"] = None
         rec["host_stream_note"] = "not measured: %s" % str(e)[:120]
@@ -408,11 +428,12 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
         try:
             from oracle import cpu_twin
 
-            _, _, sec1, thr = cpu_twin.ffb(A, b, lam, Lf, 1)  # one iteration to size the run
+            ncpu = _effective_cpus()  # (not omp_get_max_threads: the cgroup's CPU quota, see _effective_cpus)
+            _, _, sec1, thr = cpu_twin.ffb(A, b, lam, Lf, 1, threads=ncpu)  # one iteration to size the run
             steps = int(max(2, min(max_steps, 0.5 * budget_s / max(sec1, 1e-3))))
-            _, _, sec, thr = cpu_twin.ffb(A, b, lam, Lf, steps)
+            _, _, sec, thr = cpu_twin.ffb(A, b, lam, Lf, steps, threads=ncpu)
             _, _, sec_1t, _ = cpu_twin.ffb(A, b, lam, Lf, 1, threads=1)
-            cpu_twin.load().cpu_twin_set_threads(thr)
+            cpu_twin.load().cpu_twin_set_threads(ncpu)
             rec = {"value": steps / sec, "value_1thread": 1.0 / sec_1t, "unit": "it/s", "cores": int(thr), "kind": "port",
                    "impl": "C / OpenMP twin of the reference's unfused op sequence (oracle/csrc/cpu_twin.c)",
                    "sample": f"the full workload: FFB fixed-step on the downloaded {m}x{n} float32 matrix ({A.nbytes / 2**30:.1f} GiB, "
@@ -423,13 +444,23 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
     it = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(n, A.dtype), Lf=Lf))
     next(it)  # init (two passes), untimed like the GPU side
     np_budget = budget_s if rec is None else 0.35 * budget_s
-    steps_np, t0 = 0, time.perf_counter()
-    while steps_np < max_steps and (steps_np < 2 or time.perf_counter() - t0 < np_budget):
-        next(it)
-        steps_np += 1
-    dt = time.perf_counter() - t0
-    numpy_rec = {"value": steps_np / dt, "cores": int(_blas_threads()), "achieved_GBps": round(2.0 * m * n * es * steps_np / dt / 1e9, 1),
-                 "sample": f"{steps_np} iterations in {dt:.1f} s"}
+    import contextlib
+
+    try:  # the BLAS pool no larger than the CPUs the cgroup grants (an oversubscribed pool is throttled, not faster)
+        from threadpoolctl import threadpool_limits
+
+        blas_cap = threadpool_limits(limits=min(int(_blas_threads()), _effective_cpus()), user_api="blas")
+    except Exception:
+        blas_cap = contextlib.nullcontext()
+    with blas_cap:
+        blas_n = int(_blas_threads())
+        steps_np, t0 = 0, time.perf_counter()
+        while steps_np < max_steps and (steps_np < 2 or time.perf_counter() - t0 < np_budget):
+            next(it)
+            steps_np += 1
+        dt = time.perf_counter() - t0
+    numpy_rec = {"value": steps_np / dt, "cores": blas_n, "achieved_GBps": round(2.0 * m * n * es * steps_np / dt / 1e9, 1),
+                 "sample": f"{steps_np} iterations in {dt:.1f} s on {blas_n} BLAS threads"}
     if rec is None:
         one_thread, note1 = None, ""
         try:
@@ -443,7 +474,7 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
             note1 = f"; 1 BLAS thread: 1 iteration on the same matrix in {d1:.1f} s"
         except Exception:
             pass
-        rec = {"value": steps_np / dt, "value_1thread": one_thread, "unit": "it/s", "cores": int(_blas_threads()), "kind": "port",
+        rec = {"value": steps_np / dt, "value_1thread": one_thread, "unit": "it/s", "cores": blas_n, "kind": "port",
                "impl": "numpy / OpenBLAS oracle (oracle/proxgrad_oracle.py)",
                "sample": f"the full workload: oracle FFB fixed-step on the downloaded {m}x{n} {A.dtype.name} matrix "
                          f"({A.nbytes / 2**30:.1f} GiB, copied to the host in {t_dl:.1f} s), {steps_np} iterations in {dt:.1f} s{note1}"}

@@ -474,7 +474,7 @@ template <typename T>
 bool tn_supported(const pg_mat* A) {
   const int64_t rows_per_rg = 1024 / (int64_t)sizeof(T);
   const int64_t nrg = A->ld / rows_per_rg;
-  return A->m > 0 && A->n > 0 && (tn_single_wg_supported<T>(A) || tn_team_covers((int)nrg));
+  return A->m > 0 && A->n > 0 && A->n < ((int64_t)1 << 31) && (tn_single_wg_supported<T>(A) || tn_team_covers((int)nrg));
 }
 
 // Geometry of the single sweep by column length.  PG_TN_KERNEL = wave | wg | team forces one (experiments, tests).
@@ -742,7 +742,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   a.red_partials = c->red_partials;
   a.red_counter = c->red_counter;
   a.scal_out = c->dscal + PG_S_GZ;
-  a.line_cols = env_int("PG_TN_LINE_COLS", 32);  // experiments: 1 = column groups dealt one by one (round 1-2 assignment)
+  a.line_cols = env_int("PG_TN_LINE_COLS", 0) > 0 ? env_int("PG_TN_LINE_COLS", 0) : 32;  // experiments: 1 = dealt one by one (rounds 1-2)
   int blocks = 0;
   PG_TRY(launch_tn<T>(A, a, &blocks));
   f->a_passes += 1;
@@ -830,7 +830,7 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
   a.red_partials = c->red_partials;
   a.red_counter = c->red_counter;
   a.scal_out = c->dscal + PG_S_GZ;
-  a.line_cols = env_int("PG_TN_LINE_COLS", 32);  // experiments: 1 = column groups dealt one by one (round 1-2 assignment)
+  a.line_cols = env_int("PG_TN_LINE_COLS", 0) > 0 ? env_int("PG_TN_LINE_COLS", 0) : 32;  // experiments: 1 = dealt one by one (rounds 1-2)
   int blocks = 0;
   PG_TRY(launch_tn<T>(A, a, &blocks));
   int64_t fb = (A->ld + 63) / 64;

@@ -86,7 +86,7 @@ pg_status mat_fused_dys_t(pg_mat* A, const T* r, const T* xg, const T* z, double
   a.red_partials = c->red_partials;
   a.red_counter = c->red_counter;
   a.scal_out = c->dscal + PG_S_GZ;
-  a.line_cols = env_int("PG_TN_LINE_COLS", 32);  // experiments: 1 = column groups dealt one by one (round 1-2 assignment)
+  a.line_cols = env_int("PG_TN_LINE_COLS", 0) > 0 ? env_int("PG_TN_LINE_COLS", 0) : 32;  // experiments: 1 = dealt one by one (rounds 1-2)
   int blocks = 0;
   PG_TRY((launch_tn_dys<T>(A, a, &blocks)));
   int64_t fb = (A->ld + 63) / 64;

@@ -95,22 +95,31 @@ struct TNArgs {
 // jumps by N such chunks; A is still swept as one moving window (N chunks wide).  The groups left over by the last
 // incomplete round are dealt one by one again, so no unit gets more than one step more than another.
 struct CgMap {
-  int64_t head, cnt;  // steps under the chunked assignment; all steps of this unit
-  int64_t gridK, tail0, unit, nunits;
+  // 32-bit on purpose (a matrix has < 2^31 column groups): as 64-bit fields these were 13 more scalar registers live through
+  // the team kernel's steady loop plus 64-bit multiplies three times per step -- its scalar registers spilled to vector lanes
+  // (v_writelane / v_readlane 253 -> 574) and the 50000-row and Float64 team sweeps lost 6-10 %
+  int head, cnt;  // steps under the chunked assignment; all steps of this unit
+  int gridK, tail0, unit, nunits;
   int shift;  // log2 of the chunk length (groups)
-  __device__ __forceinline__ CgMap(int64_t ncg, int C, int line_cols, int64_t unit_, int64_t nunits_) : unit(unit_), nunits(nunits_) {
+  __device__ __forceinline__ CgMap(int64_t ncg64, int C, int line_cols, int64_t unit_, int64_t nunits_) : unit((int)unit_), nunits((int)nunits_) {
+    const int ncg = (int)ncg64;
     int K = line_cols / C;  // C and line_cols are powers of two
     if (K < 1) K = 1;
     shift = 31 - __builtin_clz((unsigned)K);
+    // chunking needs units * K <= 2^30 (it is <= 4096 * 32 in every launcher); otherwise deal one by one
+    if ((int64_t)nunits << shift > (int64_t(1) << 30)) shift = 0;
     gridK = nunits << shift;
-    const int64_t rounds = ncg / gridK;
+    const int rounds = ncg / gridK;
     head = rounds << shift;
     tail0 = rounds * gridK;
-    const int64_t rem = ncg - tail0;
+    const int rem = ncg - tail0;
     cnt = head + (rem > unit ? (rem - unit + nunits - 1) / nunits : 0);
   }
-  __device__ __forceinline__ int64_t at(int64_t i) const {
-    return i < head ? (i >> shift) * gridK + (unit << shift) + (i & ((int64_t(1) << shift) - 1)) : tail0 + unit + (i - head) * nunits;
+  __device__ __forceinline__ int64_t at(int64_t i64) const {
+    const int i = (int)i64;
+    const int chunked = (i >> shift) * gridK + (unit << shift) + (i & ((1 << shift) - 1));
+    const int tail = tail0 + unit + (i - head) * nunits;
+    return (int64_t)(i < head ? chunked : tail);
   }
 };
 

@@ -931,6 +931,10 @@ pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int W = env_int("PG_TNC_WAVES", 8);
   int U = 1;
   while (U * W < nrg) U *= 2;
+  // Chunks of whole output lines (CgMap) pay here as well -- 3072 / 5120 / 6144 rows: 0.836-0.857 of 8 TB/s against 0.80-0.84
+  // dealt one by one -- with ONE measured exception: columns of exactly 16 row groups (4096 rows f32), 0.79-0.80 against
+  // 0.84 (profiles/r3_tune_tn_mid_columns.log, two rounds, two boxes); that length keeps the round-robin deal.
+  if (nrg == 16 && env_int("PG_TN_LINE_COLS", 0) == 0) a.line_cols = 1;
   const int C = env_int("PG_TNC_C", 32 / U);
   const int DB = env_int("PG_TNC_DB", 0);
 #define PG_TNC_CASE(UU, CC, WW, DD) \
