@@ -731,17 +731,17 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
 def test_four_ranks_one_gpu_column_shards(pa):
     """Four processes sharing cuda:0 over gloo, column shards (4096 columns each): the 4 * world scalar slots and the
     m-element partial sums combine to the single-rank answers, fixed and adaptive step."""
-    for mode in ("adaptive",):  # (the fixed step runs with eight ranks below)
-        one = _run_bench(["--mode", mode])
-        four = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", "cols"], nproc=4, port=29655)
-        assert four["n_gpus"] == 4 and four["config"]["n_per_gpu"] * 4 == one["config"]["n"]
-        assert four["config"]["lambda"] == pytest.approx(one["config"]["lambda"], rel=1e-5)
-        f1, f4 = one["config"]["final"], four["config"]["final"]
-        assert f4["gamma"] == pytest.approx(f1["gamma"], rel=1e-4)
-        assert f4["f_x"] == pytest.approx(f1["f_x"], rel=2e-4)
-        assert f4["g_z"] == pytest.approx(f1["g_z"], rel=2e-4)
-        assert f4["res_inf_over_gamma"] == pytest.approx(f1["res_inf_over_gamma"], rel=2e-3)
-        assert four["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1)
+    mode = "adaptive"  # (the fixed step runs with eight ranks below)
+    one = _run_bench(["--mode", mode])
+    four = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", "cols"], nproc=4, port=29655)
+    assert four["n_gpus"] == 4 and four["config"]["n_per_gpu"] * 4 == one["config"]["n"]
+    assert four["config"]["lambda"] == pytest.approx(one["config"]["lambda"], rel=1e-5)
+    f1, f4 = one["config"]["final"], four["config"]["final"]
+    assert f4["gamma"] == pytest.approx(f1["gamma"], rel=1e-4)
+    assert f4["f_x"] == pytest.approx(f1["f_x"], rel=2e-4)
+    assert f4["g_z"] == pytest.approx(f1["g_z"], rel=2e-4)
+    assert f4["res_inf_over_gamma"] == pytest.approx(f1["res_inf_over_gamma"], rel=2e-3)
+    assert four["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1)
     # the driver's largest launch: eight ranks (here on one device), default sharding
     eight = _run_bench(["--backend", "gloo", "--share-device"], nproc=8, port=29657)
     one = _run_bench([])
