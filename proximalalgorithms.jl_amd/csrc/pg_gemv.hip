@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const T* __restrict
 template <typename T, int C, int UR, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict__ A, int64_t ld, int64_t n,
                                                             int64_t m, int rg_begin, int nrg,
-                                                            const T* __restrict__ r, T* __restrict__ g) {
+                                                            const T* __restrict__ r, T* __restrict__ g, int line_cols) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -126,9 +126,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_t_kernel(const T* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ncg = (n + C - 1) / C;
 
-  const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
-  const int64_t total_waves = (int64_t)gridDim.x * WAVES;
-  for (int64_t cg = gw; cg < ncg; cg += total_waves) {  // strided: see the note on blocked assignment in gemv_tn_kernel
+  // The waves of a workgroup take WAVES adjacent column groups per step, and a workgroup takes those runs in chunks of
+  // whole 128-byte lines of g (CgMap, pg_gemv_tn.h): dealt wave by wave round-robin, every line of g was written in
+  // sixteen 8-byte pieces by sixteen waves of four workgroups -- the partial writes that cost the sweeps 3-8 % of their
+  // stream (profiles/r3_mid_columns_counters.md).  PG_T_LINE_COLS = 1 restores the old deal.
+  const pgtn::CgMap map((ncg + WAVES - 1) / WAVES, C * WAVES, line_cols, blockIdx.x, gridDim.x);
+  for (int64_t i = 0; i < map.cnt; ++i) {
+    const int64_t cg = map.at(i) * WAVES + wave;
+    if (cg >= ncg) continue;  // (the last run of a matrix whose group count is no multiple of WAVES)
     const int64_t j0 = cg * C;
     const T* __restrict__ p[C];
 #pragma unroll
@@ -373,7 +378,8 @@ pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64
   }
   pg_prof_scope prof(c, PG_K_GEMV_T);
   hipLaunchKernelGGL((gemv_t_kernel<T, C, UR, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, c->stream,
-                     (const T*)A->data + col0 * A->ld, A->ld, ncols, A->m, rg_begin, nrg, r, g);
+                     (const T*)A->data + col0 * A->ld, A->ld, ncols, A->m, rg_begin, nrg, r, g,
+                     env_int("PG_T_LINE_COLS", 32));
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
