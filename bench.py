@@ -1086,6 +1086,41 @@ def run_rank(args, job, wd, world, rank, local_rank):
     collective = args.collective
     if collective == "auto":  # the library's own RCCL communicator when librccl loads and the job runs on RCCL; else torch.distributed
         collective = "native" if (args.backend == "nccl" and pa.native_rccl_available()) else "torch"
+    ctx = pa.get_context(local_rank)
+    if collective == "native" and (world > 1 or args.force_comm):
+        # First use of the library's own communicator in this job: create it and push one tiny row-sharded gradient through
+        # it (every rank holds the row [1 1 1 1]; grad at x = 1 must come back as 4 * world).  Every rank reports success or
+        # failure through torch.distributed, and unless ALL succeeded the job continues on the torch collective -- a second
+        # communicator that does not come up must not cost the run.  (A hang in here is the watchdog's: stage "init".)
+        ok, why = 1, ""
+        try:
+            comm0 = pa.NativeRcclComm(shard="rows")
+            f0 = pa.LeastSquares(np.ones((1, 4), np.float32), np.zeros(1, np.float32), comm=comm0, ctx=ctx)
+            _, g0 = f0.value_and_gradient(pa.HIPVector.from_numpy(np.ones(4, np.float32), ctx))
+            got = g0.numpy()
+            if not np.allclose(got, 4.0 * world):
+                ok, why = 0, "self-test all-reduce returned %s, expected %g" % (got.tolist(), 4.0 * world)
+            del f0, g0
+        except Exception as e:
+            ok, why = 0, "%s: %s" % (type(e).__name__, str(e)[:200])
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_all = int(flag.item())
+        else:
+            ok_all = ok
+        if not ok_all:
+            sys.stderr.write("bench.py: rank %d: native RCCL communicator unavailable (%s) -> torch.distributed collective\n" % (rank, why or "another rank failed"))
+            try:
+                from proximalalgorithms.jl_amd._lib import call as _call
+
+                _call("pg_ctx_comm_destroy", ctx.handle)
+                ctx._native_comm_shape = None
+                ctx.set_column_sharding(0, 0)
+            except Exception:
+                pass
+            collective = "torch"
+            job.meta["collective_fallback"] = why or "another rank failed"
     job.meta["collective"] = collective
     D = Dist(world, rank, local_rank, args.backend, collective, args.overlap, args.force_comm)
     D.beat = wd.beat
@@ -1095,7 +1130,6 @@ def run_rank(args, job, wd, world, rank, local_rank):
     n = args.n or n
     m_glob = m_base * world if args.scaling == "weak" else m_base
     dtype = np.float32 if args.dtype == "f32" else np.float64
-    ctx = pa.get_context(local_rank)
     # N > 1: column blocks keep the single-sweep iteration on every GPU (one all-reduce of m + 8 N elements per
     # iteration); row blocks (north_star's layout) iterate with two sweeps and all-reduce [grad ; f] (n + 1 elements)
     layout = args.sharding

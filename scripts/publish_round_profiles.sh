@@ -31,6 +31,16 @@ done
 } > $P/r3_long_and_config2_kernel_stats.md
 {
   echo "# Douglas-Rachford kernels (tests/tools/bench_dr.py --no-cpu-baseline --steps 64): kernel stats, then SQ and TCC counter passes (summed per dispatch)"
+  echo "#"
+  echo "# Reading (VERDICT r2 item 6a).  dr_step (DRStepF; the rows mix the x/y-only form, 3 vectors in + 2 out = 200 MB, and the full-state form,"
+  echo "# 3 in + 5 out) is a copy-like stream: its waves are parked on s_waitcnt for ~0.72 of their time (SQ_WAIT_ANY / SQ_WAVE_CYCLES), issue-stalled"
+  echo "# ~0.18, issuing 0.10 (VALU 0.08): nothing on the compute side is short.  On the memory side the L2's write requests to the fabric stall"
+  echo "# (TCC_EA0_WRREQ_STALL: 0.5-4.8 M cycles per launch against ~80 k cycles of kernel time per channel group), i.e. the read+write mix is what the"
+  echo "# fabric limits: the device's measured read+write (copy) ceiling is 5.5-6.0 TB/s (r3_stream_ceiling.log) and dr_step runs 5.9 TB/s by the"
+  echo "# profiler's clock (34 us for 200 MB).  Its 200 MB working set sits inside the 256 MiB Infinity Cache and gains nothing from it: resident data"
+  echo "# streams at the HBM rate (r3_mall_panel.md).  Bound: the copy ceiling, 0.73 of the 8 TB/s READ peak the roofline is priced against."
+  echo "# dr_block<64> is VALU-issue-bound instead: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.30 per wave at 3-4 waves per SIMD (r2_dr_counters.md has the floor)."
+  echo
   cat $O/prof_dr_stats.md $O/prof_dr_sq.md $O/prof_dr_tcc.md
 } > $P/r3_dr_counters.md
 cp $O/step_cols.md $P/r3_colshard_step_trace_final.md
