@@ -131,7 +131,8 @@ pg_status pg_ctx_comm_destroy(pg_ctx* ctx);
 pg_status pg_ctx_comm_stats(pg_ctx* ctx, int64_t* calls, int64_t* elements);
 /* Column sharding (the alternative to row sharding named in SURVEY 8(e)): rank `rank` of `nranks` holds the column block
  * A[:, J_rank] and the J_rank slices of all n-vectors; b and the residual are replicated.  The registered collective
- * (pg_ctx_set_allreduce / pg_ctx_comm_init) then carries A x (m elements) plus 8 * nranks scalar slots (four scalars per rank as hi / lo pairs of the working precision) -- ONE all-reduce
+ * (pg_ctx_set_allreduce / pg_ctx_comm_init) then carries A x (m elements) plus 8 * (nranks + 1) scalar slots (four scalars per rank as hi / lo pairs of
+ * the working precision, and one shared group whose first word sums the ranks' sweep-timeout flags so that all ranks fall back together) -- ONE all-reduce
  * per iteration -- and A' r needs none, so the single-sweep iteration (pg_iter_opts.single_sweep) keeps working on
  * every rank (fixed step, or FastForwardBackward's adaptive step with reuse_residual).  nranks = 0: row sharding. */
 pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
