@@ -41,6 +41,19 @@ def test_every_declared_symbol_is_exported(lib):
     assert handle.pg_abi_version() == 1
 
 
+def test_column_group_assignment_covers_every_group_once(tmp_path):
+    """CgMap (csrc/pg_cgmap.h): which column group a workgroup / wave run / team takes in its i-th step -- chunks of whole
+    output lines strided over the grid, the last incomplete round dealt one by one.  The same header the kernels include is
+    compiled for the host and checked over 2500 combinations: every group exactly once, counts balanced to one step."""
+    import subprocess
+
+    exe = tmp_path / "cgmap_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "proximalalgorithms.jl_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "c_abi", "cgmap_check.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CGMAP_OK" in out.stdout, out.stdout[-500:]
+
+
 def test_no_cpu_fallback(lib):
     import torch
 
