@@ -231,6 +231,11 @@ pg_status pg_prox_indbox(pg_ctx* ctx, int32_t dtype, int64_t n, void* y, const v
                          double hi, const void* lo_vec, const void* hi_vec, double* gy_out);
 /* g(x) for NormL1 (lam ||x||_1) */
 pg_status pg_norml1_value(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, double lam, double* out);
+/* NormL1 with per-element weights (ProximalOperators.NormL1(lambda::AbstractArray)), lam_vec a device n-vector:
+ * y_i = sign(x_i) max(|x_i| - gamma lam_i, 0), returns sum_i lam_i |y_i| ; and the value sum_i lam_i |x_i|. */
+pg_status pg_prox_norml1w(pg_ctx* ctx, int32_t dtype, int64_t n, void* y, const void* x, const void* lam_vec,
+                          double gamma, double* gy_out);
+pg_status pg_norml1w_value(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x, const void* lam_vec, double* out);
 
 /* ------------------------------------------------------------------ BLAS-1 / broadcasts -- */
 /* out .= a .* x .+ b .* y   (y may be NULL when b == 0); covers `y .= x .- gamma .* grad`
@@ -280,7 +285,8 @@ pg_status pg_dr_step(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, void* y, vo
  * norm(res, Inf) / gamma <= tol, douglas_rachford.jl:65-69, evaluated in T) inside the library.  With block = 8, 16, 32 or 64
  * that many iterations run per HBM sweep (f and g are separable, so the iterates of an element stay in registers;
  * the stop rule of every inner iteration is still evaluated and, when one of them fires, the block is replayed up to
- * it, so the state left behind is bit-identical to stepping with pg_dr_step).  block = 1 steps one by one.
+ * it, so the state left behind is bit-identical to stepping with pg_dr_step).  A remainder of fewer than `block` iterations
+ * before maxit runs in the next smaller block sizes, the last < 8 as single steps.  block = 1 steps one by one.
  * x_alt: caller-owned scratch n-vector (ping-pong partner of x; required when block > 1).  On return x, y (and r, z,
  * res when given) hold the state of iteration *k_out; scalars_out as in pg_dr_step. */
 pg_status pg_dr_run(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, void* x_alt, void* y, void* r, void* z, void* res,
@@ -347,8 +353,10 @@ pg_status pg_iter_destroy(pg_iter* it);
 /* g = IndBox with PER-ELEMENT bounds (ProximalOperators.IndBox(lo::AbstractArray, hi::AbstractArray)): lo / hi are
  * device n-vectors (this rank's slices under column sharding), borrowed for the life of the iterator; call after
  * pg_iter_create (g_kind = PG_G_INDBOX; g_p0 / g_p1 are then ignored) and before pg_iter_init.  NULL, NULL: the scalars again.
- * The single sweep reads them as two more n-vector streams next to x and z_old.  pg_iter_run_small / _coop take scalar
- * bounds only (PG_ERR_UNSUPPORTED). */
+ * g = NormL1 with PER-ELEMENT weights (ProximalOperators.NormL1(lambda::AbstractArray): g(x) = sum_j lam_j |x_j|, prox =
+ * soft threshold by gamma lam_j): the weights go in `lo`, `hi` must be NULL (g_kind = PG_G_NORML1; g_p0 is then ignored).
+ * The single sweep reads them as one or two more n-vector streams next to x and z_old.  pg_iter_run_small / _coop take
+ * scalar parameters only (PG_ERR_UNSUPPORTED). */
 pg_status pg_iter_set_g_vectors(pg_iter* it, const void* lo, const void* hi);
 /* Base.iterate(iter): forward_backward.jl:65-84 / fast_forward_backward.jl:73-97.
  * x0 is a DEVICE n-vector; it is copied, never mutated (test_lasso_small.jl:54). */

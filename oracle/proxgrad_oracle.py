@@ -184,19 +184,31 @@ class Zero:
 
 
 class NormL1:
-    """g(x) = lam * ||x||_1 ;  prox: y_i = sign(x_i) max(|x_i| - gamma lam, 0); returns g(y)."""
+    """g(x) = lam * ||x||_1 ;  prox: y_i = sign(x_i) max(|x_i| - gamma lam, 0); returns g(y).
+    ``lam`` may be an array of per-element weights (ProximalOperators.NormL1(lambda::AbstractArray)):
+    g(x) = sum_i lam_i |x_i|, threshold gamma lam_i."""
 
     def __init__(self, lam=1.0):
         self.lam = lam
 
+    def _weighted(self):
+        return not np.isscalar(self.lam)
+
     def prox(self, x, gamma):
         R = _R(x)
+        if self._weighted():
+            lam = np.asarray(self.lam, dtype=x.dtype)
+            gl = (R(gamma) * lam).astype(x.dtype)
+            y = np.where(x <= -gl, x + gl, np.where(x >= gl, x - gl, R(0))).astype(x.dtype)
+            return y, R(np.sum(lam * np.abs(y), dtype=x.dtype))
         gl = R(gamma) * R(self.lam)
         y = np.where(x <= -gl, x + gl, np.where(x >= gl, x - gl, R(0))).astype(x.dtype)
         return y, R(R(self.lam) * R(np.sum(np.abs(y), dtype=x.dtype)))
 
     def __call__(self, x):
         R = _R(x)
+        if self._weighted():
+            return R(np.sum(np.asarray(self.lam, dtype=x.dtype) * np.abs(x), dtype=x.dtype))
         return R(R(self.lam) * R(np.sum(np.abs(x), dtype=x.dtype)))
 
 

@@ -40,13 +40,14 @@ class FusedIteration:
         self._g_vectors = None
 
     def init(self, x0):
-        if hasattr(self.g, "g_vectors") and self._g_vectors is None:  # IndBox with per-element bounds
-            lo, hi = self.g.g_vectors(x0)
-            if lo is not None:
-                if lo.n != self.n or hi.n != self.n:
-                    raise ValueError("IndBox bounds must have one entry per variable")
-                call("pg_iter_set_g_vectors", self._h, lo.vp, hi.vp)
-                self._g_vectors = (lo, hi)  # keep the device vectors alive as long as the iterator
+        if hasattr(self.g, "g_vectors") and self._g_vectors is None:
+            # IndBox with per-element bounds: (lo, hi); NormL1 with per-element weights: (lam, None)
+            v0, v1 = self.g.g_vectors(x0)
+            if v0 is not None:
+                if v0.n != self.n or (v1 is not None and v1.n != self.n):
+                    raise ValueError("per-element parameters of g must have one entry per variable")
+                call("pg_iter_set_g_vectors", self._h, v0.vp, v1.vp if v1 is not None else None)
+                self._g_vectors = (v0, v1)  # keep the device vectors alive as long as the iterator
         call("pg_iter_init", self._h, x0.vp, C.byref(self.scalars))
         return self.scalars
 

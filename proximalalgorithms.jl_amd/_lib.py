@@ -110,6 +110,8 @@ SIGNATURES = {
     "pg_prox_norml1": [_vp, _i32, _i64, _vp, _vp, _f64, _f64, _pf64],
     "pg_prox_indbox": [_vp, _i32, _i64, _vp, _vp, _f64, _f64, _vp, _vp, _pf64],
     "pg_norml1_value": [_vp, _i32, _i64, _vp, _f64, _pf64],
+    "pg_prox_norml1w": [_vp, _i32, _i64, _vp, _vp, _vp, _f64, _pf64],
+    "pg_norml1w_value": [_vp, _i32, _i64, _vp, _vp, _pf64],
     "pg_axpby": [_vp, _i32, _i64, _vp, _f64, _vp, _f64, _vp],
     "pg_add_scalar": [_vp, _i32, _i64, _vp, _vp, _f64],
     "pg_fill": [_vp, _i32, _i64, _vp, _f64],

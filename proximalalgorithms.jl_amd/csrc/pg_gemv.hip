@@ -736,9 +736,9 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   a.p1 = (T)g_p1;
   a.lam_ls = (T)f->lam;
   a.g_kind = g_kind;
-  a.p0v = g_kind == PG_G_INDBOX ? g_v0 : nullptr;
+  a.p0v = g_kind == PG_G_INDBOX || g_kind == PG_G_NORML1 ? g_v0 : nullptr;  // IndBox: lo_j; NormL1: weights lam_j
   a.p1v = g_kind == PG_G_INDBOX ? g_v1 : nullptr;
-  a.gscale = g_kind == PG_G_NORML1 ? (double)(T)g_p0 : 0.0;
+  a.gscale = g_kind == PG_G_NORML1 ? (a.p0v != nullptr ? 1.0 : (double)(T)g_p0) : 0.0;
   a.g_out = g_out;
   a.y = y;
   a.z_new = z_new;

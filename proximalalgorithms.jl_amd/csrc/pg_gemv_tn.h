@@ -58,11 +58,12 @@ struct TNArgs {
   const T* z_old;  // [n] the prox output of the previous iteration (for v); may alias nothing written here
   T gamma, beta, p0, p1, lam_ls;  // p0 = gamma * lam (NormL1) | lo (IndBox) ; p1 = hi
   int g_kind;
+  // NormL1 with PER-ELEMENT weights (ProximalOperators.NormL1(lambda::AbstractArray)): lam_j = p0v[j] (p1v unused, gscale = 1);
   // IndBox with PER-ELEMENT bounds (ProximalOperators.IndBox(lo::AbstractArray, hi::AbstractArray)): lo_j = p0v[j], hi_j = p1v[j];
   // nullptr: the scalars p0 / p1.  Two more n-vector streams next to x and z_old (< 0.1 % of the sweep's bytes).
   const T* p0v = nullptr;
   const T* p1v = nullptr;
-  double gscale;  // lam for NormL1 else 0
+  double gscale;  // lam for NormL1 (1 with per-element weights) else 0
   T *g_out, *y, *z_new, *res, *v_out;  // [n] each
   T* partials;                         // [gridDim.x][ld]
   double* red_partials;
@@ -206,9 +207,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
       } else {
         const T yj = xj - a.gamma * g;
         T zj;
-        if (a.g_kind == PG_G_NORML1)
-          zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-        else if (a.g_kind == PG_G_INDBOX) {
+        if (a.g_kind == PG_G_NORML1) {
+          T th = a.p0;
+          if (a.p0v != nullptr) th = a.gamma * a.p0v[valid ? j : a.n - 1];  // per-element weights lam_j
+          zj = yj <= -th ? yj + th : (yj >= th ? yj - th : T(0));
+        } else if (a.g_kind == PG_G_INDBOX) {
           T lo = a.p0, hi = a.p1;
           if (a.p0v != nullptr) lo = a.p0v[valid ? j : a.n - 1], hi = a.p1v[valid ? j : a.n - 1];
           zj = fmin(hi, fmax(lo, yj));
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
           a.z_new[j] = zj;
           a.res[j] = rj;
           if (a.v_out != nullptr) a.v_out[j] = vj;
-          if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
+          if (a.g_kind == PG_G_NORML1) acc[0] += a.p0v != nullptr ? (double)a.p0v[j] * fabs((double)zj) : fabs((double)zj);
           acc[1] = fmax(acc[1], fabs((double)rj));
           acc[2] += (double)g * (double)rj;
           acc[3] += (double)rj * (double)rj;

@@ -100,9 +100,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
       const T xj = t.xs[c], zo = t.zos[c];
       const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
       T zj;                            // :118 / :141
-      if (a.g_kind == PG_G_NORML1)
-        zj = yj <= -a.p0 ? yj + a.p0 : (yj >= a.p0 ? yj - a.p0 : T(0));
-      else if (a.g_kind == PG_G_INDBOX) {
+      if (a.g_kind == PG_G_NORML1) {
+        T th = a.p0;
+        if (a.p0v != nullptr) th = a.gamma * a.p0v[valid ? j : a.n - 1];  // per-element weights lam_j
+        zj = yj <= -th ? yj + th : (yj >= th ? yj - th : T(0));
+      } else if (a.g_kind == PG_G_INDBOX) {
         T lo = a.p0, hi = a.p1;
         if (a.p0v != nullptr) lo = a.p0v[valid ? j : a.n - 1], hi = a.p1v[valid ? j : a.n - 1];  // per-element bounds
         zj = fmin(hi, fmax(lo, yj));
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
         a.z_new[j] = zj;
         a.res[j] = rj;
         if (a.v_out != nullptr) a.v_out[j] = vj;
-        if (a.g_kind == PG_G_NORML1) acc[0] += fabs((double)zj);
+        if (a.g_kind == PG_G_NORML1) acc[0] += a.p0v != nullptr ? (double)a.p0v[j] * fabs((double)zj) : fabs((double)zj);
         acc[1] = fmax(acc[1], fabs((double)rj));
         acc[2] += (double)g * (double)rj;
         acc[3] += (double)rj * (double)rj;

@@ -478,8 +478,12 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
 
 pg_status pg_iter_set_g_vectors(pg_iter* it, const void* lo, const void* hi) {
   PG_REQUIRE(it != nullptr, "iterator is null");
-  PG_REQUIRE((lo == nullptr) == (hi == nullptr), "lo and hi must both be vectors or both be null");
-  PG_REQUIRE(lo == nullptr || it->o.g_kind == PG_G_INDBOX, "per-element parameters are for g = IndBox");
+  if (it->o.g_kind == PG_G_NORML1) {  // per-element weights lam_j in the first vector
+    PG_REQUIRE(hi == nullptr, "g = NormL1 takes one vector (the weights); the second must be null");
+  } else {
+    PG_REQUIRE((lo == nullptr) == (hi == nullptr), "lo and hi must both be vectors or both be null");
+    PG_REQUIRE(lo == nullptr || it->o.g_kind == PG_G_INDBOX, "per-element parameters are for g = IndBox or NormL1");
+  }
   it->g_v0 = lo;
   it->g_v1 = hi;
   return PG_OK;

@@ -9,7 +9,7 @@ struct pg_iter {
   pg_ctx* ctx = nullptr;
   pg_ls* f = nullptr;
   pg_iter_opts o{};
-  const void *g_v0 = nullptr, *g_v1 = nullptr;  // IndBox: per-element bounds (pg_iter_set_g_vectors), borrowed
+  const void *g_v0 = nullptr, *g_v1 = nullptr;  // IndBox: per-element bounds; NormL1: weights in g_v0 (pg_iter_set_g_vectors), borrowed
   int dtype = PG_F32;
   int64_t n = 0;
   void* slab = nullptr;  // one allocation holding all state vectors

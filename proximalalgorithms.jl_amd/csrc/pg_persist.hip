@@ -999,7 +999,7 @@ pg_status pg_iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double 
   PG_REQUIRE(it->ctx->allreduce == nullptr && it->ctx->allreduce_begin == nullptr,
              "the single-workgroup solver does not support row-sharded operators");
   if (it->g_v0 != nullptr) {
-    pg_set_error("the single-workgroup solver takes scalar IndBox bounds only (per-element bounds: pg_iter_run)");
+    pg_set_error("the single-workgroup solver takes scalar parameters of g only (per-element bounds / weights: pg_iter_run)");
     return PG_ERR_UNSUPPORTED;
   }
   pg_mat* A = it->f->A;
@@ -1023,7 +1023,7 @@ pg_status pg_iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double t
   PG_REQUIRE(it->ctx->allreduce == nullptr && it->ctx->allreduce_begin == nullptr,
              "the cooperative solver does not support row-sharded operators");
   if (it->g_v0 != nullptr) {
-    pg_set_error("the cooperative solver takes scalar IndBox bounds only (per-element bounds: pg_iter_run)");
+    pg_set_error("the cooperative solver takes scalar parameters of g only (per-element bounds / weights: pg_iter_run)");
     return PG_ERR_UNSUPPORTED;
   }
   pg_mat* A = it->f->A;

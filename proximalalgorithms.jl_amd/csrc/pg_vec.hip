@@ -135,6 +135,40 @@ struct ProxL1F {  // y = soft(x, gamma lam); acc[0] = lam sum |y|
   __device__ double post_scale(int) const { return lam; }
 };
 
+// NormL1 with per-element weights (ProximalOperators.NormL1(lambda::AbstractArray)): g(x) = sum_i lam_i |x_i|,
+// prox: y_i = soft(x_i, gamma lam_i)
+template <typename T>
+struct Norm1WF {
+  const T* x;
+  const T* lam;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i), lv = ld<T, N>(lam, i);
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[0] += (double)lv.v[e] * fabs((double)xv.v[e]);
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
+template <typename T>
+struct ProxL1WF {
+  T* y;
+  const T* x;
+  const T* lam;
+  T gamma;
+  template <int N>
+  __device__ __forceinline__ void apply(int64_t i, double* acc) const {
+    Pack<T, N> xv = ld<T, N>(x, i), lv = ld<T, N>(lam, i), o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      o.v[e] = soft_threshold(xv.v[e], gamma * lv.v[e]);
+      acc[0] += (double)lv.v[e] * fabs((double)o.v[e]);
+    }
+    st<T, N>(y, i, o);
+  }
+  __device__ double post_scale(int) const { return 1.0; }
+};
+
 template <typename T>
 struct ProxBoxF {  // y = min(hi, max(lo, x))   (vector bounds optional)
   T* y;
@@ -171,8 +205,8 @@ struct EpilogueF {
   T* res;
   T* grad_copy;  // nullable: also materialise grad here (sharded path keeps it in the all-reduce buffer)
   T gamma, p0, p1;  // p0 = gamma*lam (NormL1) | lo (IndBox) ; p1 = hi
-  double gscale;    // lam for NormL1 else 0
-  const T* p0v = nullptr;  // IndBox: per-element bounds (nullptr: the scalars)
+  double gscale;    // lam for NormL1 (1 with per-element weights) else 0
+  const T* p0v = nullptr;  // IndBox: per-element bounds; NormL1: per-element weights lam_i (nullptr: the scalars)
   const T* p1v = nullptr;
   template <int N>
   __device__ __forceinline__ void apply(int64_t i, double* acc) const {
@@ -180,17 +214,21 @@ struct EpilogueF {
     if constexpr (GKIND == PG_G_INDBOX) {
       if (p0v != nullptr) lov = ld<T, N>(p0v, i), hiv = ld<T, N>(p1v, i);
     }
+    if constexpr (GKIND == PG_G_NORML1) {
+      if (p0v != nullptr) lov = ld<T, N>(p0v, i);
+    }
 #pragma unroll
     for (int e = 0; e < N; ++e) {
       yv.v[e] = xv.v[e] - gamma * gv.v[e];
       if constexpr (GKIND == PG_G_NORML1)
-        zv.v[e] = soft_threshold(yv.v[e], p0);
+        zv.v[e] = soft_threshold(yv.v[e], p0v != nullptr ? gamma * lov.v[e] : p0);
       else if constexpr (GKIND == PG_G_INDBOX)
         zv.v[e] = p0v != nullptr ? fmin(hiv.v[e], fmax(lov.v[e], yv.v[e])) : fmin(p1, fmax(p0, yv.v[e]));
       else
         zv.v[e] = yv.v[e];
       rv.v[e] = xv.v[e] - zv.v[e];
-      if constexpr (GKIND == PG_G_NORML1) acc[0] += fabs((double)zv.v[e]);
+      if constexpr (GKIND == PG_G_NORML1)
+        acc[0] += p0v != nullptr ? (double)lov.v[e] * fabs((double)zv.v[e]) : fabs((double)zv.v[e]);
       acc[1] = fmax(acc[1], fabs((double)rv.v[e]));
       acc[2] += (double)gv.v[e] * (double)rv.v[e];
       acc[3] += (double)rv.v[e] * (double)rv.v[e];
@@ -648,11 +686,13 @@ template <typename T>
 pg_status epilogue_t(pg_ctx* c, int64_t n, const T* x, const T* grad, double gamma, int g_kind, double g_p0,
                      double g_p1, T* y, T* z, T* res, T* grad_copy, const T* g_v0 = nullptr, const T* g_v1 = nullptr) {
   const bool v = aligned16(x) && aligned16(grad) && aligned16(y) && aligned16(z) && aligned16(res) &&
-                 (grad_copy == nullptr || aligned16(grad_copy)) && (g_v0 == nullptr || (aligned16(g_v0) && aligned16(g_v1)));
+                 (grad_copy == nullptr || aligned16(grad_copy)) && (g_v0 == nullptr || aligned16(g_v0)) &&
+                 (g_v1 == nullptr || aligned16(g_v1));
   const T gm = (T)gamma;
   pg_prof_scope prof(c, PG_K_EPILOGUE);
   if (g_kind == PG_G_NORML1) {
-    EpilogueF<T, PG_G_NORML1> f{x, grad, y, z, res, grad_copy, gm, (T)(gm * (T)g_p0), T(0), (double)(T)g_p0};
+    EpilogueF<T, PG_G_NORML1> f{x, grad, y, z, res, grad_copy, gm, (T)(gm * (T)g_p0), T(0), g_v0 != nullptr ? 1.0 : (double)(T)g_p0,
+                                g_v0, nullptr};
     return launch_ew<T, decltype(f), 4, 0x2u>(c, n, v, f, c->dscal + PG_S_GZ);
   }
   if (g_kind == PG_G_INDBOX) {
@@ -713,6 +753,16 @@ template <typename T>
 pg_status prox_l1_t(pg_ctx* c, int64_t n, void* y, const void* x, double lam, double gamma) {
   ProxL1F<T> f{(T*)y, (const T*)x, (T)((T)gamma * (T)lam), (double)(T)lam};
   return launch_ew<T, ProxL1F<T>, 1, 0u>(c, n, aligned16(x) && aligned16(y), f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status norm1w_t(pg_ctx* c, int64_t n, const void* x, const void* lam) {
+  Norm1WF<T> f{(const T*)x, (const T*)lam};
+  return launch_ew<T, Norm1WF<T>, 1, 0u>(c, n, aligned16(x) && aligned16(lam), f, c->dscal + PG_S_MISC);
+}
+template <typename T>
+pg_status prox_l1w_t(pg_ctx* c, int64_t n, void* y, const void* x, const void* lam, double gamma) {
+  ProxL1WF<T> f{(T*)y, (const T*)x, (const T*)lam, (T)gamma};
+  return launch_ew<T, ProxL1WF<T>, 1, 0u>(c, n, aligned16(x) && aligned16(y) && aligned16(lam), f, c->dscal + PG_S_MISC);
 }
 template <typename T>
 pg_status prox_box_t(pg_ctx* c, int64_t n, void* y, const void* x, double lo, double hi, const void* lov,
@@ -837,7 +887,7 @@ pg_status dr_run_t(pg_ctx* c, int64_t n, void* x, void* x_alt, void* y, void* r,
   int64_t k = 0;
   double sc[3] = {0, 0, 0};
   bool done = false;
-  if (K > 1 && maxit >= K) {
+  if (K > 1 && maxit >= 8) {
     const size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(T);
     if (c->dr_ws_bytes < nb) {
       if (c->dr_ws) {
@@ -856,51 +906,56 @@ pg_status dr_run_t(pg_ctx* c, int64_t n, void* x, void* x_alt, void* y, void* r,
     struct Blk {
       int in = 0, set = 0;
       bool live = false;
-    } A, B;
-    auto launch = [&](Blk& b, int in, int set) -> pg_status {
-      b.in = in, b.set = set, b.live = true;
-      void *xi = bufs[in], *xo = bufs[(in + 1) % 3];
-      PG_TRY(K == 64   ? (dr_block_t<T, 64>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
-             : K == 32 ? (dr_block_t<T, 32>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
-             : K == 16 ? (dr_block_t<T, 16>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
-                       : (dr_block_t<T, 8>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set])));
-      PG_HIP(hipEventRecord(c->dr_ev[set], c->stream));
-      return PG_OK;
     };
     int in = 0;
-    while (!done && maxit - k >= K) {
-      if (!A.live) PG_TRY(launch(A, in, 0));
-      // a successor only if block A cannot be the last one (it reaches maxit exactly when k + K >= maxit)
-      if (!B.live && maxit - (k + K) >= K) PG_TRY(launch(B, (A.in + 1) % 3, 1 - A.set));
-      PG_HIP(hipEventSynchronize(c->dr_ev[A.set]));
-      const double* hs = c->hscal + slot_base[A.set];
-      int hit = -1;
-      for (int j = 0; j < K && hit < 0; ++j)
-        if (k + j + 1 >= maxit || stop(hs[j])) hit = j;
-      if (hit < 0) {  // no stop inside A: its output is the next input; B (if queued) becomes the block to wait for
-        k += K;
-        in = (A.in + 1) % 3;
-        A = B;
-        B.live = false;
-      } else if (hit == K - 1 && !B.live) {  // stopped exactly at the end of A and nothing ran past it: the state is A's
-        k += K;
-        in = (A.in + 1) % 3;
-        sc[0] = hs[K - 1], sc[1] = hs[K], sc[2] = hs[K + 1];
-        done = true;
-      } else {
-        // an inner iteration stopped (or a successor has overwritten y / r / z / res): replay hit + 1 single steps from
-        // A's input -- same arithmetic, same bits; stream order puts them behind the queued successor
-        in = A.in;
-        for (int j = 0; j <= hit; ++j) PG_TRY(step(bufs[in]));
-        PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
-        for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
-        k += hit + 1;
-        done = true;
+    // blocks of Kc iterations while at least Kc are left; the remainder (< K) goes through the next smaller block sizes
+    // (32, 16, 8) instead of up to K - 1 single steps with a host round trip each, then < 8 single steps
+    for (int Kc = K; Kc >= 8 && !done; Kc >>= 1) {
+      Blk A, B;
+      auto launch = [&](Blk& b, int bin, int set) -> pg_status {
+        b.in = bin, b.set = set, b.live = true;
+        void *xi = bufs[bin], *xo = bufs[(bin + 1) % 3];
+        PG_TRY(Kc == 64   ? (dr_block_t<T, 64>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
+               : Kc == 32 ? (dr_block_t<T, 32>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
+               : Kc == 16 ? (dr_block_t<T, 16>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set]))
+                          : (dr_block_t<T, 8>(c, n, xi, xo, y, r, z, res, dv, ds, qv, qs, g_kind, g_p0, g_p1, gamma, slot_base[set])));
+        PG_HIP(hipEventRecord(c->dr_ev[set], c->stream));
+        return PG_OK;
+      };
+      while (!done && maxit - k >= Kc) {
+        if (!A.live) PG_TRY(launch(A, in, 0));
+        // a successor only if block A cannot be the last one of this size (it reaches maxit exactly when k + Kc >= maxit)
+        if (!B.live && maxit - (k + Kc) >= Kc) PG_TRY(launch(B, (A.in + 1) % 3, 1 - A.set));
+        PG_HIP(hipEventSynchronize(c->dr_ev[A.set]));
+        const double* hs = c->hscal + slot_base[A.set];
+        int hit = -1;
+        for (int j = 0; j < Kc && hit < 0; ++j)
+          if (k + j + 1 >= maxit || stop(hs[j])) hit = j;
+        if (hit < 0) {  // no stop inside A: its output is the next input; B (if queued) becomes the block to wait for
+          k += Kc;
+          in = (A.in + 1) % 3;
+          A = B;
+          B.live = false;
+        } else if (hit == Kc - 1 && !B.live) {  // stopped exactly at the end of A and nothing ran past it: the state is A's
+          k += Kc;
+          in = (A.in + 1) % 3;
+          sc[0] = hs[Kc - 1], sc[1] = hs[Kc], sc[2] = hs[Kc + 1];
+          done = true;
+        } else {
+          // an inner iteration stopped (or a successor has overwritten y / r / z / res): replay hit + 1 single steps from
+          // A's input -- same arithmetic, same bits; stream order puts them behind the queued successor
+          in = A.in;
+          for (int j = 0; j <= hit; ++j) PG_TRY(step(bufs[in]));
+          PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
+          for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
+          k += hit + 1;
+          done = true;
+        }
       }
     }
     cur = bufs[in];
   }
-  while (!done && k < maxit) {  // fewer than K iterations left (or block = 1): step by step
+  while (!done && k < maxit) {  // fewer than 8 iterations left (or block = 1): step by step
     PG_TRY(step(cur));
     PG_TRY(pg_read_scalars(c, PG_S_DR, 3));
     for (int q3 = 0; q3 < 3; ++q3) sc[q3] = c->hscal[PG_S_DR + q3];
@@ -1032,6 +1087,23 @@ pg_status pg_prox_norml1(pg_ctx* c, int32_t dtype, int64_t n, void* y, const voi
   PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr), "null vector");
   PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
   PG_TRY(dtype == PG_F32 ? prox_l1_t<float>(c, n, y, x, lam, gamma) : prox_l1_t<double>(c, n, y, x, lam, gamma));
+  return finish_scalar(c, PG_S_MISC, gy_out);
+}
+
+pg_status pg_norml1w_value(pg_ctx* c, int32_t dtype, int64_t n, const void* x, const void* lam_vec, double* out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && lam_vec != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? norm1w_t<float>(c, n, x, lam_vec) : norm1w_t<double>(c, n, x, lam_vec));
+  return finish_scalar(c, PG_S_MISC, out);
+}
+
+pg_status pg_prox_norml1w(pg_ctx* c, int32_t dtype, int64_t n, void* y, const void* x, const void* lam_vec, double gamma,
+                          double* gy_out) {
+  PG_VEC_ARGS_OK(c, n);
+  PG_REQUIRE(n == 0 || (x != nullptr && y != nullptr && lam_vec != nullptr), "null vector");
+  PG_REQUIRE(dtype == PG_F32 || dtype == PG_F64, "bad dtype");
+  PG_TRY(dtype == PG_F32 ? prox_l1w_t<float>(c, n, y, x, lam_vec, gamma) : prox_l1w_t<double>(c, n, y, x, lam_vec, gamma));
   return finish_scalar(c, PG_S_MISC, gy_out);
 }
 

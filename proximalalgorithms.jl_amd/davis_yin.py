@@ -53,7 +53,7 @@ class DavisYinIteration:
 
         if isinstance(op, SqrNormL2):
             return PG_G_SQRNORML2, op.lam, 0.0
-        if isinstance(op, IndBox) and not op._scalar:
+        if isinstance(op, (IndBox, NormL1)) and not op._scalar:
             return None
         if isinstance(op, (NormL1, IndBox, Zero)):
             p0, p1 = op.g_params()

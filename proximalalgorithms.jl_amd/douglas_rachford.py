@@ -28,7 +28,7 @@ class DouglasRachfordState:
 def _fused_ok(f, g):
     if not isinstance(f, SeparableQuadratic) or not isinstance(g, (IndBox, NormL1, Zero)):
         return False
-    return not (isinstance(g, IndBox) and not g._scalar)
+    return getattr(g, "_scalar", True)  # per-element bounds / weights: the generic engine
 
 
 class DouglasRachfordIteration:
@@ -43,7 +43,7 @@ class DouglasRachfordIteration:
         if engine is None:
             engine = "fused" if _fused_ok(self.f, self.g) else "generic"
         if engine == "fused" and not _fused_ok(self.f, self.g):
-            raise TypeError("engine='fused' needs f = SeparableQuadratic and g in {IndBox(scalar bounds), NormL1, Zero}")
+            raise TypeError("engine='fused' needs f = SeparableQuadratic and g in {IndBox(scalar bounds), NormL1(scalar lam), Zero}")
         self.engine = engine
         self.materialize = bool(materialize)
 

@@ -179,6 +179,7 @@ function (f::HIPLeastSquares{T})(x::HIPVector{T}) where {T}
 end
 
 # ---------------------------------------------------------------- prox operators -----------------------------
+# NormL1(lambda): a scalar, or per-element weights (a HIPVector), like ProximalOperators.NormL1(lambda::AbstractArray)
 struct HIPNormL1{R}
     lambda::R
 end
@@ -186,6 +187,12 @@ function ProximalCore.prox!(y::HIPVector{T}, g::HIPNormL1, x::HIPVector{T}, gamm
     gy = Ref{Float64}(0)
     check(ccall((:pg_prox_norml1, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
                 x.ctx.handle, pg_dtype(T), x.n, y.ptr, x.ptr, g.lambda, gamma, gy))
+    T(gy[])
+end
+function ProximalCore.prox!(y::HIPVector{T}, g::HIPNormL1{<:HIPVector}, x::HIPVector{T}, gamma) where {T}
+    gy = Ref{Float64}(0)
+    check(ccall((:pg_prox_norml1w, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ref{Float64}),
+                x.ctx.handle, pg_dtype(T), x.n, y.ptr, x.ptr, g.lambda.ptr, gamma, gy))
     T(gy[])
 end
 # IndBox(lo, hi): scalar bounds or per-element bounds (HIPVectors), like ProximalOperators.IndBox
@@ -221,11 +228,14 @@ struct PgIterState
     x::Ptr{Cvoid}; grad_f_x::Ptr{Cvoid}; y::Ptr{Cvoid}; z::Ptr{Cvoid}; res::Ptr{Cvoid}; z_prev::Ptr{Cvoid}; grad_f_z::Ptr{Cvoid}
 end
 g_spec(g::HIPNormL1) = (Int32(1), Float64(g.lambda), 0.0)
+g_spec(g::HIPNormL1{<:HIPVector}) = (Int32(1), 0.0, 0.0)
 g_spec(g::HIPIndBox) = (Int32(2), box_scalar(g.lo), box_scalar(g.hi))
 # per-element bounds reach the fused iteration through pg_iter_set_g_vectors (after create, before init)
 set_g_vectors!(h, g) = nothing
 set_g_vectors!(h, g::HIPIndBox{<:HIPVector}) =
     check(ccall((:pg_iter_set_g_vectors, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, g.lo.ptr, g.hi.ptr))
+set_g_vectors!(h, g::HIPNormL1{<:HIPVector}) =   # per-element weights: the first vector, the second stays null
+    check(ccall((:pg_iter_set_g_vectors, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, g.lambda.ptr, C_NULL))
 
 # extrapolation sequences (src/accel/nesterov.jl) -> (seq_kind, seq_p0, seq_p1, host-side iterator or nothing)
 const PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST, PG_SEQ_REPEATED =

@@ -172,30 +172,57 @@ class LeastSquares:
 
 
 class NormL1:
-    """g(x) = lam ||x||_1 (ProximalOperators.NormL1(lam)); prox = soft threshold."""
+    """g(x) = lam ||x||_1 (ProximalOperators.NormL1(lam)); prox = soft threshold.  ``lam`` is a nonnegative scalar or a
+    vector of per-element weights (ProximalOperators.NormL1(lambda::AbstractArray): g(x) = sum_i lam_i |x_i|)."""
 
     g_kind = PG_G_NORML1
     is_convex = True
 
     def __init__(self, lam=1.0):
-        if lam < 0:
-            raise ValueError("parameter lam must be nonnegative")
-        self.lam = float(lam)
+        self._scalar = np.isscalar(lam)
+        if self._scalar:
+            if lam < 0:
+                raise ValueError("parameter lam must be nonnegative")
+            self.lam = float(lam)
+        else:
+            self.lam = np.asarray(lam)
+            if np.any(self.lam < 0):
+                raise ValueError("coefficients in lam must be nonnegative")
+        self._lamv = None
 
     def g_params(self):
-        return self.lam, 0.0
+        """(lam, 0) as the scalars of the C ABI; per-element weights reach the fused iteration through ``g_vectors``"""
+        return (self.lam if self._scalar else 0.0), 0.0
+
+    def g_vectors(self, x):
+        """(weights, None) as a device vector shaped like ``x`` ((None, None) for a scalar lam)"""
+        return self._weights(x), None
+
+    def _weights(self, x):
+        if self._scalar:
+            return None
+        if self._lamv is None or self._lamv.dtype != x.dtype or self._lamv.ctx is not x.ctx:
+            lam = np.ascontiguousarray(np.broadcast_to(self.lam.astype(x.dtype), (x.n,)))
+            self._lamv = HIPVector.from_numpy(lam, x.ctx)
+        return self._lamv
 
     def prox_(self, y, x, gamma, want_value=True):
-        if not want_value:  # no reduction read-back: the call stays asynchronous
-            call("pg_prox_norml1", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, self.lam, float(gamma), None)
-            return None
-        out = C.c_double()
-        call("pg_prox_norml1", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, self.lam, float(gamma), C.byref(out))
-        return x.dtype.type(out.value)
+        out = C.c_double() if want_value else None  # no reduction read-back: the call stays asynchronous
+        ref = C.byref(out) if want_value else None
+        w = self._weights(x)
+        if w is not None:
+            call("pg_prox_norml1w", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, w.vp, float(gamma), ref)
+        else:
+            call("pg_prox_norml1", x.ctx.handle, x.pg_dtype, x.n, y.vp, x.vp, self.lam, float(gamma), ref)
+        return x.dtype.type(out.value) if want_value else None
 
     def __call__(self, x):
         out = C.c_double()
-        call("pg_norml1_value", x.ctx.handle, x.pg_dtype, x.n, x.vp, self.lam, C.byref(out))
+        w = self._weights(x)
+        if w is not None:
+            call("pg_norml1w_value", x.ctx.handle, x.pg_dtype, x.n, x.vp, w.vp, C.byref(out))
+        else:
+            call("pg_norml1_value", x.ctx.handle, x.pg_dtype, x.n, x.vp, self.lam, C.byref(out))
         return x.dtype.type(out.value)
 
 

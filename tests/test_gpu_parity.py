@@ -812,13 +812,17 @@ def _ffb_device_vs_oracle(pa, m, n, dtype, fixed_its, adaptive_its, z_tol, g="l1
         hi_v = (bound * rb.random(n, dtype=np.float64)).astype(dtype)
         hi_v[::97] = lo_v[::97]
         g_d, g_o, gscale = pa.IndBox(lo_v, hi_v), o.IndBox(lo_v, hi_v), 0.0
+    elif g == "l1w":  # per-element weights (ProximalOperators.NormL1(lambda::AbstractArray)): 0.25 .. 1.75 lam, some of them zero
+        lam_v = (lam * (0.25 + 1.5 * np.random.default_rng(98).random(n))).astype(dtype)
+        lam_v[::89] = 0
+        g_d, g_o, gscale = pa.NormL1(lam_v), o.NormL1(lam_v), lam_v.astype(np.float64)
     else:
         g_d, g_o, gscale = pa.NormL1(lam), o.NormL1(lam), float(lam)
 
     def objective64(z):
         nz = np.flatnonzero(z)
         r = A[:, nz].astype(np.float64) @ z[nz].astype(np.float64) - b.astype(np.float64)
-        return 0.5 * float(r @ r) + gscale * float(np.sum(np.abs(z.astype(np.float64))))
+        return 0.5 * float(r @ r) + float(np.sum(gscale * np.abs(z.astype(np.float64))))
 
     it_g = pa.FastForwardBackwardIteration(f=f_d, g=g_d, x0=x0, Lf=Lf)
     it_c = o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=g_o, x0=x0, Lf=Lf)
@@ -869,12 +873,34 @@ def test_sweep_kernels_steady_state_iterates_match_oracle(pa, m, n, what):
 
 @pytest.mark.parametrize("m,n,g", [(16384, 65536, "box"), (2048, 262144, "box"), (131072, 4096, "box"),
                                    (16384, 65536, "boxv"), (2048, 131072, "boxv"), (65536, 4096, "boxv"), (4096, 65536, "boxv"),
-                                   (7168, 32768, "boxv")])
+                                   (7168, 32768, "boxv"),
+                                   (16384, 32768, "l1w"), (2048, 65536, "l1w"), (65536, 4096, "l1w"), (4096, 32768, "l1w"),
+                                   (7168, 32768, "l1w")])
 def test_sweep_kernels_steady_state_indbox(pa, m, n, g):
     """The same comparison with g = IndBox (the other prox of the path): one workgroup, one wave and the
     team kernel with scalar bounds; with PER-ELEMENT bounds (pg_iter_set_g_vectors: two more n-vector streams in the sweep's
-    epilogue) every geometry -- gemv_tnm, gemv_tnw, gemv_tnt, gemv_tnc, gemv_tn."""
+    epilogue) every geometry -- gemv_tnm, gemv_tnw, gemv_tnt, gemv_tnc, gemv_tn; and NormL1 with PER-ELEMENT weights (one
+    more stream) through the same five."""
     _ffb_device_vs_oracle(pa, m, n, np.float32, fixed_its=20 if g == "box" else 12, adaptive_its=8 if g == "box" else 5, z_tol=1e-5, g=g)
+    if g == "l1w" and m == 2048:  # the operator on its own, both precisions, and the one-launch solvers' refusal
+        for dt in (np.float32, np.float64):
+            rng = np.random.default_rng(5)
+            xh, lam_v = rng.standard_normal(10007).astype(dt), rng.random(10007).astype(dt)
+            gd, go = pa.NormL1(lam_v), o.NormL1(lam_v)
+            xd = pa.HIPVector.from_numpy(xh)
+            yd = xd.similar()
+            gy = gd.prox_(yd, xd, dt(0.37))
+            yo, gyo = go.prox(xh, dt(0.37))
+            assert np.array_equal(yd.numpy(), yo)
+            assert float(gy) == pytest.approx(float(gyo), rel=1e-5 if dt == np.float32 else 1e-13)
+            assert float(gd(xd)) == pytest.approx(float(go(xh)), rel=1e-5 if dt == np.float32 else 1e-13)
+        with pytest.raises(ValueError):
+            pa.NormL1(np.array([0.1, -0.1]))
+        A, b, _ = o.synthetic_lasso(64, 40, seed=1, dtype=np.float32)
+        lam_v = np.linspace(0.0, 0.2, 40, dtype=np.float32)
+        z, k = pa.FastForwardBackward(tol=1e-6, maxit=500)(x0=np.zeros(40, np.float32), f=pa.LeastSquares(A, b), g=pa.NormL1(lam_v))
+        zo, ko = o.fast_forward_backward(tol=1e-6, maxit=500, x0=np.zeros(40, np.float32), f=o.LeastSquares(A, b), g=o.NormL1(lam_v))
+        assert k == ko and np.max(np.abs(z - zo)) <= 1e-5
     if g == "boxv":  # ... and the one-launch solvers refuse them (scalar bounds only) while the host-stepped loop takes them
         A, b, _ = o.synthetic_lasso(64, 40, seed=1, dtype=np.float32)
         lo_v, hi_v = np.full(40, -0.3, np.float32), np.linspace(0.01, 0.4, 40, dtype=np.float32)
@@ -1031,7 +1057,8 @@ def test_douglas_rachford_device_loop_is_bit_identical(pa, dtype, gname, block):
                 return s, k
 
     tols = [1e-3, 1e-5] if dtype == np.float32 else [1e-3, 1e-9, 1e-13]
-    cases = [(1000, t) for t in tols] + [(3, 0.0), (block, 0.0), (block + 5, 0.0), (3 * block, 0.0), (1, 0.0)]
+    cases = [(1000, t) for t in tols] + [(3, 0.0), (block, 0.0), (block + 5, 0.0), (3 * block, 0.0), (1, 0.0),
+                                           (2 * block - 1, 0.0), (block + block // 2 + 3, 0.0)]  # remainders run in smaller blocks
     seen = set()
     for maxit, tol in cases:
         s_ref, k_ref = stepwise(maxit, tol)
@@ -1263,7 +1290,7 @@ def test_douglas_rachford_at_config3_size_against_oracle(pa):
         if k == 70:
             break
     loop = pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma, materialize=False)
-    for block in (32, 64):  # two blocks of 32 + 6 single steps; one block of 64 + 6 single steps
+    for block in (32, 64):  # two blocks of 32 + 6 single steps; one block of 64 + 6 single steps (no block of 8 fits in the remainder)
         s_dev, k_dev = loop.device_run(70, 0.0, block)
         assert k_dev == 70
         assert np.array_equal(s_dev.x.numpy(), s_ref.x.numpy()) and np.array_equal(s_dev.y.numpy(), s_ref.y.numpy())
