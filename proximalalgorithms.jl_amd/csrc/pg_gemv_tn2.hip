@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WPB * 64) void gemv_tnw_kernel(TNArgs<T> a) {
     T zj;                            // :118 / :141
     if (a.g_kind == PG_G_NORML1) {
       T th = a.p0;
-      if (a.p0v != nullptr) th = a.gamma * a.p0v[jc];  // per-element weights lam_j
+      if (a.p0v != nullptr) th = pg_l1w_threshold(a.gamma, a.p0v[jc]);  // per-element weights lam_j
       zj = yj <= -th ? yj + th : (yj >= th ? yj - th : T(0));
     } else if (a.g_kind == PG_G_INDBOX) {
       T lo = a.p0, hi = a.p1;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnc_kernel(TNArgs<T> a) {
     T zj;                            // :118 / :141
     if (a.g_kind == PG_G_NORML1) {
       T th = a.p0;
-      if (a.p0v != nullptr) th = a.gamma * a.p0v[jc];  // per-element weights lam_j
+      if (a.p0v != nullptr) th = pg_l1w_threshold(a.gamma, a.p0v[jc]);  // per-element weights lam_j
       zj = yj <= -th ? yj + th : (yj >= th ? yj - th : T(0));
     } else if (a.g_kind == PG_G_INDBOX) {
       T lo = a.p0, hi = a.p1;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
       T zj;                            // :118 / :141
       if (a.g_kind == PG_G_NORML1) {
         T th = a.p0;
-        if (a.p0v != nullptr) th = a.gamma * a.p0v[valid ? j : a.n - 1];  // per-element weights lam_j
+        if (a.p0v != nullptr) th = pg_l1w_threshold(a.gamma, a.p0v[valid ? j : a.n - 1]);  // per-element weights lam_j
         zj = yj <= -th ? yj + th : (yj >= th ? yj - th : T(0));
       } else if (a.g_kind == PG_G_INDBOX) {
         T lo = a.p0, hi = a.p1;

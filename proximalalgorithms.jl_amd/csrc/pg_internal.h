@@ -245,6 +245,16 @@ __device__ __forceinline__ double pg_dpp_mov(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
 }
+// Threshold of the weighted 1-norm's prox, gamma * lam_j, ROUNDED on its own: ProximalOperators forms gl = gamma * lambda[i]
+// and then compares / adds it, so the product must not be contracted into the following add (the scalar case gets its
+// product from the host already rounded).
+template <typename T>
+__device__ __forceinline__ T pg_l1w_threshold(T gamma, T lam) {
+#pragma clang fp contract(off)
+  const T th = gamma * lam;
+  return th;
+}
+
 __device__ __forceinline__ float pg_readlane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

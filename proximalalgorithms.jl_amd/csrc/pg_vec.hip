@@ -161,7 +161,7 @@ struct ProxL1WF {
     Pack<T, N> xv = ld<T, N>(x, i), lv = ld<T, N>(lam, i), o;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      o.v[e] = soft_threshold(xv.v[e], gamma * lv.v[e]);
+      o.v[e] = soft_threshold(xv.v[e], pg_l1w_threshold(gamma, lv.v[e]));
       acc[0] += (double)lv.v[e] * fabs((double)o.v[e]);
     }
     st<T, N>(y, i, o);
@@ -221,7 +221,7 @@ struct EpilogueF {
     for (int e = 0; e < N; ++e) {
       yv.v[e] = xv.v[e] - gamma * gv.v[e];
       if constexpr (GKIND == PG_G_NORML1)
-        zv.v[e] = soft_threshold(yv.v[e], p0v != nullptr ? gamma * lov.v[e] : p0);
+        zv.v[e] = soft_threshold(yv.v[e], p0v != nullptr ? pg_l1w_threshold(gamma, lov.v[e]) : p0);
       else if constexpr (GKIND == PG_G_INDBOX)
         zv.v[e] = p0v != nullptr ? fmin(hiv.v[e], fmax(lov.v[e], yv.v[e])) : fmin(p1, fmax(p0, yv.v[e]));
       else
