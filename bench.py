@@ -89,6 +89,8 @@ def parse_args(argv=None):
                    help="seconds the main record's iteration keeps running after the K timed steps (reported as `sustained`); "
                         "default: 5 for the one-GPU headline line, 0 otherwise")
     p.add_argument("--also-budget", type=float, default=60.0, help="seconds the extra records may take in total (N = 1)")
+    p.add_argument("--no-settle", dest="settle", action="store_false",
+                   help="do not wait for the driver's background clearing of freed device memory before an extra record's set-up")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel-events", choices=["gemv", "all", "none"], default="gemv",
                    help="which kernels are bracketed by HIP event pairs in the timed region (none: no roofline object)")
@@ -1164,34 +1166,56 @@ def run_rank(args, job, wd, world, rank, local_rank):
             wd.enter("cpu_baseline", 600.0, stall=False)
             job.cpu = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
             args.no_cpu_baseline = True
+        es = np.dtype(dtype).itemsize
         P = None  # release the 64 GiB matrix
-        t_also = time.perf_counter()  # time box of the remaining records (the CPU leg is not part of it)
-        within = lambda: time.perf_counter() - t_also < args.also_budget
+        freed = [m_glob * n * es]
+        t_also = time.perf_counter()  # time box of the remaining records (the CPU leg and the settling waits are not part of it)
+        settled = [0.0]
+        within = lambda: time.perf_counter() - t_also - settled[0] < args.also_budget
 
-        def also_record(label, fn):
+        def settle():
+            # Freed device memory is cleared by the driver in the background at ~35 GB/s, and kernels that run meanwhile lose
+            # 2-4 % (profiles/r3_after_big_free.log: config 2 at 803 it/s for the 2.1 s after a 64 GiB free, 817 from then
+            # on).  A record that follows a big free waits that long before its set-up -- untimed, like the set-up itself.
+            import gc
+
+            gc.collect()
+            ctx.sync()
+            wait = min(6.0, freed[0] / 30e9 + 0.3) if args.settle else 0.0
+            if freed[0] > (1 << 30) and wait > 0:
+                time.sleep(wait)
+                settled[0] += wait
+            freed[0] = 0
+
+        def also_record(label, fn, frees=0):
             # an extra record that fails (out of memory on a smaller device, a refused shape) must not cost the headline line
             if not within():
                 return
             wd.enter(label, args.sub_record_timeout)
+            settle()
             try:
                 r = fn()
             except (pa.ProxGradError, MemoryError, RuntimeError) as e:
                 r = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             r["label"] = label
             also.append(r)
+            freed[0] = frees  # bytes of device memory this record gives back when it returns
 
         def ffb_record(mm, nn, steps_, warm_, key):
             P2 = setup_lasso(pa, ctx, D, mm, nn, dtype, args.seed, "none", "fixed")
             return run_ffb(pa, ctx, D, P2, "fixed", "one", steps_, warm_, args.kernel_events, workload_name=key)
 
-        also_record("config2", lambda: ffb_record(*WORKLOADS["config2"], max(sub_steps, 50), 5, "config2"))
+        m2_, n2_ = WORKLOADS["config2"]
+        also_record("config2", lambda: ffb_record(m2_, n2_, max(sub_steps, 50), 5, "config2"), frees=m2_ * n2_ * es)
         also_record("config3", lambda: run_config3(pa, ctx, beat=wd.beat))
-        also_record("config4", lambda: run_config4(pa, ctx, beat=wd.beat))
+        also_record("config4", lambda: run_config4(pa, ctx, beat=wd.beat), frees=16384 * 1_000_000 * 4)
         # per-GPU block shapes at N = 8, run as problems of their own on one GPU: BASELINE config 5 under the column layout
         # (131072 x 131072: one team sweep per iteration) and the headline under north_star's row layout (2048 x 2^20: the
         # short-column sweep, one wave per column group); the PMC passes of these sweeps were taken on exactly these shapes
-        also_record("config5_column_block", lambda: ffb_record(131072, 131072, sub_steps, 3, "long_columns"))
-        also_record("headline_row_block_n8", lambda: ffb_record(2048, 1 << 20, sub_steps, 3, "short_columns"))
+        also_record("config5_column_block", lambda: ffb_record(131072, 131072, sub_steps, 3, "long_columns"), frees=131072 * 131072 * es)
+        also_record("headline_row_block_n8", lambda: ffb_record(2048, 1 << 20, sub_steps, 3, "short_columns"), frees=2048 * (1 << 20) * es)
+        if settled[0] > 0:
+            extra["also_settle_s"] = round(settled[0], 2)
     elif world > 1:
         P = None
         other = "rows" if layout == "cols" else "cols"

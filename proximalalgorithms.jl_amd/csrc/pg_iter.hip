@@ -435,7 +435,14 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
     pg_set_error("column-sharded operators support the adaptive step for FastForwardBackward with reuse_residual only");
     return PG_ERR_UNSUPPORTED;
   }
-  const size_t vb = vec_bytes(it);
+  // experiment hooks: PG_ITER_VEC_SKEW = extra bytes between consecutive state vectors, PG_ITER_BASE_SKEW = offset of the
+  // first one within the allocation (both rounded to 256 B)
+  auto env_bytes = [](const char* name) -> size_t {
+    const char* v = getenv(name);
+    return v ? (size_t)pg_round_up((int64_t)strtoll(v, nullptr, 10), 256) : 0;
+  };
+  const size_t base_skew = env_bytes("PG_ITER_BASE_SKEW");
+  const size_t vb = vec_bytes(it) + env_bytes("PG_ITER_VEC_SKEW");
   const bool reuse = o->fast && o->reuse_residual != 0;
   // one read of A per iteration where the fused sweep applies: FB / FFB with a fixed step, FFB adaptive with the residual
   // pair; host-provided extrapolation coefficients arrive one step at a time, so they need the two-sweep path
@@ -444,20 +451,20 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   const int nvec = it->single_sweep ? 7 : 6;
   const size_t mb = reuse ? (size_t)pg_round_up((int64_t)((size_t)(f->A->m > 0 ? f->A->m : 1) * pg_sizeof(it->dtype)), 256) : 0;
   PG_HIP(hipSetDevice(c->device));
-  hipError_t e = hipMalloc(&it->slab, vb * nvec + 2 * mb);
+  hipError_t e = hipMalloc(&it->slab, base_skew + vb * nvec + 2 * mb);
   if (e != hipSuccess) {
     pg_set_error("state allocation (%zu bytes) failed: %s", vb * nvec, hipGetErrorString(e));
     delete it;
     return PG_ERR_ALLOC;
   }
-  e = hipMemsetAsync(it->slab, 0, vb * nvec + 2 * mb, c->stream);
+  e = hipMemsetAsync(it->slab, 0, base_skew + vb * nvec + 2 * mb, c->stream);
   if (e != hipSuccess) {
     (void)hipFree(it->slab);
     delete it;
     pg_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
     return PG_ERR_HIP;
   }
-  char* base = (char*)it->slab;
+  char* base = (char*)it->slab + base_skew;
   it->x = base + 0 * vb;
   it->grad_f_x = base + 1 * vb;
   it->y = base + 2 * vb;

@@ -37,3 +37,23 @@ gc.collect()
 for i in range(3):
     rec(m2, n2, 50, 5, "config2 after the headline #%d" % i)
 rec(m2, n2, 300, 50, "config2 after, 50 warm-up 300")
+
+# one iterator, one set of addresses: 12 consecutive windows of 50 steps -- is the spread temporal?
+import time
+
+P = bench.setup_lasso(pa, ctx, D, m2, n2, np.float32, 0, "none", "fixed")
+iteration = pa.FastForwardBackwardIteration(f=P["f"], g=pa.NormL1(P["lam"]), x0=P["zero_n"], Lf=P["Lf"])
+it = iter(iteration)
+for _ in range(10):
+    next(it)
+rates = []
+for w in range(12):
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        next(it)
+    ctx.sync()
+    rates.append(50 / (time.perf_counter() - t0))
+    if w == 5:
+        time.sleep(2.0)  # an idle gap: does the rate after it differ?
+print("same iterator, 12 windows of 50 steps (2 s idle after the 6th): " + " ".join("%.0f" % r for r in rates), flush=True)
