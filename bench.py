@@ -720,6 +720,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
         D.barrier()
         dt1 = time.perf_counter() - t1
         sustained = {"seconds": round(dt1, 2), "steps": k1, "value": round(k1 / dt1, 4), "ms_per_step": round(1e3 * dt1 / k1, 4)}
+    fallbacks = int(iteration.counters.get("sweep_fallbacks", 0))  # steps redone with two sweeps (team-sweep timeout / refusal)
     elapsed = D.max_over_ranks(elapsed)
     its = steps / elapsed
     sweeps_done = a_passes / max(steps, 1)  # reads of A per iteration actually executed
@@ -773,7 +774,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
             "%s of A sharded over %d GPU(s)" % ("columns" if cols else "rows", D.world)),
             "m": m_glob, "n": n, "mode": mode, "sharding": layout, "shards": D.world if layout != "none" else 1,
             "m_per_gpu": m_loc, "n_per_gpu": n_loc, "lambda": float(P["lam"]), "Lf": float(Lf) if Lf is not None else None,
-            "seed": P["seed"], "a_passes_per_step": a_passes / max(steps, 1),
+            "seed": P["seed"], "a_passes_per_step": a_passes / max(steps, 1), "sweep_fallbacks": fallbacks,
             "sweeps": sweeps if layout != "rows" else "two", "setup_s": round(P["setup_s"], 2),
             "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
                       "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
@@ -1217,12 +1218,21 @@ def run_rank(args, job, wd, world, rank, local_rank):
         if settled[0] > 0:
             extra["also_settle_s"] = round(settled[0], 2)
     elif world > 1:
+        es = np.dtype(dtype).itemsize
+        freed = [P["m_loc"] * P["n_loc"] * es]
         P = None
         other = "rows" if layout == "cols" else "cols"
 
         def extra_record(key, m_rec, lay, scaling):
             # an extra record that cannot run (the library refuses the shape on every rank alike) must not cost the line
             wd.enter(key, args.sub_record_timeout)
+            if args.settle and freed[0] > (1 << 30):  # the driver clears the block just freed in the background (see `settle` above);
+                import gc                             # every rank frees the same number of bytes, so all wait equally long
+
+                gc.collect()
+                ctx.sync()
+                time.sleep(min(6.0, freed[0] / 30e9 + 0.3))
+            freed[0] = (m_rec // world if lay == "rows" else m_rec) * (n if lay == "rows" else -(-n // world)) * es
             try:
                 P2 = setup_lasso(pa, ctx, D, m_rec, n, dtype, args.seed, lay, "fixed")
                 extra[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events, scaling=scaling)

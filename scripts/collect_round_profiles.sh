@@ -31,6 +31,8 @@ for mn in "131072 131072 long_131072" "65536 262144 long_65536" "50000 84000 odd
   set -- $mn; python bench.py --m $1 --n $2 --steps 30 --warmup 5 $B > $O/bench_$3.json 2>/dev/null
 done
 python bench.py --m 131072 --n 131072 --mode adaptive --steps 20 --warmup 3 $B > $O/bench_long_131072_adaptive.json 2>/dev/null
+# the team sweep (members wait for each other through memory) kept running for 45 s: `sustained` and config.sweep_fallbacks (= 0)
+python bench.py --m 131072 --n 131072 --steps 20 --warmup 3 --sustain 45 $B > $O/bench_long_131072_soak.json 2>/dev/null
 python bench.py --m 8192 --n 1048576 --dtype f64 --steps 20 --warmup 3 $B > $O/bench_f64_8192.json 2>/dev/null
 python bench.py --m 65536 --n 131072 --dtype f64 --steps 20 --warmup 3 $B > $O/bench_f64_long_65536.json 2>/dev/null
 # per-GPU shapes of the N = 2 / 4 / 8 column-block runs with the collective attached (one rank, the library's own RCCL communicator)

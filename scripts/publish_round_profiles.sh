@@ -4,7 +4,7 @@ set -e
 O=gpurun_out/r3
 P=profiles
 line() { grep '^{' "$1" | tail -1; }
-for f in default config2 long_131072 long_131072_adaptive long_65536 odd_50000 odd_100000 odd_10000 mid_10240 mid_12288 mid_24576 mid_32768 mid_7168 \
+for f in default config2 long_131072 long_131072_adaptive long_131072_soak long_65536 odd_50000 odd_100000 odd_10000 mid_10240 mid_12288 mid_24576 mid_32768 mid_7168 \
          short_4096 short_2048 short_1024 short_512 short_512x4M colshard_n524288 colshard_n262144 colshard_n131072 f64_8192 f64_long_65536 dr panoc; do
   cp $O/bench_$f.json $P/r3_bench_$f.json
 done
