@@ -32,9 +32,13 @@ Extra legs in the same line:
                 its vectors; whole_iteration reports the SURVEY 8(d) two-pass figure and the bytes actually moved.
                 traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes, quoted only while the
                 kernel sources still hash to what the passes were taken on (else null + traffic_stale).
-  cpu_baseline  the CPU restatement (oracle/, numpy + OpenBLAS, same unfused op order as the reference) timed on
-                this host on the SAME workload (the device matrix copied to host memory) when memory allows, else
-                on a bounded column sample scaled to it/s of the full workload.
+  in_library_loop  (fixed step, one rank) the same K iterations enqueued by the library without a host round trip in between
+                (pg_iter_run_batched); `value` stays the stepped loop of the reference's iterator
+  cpu_baseline  the CPU restatement (oracle/csrc/cpu_twin.c: C / OpenMP, same unfused op order as the reference; the
+                numpy + OpenBLAS oracle's rate beside it) timed on this host on the SAME workload (the device matrix copied
+                to host memory) when memory allows, else on a bounded column sample scaled to it/s of the full workload.
+  also_settle_s seconds the extra records waited (untimed) for the driver to finish clearing device memory freed just
+                before them: kernels running during that clearing lose 2-4 % (profiles/r3_freed_memory_settle.md)
 """
 import argparse
 import ctypes
@@ -721,6 +725,21 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
         dt1 = time.perf_counter() - t1
         sustained = {"seconds": round(dt1, 2), "steps": k1, "value": round(k1 / dt1, 4), "ms_per_step": round(1e3 * dt1 / k1, 4)}
     fallbacks = int(iteration.counters.get("sweep_fallbacks", 0))  # steps redone with two sweeps (team-sweep timeout / refusal)
+    in_library = None
+    if mode == "fixed" and D.world == 1 and getattr(iteration, "_fused", None) is not None:
+        # the same K iterations enqueued by the library without a host round trip in between (pg_iter_run_batched: with a
+        # fixed step nothing the host decides is needed per iteration; the stopping rule is then looked at once per batch).
+        # Reported beside `value`, which stays the stepped loop of the reference's iterator (one read-back per iteration).
+        try:
+            ctx.sync()
+            t2 = time.perf_counter()
+            k2, _ = iteration._fused.run(0, steps, 0.0, check_every=steps)
+            ctx.sync()
+            dt2 = time.perf_counter() - t2
+            in_library = {"steps": int(k2), "check_every": steps, "value": round(k2 / dt2, 4), "ms_per_step": round(1e3 * dt2 / max(k2, 1), 4)}
+        except pa.ProxGradError as e:
+            in_library = {"error": str(e)[:200]}
+        D.beat()
     elapsed = D.max_over_ranks(elapsed)
     its = steps / elapsed
     sweeps_done = a_passes / max(steps, 1)  # reads of A per iteration actually executed
@@ -791,6 +810,8 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
     del it, iteration
     if sustained is not None:
         rec["sustained"] = sustained
+    if in_library is not None:
+        rec["in_library_loop"] = in_library
     return rec
 
 
