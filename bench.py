@@ -404,8 +404,7 @@ def _cpu_bandwidth_fields(rec, m, n, es):
         rec["host_stream_GBps_1thread"] = round(g_one, 1)
         rec["host_cpus_granted"] = _effective_cpus()
         rec["host_stream_note"] = "STREAM add (Float32, numpy kernels on %d threads = the CPUs the cgroup grants, 3 x 1 GiB arrays, sustained " \
-                                  "over >= 1 s): what this host streams for this job; achieved_GBps / host_stream_GBps is the CPU " \
-                                  "leg's own roofline fraction" % T
+                                  "over >= 1 s; numpy's add pays a write-allocate, so a read-only pass can run faster: host_read_GBps)" % T
     except Exception as e:  # never let the side measurement cost the line
         rec["host_stream_GBps"] = None
         rec["host_stream_note"] = "not measured: %s" % str(e)[:120]
@@ -439,8 +438,12 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
             steps = int(max(2, min(max_steps, 0.5 * budget_s / max(sec1, 1e-3))))
             _, _, sec, thr = cpu_twin.ffb(A, b, lam, Lf, steps, threads=ncpu)
             _, _, sec_1t, _ = cpu_twin.ffb(A, b, lam, Lf, 1, threads=1)
+            read_all = cpu_twin.read_gbps(A, threads=ncpu)  # this host's read rate on the same 64 GiB, same threads
             cpu_twin.load().cpu_twin_set_threads(ncpu)
-            rec = {"value": steps / sec, "value_1thread": 1.0 / sec_1t, "unit": "it/s", "cores": int(thr), "kind": "port",
+            rec = {"host_read_GBps": round(read_all, 1),
+                   "host_read_note": "one OpenMP pass summing the same matrix on the same threads (oracle/csrc/cpu_twin.c::cpu_twin_read_pass): "
+                                     "the host's read ceiling for this job; achieved_GBps / host_read_GBps is the CPU leg's own roofline fraction",
+                   "value": steps / sec, "value_1thread": 1.0 / sec_1t, "unit": "it/s", "cores": int(thr), "kind": "port",
                    "impl": "C / OpenMP twin of the reference's unfused op sequence (oracle/csrc/cpu_twin.c)",
                    "sample": f"the full workload: FFB fixed-step on the downloaded {m}x{n} float32 matrix ({A.nbytes / 2**30:.1f} GiB, "
                              f"copied to the host in {t_dl:.1f} s), {steps} iterations in {sec:.1f} s on {thr} threads; 1 thread: "

@@ -56,6 +56,8 @@ def load():
         lib.cpu_twin_ffb.restype = C.c_float
         lib.cpu_twin_ffb.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p,
                                      C.POINTER(C.c_double)]
+        lib.cpu_twin_read_pass.restype = C.c_double
+        lib.cpu_twin_read_pass.argtypes = [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double)]
         lib.cpu_twin_threads.restype = C.c_int
         lib.cpu_twin_set_threads.argtypes = [C.c_int]
         _lib = lib
@@ -74,3 +76,16 @@ def ffb(A, b, lam, Lf, steps, threads=None):
     sec = C.c_double()
     fx = lib.cpu_twin_ffb(A.ctypes.data, m, n, m, b.ctypes.data, float(lam), float(Lf), int(steps), z.ctypes.data, C.byref(sec))
     return z, float(fx), float(sec.value), int(lib.cpu_twin_threads())
+
+
+def read_gbps(A, threads=None, min_seconds=1.0):
+    """GB/s this host reads the array `A` at with `threads` OpenMP threads (passes repeated until `min_seconds` have gone by)"""
+    lib = load()
+    if threads is not None:
+        lib.cpu_twin_set_threads(int(threads))
+    sec = C.c_double()
+    count = A.size
+    lib.cpu_twin_read_pass(A.ctypes.data, count, 1, C.byref(sec))  # sizes the run (and touches the pages)
+    reps = int(max(1, min(50, min_seconds / max(sec.value, 1e-4))))
+    lib.cpu_twin_read_pass(A.ctypes.data, count, reps, C.byref(sec))
+    return A.nbytes * reps / sec.value / 1e9

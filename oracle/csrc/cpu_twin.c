@@ -82,6 +82,27 @@ static float value_and_gradient(const float* A, long m, long n, long ld, const f
   return (float)(0.5 * nrm);
 }
 
+/* Read ceiling of this host on the SAME bytes: one pass over `count` floats summed with all threads (static chunks, like
+ * gemv_t's column blocks), `reps` passes timed together.  Returns the sum (so that the loads stay); seconds in *seconds_out. */
+double cpu_twin_read_pass(const float* a, long count, int reps, double* seconds_out) {
+  double total = 0.0;
+  const double t0 = omp_get_wtime();
+  for (int r = 0; r < reps; ++r) {
+    double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+    for (long blk = 0; blk < (count + 65535) / 65536; ++blk) {
+      const long lo = blk * 65536, hi = lo + 65536 < count ? lo + 65536 : count;
+      float acc = 0.0f;
+#pragma omp simd reduction(+ : acc)
+      for (long i = lo; i < hi; ++i) acc += a[i];
+      s += acc;
+    }
+    total += s;
+  }
+  *seconds_out = omp_get_wtime() - t0;
+  return total;
+}
+
 int cpu_twin_threads(void) { return omp_get_max_threads(); }
 void cpu_twin_set_threads(int t) { omp_set_num_threads(t); }
 

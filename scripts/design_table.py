@@ -103,7 +103,8 @@ def main():
     add(f"CPU: the C / OpenMP twin on the same 64 GiB matrix, {tw['cores']} threads / one thread; numpy + OpenBLAS oracle "
         f"(`cpu_baseline.value` = the faster of the two: {cb['value']:.2f})",
         f"{tw['value']:.2f} / {cb['value_1thread']:.2f}; {npb.get('value', float('nan')):.2f}", "", f"{twin_gbps:.0f} / {cb.get('achieved_GBps_1thread', 0):.0f} GB/s; {npb.get('achieved_GBps', 0):.0f} GB/s",
-        f"host STREAM add {cb.get('host_stream_GBps')} GB/s", "`cpu_baseline` of the line")
+        (f"host read pass over the same matrix {cb['host_read_GBps']} GB/s; " if cb.get("host_read_GBps") else "") + f"STREAM add (numpy) {cb.get('host_stream_GBps')} GB/s",
+        "`cpu_baseline` of the line")
     head = (f"streaming-read ceiling of the same box (`r3_stream_ceiling.log`, random data): {ceiling:.2f} TB/s — the headline sweep is at "
             f"{tb(r) / ceiling:.2f} of it, config 2 {tb(c2['roofline']) / ceiling:.2f}, long columns {tb(lf['roofline']) / ceiling:.2f}, "
             f"2048-row columns {tb(sh[1]['roofline']) / ceiling:.2f}" if ceiling else "")
