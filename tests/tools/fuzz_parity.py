@@ -45,8 +45,21 @@ def one_case(seed):
     b = (A @ xt + dtype(0.01) * rng.standard_normal(m).astype(dtype)).astype(dtype)
     lam = dtype(0.1) * dtype(max(np.max(np.abs(A.T @ b)), 1e-3))
     Lf = dtype(1.02 * np.linalg.norm(A.astype(np.float64), 2) ** 2) if min(m, n) > 0 else dtype(1)
-    if gname == "l1":
+    # per-element parameters of g (IndBox bounds / NormL1 weights inside the single sweep): drawn from a generator of
+    # their own so that the cases of earlier campaigns keep their seeds
+    rv = np.random.default_rng(seed + 1_000_003)
+    per_element = gname != "zero" and rv.random() < 0.3
+    if gname == "l1" and per_element:
+        lam_v = (lam * (0.25 + 1.5 * rv.random(n))).astype(dtype)
+        lam_v[rv.random(n) < 0.1] = 0
+        g_g, g_o, gname = pa.NormL1(lam_v), o.NormL1(lam_v), "l1w"
+    elif gname == "l1":
         g_g, g_o = pa.NormL1(lam), o.NormL1(lam)
+    elif gname == "box" and per_element:
+        lo_v, hi_v = (-0.3 * rv.random(n)).astype(dtype), (0.4 * rv.random(n)).astype(dtype)
+        pin = rv.random(n) < 0.1
+        hi_v[pin] = lo_v[pin]
+        g_g, g_o, gname = pa.IndBox(lo_v, hi_v), o.IndBox(lo_v, hi_v), "boxv"
     elif gname == "box":
         g_g, g_o = pa.IndBox(dtype(-0.3), dtype(0.4)), o.IndBox(dtype(-0.3), dtype(0.4))
     else:
@@ -65,7 +78,8 @@ def one_case(seed):
     F_start = 0.5 * float(b.astype(np.float64) @ b.astype(np.float64))
     It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
     f_g = pa.LeastSquares(A, b)
-    solvers = (["step", "run"] if TALL else ["step", "run", "small", "coop"]) + (["batched"] if mode == "fixed" else [])
+    solvers = (["step", "run"] if (TALL or per_element) else ["step", "run", "small", "coop"]) + (["batched"] if mode == "fixed" else [])
+    # (the one-launch solvers take scalar parameters of g only)
     fails = []
     for solver in solvers:
         it = It(f=f_g, g=g_g, x0=x0, engine="fused", **kw)
