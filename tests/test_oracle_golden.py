@@ -614,3 +614,11 @@ def test_cpu_twin_matches_the_numpy_oracle():
         assert np.max(np.abs(z - s.z)) <= 1e-5 * max(1.0, float(np.max(np.abs(s.z))))
         assert abs(fx - float(s.f_x)) <= 1e-5 * abs(float(s.f_x)) and sec > 0 and thr >= 1
         assert np.array_equal(z != 0, s.z != 0) or np.count_nonzero((z != 0) != (s.z != 0)) <= 2
+    # the host read-ceiling pass of the CPU leg: every element is read (the sum says so), the rate is a positive number
+    import ctypes as C
+
+    big = np.arange(200_003, dtype=np.float32) % 7
+    sec = C.c_double()
+    total = cpu_twin.load().cpu_twin_read_pass(big.ctypes.data, big.size, 3, C.byref(sec))
+    assert total == 3 * float(big.astype(np.float64).sum()) and sec.value > 0
+    assert cpu_twin.read_gbps(big, threads=2, min_seconds=0.01) > 0
