@@ -641,7 +641,7 @@ def test_bench_rank_failure_still_prints_a_line(pa, stage, kind):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--workload", "small",
            "--steps", "6", "--warmup", "1", "--inject-fault", "1:%s:%s" % (stage, kind), "--record-timeout", "25",
-           "--sub-record-timeout", "15", "--stall-timeout", "4", "--launch-timeout", "240"]
+           "--sub-record-timeout", "15", "--stall-timeout", "6", "--launch-timeout", "240"]
     t0 = time.time()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
     took = time.time() - t0
