@@ -372,7 +372,10 @@ pg_status pg_iter_run(pg_iter* it, int64_t k_start, int64_t maxit, double tol, i
 /* Device-resident variant for fixed-step runs: `check_every` iterations are enqueued back to
  * back with no host synchronisation in between (nothing the host decides depends on them), then the scalar block is
  * read once and the stopping rule evaluated; k_out advances in steps of `check_every` (capped by maxit).  With
- * check_every = 1 this is pg_iter_run.  Not available with an adaptive step: backtracking is a host decision. */
+ * check_every = 1 this is pg_iter_run.  Not available with an adaptive step: backtracking is a host decision.
+ * A long-column sweep that times out inside a batch (PG_ERR_TIMEOUT at the batch's read-back) cannot be redone -- the
+ * iterations behind it are already enqueued -- so the call fails and the state is undefined: re-run pg_iter_init and use
+ * pg_iter_run, which redoes a lost sweep per iteration (the Python algorithm object does exactly that). */
 pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int32_t check_every,
                               int64_t* k_out, pg_iter_scalars* out);
 /* Launch-bound sizes (0 < m * n <= 2^20 elements, e.g. the reference's shipped benchmark instances): the whole

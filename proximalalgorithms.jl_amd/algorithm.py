@@ -1,4 +1,6 @@
 """IterativeAlgorithm -- mirror of src/ProximalAlgorithms.jl:58-123."""
+from . import _lib
+from ._lib import ProxGradError
 from .device import HIPVector
 
 
@@ -94,7 +96,21 @@ class IterativeAlgorithm:
             elif unsharded and coop_rows and nbytes <= ((10 << 20) if adaptive else ((3 << 20) if check_every > 1 else (8 << 20))):
                 k, _ = fused.run_coop(1, self.maxit, tol)
             elif check_every > 1 and not adaptive:
-                k, _ = fused.run(1, self.maxit, tol, check_every=check_every)
+                try:
+                    k, _ = fused.run(1, self.maxit, tol, check_every=check_every)
+                except ProxGradError as e:
+                    # A team sweep lost inside a batch (PG_ERR_TIMEOUT, seen at the batch's one read-back) cannot be redone:
+                    # the iterations behind it are already enqueued.  Start over from x0 with the per-iteration loop, which
+                    # redoes a lost sweep with two sweeps and carries on (pg_iter_run; csrc/pg_iter.hip).
+                    if e.code != _lib.PG_ERR_TIMEOUT:
+                        raise
+                    import warnings
+
+                    warnings.warn("a long-column sweep timed out inside a batch of %d iterations; the solve restarts with "
+                                  "one synchronisation per iteration" % check_every)
+                    it.counters["sweep_fallbacks"] = it.counters.get("sweep_fallbacks", 0) + 1
+                    fused.init(it.x0)  # (the iteration holds x0 as a device vector and never writes it)
+                    k, _ = fused.run(1, self.maxit, tol)
             else:
                 k, _ = fused.run(1, self.maxit, tol)
             state._invalidate()

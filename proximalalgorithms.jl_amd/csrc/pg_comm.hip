@@ -30,23 +30,23 @@ struct RcclApi {
 };
 
 RcclApi* rccl_api() {
-  static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // (a function-local static: initialised once, thread-safe)
+  static RcclApi api = [] {
+    RcclApi a;
     // the copy already mapped by the process (torch ships one) wins; else the ROCm installation's
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (api.lib) break;
+      a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
     }
-    if (api.lib) {
-      api.get_unique_id = (ncclGetUniqueId_t)dlsym(api.lib, "ncclGetUniqueId");
-      api.comm_init_rank = (ncclCommInitRank_t)dlsym(api.lib, "ncclCommInitRank");
-      api.comm_destroy = (ncclCommDestroy_t)dlsym(api.lib, "ncclCommDestroy");
-      api.all_reduce = (ncclAllReduce_t)dlsym(api.lib, "ncclAllReduce");
-      api.error_string = (ncclGetErrorString_t)dlsym(api.lib, "ncclGetErrorString");
+    if (a.lib) {
+      a.get_unique_id = (ncclGetUniqueId_t)dlsym(a.lib, "ncclGetUniqueId");
+      a.comm_init_rank = (ncclCommInitRank_t)dlsym(a.lib, "ncclCommInitRank");
+      a.comm_destroy = (ncclCommDestroy_t)dlsym(a.lib, "ncclCommDestroy");
+      a.all_reduce = (ncclAllReduce_t)dlsym(a.lib, "ncclAllReduce");
+      a.error_string = (ncclGetErrorString_t)dlsym(a.lib, "ncclGetErrorString");
     }
-  }
+    return a;
+  }();
   if (!api.lib || !api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce) return nullptr;
   return &api;
 }
@@ -139,6 +139,9 @@ pg_status pg_ctx_comm_init(pg_ctx* c, const void* id_bytes, int32_t nranks, int3
       hipEventCreateWithFlags(&k->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&k->ev_done, hipEventDisableTiming) != hipSuccess) {
     pg_set_error("side stream / event creation failed");
+    if (k->ev_done) (void)hipEventDestroy(k->ev_done);
+    if (k->ev_ready) (void)hipEventDestroy(k->ev_ready);
+    if (k->side) (void)hipStreamDestroy(k->side);
     api->comm_destroy(k->comm);
     delete k;
     return PG_ERR_HIP;

@@ -690,6 +690,23 @@ def test_team_sweep_timeout_falls_back_to_two_sweeps(pa, mode, cols):
     assert by_k[2] == 1 and by_k[3] >= 2 and by_k[6] == 1 and by_k[7] == 1, by_k  # one read of A per step again after the fallback
 
 
+def test_team_sweep_timeout_inside_a_batch_restarts_the_solve(pa):
+    """The same fault inside pg_iter_run_batched (FastForwardBackward(device_loop=True, check_every=4)): the batch's one
+    read-back reports PG_ERR_TIMEOUT with later iterations already enqueued, so the step cannot be redone -- the algorithm
+    object warns, restarts from x0 with the per-iteration loop and returns the oracle's iterate."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "tools", "team_fault.py"), "--mode", "fixed", "--fault", "3", "--steps", "7",
+           "--n", "4096", "--batched"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    assert d["batched"] and d["warned"] and d["k"] == 8 and d["dz"] <= 1e-5 * d["z_scale"], d
+
+
 def test_bench_default_line_carries_every_single_gpu_config(pa):
     """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`): the top-level record is the fixed-step headline
     run; `also` holds the reference benchmark's adaptive mode on the same matrix and BASELINE configs 2, 3, 4, each with its

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--cols", action="store_true", help="run as the single rank of a column-sharded job (gloo, world size 1)")
     ap.add_argument("--fault", type=int, default=3, help="which team launch loses a member (0: none)")
     ap.add_argument("--steps", type=int, default=7)
+    ap.add_argument("--batched", action="store_true",
+                    help="the algorithm object with device_loop=True, check_every=4: the fault lands inside a batch, which cannot be "
+                         "redone -- the solve restarts with the per-iteration loop (a warning says so)")
     args = ap.parse_args()
     if args.fault:
         os.environ["PG_TEST_TEAM_FAULT"] = str(args.fault)  # before the context exists
@@ -55,6 +58,17 @@ def main():
     f = pa.LeastSquares(A, b, comm=comm)
     iteration = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=x0, Lf=Lf)
     ito = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0, Lf=Lf))
+    if args.batched:
+        import warnings
+
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            z, k = pa.FastForwardBackward(tol=0.0, maxit=args.steps + 1, device_loop=True, check_every=4)(x0=x0, f=f, g=pa.NormL1(lam), Lf=Lf)
+        for _ in range(args.steps + 1):
+            so = next(ito)
+        print(json.dumps({"batched": True, "k": int(k), "dz": float(np.max(np.abs(z - so.z))), "z_scale": float(max(1.0, np.max(np.abs(so.z)))),
+                          "warned": any("timed out inside a batch" in str(w.message) for w in caught)}))
+        return
     it = iter(iteration)
     rows, passes = [], 0
     for k in range(args.steps + 1):
