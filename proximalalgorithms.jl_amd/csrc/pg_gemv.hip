@@ -14,6 +14,8 @@
 //                          (pg_ls_fused_pass / pg_mat_fused_tn; column shards: one all-reduce of m + 8 N elements).
 //                          Three geometries by column length: gemv_tnw (short), gemv_tn (pg_gemv_tn.h), gemv_tnt
 //                          (long: teams of workgroups) -- see launch_tn.
+#include <mutex>
+
 #include "pg_gemv_tn.h"
 
 using namespace pgtn;
@@ -368,7 +370,9 @@ pg_status launch_t_cuw(pg_mat* A, int rg_begin, int nrg, const T* r, T* g, int64
   if (blocks > need) blocks = need;
   if (blocks < 1) blocks = 1;
   if ((int64_t)lds > LDS_DEFAULT_LIMIT) {
+    static std::mutex mu;  // (contexts of several host threads may launch the same instantiation for the first time)
     static bool opted_in[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
     const int dev = c->device & 63;
     if (!opted_in[dev]) {
       PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_t_kernel<T, C, UR, WAVES>),

@@ -979,6 +979,9 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int W = env_int("PG_TNT_WAVES", 4);
   int U = env_int("PG_TNT_U", W == 4 ? 0 : 8);
   if (U == 0) {  // four-wave members: the smallest instantiation that holds the even deal
+    // The fewest members that hold the column.  (Measured, profiles/r3_team_pattern.md: more members of fewer row groups each,
+    // where that leaves less padding -- 50000 rows as 5 x 4 x 10 instead of 4 x 4 x 13, 150000 rows as 15 x 4 x 10 instead of
+    // 10 x 4 x 15 -- is slower every time, 0.816 against 0.829 and 0.735 against 0.842 of 8 TB/s: shorter steps, same exchange.)
     int TM = (a.nrg + TEAM_MEMBER_RG - 1) / TEAM_MEMBER_RG;
     if (env_int("PG_TN_TEAM", 0) > TM) TM = env_int("PG_TN_TEAM", 0);
     U = (a.nrg + TM * 4 - 1) / (TM * 4);

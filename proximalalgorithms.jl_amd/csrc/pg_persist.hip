@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "pg_iter_internal.h"
 
@@ -921,10 +922,14 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
   p.rows_per = (int)((A->m + W - 1) / W);
   const size_t lds = (size_t)lds_for(W);
   const void* kern = reinterpret_cast<const void*>(&coop_solver_kernel<T>);
-  static bool opted_in[64] = {};
-  if (!opted_in[c->device & 63]) {
-    PG_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COOP_MAX_LDS));
-    opted_in[c->device & 63] = true;
+  {
+    static std::mutex mu;
+    static bool opted_in[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (!opted_in[c->device & 63]) {
+      PG_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COOP_MAX_LDS));
+      opted_in[c->device & 63] = true;
+    }
   }
   // workspace: [bar (8 B) | abort (4 B) | pad to 64 B][2][W][4] scalar partials [2][W][m_pad] pass-N partials [2][m_pad] r
   const size_t n_sp = (size_t)2 * W * 4, n_np = (size_t)2 * W * p.m_pad;
