@@ -214,7 +214,11 @@ pg_status pg_ls_residual_ptr(pg_ls* f, const void** r_out);
  * launch is refused (PG_ERR_UNSUPPORTED, nothing written).  One such sweep at a time per device: a member that still has
  * not heard from its team after a bounded wait gives up, and the call (or, with scalars_out == NULL, the next call that
  * synchronises) returns PG_ERR_TIMEOUT -- grad, y, z_new, res, v_next and f's residual are then undefined, x and z_old
- * intact; re-evaluate f at x (pg_ls_value) before trying again, or use pg_ls_value_and_gradient + pg_fb_epilogue. */
+ * intact; re-evaluate f at x (pg_ls_value) before trying again, or use pg_ls_value_and_gradient + pg_fb_epilogue.
+ * On a device shared with ANOTHER PROCESS that has used a cooperative launch (even an idle one) the cooperative team sweep
+ * runs at about half its rate: the device does not run the cooperative queues of two processes side by side.  The
+ * environment variable PG_TN_TEAM_PLAIN=1 (read when the context is created) launches the teams plainly instead -- full
+ * rate, no residency guarantee, the bounded wait and PG_ERR_TIMEOUT as the safety net. */
 pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,
                            double g_p0, double g_p1, void* grad, void* y, void* z_new, void* res, void* v_next,
                            double* scalars_out);
