@@ -178,7 +178,7 @@ pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int3
  * column-major store; used by LeastSquares and (later) PANOC's `mul!` with A: panoc.jl:150-190 */
 pg_status pg_mat_mul(pg_mat* A, const void* x, void* y);
 pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
-/* The single sweep for x -> f(A x) compositions (PANOC: panoc.jl:184, :197-199, and the `mul!(Az, A, z)` of the next line
+/* The single sweep for x -> f(A x) compositions (PANOC: panoc.jl:186, :199-201, and the `mul!(Az, A, z)` of the next line
  * search, fb_tools.jl:43): for a caller-supplied m-vector r (= grad f(A x)),
  *   At_r = A' r ; y = x - gamma At_r ; z = prox_{gamma g}(y) ; res = x - z ; Az = A z
  * in ONE read of A.  scalars_out (host, may be NULL) = { g(z), norm(res, Inf), dot(At_r, res), norm(res)^2 }.
@@ -186,6 +186,13 @@ pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
  * teams of workgroups); PG_ERR_UNSUPPORTED otherwise. */
 pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
                           void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out);
+/* The same sweep leaving Ares = A (x - z), the image of the forward-backward residual, instead of A z: the residual's image
+ * as a PRODUCT of the (small) residual -- its error scales with norm(res), where A x - A z carries eps * norm(A x) however
+ * small the residual has become.  PANOC with the L-BFGS image slab (pg_lbfgs_images_*) runs on it: d = -H res (panoc.jl:
+ * 114-117), A d from the images of A res, A y = A res+ - A res (panoc.jl:122-126), and the line search's A z = A x - A res
+ * (fb_tools.jl:43) shares its rounding with the A x that f(A x) was taken at. */
+pg_status pg_mat_fused_tn_res(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
+                              void* At_r, void* y, void* z, void* res, void* Ares, double* scalars_out);
 /* ------------------------------------------------------------------ LeastSquares -------- */
 /* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the
  * value_and_gradient method of benchmark/benchmarks.jl:11-17.  `b` is a device m-vector
@@ -406,6 +413,21 @@ pg_status pg_lbfgs_destroy(pg_lbfgs* L);
 pg_status pg_lbfgs_update(pg_lbfgs* L, const void* s, const void* y); /* update!  lbfgs.jl:30-50 */
 pg_status pg_lbfgs_reset(pg_lbfgs* L);                               /* reset!   lbfgs.jl:52-55 */
 pg_status pg_lbfgs_apply(pg_lbfgs* L, void* d, const void* v);       /* mul!     lbfgs.jl:64-95 */
+
+/* Images of the stored pairs under a linear map A (m rows): with A s_i and A y_i kept next to s_i, y_i, the image of the
+ * quasi-Newton direction, A (H v), follows from A v and the two-loop coefficients of the LAST pg_lbfgs_apply without
+ * reading A:  A d = H0 (A v - sum alpha_i A y_i) + sum (alpha_i - beta_i) A s_i.  This removes the `mul!(state.Ad, iter.A,
+ * state.d)` of src/algorithms/panoc.jl:180 (zerofpr.jl:193; the `mul!(state.Ax, iter.A, state.x)` of panocplus.jl:199):
+ * v = res = x - z, A v = A x - A z are m-vectors the iteration already holds (panoc.jl:181 keeps A x, the forward-backward
+ * sweep leaves A z), and the images of a new pair are differences of such m-vectors (A s = A x+ - A x, A y = A res+ - A res:
+ * panoc.jl:122-126).  _enable(m) allocates the image slab (2 M m-vectors); _update(As, Ay) must follow every
+ * pg_lbfgs_update with the images of the same pair (ignored when the pair was rejected, <s, y> <= 0: lbfgs.jl:34);
+ * _apply(Ad, Av) must follow the pg_lbfgs_apply whose direction it maps and is refused (PG_ERR_INVALID) when a pair that
+ * apply used has no current image; _ready says beforehand whether every pair the NEXT apply will use has one. */
+pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m);
+pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay);
+pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av);
+pg_status pg_lbfgs_images_ready(pg_lbfgs* L, int32_t* ready_out);
 #ifdef __cplusplus
 }
 #endif

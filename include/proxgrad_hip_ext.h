@@ -4,7 +4,7 @@
  * proxgrad_hip.h is the drop-in boundary for the ForwardBackward / FastForwardBackward path and its "next" rows
  * (DouglasRachford, PANOC / ZeroFPR / PANOCplus with L-BFGS, the device-resident loops).  What is declared here serves
  * other algorithms of the reference on the same kernels -- Davis-Yin and AFBA bodies replayed as graphs, the Broyden
- * operator, PANOC's image slab -- and is kept apart so that the boundary header matches section 8(b)'s table.
+ * operator -- and is kept apart so that the boundary header matches section 8(b)'s table.
  * Same conventions as proxgrad_hip.h.
  */
 #ifndef PROXGRAD_HIP_EXT_H
@@ -46,17 +46,6 @@ pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void*
                            int32_t g_kind, double g_p0, double g_p1, int32_t h_kind, double h_p0, double h_p1, void* grad,
                            void* z_half, void* xh, void* res, void* z_next, void* xg_next, void* A_xg_next,
                            double* scalars_out);
-
-/* ------------------------------------------------------------------ L-BFGS images ---- */
-/* Images of the stored pairs under a linear map A (m rows): with A s_i and A y_i kept next to s_i, y_i, the image of the
- * quasi-Newton direction, A (H v), follows from A v and the two-loop coefficients of the LAST pg_lbfgs_apply without
- * reading A:  A d = H0 (A v - sum alpha_i A y_i) + sum (alpha_i - beta_i) A s_i.  This removes the `mul!(Ad, A, d)` of
- * panoc.jl:178 (PANOC then reads A once per accepted step).  _enable(m) allocates the image slab; _update(As, Ay) must
- * follow every pg_lbfgs_update with the images of the same pair (ignored when the pair was rejected, <s, y> <= 0);
- * _apply(Ad, Av) must follow the pg_lbfgs_apply whose direction it maps. */
-pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m);
-pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay);
-pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av);
 
 #ifdef __cplusplus
 }

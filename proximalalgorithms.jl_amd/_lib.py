@@ -98,6 +98,7 @@ SIGNATURES = {
     "pg_mat_mul": [_vp, _vp, _vp],
     "pg_mat_mul_adjoint": [_vp, _vp, _vp],
     "pg_mat_fused_tn": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
+    "pg_mat_fused_tn_res": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_mat_fused_dys": [_vp, _vp, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _pf64],
     "pg_ls_create": [_vp, _vp, _vp, _f64, C.POINTER(_vp)],
@@ -144,6 +145,7 @@ SIGNATURES = {
     "pg_lbfgs_images_enable": [_vp, _i64],
     "pg_lbfgs_images_update": [_vp, _vp, _vp],
     "pg_lbfgs_images_apply": [_vp, _vp, _vp],
+    "pg_lbfgs_images_ready": [_vp, C.POINTER(_i32)],
 }
 _SPECIAL = {"pg_abi_version": ([], C.c_int32), "pg_last_error": ([], C.c_char_p), "pg_comm_available": ([], C.c_int32)}
 

@@ -803,7 +803,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
 // Az = A z_new (no b, no norm) from the columns while they are in registers.
 template <typename T>
 pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_kind, double g_p0, double g_p1, T* g_out,
-                         T* y, T* z_new, T* res, T* Az_out) {
+                         T* y, T* z_new, T* res, T* Az_out, bool image_of_res) {
   pg_ctx* c = A->ctx;
   if (pg_row_sharded(c) || pg_col_sharded(c) || !tn_supported<T>(A)) {
     pg_set_error("the single-sweep pass needs an unsharded operator with at most %d rows", (int)(1024 * (1024 / sizeof(T))));
@@ -826,6 +826,7 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
   const T gm = (T)gamma;
   a.gamma = gm;
   a.beta = T(0);
+  a.v_is_res = image_of_res ? 1 : 0;  // v = res = x - z  |  v = z
   a.p0 = g_kind == PG_G_NORML1 ? (T)(gm * (T)g_p0) : (T)g_p0;
   a.p1 = (T)g_p1;
   a.lam_ls = T(1);
@@ -1037,21 +1038,32 @@ pg_status pg_ls_destroy(pg_ls* f) {
   return PG_OK;
 }
 
-pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
-                          void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out) {
+static pg_status mat_fused_tn_any(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
+                                  void* At_r, void* y, void* z, void* res, void* Av, double* scalars_out, bool image_of_res) {
   PG_REQUIRE(A != nullptr, "matrix is null");
-  PG_REQUIRE(r && x && At_r && y && z && res && Az, "null vector");
+  PG_REQUIRE(r && x && At_r && y && z && res && Av, "null vector");
   PG_REQUIRE(g_kind == PG_G_ZERO || g_kind == PG_G_NORML1 || g_kind == PG_G_INDBOX, "unknown g_kind");
   PG_REQUIRE(gamma > 0, "gamma must be positive");
   PG_TRY(A->dtype == PG_F32 ? mat_fused_tn_t<float>(A, (const float*)r, (const float*)x, gamma, g_kind, g_p0, g_p1,
-                                                    (float*)At_r, (float*)y, (float*)z, (float*)res, (float*)Az)
+                                                    (float*)At_r, (float*)y, (float*)z, (float*)res, (float*)Av, image_of_res)
                             : mat_fused_tn_t<double>(A, (const double*)r, (const double*)x, gamma, g_kind, g_p0, g_p1,
-                                                     (double*)At_r, (double*)y, (double*)z, (double*)res, (double*)Az));
+                                                     (double*)At_r, (double*)y, (double*)z, (double*)res, (double*)Av,
+                                                     image_of_res));
   if (scalars_out) {
     PG_TRY(pg_read_scalars(A->ctx, PG_S_GZ, 4));
     for (int k = 0; k < 4; ++k) scalars_out[k] = A->ctx->hscal[PG_S_GZ + k];
   }
   return PG_OK;
+}
+
+pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
+                          void* At_r, void* y, void* z, void* res, void* Az, double* scalars_out) {
+  return mat_fused_tn_any(A, r, x, gamma, g_kind, g_p0, g_p1, At_r, y, z, res, Az, scalars_out, false);
+}
+
+pg_status pg_mat_fused_tn_res(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
+                              void* At_r, void* y, void* z, void* res, void* Ares, double* scalars_out) {
+  return mat_fused_tn_any(A, r, x, gamma, g_kind, g_p0, g_p1, At_r, y, z, res, Ares, scalars_out, true);
 }
 
 pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,

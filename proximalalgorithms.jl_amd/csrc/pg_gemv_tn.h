@@ -57,6 +57,10 @@ struct TNArgs {
   const T* x;      // [n]
   const T* z_old;  // [n] the prox output of the previous iteration (for v); may alias nothing written here
   T gamma, beta, p0, p1, lam_ls;  // p0 = gamma * lam (NormL1) | lo (IndBox) ; p1 = hi
+  // the vector whose image the sweep accumulates: v_j = z_j + beta (z_j - zold_j), the (extrapolated) next point
+  // (fast_forward_backward.jl:135) -- or, v_is_res != 0, v_j = res_j = x_j - z_j, the forward-backward residual itself
+  // (PANOC's image slab wants A res as a PRODUCT of the small vector, not as a difference of two large images)
+  int v_is_res = 0;
   int g_kind;
   // NormL1 with PER-ELEMENT weights (ProximalOperators.NormL1(lambda::AbstractArray)): lam_j = p0v[j] (p1v unused, gscale = 1);
   // IndBox with PER-ELEMENT bounds (ProximalOperators.IndBox(lo::AbstractArray, hi::AbstractArray)): lo_j = p0v[j], hi_j = p1v[j];
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
         } else
           zj = yj;
         const T rj = xj - zj;
-        vj = valid ? zj + a.beta * (zj - zo) : T(0);
+        vj = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);
         if ((int)threadIdx.x == c && valid) {
           a.g_out[j] = g;
           a.y[j] = yj;

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WPB * 64) void gemv_tnw_kernel(TNArgs<T> a) {
     } else
       zj = yj;
     const T rj = xj - zj;                                     // :120 / :142
-    const T vj = valid ? zj + a.beta * (zj - zo) : T(0);      // fast_forward_backward.jl:135 of the next iteration
+    const T vj = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);      // fast_forward_backward.jl:135 of the next iteration
     if (lead && valid) {
       a.g_out[j] = g;
       a.y[j] = yj;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnc_kernel(TNArgs<T> a) {
     } else
       zj = yj;
     const T rj = xj - zj;                                 // :120 / :142
-    const T vj = valid ? zj + a.beta * (zj - zo) : T(0);  // fast_forward_backward.jl:135 of the next iteration
+    const T vj = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);  // fast_forward_backward.jl:135 of the next iteration
     if (wave == 0 && lead && valid) {
       a.g_out[j] = g;
       a.y[j] = yj;
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
       } else
         zj = yj;
       const T rj = xj - zj;                             // :120 / :142
-      vj[c] = valid ? zj + a.beta * (zj - zo) : T(0);   // fast_forward_backward.jl:135 of the next iteration
+      vj[c] = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);   // fast_forward_backward.jl:135 of the next iteration
       if (member == 0 && (int)threadIdx.x == c && valid) {
         a.g_out[j] = g;
         a.y[j] = yj;

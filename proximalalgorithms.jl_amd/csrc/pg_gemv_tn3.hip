@@ -111,7 +111,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
       } else
         zj = yj;
       const T rj = xj - zj;                                   // :120 / :142
-      const T vj = valid ? zj + a.beta * (zj - zo) : T(0);    // fast_forward_backward.jl:135 of the next iteration
+      const T vj = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);    // fast_forward_backward.jl:135 of the next iteration
       if ((int)threadIdx.x == c && valid) {
         a.g_out[j] = g;
         a.y[j] = yj;

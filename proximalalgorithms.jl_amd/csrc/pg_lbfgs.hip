@@ -304,7 +304,11 @@ pg_status pg_lbfgs_images_enable(pg_lbfgs* L, int64_t m) {
 pg_status pg_lbfgs_images_update(pg_lbfgs* L, const void* As, const void* Ay) {
   PG_REQUIRE(L != nullptr && L->img_slab != nullptr, "images are not enabled");
   PG_REQUIRE(L->img_m == 0 || (As != nullptr && Ay != nullptr), "null vector");
-  if (!L->last_update_accepted || L->curridx == 0 || L->img_m == 0) return PG_OK;  // the pair was not stored (<s, y> <= 0)
+  if (!L->last_update_accepted || L->curridx == 0) return PG_OK;  // the pair was not stored (<s, y> <= 0)
+  if (L->img_m == 0) {
+    L->img_valid[L->curridx - 1] = true;
+    return PG_OK;
+  }
   const size_t nb = (size_t)L->img_m * pg_sizeof(L->dtype);
   char* base = (char*)L->img_slab;
   PG_HIP(hipMemcpyAsync(base + (size_t)(L->curridx - 1) * L->img_vb, As, nb, hipMemcpyDeviceToDevice, L->ctx->stream));
@@ -329,6 +333,20 @@ pg_status pg_lbfgs_images_apply(pg_lbfgs* L, void* Ad, const void* Av) {
     }
   }
   return L->dtype == PG_F32 ? lbfgs_images_apply_t<float>(L, Ad, Av) : lbfgs_images_apply_t<double>(L, Ad, Av);
+}
+
+pg_status pg_lbfgs_images_ready(pg_lbfgs* L, int32_t* ready_out) {
+  PG_REQUIRE(L != nullptr && ready_out != nullptr, "null argument");
+  *ready_out = 0;
+  if (L->img_slab == nullptr) return PG_OK;  // images were never enabled
+  int id = L->curridx;  // the slots the next apply walks (lbfgs.jl:72-83): newest -> oldest
+  for (int t = 0; t < L->currmem; ++t) {
+    if (id < 1 || id > L->M || !L->img_valid[id - 1]) return PG_OK;
+    id -= 1;
+    if (id == 0) id = L->M;
+  }
+  *ready_out = 1;
+  return PG_OK;
 }
 
 pg_status pg_lbfgs_apply(pg_lbfgs* L, void* d, const void* v) {

@@ -443,12 +443,13 @@ class HIPMatrix:
         call("pg_mat_mul", self._h, x.vp, out.vp)
         return out
 
-    def fused_tn(self, r, x, gamma, g, At_r, y, z, res, Az):
+    def fused_tn(self, r, x, gamma, g, At_r, y, z, res, Az, image_of_res=False):
         """ONE read of A: At_r = A' r ; y = x - gamma At_r ; z = prox_{gamma g}(y) ; res = x - z ; Az = A z
-        (pg_mat_fused_tn).  Returns (g(z), norm(res, Inf), dot(At_r, res), norm(res)^2)."""
+        (pg_mat_fused_tn) -- or, with image_of_res, Az = A res (pg_mat_fused_tn_res).  Returns (g(z), norm(res, Inf),
+        dot(At_r, res), norm(res)^2)."""
         p0, p1 = g.g_params()
         sc = (C.c_double * 4)()
-        call("pg_mat_fused_tn", self._h, r.vp, x.vp, float(gamma), g.g_kind, p0, p1, At_r.vp, y.vp, z.vp, res.vp, Az.vp, sc)
+        call("pg_mat_fused_tn_res" if image_of_res else "pg_mat_fused_tn", self._h, r.vp, x.vp, float(gamma), g.g_kind, p0, p1, At_r.vp, y.vp, z.vp, res.vp, Az.vp, sc)
         R = self.dtype.type
         return tuple(R(v) for v in sc)
 

@@ -120,7 +120,7 @@ function HIPMatrix(A::Matrix{T}; ctx = default_ctx()) where {T}
     M
 end
 
-# mul!(y, A, x) / mul!(g, A', r) on the device matrix (panoc.jl:178,184 ...)
+# mul!(y, A, x) / mul!(g, A', r) on the device matrix (panoc.jl:180,186 ...)
 function LinearAlgebra.mul!(y::HIPVector{T}, A::HIPMatrix{T}, x::HIPVector{T}) where {T}
     check(ccall((:pg_mat_mul, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), A.handle, x.ptr, y.ptr)); y
 end

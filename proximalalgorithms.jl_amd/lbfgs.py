@@ -35,6 +35,7 @@ class LBFGSOperator:
 
     # ---- images under a linear map (see include/proxgrad_hip.h: pg_lbfgs_images_*) ----
     def images_enable(self, m):
+        """keep A s_i, A y_i (m-vectors) next to the stored pairs: pg_lbfgs_images_enable"""
         call("pg_lbfgs_images_enable", self._h, int(m))
         return self
 
@@ -47,6 +48,12 @@ class LBFGSOperator:
         """to be called right after mul_(d, v): Ad = A d from A v"""
         call("pg_lbfgs_images_apply", self._h, Ad.vp, Av.vp)
         return Ad
+
+    def images_ready(self):
+        """whether every pair the next mul_ will use has its images (then images_mul_ is valid after it)"""
+        out = C.c_int32()
+        call("pg_lbfgs_images_ready", self._h, C.byref(out))
+        return bool(out.value)
 
     def __mul__(self, v):
         """L * v  lbfgs.jl:57-60"""

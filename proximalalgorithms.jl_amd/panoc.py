@@ -2,8 +2,9 @@
 
 The iteration body is the reference's, statement by statement, on device vectors; every array statement is a HIP
 kernel of libproxgrad_hip (the two GEMV orientations for `mul!` with A and A', the loss kernels, prox, AXPYs,
-reductions, and the device L-BFGS two-loop recursion).  At config-4 size (16384 x 10^6) an iteration is 2-4 passes
-over a 61 GiB matrix, so host-side sequencing of the ~40 small kernels is noise.
+reductions, and the device L-BFGS two-loop recursion).  At config-4 size (16384 x 10^6) an accepted iteration is ONE
+pass over a 61 GiB matrix (the single sweep; the `mul!(state.Ad, iter.A, state.d)` of panoc.jl:180 comes out of the
+L-BFGS operator's image slab without reading A), so host-side sequencing of the ~45 small kernels is noise.
 """
 import warnings
 
@@ -13,7 +14,7 @@ from . import _lib
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
 from .device import HIPMatrix, as_hipvector
-from .lbfgs import LBFGS
+from .lbfgs import LBFGS, LBFGSOperator
 from .operators import Zero, prox_, value_and_gradient
 
 
@@ -51,7 +52,8 @@ class PANOCIteration:
     """panoc.jl:39-52 (keyword constructor), Base.iterate :87-112 / :138-255."""
 
     def __init__(self, *, f=None, A=None, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
-                 minimum_gamma=1e-7, max_backtracks=20, directions=None, single_sweep=True):
+                 minimum_gamma=1e-7, max_backtracks=20, directions=None, single_sweep=True, images=True,
+                 refresh_every=0):
         self.f = f if f is not None else Zero()
         if A is None:
             A = _Identity()
@@ -73,6 +75,14 @@ class PANOCIteration:
         # in ONE read of A (pg_mat_fused_tn) when A is a device matrix and g one of the fused prox kinds
         self._fused_tn = bool(single_sweep) and isinstance(A, HIPMatrix) and hasattr(self.g, "g_kind") and \
             not (hasattr(self.g, "_scalar") and not self.g._scalar)
+        # `mul!(state.Ad, iter.A, state.d)` (:180) WITHOUT reading A when the directions are L-BFGS: d = -H res, and
+        # A res = A x - A z are m-vectors the iteration holds (the sweep leaves A z), so A d follows from the images A s_i,
+        # A y_i kept next to the stored pairs (pg_lbfgs_images_*); the images of a new pair are again differences of
+        # m-vectors.  What the recurrence costs: state.Ax (already a running sum in the reference, :181 / :187) now adds
+        # image-derived A d instead of products -- Float32 drift measured in tests/test_gpu_parity.py
+        # (test_panoc_image_recurrence_drift); refresh_every = K > 0 replaces every K-th update of A x by a product.
+        self._images = bool(images) and isinstance(A, HIPMatrix)
+        self.refresh_every = int(refresh_every)
 
     # mul! with A / A' (counted: each is one full read of A)
     def _mul(self, out, x):
@@ -106,6 +116,19 @@ class PANOCIteration:
         diff = grad_eps.axpby_(1.0, grad_eps, -1.0, grad_f_Ax)
         return R(self._mul_adj(None, diff).norm() / R(np.sqrt(x.n)))
 
+    def _take_Az(self, s, z, Az):
+        """`mul!(Az, A, z)` (fb_tools.jl:43, panoc.jl:210, zerofpr.jl:167) for the forward-backward point z: out of the last
+        sweep when that was taken at z -- it left A z itself, or A res = A (x - z), and then A z = A x - A res with the
+        very A x that f(A x) was evaluated at -- else a product.  Returns whether the sweep served."""
+        if getattr(s, "Az_next_valid", False) and getattr(s, "Az_next_of", None) is z:
+            if getattr(s, "Az_next_is_res", False):
+                Az.axpby_(1.0, s.Ax, -1.0, s.Az_next)
+            else:
+                Az.copy_from(s.Az_next)
+            return True
+        self._mul(Az, z)
+        return False
+
     def _backtrack_stepsize(self, s, z, g_z, Az, grad_f_Az):
         """backtrack_stepsize!  fb_tools.jl:24-63 with the linear map A and alpha = iter.alpha; z / Az / grad_f_Az
         are the forward-backward point and its images (state.z | state.xbar ...).  Returns (gamma, g_z, f_Az, f_Az_upp)."""
@@ -113,11 +136,7 @@ class PANOCIteration:
         eps = R(np.finfo(R).eps)
         gamma, reduce_gamma = R(s.gamma), R(0.5)
         f_Az_upp = self._model(s, gamma)  # :42
-        if getattr(s, "Az_next_valid", False) and getattr(s, "Az_next_of", None) is z:
-            Az.copy_from(s.Az_next)  # :43 -- the last sweep already formed A z
-            s.Az_next_valid = False
-        else:
-            self._mul(Az, z)  # :43
+        self._take_Az(s, z, Az)  # :43
         f_Az, _ = value_and_gradient_into(self.f, Az, grad_f_Az)  # :44 (grad kept: :56-58)
         tol = R(10) * eps * (R(1) + abs(f_Az))
         while f_Az > f_Az_upp + tol and gamma >= self.minimum_gamma:  # :46
@@ -157,32 +176,58 @@ class PANOCIteration:
             setattr(s, name, s.x.similar())
         for name in ("Ad", "Ax_d", "grad_f_Ax_d", "Az", "grad_f_Az", "Az_next"):
             setattr(s, name, s.Ax.similar())
-        s.Az_next_valid = False
+        s.Az_next_valid, s.Az_next_of, s.Az_next_is_res = False, None, False
         s.f_Ax_d = R(0)
         s.res_inf = None
+        self._images_init(s)
         return s
+
+    def _images_init(self, s):
+        """the image slab of the L-BFGS operator and the m-vectors the image recurrences need"""
+        s.img = self._images and isinstance(s.H, LBFGSOperator)
+        s.img_steps = 0
+        if s.img:
+            s.H.images_enable(s.Ax.n)
+            for name in ("Ares", "As", "Ay"):
+                setattr(s, name, s.Ax.similar())
 
     def _step(self, s):
         R = s.x.dtype.type
         inf = R(np.inf)
         f_Az, a, b, c = inf, inf, inf, inf  # :139
-        if self.adaptive:  # :141-161
+        have_Az = False  # state.Az holds A z for the current z
+        # the last sweep left A res for this very (x, z) pair (the image slab's input, below)
+        sweep_Ares = s.img and s.Az_next_valid and s.Az_next_of is s.z and s.Az_next_is_res
+        if self.adaptive:  # :141-163
             gamma_prev = s.gamma
             s.gamma, s.g_z, f_Az, f_Az_upp = self._backtrack_stepsize(s, s.z, s.g_z, s.Az, s.grad_f_Az)
+            have_Az = True
             if s.gamma != gamma_prev and s.H is not None:
                 s.H.reset_()
         else:
-            f_Az_upp = self._model(s)  # :163
-        FBE_x = R(f_Az_upp + s.g_z)  # :167
-        if s.H is not None:  # :170 (set_next_direction! :114-117)
+            f_Az_upp = self._model(s)  # :165
+            if s.Az_next_valid and s.Az_next_of is s.z:
+                have_Az = self._take_Az(s, s.z, s.Az)  # the last sweep serves :209-211 (and the images below)
+        FBE_x = R(f_Az_upp + s.g_z)  # :169
+        use_img = s.img = s.img and self._fused_tn
+        if s.img:
+            if not have_Az:
+                self._mul(s.Az, s.z)  # (first iteration with a fixed step) one read here instead of the A d below
+                have_Az = True
+            if sweep_Ares and s.Az_next_valid:  # (a rejected gamma recomputes z and invalidates the sweep's output)
+                s.Ares.copy_from(s.Az_next)  # A res as a product of the residual itself
+            else:
+                s.Ares.axpby_(1.0, s.Ax, -1.0, s.Az)  # A res = A x - A z
+            use_img = s.H.images_ready()
+        if s.H is not None:  # :172 (set_next_direction! :114-117)
             s.H.mul_(s.d, s.res)
             s.d.axpby_(-1.0, s.d)
         else:
             s.d.axpby_(-1.0, s.res)
-        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :193
-        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))  # :194
-        threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :195 (the residual of the CURRENT point)
-        # :173-174, :186-191 -- the reference's copyto! statements are reference swaps here: x_prev / res_prev take the
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :195
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))  # :196
+        threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :197 (the residual of the CURRENT point)
+        # :175-176, :188-192 -- the reference's copyto! statements are reference swaps here: x_prev / res_prev take the
         # current buffers, the trial point x + d (tau = 1) is formed directly in x / Ax / grad_f_Ax / At_grad_f_Ax, and
         # the separate copies the line search interpolates from (x_d, Ax_d, grad_f_Ax_d, At_grad_f_Ax_d) are only
         # materialised if a backtrack actually happens (_materialize_trial).  Same values in every named vector whenever
@@ -190,18 +235,27 @@ class PANOCIteration:
         s.x_prev, s.x = s.x, s.x_prev
         s.res_prev, s.res = s.res, s.res_prev
         s.res_stats = s.res_inf = None
-        s.tau = R(1)  # :177
-        self._mul(s.Ad, s.d)  # :178
-        s.x.axpby_(1.0, s.x_prev, 1.0, s.d)  # :180, :186
-        s.Ax.axpby_(1.0, s.Ax, 1.0, s.Ad)  # :181, :187
-        s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :182-183, :188-189
+        s.tau = R(1)  # :179
+        if use_img:  # :180 without reading A: d = -(H res)  =>  A d = -(image of A res under the two-loop coefficients)
+            s.H.images_mul_(s.Ad, s.Ares)
+            s.Ad.axpby_(-1.0, s.Ad)
+        else:
+            self._mul(s.Ad, s.d)  # :180
+        s.x.axpby_(1.0, s.x_prev, 1.0, s.d)  # :182, :188
+        s.img_steps += 1
+        if use_img and self.refresh_every > 0 and s.img_steps % self.refresh_every == 0:
+            self._mul(s.Ax, s.x)  # the running sum A x restarted from a product
+        else:
+            s.Ax.axpby_(1.0, s.Ax, 1.0, s.Ad)  # :183, :189
+        s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :184-185, :190, :193
         s.f_Ax_d = s.f_Ax
-        s.z_curr, s.z = s.z, s.z_curr  # :190 (z is rewritten below)
+        s.z_curr, s.z = s.z, s.z_curr  # :192 (z is rewritten below)
         fused = False
         if self._fused_tn:
-            # :184 and :197-199 in one read of A, which also leaves A z for the next iteration's line search
+            # :186 and :199-201 in one read of A, which also leaves A z for the next iteration's line search
             try:
-                sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res, s.Az_next)
+                sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res, s.Az_next,
+                                     image_of_res=s.img)  # with the image slab: A res in place of A z (_take_Az)
                 s.g_z = sc[0]
                 fused = True
             except ProxGradError as e:
@@ -210,27 +264,28 @@ class PANOCIteration:
                 self._fused_tn = False  # shape outside the kernel's range: separate sweeps from now on
         if fused:
             self.counters["A_passes"] += 1
-            s.Az_next_valid, s.Az_next_of = True, s.z
+            s.Az_next_valid, s.Az_next_of, s.Az_next_is_res = True, s.z, s.img
             s.res_stats, s.res_inf = (sc[1], sc[2], sc[3]), sc[1]  # norm(res, Inf), <At_grad, res>, ||res||^2 of this pair
         else:
-            self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :184, :189
-            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :197
-            s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :198
-            s.res.axpby_(1.0, s.x, -1.0, s.z)  # :199
-        FBE_x_new = R(self._model(s) + s.g_z)  # :200
+            self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :186, :191
+            s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :199
+            s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :200
+            s.res.axpby_(1.0, s.x, -1.0, s.z)  # :201
+        FBE_x_new = R(self._model(s) + s.g_z)  # :202
         quad = getattr(self.f, "is_generalized_quadratic", False)
-        for k in range(1, self.max_backtracks + 1):  # :202-250
+        for k in range(1, self.max_backtracks + 1):  # :204-250
             if FBE_x_new <= threshold:
                 break
             if k == 1:
                 self._materialize_trial(s)
             s.Az_next_valid = False  # z is about to be recomputed
-            if np.isinf(f_Az):  # :207-209
+            if np.isinf(f_Az) and not have_Az:  # :209-211
                 self._mul(s.Az, s.z_curr)
-            s.tau = R(0) if k >= self.max_backtracks else R(s.tau / R(2))  # :211
-            s.x.axpby_(s.tau, s.x_d, R(1) - s.tau, s.z_curr)  # :212
-            s.Ax.axpby_(s.tau, s.Ax_d, R(1) - s.tau, s.Az)  # :213
-            if quad:  # :215-237
+                have_Az = True
+            s.tau = R(0) if k >= self.max_backtracks else R(s.tau / R(2))  # :213
+            s.x.axpby_(s.tau, s.x_d, R(1) - s.tau, s.z_curr)  # :214
+            s.Ax.axpby_(s.tau, s.Ax_d, R(1) - s.tau, s.Az)  # :215
+            if quad:  # :217-237
                 if np.isinf(f_Az):
                     f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)
                 if np.isinf(c):
@@ -253,11 +308,19 @@ class PANOCIteration:
             s.x_prev.axpby_(1.0, s.x, -1.0, s.x_prev)
             s.res_prev.axpby_(1.0, s.res, -1.0, s.res_prev)
             s.H.update_(s.x_prev, s.res_prev)
+            if s.img:  # the images of the pair, from m-vectors: A s = tau A d + (1 - tau) A (z_curr - x_prev) (:214),
+                # A y = A res+ - A res_prev, both residual images being products of the residuals themselves
+                if not (s.Az_next_valid and s.Az_next_of is s.z and s.Az_next_is_res):  # z was recomputed by the tau search
+                    self._mul(s.Az_next, s.res)  # (with an adaptive step this also serves the next line search, _take_Az)
+                    s.Az_next_valid, s.Az_next_of, s.Az_next_is_res = True, s.z, True
+                s.As.axpby_(s.tau, s.Ad, -(R(1) - s.tau), s.Ares)
+                s.Ay.axpby_(1.0, s.Az_next, -1.0, s.Ares)
+                s.H.images_update_(s.As, s.Ay)
         return s
 
     @staticmethod
     def _materialize_trial(s):
-        """the tau = 1 endpoint of the line search as separate vectors (panoc.jl:180-184), made only when a backtrack
+        """the tau = 1 endpoint of the line search as separate vectors (panoc.jl:182-186), made only when a backtrack
         is about to overwrite x / Ax / grad_f_Ax / At_grad_f_Ax"""
         s.x_d.copy_from(s.x)
         s.Ax_d.copy_from(s.Ax)

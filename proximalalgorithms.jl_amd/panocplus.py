@@ -6,6 +6,7 @@ import numpy as np
 from . import _lib
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
+from .lbfgs import LBFGSOperator
 from .operators import prox_
 from .panoc import PANOCIteration, value_and_gradient_into
 
@@ -47,6 +48,15 @@ class PANOCplusIteration(PANOCIteration):
             self._mul(s.Az, s.z)
             value_and_gradient_into(self.f, s.Az, s.grad_f_Az)
         self._mul_adj(s.At_grad_f_Az, s.grad_f_Az)  # :127
+        # the image slab (panoc.py): x = x_prev + d with d = -H res_prev, so `mul!(state.Ax, iter.A, state.x)` (:199)
+        # becomes A x_prev + (image of A (-res_prev)), A res_prev = A x_prev - A z_prev being held (:199, :210)
+        s.img = self._images and isinstance(s.H, LBFGSOperator)
+        s.img_steps = 0
+        if s.img:
+            s.H.images_enable(s.Ax.n)
+            for name in ("Ax_prev", "Ad", "Ares", "Ares_prev", "As", "Ay"):
+                setattr(s, name, s.Ax.similar())
+            s.Ares.axpby_(1.0, s.Ax, -1.0, s.Az)  # A res at the initial point
         return s
 
     def _step(self, s):
@@ -59,15 +69,23 @@ class PANOCplusIteration(PANOCIteration):
         s.x_prev, s.x = s.x, s.x_prev
         s.res_prev, s.res = s.res, s.res_prev
         s.res_stats = None
+        if s.img:
+            s.Ax_prev, s.Ax = s.Ax, s.Ax_prev
+            s.Ares_prev, s.Ares = s.Ares, s.Ares_prev  # A res_prev: the last sweep's product (state.Ares is rewritten below)
         tau_backtracks = 0
         can_update_direction = True
-        while True:  # :183-235
+        use_img = False
+        while True:  # :183-234
             if can_update_direction:
+                use_img = s.img and s.H.images_ready()
                 if s.H is not None:  # set_next_direction! :130-138
                     s.H.mul_(s.d, s.res_prev)
                     s.d.axpby_(-1.0, s.d)
                 else:
                     s.d.axpby_(-1.0, s.res_prev)
+                if use_img:  # A d without reading A: d = -(H res_prev)
+                    s.H.images_mul_(s.Ad, s.Ares_prev)
+                    s.Ad.axpby_(-1.0, s.Ad)
                 s.tau = R(1)  # :189
                 s.x.axpby_(1.0, s.x_prev, 1.0, s.d)  # :190
                 tau_backtracks = 0
@@ -75,12 +93,22 @@ class PANOCplusIteration(PANOCIteration):
                 s.x.axpby_(1.0, s.x_prev, -(R(1) - s.tau), s.res_prev)
                 s.x.axpby_(1.0, s.x, s.tau, s.d)
                 tau_backtracks += 1
-            self._mul(s.Ax, s.x)  # :199
+            s.img_steps += 1
+            if use_img and not (self.refresh_every > 0 and s.img_steps % self.refresh_every == 0):
+                # :199 from m-vectors: A x = A x_prev - (1 - tau) A res_prev + tau A d
+                s.Ax.axpby_(1.0, s.Ax_prev, s.tau, s.Ad)
+                if s.tau != R(1):
+                    s.Ax.axpby_(1.0, s.Ax, -(R(1) - s.tau), s.Ares_prev)
+            else:
+                self._mul(s.Ax, s.x)  # :199
             s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :200-201
             fused = False
             if self._fused_tn:  # :202-206 and :210 in one read of A (pg_mat_fused_tn)
                 try:
-                    sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res, s.Az)
+                    sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res,
+                                         s.Ares if s.img else s.Az, image_of_res=s.img)
+                    if s.img:  # :210 as A x - A res, A res being the sweep's product of the residual itself
+                        s.Az.axpby_(1.0, s.Ax, -1.0, s.Ares)
                     s.g_z = sc[0]
                     s.res_stats = (sc[1], sc[2], sc[3])  # the sweep's own reductions of this (At_grad, res) pair
                     fused = True
@@ -98,6 +126,8 @@ class PANOCplusIteration(PANOCIteration):
             f_Az_upp = self._model(s)  # :208
             if not fused:
                 self._mul(s.Az, s.z)  # :210
+                if s.img:
+                    s.Ares.axpby_(1.0, s.Ax, -1.0, s.Az)
             f_Az, _ = value_and_gradient_into(self.f, s.Az, s.grad_f_Az)  # :211-212
             if self.gamma is None or self.adaptive:  # :213-224
                 tol2 = R(10) * R(np.finfo(R).eps) * (R(1) + abs(f_Az))
@@ -119,6 +149,13 @@ class PANOCplusIteration(PANOCIteration):
             s.x_prev.axpby_(1.0, s.x, -1.0, s.x_prev)
             s.res_prev.axpby_(1.0, s.res, -1.0, s.res_prev)
             s.H.update_(s.x_prev, s.res_prev)
+            if s.img:  # A s = tau A d - (1 - tau) A res_prev (:193-195), A y = A res - A res_prev
+                if use_img:
+                    s.As.axpby_(s.tau, s.Ad, -(R(1) - s.tau), s.Ares_prev)
+                else:
+                    s.As.axpby_(1.0, s.Ax, -1.0, s.Ax_prev)
+                s.Ay.axpby_(1.0, s.Ares, -1.0, s.Ares_prev)
+                s.H.images_update_(s.As, s.Ay)
         return s
 
 

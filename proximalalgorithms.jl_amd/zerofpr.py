@@ -6,6 +6,7 @@ import numpy as np
 from . import _lib
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
+from .lbfgs import LBFGSOperator
 from .operators import prox_
 from .panoc import PANOCIteration, value_and_gradient_into
 
@@ -41,53 +42,89 @@ class ZeroFPRIteration(PANOCIteration):
             setattr(s, name, s.x.similar())
         for name in ("Axbar", "grad_f_Axbar", "Ad", "Az_next"):
             setattr(s, name, s.Ax.similar())
-        s.Az_next_valid, s.Az_next_of = False, None
+        s.Az_next_valid, s.Az_next_of, s.Az_next_is_res = False, None, False
         s.is_prev_set = False
+        s.img = self._images and self._fused_tn and isinstance(s.H, LBFGSOperator)
+        s.img_prev_set = False
+        if s.img:  # the image slab (panoc.py): A d of :194 without reading A
+            s.H.images_enable(s.Ax.n)
+            for name in ("Ares", "Axbar_prev", "Ares_prev"):
+                setattr(s, name, s.Ax.similar())
         return s
 
     def _step(self, s):
         R = s.x.dtype.type
-        if self.adaptive:  # :143-164
+        if self.adaptive:  # :143-165
             gamma_prev = s.gamma
             s.gamma, s.g_xbar, f_Axbar, f_Axbar_upp = self._backtrack_stepsize(s, s.xbar, s.g_xbar, s.Axbar, s.grad_f_Axbar)
             if s.gamma != gamma_prev and s.H is not None:
                 s.H.reset_()
-        else:  # :165-170
+        else:  # :166-171
             if s.Az_next_valid and s.Az_next_of is s.xbar:
                 s.Axbar.copy_from(s.Az_next)  # the last sweep of the previous iteration already formed A xbar
                 s.Az_next_valid = False
             else:
-                self._mul(s.Axbar, s.xbar)
+                self._mul(s.Axbar, s.xbar)  # :167
             f_Axbar, _ = value_and_gradient_into(self.f, s.Axbar, s.grad_f_Axbar)
             f_Axbar_upp = self._model(s)
-        FBE_x = R(f_Axbar_upp + s.g_xbar)  # :173
-        self._mul_adj(s.At_grad_f_Axbar, s.grad_f_Axbar)  # :176
-        s.y.axpby_(1.0, s.xbar, -s.gamma, s.At_grad_f_Axbar)  # :177
-        prox_(s.xbarbar, self.g, s.y, s.gamma)  # :178
-        s.res_xbar.axpby_(1.0, s.xbar, -1.0, s.xbarbar)  # :179
-        if s.is_prev_set and s.H is not None:  # :181-183 (update_direction_state! :118-126)
+        FBE_x = R(f_Axbar_upp + s.g_xbar)  # :174
+        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :196
+        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
+        threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :198 (moved up: state.res / its reductions are not touched before)
+        # :177-180.  With the image slab on, as ONE sweep that also leaves A res_xbar = A (xbar - xbarbar)
+        # (pg_mat_fused_tn_res): the image of the direction (:194) and the images of the next pair (:118-126) then come
+        # from products of the residuals themselves and from A xbar, a product as well (the second sweep leaves it) --
+        # nothing here is a running sum, so nothing drifts.
+        s.img = s.img and self._fused_tn
+        fused_res = False
+        if s.img:
+            try:
+                self.A.fused_tn(s.grad_f_Axbar, s.xbar, s.gamma, self.g, s.At_grad_f_Axbar, s.y, s.xbarbar, s.res_xbar, s.Ares,
+                                image_of_res=True)
+                self.counters["A_passes"] += 1
+                fused_res = True
+            except ProxGradError as e:
+                if e.code != _lib.PG_ERR_UNSUPPORTED:
+                    raise
+                self._fused_tn = s.img = False
+        if not fused_res:
+            self._mul_adj(s.At_grad_f_Axbar, s.grad_f_Axbar)  # :177
+            s.y.axpby_(1.0, s.xbar, -s.gamma, s.At_grad_f_Axbar)  # :178
+            prox_(s.xbarbar, self.g, s.y, s.gamma)  # :179
+            s.res_xbar.axpby_(1.0, s.xbar, -1.0, s.xbarbar)  # :180
+        if s.is_prev_set and s.H is not None:  # :182-184 (update_direction_state! :118-126)
             s.xbar_prev.axpby_(1.0, s.xbar, -1.0, s.xbar_prev)
             s.res_xbar_prev.axpby_(1.0, s.res_xbar, -1.0, s.res_xbar_prev)
             s.H.update_(s.xbar_prev, s.res_xbar_prev)
-        s.xbar_prev.copy_from(s.xbar)  # :185-187
+            if fused_res and s.img_prev_set:
+                s.Axbar_prev.axpby_(1.0, s.Axbar, -1.0, s.Axbar_prev)
+                s.Ares_prev.axpby_(1.0, s.Ares, -1.0, s.Ares_prev)
+                s.H.images_update_(s.Axbar_prev, s.Ares_prev)
+        s.xbar_prev.copy_from(s.xbar)  # :186-188
         s.res_xbar_prev.copy_from(s.res_xbar)
         s.is_prev_set = True
-        if s.H is not None:  # :189 (set_next_direction! :113-116)
+        s.img_prev_set = fused_res
+        if fused_res:
+            s.Axbar_prev.copy_from(s.Axbar)
+            s.Ares_prev.copy_from(s.Ares)
+        use_img = fused_res and s.H.images_ready()
+        if s.H is not None:  # :190 (set_next_direction! :113-116)
             s.H.mul_(s.d, s.res_xbar)
             s.d.axpby_(-1.0, s.d)
         else:
             s.d.axpby_(-1.0, s.res)
-        s.tau = R(1)  # :192
-        self._mul(s.Ad, s.d)  # :193
-        sigma = R(self.beta * (R(0.5) / s.gamma) * (R(1) - self.alpha))  # :195
-        tol = R(10) * R(np.finfo(R).eps) * (R(1) + abs(FBE_x))
-        threshold = R(FBE_x - sigma * self._res_sq(s) + tol)  # :197
-        for k in range(1, self.max_backtracks + 1):  # :199-217
-            s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :200
-            s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :201
-            s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :203-204
+        s.tau = R(1)  # :193
+        if use_img:  # :194 without reading A: d = -(H res_xbar)
+            s.H.images_mul_(s.Ad, s.Ares)
+            s.Ad.axpby_(-1.0, s.Ad)
+        else:
+            self._mul(s.Ad, s.d)  # :194
+        for k in range(1, self.max_backtracks + 1):  # :200-217
+            s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :201
+            s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :202
+            s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :204-205
             fused = False
-            if self._fused_tn:  # :205-208 and the A xbar of the next iteration (:43 / :166) in one read of A
+            if self._fused_tn:  # :206-209 and the A xbar of the next iteration (fb_tools.jl:43 / :167) in one read of A
                 try:
                     sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)
                     s.g_xbar = sc[0]
@@ -102,15 +139,15 @@ class ZeroFPRIteration(PANOCIteration):
                 s.res_stats, s.res_inf = (sc[1], sc[2], sc[3]), sc[1]  # the sweep's own reductions of (At_grad, res)
             else:
                 s.res_stats = s.res_inf = None
-                self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :205
-                s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :206
-                s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :207
-                s.res.axpby_(1.0, s.x, -1.0, s.xbar)  # :208
+                self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :206
+                s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :207
+                s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :208
+                s.res.axpby_(1.0, s.x, -1.0, s.xbar)  # :209
                 s.Az_next_valid = False
-            FBE_x = R(self._model(s) + s.g_xbar)  # :209
+            FBE_x = R(self._model(s) + s.g_xbar)  # :210
             if FBE_x <= threshold:
                 break
-            s.tau = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))  # :215
+            s.tau = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))  # :216
         return s
 
 
