@@ -405,6 +405,16 @@ pg_status pg_iter_run_small(pg_iter* it, int64_t k_start, int64_t maxit, double 
 pg_status pg_iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol, int32_t blocks, int64_t* k_out,
                            pg_iter_scalars* out);
 pg_status pg_iter_state_view(pg_iter* it, pg_iter_state* out);
+/* Checkpoint / resume.  In the reference `iterate(iter, saved_state)` continues a solve from any saved state, because the
+ * state struct holds all algorithm memory (forward_backward.jl:52-63; fast_forward_backward.jl:60-71 with the mutable
+ * AdaptiveNesterovSequence, nesterov.jl:56-60).  _download writes that memory -- state vectors, residual vectors, gamma,
+ * f_x, g_z, the sequence state (stepsize, theta, t, k), and the speculative first half of the next single-sweep iteration
+ * -- into ONE host blob of pg_iter_state_bytes bytes (syncs); _upload puts a blob into an iterator created with the same
+ * options over an equal f (pg_iter_init not needed), after which pg_iter_step continues bit-identically to the solve the
+ * blob was taken from.  Host-drawn extrapolation sequences (PG_SEQ_HOST) live in the caller and are refused. */
+pg_status pg_iter_state_bytes(pg_iter* it, int64_t* bytes_out);
+pg_status pg_iter_state_download(pg_iter* it, void* host_blob, int64_t bytes);
+pg_status pg_iter_state_upload(pg_iter* it, const void* host_blob, int64_t bytes, pg_iter_scalars* out);
 
 /* ------------------------------------------------------------------ L-BFGS (config 4) --- */
 /* LBFGSOperator{M}: src/accel/lbfgs.jl:5-95 */

@@ -4,7 +4,7 @@
  * proxgrad_hip.h is the drop-in boundary for the ForwardBackward / FastForwardBackward path and its "next" rows
  * (DouglasRachford, PANOC / ZeroFPR / PANOCplus with L-BFGS, the device-resident loops).  What is declared here serves
  * other algorithms of the reference on the same kernels -- Davis-Yin and AFBA bodies replayed as graphs, the Broyden
- * operator -- and is kept apart so that the boundary header matches section 8(b)'s table.
+ * operator, the fault-injection hook of the tests -- and is kept apart so that the boundary header matches section 8(b)'s table.
  * Same conventions as proxgrad_hip.h.
  */
 #ifndef PROXGRAD_HIP_EXT_H
@@ -46,6 +46,13 @@ pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void*
                            int32_t g_kind, double g_p0, double g_p1, int32_t h_kind, double h_p0, double h_p1, void* grad,
                            void* z_half, void* xh, void* res, void* z_next, void* xg_next, void* A_xg_next,
                            double* scalars_out);
+
+/* ------------------------------------------------------------------ fault injection (tests) ---- */
+/* The kth_launch-th long-column (team) sweep launched on this context from now on (1-based; 0 switches the hook off) fails:
+ * kind 0 -- one workgroup of one team is never started, its team-mates run into their bounded wait and the step is redone with
+ * two sweeps (PG_FLAG_SWEEP_FALLBACK); kind 1 -- the launch is refused (PG_ERR_UNSUPPORTED), as a cooperative launch that
+ * does not fit next to other work would be.  Nothing in the library reads the environment for this. */
+pg_status pg_ctx_test_team_fault(pg_ctx* ctx, int32_t kth_launch, int32_t kind);
 
 #ifdef __cplusplus
 }

@@ -39,15 +39,19 @@ class FusedIteration:
         self.dtype = f.A.dtype
         self._g_vectors = None
 
-    def init(self, x0):
+    def _bind_g_vectors(self, like):
+        """IndBox with per-element bounds: (lo, hi); NormL1 with per-element weights: (lam, None) --
+        pg_iter_set_g_vectors, once; `like` is any device vector of the problem's element type and context"""
         if hasattr(self.g, "g_vectors") and self._g_vectors is None:
-            # IndBox with per-element bounds: (lo, hi); NormL1 with per-element weights: (lam, None)
-            v0, v1 = self.g.g_vectors(x0)
+            v0, v1 = self.g.g_vectors(like)
             if v0 is not None:
                 if v0.n != self.n or (v1 is not None and v1.n != self.n):
                     raise ValueError("per-element parameters of g must have one entry per variable")
                 call("pg_iter_set_g_vectors", self._h, v0.vp, v1.vp if v1 is not None else None)
                 self._g_vectors = (v0, v1)  # keep the device vectors alive as long as the iterator
+
+    def init(self, x0):
+        self._bind_g_vectors(x0)
         call("pg_iter_init", self._h, x0.vp, C.byref(self.scalars))
         return self.scalars
 
@@ -81,6 +85,22 @@ class FusedIteration:
         call("pg_iter_run_coop", self._h, int(k_start), int(maxit), float(tol), int(blocks), C.byref(k),
              C.byref(self.scalars))
         return k.value, self.scalars
+
+    def state_download(self):
+        """all algorithm memory of the iterator as one host blob (pg_iter_state_download): what `iterate(iter, saved_state)`
+        resumes from in the reference (fast_forward_backward.jl:60-71)"""
+        nbytes = C.c_int64()
+        call("pg_iter_state_bytes", self._h, C.byref(nbytes))
+        blob = (C.c_char * nbytes.value)()
+        call("pg_iter_state_download", self._h, blob, nbytes.value)
+        return bytes(blob)
+
+    def state_upload(self, blob):
+        """put a saved state into this (freshly created, same options) iterator; the next step() continues the saved solve"""
+        self._bind_g_vectors(HIPVector.empty(self.n, self.dtype, self.ctx))
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        call("pg_iter_state_upload", self._h, buf, len(blob), C.byref(self.scalars))
+        return self.scalars
 
     def view(self):
         st = _lib.pg_iter_state()

@@ -78,6 +78,7 @@ SIGNATURES = {
     "pg_ctx_profile_enable": [_vp, _i32],
     "pg_ctx_profile_select": [_vp, C.c_uint32],
     "pg_ctx_set_column_sharding": [_vp, _i32, _i32],
+    "pg_ctx_test_team_fault": [_vp, _i32, _i32],
     "pg_ctx_profile_reset": [_vp],
     "pg_ctx_profile_read": [_vp, _i32, C.POINTER(_i64), _pf64],
     "pg_malloc": [_vp, _sz, C.POINTER(_vp)],
@@ -137,6 +138,9 @@ SIGNATURES = {
     "pg_iter_run_small": [_vp, _i64, _i64, _f64, C.POINTER(_i64), C.POINTER(pg_iter_scalars)],
     "pg_iter_run_coop": [_vp, _i64, _i64, _f64, _i32, C.POINTER(_i64), C.POINTER(pg_iter_scalars)],
     "pg_iter_state_view": [_vp, C.POINTER(pg_iter_state)],
+    "pg_iter_state_bytes": [_vp, C.POINTER(_i64)],
+    "pg_iter_state_download": [_vp, _vp, _i64],
+    "pg_iter_state_upload": [_vp, _vp, _i64, C.POINTER(pg_iter_scalars)],
     "pg_lbfgs_create": [_vp, _i32, _i32, _i64, C.POINTER(_vp)],
     "pg_lbfgs_destroy": [_vp],
     "pg_lbfgs_update": [_vp, _vp, _vp],

@@ -102,12 +102,15 @@ class IterativeAlgorithm:
                     # A team sweep lost inside a batch (PG_ERR_TIMEOUT, seen at the batch's one read-back) cannot be redone:
                     # the iterations behind it are already enqueued.  Start over from x0 with the per-iteration loop, which
                     # redoes a lost sweep with two sweeps and carries on (pg_iter_run; csrc/pg_iter.hip).
-                    if e.code != _lib.PG_ERR_TIMEOUT:
+                    # (PG_ERR_UNSUPPORTED at that read-back: with column shards some rank's sweep was refused at launch; every
+                    # rank sees it in the same batch and has left the single-sweep mode.)
+                    if e.code not in (_lib.PG_ERR_TIMEOUT, _lib.PG_ERR_UNSUPPORTED):
                         raise
                     import warnings
 
-                    warnings.warn("a long-column sweep timed out inside a batch of %d iterations; the solve restarts with "
-                                  "one synchronisation per iteration" % check_every)
+                    warnings.warn("a long-column sweep %s inside a batch of %d iterations; the solve restarts with one "
+                                  "synchronisation per iteration"
+                                  % ("timed out" if e.code == _lib.PG_ERR_TIMEOUT else "was refused", check_every))
                     it.counters["sweep_fallbacks"] = it.counters.get("sweep_fallbacks", 0) + 1
                     fused.init(it.x0)  # (the iteration holds x0 as a device vector and never writes it)
                     k, _ = fused.run(1, self.maxit, tol)

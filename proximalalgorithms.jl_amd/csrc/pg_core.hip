@@ -54,7 +54,6 @@ pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out) {
   }
   PG_HIP(hipMemset(c->red_counter, 0, sizeof(unsigned) * 8));
   memset(c->hscal, 0, sizeof(double) * PG_S_COUNT);
-  if (const char* v = getenv("PG_TEST_TEAM_FAULT")) c->test_team_fault = atoi(v);
   if (const char* v = getenv("PG_TN_TEAM_PLAIN")) c->team_plain_launch = atoi(v) != 0;
   PG_HIP(hipDeviceSynchronize());
   *out = c;
@@ -170,6 +169,14 @@ pg_status pg_graph_destroy(pg_graph* g) {
 pg_status pg_ctx_profile_enable(pg_ctx* c, int32_t enable) {
   PG_REQUIRE(c != nullptr, "ctx is null");
   c->profiling = enable != 0;
+  return PG_OK;
+}
+
+pg_status pg_ctx_test_team_fault(pg_ctx* c, int32_t kth_launch, int32_t kind) {
+  PG_REQUIRE(c != nullptr && kth_launch >= 0 && (kind == 0 || kind == 1), "bad argument");
+  c->test_team_fault = kth_launch;
+  c->test_team_fault_kind = kind;
+  c->team_launches = 0;
   return PG_OK;
 }
 
@@ -316,6 +323,11 @@ pg_status pg_read_scalars(pg_ctx* c, int first, int count) {
   (void)count;
   if (c->capturing) return PG_OK;  // recorded, not run: the caller's scalars are placeholders
   PG_HIP(hipStreamSynchronize(c->stream));
+  if (c->hscal[PG_S_TEAMERR] == 2.0) {  // column shards: some rank's sweep was refused at launch (pg_gemv.hip)
+    c->hscal[PG_S_TEAMERR] = 0.0;
+    pg_set_error("single-sweep pass: the sweep was refused at launch on one of the column shards; every rank leaves the single-sweep mode");
+    return PG_ERR_UNSUPPORTED;
+  }
   if (c->hscal[PG_S_TEAMERR] != 0.0) {  // a workgroup team of the long-column sweep gave up waiting (pg_gemv_tn2.hip)
     c->hscal[PG_S_TEAMERR] = 0.0;
     c->team_timeout = true;

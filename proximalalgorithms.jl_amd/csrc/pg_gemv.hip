@@ -491,7 +491,7 @@ bool tn_supported(const pg_mat* A) {
 template <typename T>
 pg_status launch_tn(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int nrg = a.nrg;
-  const char* force = getenv("PG_TN_KERNEL");
+  const char* force = env_str("PG_TN_KERNEL");
   const bool single_ok = tn_single_wg_supported<T>(A);
   if (force != nullptr && *force) {
     if (force[0] == 'm')  // experiments: a named instantiation of gemv_tnm_kernel (pg_gemv_tn3.hip)
@@ -614,7 +614,10 @@ __device__ __forceinline__ void col_unpack(const T* __restrict__ slots, int nran
   s4[1] = ri;
   s4[2] = dg;
   s4[3] = rs;
-  if (team_err != nullptr && slots[COL_SLOTS * nranks] != T(0)) *team_err = 1.0;  // some rank's sweep timed out: every rank falls back
+  if (team_err != nullptr) {  // some rank's sweep timed out (1) or was refused at launch (2): every rank falls back in this step
+    if (slots[COL_SLOTS * nranks + 1] != T(0)) *team_err = 2.0;
+    else if (slots[COL_SLOTS * nranks] != T(0)) *team_err = 1.0;
+  }
 }
 
 template <typename T>
@@ -652,6 +655,7 @@ pg_status col_ensure_cbuf(pg_ls* f) {
     pg_set_error("hipMalloc for the column-sharding payload failed: %s", hipGetErrorString(e));
     return PG_ERR_ALLOC;
   }
+  PG_HIP(hipMemsetAsync(f->cbuf, 0, bytes, f->ctx->stream));  // no slot is ever read before it was written, whatever the rank count
   return PG_OK;
 }
 
@@ -754,8 +758,15 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   a.scal_out = c->dscal + PG_S_GZ;
   a.line_cols = env_int("PG_TN_LINE_COLS", 0) > 0 ? env_int("PG_TN_LINE_COLS", 0) : 32;  // experiments: 1 = dealt one by one (rounds 1-2)
   int blocks = 0;
-  PG_TRY(launch_tn<T>(A, a, &blocks));
-  f->a_passes += 1;
+  const pg_status launched = launch_tn<T>(A, a, &blocks);
+  // Column shards: a sweep refused on THIS rank only (a cooperative launch that does not fit next to something else on the
+  // device) must not leave the peers alone in this step's all-reduce.  The rank posts the same collective with an empty
+  // m-vector and its refused flag set; every rank then sees PG_ERR_UNSUPPORTED at the scalar read-back, drops the step
+  // and leaves the single-sweep mode together (pg_iter.hip::redo_with_two_sweeps).
+  const bool refused = launched == PG_ERR_UNSUPPORTED && cols;
+  if (refused) blocks = 0;
+  else PG_TRY(launched);
+  if (!refused) f->a_passes += 1;
   int64_t fb = (A->ld + 63) / 64;
   if (fb > 1024) fb = 1024;
   if (cols) {
@@ -770,6 +781,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
     pk.rank = c->shard_rank;
     pk.s4 = c->dscal + PG_S_GZ;
     pk.team_err = c->dscal + PG_S_TEAMERR;
+    pk.refused = refused ? 1 : 0;
     {
       pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
       hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,

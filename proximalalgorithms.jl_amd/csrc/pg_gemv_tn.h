@@ -297,8 +297,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tn_kernel(TNArgs<T> a) {
 // Column shards: the scalar slots behind the m-vector of the all-reduce payload (pg_gemv.hip, "column sharding").  Every rank
 // owns COL_SLOTS working-precision words -- its four epilogue scalars as (hi, lo) pairs -- that are zero on all other ranks,
 // so the SUM all-reduce acts as an all-gather; one more group of COL_SLOTS words behind them is shared: word 0 carries this
-// rank's team-timeout flag (PG_S_TEAMERR), whose sum tells EVERY rank that some rank's sweep failed (they must fall back
-// together: the two-sweep retry issues a different collective).
+// rank's team-timeout flag (PG_S_TEAMERR), word 1 its launch-refused flag; their sums tell EVERY rank that some rank's sweep
+// failed (they must fall back together: the two-sweep retry issues a different collective).
 constexpr int COL_SLOTS = 8;
 template <typename T>
 struct ColPack {
@@ -306,6 +306,7 @@ struct ColPack {
   int nranks = 0, rank = 0;
   const double* s4 = nullptr;        // this rank's { g(z), ||res||_inf, <g, res>, ||res||^2 }
   const double* team_err = nullptr;  // this rank's PG_S_TEAMERR
+  int refused = 0;                   // this rank's sweep was refused at launch (nothing ran): word 1 of the shared group
 };
 template <typename T>
 __device__ __forceinline__ void col_pack_slot(const ColPack<T>& p, int t) {
@@ -317,6 +318,8 @@ __device__ __forceinline__ void col_pack_slot(const ColPack<T>& p, int t) {
     v = (t & 1) ? (T)(d - (double)hi) : hi;
   } else if (t == COL_SLOTS * p.nranks) {
     v = (p.team_err != nullptr && *p.team_err != 0.0) ? T(1) : T(0);
+  } else if (t == COL_SLOTS * p.nranks + 1) {
+    v = p.refused ? T(1) : T(0);
   }
   p.slots[t] = v;
 }
@@ -334,7 +337,8 @@ __global__ __launch_bounds__(1024) void gemv_n_finish_kernel(const T* __restrict
   const int sg = threadIdx.x >> 6;
   double sq = 0.0;
   // column shards: the scalar slots of the all-reduce payload ride in this launch (they were their own kernel before)
-  if (pack.slots != nullptr && blockIdx.x == 0) col_pack_slot(pack, (int)threadIdx.x);
+  if (pack.slots != nullptr && blockIdx.x == 0)
+    for (int t = (int)threadIdx.x; t < COL_SLOTS * (pack.nranks + 1); t += (int)blockDim.x) col_pack_slot(pack, t);
   for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < ld; row0 += (int64_t)gridDim.x * 64) {
     const int64_t i = row0 + rx;
     double acc = 0.0;
@@ -378,7 +382,10 @@ __global__ __launch_bounds__(1024) void gemv_n_finish_kernel(const T* __restrict
   }
 }
 
+using ::pg_tuning_enabled;
+using ::env_str;
 inline int env_int(const char* name, int dflt) {
+  if (!pg_tuning_enabled()) return dflt;
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }

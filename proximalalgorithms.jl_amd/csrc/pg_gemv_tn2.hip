@@ -829,8 +829,17 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.nteams = (int)nteams;
   a.xch = (unsigned long long*)A->xch;
   a.team_err = c->dscal + PG_S_TEAMERR;
-  A->xch_epoch = (A->xch_epoch % 255u) + 1u;  // 1 .. 255: never the all-zero tag of a fresh ring
-  a.tag_base = A->xch_epoch << 24;
+  if (c->capturing) {
+    // a recorded launch replays with the kernel arguments baked in, so its tags cannot carry a fresh epoch: every replay
+    // would meet its own granules of the previous replay (same step, same tag) in the ring.  The recorded body therefore
+    // zeroes the ring itself before the sweep (a memset node, as before round 3) under the reserved epoch 255, which no
+    // uncaptured launch uses.
+    PG_HIP(hipMemsetAsync(A->xch, 0, xch_bytes, c->stream));
+    a.tag_base = 255u << 24;
+  } else {
+    A->xch_epoch = (A->xch_epoch % 254u) + 1u;  // 1 .. 254: never the all-zero tag of a fresh ring, never a replay's 255
+    a.tag_base = A->xch_epoch << 24;
+  }
 #ifdef PG_TNT_EXPERIMENT
   a.dbg = env_int("PG_TNT_DBG", 0);
 #endif
@@ -857,8 +866,13 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // PG_S_TEAMERR -> PG_ERR_TIMEOUT at the next scalar read-back, which the iterations turn into a two-sweep retry).
   unsigned grid = (unsigned)(nteams * TM);
   c->team_launches++;
-  if (c->test_team_fault > 0 && c->team_launches == c->test_team_fault && TM > 1)
+  if (c->test_team_fault > 0 && c->team_launches == c->test_team_fault && TM > 1) {
+    if (c->test_team_fault_kind == 1) {  // test hook: this launch is refused, as a cooperative launch that does not fit would be
+      pg_set_error("cooperative launch of the long-column sweep was refused (injected by pg_ctx_test_team_fault)");
+      return PG_ERR_UNSUPPORTED;
+    }
     grid -= 1;  // test hook: the last member of the last team is never started, its team-mates time out
+  }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   if (c->team_plain_launch || c->capturing) {  // (stream capture records plain launches only)
     hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);

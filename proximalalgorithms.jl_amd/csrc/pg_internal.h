@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -109,10 +110,11 @@ struct pg_ctx {
   hipEvent_t dr_ev[2] = {nullptr, nullptr};
   size_t coop_ws_bytes = 0;
   // long-column sweep (gemv_tnt_kernel, pg_gemv_tn2.hip): a timeout seen by the last scalar read-back, and the test hook
-  // PG_TEST_TEAM_FAULT = k (read once, here): the k-th team launch on this context (1-based) goes out with one workgroup
+  // pg_ctx_test_team_fault(ctx, k) (tests only; proxgrad_hip_ext.h): the k-th team launch on this context (1-based) goes out with one workgroup
   // missing, so that one team times out
   bool team_timeout = false;
   int test_team_fault = 0;
+  int test_team_fault_kind = 0;  // 0: one workgroup never starts (its team times out); 1: the launch is refused
   long team_launches = 0;
   bool team_plain_launch = false;  // PG_TN_TEAM_PLAIN = 1: plain instead of cooperative launch (A/B measurements)
   // stream capture (pg_ctx_capture_begin / _end): launches are recorded into a hipGraph instead of executed; scalar
@@ -448,4 +450,13 @@ __device__ __forceinline__ bool grid_reduce_finalize_streamed(WaveVal wave_val, 
   if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
 }
+// Tuning knobs (PG_N_*, PG_T_*, PG_TN*, ...) are for experiments: they are looked up only in a process that was started
+// with PG_TUNE set (read once); a production process never calls getenv on the launch path and cannot be steered by a
+// stray variable.
+inline bool pg_tuning_enabled() {
+  static const bool on = getenv("PG_TUNE") != nullptr;
+  return on;
+}
+inline const char* env_str(const char* name) { return pg_tuning_enabled() ? getenv(name) : nullptr; }
+
 #endif  // __HIPCC__

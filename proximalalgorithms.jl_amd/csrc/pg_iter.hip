@@ -203,7 +203,15 @@ pg_status redo_with_two_sweeps(pg_iter* it, pg_status why, bool residual_intact)
   c->team_timeout = false;
   it->sp_ready = false;
   it->flags |= PG_FLAG_SWEEP_FALLBACK;
-  if (why == PG_ERR_UNSUPPORTED) it->single_sweep = false;
+  if (why == PG_ERR_UNSUPPORTED) {
+    // refused: nothing of the sweep ran, and it would be refused again -- also inside a batch (defer_sync): the two sweeps
+    // are enqueued in its place and the batch's one read-back takes f(x) from PG_S_F like any two-sweep iteration.  With
+    // column shards the refusal of ONE rank reaches every rank through the payload's flag (pg_gemv.hip), as
+    // PG_ERR_UNSUPPORTED at the scalar read-back, i.e. here -- outside a batch only; inside one the batch fails with that
+    // code on every rank and the caller restarts it step by step (algorithm.py).
+    it->single_sweep = false;
+    it->fx_src = -1;
+  }
   if (residual_intact) {  // f->r = A x - b and dscal[PG_S_F] = f(x) are still those of x: only A' r is missing
     PG_TRY(pg_ls_grad_stage_async(it->f, it->grad_f_x));
   } else {
@@ -254,7 +262,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
                                             it->gamma, beta2, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res,
                                             it->x_next, it->g_v0, it->g_v1);
       if (st == PG_OK && !it->defer_sync) st = read_sweep_scalars<T>(it);
-      if (sweep_lost(st) && !it->defer_sync) return redo_with_two_sweeps<T>(it, st, false);
+      if (sweep_lost(st) && (!it->defer_sync || st == PG_ERR_UNSUPPORTED)) return redo_with_two_sweeps<T>(it, st, false);
       PG_TRY(st);
       it->sp_beta = beta2;
       it->spec_stepsize = (double)s2.stepsize, it->spec_theta = (double)s2.theta, it->spec_t = (double)s2.t, it->spec_k = s2.k;
@@ -280,7 +288,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
                                             0.0, o.g_kind, o.g_p0, o.g_p1, it->grad_f_x, it->y, it->z, it->res, nullptr, it->g_v0,
                                             it->g_v1);
       if (st == PG_OK && !it->defer_sync) st = read_sweep_scalars<T>(it);
-      if (sweep_lost(st) && !it->defer_sync) return redo_with_two_sweeps<T>(it, st, false);
+      if (sweep_lost(st) && (!it->defer_sync || st == PG_ERR_UNSUPPORTED)) return redo_with_two_sweeps<T>(it, st, false);
       PG_TRY(st);
       it->sp_gen = f->r_gen;
       it->sp_ready = true;
@@ -438,7 +446,7 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   // experiment hooks: PG_ITER_VEC_SKEW = extra bytes between consecutive state vectors, PG_ITER_BASE_SKEW = offset of the
   // first one within the allocation (both rounded to 256 B)
   auto env_bytes = [](const char* name) -> size_t {
-    const char* v = getenv(name);
+    const char* v = env_str(name);
     return v ? (size_t)pg_round_up((int64_t)strtoll(v, nullptr, 10), 256) : 0;
   };
   const size_t base_skew = env_bytes("PG_ITER_BASE_SKEW");
@@ -581,6 +589,129 @@ pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, doubl
     it->res_sq = f32 ? (double)(float)c->hscal[PG_S_RESSQ] : c->hscal[PG_S_RESSQ];
   }
   *k_out = k;
+  fill_scalars(it, out);
+  return PG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Checkpoint / resume.  The reference keeps ALL algorithm memory in the state struct (forward_backward.jl:52-63,
+// fast_forward_backward.jl:60-71 incl. the mutable AdaptiveNesterovSequence, nesterov.jl:56-60), so `iterate(iter, saved)`
+// resumes a solve.  Here that memory is: the state vectors, the residual vectors (A x - b; for the adaptive fast iteration
+// the pair A z - b, A z_prev - b), the scalars, the sequence state and -- single-sweep iterations -- the speculative first
+// half of the next iteration (x_next, its residual, the sequence state after its coefficient), which the last sweep produced
+// with its own summation order: dropping it would resume correctly but not bit-identically.  One host blob carries it all.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct StateBlobHeader {
+  uint32_t magic, version;
+  int32_t dtype, fast, adaptive, single_sweep, reuse, g_kind;
+  int64_t n, m, ld, bytes;
+  double gamma, f_x, g_z, res_inf, dot_gr, res_sq, beta, f_z, f_z_upp;
+  double seq_stepsize, seq_theta, seq_t;
+  int64_t seq_k;
+  double sp_f, sp_beta, spec_stepsize, spec_theta, spec_t;
+  int64_t spec_k, a_passes;
+  int32_t flags, n_backtracks, rz_valid, sp_ready, sp_slot, r_current, reserved0, reserved1;
+};
+constexpr uint32_t STATE_MAGIC = 0x54534750u;  // "PGST"
+
+inline int64_t state_blob_bytes(const pg_iter* it) {
+  const size_t s = pg_sizeof(it->dtype);
+  const int nvec = 6 + (it->x_next != nullptr ? 1 : 0);
+  const pg_mat* A = it->f->A;
+  return (int64_t)(sizeof(StateBlobHeader) + (size_t)nvec * (size_t)it->n * s + (size_t)A->ld * s +
+                   (it->rz != nullptr ? 2 * (size_t)A->m * s : 0));
+}
+
+// the vectors of the blob in their fixed order
+inline int state_vectors(pg_iter* it, void** ptrs, size_t* bytes) {
+  const size_t s = pg_sizeof(it->dtype);
+  const size_t nb = (size_t)it->n * s;
+  int k = 0;
+  auto add = [&](void* p, size_t b) { ptrs[k] = p, bytes[k] = b, ++k; };
+  add(it->x, nb), add(it->grad_f_x, nb), add(it->y, nb), add(it->z, nb), add(it->res, nb);
+  add(it->o.fast ? it->z_prev : it->grad_f_z, nb);
+  if (it->x_next != nullptr) add(it->x_next, nb);
+  add(it->f->r, (size_t)it->f->A->ld * s);
+  if (it->rz != nullptr) add(it->rz, (size_t)it->f->A->m * s), add(it->rz_prev, (size_t)it->f->A->m * s);
+  return k;
+}
+}  // namespace
+
+pg_status pg_iter_state_bytes(pg_iter* it, int64_t* bytes_out) {
+  PG_REQUIRE(it != nullptr && bytes_out != nullptr, "null argument");
+  *bytes_out = state_blob_bytes(it);
+  return PG_OK;
+}
+
+pg_status pg_iter_state_download(pg_iter* it, void* host_blob, int64_t bytes) {
+  PG_REQUIRE(it != nullptr && host_blob != nullptr, "null argument");
+  PG_REQUIRE(it->initialized, "pg_iter_init has not been called");
+  PG_REQUIRE(bytes >= state_blob_bytes(it), "the blob is smaller than pg_iter_state_bytes");
+  PG_REQUIRE(it->o.seq_kind != PG_SEQ_HOST || !it->o.fast, "a host-drawn extrapolation sequence lives in the caller: nothing to save here");
+  pg_ctx* c = it->ctx;
+  StateBlobHeader h;
+  memset(&h, 0, sizeof(h));
+  h.magic = STATE_MAGIC, h.version = 1;
+  h.dtype = it->dtype, h.fast = it->o.fast, h.adaptive = it->adaptive ? 1 : 0, h.single_sweep = it->single_sweep ? 1 : 0;
+  h.reuse = it->rz != nullptr ? 1 : 0, h.g_kind = it->o.g_kind;
+  h.n = it->n, h.m = it->f->A->m, h.ld = it->f->A->ld, h.bytes = state_blob_bytes(it);
+  h.gamma = it->gamma, h.f_x = it->f_x, h.g_z = it->g_z, h.res_inf = it->res_inf, h.dot_gr = it->dot_gr, h.res_sq = it->res_sq;
+  h.beta = it->beta, h.f_z = it->f_z, h.f_z_upp = it->f_z_upp;
+  h.seq_stepsize = it->seq_stepsize, h.seq_theta = it->seq_theta, h.seq_t = it->seq_t, h.seq_k = it->seq_k;
+  h.sp_f = it->sp_f, h.sp_beta = it->sp_beta, h.spec_stepsize = it->spec_stepsize, h.spec_theta = it->spec_theta;
+  h.spec_t = it->spec_t, h.spec_k = it->spec_k, h.a_passes = it->f->a_passes - it->passes0;
+  h.flags = it->flags, h.n_backtracks = it->n_backtracks, h.rz_valid = it->rz_valid ? 1 : 0, h.sp_ready = it->sp_ready ? 1 : 0;
+  h.sp_slot = it->sp_slot, h.r_current = it->sp_gen == it->f->r_gen ? 1 : 0;
+  memcpy(host_blob, &h, sizeof(h));
+  char* dst = (char*)host_blob + sizeof(h);
+  void* ptrs[12];
+  size_t nb[12];
+  const int k = state_vectors(it, ptrs, nb);
+  for (int i = 0; i < k; ++i) {
+    if (nb[i]) PG_HIP(hipMemcpyAsync(dst, ptrs[i], nb[i], hipMemcpyDeviceToHost, c->stream));
+    dst += nb[i];
+  }
+  PG_HIP(hipStreamSynchronize(c->stream));
+  return PG_OK;
+}
+
+pg_status pg_iter_state_upload(pg_iter* it, const void* host_blob, int64_t bytes, pg_iter_scalars* out) {
+  PG_REQUIRE(it != nullptr && host_blob != nullptr, "null argument");
+  PG_REQUIRE(bytes >= (int64_t)sizeof(StateBlobHeader), "the blob is shorter than its header");
+  StateBlobHeader h;
+  memcpy(&h, host_blob, sizeof(h));
+  PG_REQUIRE(h.magic == STATE_MAGIC && h.version == 1, "not a state blob of this library version");
+  PG_REQUIRE(h.dtype == it->dtype && h.n == it->n && h.m == it->f->A->m && h.ld == it->f->A->ld,
+             "the blob was saved for another problem size or element type");
+  PG_REQUIRE(h.fast == it->o.fast && h.adaptive == (it->adaptive ? 1 : 0) && h.g_kind == it->o.g_kind,
+             "the blob was saved by another iteration type (fast / adaptive / g)");
+  PG_REQUIRE(h.single_sweep == (it->single_sweep ? 1 : 0) && h.reuse == (it->rz != nullptr ? 1 : 0),
+             "the blob was saved by an iterator with other sweep options (single_sweep / reuse_residual / sharding)");
+  PG_REQUIRE(h.bytes == state_blob_bytes(it) && bytes >= h.bytes, "the blob is truncated");
+  pg_ctx* c = it->ctx;
+  const char* src = (const char*)host_blob + sizeof(h);
+  void* ptrs[12];
+  size_t nb[12];
+  const int k = state_vectors(it, ptrs, nb);
+  for (int i = 0; i < k; ++i) {
+    if (nb[i]) PG_HIP(hipMemcpyAsync(ptrs[i], src, nb[i], hipMemcpyHostToDevice, c->stream));
+    src += nb[i];
+  }
+  PG_HIP(hipStreamSynchronize(c->stream));  // the caller's blob may go away after this call
+  it->gamma = h.gamma, it->f_x = h.f_x, it->g_z = h.g_z, it->res_inf = h.res_inf, it->dot_gr = h.dot_gr, it->res_sq = h.res_sq;
+  it->beta = h.beta, it->f_z = h.f_z, it->f_z_upp = h.f_z_upp;
+  it->seq_stepsize = h.seq_stepsize, it->seq_theta = h.seq_theta, it->seq_t = h.seq_t, it->seq_k = h.seq_k;
+  it->sp_f = h.sp_f, it->sp_beta = h.sp_beta, it->spec_stepsize = h.spec_stepsize, it->spec_theta = h.spec_theta;
+  it->spec_t = h.spec_t, it->spec_k = h.spec_k;
+  it->flags = h.flags, it->n_backtracks = h.n_backtracks, it->rz_valid = h.rz_valid != 0, it->sp_ready = h.sp_ready != 0;
+  it->sp_slot = h.sp_slot;
+  it->fx_src = -1;
+  it->defer_sync = false;
+  it->f->r_gen++;  // f->r was rewritten
+  it->sp_gen = h.r_current ? it->f->r_gen : it->f->r_gen - 1;
+  it->passes0 = it->f->a_passes - h.a_passes;
+  it->initialized = true;
   fill_scalars(it, out);
   return PG_OK;
 }

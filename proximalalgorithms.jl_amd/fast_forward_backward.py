@@ -87,7 +87,7 @@ class FastForwardBackwardIteration:
                     return _lib.PG_SEQ_REPEATED, float(beta), 0.0, None
         return _lib.PG_SEQ_HOST, 0.0, 0.0, iter(s)  # Iterators.Stateful(seq)  (:90-92)
 
-    def _iter_fused(self):
+    def _iter_fused(self, resume_blob=None):
         R = self.x0.dtype.type
         kind, p0, p1, host_iter = self._seq_spec()
         fi = FusedIteration(self.f, self.g, fast=True, Lf=self.Lf, gamma=self.gamma, adaptive=self.adaptive,
@@ -110,8 +110,13 @@ class FastForwardBackwardIteration:
             if sc.flags & _lib.PG_FLAG_SWEEP_FALLBACK:  # this step's single sweep was lost and redone with two sweeps
                 self.counters["sweep_fallbacks"] = self.counters.get("sweep_fallbacks", 0) + 1
 
-        refresh(fi.init(self.x0))
-        yield state
+        if resume_blob is None:
+            refresh(fi.init(self.x0))
+            yield state
+        else:  # `iterate(iter, saved_state)`: the first state yielded is the one AFTER the saved one
+            if host_iter is not None:
+                raise ValueError("a host-drawn extrapolation sequence is not part of the saved state")
+            refresh(fi.state_upload(resume_blob))
         while True:
             beta = float(next(host_iter)) if host_iter is not None else 0.0
             refresh(fi.step(beta))
@@ -158,6 +163,22 @@ class FastForwardBackwardIteration:
             s.res.axpby_(1.0, s.x, -1.0, s.z)  # :142
             s.res_inf = None
             yield s
+
+    def save_state(self):
+        """All algorithm memory of the running solve as bytes -- the state struct of the reference (fast_forward_backward.jl:60-71), which
+        `iterate(iter, state)` resumes from: state vectors, residuals, gamma, f_x, g_z, the extrapolation sequence's state.
+        Engine "fused" only (pg_iter_state_download)."""
+        if getattr(self, "_fused", None) is None:
+            raise ValueError("save_state needs a started iteration on the fused engine")
+        return self._fused.state_download()
+
+    def resume(self, blob):
+        """`Base.iterate(iter, saved_state)` over and over: an iterator of the states that FOLLOW the saved one, bit-identical
+        to the solve the blob was taken from (a fresh library iterator with this iteration's options takes the blob:
+        pg_iter_state_upload).  x0 is not read."""
+        if self.engine != "fused":
+            raise ValueError("resume needs the fused engine")
+        return self._iter_fused(resume_blob=blob)
 
     def __iter__(self):
         if self.engine == "fused":

@@ -92,7 +92,7 @@ class ForwardBackwardIteration:
         self.counters = {}
 
     # ---- fused engine ----
-    def _iter_fused(self):
+    def _iter_fused(self, resume_blob=None):
         R = self.x0.dtype.type
         fi = FusedIteration(self.f, self.g, fast=False, Lf=self.Lf, gamma=self.gamma, adaptive=self.adaptive,
                             minimum_gamma=self.minimum_gamma, reduce_gamma=self.reduce_gamma,
@@ -113,8 +113,11 @@ class ForwardBackwardIteration:
             if sc.flags & _lib.PG_FLAG_SWEEP_FALLBACK:  # this step's single sweep was lost and redone with two sweeps
                 self.counters["sweep_fallbacks"] = self.counters.get("sweep_fallbacks", 0) + 1
 
-        refresh(fi.init(self.x0))
-        yield state
+        if resume_blob is None:
+            refresh(fi.init(self.x0))
+            yield state
+        else:  # `iterate(iter, saved_state)`: the first state yielded is the one AFTER the saved one
+            refresh(fi.state_upload(resume_blob))
         while True:
             refresh(fi.step())
             yield state
@@ -153,6 +156,22 @@ class ForwardBackwardIteration:
             s.res.axpby_(1.0, s.x, -1.0, s.z)  # :120
             s.res_inf = None
             yield s
+
+    def save_state(self):
+        """All algorithm memory of the running solve as bytes -- the state struct of the reference (forward_backward.jl:52-63), which
+        `iterate(iter, state)` resumes from: state vectors, residuals, gamma, f_x, g_z, the extrapolation sequence's state.
+        Engine "fused" only (pg_iter_state_download)."""
+        if getattr(self, "_fused", None) is None:
+            raise ValueError("save_state needs a started iteration on the fused engine")
+        return self._fused.state_download()
+
+    def resume(self, blob):
+        """`Base.iterate(iter, saved_state)` over and over: an iterator of the states that FOLLOW the saved one, bit-identical
+        to the solve the blob was taken from (a fresh library iterator with this iteration's options takes the blob:
+        pg_iter_state_upload).  x0 is not read."""
+        if self.engine != "fused":
+            raise ValueError("resume needs the fused engine")
+        return self._iter_fused(resume_blob=blob)
 
     def __iter__(self):
         if self.engine == "fused":

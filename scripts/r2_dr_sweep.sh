@@ -1,4 +1,5 @@
 #!/bin/bash
+export PG_TUNE=1  # the library reads its tuning variables only when this is set
 # Sweep of the Douglas-Rachford stepping kernel's launch geometry (PG_DR_STEP_GEOM = threads x blocks/CU x vectors/trip);
 # one process per setting (the knob is read once).  Output: one line per setting with the kernel's average launch time.
 for g in 1024x1x2 1024x1x1 1024x1x4 1024x2x1 1024x2x2 512x2x2 512x2x4 512x4x1 512x4x2 256x4x2 256x4x4 256x8x1 256x8x2 256x8x4; do

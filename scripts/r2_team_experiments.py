@@ -3,6 +3,9 @@ the perturbed runs are WRONG by construction): where does the gap to the one-wor
   PG_TNT_DBG bit 0: never wait for the other members; bit 1: accumulate from the register tile (no LDS read-back);
   bit 2: do not park tiles in LDS."""
 import os, sys
+
+os.environ.setdefault("PG_TUNE", "1")  # the library reads its tuning variables only when this is set
+
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import proximalalgorithms.jl_amd as pa

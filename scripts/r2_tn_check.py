@@ -5,6 +5,9 @@
     python scripts/r2_tn_check.py team [m n]...  sweep of the long-column (workgroup team) kernel
 Prints plain text; the tables kept under profiles/ come from here."""
 import os
+
+os.environ.setdefault("PG_TUNE", "1")  # the library reads its tuning variables only when this is set
+
 import sys
 import time
 

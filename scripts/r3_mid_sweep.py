@@ -4,6 +4,9 @@ default dispatch, interleaved A/B (median of five rounds), plus a correctness ch
     python scripts/r3_mid_sweep.py check
     python scripts/r3_mid_sweep.py ab [m n]..."""
 import os
+
+os.environ.setdefault("PG_TUNE", "1")  # the library reads its tuning variables only when this is set
+
 import sys
 
 import numpy as np

@@ -4,6 +4,9 @@ the same address runs 777..820 it/s from one iterator to the next, +-0.2 % withi
 the state vectors staggered (PG_ITER_VEC_SKEW) or shifted (PG_ITER_BASE_SKEW), three interleaved rounds.
     python scripts/r3_slab_layout.py [config2|headline]"""
 import os
+
+os.environ.setdefault("PG_TUNE", "1")  # the library reads its tuning variables only when this is set
+
 import sys
 import time
 

@@ -3,6 +3,9 @@
 Usage: python scripts/tune_gemv.py [m n]...   -> prints GB/s per configuration and checks results agree."""
 import itertools
 import os
+
+os.environ.setdefault("PG_TUNE", "1")  # the library reads its tuning variables only when this is set
+
 import sys
 
 import numpy as np

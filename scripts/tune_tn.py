@@ -2,6 +2,9 @@
 """Sweep of the single-sweep kernel's launch geometry (environment tunables of csrc/pg_gemv.hip: PG_TN_WAVES, PG_TN_C,
 PG_TN_BLOCKS_PER_CU): python scripts/tune_tn.py [m n]...  -> GB/s of gemv_tn per configuration, best first."""
 import os, sys, numpy as np
+
+os.environ.setdefault("PG_TUNE", "1")  # the library reads its tuning variables only when this is set
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import proximalalgorithms.jl_amd as pa
 

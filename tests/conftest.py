@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the suite drives kernel geometry through the PG_* tuning variables in places: the library only looks at them in a process
+# started with PG_TUNE set (csrc/pg_internal.h::pg_tuning_enabled)
+os.environ.setdefault("PG_TUNE", "1")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 if GOLDEN not in sys.path:
     sys.path.insert(0, GOLDEN)

@@ -664,7 +664,7 @@ def test_bench_rank_failure_still_prints_a_line(pa, stage, kind):
 @pytest.mark.parametrize("mode,cols", [("fixed", False), ("adaptive", False), ("fixed", True)])
 def test_team_sweep_timeout_falls_back_to_two_sweeps(pa, mode, cols):
     """65536 x 4096 (teams of four workgroups per column group): the third team launch of the solve goes out with one
-    workgroup missing (PG_TEST_TEAM_FAULT, read at context creation -> own process).  That step's sweep times out, its
+    workgroup missing (pg_ctx_test_team_fault; own process).  That step's sweep times out, its
     uncommitted outputs are discarded, the step is redone with two sweeps and flagged; the iterates stay the oracle's
     (1e-5 max(1, |z|) in Float32), the step size sequence too, and the following steps are back to one read
     of A per iteration.  cols: the same as the single rank of a column-sharded job, where the
@@ -705,6 +705,91 @@ def test_team_sweep_timeout_inside_a_batch_restarts_the_solve(pa):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(out.stdout.splitlines()[-1])
     assert d["batched"] and d["warned"] and d["k"] == 8 and d["dz"] <= 1e-5 * d["z_scale"], d
+
+
+@pytest.mark.parametrize("fast,adaptive,g", [(True, True, "l1"), (True, False, "l1"), (False, True, "box"), (False, False, "boxv"),
+                                             (True, True, "l1-two-sweeps")])
+def test_saved_state_resumes_bit_identically(pa, fast, adaptive, g):
+    """SURVEY section 5 (checkpoint / resume): the reference's `iterate(iter, saved_state)` continues from any saved state,
+    all algorithm memory being in the state struct (fast_forward_backward.jl:60-71, nesterov.jl:56-60).  Here: 30 iterations,
+    pg_iter_state_download, the iterator destroyed, a NEW iterator (same options) takes the blob (pg_iter_state_upload, no
+    pg_iter_init) and runs 30 more = 60 iterations straight, bit for bit in every state vector and scalar -- including the
+    speculative half iteration a single sweep leaves behind (dropping it would change the summation order of one A x)."""
+    import gc
+
+    dtype = np.float32
+    m, n = 1500, 2600
+    A, b, lam = synthetic_problem(m, n, dtype, seed=11)
+    rng = np.random.default_rng(3)
+    x0 = (0.1 * rng.standard_normal(n)).astype(dtype)
+    if g.startswith("l1"):
+        make_g = lambda: pa.NormL1(lam)
+    elif g == "box":
+        make_g = lambda: pa.IndBox(dtype(-0.05), dtype(0.08))
+    else:
+        lo = (-0.05 - 0.05 * rng.random(n)).astype(dtype)
+        make_g = lambda: pa.IndBox(lo, (lo + dtype(0.12)).astype(dtype))
+    Lf = None if adaptive else dtype(power_Lf(A))
+    cls = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
+    kw = dict(single_sweep=False) if g.endswith("two-sweeps") else {}
+    f = pa.LeastSquares(A, b)
+    make = lambda: cls(f=f, g=make_g(), x0=x0, Lf=Lf, **kw)
+    fields = ("x", "grad_f_x", "y", "z", "res") + (("z_prev",) if fast else ())
+
+    def snap(s):
+        return {k: getattr(s, k).numpy().copy() for k in fields} | {"gamma": float(s.gamma), "f_x": float(s.f_x), "g_z": float(s.g_z),
+                                                                      "res_inf": float(s.res_inf)}
+
+    straight = [snap(s) for s in itertools.islice(make(), 60)]
+    first = make()
+    it = iter(first)
+    for _ in range(30):
+        s = next(it)
+    assert np.array_equal(snap(s)["z"], straight[29]["z"])
+    blob = first.save_state()
+    assert isinstance(blob, bytes) and len(blob) > 6 * n * 4
+    del it, s, first
+    gc.collect()  # pg_iter_destroy of the first iterator
+    resumed = make()
+    for k, s in enumerate(itertools.islice(resumed.resume(blob), 30), start=30):
+        got, ref = snap(s), straight[k]
+        for name in ref:
+            assert np.array_equal(got[name], ref[name]), (name, k)
+    # a blob of another iteration type is refused, not misread
+    other = (pa.ForwardBackwardIteration if fast else pa.FastForwardBackwardIteration)(f=f, g=make_g(), x0=x0, Lf=Lf)
+    with pytest.raises(pa.ProxGradError, match="another iteration type"):
+        next(other.resume(blob))
+    with pytest.raises(pa.ProxGradError, match="truncated|shorter"):
+        next(make().resume(blob[: len(blob) // 2]))
+
+
+@pytest.mark.parametrize("cols,batched", [(True, False), (False, True), (True, True)])
+def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, cols, batched):
+    """a REFUSED cooperative launch (injected: pg_ctx_test_team_fault kind 1) must be survivable where a
+    timeout is.  Stepped, column shards: the refusing rank still posts the step's all-reduce with its refused flag, every
+    rank reads PG_ERR_UNSUPPORTED back, redoes the step with two sweeps and stays with two sweeps (the peers are never left
+    alone in a collective).  Inside pg_iter_run_batched: unsharded, nothing was enqueued, so the two sweeps take the sweep's
+    place within the batch (no restart, no warning); column shards, the batch fails on every rank with that code and the
+    algorithm object restarts it step by step.  Iterates = the oracle's in every case."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "tools", "team_fault.py"), "--mode", "fixed", "--fault", "3", "--steps", "7",
+           "--n", "4096", "--refuse"] + (["--cols"] if cols else []) + (["--batched"] if batched else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    if batched:
+        assert d["batched"] and d["warned"] == cols and d["k"] == 8 and d["dz"] <= 1e-5 * d["z_scale"], d
+        return
+    steps = d["steps"]
+    assert [r["k"] for r in steps if r["flags"] & d["fallback_flag"]] == [3], steps
+    for r in steps:
+        assert r["dz"] <= 1e-5 * r["z_scale"] and r["gamma"] == pytest.approx(r["gamma_oracle"], rel=1e-6), r
+    by_k = {r["k"]: r["a_passes"] for r in steps}
+    assert by_k[2] == 1 and by_k[3] == 2 and by_k[6] == 2 and by_k[7] == 2, by_k  # two sweeps from the refusal on
 
 
 def test_bench_default_line_carries_every_single_gpu_config(pa):

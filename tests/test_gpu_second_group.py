@@ -592,6 +592,38 @@ def test_graph_replay_matches_plain_stepping(pa, stream_ctx, dtype):
         assert ita == itg and np.array_equal(a, g), solver.__name__
 
 
+def test_graph_replay_of_a_team_sweep(pa, stream_ctx):
+    """a recorded long-column sweep replays with its kernel arguments baked in, so the exchange ring's
+    launch epoch cannot advance between replays; with few columns (every step within the ring's 8 slots) a replay would
+    meet its own granules of the previous replay.  The recorded body zeroes the ring itself (reserved epoch): Chambolle-Pock
+    with a 40000 x 48 device matrix L (teams of three workgroups, one step per team) replayed 12 times against plain
+    stepping, bit for bit, and a plain step after the replays (its epoch must not collide with the recorded one)."""
+    from proximalalgorithms.jl_amd.algorithm import graph_iterate
+
+    dtype = np.float32
+    rng = np.random.default_rng(23)
+    m, n = 40000, 48
+    A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+    b = rng.standard_normal(m).astype(dtype)
+    lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
+    L = pa.HIPMatrix.from_numpy(A, stream_ctx)
+    make = lambda: pa.ChambollePockIteration(x0=np.zeros(n, dtype), y0=np.zeros(m, dtype), g=pa.NormL1(lam),
+                                             h=pa.SquaredDistance(b), L=L)
+    plain_it, graph_it = make(), make()
+    plain, replay = iter(plain_it), graph_iterate(graph_it)
+    for k in range(12):
+        sp, sg = next(plain), next(replay)
+        assert np.array_equal(sp.x.numpy(), sg.x.numpy()) and np.array_equal(sp.y.numpy(), sg.y.numpy()), k
+    assert graph_it.graph is not None and graph_it.single_sweep and plain_it.single_sweep
+    assert np.any(sp.x.numpy() != 0)
+    # uncaptured launches on the same matrix after the replays
+    more = iter(make())
+    ref = iter(make())
+    for k in range(3):
+        s1, s2 = next(more), next(ref)
+        assert np.array_equal(s1.x.numpy(), s2.x.numpy()), k
+
+
 def test_graph_falls_back_on_default_stream_and_refuses_allocation(pa, stream_ctx):
     from proximalalgorithms.jl_amd import device
     from proximalalgorithms.jl_amd.algorithm import graph_iterate

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The long-column sweep losing a team member in the middle of a solve.
 
-PG_TEST_TEAM_FAULT = k (read once, when the context is created) makes the k-th team launch go out with one workgroup
+pg_ctx_test_team_fault(ctx, k, kind) makes the k-th team launch go out with one workgroup
 missing: its team-mates give up after their bounded wait, the step's scalar read-back reports PG_ERR_TIMEOUT and the
 iteration redoes that step with two sweeps (PG_FLAG_SWEEP_FALLBACK), then goes back to one sweep per iteration.  This
 script runs FastForwardBackward (fixed or adaptive step, unsharded or as the single rank of a column-sharded job) on a
@@ -25,16 +25,18 @@ def main():
     ap.add_argument("--mode", choices=["fixed", "adaptive"], default="fixed")
     ap.add_argument("--cols", action="store_true", help="run as the single rank of a column-sharded job (gloo, world size 1)")
     ap.add_argument("--fault", type=int, default=3, help="which team launch loses a member (0: none)")
+    ap.add_argument("--refuse", action="store_true", help="the faulty launch is REFUSED (PG_ERR_UNSUPPORTED) instead of losing a member")
     ap.add_argument("--steps", type=int, default=7)
     ap.add_argument("--batched", action="store_true",
                     help="the algorithm object with device_loop=True, check_every=4: the fault lands inside a batch, which cannot be "
                          "redone -- the solve restarts with the per-iteration loop (a warning says so)")
     args = ap.parse_args()
-    if args.fault:
-        os.environ["PG_TEST_TEAM_FAULT"] = str(args.fault)  # before the context exists
     import proximalalgorithms.jl_amd as pa
     from oracle import proxgrad_oracle as o
     from proximalalgorithms.jl_amd import _lib
+
+    if args.fault:
+        _lib.call("pg_ctx_test_team_fault", pa.get_context().handle, args.fault, 1 if args.refuse else 0)
 
     m, n, dtype = args.m, args.n, np.float32
     A, b, _ = o.synthetic_lasso(m, n, seed=3, dtype=dtype)
@@ -67,7 +69,7 @@ def main():
         for _ in range(args.steps + 1):
             so = next(ito)
         print(json.dumps({"batched": True, "k": int(k), "dz": float(np.max(np.abs(z - so.z))), "z_scale": float(max(1.0, np.max(np.abs(so.z)))),
-                          "warned": any("timed out inside a batch" in str(w.message) for w in caught)}))
+                          "warned": any("inside a batch" in str(w.message) for w in caught)}))
         return
     it = iter(iteration)
     rows, passes = [], 0
