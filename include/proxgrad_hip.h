@@ -136,6 +136,23 @@ pg_status pg_ctx_comm_stats(pg_ctx* ctx, int64_t* calls, int64_t* elements);
  * per iteration -- and A' r needs none, so the single-sweep iteration (pg_iter_opts.single_sweep) keeps working on
  * every rank (fixed step, or FastForwardBackward's adaptive step with reuse_residual).  nranks = 0: row sharding. */
 pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
+/* Row teams: north_star's ROW layout (GPU p holds the row block A_p; benchmark/benchmarks.jl:15-16 become A_p x - b_p and
+ * sum_p A_p' res_p) at ONE read of A per iteration.  Instead of all-reducing A' res between two sweeps, the devices exchange
+ * the per-column partial dots INSIDE the sweep: every device pushes its partial, as a tagged 8-byte granule, into the inbox
+ * of every device (peer-visible memory, xGMI stores), finds all partials of a column in its own memory a few steps later,
+ * sums them in device order and goes on with the prox and A_p v while the column tile waits in LDS (csrc/pg_gemv_tn4.hip).
+ * f and the bounded-wait timeout flag are exchanged the same way after the sweep, so a steady-state iteration issues no
+ * collective; initialisation, the line search and the two-sweep fallback still use the registered all-reduce.
+ *   _alloc   this context's inbox (fine-grained device memory, zeroed; freed with the context)
+ *   _export  its IPC handle (64 bytes) for the other processes of the node;  _import  opens a peer's handle here
+ *   pg_ctx_set_row_team(ctx, nranks, rank, inboxes, max_workgroups): inboxes[q] = device q's inbox as mapped into THIS
+ *            process (inboxes[rank] = the own one); max_workgroups = workgroups per device (0: one per compute unit),
+ *            the same on every device; nranks <= 1 switches the mode off.  2..16 devices, row blocks of at most 16384
+ *            (Float32) / 8192 (Float64) rows per device, fixed step (the adaptive step keeps the two-sweep path). */
+pg_status pg_ctx_row_team_alloc(pg_ctx* ctx, void** inbox_out, int64_t* bytes_out);
+pg_status pg_ctx_row_team_export(pg_ctx* ctx, void* handle_out /* 64 bytes */);
+pg_status pg_ctx_row_team_import(pg_ctx* ctx, const void* handle /* 64 bytes */, void** inbox_out);
+pg_status pg_ctx_set_row_team(pg_ctx* ctx, int32_t nranks, int32_t rank, void* const* inboxes, int32_t max_workgroups);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every

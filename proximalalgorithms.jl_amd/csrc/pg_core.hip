@@ -63,6 +63,9 @@ pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out) {
 pg_status pg_ctx_destroy(pg_ctx* c) {
   if (!c) return PG_OK;
   if (c->comm) (void)pg_ctx_comm_destroy(c);
+  for (void* p : c->rteam_imported) (void)hipIpcCloseMemHandle(p);
+  if (c->rteam.own) (void)hipFree(c->rteam.own);
+  if (c->rteam.f_local) (void)hipFree(c->rteam.f_local);
   if (c->red_partials) (void)hipFree(c->red_partials);
   if (c->red_counter) (void)hipFree(c->red_counter);
   if (c->hscal) (void)hipHostFree(c->hscal);
@@ -169,6 +172,73 @@ pg_status pg_graph_destroy(pg_graph* g) {
 pg_status pg_ctx_profile_enable(pg_ctx* c, int32_t enable) {
   PG_REQUIRE(c != nullptr, "ctx is null");
   c->profiling = enable != 0;
+  return PG_OK;
+}
+
+// ---- row teams (pg_gemv_tn4.hip) --------------------------------------------------------------------------------
+pg_status pg_ctx_row_team_alloc(pg_ctx* c, void** inbox_out, int64_t* bytes_out) {
+  PG_REQUIRE(c != nullptr && inbox_out != nullptr, "null argument");
+  const size_t bytes = pgtn::peer_inbox_bytes();
+  if (c->rteam.own == nullptr) {
+    PG_HIP(hipSetDevice(c->device));
+    // uncached / fine-grained device memory: a peer's stores must become visible to a running kernel of this device
+    hipError_t e = hipExtMallocWithFlags(&c->rteam.own, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipExtMallocWithFlags(&c->rteam.own, bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      pg_set_error("allocation of the row-team inbox (%zu bytes of fine-grained device memory) failed: %s", bytes, hipGetErrorString(e));
+      return PG_ERR_ALLOC;
+    }
+    PG_HIP(hipMemset(c->rteam.own, 0, bytes));
+    if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, sizeof(double)));
+  }
+  *inbox_out = c->rteam.own;
+  if (bytes_out) *bytes_out = (int64_t)bytes;
+  return PG_OK;
+}
+
+pg_status pg_ctx_row_team_export(pg_ctx* c, void* handle_out) {
+  PG_REQUIRE(c != nullptr && handle_out != nullptr, "null argument");
+  PG_REQUIRE(c->rteam.own != nullptr, "pg_ctx_row_team_alloc has not been called");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI passes IPC handles as 64 bytes");
+  hipIpcMemHandle_t h;
+  PG_HIP(hipIpcGetMemHandle(&h, c->rteam.own));
+  memcpy(handle_out, &h, sizeof(h));
+  return PG_OK;
+}
+
+pg_status pg_ctx_row_team_import(pg_ctx* c, const void* handle, void** inbox_out) {
+  PG_REQUIRE(c != nullptr && handle != nullptr && inbox_out != nullptr, "null argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  PG_HIP(hipSetDevice(c->device));
+  void* p = nullptr;
+  PG_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  c->rteam_imported.push_back(p);
+  *inbox_out = p;
+  return PG_OK;
+}
+
+pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* const* inboxes, int32_t max_workgroups) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  if (nranks <= 1) {
+    c->rteam.n = 0;
+    return PG_OK;
+  }
+  PG_REQUIRE(nranks <= 16 && rank >= 0 && rank < nranks && inboxes != nullptr, "a row team has 2..16 devices");
+  PG_REQUIRE(max_workgroups >= 0, "negative workgroup count");
+  for (int q = 0; q < nranks; ++q) PG_REQUIRE(inboxes[q] != nullptr, "an inbox pointer is null");
+  PG_REQUIRE(c->rteam.own != nullptr && inboxes[rank] == c->rteam.own, "inboxes[rank] must be this context's own inbox (pg_ctx_row_team_alloc)");
+  c->rteam.n = nranks;
+  c->rteam.rank = rank;
+  c->rteam.max_wgs = max_workgroups;
+  for (int q = 0; q < 16; ++q) c->rteam.inbox[q] = q < nranks ? inboxes[q] : nullptr;
+  // epochs restart together: every device of the team makes this call at the same point of the program
+  c->rteam.epoch = c->rteam.scal_epoch = 0;
+  PG_HIP(hipMemset(c->rteam.own, 0, pgtn::peer_inbox_bytes()));
   return PG_OK;
 }
 

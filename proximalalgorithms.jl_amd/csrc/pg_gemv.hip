@@ -721,8 +721,14 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
                           const T* g_v0, const T* g_v1) {
   pg_ctx* c = f->ctx;
   pg_mat* A = f->A;
-  if (pg_row_sharded(c) || !tn_supported<T>(A)) {
-    pg_set_error("the single-sweep pass needs an unsharded or column-sharded operator with at most %d rows",
+  // row shards: only as a row TEAM (pg_ctx_set_row_team): the devices exchange the per-column partial dots inside the sweep
+  const bool rteam = pg_row_sharded(c) && c->rteam.n > 1;
+  if (rteam && !tn_peer_covers((int)(A->ld / (1024 / (int64_t)sizeof(T))))) {
+    pg_set_error("a row-team sweep covers row blocks of at most %d rows per device", (int)(64 * (1024 / sizeof(T))));
+    return PG_ERR_UNSUPPORTED;
+  }
+  if ((pg_row_sharded(c) && !rteam) || !tn_supported<T>(A)) {
+    pg_set_error("the single-sweep pass needs an unsharded or column-sharded operator (or a row team) with at most %d rows",
                  (int)(1024 * (1024 / sizeof(T))));  // 1024 row groups: teams of up to 16 workgroups (pg_gemv_tn2.hip)
     return PG_ERR_UNSUPPORTED;
   }
@@ -758,7 +764,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   a.scal_out = c->dscal + PG_S_GZ;
   a.line_cols = env_int("PG_TN_LINE_COLS", 0) > 0 ? env_int("PG_TN_LINE_COLS", 0) : 32;  // experiments: 1 = dealt one by one (rounds 1-2)
   int blocks = 0;
-  const pg_status launched = launch_tn<T>(A, a, &blocks);
+  const pg_status launched = rteam ? launch_tn_peer<T>(A, a, &blocks) : launch_tn<T>(A, a, &blocks);
   // Column shards: a sweep refused on THIS rank only (a cooperative launch that does not fit next to something else on the
   // device) must not leave the peers alone in this step's all-reduce.  The rank posts the same collective with an empty
   // m-vector and its refused flag set; every rank then sees PG_ERR_UNSUPPORTED at the scalar read-back, drops the step
@@ -800,12 +806,16 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
     if (r_dst == (T*)f->r) f->r_gen++;
     return PG_OK;
   }
-  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
-  hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
-                     (const T*)A->partials, A->ld, A->m, blocks, (const T*)f->b, r_dst,
-                     r_dst == (T*)f->r ? A->ld : A->m /* only f->r is padded to ld */, 0.5 * f->lam,
-                     c->red_partials, c->red_counter, f_dst, (T*)nullptr, ColPack<T>{});
-  PG_LAUNCH_CHECK();
+  {
+    pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, true>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
+                       (const T*)A->partials, A->ld, A->m, blocks, (const T*)f->b, r_dst,
+                       r_dst == (T*)f->r ? A->ld : A->m /* only f->r is padded to ld */, 0.5 * f->lam,
+                       c->red_partials, c->red_counter, rteam ? c->rteam.f_local : f_dst, (T*)nullptr, ColPack<T>{});
+    PG_LAUNCH_CHECK();
+  }
+  // row team: f = sum_p 1/2 lam ||A_p v - b_p||^2 and the devices' timeout flags, exchanged like the dots (no collective)
+  if (rteam) PG_TRY(peer_scalar_exchange(c, c->rteam.f_local, f_dst != nullptr ? f_dst : c->rteam.f_local));
   if (r_dst == (T*)f->r) f->r_gen++;
   return PG_OK;
 }
@@ -967,7 +977,10 @@ pg_status pg_ls_allreduce_epilogue_scalars(pg_ls* f) {
 
 bool pg_ls_fused_pass_supported(const pg_ls* f) {
   const pg_ctx* c = f->ctx;
-  if (pg_row_sharded(c)) return false;
+  if (pg_row_sharded(c)) {  // as a row team only (pg_gemv_tn4.hip)
+    const int64_t nrg = f->A->ld / (1024 / (int64_t)pg_sizeof(f->A->dtype));
+    return c->rteam.n > 1 && f->A->m > 0 && f->A->n > 0 && tn_peer_covers((int)nrg);
+  }
   return f->A->dtype == PG_F32 ? tn_supported<float>(f->A) : tn_supported<double>(f->A);
 }
 

@@ -86,6 +86,10 @@ struct TNArgs {
   unsigned tag_base = 0;  // launch epoch << 24: the tag of step i is tag_base + i + 1, so granules of earlier launches never match
   unsigned long long* xch = nullptr;  // [nteams][ring][team_size * C * granules-per-value]
   double* team_err = nullptr;         // set to 1 when a team member gave up waiting (bounded spin)
+  // PEER teams (row blocks on several devices, pg_gemv_tn4.hip): this device's index, the number of devices, and every
+  // device's inbox ring as mapped into THIS device's address space (peer_ring[peer_rank] == xch)
+  int peer_n = 0, peer_rank = 0;
+  unsigned long long* peer_ring[16] = {};
 #ifdef PG_TNT_EXPERIMENT
   int dbg = 0;  // timing experiments of the team kernel (wrong results): see pg_gemv_tn2.hip
 #endif
@@ -451,6 +455,11 @@ template <typename T>
 pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out);
 template <typename T>
 pg_status launch_tn_coop(pg_mat* A, TNArgs<T>& a, int* blocks_out);
+// PEER teams: the same sweep with the rows of a column on several DEVICES (pg_gemv_tn4.hip; pg_ctx_set_row_team)
+bool tn_peer_covers(int nrg);
+template <typename T>
+pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out);
+pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out);
 // gemv_tnm_kernel: 29 .. 128 row groups, the headline's 64 among them (pg_gemv_tn3.hip)
 bool tn_mid_covers(int nrg);
 template <typename T>

@@ -431,341 +431,7 @@ pg_status launch_tnc(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   return PG_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// LONG columns: teams of workgroups
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int TEAM_MEMBER_RG = 64;              // a member holds WAVES * U = 64 row groups of every column (16384 rows in Float32)
-constexpr int TEAM_MAX = 16;                    // members per team: up to 1024 row groups (262144 rows f32, 131072 f64)
-constexpr int TEAM_RING = 8;                    // granule ring slots per team (>= 2 LAG + 2, see the protocol note)
-constexpr long long TEAM_SPIN_LIMIT = 1 << 21;  // polls before a member gives up (~ seconds): bounded, never a hang
-
-template <typename T, int C>
-struct Pending {
-  unsigned long long w;  // this lane's granule of the awaited step
-  T xs[C], zos[C];       // the columns' x_j and z_old_j, fetched together with the poll
-};
-
-// Protocol.  Step i of a team = column group map.at(i) (CgMap, pg_gemv_tn.h: chunks of whole output lines per team).  Member p writes its C partial dots of step i as
-// granules {value bits (32 per granule; an f64 takes two), tag = i + 1} into ring slot i % TEAM_RING at offset
-// (p * C + c) * G + h with ONE 8-byte agent-scope store each, so a reader that sees the tag sees the value.  Every wave
-// of every member polls the team_size * C * G granules of a step (one lane per granule), then sums the values in member
-// order.  A member posts step i only after it has consumed step i - LAG - 1, i.e. after ALL members have posted step
-// i - LAG - 1, which each of them did after consuming step i - 2 LAG - 2: a ring of 2 LAG + 2 slots is never
-// overwritten before everyone has read it.  Tags carry the launch epoch in their high byte (tag = epoch << 24 | i + 1, i + 1
-// < 2^24), so the ring needs no zeroing between launches: every slot is rewritten by every launch (the step count of a
-// matrix is fixed), and a granule left by the launch 256 epochs ago has been overwritten 255 times since.
-//
-// Where the column tiles live.  PF + 1 register tiles rotate (one being dotted, PF being loaded), as in
-// gemv_tn_kernel.  A tile whose totals are still travelling (LAG > 0) is parked in LDS -- LAG slots of
-// WAVES * C * U KiB, 128 KiB of the CU's 160 KiB at the default geometry -- and read back, 16 bytes per lane at a time,
-// for the A v accumulation: every wave touches only its own region of a slot (no barrier), reads the slot of step
-// i - LAG and then parks step i in the same slot.  (Keeping the waiting tiles in registers was tried first: the kernel
-// then needs ~340 VGPRs and spills whole tiles to scratch.)
-//
-// What the loop body may not contain (each cost a factor on the device, all seen in the disassembly): a branch around any
-// of the streaming loads, taken or not -- the compiler then no longer counts the loads in flight and waits for ALL of them
-// (s_waitcnt vmcnt(0)) before every dot product; a load inside the retry loop of the poll without a first look outside
-// it -- same effect at the loop header; the small loads (poll, x_j, z_old_j) issued AFTER the tile loads -- they return
-// in order, so reading them waits for the tile too.  Hence: a branch-free steady-state loop (ALL = true) between a
-// conditional head and tail, row groups past the end of a column clamped (masked through r = 0) instead of skipped.
-template <typename T, int U, int C, int WAVES, int LAG, int PF = 1>
-__global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
-  using V = typename VecOf<T>::type;
-  constexpr int VEC = VecOf<T>::N;
-  constexpr int G = (int)sizeof(T) / 4;  // granules per value
-  static_assert(2 * LAG + 2 <= TEAM_RING, "granule ring too short for this lag");
-  static_assert(TEAM_MAX * C * G <= 64, "one lane per granule of a step");
-  __shared__ T sm_dot[2][C][WAVES];
-  extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
-  V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][WAVES][C][U][64]
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int team = (int)(blockIdx.x % (unsigned)a.nteams);
-  const int member = (int)(blockIdx.x / (unsigned)a.nteams);
-  const int TM = a.team_size;
-  const int npoll = TM * C * G;
-  const int64_t ncg = (a.n + C - 1) / C;
-  const CgMap map(ncg, C, a.line_cols, team, a.nteams);  // step i of this team = column group map.at(i)
-  const int64_t cnt = map.cnt;
-  const int rg0 = (member * WAVES + wave) * a.ueff;  // this wave's first row group: a contiguous run of ueff <= U KiB of each column
-  unsigned long long* const ring = a.xch + (size_t)team * TEAM_RING * (size_t)(TEAM_MAX * C * G);
-
-  V rk[U], racc[U];
-  int rgc[U];  // row groups past the end of the column are clamped to the last one; their r is zero
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    rgc[u] = min(rg0 + min(u, a.ueff - 1), a.nrg - 1);  // past the run: the wave's own last row group again (a cached load)
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
-    if (u < a.ueff && rg0 + u < a.nrg) {
-      rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)(rg0 + u) * (WAVE * VEC) + lane * VEC);
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) rk[u][e] = T(0);
-    }
-  }
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  bool dead = false;  // wave-uniform: a poll timed out, stop waiting (the launch is reported as failed)
-
-  struct Tile {
-    V col[C][U];
-  };
-  auto load = [&](Tile& t, int64_t i) __attribute__((always_inline)) {
-    const int64_t j0 = map.at(i) * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
-      // wave-uniform base (scalar registers) + one shared per-lane offset: no 64-bit vector address per load
-      const T* __restrict__ p = a.A + j * a.ld;
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        t.col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rgc[u] * (WAVE * VEC)) + lane);
-    }
-  };
-  // this member's partial dots of step i -> ring
-  auto dot_post = [&](const Tile& t, int64_t i) __attribute__((always_inline)) {
-    const int buf = (int)(i & 1);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      T d = T(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) d = fma(t.col[c][u][e], rk[u][e], d);
-      }
-      d = wave_allsum(d);
-      if (lane == 0) sm_dot[buf][c][wave] = d;
-    }
-    __syncthreads();
-    if (wave == 0 && lane < C * G) {
-      T mine = T(0);
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        T s = sm_dot[buf][c][0];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += sm_dot[buf][c][w];
-        if (lane / G == c) mine = s;
-      }
-      unsigned bits;
-      if constexpr (G == 1) {
-        bits = __builtin_bit_cast(unsigned, mine);
-      } else {
-        const unsigned long long b = __builtin_bit_cast(unsigned long long, mine);
-        bits = (lane % G) == 0 ? (unsigned)b : (unsigned)(b >> 32);
-      }
-      const unsigned long long word = ((unsigned long long)(a.tag_base + (unsigned)(i + 1)) << 32) | bits;
-      __hip_atomic_store(ring + (size_t)(i % TEAM_RING) * (TEAM_MAX * C * G) + (size_t)member * (C * G) + lane, word,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  const int poll_lane = lane < npoll ? lane : npoll - 1;  // every lane polls (no exec-masked load): lanes >= npoll repeat the last granule
-  auto poll_word = [&](int64_t i) __attribute__((always_inline)) -> unsigned long long {
-    return __hip_atomic_load(ring + (size_t)(i % TEAM_RING) * (TEAM_MAX * C * G) + poll_lane, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto fetch_xz = [&](Pending<T, C>& pd, int64_t i) __attribute__((always_inline)) {
-    const int64_t j0 = map.at(i) * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
-      pd.xs[c] = a.x[jc];
-      pd.zos[c] = a.z_old[jc];
-    }
-  };
-  // totals of step i (all members have posted, or will shortly) -> epilogue -> v_j (0 for columns past the end)
-  auto totals = [&](int64_t i, Pending<T, C>& pd, T (&vj)[C]) __attribute__((always_inline)) {
-    const unsigned tag = a.tag_base + (unsigned)(i + 1);
-#ifdef PG_TNT_EXPERIMENT
-    if (a.dbg & 1) dead = true;  // timing experiment: never wait (totals are then wrong)
-#endif
-    // The first look at the granules stays OUTSIDE the retry loop (see the note above the kernel).
-    if (!dead && __builtin_amdgcn_ballot_w64((unsigned)(pd.w >> 32) == tag) != ~0ull) {
-      long long spins = 0;
-      for (;;) {
-        __builtin_amdgcn_s_sleep(1);
-        pd.w = poll_word(i);
-        if (__builtin_amdgcn_ballot_w64((unsigned)(pd.w >> 32) == tag) == ~0ull) break;
-        if (++spins > TEAM_SPIN_LIMIT) {
-          dead = true;
-          if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    const int w_lo = (int)(unsigned)pd.w;
-    const int64_t j0 = map.at(i) * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      T g = T(0);
-      for (int p = 0; p < TM; ++p) {  // member order: every member forms the same bits
-        const int idx = (p * C + c) * G;
-        if constexpr (G == 1) {
-          g += __builtin_bit_cast(float, __builtin_amdgcn_readlane(w_lo, idx));
-        } else {
-          const unsigned lo = (unsigned)__builtin_amdgcn_readlane(w_lo, idx);
-          const unsigned hi = (unsigned)__builtin_amdgcn_readlane(w_lo, idx + 1);
-          g += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-        }
-      }
-      const int64_t j = j0 + c;
-      const bool valid = j < a.n;
-      if (a.lam_ls != T(1)) g = a.lam_ls * g;
-      const T xj = pd.xs[c], zo = pd.zos[c];
-      const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
-      T zj;                            // :118 / :141
-      if (a.g_kind == PG_G_NORML1) {
-        T th = a.p0;
-        if (a.p0v != nullptr) th = pg_l1w_threshold(a.gamma, a.p0v[valid ? j : a.n - 1]);  // per-element weights lam_j
-        zj = yj <= -th ? yj + th : (yj >= th ? yj - th : T(0));
-      } else if (a.g_kind == PG_G_INDBOX) {
-        T lo = a.p0, hi = a.p1;
-        if (a.p0v != nullptr) lo = a.p0v[valid ? j : a.n - 1], hi = a.p1v[valid ? j : a.n - 1];  // per-element bounds
-        zj = fmin(hi, fmax(lo, yj));
-      } else
-        zj = yj;
-      const T rj = xj - zj;                             // :120 / :142
-      vj[c] = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);   // fast_forward_backward.jl:135 of the next iteration
-      if (member == 0 && (int)threadIdx.x == c && valid) {
-        a.g_out[j] = g;
-        a.y[j] = yj;
-        a.z_new[j] = zj;
-        a.res[j] = rj;
-        if (a.v_out != nullptr) a.v_out[j] = vj[c];
-        if (a.g_kind == PG_G_NORML1) acc[0] += a.p0v != nullptr ? (double)a.p0v[j] * fabs((double)zj) : fabs((double)zj);
-        acc[1] = fmax(acc[1], fabs((double)rj));
-        acc[2] += (double)g * (double)rj;
-        acc[3] += (double)rj * (double)rj;
-      }
-    }
-  };
-  auto park_slot = [&](int64_t i) { return park + ((size_t)(LAG > 0 ? i % (LAG > 0 ? LAG : 1) : 0) * WAVES + wave) * (C * U * WAVE) + lane; };
-
-  // One step: [poll the totals of step i - LAG, fetch its x_j / z_old_j] [start loading tile i + 1 into `nxt`]
-  // [dot + post tile i = `cur`] [totals of step i - LAG -> v_j ; A v accumulation from the parked tile] [park `cur`].
-  // ALL = steady state: every part runs, no branch.
-  auto step = [&](auto allc, Tile& cur, Tile& nxt, int64_t i) __attribute__((always_inline)) {
-    constexpr bool ALL = decltype(allc)::value;
-    if (!ALL && i >= cnt + LAG) return;
-    const bool has_fma = ALL || i >= LAG;
-    Pending<T, C> pd{};
-    // scheduling fences around the load issue: `nxt` is the register tile the previous step read last; without them the
-    // scheduler hoists these loads above that step's multiply-adds into fresh registers and the kernel spills
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_fma) {
-      if constexpr (LAG > 0) pd.w = poll_word(i - LAG);  // issued BEFORE the next tile's loads: it returns first
-      fetch_xz(pd, i - LAG);
-    }
-    if (ALL || i + PF < cnt) load(nxt, i + PF);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ALL || i < cnt) dot_post(cur, i);
-    if constexpr (LAG == 0) {
-      if (has_fma) pd.w = poll_word(i);
-    }
-    if (has_fma) {
-      T vj[C];
-      totals(i - LAG, pd, vj);
-      if constexpr (LAG == 0) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(cur.col[c][u][e], vj[c], racc[u][e]);
-          }
-        }
-#ifdef PG_TNT_EXPERIMENT
-      } else if (a.dbg & 2) {  // timing experiment: no LDS read-back (wrong tile)
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(cur.col[c][u][e], vj[c], racc[u][e]);
-          }
-        }
-#endif
-      } else {
-        // Four 16-byte reads at a time.  Left alone the compiler issues all C * U reads up front (C * U * 4 registers) and,
-        // for two columns per step, makes room by spilling the tile that is in flight.  The address of every chunk depends
-        // (through an opaque v_mov that always yields 0) on an accumulator of the previous chunk, which pins the order
-        // read 4 -> multiply-add 4 -> read 4 ...
-        const V* __restrict__ src = park_slot(i - LAG);
-        int dep = 0;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-#pragma unroll
-          for (int u0 = 0; u0 < U; u0 += 4) {
-            const V* __restrict__ sp = src + dep;
-            V col[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (u0 + k < U) col[k] = sp[(c * U + u0 + k) * WAVE];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (u0 + k < U) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) racc[u0 + k][e] = fma(col[k][e], vj[c], racc[u0 + k][e]);
-              }
-            }
-            asm volatile("v_mov_b32 %0, 0" : "=v"(dep) : "v"(racc[u0][0]));
-          }
-        }
-      }
-    }
-    // Pin the accumulators HERE.  Their only use is at the end of the kernel, so the compiler is free to sink this step's
-    // multiply-adds into the next step (keeping this step's tile alive across it: +C * U * 4 registers, whole tiles spilled).
-#pragma unroll
-    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(racc[u]));
-    if constexpr (LAG > 0) {
-#ifdef PG_TNT_EXPERIMENT
-      if (!(a.dbg & 4))
-#endif
-      if (ALL || i < cnt) {  // same slot as the tile just read: this wave's region only, program order suffices
-        V* __restrict__ dst = park_slot(i);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) dst[(c * U + u) * WAVE] = cur.col[c][u];
-        }
-      }
-    }
-  };
-
-  // PF + 1 register tiles rotate: tile i is dotted while tiles i + 1 .. i + PF are in flight.  Named variables, not an
-  // array: an array of tiles handed to the step by reference ends up in scratch memory.
-  constexpr int NR = PF + 1;
-  static_assert(NR == 2 || NR == 3, "two or three register tiles");
-  Tile ta, tb, tc;
-  if (cnt > 0) load(ta, 0);
-  if constexpr (PF > 1) {
-    if (cnt > 1) load(tb, 1);
-  }
-  auto round = [&](auto allc, int64_t base) __attribute__((always_inline)) {
-    if constexpr (NR == 2) {
-      step(allc, ta, tb, base);
-      step(allc, tb, ta, base + 1);
-    } else {  // tile i in t[i % 3], loading tile i + 2 into t[(i + 2) % 3]
-      step(allc, ta, tc, base);
-      step(allc, tb, ta, base + 1);
-      step(allc, tc, tb, base + 2);
-    }
-  };
-  constexpr int64_t HEAD = (LAG + NR - 1) / NR * NR;  // first round boundary from which every step has totals to consume
-  int64_t base = 0;
-  for (; base < HEAD && base < cnt + LAG; base += NR) round(std::false_type{}, base);
-  if (base + NR + PF <= cnt) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the steady loop starts from a state the compiler knows exactly
-    for (; base + NR + PF <= cnt; base += NR) round(std::true_type{}, base);
-  }
-  for (; base < cnt + LAG; base += NR) round(std::false_type{}, base);
-  // this member's rows of the team's partial of A v
-  T* part = a.partials + (int64_t)team * a.ld + lane * VEC;
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (u < a.ueff && rg0 + u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)(rg0 + u) * (WAVE * VEC)) = racc[u];
-  const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
-  grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
-}
+#include "pg_gemv_tnt.h"  // gemv_tnt_kernel: the team sweep (shared with pg_gemv_tn4.hip)
 
 template <typename T, int U, int C, int LAG, int PF, int WAVES>
 pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {

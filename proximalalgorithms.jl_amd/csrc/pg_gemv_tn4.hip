@@ -1,0 +1,204 @@
+// Row teams: north_star's ROW layout (GPU p holds the row block A_p, the n-vectors are replicated) at ONE read of A per
+// iteration.
+//
+// benchmark/benchmarks.jl:15-16 are two products: res = A x - b, then A' res.  Under row blocks A' res = sum_p A_p' res_p is
+// needed globally before the prox, so the row-sharded iteration reads its block twice: sweep, all-reduce of
+// n + 1 elements, replicated epilogue, sweep.  Here the devices form PEER teams instead (gemv_tnt_kernel<..., PEER>,
+// pg_gemv_tnt.h): workgroup w of every device walks the same column groups in the same order; for a column j device p forms
+// its partial dot A_p[:, j]' res_p and pushes it, as one tagged 8-byte granule, into the inbox of every device; LAG steps
+// later every device finds all partials in its OWN memory, sums them in device order (the same bits everywhere), applies
+// the prox and accumulates A_p[:, j] v_j from the tile that waited in LDS.  What crosses the fabric per iteration is
+// 8 (N - 1) n bytes of granule pushes per device (58 MB at N = 8, n = 2^20) instead of a 4 MiB all-reduce -- more bytes, but
+// no second read of the 8 GiB block.  After the sweep: r_p = A_p v - b_p and 1/2 ||r_p||^2 locally (gemv_n_finish), then
+// peer_scalars_kernel exchanges { 1/2 ||r_p||^2, this device's timeout flag } the same way, so that f and the decision to
+// fall back are the same on every device without a collective.
+//
+// Reference statements: benchmark/benchmarks.jl:15-16, fast_forward_backward.jl:135-142 (forward_backward.jl:113-120).
+#include <mutex>
+#include <type_traits>
+
+#include "pg_gemv_tn.h"
+
+namespace pgtn {
+namespace {
+#include "pg_gemv_tnt.h"
+
+constexpr int PEER_TEAMS_MAX = 256;  // workgroups per device the inbox has ring space for
+constexpr size_t PEER_RING_BYTES = (size_t)PEER_TEAMS_MAX * PEER_RING * (size_t)(TEAM_MAX * 4 * 2) * sizeof(unsigned long long);  // C * G <= 8
+constexpr int PEER_SCAL_GRANULES = 4;  // per device and slot: f (two halves), the timeout flag, one spare
+constexpr size_t PEER_SCAL_BYTES = 2 * (size_t)TEAM_MAX * PEER_SCAL_GRANULES * sizeof(unsigned long long);
+
+struct PeerScalArgs {
+  int n, rank;
+  unsigned tag;
+  int slot;
+  unsigned long long* inbox[TEAM_MAX];  // every device's scalar inbox as seen from here
+  const double* f_local;                // this device's 1/2 lam ||r_p||^2
+  double* f_out;                        // sum over the devices, in device order
+  double* team_err;                     // in: this device's flag; out: any device's
+};
+
+// one wave: post {f lo, f hi, err} into every inbox, wait for all of them here, combine in device order
+__global__ __launch_bounds__(64) void peer_scalars_kernel(PeerScalArgs p) {
+  const int lane = threadIdx.x;
+  const double f = *p.f_local;
+  const unsigned long long fb = __builtin_bit_cast(unsigned long long, f);
+  const unsigned err = *p.team_err != 0.0 ? 1u : 0u;
+  const size_t base = (size_t)p.slot * TEAM_MAX * PEER_SCAL_GRANULES;
+  if (lane < 3) {
+    const unsigned bits = lane == 0 ? (unsigned)fb : (lane == 1 ? (unsigned)(fb >> 32) : err);
+    const unsigned long long word = ((unsigned long long)p.tag << 32) | bits;
+    for (int q = 0; q < p.n; ++q)
+      __hip_atomic_store(p.inbox[q] + base + (size_t)p.rank * PEER_SCAL_GRANULES + lane, word, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const int npoll = p.n * PEER_SCAL_GRANULES;
+  int pl = lane < npoll ? lane : npoll - 1;
+  if ((pl & 3) == 3) pl -= 1;  // the spare granule is never written: look at the flag granule instead
+  const unsigned long long* src = p.inbox[p.rank] + base + pl;
+  unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  bool dead = false;
+  long long spins = 0;
+  while (__builtin_amdgcn_ballot_w64((unsigned)(w >> 32) == p.tag) != ~0ull) {
+    __builtin_amdgcn_s_sleep(2);
+    w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (++spins > TEAM_SPIN_LIMIT) {
+      dead = true;
+      break;
+    }
+  }
+  const int lo = (int)(unsigned)w;
+  double total = 0.0;
+  unsigned any = dead ? 1u : 0u;
+  for (int q = 0; q < p.n; ++q) {
+    const unsigned l0 = (unsigned)__shfl(lo, q * PEER_SCAL_GRANULES + 0);
+    const unsigned l1 = (unsigned)__shfl(lo, q * PEER_SCAL_GRANULES + 1);
+    const unsigned l2 = (unsigned)__shfl(lo, q * PEER_SCAL_GRANULES + 2);
+    total += __builtin_bit_cast(double, ((unsigned long long)l1 << 32) | l0);
+    any |= l2;
+  }
+  if (lane == 0) {
+    *p.f_out = total;
+    if (any) *p.team_err = 1.0;
+  }
+}
+
+template <typename T, int U, int C, int LAG, int PF>
+pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  constexpr int WAVES = 4;
+  constexpr int G = (int)sizeof(T) / 4;
+  static_assert(C * G <= 8, "the inbox holds eight granules per member and step");
+  pg_ctx* c = A->ctx;
+  const pg_row_team& rt = c->rteam;
+  const int64_t ncg = (A->n + C - 1) / C;
+  if (rt.n * C * G > 64) {
+    pg_set_error("a row team of %d devices with %d columns per step needs more than one lane per granule", rt.n, C);
+    return PG_ERR_UNSUPPORTED;
+  }
+  int64_t nteams = rt.max_wgs > 0 ? rt.max_wgs : c->num_cu;
+  if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
+  if (nteams > ncg) nteams = ncg;
+  if (nteams < 1) nteams = 1;
+  PG_TRY(ensure_partials(A, (int)nteams));
+  a.partials = (T*)A->partials;
+  a.team_size = 1;
+  a.ueff = (a.nrg + WAVES - 1) / WAVES;
+  if (a.ueff > U) {
+    pg_set_error("gemv_tnt<U = %d, PEER> launched for %d row groups per wave", U, a.ueff);
+    return PG_ERR_INVALID;
+  }
+  const int64_t steps = (ncg + nteams - 1) / nteams;
+  if (steps + 1 >= (1 << 24)) {
+    pg_set_error("the row-team sweep covers at most 2^24 column groups per workgroup (%lld here)", (long long)steps);
+    return PG_ERR_UNSUPPORTED;
+  }
+  a.nteams = (int)nteams;
+  a.peer_n = rt.n;
+  a.peer_rank = rt.rank;
+  for (int q = 0; q < rt.n; ++q) a.peer_ring[q] = (unsigned long long*)rt.inbox[q];
+  a.xch = a.peer_ring[rt.rank];
+  a.team_err = c->dscal + PG_S_TEAMERR;
+  // every device launches the same sweeps in the same order, so the epochs agree without being communicated
+  c->rteam.epoch = (c->rteam.epoch % 254u) + 1u;
+  a.tag_base = c->rteam.epoch << 24;
+  *blocks_out = (int)nteams;
+  const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
+  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true>);
+  if (lds + 4096 > 64 * 1024) {
+    static std::mutex mu;
+    static bool opted_in[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    const int dev = c->device & 63;
+    if (!opted_in[dev]) {
+      PG_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      opted_in[dev] = true;
+    }
+  }
+  unsigned grid = (unsigned)nteams;
+  c->team_launches++;
+  if (c->test_team_fault > 0 && c->team_launches == c->test_team_fault && grid > 1) {
+    if (c->test_team_fault_kind == 1) {
+      pg_set_error("the row-team sweep was refused (injected by pg_ctx_test_team_fault)");
+      return PG_ERR_UNSUPPORTED;
+    }
+    grid -= 1;  // test hook: one workgroup of this device never starts; its peers on the other devices time out
+  }
+  pg_prof_scope prof(c, PG_K_GEMV_TN);
+  // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead
+  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+}  // namespace
+
+bool tn_peer_covers(int nrg) { return nrg >= 1 && nrg <= 64; }
+
+// Tunables (environment, for experiments): PG_TNP_C, PG_TNP_LAG.
+template <typename T>
+pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+  // One tile (C columns of this device's rows) per step and workgroup is 32 KiB where the block is short enough, so that a
+  // step lasts ~1.2 us at the device's streaming rate and LAG = 4 steps give the granules ~5 us to cross the fabric; LAG
+  // tiles wait in LDS (128 KiB).  16384-row blocks (config 5 on 8 devices) are 64 KiB per step: LAG = 2, ~2.4 us per step.
+  const int per_wave = (a.nrg + 3) / 4;
+  int U = 2;
+  while (U < per_wave) U *= 2;
+  const int C = env_int("PG_TNP_C", U >= 8 ? 1 : 8 / U);
+  const int LAG = env_int("PG_TNP_LAG", U == 16 ? 2 : 4);
+#define PG_TNP_CASE(UU, CC, LL) \
+  if (U == UU && C == CC && LAG == LL) return launch_tnp<T, UU, CC, LL, 2>(A, a, blocks_out)
+  PG_TNP_CASE(2, 4, 4);
+  PG_TNP_CASE(4, 2, 4);
+  PG_TNP_CASE(8, 1, 4);
+  PG_TNP_CASE(16, 1, 2);
+  PG_TNP_CASE(2, 4, 2);
+  PG_TNP_CASE(8, 1, 2);
+#undef PG_TNP_CASE
+  pg_set_error("no row-team instantiation for U=%d C=%d LAG=%d", U, C, LAG);
+  return PG_ERR_UNSUPPORTED;
+}
+template pg_status launch_tn_peer<float>(pg_mat*, TNArgs<float>&, int*);
+template pg_status launch_tn_peer<double>(pg_mat*, TNArgs<double>&, int*);
+
+size_t peer_inbox_bytes() { return PEER_RING_BYTES + PEER_SCAL_BYTES; }
+
+// f_out = sum over the devices of *f_local (device order), PG_S_TEAMERR = any device's flag: one launch, no collective
+pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) {
+  pg_row_team& rt = c->rteam;
+  PeerScalArgs p;
+  p.n = rt.n;
+  p.rank = rt.rank;
+  rt.scal_epoch = (rt.scal_epoch % 0xFFFFFEu) + 1u;
+  p.tag = rt.scal_epoch;
+  p.slot = (int)(rt.scal_epoch & 1u);
+  for (int q = 0; q < TEAM_MAX; ++q)
+    p.inbox[q] = q < rt.n ? (unsigned long long*)((char*)rt.inbox[q] + PEER_RING_BYTES) : nullptr;
+  p.f_local = f_local;
+  p.f_out = f_out;
+  p.team_err = c->dscal + PG_S_TEAMERR;
+  hipLaunchKernelGGL(peer_scalars_kernel, dim3(1), dim3(64), 0, c->stream, p);
+  PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+}  // namespace pgtn

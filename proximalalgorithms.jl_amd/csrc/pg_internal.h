@@ -83,8 +83,25 @@ struct pg_comm {
   int64_t calls = 0, elements = 0;  // telemetry: all-reduces issued through the native path and their total length
 };
 
+// Row teams (pg_ctx_set_row_team): the devices of a row-sharded job exchange per-column partial dots through each other's
+// inbox (peer-visible memory) inside the sweep kernel, so that an iteration reads its row block once (pg_gemv_tn4.hip)
+struct pg_row_team {
+  int n = 0, rank = 0;        // devices in the team (0 / 1: off), this device's index
+  void* inbox[16] = {};       // every device's inbox as mapped HERE (inbox[rank] is this device's own)
+  void* own = nullptr;        // ... allocated by pg_ctx_row_team_alloc (freed with the context)
+  int max_wgs = 0;            // workgroups per device (0: one per compute unit); must be the same on every device
+  unsigned epoch = 0, scal_epoch = 0;  // launch epochs of the granule tags: advance in step on every device
+  double* f_local = nullptr;  // device scalar: this device's 1/2 lam ||r_p||^2 between the finish kernel and the exchange
+};
+
+namespace pgtn {
+size_t peer_inbox_bytes();  // pg_gemv_tn4.hip: granule ring + scalar inbox of one device
+}
+
 struct pg_ctx {
   int device = 0;
+  pg_row_team rteam;
+  std::vector<void*> rteam_imported;  // peers' inboxes opened through IPC handles (closed with the context)
   hipStream_t stream = nullptr;
   hipDeviceProp_t prop{};
   int num_cu = 256;

@@ -455,7 +455,7 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   // one read of A per iteration where the fused sweep applies: FB / FFB with a fixed step, FFB adaptive with the residual
   // pair; host-provided extrapolation coefficients arrive one step at a time, so they need the two-sweep path
   it->single_sweep = o->single_sweep != 0 && pg_ls_fused_pass_supported(f) && !(o->fast && o->seq_kind == PG_SEQ_HOST) &&
-                     (!it->adaptive || (o->fast && reuse));
+                     (!it->adaptive || (o->fast && reuse && !pg_row_sharded(c)));  // (row teams: fixed step only)
   const int nvec = it->single_sweep ? 7 : 6;
   const size_t mb = reuse ? (size_t)pg_round_up((int64_t)((size_t)(f->A->m > 0 ? f->A->m : 1) * pg_sizeof(it->dtype)), 256) : 0;
   PG_HIP(hipSetDevice(c->device));

@@ -8,6 +8,10 @@ Column sharding (``shard="cols"``): every rank holds a column block of A and the
 the residual are replicated.  A' r is then local and what crosses ranks is A x (m elements) plus 8 * world scalar slots (four scalars per rank, each as a hi / lo pair)
 -- ONE all-reduce per iteration, 64x smaller than the row-sharded payload at the headline shape -- so every rank keeps
 the single-sweep iteration (A read once per iteration).
+
+Row teams (``attach_row_team`` / ``row_team_in_process``): the row layout at ONE read of A per iteration -- the GPUs exchange
+the per-column partial dots inside the sweep kernel through each other's inbox (peer-visible memory over xGMI, mapped with
+IPC handles; csrc/pg_gemv_tn4.hip) instead of all-reducing A' r between two sweeps.
 """
 
 def shard_rows(m_global, world_size, rank):
@@ -188,3 +192,65 @@ class NativeRcclComm:
         self._ctx = ctx
         self._calls0, self._elements0 = 0, 0
         self._calls0, self._elements0 = self._stats()
+
+
+def _row_team_alloc(ctx):
+    import ctypes as C
+
+    from ._lib import call
+
+    inbox, nbytes = C.c_void_p(), C.c_int64()
+    call("pg_ctx_row_team_alloc", ctx.handle, C.byref(inbox), C.byref(nbytes))
+    return inbox.value
+
+
+def _row_team_set(ctx, rank, inboxes, max_workgroups):
+    import ctypes as C
+
+    from ._lib import call
+
+    arr = (C.c_void_p * len(inboxes))(*inboxes)
+    call("pg_ctx_set_row_team", ctx.handle, len(inboxes), int(rank), arr, int(max_workgroups))
+    ctx._row_team = (len(inboxes), int(rank), int(max_workgroups))
+
+
+def attach_row_team(ctx, world_size=None, rank=None, group=None, max_workgroups=0):
+    """One process per GPU: make the row-sharded job on ``ctx`` a row team (pg_ctx_set_row_team).  Every rank allocates its
+    inbox, the IPC handles travel with torch.distributed (any backend), every rank opens its peers' inboxes.  The collective
+    registered on the context (TorchDistributedComm / NativeRcclComm, shard="rows") stays in place for initialisation, the
+    line search and the two-sweep fallback.  Call on every rank at the same point of the program."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from ._lib import call
+
+    if world_size is None:
+        world_size, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world_size <= 1:
+        call("pg_ctx_set_row_team", ctx.handle, 0, 0, None, 0)
+        return
+    own = _row_team_alloc(ctx)
+    handle = C.create_string_buffer(64)
+    call("pg_ctx_row_team_export", ctx.handle, handle)
+    handles = [None] * world_size
+    dist.all_gather_object(handles, bytes(handle.raw), group=group)
+    inboxes = []
+    for q, h in enumerate(handles):
+        if q == rank:
+            inboxes.append(own)
+        else:
+            p = C.c_void_p()
+            call("pg_ctx_row_team_import", ctx.handle, C.create_string_buffer(h, 64), C.byref(p))
+            inboxes.append(p.value)
+    _row_team_set(ctx, rank, inboxes, max_workgroups)
+    dist.barrier(group=group)  # nobody sweeps before every inbox is mapped and zeroed
+
+
+def row_team_in_process(contexts, max_workgroups=0):
+    """Several contexts of ONE process as a row team (plain device pointers, no IPC): contexts[p] plays device p.  On a
+    one-GPU box this runs the whole protocol between streams of the same device, each context limited to
+    ``max_workgroups`` workgroups so that all members are resident together (tests; a functional check, not a layout)."""
+    inboxes = [_row_team_alloc(c) for c in contexts]
+    for p, c in enumerate(contexts):
+        _row_team_set(c, p, inboxes, max_workgroups)

@@ -30,3 +30,49 @@ class ScaleComm:
         ctx.set_allreduce(fn)
         if self.overlap:
             ctx.set_allreduce_async(fn, wait)
+
+
+class ThreadAllReduce:
+    """Test double for the collective between SEVERAL CONTEXTS OF ONE PROCESS, one host thread per context (the row-team
+    test on a one-GPU box): a SUM all-reduce through the host -- every rank downloads its payload, the ranks meet at a
+    barrier, each sums the payloads in rank order and uploads the result.  ``view(rank)`` is what a LeastSquares takes as
+    ``comm``."""
+
+    def __init__(self, world_size):
+        import threading
+
+        self.world_size = int(world_size)
+        self.barrier = threading.Barrier(self.world_size)
+        self.slots = [None] * self.world_size
+        self.calls = [0] * self.world_size
+
+    def view(self, rank):
+        outer = self
+
+        class _Rank:
+            world_size, shard = outer.world_size, "rows"
+
+            def attach(self, ctx):
+                import ctypes as C
+
+                import numpy as np
+
+                from proximalalgorithms.jl_amd._lib import call
+                from proximalalgorithms.jl_amd.device import _PG2NP
+
+                def fn(ptr, count, pg_dtype, stream):
+                    outer.calls[rank] += 1
+                    host = np.empty(count, _PG2NP[pg_dtype])
+                    call("pg_memcpy_d2h", ctx.handle, host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), host.nbytes)
+                    outer.slots[rank] = host
+                    outer.barrier.wait(timeout=120)
+                    total = outer.slots[0].copy()
+                    for q in range(1, outer.world_size):
+                        total += outer.slots[q]
+                    outer.barrier.wait(timeout=120)  # nobody overwrites a slot before everybody has summed
+                    call("pg_memcpy_h2d", ctx.handle, C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), total.nbytes)
+
+                ctx.set_allreduce(fn)
+                ctx.set_column_sharding(0, rank)
+
+        return _Rank()

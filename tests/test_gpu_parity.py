@@ -792,6 +792,49 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, cols, bat
     assert by_k[2] == 1 and by_k[3] == 2 and by_k[6] == 2 and by_k[7] == 2, by_k  # two sweeps from the refusal on
 
 
+@pytest.mark.parametrize("args,checks", [
+    (["--m", "4096", "--n", "8192"], dict()),                                   # 2 ranks x 2048 rows: U = 2, C = 4, LAG = 4
+    (["--m", "32768", "--n", "4096"], dict()),                                  # 2 x 16384 rows (config 5's block): U = 16, LAG = 2
+    (["--m", "2048", "--n", "8192", "--dtype", "f64"], dict(tol=1e-11)),         # Float64: two granules per value
+    (["--m", "16384", "--n", "4096", "--ranks", "8"], dict()),                  # 8 ranks x 2048 rows: the headline's N = 8 block
+    (["--m", "6144", "--n", "4096", "--ranks", "3", "--fast", "0", "--g", "box"], dict()),  # ForwardBackward + IndBox, 3 ranks
+    (["--m", "4096", "--n", "8192", "--fault", "3"], dict(fault_step=3)),       # rank 1 loses a workgroup in its 3rd sweep
+])
+def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
+    """north_star's ROW layout at one read of A per iteration, exercised on ONE GPU.  The ranks
+    are contexts of one process (one thread and one stream each, num_cu / ranks workgroups each so that all members are
+    resident together); workgroup w of every rank walks the same columns, the per-column partial dots travel as tagged
+    8-byte granules into every rank's inbox and are summed in rank order (csrc/pg_gemv_tn4.hip).  Asserted: the iterates
+    of EVERY rank equal the CPU restatement on the whole matrix (1e-5 max(1, |z|) in Float32), the ranks agree
+    bit for bit, from the second step on every step is ONE read of the row block, and the whole solve issues two
+    all-reduces (initialisation) -- none in the steady state.  fault: a member that never starts makes its peers' bounded
+    waits expire; the flag travels with the scalar exchange, every rank redoes THAT step with two sweeps + the registered
+    all-reduce and returns to one read of A."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "row_team.py"), "--steps", "12"] + args,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    assert d["team"] and d["ranks_agree_bitwise"], d
+    tol = checks.get("tol", 1e-5)
+    fault = checks.get("fault_step")
+    for rows in d["steps"]:
+        for r in rows:
+            assert r["dz"] <= tol * r["z_scale"], r
+        flagged = [r["k"] for r in rows if r["flags"] & d["fallback_flag"]]
+        assert flagged == ([fault] if fault else []), flagged
+        by_k = {r["k"]: r["a_passes"] for r in rows}
+        steady = [k for k in by_k if k >= 2 and (not fault or k not in (fault, fault + 1))]
+        assert all(by_k[k] == 1 for k in steady), by_k
+        if fault:
+            assert by_k[fault] >= 2, by_k
+    assert all(c == (4 if fault else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
+
+
 def test_bench_default_line_carries_every_single_gpu_config(pa):
     """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`): the top-level record is the fixed-step headline
     run; `also` holds the reference benchmark's adaptive mode on the same matrix and BASELINE configs 2, 3, 4, each with its

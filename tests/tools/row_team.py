@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Row teams on ONE GPU: the ranks of a row-sharded FastForwardBackward solve are contexts of this
+process, one host thread and one stream each, every context limited to num_cu / ranks workgroups so that all team members
+are resident together; the inboxes are plain device pointers (sharding.row_team_in_process), the registered collective
+(initialisation, fallback) is a host-side double between the threads (tests/_doubles.ThreadAllReduce).  Every rank runs
+the reference's iteration on its row block of A; the iterates are compared with the CPU restatement on the WHOLE matrix and
+between the ranks (bit for bit).  Prints one JSON document.  Not two processes: their queues would alternate on one device
+(profiles/r3_team_coop_vs_plain.md)."""
+import argparse
+import itertools
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+
+# one HIP stream per rank, and every stream needs a hardware queue of its own: two sweeps that wait for each other on ONE
+# queue would run one after the other (the runtime's default is four queues per process)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--ranks", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--fast", type=int, default=1)
+    ap.add_argument("--g", choices=["l1", "box"], default="l1")
+    ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
+    ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
+    ap.add_argument("--no-team", action="store_true", help="plain row shards (two sweeps + all-reduce) for comparison")
+    args = ap.parse_args()
+    import proximalalgorithms.jl_amd as pa
+    from _doubles import ThreadAllReduce
+    from oracle import proxgrad_oracle as o
+    from proximalalgorithms.jl_amd import _lib
+
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    m, n, N = args.m, args.n, args.ranks
+    A, b, _ = o.synthetic_lasso(m, n, seed=3, dtype=dtype)
+    lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
+    v = np.ones(n, dtype) / dtype(np.sqrt(n))
+    for _ in range(20):
+        v = A.T @ (A @ v)
+        v /= np.linalg.norm(v)
+    Lf = dtype(1.1) * dtype(np.linalg.norm(A @ v) ** 2)
+    x0 = np.zeros(n, dtype)
+    mk_g = (lambda: pa.NormL1(lam)) if args.g == "l1" else (lambda: pa.IndBox(dtype(-0.02), dtype(0.03)))
+    mk_go = (lambda: o.NormL1(lam)) if args.g == "l1" else (lambda: o.IndBox(dtype(-0.02), dtype(0.03)))
+    Iter = pa.FastForwardBackwardIteration if args.fast else pa.ForwardBackwardIteration
+    IterO = o.FastForwardBackwardIteration if args.fast else o.ForwardBackwardIteration
+    ref = [s.z.copy() for s in itertools.islice(IterO(f=o.LeastSquares(A, b), g=mk_go(), x0=x0, Lf=Lf), args.steps + 1)]
+
+    comm = ThreadAllReduce(N)
+    ctxs = [None] * N
+    sync = threading.Barrier(N)
+    results = [None] * N
+    errors = []
+    num_cu = pa.get_context().device_info()["compute_units"]
+    max_wgs = args.max_wgs or max(1, num_cu // N)
+
+    def worker(r):
+        try:
+            ctx = pa.Context.on_new_stream()
+            ctxs[r] = ctx
+            off, cnt = pa.shard_rows(m, N, r)
+            A_loc = pa.HIPMatrix.from_numpy(np.asfortranarray(A[off:off + cnt]), ctx)
+            f = pa.LeastSquares(A_loc, pa.HIPVector.from_numpy(b[off:off + cnt], ctx), comm=comm.view(r))
+            sync.wait(timeout=120)
+            if r == 0 and not args.no_team:
+                pa.row_team_in_process(ctxs, max_wgs)
+            sync.wait(timeout=120)
+            if args.fault and r == 1:
+                _lib.call("pg_ctx_test_team_fault", ctx.handle, args.fault, 0)
+            iteration = Iter(f=f, g=mk_g(), x0=pa.HIPVector.from_numpy(x0, ctx), Lf=Lf)
+            rows, passes, zs = [], 0, []
+            for k, s in enumerate(itertools.islice(iteration, args.steps + 1)):
+                z = s.z.numpy()
+                p = iteration.counters.get("a_passes", 0)
+                rows.append({"k": k, "flags": int(getattr(s, "flags", 0)), "a_passes": int(p - passes), "f_x": float(s.f_x),
+                             "dz": float(np.max(np.abs(z - ref[k]))), "z_scale": float(max(1.0, np.max(np.abs(ref[k]))))})
+                passes = p
+                zs.append(z)
+            results[r] = (rows, zs, comm.calls[r])
+        except BaseException as e:  # noqa: BLE001 -- reported in the JSON document, the other threads are released
+            import traceback
+
+            errors.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
+            sync.abort()
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        print(json.dumps({"error": errors}))
+        sys.exit(1)
+    same = all(np.array_equal(results[0][1][k], results[r][1][k]) for r in range(1, N) for k in range(args.steps + 1))
+    print(json.dumps({"m": m, "n": n, "ranks": N, "dtype": args.dtype, "max_wgs": max_wgs, "team": not args.no_team,
+                      "ranks_agree_bitwise": bool(same), "fallback_flag": _lib.PG_FLAG_SWEEP_FALLBACK,
+                      "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)]}))
+
+
+if __name__ == "__main__":
+    main()
