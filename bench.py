@@ -87,6 +87,10 @@ def parse_args(argv=None):
     p.add_argument("--sharding", choices=["auto", "rows", "cols"], default="auto",
                    help="N > 1: layout of the TOP-LEVEL record (auto: column blocks for the fixed-step single-sweep run, row "
                         "blocks otherwise); the other layout is reported as a sub-record")
+    p.add_argument("--row-teams", action="store_true",
+                   help="with --sharding rows: the ranks exchange per-column partial dots through each other's inbox inside the "
+                        "sweep (one read of A per iteration) instead of all-reducing A'r between two sweeps")
+    p.add_argument("--no-row-teams", action="store_true", help="N > 1: skip the two row-team records at the end of the line")
     p.add_argument("--no-also", action="store_true",
                    help="skip the extra records (N = 1: adaptive headline + configs 2 / 3 / 4; N > 1: the other layouts)")
     p.add_argument("--sustain", type=float, default=None,
@@ -625,7 +629,7 @@ class Dist:
         return dist.get_world_size()
 
 
-def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
+def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode, row_teams=False):
     """A resident in HBM (this rank's block), b, lam = 0.1 ||A'b||_inf (test_lasso_small.jl:29), Lf (fixed step) -- untimed."""
     import numpy as np
     import torch.distributed as dist
@@ -660,6 +664,10 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
                 else pa.TorchDistributedComm(overlap=D.overlap, shard=shard))
     D.beat()
     f = pa.LeastSquares(A, b, comm=comm)
+    # row blocks as a row TEAM (one read of A per iteration; csrc/pg_gemv_tn4.hip): the ranks map each other's inbox through
+    # IPC handles.  The context outlives this record, so the mode is switched off again for every other layout.
+    teams = bool(row_teams) and layout == "rows" and D.world > 1
+    pa.attach_row_team(ctx, *((None, None) if teams else (1, 0)))
     zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)
     _, g0 = f.value_and_gradient(zero_n)  # = -A'b (row blocks: all-reduced; column blocks: this rank's columns)
     g0_inf = float(g0.norm_inf())
@@ -684,7 +692,8 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode):
         del f0
     ctx.sync()
     return {"A": A, "b": b, "f": f, "comm": comm, "lam": lam, "Lf": Lf, "zero_n": zero_n, "m_glob": m_glob, "n": n,
-            "m_loc": m_loc, "n_loc": n_loc, "layout": layout, "dtype": dtype, "setup_s": time.perf_counter() - t0, "seed": seed}
+            "m_loc": m_loc, "n_loc": n_loc, "layout": layout, "dtype": dtype, "setup_s": time.perf_counter() - t0, "seed": seed,
+            "row_teams": teams}
 
 
 def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_name=None, scaling="strong", sustain=0.0):
@@ -805,7 +814,8 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
             "m": m_glob, "n": n, "mode": mode, "sharding": layout, "shards": D.world if layout != "none" else 1,
             "m_per_gpu": m_loc, "n_per_gpu": n_loc, "lambda": float(P["lam"]), "Lf": float(Lf) if Lf is not None else None,
             "seed": P["seed"], "a_passes_per_step": a_passes / max(steps, 1), "sweep_fallbacks": fallbacks,
-            "sweeps": sweeps if layout != "rows" else "two", "setup_s": round(P["setup_s"], 2),
+            "sweeps": sweeps if (layout != "rows" or P.get("row_teams")) else "two", "row_teams": bool(P.get("row_teams")),
+            "setup_s": round(P["setup_s"], 2),
             "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
                       "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
         "roofline": roofline,
@@ -817,7 +827,9 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
         rec["collective"] = {"backend": "rccl" if D.backend == "nccl" else D.backend, "through": D.collective,
                              "allreduce_calls_per_step": round(calls / max(steps, 1), 3) if calls else None,
                              "allreduce_payload_bytes_per_call": int(elems / calls * es) if calls else None,
-                             "layout_payload": ("[A v partial (m) ; 8 N scalar slots]" if cols else "[grad (n) ; f]")}
+                             "layout_payload": ("[A v partial (m) ; 8 N scalar slots]" if cols else
+                                                "none in the steady state: per-column granules through the peers' inboxes"
+                                                if P.get("row_teams") else "[grad (n) ; f]")}
     del it, iteration
     if sustained is not None:
         rec["sustained"] = sustained
@@ -1187,7 +1199,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
     if args.sustain is None:
         args.sustain = 5.0 if (named == "headline" and world == 1 and not args.force_comm) else 0.0
     wd.enter("main", args.record_timeout + args.sustain)
-    P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode)
+    P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode, row_teams=args.row_teams)
     job.main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
                            workload_name=named, scaling=args.scaling, sustain=args.sustain)
     wd.main_done = True
@@ -1263,7 +1275,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
         P = None
         other = "rows" if layout == "cols" else "cols"
 
-        def extra_record(key, m_rec, lay, scaling):
+        def extra_record(key, m_rec, lay, scaling, teams=False):
             # an extra record that cannot run (the library refuses the shape on every rank alike) must not cost the line
             wd.enter(key, args.sub_record_timeout)
             if args.settle and freed[0] > (1 << 30):  # the driver clears the block just freed in the background (see `settle` above);
@@ -1274,7 +1286,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
                 time.sleep(min(6.0, freed[0] / 30e9 + 0.3))
             freed[0] = (m_rec // world if lay == "rows" else m_rec) * (n if lay == "rows" else -(-n // world)) * es
             try:
-                P2 = setup_lasso(pa, ctx, D, m_rec, n, dtype, args.seed, lay, "fixed")
+                P2 = setup_lasso(pa, ctx, D, m_rec, n, dtype, args.seed, lay, "fixed", row_teams=teams)
                 extra[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events, scaling=scaling)
             except pa.ProxGradError as e:
                 # only what every rank sees alike: a refused shape or a failed allocation.  A failed collective or HIP call
@@ -1291,6 +1303,11 @@ def run_rank(args, job, wd, world, rank, local_rank):
             if args.scaling == "weak" and lay == layout:
                 continue
             extra_record("config5_weak_%s" % lay, m_base * world, lay, "weak")
+        # north_star's row layout at ONE read of A per iteration (row teams).  Last: never run on real xGMI before the first
+        # SCALE collection, and a record that fails or times out here costs none of the ones above.
+        if not args.no_row_teams:
+            extra_record("rows_strong_teams", m_base, "rows", "strong", teams=True)
+            extra_record("config5_weak_rows_teams", m_base * world, "rows", "weak", teams=True)
 
     if rank == 0 and job.cpu is None and world == 1 and not args.no_cpu_baseline and P is not None:
         wd.enter("cpu_baseline", 600.0, stall=False)

@@ -23,8 +23,8 @@ namespace pgtn {
 namespace {
 #include "pg_gemv_tnt.h"
 
-constexpr int PEER_TEAMS_MAX = 256;  // workgroups per device the inbox has ring space for
-constexpr size_t PEER_RING_BYTES = (size_t)PEER_TEAMS_MAX * PEER_RING * (size_t)(TEAM_MAX * 4 * 2) * sizeof(unsigned long long);  // C * G <= 8
+constexpr int PEER_TEAMS_MAX = 512;  // workgroups per device the inbox has ring space for (two per compute unit)
+constexpr size_t PEER_RING_BYTES = (size_t)PEER_TEAMS_MAX * PEER_RING * (size_t)(TEAM_MAX * 8) * sizeof(unsigned long long);  // C * G <= 8
 constexpr int PEER_SCAL_GRANULES = 4;  // per device and slot: f (two halves), the timeout flag, one spare
 constexpr size_t PEER_SCAL_BYTES = 2 * (size_t)TEAM_MAX * PEER_SCAL_GRANULES * sizeof(unsigned long long);
 
@@ -95,7 +95,11 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     pg_set_error("a row team of %d devices with %d columns per step needs more than one lane per granule", rt.n, C);
     return PG_ERR_UNSUPPORTED;
   }
-  int64_t nteams = rt.max_wgs > 0 ? rt.max_wgs : c->num_cu;
+  // two workgroups per compute unit where the parked tiles leave room for two (64 KiB each): measured on 2048- / 4096- /
+  // 8192-row blocks, two members sharing one device, 5.50 / 6.08 / 6.28 TB/s against 3.31 / 5.16 / 6.19 with one
+  // (profiles/r4_row_team_one_gpu.md)
+  constexpr size_t PARK = (size_t)LAG * WAVES * C * U * 1024;
+  int64_t nteams = rt.max_wgs > 0 ? rt.max_wgs : (int64_t)c->num_cu * (PARK <= 64 * 1024 ? 2 : 1);
   if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
   if (nteams > ncg) nteams = ncg;
   if (nteams < 1) nteams = 1;
@@ -157,14 +161,16 @@ bool tn_peer_covers(int nrg) { return nrg >= 1 && nrg <= 64; }
 // Tunables (environment, for experiments): PG_TNP_C, PG_TNP_LAG.
 template <typename T>
 pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
-  // One tile (C columns of this device's rows) per step and workgroup is 32 KiB where the block is short enough, so that a
-  // step lasts ~1.2 us at the device's streaming rate and LAG = 4 steps give the granules ~5 us to cross the fabric; LAG
-  // tiles wait in LDS (128 KiB).  16384-row blocks (config 5 on 8 devices) are 64 KiB per step: LAG = 2, ~2.4 us per step.
+  // One tile (C columns of this device's rows) per step and workgroup is 32 KiB where the block is short enough (64 KiB for
+  // 16384-row blocks, config 5 on 8 devices) and LAG = 2 tiles wait in LDS, which leaves room for TWO workgroups per compute
+  // unit on the short blocks: a step then lasts ~2.4 us at the device's streaming rate either way, so the granules of a
+  // step have ~5 us to cross the fabric and be found.  (LAG = 4 with one workgroup per compute unit: same slack, 0.6-0.85 of
+  // the rate -- one workgroup's per-step chain of barrier, post, poll and LDS round trip is not hidden by a second one.)
   const int per_wave = (a.nrg + 3) / 4;
   int U = 2;
   while (U < per_wave) U *= 2;
   const int C = env_int("PG_TNP_C", U >= 8 ? 1 : 8 / U);
-  const int LAG = env_int("PG_TNP_LAG", U == 16 ? 2 : 4);
+  const int LAG = env_int("PG_TNP_LAG", 2);
 #define PG_TNP_CASE(UU, CC, LL) \
   if (U == UU && C == CC && LAG == LL) return launch_tnp<T, UU, CC, LL, 2>(A, a, blocks_out)
   PG_TNP_CASE(2, 4, 4);
@@ -173,6 +179,11 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TNP_CASE(16, 1, 2);
   PG_TNP_CASE(2, 4, 2);
   PG_TNP_CASE(8, 1, 2);
+  PG_TNP_CASE(4, 2, 2);
+  if constexpr (sizeof(T) == 4) {
+    PG_TNP_CASE(2, 8, 2);
+    PG_TNP_CASE(4, 4, 2);
+  }
 #undef PG_TNP_CASE
   pg_set_error("no row-team instantiation for U=%d C=%d LAG=%d", U, C, LAG);
   return PG_ERR_UNSUPPORTED;

@@ -203,6 +203,10 @@ pg_status redo_with_two_sweeps(pg_iter* it, pg_status why, bool residual_intact)
   c->team_timeout = false;
   it->sp_ready = false;
   it->flags |= PG_FLAG_SWEEP_FALLBACK;
+  // three lost sweeps in a row are not bad luck (a device shared with another process: its kernels and ours alternate, so
+  // the members of a team never run together): stay with two sweeps instead of paying the bounded wait in every step.
+  // The count is the same on every rank of a sharded job (the flag is exchanged), so they leave the mode together.
+  if (why == PG_ERR_TIMEOUT && ++it->timeouts_in_a_row >= 3) it->single_sweep = false;
   if (why == PG_ERR_UNSUPPORTED) {
     // refused: nothing of the sweep ran, and it would be refused again -- also inside a batch (defer_sync): the two sweeps
     // are enqueued in its place and the batch's one read-back takes f(x) from PG_S_F like any two-sweep iteration.  With
@@ -268,6 +272,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
       it->spec_stepsize = (double)s2.stepsize, it->spec_theta = (double)s2.theta, it->spec_t = (double)s2.t, it->spec_k = s2.k;
       it->sp_gen = f->r_gen;
       it->sp_ready = true;
+      it->timeouts_in_a_row = 0;
     } else {
       // ---- ForwardBackward, fixed step: forward_backward.jl:111-120 (the next point is the prox output itself) ----
       const bool fresh_first_half = !(it->sp_ready && it->sp_gen == f->r_gen);
@@ -292,6 +297,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
       PG_TRY(st);
       it->sp_gen = f->r_gen;
       it->sp_ready = true;
+      it->timeouts_in_a_row = 0;
     }
     return PG_OK;
   }
@@ -344,6 +350,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
   }
   PG_TRY(st);
   it->sp_ready = true;
+  it->timeouts_in_a_row = 0;
   it->rz_valid = false;
   it->f_x = Arith<T>::r(c->hscal[PG_S_F]);  // from the residual combination
   return PG_OK;

@@ -41,6 +41,7 @@ struct pg_iter {
   uint64_t sp_gen = 0;
   double sp_f = 0, sp_beta = 0;
   int sp_slot = 0;
+  int timeouts_in_a_row = 0;  // consecutive sweeps lost to a team timeout (three: the iterator stays with two sweeps)
   int fx_src = -1;  // deferred reads (pg_iter_run_batched): scalar slot that holds f(x) of the current state, -1 = f_x is current
   double spec_stepsize = -1, spec_theta = -1, spec_t = 1;
   int64_t spec_k = 1;

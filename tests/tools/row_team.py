@@ -36,7 +36,12 @@ def main():
     ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
     ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
     ap.add_argument("--no-team", action="store_true", help="plain row shards (two sweeps + all-reduce) for comparison")
+    ap.add_argument("--bench", action="store_true",
+                    help="timing instead of parity: synthetic row blocks generated on the device (no host copy, no oracle), "
+                         "--steps timed iterations after 3 warm-up steps; prints it/s and the aggregate bytes of A per second")
     args = ap.parse_args()
+    if args.bench:
+        return bench(args)
     import proximalalgorithms.jl_amd as pa
     from _doubles import ThreadAllReduce
     from oracle import proxgrad_oracle as o
@@ -108,6 +113,80 @@ def main():
     print(json.dumps({"m": m, "n": n, "ranks": N, "dtype": args.dtype, "max_wgs": max_wgs, "team": not args.no_team,
                       "ranks_agree_bitwise": bool(same), "fallback_flag": _lib.PG_FLAG_SWEEP_FALLBACK,
                       "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)]}))
+
+
+def bench(args):
+    """all ranks of a row team on ONE device, timed: what the PEER sweep streams when the members share the chip (the exchange
+    then crosses no fabric -- a lower bound on its latency, an upper bound on nothing else)"""
+    import math
+    import time
+
+    import proximalalgorithms.jl_amd as pa
+    from _doubles import ThreadAllReduce
+
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    m, n, N = args.m, args.n, args.ranks
+    comm = ThreadAllReduce(N)
+    ctxs, out, errors = [None] * N, [None] * N, []
+    sync = threading.Barrier(N)
+    num_cu = pa.get_context().device_info()["compute_units"]
+    max_wgs = args.max_wgs or max(1, num_cu // N)
+    Lf = dtype(1.1 * (1.0 + math.sqrt(n / m)) ** 2)  # ||A||^2 of a Gaussian matrix scaled by 1 / sqrt(m), with margin
+
+    def worker(r):
+        try:
+            ctx = pa.Context.on_new_stream()
+            ctxs[r] = ctx
+            off, cnt = pa.shard_rows(m, N, r)
+            A_loc = pa.HIPMatrix.synthetic(cnt, n, dtype, seed=0, row_offset=off, m_global=m, ctx=ctx)
+            rng = np.random.default_rng(5)
+            xt = np.zeros(n, dtype)
+            xt[rng.choice(n, size=max(1, n // 1000), replace=False)] = 1.0
+            b = A_loc.mul(pa.HIPVector.from_numpy(xt, ctx))
+            f = pa.LeastSquares(A_loc, b, comm=comm.view(r))
+            sync.wait(timeout=300)
+            if r == 0 and not args.no_team:
+                pa.row_team_in_process(ctxs, max_wgs)
+            sync.wait(timeout=300)
+            iteration = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(dtype(0.05)), x0=pa.HIPVector.zeros(n, dtype, ctx), Lf=Lf)
+            it = iter(iteration)
+            for _ in range(4):
+                s = next(it)
+            p0 = iteration.counters.get("a_passes", 0)
+            ctx.profile(True, kernels=("gemv_n_partial", "gemv_t", "gemv_tn"))
+            ctx.profile_reset()
+            ctx.sync()
+            sync.wait(timeout=300)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                s = next(it)
+            ctx.sync()
+            sync.wait(timeout=300)
+            dt = time.perf_counter() - t0
+            prof = ctx.profile_read()
+            out[r] = {"seconds": dt, "a_passes_per_step": (iteration.counters.get("a_passes", 0) - p0) / args.steps,
+                      "fallbacks": iteration.counters.get("sweep_fallbacks", 0), "res_inf": float(s.res_inf),
+                      "kernels": {k: [v[0], round(v[1] / max(v[0], 1), 4)] for k, v in prof.items() if v[0]}}
+        except BaseException as e:  # noqa: BLE001
+            import traceback
+
+            errors.append("rank %d: %s\n%s" % (r, e, traceback.format_exc()))
+            sync.abort()
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        print(json.dumps({"error": errors}))
+        sys.exit(1)
+    dt = max(o_["seconds"] for o_ in out)
+    es = np.dtype(dtype).itemsize
+    print(json.dumps({"bench": True, "m": m, "n": n, "ranks": N, "dtype": args.dtype, "team": not args.no_team, "max_wgs": max_wgs,
+                      "it_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+                      "A_bytes_per_s_all_ranks": m * n * es * out[0]["a_passes_per_step"] * args.steps / dt, "ranks_out": out}))
 
 
 if __name__ == "__main__":
