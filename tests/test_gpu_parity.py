@@ -625,6 +625,15 @@ def test_bench_self_launched_two_ranks_reports_every_layout(pa):
     assert d["rows_strong"]["config"]["lambda"] == pytest.approx(d["config"]["lambda"], rel=1e-5)
     assert d["config5_weak_rows"]["config"]["lambda"] == pytest.approx(d["config5_weak_cols"]["config"]["lambda"], rel=1e-5)
     assert d["config5_weak_rows"]["config"]["final"]["f_x"] == pytest.approx(d["config5_weak_cols"]["config"]["final"]["f_x"], rel=5e-4)
+    # the row layout as a row TEAM (one read of A per iteration), inboxes mapped through IPC handles between the two
+    # processes.  On ONE device the kernels of two processes are not run side by side, so every team sweep runs into its
+    # bounded wait and is redone with two sweeps (after three in a row the iterator stays there): what this checks is the
+    # plumbing (alloc / export / import / set across processes) and that the fallback ends at the same iterate.
+    for key, base in (("rows_strong_teams", "rows_strong"), ("config5_weak_rows_teams", "config5_weak_rows")):
+        r = d[key]
+        assert r["config"]["row_teams"] and r["config"]["sharding"] == "rows" and r["ranks_seen_by_rccl"] == 2
+        assert r["config"]["final"]["f_x"] == pytest.approx(d[base]["config"]["final"]["f_x"], rel=1e-5)
+        assert r["config"]["final"]["g_z"] == pytest.approx(d[base]["config"]["final"]["g_z"], rel=1e-5)
 
 
 @pytest.mark.parametrize("stage,kind", [("main", "hang"), ("rows_strong", "hang"), ("config5_weak_rows", "exit")])
