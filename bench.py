@@ -400,6 +400,12 @@ def host_stream_gbps(threads=None, mib_per_array=1024, reps=3):
 def _cpu_bandwidth_fields(rec, m, n, es):
     """what the it/s of the CPU leg means in bytes: the oracle streams A twice per iteration (A x, then A' r)"""
     rec["achieved_GBps"] = round(2.0 * m * n * es * rec["value"] / 1e9, 1)
+    if rec.get("host_read_GBps") is not None:
+        # a ceiling only if it bounds what it is compared with: say which it is on this host
+        rec["host_read_is_ceiling"] = bool(rec["host_read_GBps"] >= rec["achieved_GBps"])
+        rec["host_read_note"] += ("; the host's read ceiling for this job: achieved_GBps / host_read_GBps is the CPU leg's own roofline fraction"
+                                  if rec["host_read_is_ceiling"] else
+                                  "; NOT a ceiling on this host (the iteration's own passes stream faster): read it as a second rate, no more")
     if rec.get("value_1thread"):
         rec["achieved_GBps_1thread"] = round(2.0 * m * n * es * rec["value_1thread"] / 1e9, 1)
     try:
@@ -427,7 +433,16 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
     from oracle import proxgrad_oracle as o
 
     t0 = time.perf_counter()
-    A = A_dev.numpy()
+    A = None
+    try:  # pages of the host copy placed by the threads that will stream them (a multi-socket host)
+        from oracle import cpu_twin
+
+        m_, n_ = A_dev.shape
+        if A_dev.dtype == np.float32:
+            A = cpu_twin.first_touch(np.empty((m_, n_), np.float32, order="F"), threads=_effective_cpus())
+    except Exception:
+        A = None
+    A = A_dev.numpy(out=A)
     b = b_dev.numpy()
     t_dl = time.perf_counter() - t0
     m, n = A.shape
@@ -445,8 +460,8 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
             read_all = cpu_twin.read_gbps(A, threads=ncpu)  # this host's read rate on the same 64 GiB, same threads
             cpu_twin.load().cpu_twin_set_threads(ncpu)
             rec = {"host_read_GBps": round(read_all, 1),
-                   "host_read_note": "one OpenMP pass summing the same matrix on the same threads (oracle/csrc/cpu_twin.c::cpu_twin_read_pass): "
-                                     "the host's read ceiling for this job; achieved_GBps / host_read_GBps is the CPU leg's own roofline fraction",
+                   "host_read_note": "one OpenMP pass summing the same matrix on the same threads, eight independent partial sums per "
+                                     "thread, pages first-touched by the threads that read them (oracle/csrc/cpu_twin.c::cpu_twin_read_pass)",
                    "value": steps / sec, "value_1thread": 1.0 / sec_1t, "unit": "it/s", "cores": int(thr), "kind": "port",
                    "impl": "C / OpenMP twin of the reference's unfused op sequence (oracle/csrc/cpu_twin.c)",
                    "sample": f"the full workload: FFB fixed-step on the downloaded {m}x{n} float32 matrix ({A.nbytes / 2**30:.1f} GiB, "
@@ -1019,6 +1034,74 @@ def summary_row(r):
     return [r.get("value"), r.get("ms_per_step"), roof.get("kernel"), roof.get("frac")]
 
 
+def wall_ledger(d):
+    """{stage: seconds} of a finished line: import, init, the top-level record and every further record (their set-up, warm-up,
+    timed steps, profile read-back and settling waits included), and what is left over (finalize, interpreter start)"""
+    w = dict((d.get("job") or {}).get("wall") or {})
+    out = {"import": w.get("import_s"), "init": w.get("init_s"), "main": d.get("wall_s")}
+    for k_, v in d.items():
+        if isinstance(v, dict) and "wall_s" in v:
+            out[k_] = v["wall_s"]
+    known = sum(v for v in out.values() if v)
+    if w.get("total_s") is not None:
+        out["other"] = round(max(0.0, w["total_s"] - known), 2)
+        out["total"] = w["total_s"]
+    return out
+
+
+def extrapolate_ledger(d, m_full, n_full, steps_full=50, warmup_full=5, gen_rate=2.4e12, stream_rate=7.0e12, clear_rate=30e9):
+    """The ledger of a reduced-size dry run (`--gpus N --share-device --backend gloo --m .. --n ..`) scaled to the full
+    problem: every record keeps its measured wall time (process start, collective set-up, Python, launch overheads -- what a
+    dry run CAN measure) and gains what the full-size block adds: its generation at the measured 2.4 TB/s, the streaming
+    passes of set-up and iterations at 7 TB/s, and the driver's background clearing of the block freed before it (30 GB/s,
+    capped at 6 s like bench.py's settle).  Returns ({stage: seconds}, total)."""
+    led = wall_ledger(d)
+    world = d.get("n_gpus", 1)
+    es = 4 if d.get("dtype", "f32") == "f32" else 8
+    out = dict(led)
+
+    def add(key, rec, steps, warm):
+        cfg = rec.get("config") or {}
+        if "m" not in cfg:
+            return
+        weak = rec.get("scaling") == "weak"
+        m_glob = m_full * world if weak else m_full
+        blk_full = m_glob * n_full * es / world  # bytes of this rank's block at full size
+        blk_dry = cfg["m"] * cfg["n"] * es / world
+        passes = float(cfg.get("a_passes_per_step") or 2.0)
+        extra_bytes = max(0.0, blk_full - blk_dry)
+        setup = extra_bytes / gen_rate + 31 * 2 * extra_bytes / stream_rate  # generation, 30 power iterations + one gradient
+        timed = (steps + warm + 2) * passes * extra_bytes / stream_rate
+        settle = min(6.0, blk_full / clear_rate + 0.3)
+        out[key] = round((led.get(key) or 0.0) + setup + timed + settle, 2)
+
+    add("main", d, steps_full, warmup_full)
+    for k_, v in d.items():
+        if isinstance(v, dict) and "wall_s" in v and "config" in v:
+            add(k_, v, max(4, min(steps_full, 20)), 3)
+    total = sum(v for k_, v in out.items() if k_ not in ("total", "other") and v) + (led.get("other") or 0.0)
+    out["total"] = round(total, 2)
+    return out, total
+
+
+def flat_summary(prefix, r):
+    """a record as scalar keys of `config` (<prefix>_it_s, _ms, _frac, _kernel, _a_passes; _error when it failed): the form the
+    driver's BENCH_rNN.json keeps (it drops nested values under `config`)"""
+    if not isinstance(r, dict) or "value" not in r:
+        return {prefix + "_error": str((r or {}).get("error", "not measured"))[:120] if isinstance(r, dict) else "not measured"}
+    roof = r.get("roofline") or {}
+    cfg = r.get("config") or {}
+    out = {prefix + "_it_s": r.get("value"), prefix + "_ms": r.get("ms_per_step"), prefix + "_frac": roof.get("frac"),
+           prefix + "_kernel": roof.get("kernel")}
+    passes = cfg.get("a_passes_per_step", cfg.get("A_passes_per_step"))
+    if passes is not None:
+        out[prefix + "_a_passes"] = passes
+    if isinstance(r.get("stepping"), dict):  # config 3: the reference-API stepping rate beside the in-library loop's
+        out[prefix + "_stepping_it_s"] = r["stepping"].get("value")
+        out[prefix + "_stepping_frac"] = (r["stepping"].get("roofline") or {}).get("frac")
+    return out
+
+
 class Job:
     """what rank 0 needs to print the line at any moment: the records measured so far"""
 
@@ -1039,9 +1122,14 @@ class Job:
             also = self.extra.get("also")
             if also is not None:  # the driver keeps `config` whole and drops unknown top-level keys
                 config["also_summary"] = {a.get("label", "?"): summary_row(a) for a in also}
+                for a in also:  # ... and, as round 3's record showed, nested values under `config` too: the same as flat scalars
+                    config.update(flat_summary("also_%s" % a.get("label", "?"), a))
             subs = {k_: summary_row(v) for k_, v in self.extra.items() if k_ != "also" and isinstance(v, dict) and ("value" in v or "error" in v)}
             if subs:
                 config["layouts_summary"] = subs
+                for k_, v in self.extra.items():
+                    if k_ != "also" and isinstance(v, dict) and ("value" in v or "error" in v):
+                        config.update(flat_summary("layout_%s" % k_, v))
             if "sustained" in r:
                 config["sustained_it_s"] = r["sustained"]["value"]
             d = {"metric": metric_name(args, self.world), "value": r["value"], "unit": "it/s", "n_gpus": self.world,
@@ -1050,7 +1138,7 @@ class Job:
                  "roofline": r["roofline"], "cpu_baseline": self.cpu}
             if "in_library_loop" in r and "value" in r["in_library_loop"]:
                 config["in_library_loop_it_s"] = r["in_library_loop"]["value"]
-            for k_ in ("ranks_seen_by_rccl", "collective", "sustained", "in_library_loop"):
+            for k_ in ("ranks_seen_by_rccl", "collective", "sustained", "in_library_loop", "wall_s"):
                 if k_ in r:
                     d[k_] = r[k_]
             if error is not None:
@@ -1105,6 +1193,7 @@ def main():
 
 
 def run_rank(args, job, wd, world, rank, local_rank):
+    t_rank0 = time.perf_counter()
     wd.enter("import", 600.0, stall=False)  # the first `import torch` on a fresh box pages the image in: minutes, not a hang
     import numpy as np
     import torch
@@ -1112,6 +1201,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
 
     import proximalalgorithms.jl_amd as pa
 
+    t_imported = time.perf_counter()
     wd.enter("init", args.init_timeout + 30.0, stall=False)
     if args.share_device:
         local_rank = 0
@@ -1138,6 +1228,9 @@ def run_rank(args, job, wd, world, rank, local_rank):
             dist.init_process_group("gloo", timeout=tmo)
         job.meta["backend"] = "rccl" if args.backend == "nccl" else args.backend
         job.meta["ranks_seen_by_rccl"] = dist.get_world_size()
+        if job.meta["ranks_seen_by_rccl"] != world:  # before any record is timed: a job whose collective spans fewer ranks
+            raise RuntimeError("the collective backend reports %d ranks, the job was launched with %d"  # must not print rates
+                               % (job.meta["ranks_seen_by_rccl"], world))
     collective = args.collective
     if collective == "auto":  # the library's own RCCL communicator when librccl loads and the job runs on RCCL; else torch.distributed
         collective = "native" if (args.backend == "nccl" and pa.native_rccl_available()) else "torch"
@@ -1198,10 +1291,14 @@ def run_rank(args, job, wd, world, rank, local_rank):
 
     if args.sustain is None:
         args.sustain = 5.0 if (named == "headline" and world == 1 and not args.force_comm) else 0.0
+    # the wall-clock ledger of the job (seconds of this rank): what a first run on N GPUs must fit into --launch-timeout
+    job.meta["wall"] = {"import_s": round(t_imported - t_rank0, 2), "init_s": round(time.perf_counter() - t_imported, 2)}
     wd.enter("main", args.record_timeout + args.sustain)
+    t_rec = time.perf_counter()
     P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode, row_teams=args.row_teams)
     job.main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
                            workload_name=named, scaling=args.scaling, sustain=args.sustain)
+    job.main_rec["wall_s"] = round(time.perf_counter() - t_rec, 2)
     wd.main_done = True
     extra = job.extra
     sub_steps = max(4, min(args.steps, 20))
@@ -1278,6 +1375,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
         def extra_record(key, m_rec, lay, scaling, teams=False):
             # an extra record that cannot run (the library refuses the shape on every rank alike) must not cost the line
             wd.enter(key, args.sub_record_timeout)
+            t_sub = time.perf_counter()
             if args.settle and freed[0] > (1 << 30):  # the driver clears the block just freed in the background (see `settle` above);
                 import gc                             # every rank frees the same number of bytes, so all wait equally long
 
@@ -1294,6 +1392,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
                 if e.code not in (pa.PG_ERR_UNSUPPORTED, pa.PG_ERR_ALLOC):
                     raise
                 extra[key] = {"error": str(e)[:300]}
+            extra[key]["wall_s"] = round(time.perf_counter() - t_sub, 2)
 
         if args.scaling == "strong":
             # the same global problem in the other layout (row blocks = north_star's contract)
@@ -1312,6 +1411,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
     if rank == 0 and job.cpu is None and world == 1 and not args.no_cpu_baseline and P is not None:
         wd.enter("cpu_baseline", 600.0, stall=False)
         job.cpu = cpu_leg(args, P, m_glob, n, np.dtype(dtype).itemsize)
+    job.meta["wall"]["total_s"] = round(time.perf_counter() - t_rank0, 2)
     wd.enter("finalize", 60.0)
     if world > 1 or args.force_comm:
         dist.barrier()

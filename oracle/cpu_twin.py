@@ -58,6 +58,8 @@ def load():
                                      C.POINTER(C.c_double)]
         lib.cpu_twin_read_pass.restype = C.c_double
         lib.cpu_twin_read_pass.argtypes = [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double)]
+        lib.cpu_twin_first_touch.restype = None
+        lib.cpu_twin_first_touch.argtypes = [C.c_void_p, C.c_long]
         lib.cpu_twin_threads.restype = C.c_int
         lib.cpu_twin_set_threads.argtypes = [C.c_int]
         _lib = lib
@@ -89,3 +91,12 @@ def read_gbps(A, threads=None, min_seconds=1.0):
     reps = int(max(1, min(50, min_seconds / max(sec.value, 1e-4))))
     lib.cpu_twin_read_pass(A.ctypes.data, count, reps, C.byref(sec))
     return A.nbytes * reps / sec.value / 1e9
+
+
+def first_touch(A, threads=None):
+    """touch the pages of the (uninitialised) array `A` from the threads that will later stream them (cpu_twin_first_touch)"""
+    lib = load()
+    if threads is not None:
+        lib.cpu_twin_set_threads(int(threads))
+    lib.cpu_twin_first_touch(A.ctypes.data, A.size)
+    return A

@@ -83,7 +83,9 @@ static float value_and_gradient(const float* A, long m, long n, long ld, const f
 }
 
 /* Read ceiling of this host on the SAME bytes: one pass over `count` floats summed with all threads (static chunks, like
- * gemv_t's column blocks), `reps` passes timed together.  Returns the sum (so that the loads stay); seconds in *seconds_out. */
+ * gemv_t's column blocks), `reps` passes timed together.  Eight independent partial sums per thread: with ONE the loop is
+ * bound by the latency of the dependent vector add (round 3: the pass ran at half of what sgemv sustained on the same matrix),
+ * not by memory.  Returns the sum (so that the loads stay); seconds in *seconds_out. */
 double cpu_twin_read_pass(const float* a, long count, int reps, double* seconds_out) {
   double total = 0.0;
   const double t0 = omp_get_wtime();
@@ -92,15 +94,37 @@ double cpu_twin_read_pass(const float* a, long count, int reps, double* seconds_
 #pragma omp parallel for schedule(static) reduction(+ : s)
     for (long blk = 0; blk < (count + 65535) / 65536; ++blk) {
       const long lo = blk * 65536, hi = lo + 65536 < count ? lo + 65536 : count;
-      float acc = 0.0f;
-#pragma omp simd reduction(+ : acc)
-      for (long i = lo; i < hi; ++i) acc += a[i];
-      s += acc;
+      float acc[8][16];
+      for (int u = 0; u < 8; ++u)
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0.0f;
+      long i = lo;
+      for (; i + 128 <= hi; i += 128) {
+        for (int u = 0; u < 8; ++u) {
+#pragma omp simd
+          for (int e = 0; e < 16; ++e) acc[u][e] += a[i + u * 16 + e];
+        }
+      }
+      float tail = 0.0f;
+      for (; i < hi; ++i) tail += a[i];
+      for (int u = 0; u < 8; ++u)
+        for (int e = 0; e < 16; ++e) tail += acc[u][e];
+      s += tail;
     }
     total += s;
   }
   *seconds_out = omp_get_wtime() - t0;
   return total;
+}
+
+/* First touch of a buffer that a single-threaded copy is about to fill (the 64 GiB download of the device matrix): every
+ * thread writes the pages of the static chunk it will later READ (gemv_t's column blocks, the read pass), so that on a
+ * multi-socket host the pages live next to the cores that stream them instead of all on the copying thread's node. */
+void cpu_twin_first_touch(float* a, long count) {
+#pragma omp parallel for schedule(static)
+  for (long blk = 0; blk < (count + 65535) / 65536; ++blk) {
+    const long lo = blk * 65536, hi = lo + 65536 < count ? lo + 65536 : count;
+    for (long i = lo; i < hi; i += 1024) a[i] = 0.0f; /* one store per 4 KiB page */
+  }
 }
 
 int cpu_twin_threads(void) { return omp_get_max_threads(); }

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libproxgrad_hip.so")
+# PG_LIB_PATH: another build of the SAME library (scripts/sanitize_host.sh loads the host-instrumented one); never a fallback
+LIB_PATH = os.environ.get("PG_LIB_PATH") or os.path.join(HERE, "libproxgrad_hip.so")
 
 PG_F32, PG_F64 = 0, 1
 PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX, PG_G_SQRNORML2 = 0, 1, 2, 3

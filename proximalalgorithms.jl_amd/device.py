@@ -431,8 +431,12 @@ class HIPMatrix:
         call("pg_mat_info", self._h, C.byref(m), C.byref(n), C.byref(ld), C.byref(dt), C.byref(p))
         return {"m": m.value, "n": n.value, "ld": ld.value, "dtype": dt.value, "ptr": p.value}
 
-    def numpy(self):
-        out = np.empty((self.m, self.n), dtype=self.dtype, order="F")
+    def numpy(self, out=None):
+        """the matrix on the host (column-major); `out`: a caller-prepared (m, n) Fortran-ordered array of the same dtype"""
+        if out is None:
+            out = np.empty((self.m, self.n), dtype=self.dtype, order="F")
+        elif out.shape != (self.m, self.n) or out.dtype != self.dtype or not out.flags.f_contiguous:
+            raise ValueError("out must be a column-major (m, n) array of the matrix's dtype")
         if out.size:
             call("pg_mat_download", self._h, out.ctypes.data_as(C.c_void_p), max(self.m, 1))
         return out

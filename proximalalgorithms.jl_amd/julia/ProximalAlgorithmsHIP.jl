@@ -131,11 +131,19 @@ end
 # The single sweep for x -> loss(A x) terms: At_r = A'r, y = x - gamma At_r, z = prox_{gamma g}(y), res = x - z and Az = A z in
 # ONE read of A (g_kind: 0 Zero, 1 NormL1(p0 = lam), 2 IndBox(p0 = lo, p1 = hi)); returns (g(z), norm(res, Inf), dot(At_r, res),
 # norm(res)^2).  This is what lets FB / FFB / Vu-Condat / LiLin on such terms run at one read of A per iteration.
-function fused_tn!(A::HIPMatrix{T}, r, x, gamma, g_kind, p0, p1, At_r, y, z, res, Az) where {T}
+# image_of_res = true: the last output is A (x - z), the image of the forward-backward residual as a product of the residual
+# itself (pg_mat_fused_tn_res) -- what PANOC with the L-BFGS image slab runs on (HIPLBFGSOperator below).
+function fused_tn!(A::HIPMatrix{T}, r, x, gamma, g_kind, p0, p1, At_r, y, z, res, Az; image_of_res::Bool = false) where {T}
     sc = zeros(Float64, 4)
-    check(ccall((:pg_mat_fused_tn, libpg), Int32,
-                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),
-                A.handle, r.ptr, x.ptr, gamma, g_kind, p0, p1, At_r.ptr, y.ptr, z.ptr, res.ptr, Az.ptr, sc))
+    if image_of_res
+        check(ccall((:pg_mat_fused_tn_res, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),
+                    A.handle, r.ptr, x.ptr, gamma, g_kind, p0, p1, At_r.ptr, y.ptr, z.ptr, res.ptr, Az.ptr, sc))
+    else
+        check(ccall((:pg_mat_fused_tn, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),
+                    A.handle, r.ptr, x.ptr, gamma, g_kind, p0, p1, At_r.ptr, y.ptr, z.ptr, res.ptr, Az.ptr, sc))
+    end
     (sc[1], sc[2], sc[3], sc[4])
 end
 
@@ -292,6 +300,7 @@ mutable struct HIPIterState{R,T}
     z_prev::Union{Nothing,HIPVector{T}}
     extrapolation_sequence::Any   # Iterators.Stateful for host-drawn coefficients, else the (kind, p0, p1) the library runs
     res_inf::R
+    keepalive::Any                # iter.g: the library BORROWS its per-element vectors (pg_iter_set_g_vectors) for the life of the handle
 end
 
 function refresh!(st::HIPIterState{R,T}, sc::PgIterScalars, ctx, n) where {R,T}
@@ -321,7 +330,7 @@ function Base.iterate(iter::HIPIteration)
     sc = Ref{PgIterScalars}()
     check(ccall((:pg_iter_init, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterScalars}), h[], x0.ptr, sc))
     st = HIPIterState{R,T}(h[], x0, R(0), x0, R(0), x0, x0, R(0), x0, nothing,
-                           host_seq === nothing ? (skind, sp0, sp1) : host_seq, R(0))
+                           host_seq === nothing ? (skind, sp0, sp1) : host_seq, R(0), iter.g)
     finalizer(s -> ccall((:pg_iter_destroy, libpg), Int32, (Ptr{Cvoid},), s.handle), st)
     refresh!(st, sc[], iter.f.A.ctx, length(x0))
     return st, st
@@ -362,10 +371,13 @@ function hip_solve(iter::HIPIteration; maxit = 10_000, tol = 1e-8)
     nbytes = A.m * A.n * sizeof(T)
     k = Ref{Int64}(0)
     sc = Ref{PgIterScalars}()
-    if A.m * A.n <= 8192
+    # the one-launch solvers take scalar parameters of g only (they return PG_ERR_UNSUPPORTED once pg_iter_set_g_vectors was
+    # called): per-element bounds / weights run through pg_iter_run
+    g_has_vectors = (iter.g isa HIPIndBox{<:HIPVector}) || (iter.g isa HIPNormL1{<:HIPVector})
+    if !g_has_vectors && A.m * A.n <= 8192
         check(ccall((:pg_iter_run_small, libpg), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Ref{Int64}, Ref{PgIterScalars}),
                     st.handle, 1, maxit, tol, k, sc))
-    elseif 3 * cld(A.m, 64) * 64 * sizeof(T) <= 96 * 1024 && nbytes <= (iter.adaptive ? 10 : 6) << 20
+    elseif !g_has_vectors && 3 * cld(A.m, 64) * 64 * sizeof(T) <= 96 * 1024 && nbytes <= (iter.adaptive ? 10 : 6) << 20
         check(ccall((:pg_iter_run_coop, libpg), Int32, (Ptr{Cvoid}, Int64, Int64, Float64, Int32, Ref{Int64}, Ref{PgIterScalars}),
                     st.handle, 1, maxit, tol, 0, k, sc))
     else
@@ -375,6 +387,94 @@ function hip_solve(iter::HIPIteration; maxit = 10_000, tol = 1e-8)
     refresh!(st, sc[], A.ctx, st.x.n)
     return st.z, Int(k[])   # the aliased device vector, like IterativeAlgorithm's `solution(iter, state)`; Array(z) copies to the host
 end
+
+# Checkpoint / resume.  In the reference `iterate(iter, saved_state)` continues from any saved state (all algorithm memory is
+# in the state struct: fast_forward_backward.jl:60-71, nesterov.jl:56-60).  The library's state lives on the device, so the
+# saved form is a host blob: save_state(st) :: Vector{UInt8}; resume(iter, blob) creates a fresh library iterator with
+# `iter`'s options, uploads the blob (pg_iter_state_upload; pg_iter_init is not needed) and returns the state object from
+# which `iterate(iter, state)` continues bit-identically.  Host-drawn extrapolation sequences are not part of the blob.
+function save_state(st::HIPIterState)
+    nbytes = Ref{Int64}(0)
+    check(ccall((:pg_iter_state_bytes, libpg), Int32, (Ptr{Cvoid}, Ref{Int64}), st.handle, nbytes))
+    blob = Vector{UInt8}(undef, nbytes[])
+    check(ccall((:pg_iter_state_download, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), st.handle, blob, nbytes[]))
+    blob
+end
+function resume(iter::HIPIteration, blob::Vector{UInt8})
+    T = eltype(iter.x0)
+    R = real(T)
+    x0 = iter.x0 isa HIPVector ? iter.x0 : HIPVector(iter.x0; ctx = iter.f.A.ctx)
+    kind, p0, p1 = g_spec(iter.g)
+    fast = is_fast(iter)
+    skind, sp0, sp1, host_seq = fast ? seq_spec(iter.extrapolation_sequence, R) : (PG_SEQ_ADAPTIVE, 0.0, 0.0, nothing)
+    host_seq === nothing || error("a host-drawn extrapolation sequence is not part of a saved state")
+    opts = Ref(PgIterOpts(fast, iter.adaptive, something(iter.Lf, -1.0), something(iter.gamma, -1.0),
+                          iter.minimum_gamma, iter.reduce_gamma, iter.increase_gamma, fast ? iter.mf : 0.0,
+                          skind, sp0, sp1, kind, p0, p1, 1, 1))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_iter_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{PgIterOpts}, Ref{Ptr{Cvoid}}),
+                iter.f.A.ctx.handle, iter.f.handle, opts, h))
+    set_g_vectors!(h[], iter.g)
+    sc = Ref{PgIterScalars}()
+    check(ccall((:pg_iter_state_upload, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{PgIterScalars}), h[], blob, length(blob), sc))
+    st = HIPIterState{R,T}(h[], x0, R(0), x0, R(0), x0, x0, R(0), x0, nothing, (skind, sp0, sp1), R(0), iter.g)
+    finalizer(s -> ccall((:pg_iter_destroy, libpg), Int32, (Ptr{Cvoid},), s.handle), st)
+    refresh!(st, sc[], iter.f.A.ctx, length(x0))
+    return st
+end
+
+# LBFGSOperator on the device (src/accel/lbfgs.jl:5-95) with the image slab: `ProximalAlgorithms.initialize(LBFGS(M), x)` for a
+# HIPVector x gives this operator; update! / reset! / mul! are the reference's methods.  With images enabled (enable_images!)
+# the image A (H v) of a direction follows from A v without reading A (images_mul!), which removes the
+# `mul!(state.Ad, iter.A, state.d)` of panoc.jl:180.
+mutable struct HIPLBFGSOperator{T}
+    handle::Ptr{Cvoid}
+    ctx::HIPContext
+    n::Int
+end
+function HIPLBFGSOperator(M::Integer, x::HIPVector{T}) where {T}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_lbfgs_create, libpg), Int32, (Ptr{Cvoid}, Int32, Int32, Int64, Ref{Ptr{Cvoid}}), x.ctx.handle, pg_dtype(T), M, x.n, h))
+    L = HIPLBFGSOperator{T}(h[], x.ctx, x.n)
+    finalizer(l -> ccall((:pg_lbfgs_destroy, libpg), Int32, (Ptr{Cvoid},), l.handle), L)
+end
+ProximalAlgorithms.initialize(::ProximalAlgorithms.LBFGS{M}, x::HIPVector) where {M} = HIPLBFGSOperator(M, x)   # lbfgs.jl:103-105
+ProximalAlgorithms.update!(L::HIPLBFGSOperator, s::HIPVector, y::HIPVector) =   # lbfgs.jl:30-50
+    (check(ccall((:pg_lbfgs_update, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), L.handle, s.ptr, y.ptr)); L)
+ProximalAlgorithms.reset!(L::HIPLBFGSOperator) = (check(ccall((:pg_lbfgs_reset, libpg), Int32, (Ptr{Cvoid},), L.handle)); L)   # :52-55
+LinearAlgebra.mul!(d::HIPVector{T}, L::HIPLBFGSOperator{T}, v::HIPVector{T}) where {T} =   # :64-95
+    (check(ccall((:pg_lbfgs_apply, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), L.handle, d.ptr, v.ptr)); d)
+enable_images!(L::HIPLBFGSOperator, m::Integer) = (check(ccall((:pg_lbfgs_images_enable, libpg), Int32, (Ptr{Cvoid}, Int64), L.handle, m)); L)
+images_update!(L::HIPLBFGSOperator, As::HIPVector, Ay::HIPVector) =   # right after update!(L, s, y)
+    (check(ccall((:pg_lbfgs_images_update, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), L.handle, As.ptr, Ay.ptr)); L)
+images_mul!(Ad::HIPVector, L::HIPLBFGSOperator, Av::HIPVector) =       # right after mul!(d, L, v): Ad = A d from A v
+    (check(ccall((:pg_lbfgs_images_apply, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), L.handle, Ad.ptr, Av.ptr)); Ad)
+function images_ready(L::HIPLBFGSOperator)
+    r = Ref{Int32}(0)
+    check(ccall((:pg_lbfgs_images_ready, libpg), Int32, (Ptr{Cvoid}, Ref{Int32}), L.handle, r))
+    r[] != 0
+end
+
+# Row teams (INTEGRATION.md section 3): north_star's row layout at one read of A per iteration.  Each process allocates its
+# inbox, ships the 64-byte IPC handle to its peers (MPI.jl / Distributed), opens theirs and registers the list.
+function row_team_inbox(ctx::HIPContext)
+    p = Ref{Ptr{Cvoid}}(C_NULL); nb = Ref{Int64}(0)
+    check(ccall((:pg_ctx_row_team_alloc, libpg), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Int64}), ctx.handle, p, nb))
+    p[]
+end
+function row_team_handle(ctx::HIPContext)
+    h = Vector{UInt8}(undef, 64)
+    check(ccall((:pg_ctx_row_team_export, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.handle, h))
+    h
+end
+function row_team_open(ctx::HIPContext, handle::Vector{UInt8})
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_ctx_row_team_import, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx.handle, handle, p))
+    p[]
+end
+set_row_team!(ctx::HIPContext, rank::Integer, inboxes::Vector{Ptr{Cvoid}}; max_workgroups::Integer = 0) =
+    check(ccall((:pg_ctx_set_row_team, libpg), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, Int32),
+                ctx.handle, length(inboxes), rank, inboxes, max_workgroups))
 
 # DouglasRachford on a separable quadratic + box / L1 (douglas_rachford.jl:53-70): the whole loop in the library,
 # 16 iterations per HBM sweep (pg_dr_run); d, q: scalars or HIPVectors; g: HIPIndBox / HIPNormL1.
@@ -395,7 +495,8 @@ end
 
 export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
        HIPForwardBackwardIteration, HIPFastForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve,
-       hip_douglas_rachford,
+       hip_douglas_rachford, save_state, resume, HIPLBFGSOperator, enable_images!, images_update!, images_mul!, images_ready,
+       row_team_inbox, row_team_handle, row_team_open, set_row_team!,
        fused_tn!, fused_dys!
 
 end # module

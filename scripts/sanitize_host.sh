@@ -1,0 +1,86 @@
+#!/usr/bin/env bash
+# Host-side sanitizer job (SURVEY section 5 "ASan/UBSan for the host C++").  CPU only: no GPU
+# AddressSanitizer, no XNACK.  Three legs, each built with -fsanitize=address,undefined and run under the sanitizer runtime:
+#   1. tests/c_abi/cgmap_check.cpp      the column-group map of every sweep kernel (csrc/pg_cgmap.h), 2556 cases
+#   2. oracle/csrc/cpu_twin.c           the C / OpenMP CPU leg (iterations, read pass, first touch) against the numpy oracle
+#   3. libproxgrad_hip.so, HOST code    hipcc -fsanitize=address,undefined -fno-gpu-sanitize in a scratch copy of the package;
+#                                       the `not gpu` tests that call into the library (symbol table, argument validation,
+#                                       no-CPU-fallback errors, the host-side Nesterov sequences, bench.py without a GPU)
+#                                       run against it with the sanitizer runtime preloaded into python
+# Usage: scripts/sanitize_host.sh [log]      (default log: profiles/r4_host_sanitizers.log; exit code 0 = clean)
+set -u
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+LOG="${1:-$ROOT/profiles/r4_host_sanitizers.log}"
+WORK="$(mktemp -d /tmp/pg_asan.XXXXXX)"
+trap 'rm -rf "$WORK"' EXIT
+export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=97"   # (python itself leaks by design)
+export UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98"
+fail=0
+{
+echo "# host sanitizers, $(date -u +%Y-%m-%dT%H:%MZ), gcc $(gcc -dumpversion), $(/opt/rocm/bin/hipcc --version | grep -m1 -i 'clang version')"
+
+echo "== 1. cgmap_check.cpp (g++ -fsanitize=address,undefined)"
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -I "$ROOT/proximalalgorithms.jl_amd/csrc" \
+    "$ROOT/tests/c_abi/cgmap_check.cpp" -o "$WORK/cgmap_asan" && "$WORK/cgmap_asan"
+rc=$?; echo "rc=$rc"; [ $rc -ne 0 ] && fail=1
+
+echo "== 2. cpu_twin.c (gcc -fsanitize=address,undefined -fopenmp), driven from python with libasan preloaded"
+gcc -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fopenmp -shared -fPIC "$ROOT/oracle/csrc/cpu_twin.c" \
+    -o "$WORK/libcpu_twin_asan.so" -lm
+LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" PG_CPU_TWIN_LIB="$WORK/libcpu_twin_asan.so" \
+  python3 - "$ROOT" <<'PY'
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import cpu_twin, proxgrad_oracle as o
+cpu_twin._lib = None
+cpu_twin.lib_path = lambda: os.environ["PG_CPU_TWIN_LIB"]   # the instrumented build instead of oracle/_build
+cpu_twin.build = lambda force=False: os.environ["PG_CPU_TWIN_LIB"]
+for (m, n) in ((1, 1), (7, 5), (300, 900), (257, 1031)):
+    A, b, _ = o.synthetic_lasso(m, n, seed=2, dtype=np.float32)
+    A = np.asfortranarray(A)
+    lam = np.float32(0.1) * np.float32(np.max(np.abs(A.T @ b)))
+    Lf = np.float32(1.05) * np.float32(np.linalg.norm(A.astype(np.float64), 2) ** 2)
+    it = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(n, np.float32), Lf=Lf))
+    for _ in range(11):
+        s = next(it)
+    for threads in (1, 3):
+        z, fx, sec, thr = cpu_twin.ffb(A, b, lam, Lf, 10, threads=threads)
+        assert np.max(np.abs(z - s.z)) <= 1e-5 * max(1.0, float(np.max(np.abs(s.z)))), (m, n, threads)
+for count in (1, 127, 128, 65536, 65537, 200_003):
+    big = (np.arange(count, dtype=np.float32) % 7)
+    sec = C.c_double()
+    tot = cpu_twin.load().cpu_twin_read_pass(big.ctypes.data, big.size, 2, C.byref(sec))
+    assert tot == 2 * float(big.astype(np.float64).sum()), count
+    buf = np.empty(count, np.float32)
+    cpu_twin.first_touch(buf, threads=3)
+print("cpu_twin under ASan/UBSan: OK")
+PY
+rc=$?; echo "rc=$rc"; [ $rc -ne 0 ] && fail=1
+
+echo "== 3. libproxgrad_hip.so host code (hipcc -fsanitize=address,undefined -fno-gpu-sanitize), not-gpu tests"
+cp -r "$ROOT/proximalalgorithms.jl_amd" "$WORK/pkg" && cp -r "$ROOT/include" "$WORK/include"
+rm -f "$WORK"/pkg/csrc/*.o "$WORK/pkg/libproxgrad_hip.so"
+CLANG_RT="$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)"
+( cd "$WORK" && PG_EXTRA_HIPCC_FLAGS="-fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -g -shared-libsan" \
+    python3 -c "
+import importlib.util, sys
+spec = importlib.util.spec_from_file_location('b', 'pkg/_build.py'); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+import subprocess
+orig = subprocess.run
+def run(cmd, **kw):
+    if '-shared' in cmd: cmd = cmd + ['-fsanitize=address,undefined', '-shared-libsan']
+    return orig(cmd, **kw)
+subprocess.run = run
+print(b.build(force=True, verbose=False))" )
+rc=$?; echo "build rc=$rc"; [ $rc -ne 0 ] && fail=1
+echo "instrumented: $(nm -D --undefined-only "$WORK/pkg/libproxgrad_hip.so" 2>/dev/null | grep -c -E '__asan_|__ubsan_') undefined __asan_* / __ubsan_* references in the library"
+if [ $rc -eq 0 ]; then
+  ( cd "$ROOT" && LD_PRELOAD="$CLANG_RT" PG_LIB_PATH="$WORK/pkg/libproxgrad_hip.so" \
+      python3 -m pytest tests/test_cpu_host.py tests/test_julia_glue.py -q -x -p no:cacheprovider \
+      -k "symbol or no_cpu_fallback or host_sequences or without_a_gpu or cli_parses or julia" 2>&1 | tail -8 )
+  rc=${PIPESTATUS[0]}; echo "rc=$rc"; [ $rc -ne 0 ] && fail=1
+fi
+echo "== result: $([ $fail -eq 0 ] && echo CLEAN || echo FINDINGS)"
+} 2>&1 | tee "$LOG"
+exit $(grep -q "== result: CLEAN" "$LOG" && echo 0 || echo 1)

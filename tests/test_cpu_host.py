@@ -264,6 +264,78 @@ time.sleep(30)
             assert d["value"] is None
 
 
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_config_carries_every_other_record_as_scalars():
+    """the driver's BENCH_rNN.json keeps the scalar keys of `config` and drops nested ones, so every further
+    record (N = 1: adaptive, configs 2 / 3 / 4, the per-GPU block shapes; N > 1: the other layouts) is ALSO written as flat
+    scalars `config.also_<label>_{it_s, ms, frac, kernel, a_passes}` / `config.layout_<key>_...`; a failed record as
+    `..._error`.  Everything under `config` except the two documented summary dicts and `final` is a scalar."""
+    bench = _bench_module()
+    args = bench.parse_args(["--workload", "small"])
+    job = bench.Job(args, 1, 0)
+    job.main_rec = {"value": 105.0, "ms_per_step": 9.5, "config": {"workload": "w", "m": 16, "final": {"gamma": 0.1}},
+                    "roofline": {"kernel": "gemv_tn", "frac": 0.91}, "sustained": {"value": 104.0}}
+    job.extra["also"] = [
+        {"label": "config2", "value": 811.0, "ms_per_step": 1.23, "roofline": {"kernel": "gemv_tn", "frac": 0.89},
+         "config": {"a_passes_per_step": 1.0}},
+        {"label": "config3", "value": 3e5, "ms_per_step": 0.0033, "roofline": {"kernel": "dr_step", "frac": 0.73},
+         "stepping": {"value": 2e4, "roofline": {"frac": 0.73}}, "config": {}},
+        {"label": "config4", "value": 107.0, "ms_per_step": 9.3, "roofline": {"kernel": "gemv_tn", "frac": 0.9},
+         "config": {"A_passes_per_step": 1.0}},
+        {"label": "config5_column_block", "error": "MemoryError: out of memory"},
+    ]
+    cfg = job.line()["config"]
+    assert cfg["also_config2_it_s"] == 811.0 and cfg["also_config2_ms"] == 1.23 and cfg["also_config2_frac"] == 0.89
+    assert cfg["also_config2_kernel"] == "gemv_tn" and cfg["also_config2_a_passes"] == 1.0
+    assert cfg["also_config3_it_s"] == 3e5 and cfg["also_config3_stepping_it_s"] == 2e4 and cfg["also_config3_stepping_frac"] == 0.73
+    assert cfg["also_config4_it_s"] == 107.0 and cfg["also_config4_a_passes"] == 1.0
+    assert "out of memory" in cfg["also_config5_column_block_error"]
+    assert cfg["sustained_it_s"] == 104.0
+    nested = {k for k, v in cfg.items() if isinstance(v, (dict, list))}
+    assert nested == {"also_summary", "final"}, nested
+    # N > 1: the other layouts
+    job2 = bench.Job(bench.parse_args(["--gpus", "8"]), 8, 0)
+    job2.main_rec = dict(job.main_rec)
+    job2.extra["rows_strong"] = {"value": 405.0, "ms_per_step": 2.47, "roofline": {"kernel": "gemv_t", "frac": 0.9},
+                                 "config": {"a_passes_per_step": 2.0}}
+    job2.extra["rows_strong_teams"] = {"error": "timed out"}
+    cfg2 = job2.line()["config"]
+    assert cfg2["layout_rows_strong_it_s"] == 405.0 and cfg2["layout_rows_strong_a_passes"] == 2.0
+    assert cfg2["layout_rows_strong_teams_error"] == "timed out"
+
+
+def test_bench_wall_clock_ledger_and_its_extrapolation():
+    """the wall-clock ledger of a line (import, init, every record's wall time) and its
+    extrapolation from a reduced-size dry run to the full problem: measured overheads kept, the full-size block's generation
+    (2.4 TB/s), streaming passes (7 TB/s) and freed-memory settling added per record."""
+    bench = _bench_module()
+    rec = lambda m, n, scaling, wall, passes: {"value": 1.0, "scaling": scaling, "wall_s": wall,
+                                               "config": {"m": m, "n": n, "a_passes_per_step": passes}}
+    d = {"n_gpus": 8, "dtype": "f32", "wall_s": 6.0, "scaling": "strong", "config": {"m": 2048, "n": 131072, "a_passes_per_step": 1.0},
+         "job": {"wall": {"import_s": 40.0, "init_s": 8.0, "total_s": 75.0}},
+         "rows_strong": rec(2048, 131072, "strong", 5.0, 2.0), "config5_weak_rows": rec(16384, 131072, "weak", 6.0, 2.0),
+         "config5_weak_cols": rec(16384, 131072, "weak", 7.0, 1.0)}
+    led = bench.wall_ledger(d)
+    assert led["import"] == 40.0 and led["main"] == 6.0 and led["rows_strong"] == 5.0 and led["total"] == 75.0
+    assert led["other"] == pytest.approx(75.0 - (40 + 8 + 6 + 5 + 6 + 7))
+    full, total = bench.extrapolate_ledger(d, 16384, 1 << 20)
+    assert full["import"] == 40.0 and full["main"] > led["main"] and full["config5_weak_rows"] > full["rows_strong"] > led["rows_strong"]
+    # config 5's 64 GiB blocks: 31 two-pass evaluations + 25 iterations of two passes at 7 TB/s + generation + settling
+    blk = 131072 * (1 << 20) * 4 / 8
+    expect = 6.0 + blk / 2.4e12 + 62 * blk / 7e12 + 25 * 2 * blk / 7e12 + min(6.0, blk / 30e9 + 0.3)
+    assert full["config5_weak_rows"] == pytest.approx(expect, rel=0.02)
+    assert total == pytest.approx(sum(v for k, v in full.items() if k not in ("total", "other")) + led["other"])
+    assert total < 900
+
+
 def test_pmc_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     """roofline.traffic is only quoted while the sweep-kernel sources hash to what the rocprofv3 --pmc passes were taken
     on; otherwise bench.py reports traffic = null with traffic_stale = true."""

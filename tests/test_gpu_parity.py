@@ -670,24 +670,35 @@ def test_bench_rank_failure_still_prints_a_line(pa, stage, kind):
     assert d["job"]["backend"] == "gloo" and d["job"]["ranks_seen_by_rccl"] == 2 and d["job"]["collective"] == "torch"
 
 
-@pytest.mark.parametrize("mode,cols", [("fixed", False), ("adaptive", False), ("fixed", True)])
-def test_team_sweep_timeout_falls_back_to_two_sweeps(pa, mode, cols):
+_TEAM_FAULT_CASES = ["fixed", "adaptive", "fixed-cols", "fixed-batched", "fixed-cols-refuse", "fixed-batched-refuse",
+                     "fixed-cols-batched-refuse"]
+
+
+@pytest.fixture(scope="session")
+def team_fault_runs():
+    """tests/tools/team_fault.py ONCE for all cases below (its own process: the fault hook and the gloo group of the
+    column-sharded cases stay out of this one): 65536 x 4096, the matrix and the oracle's iterates shared by the cases."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "tools", "team_fault.py"), "--fault", "3", "--steps", "7", "--n", "4096",
+           "--cases", ",".join(_TEAM_FAULT_CASES)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    return json.loads(out.stdout.splitlines()[-1])
+
+
+@pytest.mark.parametrize("case", ["fixed", "adaptive", "fixed-cols"])
+def test_team_sweep_timeout_falls_back_to_two_sweeps(pa, team_fault_runs, case):
     """65536 x 4096 (teams of four workgroups per column group): the third team launch of the solve goes out with one
     workgroup missing (pg_ctx_test_team_fault; own process).  That step's sweep times out, its
     uncommitted outputs are discarded, the step is redone with two sweeps and flagged; the iterates stay the oracle's
     (1e-5 max(1, |z|) in Float32), the step size sequence too, and the following steps are back to one read
     of A per iteration.  cols: the same as the single rank of a column-sharded job, where the
     timeout flag travels through the all-reduce payload."""
-    import json
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tests", "tools", "team_fault.py"), "--mode", mode, "--fault", "3", "--steps", "7",
-           "--n", "4096"]
-    out = subprocess.run(cmd + (["--cols"] if cols else []), capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    d = json.loads(out.stdout.splitlines()[-1])
+    d = team_fault_runs[case]
     steps = d["steps"]
     flagged = [r["k"] for r in steps if r["flags"] & d["fallback_flag"]]
     assert flagged == [3] and d["sweep_fallbacks"] == 1, (flagged, steps)
@@ -699,20 +710,11 @@ def test_team_sweep_timeout_falls_back_to_two_sweeps(pa, mode, cols):
     assert by_k[2] == 1 and by_k[3] >= 2 and by_k[6] == 1 and by_k[7] == 1, by_k  # one read of A per step again after the fallback
 
 
-def test_team_sweep_timeout_inside_a_batch_restarts_the_solve(pa):
+def test_team_sweep_timeout_inside_a_batch_restarts_the_solve(pa, team_fault_runs):
     """The same fault inside pg_iter_run_batched (FastForwardBackward(device_loop=True, check_every=4)): the batch's one
     read-back reports PG_ERR_TIMEOUT with later iterations already enqueued, so the step cannot be redone -- the algorithm
     object warns, restarts from x0 with the per-iteration loop and returns the oracle's iterate."""
-    import json
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tests", "tools", "team_fault.py"), "--mode", "fixed", "--fault", "3", "--steps", "7",
-           "--n", "4096", "--batched"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    d = json.loads(out.stdout.splitlines()[-1])
+    d = team_fault_runs["fixed-batched"]
     assert d["batched"] and d["warned"] and d["k"] == 8 and d["dz"] <= 1e-5 * d["z_scale"], d
 
 
@@ -773,23 +775,14 @@ def test_saved_state_resumes_bit_identically(pa, fast, adaptive, g):
 
 
 @pytest.mark.parametrize("cols,batched", [(True, False), (False, True), (True, True)])
-def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, cols, batched):
+def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_fault_runs, cols, batched):
     """a REFUSED cooperative launch (injected: pg_ctx_test_team_fault kind 1) must be survivable where a
     timeout is.  Stepped, column shards: the refusing rank still posts the step's all-reduce with its refused flag, every
     rank reads PG_ERR_UNSUPPORTED back, redoes the step with two sweeps and stays with two sweeps (the peers are never left
     alone in a collective).  Inside pg_iter_run_batched: unsharded, nothing was enqueued, so the two sweeps take the sweep's
     place within the batch (no restart, no warning); column shards, the batch fails on every rank with that code and the
     algorithm object restarts it step by step.  Iterates = the oracle's in every case."""
-    import json
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tests", "tools", "team_fault.py"), "--mode", "fixed", "--fault", "3", "--steps", "7",
-           "--n", "4096", "--refuse"] + (["--cols"] if cols else []) + (["--batched"] if batched else [])
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    d = json.loads(out.stdout.splitlines()[-1])
+    d = team_fault_runs["fixed" + ("-cols" if cols else "") + ("-batched" if batched else "") + "-refuse"]
     if batched:
         assert d["batched"] and d["warned"] == cols and d["k"] == 8 and d["dz"] <= 1e-5 * d["z_scale"], d
         return
@@ -924,7 +917,7 @@ def test_four_ranks_one_gpu_column_shards(pa):
     m-element partial sums combine to the single-rank answers, fixed and adaptive step."""
     mode = "adaptive"  # (the fixed step runs with eight ranks below)
     one = _run_bench(["--mode", mode])
-    four = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", "cols"], nproc=4, port=29655)
+    four = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", "cols", "--no-also"], nproc=4, port=29655)
     assert four["n_gpus"] == 4 and four["config"]["n_per_gpu"] * 4 == one["config"]["n"]
     assert four["config"]["lambda"] == pytest.approx(one["config"]["lambda"], rel=1e-5)
     f1, f4 = one["config"]["final"], four["config"]["final"]
@@ -934,11 +927,28 @@ def test_four_ranks_one_gpu_column_shards(pa):
     assert f4["res_inf_over_gamma"] == pytest.approx(f1["res_inf_over_gamma"], rel=2e-3)
     assert four["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1)
     # the driver's largest launch: eight ranks (here on one device), default sharding
-    eight = _run_bench(["--backend", "gloo", "--share-device"], nproc=8, port=29657)
+    # (without the two row-team records: eight PROCESSES on one device run every team sweep into its bounded wait -- the
+    # two-rank test above covers that path)
+    eight = _run_bench(["--backend", "gloo", "--share-device", "--no-row-teams"], nproc=8, port=29657)
     one = _run_bench([])
     assert eight["n_gpus"] == 8 and eight["config"]["sharding"] == "cols" and eight["config"]["n_per_gpu"] * 8 == one["config"]["n"]
     assert eight["config"]["final"]["f_x"] == pytest.approx(one["config"]["final"]["f_x"], rel=2e-4)
     assert eight["config"]["final"]["res_inf_over_gamma"] == pytest.approx(one["config"]["final"]["res_inf_over_gamma"], rel=2e-3)
+    # the wall-clock ledger of this reduced-size dry run -- process start, collective set-up and
+    # every record's own overheads MEASURED with eight ranks -- extrapolated to the headline (each record gains its full-size
+    # block's generation at 2.4 TB/s, streaming passes at 7 TB/s and the freed-memory settling wait): the top-level record,
+    # rows_strong and config 5 in both layouts must fit --launch-timeout (900 s) with margin
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    led = bench.wall_ledger(eight)
+    for key in ("import", "init", "main", "rows_strong", "config5_weak_rows", "config5_weak_cols", "total"):
+        assert led.get(key) is not None and led[key] >= 0, (key, led)
+    full, total = bench.extrapolate_ledger(eight, 16384, 1 << 20)
+    print("eight-rank dry-run ledger:", led, "extrapolated to 16384 x 2^20:", full)
+    assert total < 0.5 * 900, (led, full)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1490,15 +1500,15 @@ def test_panoc_image_recurrence_drift(pa):
 
 def test_panoc_at_config4_column_length_against_oracle(pa):
     """BASELINE config 4's kernels in their steady state: the headline column length (m = 16384 ->
-    gemv_n / gemv_t / the pg_mat_fused_tn sweep in the geometries the 16384 x 10^6 run uses) and n = 65536 (4 GiB)."""
-    _panoc_logistic_vs_oracle(pa, 16384, 65536, 10)
+    gemv_n / gemv_t / the pg_mat_fused_tn sweep in the geometries the 16384 x 10^6 run uses) and n = 32768 (2 GiB)."""
+    _panoc_logistic_vs_oracle(pa, 16384, 32768, 10)
 
 
 @pytest.mark.parametrize("alg", ["ZeroFPRIteration", "PANOCplusIteration"])
 def test_zerofpr_panocplus_at_config4_column_length_against_oracle(pa, alg):
-    """SURVEY 8(f) row 4 at the headline column length (16384 x 65536, logistic + L1, L-BFGS(5), adaptive): the same
+    """SURVEY 8(f) row 4 at the headline column length (16384 x 32768, logistic + L1, L-BFGS(5), adaptive): the same
     criteria as PANOC above."""
-    _panoc_logistic_vs_oracle(pa, 16384, 65536, 8, alg=alg, passes_per_it=2.6)
+    _panoc_logistic_vs_oracle(pa, 16384, 32768, 8, alg=alg, passes_per_it=2.6)
 
 
 def test_panoc_at_config4_full_size_against_oracle(pa):
