@@ -74,9 +74,12 @@ enum {
 /* flags reported in pg_iter_scalars.flags */
 enum {
   PG_FLAG_GAMMA_TOO_SMALL = 1, /* fb_tools.jl:59-61 (@warn, not an error) */
-  PG_FLAG_SWEEP_FALLBACK = 2   /* this iteration's single sweep was refused at launch or timed out (PG_ERR_TIMEOUT): its
+  PG_FLAG_SWEEP_FALLBACK = 2,  /* this iteration's single sweep was refused at launch or timed out (PG_ERR_TIMEOUT): its
                                 * uncommitted outputs were discarded and the iteration redone with two sweeps (A x, A' r) --
                                 * same iterate, more reads of A (pg_iter_scalars.a_passes shows them) */
+  PG_FLAG_COOP_SLOW = 4        /* reported once: the cooperative launch of the long-column sweep ran at under 4 TB/s twice in a
+                                * row: the device is shared with a process that holds a cooperative queue and alternates between
+                                * the two (same results, ~0.45 of the rate; a line on stderr names the remedy, PG_TN_TEAM_PLAIN=1) */
 };
 
 typedef struct pg_ctx pg_ctx;

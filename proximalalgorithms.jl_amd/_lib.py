@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("PG_LIB_PATH") or os.path.join(HERE, "libproxgrad_hip.
 PG_F32, PG_F64 = 0, 1
 PG_G_ZERO, PG_G_NORML1, PG_G_INDBOX, PG_G_SQRNORML2 = 0, 1, 2, 3
 PG_SEQ_ADAPTIVE, PG_SEQ_FIXED, PG_SEQ_SIMPLE, PG_SEQ_CONSTANT, PG_SEQ_HOST, PG_SEQ_REPEATED = 0, 1, 2, 3, 4, 5
-PG_FLAG_GAMMA_TOO_SMALL, PG_FLAG_SWEEP_FALLBACK = 1, 2
+PG_FLAG_GAMMA_TOO_SMALL, PG_FLAG_SWEEP_FALLBACK, PG_FLAG_COOP_SLOW = 1, 2, 4
 PG_K_GEMV_N, PG_K_GEMV_N_FINISH, PG_K_GEMV_T, PG_K_EPILOGUE, PG_K_EXTRAPOLATE, PG_K_DR_STEP = range(6)
 KERNEL_NAMES = ["gemv_n_partial", "gemv_n_finish", "gemv_t", "fb_epilogue", "extrapolate", "dr_step", "gemv_tn"]
 

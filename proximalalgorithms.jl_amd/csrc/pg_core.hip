@@ -63,6 +63,8 @@ pg_status pg_ctx_create(int32_t device, void* stream, pg_ctx** out) {
 pg_status pg_ctx_destroy(pg_ctx* c) {
   if (!c) return PG_OK;
   if (c->comm) (void)pg_ctx_comm_destroy(c);
+  for (hipEvent_t e : c->coop_probe)
+    if (e) (void)hipEventDestroy(e);
   for (void* p : c->rteam_imported) (void)hipIpcCloseMemHandle(p);
   if (c->rteam.own) (void)hipFree(c->rteam.own);
   if (c->rteam.f_local) (void)hipFree(c->rteam.f_local);

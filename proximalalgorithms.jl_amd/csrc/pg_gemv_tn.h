@@ -53,6 +53,7 @@ struct TNArgs {
   int64_t ld, n, m;
   int nrg;  // 1 KiB row groups of a column
   int ueff = 0;  // team kernel: row groups per wave = ceil(nrg / (members * waves)) <= U, the rows dealt evenly over the team
+  int deal_even = 0;  // team kernel: waves hold floor or ceil of nrg / (members * waves) row groups (pg_gemv_tnt.h) instead of ueff each
   const T* r;      // [ld] A x - b (lam not applied)
   const T* x;      // [n]
   const T* z_old;  // [n] the prox output of the previous iteration (for v); may alias nothing written here

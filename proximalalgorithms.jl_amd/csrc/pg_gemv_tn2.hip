@@ -483,6 +483,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.partials = (T*)A->partials;
   a.team_size = TM;
   a.ueff = WAVES == 4 ? (a.nrg + TM * WAVES - 1) / (TM * WAVES) : U;
+  a.deal_even = WAVES == 4 && env_int("PG_TNT_EVEN", 1) ? 1 : 0;
   if (a.ueff > U) {
     pg_set_error("gemv_tnt<U = %d> launched for %d row groups per wave", U, a.ueff);
     return PG_ERR_INVALID;
@@ -545,8 +546,44 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     PG_LAUNCH_CHECK();
     return PG_OK;
   }
+  // the probe of the previous cooperative sweep, if it has finished: was it at streaming rate?
+  constexpr double COOP_SLOW_BYTES_PER_S = 4.0e12;  // the sweep streams 6.9-7.2 TB/s; next to a foreign cooperative queue 3.1
+  if (c->coop_probe_bytes > 0 && hipEventQuery(c->coop_probe[1]) == hipSuccess) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->coop_probe[0], c->coop_probe[1]) == hipSuccess && ms > 0.f) {
+      const double rate = c->coop_probe_bytes / (1e-3 * (double)ms);
+      c->coop_slow_in_a_row = rate < COOP_SLOW_BYTES_PER_S ? c->coop_slow_in_a_row + 1 : 0;
+      if (c->coop_slow_in_a_row == 2) {
+        // Measured (profiles/r4_coop_probe.md): switching THIS context to plain launches now does not bring the rate back -- a
+        // process that has used its cooperative queue stays in the device's alternation -- so the library only says what it
+        // sees; the remedy is to start the process with PG_TN_TEAM_PLAIN=1 (read at context creation).
+        c->coop_slow = true;
+        fprintf(stderr, "libproxgrad_hip: the cooperative team sweep ran at %.1f TB/s twice in a row (it streams ~7): another process "
+                        "holds a cooperative queue on this device and the device alternates between the two.  Results are unaffected; "
+                        "start this process with PG_TN_TEAM_PLAIN=1 to launch the sweep plainly (full rate next to an idle process)\n",
+                rate / 1e12);
+      }
+    }
+    c->coop_probe_bytes = 0;
+  } else {
+    (void)hipGetLastError();  // hipErrorNotReady of the query is not an error
+  }
+  const double sweep_bytes = (double)A->m * (double)A->n * sizeof(T);
+  const bool probe = c->coop_probes_left > 0 && c->coop_probe_bytes == 0 && sweep_bytes >= (double)(1u << 30) && !c->profiling;
+  if (probe) {
+    if (c->coop_probe[0] == nullptr) {
+      PG_HIP(hipEventCreate(&c->coop_probe[0]));
+      PG_HIP(hipEventCreate(&c->coop_probe[1]));
+    }
+    PG_HIP(hipEventRecord(c->coop_probe[0], c->stream));
+  }
   void* args[1] = {(void*)&a};
   hipError_t e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(WAVES * 64), args, (unsigned)lds, c->stream);
+  if (probe && e == hipSuccess) {
+    PG_HIP(hipEventRecord(c->coop_probe[1], c->stream));
+    c->coop_probe_bytes = sweep_bytes;
+    c->coop_probes_left--;
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     pg_set_error("cooperative launch of the long-column sweep (%u workgroups of %d threads, %zu bytes of LDS) was refused: %s",

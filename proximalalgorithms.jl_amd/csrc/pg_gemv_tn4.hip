@@ -107,6 +107,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.partials = (T*)A->partials;
   a.team_size = 1;
   a.ueff = (a.nrg + WAVES - 1) / WAVES;
+  a.deal_even = 1;
   if (a.ueff > U) {
     pg_set_error("gemv_tnt<U = %d, PEER> launched for %d row groups per wave", U, a.ueff);
     return PG_ERR_INVALID;

@@ -69,7 +69,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   const int64_t ncg = (a.n + C - 1) / C;
   const CgMap map(ncg, C, a.line_cols, team, a.nteams);  // step i of this team = column group map.at(i)
   const int64_t cnt = map.cnt;
-  const int rg0 = ((PEER ? 0 : member) * WAVES + wave) * a.ueff;  // this wave's first row group: a contiguous run of ueff <= U KiB of each column
+  // This wave's contiguous run of row groups [rg0, rg0 + nu) of every column, nu <= U.  deal_even: the nrg row groups are dealt
+  // over the team's TMe * WAVES waves as evenly as whole row groups allow -- base = nrg / waves each, one more for the first
+  // nrg % waves waves counted wave-index-major (wave 0 of every member, then wave 1 of every member, ...), so that the extra
+  // row groups spread over the MEMBERS (a team is as fast as its fullest member: 196 row groups over 4 x 4 waves are 49 per
+  // member -- 13 + 12 + 12 + 12 -- where ceil(196 / 16) = 13 for everyone made three members of 52 and one of 40).
+  const int TMe = PEER ? 1 : TM, memb = PEER ? 0 : member;
+  int nu = a.ueff, rg0 = (memb * WAVES + wave) * a.ueff;
+  if (a.deal_even) {
+    const int base = a.nrg / (TMe * WAVES), extra = a.nrg % (TMe * WAVES);
+    nu = base + ((wave * TMe + memb) < extra ? 1 : 0);
+    int before = 0;  // waves ahead of this one (member-major row order) that hold base + 1
+    for (int mm = 0; mm < memb; ++mm)
+      for (int w = 0; w < WAVES; ++w) before += (w * TMe + mm) < extra ? 1 : 0;
+    for (int w = 0; w < wave; ++w) before += (w * TMe + memb) < extra ? 1 : 0;
+    rg0 = (memb * WAVES + wave) * base + before;
+  }
   const size_t ring_off = (size_t)team * RING * (size_t)(TEAM_MAX * C * G);
   unsigned long long* const ring = a.xch + ring_off;
 
@@ -77,10 +92,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   int rgc[U];  // row groups past the end of the column are clamped to the last one; their r is zero
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    rgc[u] = min(rg0 + min(u, a.ueff - 1), a.nrg - 1);  // past the run: the wave's own last row group again (a cached load)
+    rgc[u] = max(0, min(rg0 + min(u, nu - 1), a.nrg - 1));  // past the run: the wave's own last row group again (a cached load)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
-    if (u < a.ueff && rg0 + u < a.nrg) {
+    if (u < nu && rg0 + u < a.nrg) {
       rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)(rg0 + u) * (WAVE * VEC) + lane * VEC);
     } else {
 #pragma unroll
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   T* part = a.partials + (int64_t)team * a.ld + lane * VEC;
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    if (u < a.ueff && rg0 + u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)(rg0 + u) * (WAVE * VEC)) = racc[u];
+    if (u < nu && rg0 + u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)(rg0 + u) * (WAVE * VEC)) = racc[u];
   const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
   grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
 }

@@ -134,6 +134,15 @@ struct pg_ctx {
   int test_team_fault_kind = 0;  // 0: one workgroup never starts (its team times out); 1: the launch is refused
   long team_launches = 0;
   bool team_plain_launch = false;  // PG_TN_TEAM_PLAIN = 1: plain instead of cooperative launch (A/B measurements)
+  // Cooperative queues of different PROCESSES are not run side by side on one device: next to any process that holds one
+  // (even an idle one) the cooperative team sweep runs at 0.45 of its rate, silently (profiles/r3_team_coop_vs_plain.md).
+  // The first cooperative sweeps of a context over a matrix of >= 1 GiB are therefore timed with an event pair; two in a row
+  // below COOP_SLOW_BYTES_PER_S are reported: one line on stderr and PG_FLAG_COOP_SLOW (the remedy, PG_TN_TEAM_PLAIN=1, must
+  // be in place before the process's first cooperative launch: switching afterwards does not help, profiles/r4_coop_probe.md).
+  hipEvent_t coop_probe[2] = {nullptr, nullptr};
+  double coop_probe_bytes = 0;  // bytes of the probed launch (0: no probe in flight)
+  int coop_probes_left = 6, coop_slow_in_a_row = 0;
+  bool coop_slow = false;  // reported once through the iteration flags
   // stream capture (pg_ctx_capture_begin / _end): launches are recorded into a hipGraph instead of executed; scalar
   // read-backs are skipped (their host values are not meaningful until the graph has run)
   bool capturing = false;

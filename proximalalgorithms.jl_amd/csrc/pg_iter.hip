@@ -359,6 +359,10 @@ pg_status iter_step_single_sweep(pg_iter* it) {
 template <typename T>
 pg_status iter_step(pg_iter* it, double host_beta) {
   it->flags = 0;
+  if (it->ctx->coop_slow) {  // (pg_gemv_tn2.hip::launch_tnt switched this context to plain launches: say so once)
+    it->flags |= PG_FLAG_COOP_SLOW;
+    it->ctx->coop_slow = false;
+  }
   it->n_backtracks = 0;
   it->f_z = it->f_z_upp = NAN;
   if (it->single_sweep && !(it->defer_sync && it->adaptive)) return iter_step_single_sweep<T>(it);
