@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Write the "Measured (round 3)" table of DESIGN.md from the bench lines under profiles/ (run after
-scripts/publish_round_profiles.sh): the table is transcribed by a program, not by hand.
+"""Write the "Measured" table of DESIGN.md from the bench lines under profiles/ (run after
+scripts/publish_round4_profiles.sh): the table is transcribed by a program, not by hand.  Every line is taken from the NEWEST
+round that collected it (profiles/r4_<name>, else profiles/r3_<name>); the source column names the file actually used.
     python scripts/design_table.py           print the table
     python scripts/design_table.py --apply   replace the block between the <!-- measured:begin/end --> markers of DESIGN.md"""
 import json
@@ -12,11 +13,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 
 
+USED = {}
+
+
+def pick(name):
+    """profiles/r4_<name> when this round collected it, else round 3's"""
+    for rnd in ("r4", "r3"):
+        if os.path.exists(os.path.join(P, f"{rnd}_{name}")):
+            USED[name] = rnd
+            return f"{rnd}_{name}"
+    raise SystemExit(name + ": not collected")
+
+
 def line(name):
+    name = pick(name[3:]) if name.startswith("r3_") else name
     for l in open(os.path.join(P, name)):
         if l.startswith("{"):
             return json.loads(l)
     raise SystemExit(name + ": no JSON line")
+
+
+def src(*names):
+    """`rX_name` for the source column (after the lines were read)"""
+    return ", ".join("`%s_%s`" % (USED.get(n, "r3"), n) for n in names)
 
 
 def tb(r):
@@ -32,7 +51,7 @@ def main():
     also = {a["label"]: a for a in d["also"]}
     r = d["roofline"]
     ceiling = None
-    for l in open(os.path.join(P, "r3_stream_ceiling.log")):
+    for l in open(os.path.join(P, pick("stream_ceiling.log"))):
         m = re.search(r"wave-contiguous runs \(the sweeps' pattern\) ([0-9.]+) GB/s", l)
         if m:
             ceiling = float(m.group(1)) / 1e3
@@ -43,13 +62,13 @@ def main():
     sus = d.get("sustained")
     add("headline 16384 × 2^20, fixed step (the driver's line)",
         f"**{d['value']:.1f}** ({d['ms_per_step']:.2f} ms/step" + (f"; kept running for {sus['seconds']:.0f} s: {sus['value']:.1f}" if sus else "") + ")",
-        f"`gemv_tnm<16,2,4>` {r['avg_launch_ms']:.2f} ms", f"{tb(r):.2f} TB/s", f"**{r['frac']:.3f}**", "`r3_bench_default.json`")
+        f"`gemv_tnm<16,2,4>` {r['avg_launch_ms']:.2f} ms", f"{tb(r):.2f} TB/s", f"**{r['frac']:.3f}**", src("bench_default.json"))
     a = also["headline_adaptive"]
     add("the same, adaptive step (`benchmarks.jl:55-61`)", f"{a['value']:.1f}", f"{a['roofline']['avg_launch_ms']:.2f} ms", f"{tb(a['roofline']):.2f} TB/s",
         f"{a['roofline']['frac']:.3f}", "`also[0]` of the same line")
     c2, a2 = line("r3_bench_config2.json"), also["config2"]
     add("config 2, 8192 × 262144", f"{c2['value']:.0f} ({a2['value']:.0f} inside `also`)", f"`gemv_tnm<4,4,8>` {c2['roofline']['avg_launch_ms']:.3f} ms",
-        f"{tb(c2['roofline']):.2f} TB/s", f"{c2['roofline']['frac']:.3f} ({a2['roofline']['frac']:.3f})", "`r3_bench_config2.json`, `also[1]`")
+        f"{tb(c2['roofline']):.2f} TB/s", f"{c2['roofline']['frac']:.3f} ({a2['roofline']['frac']:.3f})", src("bench_config2.json") + ", `also[1]`")
     c3 = also["config3"]
     s3, l3 = c3["stepping"], c3["device_loop"]
     r3 = s3["roofline"]
@@ -64,40 +83,43 @@ def main():
         f"`dr_block<{kk}>` {l3['roofline']['avg_launch_ms'] * 1e3:.0f} µs",
         f"VALU-bound: {l3['valu']['frac']:.2f} of the loop's VALU issue floor ({l3['valu']['floor_ms_per_launch'] * 1e3:.0f} µs)", "—", "`also[2].device_loop`")
     c4 = also["config4"]
+    pick("bench_panoc.json")
     pk = c4["roofline"]["per_kernel"]
-    add("config 4, PANOC logistic + L1 16384 × 10^6, L-BFGS(5), adaptive", f"{c4['value']:.1f} ({c4['config']['A_passes_per_step']:.1f} reads of A per iteration)",
-        f"sweep {pk['gemv_tn']['avg_ms']:.2f} ms, `gemv_n_partial` {pk['gemv_n_partial']['avg_ms']:.2f} ms",
-        f"{pk['gemv_tn']['GBps'] / 1e3:.2f} / {pk['gemv_n_partial']['GBps'] / 1e3:.2f} TB/s",
-        f"{pk['gemv_tn']['GBps'] / 8e3:.3f} / {pk['gemv_n_partial']['GBps'] / 8e3:.3f}", "`also[3]`, `r3_bench_panoc.json`")
+    ks = [k for k in ("gemv_tn", "gemv_n_partial") if k in pk]
+    add("config 4, PANOC logistic + L1 16384 × 10^6, L-BFGS(5), adaptive (round 3: 54.9 it/s at 2.0 reads)",
+        f"**{c4['value']:.1f}** ({c4['config']['A_passes_per_step']:.1f} reads of A per iteration)",
+        ", ".join(("sweep" if k == "gemv_tn" else f"`{k}`") + f" {pk[k]['avg_ms']:.2f} ms" for k in ks),
+        " / ".join(f"{pk[k]['GBps'] / 1e3:.2f}" for k in ks) + " TB/s", " / ".join(f"{pk[k]['GBps'] / 8e3:.3f}" for k in ks),
+        "`also[3]`, " + src("bench_panoc.json"))
     lf, la, l6 = line("r3_bench_long_131072.json"), line("r3_bench_long_131072_adaptive.json"), line("r3_bench_long_65536.json")
     add("long columns 131072 × 131072 (config 5's per-GPU block under column shards), fixed / adaptive",
         f"**{lf['value']:.1f} / {la['value']:.1f}** with ONE read of A", f"`gemv_tnt<16,1,4,2,2>` (cooperative launch) {lf['roofline']['avg_launch_ms']:.2f} ms",
-        f"{tb(lf['roofline']):.2f} TB/s", f"**{lf['roofline']['frac']:.3f}**", "`r3_bench_long_131072*.json`, `also[4]`")
+        f"{tb(lf['roofline']):.2f} TB/s", f"**{lf['roofline']['frac']:.3f}**", src("bench_long_131072.json", "bench_long_131072_adaptive.json") + ", `also[4]`")
     add("long columns 65536 × 262144", f"{l6['value']:.1f}", f"{l6['roofline']['avg_launch_ms']:.2f} ms", f"{tb(l6['roofline']):.2f} TB/s",
-        f"{l6['roofline']['frac']:.3f}", "`r3_bench_long_65536.json`")
+        f"{l6['roofline']['frac']:.3f}", src("bench_long_65536.json"))
     od = [line(f"r3_bench_odd_{k}.json") for k in ("50000", "100000", "10000")]
     add("column lengths that fill no power of two: 50000 × 84000 / 100000 × 84000 (exact-`U` team members) / 10000 × 420000 (`gemv_tnm<10,4,4>`)",
         " / ".join(f"{x['value']:.0f}" for x in od), " / ".join(f"{x['roofline']['avg_launch_ms']:.2f}" for x in od) + " ms",
-        " / ".join(f"{tb(x['roofline']):.2f}" for x in od) + " TB/s", " / ".join(f"{x['roofline']['frac']:.3f}" for x in od) + " (round 2: 0.83 / 0.86 / 0.76)",
-        "`r3_bench_odd_*.json`")
+        " / ".join(f"{tb(x['roofline']):.2f}" for x in od) + " TB/s", " / ".join(f"{x['roofline']['frac']:.3f}" for x in od) + " (round 3: 0.824 / 0.866 / 0.868)",
+        src("bench_odd_50000.json", "bench_odd_100000.json", "bench_odd_10000.json"))
     md = [line(f"r3_bench_mid_{k}.json") for k in ("7168", "10240", "12288", "24576", "32768")]
     add("mid-length columns 7168 × 299593 (`gemv_tn<4,8,8>`) / 10240 × 209715 / 12288 × 174762 / 24576 × 87381 / 32768 × 65536 (`gemv_tnm`, `U` = 10 / 12 / 12 / 16)",
         " / ".join(f"{x['value']:.0f}" for x in md), " / ".join(f"{x['roofline']['avg_launch_ms']:.3f}" for x in md) + " ms",
-        " / ".join(f"{tb(x['roofline']):.2f}" for x in md) + " TB/s", "**" + " / ".join(f"{x['roofline']['frac']:.3f}" for x in md) + "**", "`r3_bench_mid_*.json`")
+        " / ".join(f"{tb(x['roofline']):.2f}" for x in md) + " TB/s", "**" + " / ".join(f"{x['roofline']['frac']:.3f}" for x in md) + "**", src("bench_mid_7168.json") + " ...")
     sh = [line(f"r3_bench_short_{k}.json") for k in ("4096", "2048", "1024", "512x4M", "512")]
     add("short columns 4096 (`gemv_tnc`) / 2048 / 1024 × 2^20 / 512 × 2^22 / 512 × 2^20 (`gemv_tnw`; row-shard shapes of N = 8 and below)",
         " / ".join(f"{x['value']:.0f}" for x in sh), " / ".join(f"{x['roofline']['avg_launch_ms']:.3f}" for x in sh) + " ms",
-        " / ".join(f"{tb(x['roofline']):.2f}" for x in sh) + " TB/s", " / ".join(f"{x['roofline']['frac']:.3f}" for x in sh), "`r3_bench_short_*.json`, `also[5]`")
+        " / ".join(f"{tb(x['roofline']):.2f}" for x in sh) + " TB/s", " / ".join(f"{x['roofline']['frac']:.3f}" for x in sh), src("bench_short_4096.json", "bench_short_2048.json", "bench_short_1024.json") + " ..., `also[5]`")
     cs = [line(f"r3_bench_colshard_n{k}.json") for k in ("524288", "262144", "131072")]
     add("column-shard shapes with the collective attached (one rank, native RCCL communicator): n = 2^19 / 2^18 / 2^17",
         " / ".join(f"{x['value']:.1f}" for x in cs) + " (" + " / ".join(f"{x['value'] / d['value']:.2f}×" for x in cs) +
         " this box's one-GPU rate before the 64 KiB all-reduce)",
         " / ".join(f"{x['roofline']['avg_launch_ms']:.2f}" for x in cs) + " ms", "",
-        " / ".join(f"{x['roofline']['frac']:.3f}" for x in cs), "`r3_bench_colshard_n*.json`, `r3_colshard_step_trace*.md`")
+        " / ".join(f"{x['roofline']['frac']:.3f}" for x in cs), src("bench_colshard_n524288.json") + " ..., `r3_colshard_step_trace*.md`")
     f8, fl = line("r3_bench_f64_8192.json"), line("r3_bench_f64_long_65536.json")
     add("Float64: 8192 × 2^20 (`gemv_tnm<double,16,2,4>`) / long columns 65536 × 131072", f"{f8['value']:.1f} / {fl['value']:.1f}",
         f"{f8['roofline']['avg_launch_ms']:.2f} / {fl['roofline']['avg_launch_ms']:.2f} ms", f"{tb(f8['roofline']):.2f} / {tb(fl['roofline']):.2f} TB/s",
-        f"{f8['roofline']['frac']:.3f} / {fl['roofline']['frac']:.3f}", "`r3_bench_f64_*.json`")
+        f"{f8['roofline']['frac']:.3f} / {fl['roofline']['frac']:.3f}", src("bench_f64_8192.json", "bench_f64_long_65536.json"))
     cb = d["cpu_baseline"]
     npb = cb.get("numpy_openblas", {})
     tw = cb.get("c_openmp_twin") or {"value": cb["value"], "cores": cb["cores"]}  # present when OpenBLAS was the faster one (= `value`)
@@ -107,7 +129,7 @@ def main():
         f"{tw['value']:.2f} / {cb['value_1thread']:.2f}; {npb.get('value', float('nan')):.2f}", "", f"{twin_gbps:.0f} / {cb.get('achieved_GBps_1thread', 0):.0f} GB/s; {npb.get('achieved_GBps', 0):.0f} GB/s",
         (f"host read pass over the same matrix {cb['host_read_GBps']} GB/s; " if cb.get("host_read_GBps") else "") + f"STREAM add (numpy) {cb.get('host_stream_GBps')} GB/s",
         "`cpu_baseline` of the line")
-    head = (f"streaming-read ceiling of the same box (`r3_stream_ceiling.log`, random data): {ceiling:.2f} TB/s — the headline sweep is at "
+    head = (f"streaming-read ceiling of the same box ({src('stream_ceiling.log')}, random data): {ceiling:.2f} TB/s — the headline sweep is at "
             f"{tb(r) / ceiling:.2f} of it, config 2 {tb(c2['roofline']) / ceiling:.2f}, long columns {tb(lf['roofline']) / ceiling:.2f}, "
             f"2048-row columns {tb(sh[1]['roofline']) / ceiling:.2f}" if ceiling else "")
     text = head + "\n\n" + "\n".join(rows) + "\n"
