@@ -151,7 +151,8 @@ pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
  *   pg_ctx_set_row_team(ctx, nranks, rank, inboxes, max_workgroups): inboxes[q] = device q's inbox as mapped into THIS
  *            process (inboxes[rank] = the own one); max_workgroups = workgroups per device (0: one per compute unit),
  *            the same on every device; nranks <= 1 switches the mode off.  2..16 devices, row blocks of at most 16384
- *            (Float32) / 8192 (Float64) rows per device, fixed step (the adaptive step keeps the two-sweep path). */
+ *            (Float32) / 8192 (Float64) rows per device; fixed step, or FastForwardBackward's adaptive step with
+ *            reuse_residual (the line search's rejected trials use the registered all-reduce). */
 pg_status pg_ctx_row_team_alloc(pg_ctx* ctx, void** inbox_out, int64_t* bytes_out);
 pg_status pg_ctx_row_team_export(pg_ctx* ctx, void* handle_out /* 64 bytes */);
 pg_status pg_ctx_row_team_import(pg_ctx* ctx, const void* handle /* 64 bytes */, void** inbox_out);

@@ -23,7 +23,7 @@ namespace pgtn {
 namespace {
 #include "pg_gemv_tnt.h"
 
-constexpr int PEER_TEAMS_MAX = 512;  // workgroups per device the inbox has ring space for (two per compute unit)
+constexpr int PEER_TEAMS_MAX = 1024;  // workgroups per device the inbox has ring space for (up to four per compute unit)
 constexpr size_t PEER_RING_BYTES = (size_t)PEER_TEAMS_MAX * PEER_RING * (size_t)(TEAM_MAX * 8) * sizeof(unsigned long long);  // C * G <= 8
 constexpr int PEER_SCAL_GRANULES = 4;  // per device and slot: f (two halves), the timeout flag, one spare
 constexpr size_t PEER_SCAL_BYTES = 2 * (size_t)TEAM_MAX * PEER_SCAL_GRANULES * sizeof(unsigned long long);
@@ -95,11 +95,11 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     pg_set_error("a row team of %d devices with %d columns per step needs more than one lane per granule", rt.n, C);
     return PG_ERR_UNSUPPORTED;
   }
-  // two workgroups per compute unit where the parked tiles leave room for two (64 KiB each): measured on 2048- / 4096- /
-  // 8192-row blocks, two members sharing one device, 5.50 / 6.08 / 6.28 TB/s against 3.31 / 5.16 / 6.19 with one
-  // (profiles/r4_row_team_one_gpu.md)
+  // as many workgroups per compute unit as the parked tiles leave room for (four of 32 KiB, two of 64 KiB, one of 128 KiB):
+  // measured on 2048- / 4096- / 8192-row blocks, two members sharing one device, 5.87 (four) / 6.08 (two) / 6.28 (two) TB/s
+  // against 3.31 / 5.16 / 6.19 with one (profiles/r4_row_team_one_gpu.md)
   constexpr size_t PARK = (size_t)LAG * WAVES * C * U * 1024;
-  int64_t nteams = rt.max_wgs > 0 ? rt.max_wgs : (int64_t)c->num_cu * (PARK <= 64 * 1024 ? 2 : 1);
+  int64_t nteams = rt.max_wgs > 0 ? rt.max_wgs : (int64_t)c->num_cu * (PARK <= 32 * 1024 ? 4 : PARK <= 64 * 1024 ? 2 : 1);
   if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
   if (nteams > ncg) nteams = ncg;
   if (nteams < 1) nteams = 1;
@@ -162,15 +162,15 @@ bool tn_peer_covers(int nrg) { return nrg >= 1 && nrg <= 64; }
 // Tunables (environment, for experiments): PG_TNP_C, PG_TNP_LAG.
 template <typename T>
 pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
-  // One tile (C columns of this device's rows) per step and workgroup is 32 KiB where the block is short enough (64 KiB for
-  // 16384-row blocks, config 5 on 8 devices) and LAG = 2 tiles wait in LDS, which leaves room for TWO workgroups per compute
-  // unit on the short blocks: a step then lasts ~2.4 us at the device's streaming rate either way, so the granules of a
-  // step have ~5 us to cross the fabric and be found.  (LAG = 4 with one workgroup per compute unit: same slack, 0.6-0.85 of
+  // One tile (C columns of this device's rows) per step and workgroup is 16 KiB on 2048-row blocks, 32 KiB on 4096 / 8192 rows,
+  // 64 KiB on 16384 rows (config 5 on 8 devices), and LAG = 2 tiles wait in LDS, which leaves room for four / two / one
+  // workgroups per compute unit: the parked bytes per compute unit are 128 KiB in every case, so the granules of a step have
+  // ~5-6 us at the device's streaming rate to cross the fabric and be found.  (LAG = 4 with one workgroup per compute unit: same slack, 0.6-0.85 of
   // the rate -- one workgroup's per-step chain of barrier, post, poll and LDS round trip is not hidden by a second one.)
   const int per_wave = (a.nrg + 3) / 4;
   int U = 2;
   while (U < per_wave) U *= 2;
-  const int C = env_int("PG_TNP_C", U >= 8 ? 1 : 8 / U);
+  const int C = env_int("PG_TNP_C", U >= 8 ? 1 : 2);  // (U = 2: 16 KiB tiles, four workgroups per compute unit)
   const int LAG = env_int("PG_TNP_LAG", 2);
 #define PG_TNP_CASE(UU, CC, LL) \
   if (U == UU && C == CC && LAG == LL) return launch_tnp<T, UU, CC, LL, 2>(A, a, blocks_out)
@@ -181,6 +181,10 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TNP_CASE(2, 4, 2);
   PG_TNP_CASE(8, 1, 2);
   PG_TNP_CASE(4, 2, 2);
+  PG_TNP_CASE(2, 2, 2);
+  PG_TNP_CASE(2, 2, 4);
+  PG_TNP_CASE(4, 1, 2);
+  PG_TNP_CASE(4, 1, 4);
   if constexpr (sizeof(T) == 4) {
     PG_TNP_CASE(2, 8, 2);
     PG_TNP_CASE(4, 4, 2);
@@ -214,3 +218,5 @@ pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) 
 }
 
 }  // namespace pgtn
+
+pg_status pg_rteam_sum_scalar(pg_ctx* c, const double* local, double* out) { return pgtn::peer_scalar_exchange(c, local, out); }

@@ -335,8 +335,11 @@ pg_status iter_step_single_sweep(pg_iter* it) {
   PG_TRY(pg_extrapolate(c, it->dtype, it->n, it->x, it->z, it->z_prev, it->beta));                  // :135
   std::swap(it->z_prev, it->z);                                                                     // :136
   // A x - b = (1 + beta)(A z - b) - beta (A z_prev - b)   (:138 without reading A)
+  // (row teams: the combination covers this device's rows; f = the sum over the devices, exchanged like the sweep's own f)
+  const bool rteam = pg_row_sharded(c) && c->rteam.n > 1;
   PG_TRY(pg_residual_combo_async(c, it->dtype, f->A->m, f->r, (double)(T(1) + (T)it->beta), it->rz,
-                                 (double)(-(T)it->beta), it->rz_prev, 0.5 * f->lam, nullptr));
+                                 (double)(-(T)it->beta), it->rz_prev, 0.5 * f->lam, nullptr, rteam ? c->rteam.f_local : nullptr));
+  if (rteam) PG_TRY(pg_rteam_sum_scalar(c, c->rteam.f_local, c->dscal + PG_S_F));
   f->r_gen++;
   std::swap(it->rz_prev, it->rz);  // the residual at the new z_prev
   // A' r, prox (:138-142) and the residual of the NEW z for the next line search, one sweep
@@ -466,7 +469,7 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   // one read of A per iteration where the fused sweep applies: FB / FFB with a fixed step, FFB adaptive with the residual
   // pair; host-provided extrapolation coefficients arrive one step at a time, so they need the two-sweep path
   it->single_sweep = o->single_sweep != 0 && pg_ls_fused_pass_supported(f) && !(o->fast && o->seq_kind == PG_SEQ_HOST) &&
-                     (!it->adaptive || (o->fast && reuse && !pg_row_sharded(c)));  // (row teams: fixed step only)
+                     (!it->adaptive || (o->fast && reuse));
   const int nvec = it->single_sweep ? 7 : 6;
   const size_t mb = reuse ? (size_t)pg_round_up((int64_t)((size_t)(f->A->m > 0 ? f->A->m : 1) * pg_sizeof(it->dtype)), 256) : 0;
   PG_HIP(hipSetDevice(c->device));

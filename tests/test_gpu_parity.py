@@ -801,6 +801,7 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "16384", "--n", "4096", "--ranks", "8"], dict()),                  # 8 ranks x 2048 rows: the headline's N = 8 block
     (["--m", "6144", "--n", "4096", "--ranks", "3", "--fast", "0", "--g", "box"], dict()),  # ForwardBackward + IndBox, 3 ranks
     (["--m", "4096", "--n", "8192", "--fault", "3"], dict(fault_step=3)),       # rank 1 loses a workgroup in its 3rd sweep
+    (["--m", "8192", "--n", "8192", "--ranks", "4", "--adaptive"], dict(adaptive=True)),  # adaptive step: line search on the residual pair
 ])
 def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     """north_star's ROW layout at one read of A per iteration, exercised on ONE GPU.  The ranks
@@ -809,7 +810,7 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     8-byte granules into every rank's inbox and are summed in rank order (csrc/pg_gemv_tn4.hip).  Asserted: the iterates
     of EVERY rank equal the CPU restatement on the whole matrix (1e-5 max(1, |z|) in Float32), the ranks agree
     bit for bit, from the second step on every step is ONE read of the row block, and the whole solve issues two
-    all-reduces (initialisation) -- none in the steady state.  fault: a member that never starts makes its peers' bounded
+    all-reduces (initialisation; three with the adaptive step's estimate of the step size) -- none in the steady state.  fault: a member that never starts makes its peers' bounded
     waits expire; the flag travels with the scalar exchange, every rank redoes THAT step with two sweeps + the registered
     all-reduce and returns to one read of A."""
     import json
@@ -829,12 +830,14 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
             assert r["dz"] <= tol * r["z_scale"], r
         flagged = [r["k"] for r in rows if r["flags"] & d["fallback_flag"]]
         assert flagged == ([fault] if fault else []), flagged
+        if checks.get("adaptive"):  # the same backtracking decisions as the oracle on the whole matrix
+            assert all(r["gamma"] == pytest.approx(r["gamma_oracle"], rel=1e-6) for r in rows), rows
         by_k = {r["k"]: r["a_passes"] for r in rows}
         steady = [k for k in by_k if k >= 2 and (not fault or k not in (fault, fault + 1))]
         assert all(by_k[k] == 1 for k in steady), by_k
         if fault:
             assert by_k[fault] >= 2, by_k
-    assert all(c == (4 if fault else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
+    assert all(c == (4 if fault else 3 if checks.get("adaptive") else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
 
 
 def test_bench_default_line_carries_every_single_gpu_config(pa):

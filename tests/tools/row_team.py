@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--fast", type=int, default=1)
+    ap.add_argument("--adaptive", action="store_true", help="adaptive step (no Lf): FastForwardBackward's line search with the residual pair")
     ap.add_argument("--g", choices=["l1", "box"], default="l1")
     ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
     ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
@@ -56,12 +57,15 @@ def main():
         v = A.T @ (A @ v)
         v /= np.linalg.norm(v)
     Lf = dtype(1.1) * dtype(np.linalg.norm(A @ v) ** 2)
+    if args.adaptive:
+        Lf = None
     x0 = np.zeros(n, dtype)
     mk_g = (lambda: pa.NormL1(lam)) if args.g == "l1" else (lambda: pa.IndBox(dtype(-0.02), dtype(0.03)))
     mk_go = (lambda: o.NormL1(lam)) if args.g == "l1" else (lambda: o.IndBox(dtype(-0.02), dtype(0.03)))
     Iter = pa.FastForwardBackwardIteration if args.fast else pa.ForwardBackwardIteration
     IterO = o.FastForwardBackwardIteration if args.fast else o.ForwardBackwardIteration
-    ref = [s.z.copy() for s in itertools.islice(IterO(f=o.LeastSquares(A, b), g=mk_go(), x0=x0, Lf=Lf), args.steps + 1)]
+    ref_states = [(s.z.copy(), float(s.gamma)) for s in itertools.islice(IterO(f=o.LeastSquares(A, b), g=mk_go(), x0=x0, Lf=Lf), args.steps + 1)]
+    ref = [r[0] for r in ref_states]
 
     comm = ThreadAllReduce(N)
     ctxs = [None] * N
@@ -90,6 +94,7 @@ def main():
                 z = s.z.numpy()
                 p = iteration.counters.get("a_passes", 0)
                 rows.append({"k": k, "flags": int(getattr(s, "flags", 0)), "a_passes": int(p - passes), "f_x": float(s.f_x),
+                             "gamma": float(s.gamma), "gamma_oracle": ref_states[k][1],
                              "dz": float(np.max(np.abs(z - ref[k]))), "z_scale": float(max(1.0, np.max(np.abs(ref[k]))))})
                 passes = p
                 zs.append(z)
