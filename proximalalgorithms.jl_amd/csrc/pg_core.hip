@@ -240,6 +240,7 @@ pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* con
   for (int q = 0; q < 16; ++q) c->rteam.inbox[q] = q < nranks ? inboxes[q] : nullptr;
   // epochs restart together: every device of the team makes this call at the same point of the program
   c->rteam.epoch = c->rteam.scal_epoch = 0;
+  c->rteam.ring_sig = 0;
   PG_HIP(hipMemset(c->rteam.own, 0, pgtn::peer_inbox_bytes()));
   return PG_OK;
 }

@@ -20,6 +20,7 @@
 #include "pg_gemv_tn.h"
 
 namespace pgtn {
+pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out);
 namespace {
 #include "pg_gemv_tnt.h"
 
@@ -123,6 +124,20 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   for (int q = 0; q < rt.n; ++q) a.peer_ring[q] = (unsigned long long*)rt.inbox[q];
   a.xch = a.peer_ring[rt.rank];
   a.team_err = c->dscal + PG_S_TEAMERR;
+  // The tags make a slot self-describing only among launches of ONE ring layout (every launch rewrites every slot it polls, so
+  // a granule of the same epoch 254 launches ago is long gone).  When the layout changes -- another matrix shape, another
+  // geometry -- an address may still hold a granule of the old layout's launch with the very tag the new one will wait for.
+  // So on a layout change every device clears its own inbox and the devices meet in one scalar exchange before the sweep: a
+  // peer starts pushing granules of the new layout only after that exchange, i.e. after this device's clear (stream order);
+  // and nothing of the previous launch is still in flight, because ITS scalar exchange has completed everywhere.  All devices
+  // see the change at the same launch (same sequence of calls), so the extra exchange pairs up.
+  const unsigned long long sig = ((unsigned long long)nteams << 32) | ((unsigned long long)C << 24) | ((unsigned long long)G << 16) |
+                                 ((unsigned long long)LAG << 8) | (unsigned long long)rt.n;
+  if (sig != c->rteam.ring_sig) {
+    PG_HIP(hipMemsetAsync(rt.inbox[rt.rank], 0, PEER_RING_BYTES, c->stream));
+    PG_TRY(peer_scalar_exchange(c, c->rteam.f_local, c->rteam.f_local));
+    c->rteam.ring_sig = sig;
+  }
   // every device launches the same sweeps in the same order, so the epochs agree without being communicated
   c->rteam.epoch = (c->rteam.epoch % 254u) + 1u;
   a.tag_base = c->rteam.epoch << 24;

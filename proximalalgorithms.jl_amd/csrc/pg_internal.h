@@ -91,6 +91,7 @@ struct pg_row_team {
   void* own = nullptr;        // ... allocated by pg_ctx_row_team_alloc (freed with the context)
   int max_wgs = 0;            // workgroups per device (0: one per compute unit); must be the same on every device
   unsigned epoch = 0, scal_epoch = 0;  // launch epochs of the granule tags: advance in step on every device
+  unsigned long long ring_sig = 0;     // layout of the granule ring the last sweep used (workgroups, C, G, LAG, devices)
   double* f_local = nullptr;  // device scalar: this device's 1/2 lam ||r_p||^2 between the finish kernel and the exchange
 };
 

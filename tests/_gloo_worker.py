@@ -1,8 +1,9 @@
 """Worker for test_world_size_2_gloo_sharded_path (launched by torch.distributed.run, backend gloo, CPU).
 
 The compute engine on CPU is the oracle (allowed: this is test code); what is under test is the package's
-host-side sharding logic: shard_rows, allreduce_sum_ with the [grad ; f] payload convention, and that the
-sharded operator drives the iteration to the unsharded answer."""
+host-side sharding logic: shard_rows, allreduce_sum_ with the [grad ; f] payload convention, that the
+sharded operator drives the iteration to the unsharded answer, and the arithmetic protocols of the column-sharded sweep and of the
+row-team sweep (per-column partial dots summed in rank order) restated on the CPU."""
 import os
 import sys
 
@@ -112,6 +113,53 @@ def main():
             assert np.max(np.abs(z - s_ref.z[coff:coff + ccnt])) <= tol * max(1.0, np.max(np.abs(s_ref.z))), k
             assert abs(res_inf - np.max(np.abs(s_ref.res))) <= tol * max(1.0, np.max(np.abs(s_ref.res))), k
             assert abs(lam * gz - s_ref.g_z) <= 10 * tol * max(1.0, abs(s_ref.g_z)), k
+    # ---- row teams: the protocol of csrc/pg_gemv_tn4.hip (gemv_tnt_kernel<..., PEER>) on the CPU ----
+    # every rank holds the row block A_p, b_p and the replicated n-vectors; per COLUMN the ranks exchange their partial dots
+    # A_p[:, j]' r_p (here: one all-gather of the n partials instead of tagged granules) and every rank sums them IN RANK
+    # ORDER -- the same bits on every rank; f = sum_p 1/2 ||A_p v - b_p||^2 is exchanged the same way.  No all-reduce in the
+    # steady state; the iterates are the unsharded oracle's and identical on the two ranks, bit for bit.
+    for dtype in (np.float32, np.float64):
+        A, b, _ = o.synthetic_lasso(m, n, seed=0, dtype=dtype)
+        lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
+        Lf = dtype(1.05 * np.linalg.norm(A.astype(np.float64), 2) ** 2)
+        gamma = dtype(1) / Lf
+        off, cnt = pa.shard_rows(m, world, rank)
+        A_loc, b_loc = A[off:off + cnt], b[off:off + cnt]
+        ref = iter(o.FastForwardBackwardIteration(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=np.zeros(n, dtype), Lf=Lf))
+        next(ref)
+
+        def gather_rank_order(vec):
+            t = torch.from_numpy(np.ascontiguousarray(vec))
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            tot = parts[0].numpy().copy()
+            for q in range(1, world):
+                tot = tot + parts[q].numpy()  # rank order, like the member-order sum of the granules
+            return tot
+
+        x = np.zeros(n, dtype)
+        r = A_loc @ x - b_loc
+        grad = gather_rank_order(A_loc.T @ r)
+        z, _ = o.NormL1(lam).prox(x - gamma * grad, gamma)
+        z_prev = x.copy()
+        seq = o.AdaptiveNesterovSequence(dtype(0))
+        x_next = z + seq.next(gamma) * (z - z_prev)
+        r = A_loc @ x_next - b_loc
+        for k in range(2, 40):
+            s_ref = next(ref)
+            x, z_prev = x_next, z
+            beta2 = seq.next(gamma)
+            grad = gather_rank_order(A_loc.T @ r)  # the per-column exchange inside the sweep
+            z, _ = o.NormL1(lam).prox(x - gamma * grad, gamma)
+            x_next = z + beta2 * (z - z_prev)
+            r = A_loc @ x_next - b_loc  # the same sweep: A_p v from the column tiles
+            f_next = float(gather_rank_order(np.array([0.5 * float(r.astype(np.float64) @ r.astype(np.float64))]))[0])
+            tol = 2e-4 if dtype == np.float32 else 1e-10
+            assert np.max(np.abs(z - s_ref.z)) <= tol * max(1.0, np.max(np.abs(s_ref.z))), k
+            assert f_next >= 0
+        both = gather_rank_order(np.concatenate([z.astype(np.float64), -z.astype(np.float64)]) if rank == 0 else
+                                 np.concatenate([-z.astype(np.float64), z.astype(np.float64)]))
+        assert np.all(both == 0), "the replicated iterate differs between the ranks"
     dist.barrier()
     if rank == 0:
         print("GLOO_SHARDED_OK")

@@ -802,6 +802,7 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "6144", "--n", "4096", "--ranks", "3", "--fast", "0", "--g", "box"], dict()),  # ForwardBackward + IndBox, 3 ranks
     (["--m", "4096", "--n", "8192", "--fault", "3"], dict(fault_step=3)),       # rank 1 loses a workgroup in its 3rd sweep
     (["--m", "8192", "--n", "8192", "--ranks", "4", "--adaptive"], dict(adaptive=True)),  # adaptive step: line search on the residual pair
+    (["--m", "4096", "--n", "8192", "--then-n", "700"], dict(second=True)),    # a second matrix on the same contexts: another ring layout
 ])
 def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     """north_star's ROW layout at one read of A per iteration, exercised on ONE GPU.  The ranks
@@ -837,6 +838,10 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
         assert all(by_k[k] == 1 for k in steady), by_k
         if fault:
             assert by_k[fault] >= 2, by_k
+    if checks.get("second"):  # the inboxes are cleared and the ranks meet once before the new layout's first sweep
+        for sec in d["second"]:
+            assert sec["max_dz_rel"] <= tol and sec["fallbacks"] == 0 and sec["a_passes"] <= 12 + 4, sec
+        return
     assert all(c == (4 if fault else 3 if checks.get("adaptive") else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
 
 

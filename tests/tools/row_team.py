@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
     ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
     ap.add_argument("--no-team", action="store_true", help="plain row shards (two sweeps + all-reduce) for comparison")
+    ap.add_argument("--then-n", type=int, default=0,
+                    help="afterwards a SECOND problem with this many columns on the same contexts (another ring layout: the "
+                         "devices clear their inboxes and meet in one exchange before its first sweep)")
     ap.add_argument("--bench", action="store_true",
                     help="timing instead of parity: synthetic row blocks generated on the device (no host copy, no oracle), "
                          "--steps timed iterations after 3 warm-up steps; prints it/s and the aggregate bytes of A per second")
@@ -50,6 +53,14 @@ def main():
 
     dtype = np.float32 if args.dtype == "f32" else np.float64
     m, n, N = args.m, args.n, args.ranks
+    second = None
+    if args.then_n:  # the follow-up problem, prepared up front (oracle iterates included)
+        A2, b2, _ = o.synthetic_lasso(m, args.then_n, seed=4, dtype=dtype)
+        lam2 = dtype(0.1) * dtype(np.max(np.abs(A2.T @ b2)))
+        Lf2 = dtype(1.1) * dtype(np.linalg.norm(A2.astype(np.float64), 2) ** 2)
+        ref2 = [s.z.copy() for s in itertools.islice(o.FastForwardBackwardIteration(f=o.LeastSquares(A2, b2), g=o.NormL1(lam2),
+                                                                                   x0=np.zeros(args.then_n, dtype), Lf=Lf2), args.steps + 1)]
+        second = (A2, b2, lam2, Lf2, ref2)
     A, b, _ = o.synthetic_lasso(m, n, seed=3, dtype=dtype)
     lam = dtype(0.1) * dtype(np.max(np.abs(A.T @ b)))
     v = np.ones(n, dtype) / dtype(np.sqrt(n))
@@ -98,7 +109,18 @@ def main():
                              "dz": float(np.max(np.abs(z - ref[k]))), "z_scale": float(max(1.0, np.max(np.abs(ref[k]))))})
                 passes = p
                 zs.append(z)
-            results[r] = (rows, zs, comm.calls[r])
+            second_dz = None
+            if second is not None:
+                A2, b2, lam2, Lf2, ref2 = second
+                A2_loc = pa.HIPMatrix.from_numpy(np.asfortranarray(A2[off:off + cnt]), ctx)
+                f2 = pa.LeastSquares(A2_loc, pa.HIPVector.from_numpy(b2[off:off + cnt], ctx), comm=comm.view(r))
+                it2 = pa.FastForwardBackwardIteration(f=f2, g=pa.NormL1(lam2), x0=pa.HIPVector.zeros(args.then_n, dtype, ctx), Lf=Lf2)
+                second_dz = []
+                for k, s in enumerate(itertools.islice(it2, args.steps + 1)):
+                    second_dz.append(float(np.max(np.abs(s.z.numpy() - ref2[k])) / max(1.0, float(np.max(np.abs(ref2[k]))))))
+                second_dz = {"max_dz_rel": max(second_dz), "a_passes": int(it2.counters.get("a_passes", 0)),
+                             "fallbacks": int(it2.counters.get("sweep_fallbacks", 0))}
+            results[r] = (rows, zs, comm.calls[r], second_dz)
         except BaseException as e:  # noqa: BLE001 -- reported in the JSON document, the other threads are released
             import traceback
 
@@ -117,7 +139,8 @@ def main():
     same = all(np.array_equal(results[0][1][k], results[r][1][k]) for r in range(1, N) for k in range(args.steps + 1))
     print(json.dumps({"m": m, "n": n, "ranks": N, "dtype": args.dtype, "max_wgs": max_wgs, "team": not args.no_team,
                       "ranks_agree_bitwise": bool(same), "fallback_flag": _lib.PG_FLAG_SWEEP_FALLBACK,
-                      "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)]}))
+                      "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)],
+                      "second": [results[r][3] for r in range(N)]}))
 
 
 def bench(args):
