@@ -803,6 +803,7 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "4096", "--n", "8192", "--fault", "3"], dict(fault_step=3)),       # rank 1 loses a workgroup in its 3rd sweep
     (["--m", "8192", "--n", "8192", "--ranks", "4", "--adaptive"], dict(adaptive=True)),  # adaptive step: line search on the residual pair
     (["--m", "4096", "--n", "8192", "--then-n", "700"], dict(second=True)),    # a second matrix on the same contexts: another ring layout
+    (["--m", "5000", "--n", "1001", "--ranks", "3", "--dtype", "f64"], dict(tol=1e-11)),  # ragged: 1667 / 1667 / 1666 rows, odd column count
 ])
 def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     """north_star's ROW layout at one read of A per iteration, exercised on ONE GPU.  The ranks
