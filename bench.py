@@ -91,6 +91,7 @@ def parse_args(argv=None):
                    help="with --sharding rows: the ranks exchange per-column partial dots through each other's inbox inside the "
                         "sweep (one read of A per iteration) instead of all-reducing A'r between two sweeps")
     p.add_argument("--no-row-teams", action="store_true", help="N > 1: skip the two row-team records at the end of the line")
+    p.add_argument("--row-teams-child", action="store_true", help=argparse.SUPPRESS)  # the isolated process of those two records
     p.add_argument("--no-also", action="store_true",
                    help="skip the extra records (N = 1: adaptive headline + configs 2 / 3 / 4; N > 1: the other layouts)")
     p.add_argument("--sustain", type=float, default=None,
@@ -1290,6 +1291,8 @@ def run_rank(args, job, wd, world, rank, local_rank):
     if world == 1:  # the shapes further PMC passes were taken on (profiles/pmc_traffic.json)
         named = {(131072, 131072): "long_columns", (2048, 1 << 20): "short_columns"}.get((m_glob, n), named)
 
+    if args.row_teams_child:
+        return row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype)
     if args.sustain is None:
         args.sustain = 5.0 if (named == "headline" and world == 1 and not args.force_comm) else 0.0
     # the wall-clock ledger of the job (seconds of this rank): what a first run on N GPUs must fit into --launch-timeout
@@ -1406,8 +1409,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
         # north_star's row layout at ONE read of A per iteration (row teams).  Last: never run on real xGMI before the first
         # SCALE collection, and a record that fails or times out here costs none of the ones above.
         if not args.no_row_teams:
-            extra_record("rows_strong_teams", m_base, "rows", "strong", teams=True)
-            extra_record("config5_weak_rows_teams", m_base * world, "rows", "weak", teams=True)
+            row_team_records_in_a_child(args, job, wd, ctx, world, rank)
 
     if rank == 0 and job.cpu is None and world == 1 and not args.no_cpu_baseline and P is not None:
         wd.enter("cpu_baseline", 600.0, stall=False)
@@ -1421,6 +1423,102 @@ def run_rank(args, job, wd, world, rank, local_rank):
     if rank == 0:
         job.write()
     return 0
+
+
+ROW_TEAM_RECORDS = (("rows_strong_teams", "strong"), ("config5_weak_rows_teams", "weak"))
+
+
+def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
+    """`--row-teams-child`: the two row-team records (north_star's row layout at ONE read of A per iteration: the ranks push
+    per-column partial dots into each other's IPC-mapped inbox inside the sweep, csrc/pg_gemv_tn4.hip) in a process group of
+    their own.  They are the only part of an N > 1 line that has never run on more than one GPU; a GPU fault in here must
+    not take the measured line with it, so every rank of the job starts THIS program as a child after its own records (never
+    an exec), waits for it under a deadline and merges what rank 0's child printed."""
+    import torch.distributed as dist
+
+    records = {}
+    sub_steps = max(4, min(args.steps, 20))
+    for key, scaling in ROW_TEAM_RECORDS:
+        wd.enter(key, args.sub_record_timeout)
+        t_sub = time.perf_counter()
+        try:
+            P2 = setup_lasso(pa, ctx, D, m_base * world if scaling == "weak" else m_base, n, dtype, args.seed, "rows", "fixed", row_teams=True)
+            records[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events, scaling=scaling)
+            del P2
+        except Exception as e:  # noqa: BLE001 -- reported in the record; the ranks may be out of step now, so the other one is skipped
+            traceback.print_exc()
+            records[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            records[key]["wall_s"] = round(time.perf_counter() - t_sub, 2)
+            break
+        records[key]["wall_s"] = round(time.perf_counter() - t_sub, 2)
+        import gc
+
+        gc.collect()
+        ctx.sync()
+        time.sleep(0.5)
+    wd.enter("finalize", 60.0)
+    if rank == 0:
+        os.write(job.json_fd, (json.dumps({"row_team_records": records}) + "\n").encode())
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+    wd.close()
+    return 0
+
+
+def row_team_records_in_a_child(args, job, wd, ctx, world, rank):
+    """parent side of row_team_child: free this rank's blocks, start the child (same ranks, another rendezvous port), wait,
+    merge rank 0's records into the line.  Whatever the child does -- refuses, times out, dies of a GPU fault -- the records
+    measured before it stand and the exit code is not its business."""
+    import gc
+
+    gc.collect()
+    ctx.sync()
+    budget = 2.0 * args.sub_record_timeout + args.init_timeout + 60.0
+    wd.enter("row_teams_child", budget + 30.0, stall=False)
+    t0 = time.perf_counter()
+    # the child ranks rendezvous on a store of their own: not the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE would make
+    # rank 0 a client of a server nobody runs on the new port)
+    env = {k_: v for k_, v in os.environ.items() if not k_.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29577")) + 23)
+    argv = [a for a in sys.argv[1:] if a != "--row-teams"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--row-teams-child"]
+    out, err, note = "", "", None
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True, text=True)
+        try:
+            out, err = proc.communicate(timeout=budget)
+            if proc.returncode != 0:
+                note = "the row-team child exited with code %d" % proc.returncode
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, err = proc.communicate()
+            note = "the row-team child did not finish within %.0f s" % budget
+    except Exception as e:  # noqa: BLE001
+        note = "the row-team child could not be started: %s" % str(e)[:200]
+    if err:
+        sys.stderr.write(err[-4000:])
+    if rank != 0:
+        return
+    recs = None
+    for ln in out.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and "row_team_records" in ln:
+            try:
+                recs = json.loads(ln)["row_team_records"]
+            except ValueError:
+                pass
+    for key, _ in ROW_TEAM_RECORDS:
+        if recs and key in recs:
+            job.extra[key] = recs[key]
+        else:
+            job.extra[key] = {"error": note or "no record from the row-team child", "stderr_tail": [l_ for l_ in err.splitlines() if l_.strip()][-4:]}
+    job.extra["row_teams_child_s"] = round(time.perf_counter() - t0, 2)
 
 
 def cpu_leg(args, P, m_glob, n, es):

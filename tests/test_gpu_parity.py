@@ -521,6 +521,8 @@ def _run_bench(extra, nproc=1, port=29641, cpu_baseline=False):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--workload", "small", "--steps", "12", "--warmup", "2"] + ([] if cpu_baseline else ["--no-cpu-baseline"]) + extra
+    if nproc > 1 and "--no-row-teams" not in common:  # (the row-team records -- a child process group -- have their own test)
+        common.append("--no-row-teams")
     if nproc == 1:
         cmd = [sys.executable, os.path.join(root, "bench.py")] + common
     else:
