@@ -837,6 +837,8 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
                       "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
         "roofline": roofline,
     }
+    if P.get("row_teams"):  # how the granule exchange went (sweeps, waves that had to wait, polls spent waiting), this rank
+        rec["config"]["row_team_stats"] = pa.row_team_stats(ctx)
     if layout != "none":
         calls = getattr(comm, "calls", 0) - calls0
         elems = getattr(comm, "elements", 0) - elems0

@@ -157,6 +157,10 @@ pg_status pg_ctx_row_team_alloc(pg_ctx* ctx, void** inbox_out, int64_t* bytes_ou
 pg_status pg_ctx_row_team_export(pg_ctx* ctx, void* handle_out /* 64 bytes */);
 pg_status pg_ctx_row_team_import(pg_ctx* ctx, const void* handle /* 64 bytes */, void** inbox_out);
 pg_status pg_ctx_set_row_team(pg_ctx* ctx, int32_t nranks, int32_t rank, void* const* inboxes, int32_t max_workgroups);
+/* telemetry since the last pg_ctx_set_row_team (syncs): row-team sweeps launched; waves that did not find a step's granules at
+ * their first look; polls (one per ~64 clocks) those waves spent waiting.  late_waves / (sweeps * steps * waves) near 0 means the
+ * exchange fits its lag; a large wait_polls with no fallback means the fabric's latency, not the kernel, sets the rate. */
+pg_status pg_ctx_row_team_stats(pg_ctx* ctx, int64_t* sweeps, int64_t* late_waves, int64_t* wait_polls);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every

@@ -68,6 +68,7 @@ pg_status pg_ctx_destroy(pg_ctx* c) {
   for (void* p : c->rteam_imported) (void)hipIpcCloseMemHandle(p);
   if (c->rteam.own) (void)hipFree(c->rteam.own);
   if (c->rteam.f_local) (void)hipFree(c->rteam.f_local);
+  if (c->rteam.wait_stats) (void)hipFree(c->rteam.wait_stats);
   if (c->red_partials) (void)hipFree(c->red_partials);
   if (c->red_counter) (void)hipFree(c->red_counter);
   if (c->hscal) (void)hipHostFree(c->hscal);
@@ -196,6 +197,10 @@ pg_status pg_ctx_row_team_alloc(pg_ctx* c, void** inbox_out, int64_t* bytes_out)
     }
     PG_HIP(hipMemset(c->rteam.own, 0, bytes));
     if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, sizeof(double)));
+    if (c->rteam.wait_stats == nullptr) {
+      PG_HIP(hipMalloc((void**)&c->rteam.wait_stats, 2 * sizeof(unsigned long long)));
+      PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
+    }
   }
   *inbox_out = c->rteam.own;
   if (bytes_out) *bytes_out = (int64_t)bytes;
@@ -241,7 +246,22 @@ pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* con
   // epochs restart together: every device of the team makes this call at the same point of the program
   c->rteam.epoch = c->rteam.scal_epoch = 0;
   c->rteam.ring_sig = 0;
+  c->rteam.sweeps = 0;
+  if (c->rteam.wait_stats) PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
   PG_HIP(hipMemset(c->rteam.own, 0, pgtn::peer_inbox_bytes()));
+  return PG_OK;
+}
+
+pg_status pg_ctx_row_team_stats(pg_ctx* c, int64_t* sweeps, int64_t* late_waves, int64_t* wait_polls) {
+  PG_REQUIRE(c != nullptr, "ctx is null");
+  unsigned long long h[2] = {0, 0};
+  if (c->rteam.wait_stats) {
+    PG_HIP(hipStreamSynchronize(c->stream));
+    PG_HIP(hipMemcpy(h, c->rteam.wait_stats, sizeof(h), hipMemcpyDeviceToHost));
+  }
+  if (sweeps) *sweeps = c->rteam.sweeps;
+  if (late_waves) *late_waves = (int64_t)h[0];
+  if (wait_polls) *wait_polls = (int64_t)h[1];
   return PG_OK;
 }
 

@@ -91,6 +91,7 @@ struct TNArgs {
   // device's inbox ring as mapped into THIS device's address space (peer_ring[peer_rank] == xch)
   int peer_n = 0, peer_rank = 0;
   unsigned long long* peer_ring[16] = {};
+  unsigned long long* wait_stats = nullptr;  // PEER: { waves that found their granules late, polls they spent waiting } (telemetry)
 #ifdef PG_TNT_EXPERIMENT
   int dbg = 0;  // timing experiments of the team kernel (wrong results): see pg_gemv_tn2.hip
 #endif

@@ -124,6 +124,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   for (int q = 0; q < rt.n; ++q) a.peer_ring[q] = (unsigned long long*)rt.inbox[q];
   a.xch = a.peer_ring[rt.rank];
   a.team_err = c->dscal + PG_S_TEAMERR;
+  a.wait_stats = c->rteam.wait_stats;
+  c->rteam.sweeps++;
   // The tags make a slot self-describing only among launches of ONE ring layout (every launch rewrites every slot it polls, so
   // a granule of the same epoch 254 launches ago is long gone).  When the layout changes -- another matrix shape, another
   // geometry -- an address may still hold a granule of the old layout's launch with the very tag the new one will wait for.

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   bool dead = false;  // wave-uniform: a poll timed out, stop waiting (the launch is reported as failed)
+  unsigned late_steps = 0, late_polls = 0;  // PEER telemetry: steps whose granules were not there at the first look, polls spent
 
   struct Tile {
     V col[C][U];
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
           if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
+      }
+      if constexpr (PEER) {  // telemetry (kept in registers, ONE atomic pair per wave at the end of the kernel)
+        late_steps += 1;
+        late_polls += (unsigned)(spins + 1);
       }
     }
     const int w_lo = (int)(unsigned)pd.w;
@@ -365,6 +370,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
 #pragma unroll
   for (int u = 0; u < U; ++u)
     if (u < nu && rg0 + u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)(rg0 + u) * (WAVE * VEC)) = racc[u];
+  if constexpr (PEER) {
+    if (lane == 0 && a.wait_stats != nullptr && late_steps != 0) {
+      atomicAdd(a.wait_stats, (unsigned long long)late_steps);
+      atomicAdd(a.wait_stats + 1, (unsigned long long)late_polls);
+    }
+  }
   const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
   grid_reduce_finalize<4, 0x2u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
 }

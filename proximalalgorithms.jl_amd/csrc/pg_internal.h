@@ -93,6 +93,8 @@ struct pg_row_team {
   unsigned epoch = 0, scal_epoch = 0;  // launch epochs of the granule tags: advance in step on every device
   unsigned long long ring_sig = 0;     // layout of the granule ring the last sweep used (workgroups, C, G, LAG, devices)
   double* f_local = nullptr;  // device scalar: this device's 1/2 lam ||r_p||^2 between the finish kernel and the exchange
+  unsigned long long* wait_stats = nullptr;  // device: { late waves, polls spent waiting } since pg_ctx_set_row_team (telemetry)
+  long long sweeps = 0;       // row-team sweeps launched since pg_ctx_set_row_team
 };
 
 namespace pgtn {

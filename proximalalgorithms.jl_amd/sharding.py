@@ -260,3 +260,15 @@ def row_team_in_process(contexts, max_workgroups=0):
     inboxes = [_row_team_alloc(c) for c in contexts]
     for p, c in enumerate(contexts):
         _row_team_set(c, p, inboxes, max_workgroups)
+
+
+def row_team_stats(ctx):
+    """{sweeps, late_waves, wait_polls} since the context became a row team (pg_ctx_row_team_stats): how often a wave did not
+    find a step's granules at its first look, and how long it polled -- the first thing to read after a run on real fabric"""
+    import ctypes as C
+
+    from ._lib import call
+
+    a, b, c_ = C.c_int64(), C.c_int64(), C.c_int64()
+    call("pg_ctx_row_team_stats", ctx.handle, C.byref(a), C.byref(b), C.byref(c_))
+    return {"sweeps": a.value, "late_waves": b.value, "wait_polls": c_.value}

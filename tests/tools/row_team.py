@@ -193,6 +193,7 @@ def bench(args):
             dt = time.perf_counter() - t0
             prof = ctx.profile_read()
             out[r] = {"seconds": dt, "a_passes_per_step": (iteration.counters.get("a_passes", 0) - p0) / args.steps,
+                      "row_team_stats": None if args.no_team else pa.row_team_stats(ctx),
                       "fallbacks": iteration.counters.get("sweep_fallbacks", 0), "res_inf": float(s.res_inf),
                       "kernels": {k: [v[0], round(v[1] / max(v[0], 1), 4)] for k, v in prof.items() if v[0]}}
         except BaseException as e:  # noqa: BLE001
