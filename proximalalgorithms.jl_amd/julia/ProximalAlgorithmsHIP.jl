@@ -472,6 +472,11 @@ function row_team_open(ctx::HIPContext, handle::Vector{UInt8})
     check(ccall((:pg_ctx_row_team_import, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx.handle, handle, p))
     p[]
 end
+function row_team_stats(ctx::HIPContext)   # (sweeps, late wave-steps, polls spent waiting) since set_row_team!
+    a = Ref{Int64}(0); b = Ref{Int64}(0); c = Ref{Int64}(0)
+    check(ccall((:pg_ctx_row_team_stats, libpg), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), ctx.handle, a, b, c))
+    (sweeps = a[], late_waves = b[], wait_polls = c[])
+end
 set_row_team!(ctx::HIPContext, rank::Integer, inboxes::Vector{Ptr{Cvoid}}; max_workgroups::Integer = 0) =
     check(ccall((:pg_ctx_set_row_team, libpg), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, Int32),
                 ctx.handle, length(inboxes), rank, inboxes, max_workgroups))
@@ -496,7 +501,7 @@ end
 export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
        HIPForwardBackwardIteration, HIPFastForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve,
        hip_douglas_rachford, save_state, resume, HIPLBFGSOperator, enable_images!, images_update!, images_mul!, images_ready,
-       row_team_inbox, row_team_handle, row_team_open, set_row_team!,
+       row_team_inbox, row_team_handle, row_team_open, set_row_team!, row_team_stats,
        fused_tn!, fused_dys!
 
 end # module
