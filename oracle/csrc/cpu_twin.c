@@ -94,20 +94,24 @@ double cpu_twin_read_pass(const float* a, long count, int reps, double* seconds_
 #pragma omp parallel for schedule(static) reduction(+ : s)
     for (long blk = 0; blk < (count + 65535) / 65536; ++blk) {
       const long lo = blk * 65536, hi = lo + 65536 < count ? lo + 65536 : count;
-      float acc[8][16];
-      for (int u = 0; u < 8; ++u)
-        for (int e = 0; e < 16; ++e) acc[u][e] = 0.0f;
-      long i = lo;
-      for (; i + 128 <= hi; i += 128) {
-        for (int u = 0; u < 8; ++u) {
-#pragma omp simd
-          for (int e = 0; e < 16; ++e) acc[u][e] += a[i + u * 16 + e];
-        }
+      /* eight scalar accumulators under `omp simd reduction`: each becomes a vector register of its own, i.e. eight independent
+       * dependency chains per thread (one chain -- or accumulators the compiler keeps in memory -- is latency-bound) */
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+      const long n8 = (hi - lo) / 8;  /* eight contiguous runs of n8 floats each: eight streams, no shuffles */
+      const float* p = a + lo;
+#pragma omp simd reduction(+ : s0, s1, s2, s3, s4, s5, s6, s7)
+      for (long k = 0; k < n8; ++k) {
+        s0 += p[k];
+        s1 += p[n8 + k];
+        s2 += p[2 * n8 + k];
+        s3 += p[3 * n8 + k];
+        s4 += p[4 * n8 + k];
+        s5 += p[5 * n8 + k];
+        s6 += p[6 * n8 + k];
+        s7 += p[7 * n8 + k];
       }
-      float tail = 0.0f;
-      for (; i < hi; ++i) tail += a[i];
-      for (int u = 0; u < 8; ++u)
-        for (int e = 0; e < 16; ++e) tail += acc[u][e];
+      float tail = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+      for (long i = lo + 8 * n8; i < hi; ++i) tail += a[i];
       s += tail;
     }
     total += s;
