@@ -21,7 +21,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--loss", choices=["logistic", "sqdist"], default="logistic")
-    ap.add_argument("--algo", choices=["panoc", "ffb", "ffb-generic"], default="panoc",
+    ap.add_argument("--images", type=int, default=1, help="0: the explicit product A d (panoc.jl:180) instead of the L-BFGS image slab")
+    ap.add_argument("--algo", choices=["panoc", "zerofpr", "panocplus", "ffb", "ffb-generic"], default="panoc",
                     help="ffb: FastForwardBackward (adaptive) on Composed(loss, A), engine 'composed' (one read of A per "
                          "iteration); ffb-generic: the same with separate GEMV passes")
     args = ap.parse_args()
@@ -39,8 +40,9 @@ def main():
     f = pa.LogisticLoss(b) if args.loss == "logistic" else pa.SquaredDistance(b)
     _, g0 = f.value_and_gradient(pa.HIPVector.zeros(m, dtype))
     lam = dtype(0.1) * A.mul_adjoint(g0).norm_inf()
-    if args.algo == "panoc":
-        iteration = pa.PANOCIteration(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype))
+    newton = {"panoc": "PANOCIteration", "zerofpr": "ZeroFPRIteration", "panocplus": "PANOCplusIteration"}
+    if args.algo in newton:
+        iteration = getattr(pa, newton[args.algo])(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype), images=bool(args.images))
     else:
         iteration = pa.FastForwardBackwardIteration(f=pa.Composed(f, A), g=pa.NormL1(lam), x0=np.zeros(n, dtype),
                                                     engine="composed" if args.algo == "ffb" else "generic")
@@ -48,7 +50,7 @@ def main():
     s = next(it)
     for _ in range(args.warmup):
         s = next(it)
-    key = "A_passes" if args.algo == "panoc" else "a_passes"
+    key = "A_passes" if args.algo in newton else "a_passes"
     p0 = iteration.counters.get(key, 0)
     ctx.profile(True)
     ctx.profile_reset()
@@ -64,7 +66,8 @@ def main():
     if args.algo == "ffb-generic":  # the generic engine does not count: 2 passes per gradient + 1 per line-search f(z)
         passes = 3 * args.steps
     gemv_ms = prof["gemv_n_partial"][1] + prof["gemv_t"][1] + prof["gemv_tn"][1]
-    name = "PANOC iters/sec, %s + L1, m=%d n=%d f32, LBFGS(5), adaptive" if args.algo == "panoc" else \
+    name = (args.algo.upper() if args.algo == "panoc" else {"zerofpr": "ZeroFPR", "panocplus": "PANOCplus"}.get(args.algo, "")) + \
+        " iters/sec, %s + L1, m=%d n=%d f32, LBFGS(5), adaptive" + ("" if args.images else ", explicit A d") if args.algo in newton else \
         "FastForwardBackward (" + args.algo + ") iters/sec, %s + L1, m=%d n=%d f32, adaptive"
     out = {"metric": name % (args.loss, m, n),
            "value": args.steps / dt, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,

@@ -1468,6 +1468,13 @@ def test_image_slab_iterations_equal_explicit_products(pa, alg):
             ref = getattr(s2, sol).numpy()
             assert np.max(np.abs(getattr(s1, sol).numpy() - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (kw, k)
         assert its[0].counters["A_passes"] <= its[1].counters["A_passes"] - 20, [i.counters for i in its]
+    # refresh_every = K: every K-th update of the running sum A x is a product again (PANOC / PANOCplus; a no-op for ZeroFPR,
+    # which holds no running sum) -- same iterates, K-fold fewer reads saved
+    if alg != "ZeroFPRIteration":
+        a, b_ = (getattr(pa, alg)(f=pa.SquaredDistance(b), A=A, g=pa.NormL1(lam), x0=x0, **kw) for kw in (dict(refresh_every=4), dict(images=False)))
+        for k, (s1, s2) in enumerate(itertools.islice(zip(a, b_), 25)):
+            assert np.max(np.abs(getattr(s1, sol).numpy() - getattr(s2, sol).numpy())) <= 1e-9, k
+        assert its[0].counters["A_passes"] < a.counters["A_passes"] < b_.counters["A_passes"]
 
 
 def test_panoc_image_recurrence_drift(pa):
