@@ -806,6 +806,7 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "8192", "--n", "8192", "--ranks", "4", "--adaptive"], dict(adaptive=True)),  # adaptive step: line search on the residual pair
     (["--m", "4096", "--n", "8192", "--then-n", "700"], dict(second=True)),    # a second matrix on the same contexts: another ring layout
     (["--m", "5000", "--n", "1001", "--ranks", "3", "--dtype", "f64"], dict(tol=1e-11)),  # ragged: 1667 / 1667 / 1666 rows, odd column count
+    (["--m", "4096", "--n", "8192", "--batched"], dict(batched=True)),          # + the in-library batched loop (one read-back per four iterations)
 ])
 def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     """north_star's ROW layout at one read of A per iteration, exercised on ONE GPU.  The ranks
@@ -841,9 +842,14 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
         assert all(by_k[k] == 1 for k in steady), by_k
         if fault:
             assert by_k[fault] >= 2, by_k
+    if checks.get("batched"):  # the scalar exchange is the only thing that holds the ranks together inside a batch
+        for bt in d["batched"]:
+            assert bt["k"] == 13 and bt["dz_rel"] <= tol, bt
     if checks.get("second"):  # the inboxes are cleared and the ranks meet once before the new layout's first sweep
         for sec in d["second"]:
             assert sec["max_dz_rel"] <= tol and sec["fallbacks"] == 0 and sec["a_passes"] <= 12 + 4, sec
+        return
+    if checks.get("batched"):
         return
     assert all(c == (4 if fault else 3 if checks.get("adaptive") else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
 

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
     ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
     ap.add_argument("--no-team", action="store_true", help="plain row shards (two sweeps + all-reduce) for comparison")
+    ap.add_argument("--batched", action="store_true",
+                    help="afterwards the same solve through the algorithm object with device_loop=True, check_every=4 (pg_iter_run_batched: "
+                         "sweeps, finish kernels and scalar exchanges of four iterations enqueued back to back, one host read-back per batch)")
     ap.add_argument("--then-n", type=int, default=0,
                     help="afterwards a SECOND problem with this many columns on the same contexts (another ring layout: the "
                          "devices clear their inboxes and meet in one exchange before its first sweep)")
@@ -109,6 +112,12 @@ def main():
                              "dz": float(np.max(np.abs(z - ref[k]))), "z_scale": float(max(1.0, np.max(np.abs(ref[k]))))})
                 passes = p
                 zs.append(z)
+            batched = None
+            if args.batched:
+                zb, kb = pa.FastForwardBackward(tol=0.0, maxit=args.steps + 1, device_loop=True, check_every=4)(
+                    x0=pa.HIPVector.from_numpy(x0, ctx), f=f, g=mk_g(), Lf=Lf)
+                zb = zb.numpy() if hasattr(zb, "numpy") else np.asarray(zb)
+                batched = {"k": int(kb), "dz_rel": float(np.max(np.abs(zb - ref[args.steps])) / max(1.0, float(np.max(np.abs(ref[args.steps])))))}
             second_dz = None
             if second is not None:
                 A2, b2, lam2, Lf2, ref2 = second
@@ -120,7 +129,7 @@ def main():
                     second_dz.append(float(np.max(np.abs(s.z.numpy() - ref2[k])) / max(1.0, float(np.max(np.abs(ref2[k]))))))
                 second_dz = {"max_dz_rel": max(second_dz), "a_passes": int(it2.counters.get("a_passes", 0)),
                              "fallbacks": int(it2.counters.get("sweep_fallbacks", 0))}
-            results[r] = (rows, zs, comm.calls[r], second_dz)
+            results[r] = (rows, zs, comm.calls[r], second_dz, batched)
         except BaseException as e:  # noqa: BLE001 -- reported in the JSON document, the other threads are released
             import traceback
 
@@ -140,7 +149,7 @@ def main():
     print(json.dumps({"m": m, "n": n, "ranks": N, "dtype": args.dtype, "max_wgs": max_wgs, "team": not args.no_team,
                       "ranks_agree_bitwise": bool(same), "fallback_flag": _lib.PG_FLAG_SWEEP_FALLBACK,
                       "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)],
-                      "second": [results[r][3] for r in range(N)]}))
+                      "second": [results[r][3] for r in range(N)], "batched": [results[r][4] for r in range(N)]}))
 
 
 def bench(args):
