@@ -895,6 +895,23 @@ def run_config3(pa, ctx, n=10_000_000, steps=200, beat=lambda: None):
                        "roofline": {"bound": "hbm", "kernel": "dr_step", "avg_launch_ms": round(ms / cnt, 5),
                                     "algorithmic_bytes_per_launch": b5, "achieved": round(b5 / (ms / cnt * 1e-3) / 1e9, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b5 / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    out["stepping"]["lookahead"] = True  # iteration k + 1 is in flight while the host reads iteration k's scalar (pg_dr_step_async)
+    try:  # the same loop with one launch and one read-back per iteration (rounds 1-3), for the difference
+        it1 = iter(pa.DouglasRachfordIteration(f=pa.SeparableQuadratic(d, q), g=pa.IndBox(lo, hi), x0=x0, gamma=gamma,
+                                               materialize=False, lookahead=False))
+        for _ in range(20):
+            s1 = next(it1)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            s1 = next(it1)
+            float(s1.res_inf) / float(gamma) <= 1e-8
+        ctx.sync()
+        out["stepping"]["no_lookahead_it_s"] = round(steps / (time.perf_counter() - t1), 1)
+        del it1, s1
+    except Exception as e:  # noqa: BLE001
+        out["stepping"]["no_lookahead_it_s"] = None
+    beat()
     # The same kernel WITHOUT a marker packet around every launch: 100 launches back to back (no scalar read-back) between
     # ONE event pair.  The per-launch pairs above put two marker packets next to a ~35 us kernel and read ~3 us more than
     # rocprofv3's kernel-trace does for the same launches; this figure is the one that agrees with the profiler.

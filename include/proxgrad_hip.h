@@ -317,6 +317,15 @@ pg_status pg_dr_step(pg_ctx* ctx, int32_t dtype, int64_t n, void* x, void* y, vo
                      const void* d_vec, double d, const void* q_vec, double q, int32_t g_kind, double g_p0,
                      double g_p1, double gamma, double* scalars_out /* host, 3 doubles; NULL = no sync */);
 
+/* Stepping (douglas_rachford.jl:53-63, one Base.iterate per call) with the NEXT iteration already in flight: iteration k + 1
+ * reads nothing but x_k, so it can be launched -- out of place, into a second set of state vectors -- before the host has
+ * read iteration k's norm(res, Inf); the host's round trip (half as long as the 34 us kernel at n = 10^7) then hides behind
+ * the kernel.  _async: one iteration x_in -> (x_out, y, r, z, res) (r, z, res nullable), scalars to slot 0 | 1, an event
+ * recorded behind it; _wait: block on THAT iteration only and return { norm(res, Inf), f(y), g(z) }. */
+pg_status pg_dr_step_async(pg_ctx* ctx, int32_t dtype, int64_t n, const void* x_in, void* x_out, void* y, void* r, void* z,
+                           void* res, const void* d_vec, double d, const void* q_vec, double q, int32_t g_kind, double g_p0,
+                           double g_p1, double gamma, int32_t slot);
+pg_status pg_dr_step_wait(pg_ctx* ctx, int32_t slot, double* scalars_out /* host, 3 doubles */);
 /* The DouglasRachford driver loop (src/ProximalAlgorithms.jl:114-123 with the default stop rule
  * norm(res, Inf) / gamma <= tol, douglas_rachford.jl:65-69, evaluated in T) inside the library.  With block = 8, 16, 32 or 64
  * that many iterations run per HBM sweep (f and g are separable, so the iterates of an element stay in registers;

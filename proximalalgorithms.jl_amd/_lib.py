@@ -131,6 +131,8 @@ SIGNATURES = {
     "pg_loss_value_and_gradient": [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _pf64],
     "pg_prox_sepquad": [_vp, _i32, _i64, _vp, _vp, _vp, _f64, _vp, _f64, _f64, _pf64],
     "pg_dr_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _i32, _f64, _f64, _f64, _pf64],
+    "pg_dr_step_async": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _i32, _f64, _f64, _f64, _i32],
+    "pg_dr_step_wait": [_vp, _i32, _pf64],
     "pg_dr_run": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _i32, _f64, _f64, _f64, _f64, _i64,
                   _i32, C.POINTER(_i64), _pf64],
     "pg_iter_opts_default": [C.POINTER(pg_iter_opts)],

@@ -68,7 +68,9 @@ enum {
   PG_S_TEAMERR = 14, // set to 1 by a workgroup team of the long-column sweep that gave up waiting for a member
   PG_S_DRRUN = 16,   // pg_dr_run block: { ||res||_inf of each of the K <= 64 inner iterations, f(y), g(z) }
   PG_S_DRRUN2 = 82,  // second set of the same (two blocks of pg_dr_run are in flight)
-  PG_S_COUNT = 148
+  PG_S_DRA = 148,    // pg_dr_step_async, slot 0: { ||res||_inf, f(y), g(z) }
+  PG_S_DRB = 151,    // ... slot 1 (the iteration launched while slot 0's is being looked at)
+  PG_S_COUNT = 154
 };
 
 constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize

@@ -35,7 +35,7 @@ class DouglasRachfordIteration:
     """douglas_rachford.jl:30-41 (keyword constructor: f, g, x0, gamma) and Base.iterate :53-63.
     ``materialize=False`` (fused engine only) skips writing r, z, res: x and y are the only n-vector writes."""
 
-    def __init__(self, *, f=None, g=None, x0, gamma, engine=None, materialize=True):
+    def __init__(self, *, f=None, g=None, x0, gamma, engine=None, materialize=True, lookahead=True):
         self.f = f if f is not None else Zero()
         self.g = g if g is not None else Zero()
         self.x0 = as_hipvector(x0)
@@ -46,6 +46,10 @@ class DouglasRachfordIteration:
             raise TypeError("engine='fused' needs f = SeparableQuadratic and g in {IndBox(scalar bounds), NormL1(scalar lam), Zero}")
         self.engine = engine
         self.materialize = bool(materialize)
+        # fused engine: iteration k + 1 is launched (into a second set of state vectors) before iteration k's scalars are read
+        # (pg_dr_step_async): the state yielded is the reference's state k, bit for bit; its vectors stay valid until the NEXT
+        # state is yielded, as in the reference (states are updated in place).  lookahead=False: one launch, one read-back.
+        self.lookahead = bool(lookahead)
 
     def device_run(self, maxit, tol, block=64):
         """The driver loop of ProximalAlgorithms.jl:114-123 with the default stop rule, inside the library
@@ -74,6 +78,26 @@ class DouglasRachfordIteration:
             p0, p1 = self.g.g_params()
             sc = (C.c_double * 3)()
             opt = (lambda v: v.vp) if self.materialize else (lambda v: None)
+            if self.lookahead:
+                h, dt, n, gk, gm = s.x.ctx.handle, s.x.pg_dtype, s.x.n, self.g.g_kind, float(self.gamma)
+                names = ("x", "y", "r", "z", "res")
+                sets = [{k: getattr(s, k) for k in names}, {k: s.x.similar() for k in names}]
+                x_in = s.x.copy()  # (state.x is written by the first iteration: it reads a copy of x0)
+
+                def launch(src, dst, slot):
+                    call("pg_dr_step_async", h, dt, n, src.vp, dst["x"].vp, dst["y"].vp, opt(dst["r"]), opt(dst["z"]), opt(dst["res"]),
+                         dv, d, qv, q, gk, p0, p1, gm, slot)
+
+                launch(x_in, sets[0], 0)
+                i = 0
+                while True:
+                    launch(sets[i]["x"], sets[1 - i], 1 - i)  # iteration k + 1, behind iteration k on the stream
+                    call("pg_dr_step_wait", h, i, sc)  # iteration k (its successor keeps running)
+                    for k in names:
+                        setattr(s, k, sets[i][k])
+                    s.res_inf, s.f_y, s.g_z = R(sc[0]), R(sc[1]), R(sc[2])
+                    yield s
+                    i = 1 - i
             while True:
                 call("pg_dr_step", s.x.ctx.handle, s.x.pg_dtype, s.x.n, s.x.vp, s.y.vp, opt(s.r), opt(s.z), opt(s.res),
                      dv, d, qv, q, self.g.g_kind, p0, p1, float(self.gamma), sc)
