@@ -264,6 +264,83 @@ time.sleep(30)
             assert d["value"] is None
 
 
+def test_team_ring_protocol_model():
+    """The granule ring of the team sweep (csrc/pg_gemv_tnt.h; the same protocol between workgroups of one device and, PEER,
+    between devices) as a model: every member, in its own order, POSTS step i into slot i % RING of every inbox and then CONSUMES
+    step i - LAG (waiting until all members have posted it).  Claim checked here under random interleavings: a slot is never
+    overwritten before its previous content (step i - RING) was consumed by the inbox's owner iff RING >= 2 LAG + 2 -- so the
+    constants in the source (TEAM_RING for LAG <= 3, PEER_RING for the PEER instantiations' LAG) are deep enough, and one slot
+    less is not."""
+    import random
+
+    src = open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "csrc", "pg_gemv_tnt.h")).read()
+    team_ring = int(re.search(r"constexpr int TEAM_RING = (\d+);", src).group(1))
+    peer_ring = int(re.search(r"constexpr int PEER_RING = (\d+);", src).group(1))
+    assert "static_assert(2 * LAG + 2 <= RING" in src
+    tn4 = open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "csrc", "pg_gemv_tn4.hip")).read()
+    peer_lags = {int(m.group(3)) for m in re.finditer(r"PG_TNP_CASE\((\d+), (\d+), (\d+)\)", tn4)}
+    assert peer_lags and max(peer_lags) * 2 + 2 <= peer_ring and 2 * 2 + 2 <= team_ring
+
+    def run(members, lag, ring, steps, seed):
+        """returns True when some post overwrote an unconsumed slot.  seed None: adversarial schedule -- member 0 runs whenever it
+        can, the others move one action at a time only while it is blocked (the widest skew the protocol allows)"""
+        rng = random.Random(seed)
+        posted = [-1] * members    # last step each member has posted
+        consumed = [-1] * members  # last step each member has consumed
+        phase = [0] * members      # 0: about to post step posted + 1; 1: about to consume step posted - lag
+
+        def can_move(m):
+            if phase[m] == 0:
+                if posted[m] < steps - 1:
+                    return True
+                return consumed[m] < steps - 1 and all(p >= consumed[m] + 1 for p in posted)  # tail: the last LAG totals
+            j = posted[m] - lag
+            return j < 0 or all(p >= j for p in posted)
+
+        def move(m):
+            if phase[m] == 0 and posted[m] < steps - 1:
+                i = posted[m] + 1
+                for q in range(members):  # the write lands in q's inbox slot i % ring: its old content is step i - ring
+                    if i - ring >= 0 and consumed[q] < i - ring:
+                        return True
+                posted[m] = i
+                phase[m] = 1
+            elif phase[m] == 0:
+                consumed[m] += 1
+            else:
+                j = posted[m] - lag
+                if j >= 0:
+                    consumed[m] = j
+                phase[m] = 0
+            return False
+
+        rr = 1
+        while any(c < steps - 1 for c in consumed):
+            movable = [m for m in range(members) if can_move(m)]
+            assert movable, "the protocol cannot deadlock"
+            if seed is None:
+                if 0 in movable:
+                    m = 0
+                else:
+                    while rr not in movable:
+                        rr = rr % (members - 1) + 1 if members > 1 else 0
+                    m = rr
+                    rr = rr % (members - 1) + 1 if members > 1 else 0
+            else:
+                m = rng.choice(movable)
+            if move(m):
+                return True
+        return False
+
+    for members, lag in ((2, 2), (8, 2), (16, 2), (4, 4), (8, 7), (3, 0), (5, 1)):
+        need = 2 * lag + 2
+        for seed in (None, 0, 1, 2, 3, 4, 5, 6, 7):
+            assert not run(members, lag, need, 6 * need, seed), (members, lag, seed)
+        assert run(members, lag, need - 1, 6 * need, None), (members, lag)  # one slot less is overrun at the widest skew
+    assert not any(run(8, max(peer_lags), peer_ring, 120, s) for s in (None, 1, 2))
+    assert not any(run(16, 2, team_ring, 120, s) for s in (None, 1, 2))
+
+
 def _bench_module():
     import importlib.util
 
