@@ -462,8 +462,9 @@ def cpu_baseline_full(A_dev, b_dev, lam, Lf, budget_s=25.0, max_steps=8):
             read_all = cpu_twin.read_gbps(A, threads=ncpu)  # this host's read rate on the same 64 GiB, same threads
             cpu_twin.load().cpu_twin_set_threads(ncpu)
             rec = {"host_read_GBps": round(read_all, 1),
-                   "host_read_note": "one OpenMP pass summing the same matrix on the same threads, eight independent partial sums per "
-                                     "thread, pages first-touched by the threads that read them (oracle/csrc/cpu_twin.c::cpu_twin_read_pass)",
+                   "host_read_note": "OpenMP passes summing the same matrix on the same threads, pages first-touched by the threads that read "
+                                     "them; the better of two access patterns (eight interleaved streams per thread / one contiguous stream "
+                                     "per thread: oracle/csrc/cpu_twin.c::cpu_twin_read_pass, _seq)",
                    "value": steps / sec, "value_1thread": 1.0 / sec_1t, "unit": "it/s", "cores": int(thr), "kind": "port",
                    "impl": "C / OpenMP twin of the reference's unfused op sequence (oracle/csrc/cpu_twin.c)",
                    "sample": f"the full workload: FFB fixed-step on the downloaded {m}x{n} float32 matrix ({A.nbytes / 2**30:.1f} GiB, "

@@ -120,6 +120,29 @@ double cpu_twin_read_pass(const float* a, long count, int reps, double* seconds_
   return total;
 }
 
+/* The same pass in gemv_t's own access pattern: every thread walks its chunk as ONE contiguous stream, 16384-float runs summed
+ * with a single `omp simd` reduction each (the compiler's unrolled vector accumulators) -- on some hosts this pattern streams
+ * faster than eight interleaved streams per thread, on others slower; the CPU leg reports the better of the two as the host's
+ * read rate. */
+double cpu_twin_read_pass_seq(const float* a, long count, int reps, double* seconds_out) {
+  double total = 0.0;
+  const double t0 = omp_get_wtime();
+  for (int r = 0; r < reps; ++r) {
+    double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+    for (long blk = 0; blk < (count + 16383) / 16384; ++blk) {
+      const long lo = blk * 16384, hi = lo + 16384 < count ? lo + 16384 : count;
+      float sum = 0.f;
+#pragma omp simd reduction(+ : sum)
+      for (long i = lo; i < hi; ++i) sum += a[i];
+      s += sum;
+    }
+    total += s;
+  }
+  *seconds_out = omp_get_wtime() - t0;
+  return total;
+}
+
 /* First touch of a buffer that a single-threaded copy is about to fill (the 64 GiB download of the device matrix): every
  * thread writes the pages of the static chunk it will later READ (gemv_t's column blocks, the read pass), so that on a
  * multi-socket host the pages live next to the cores that stream them instead of all on the copying thread's node. */

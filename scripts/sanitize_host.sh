@@ -50,8 +50,9 @@ for (m, n) in ((1, 1), (7, 5), (300, 900), (257, 1031)):
 for count in (1, 127, 128, 65536, 65537, 200_003):
     big = (np.arange(count, dtype=np.float32) % 7)
     sec = C.c_double()
-    tot = cpu_twin.load().cpu_twin_read_pass(big.ctypes.data, big.size, 2, C.byref(sec))
-    assert tot == 2 * float(big.astype(np.float64).sum()), count
+    for fn in (cpu_twin.load().cpu_twin_read_pass, cpu_twin.load().cpu_twin_read_pass_seq):
+        tot = fn(big.ctypes.data, big.size, 2, C.byref(sec))
+        assert tot == 2 * float(big.astype(np.float64).sum()), count
     buf = np.empty(count, np.float32)
     cpu_twin.first_touch(buf, threads=3)
 print("cpu_twin under ASan/UBSan: OK")

@@ -619,6 +619,7 @@ def test_cpu_twin_matches_the_numpy_oracle():
 
     big = np.arange(200_003, dtype=np.float32) % 7
     sec = C.c_double()
-    total = cpu_twin.load().cpu_twin_read_pass(big.ctypes.data, big.size, 3, C.byref(sec))
-    assert total == 3 * float(big.astype(np.float64).sum()) and sec.value > 0
+    for fn in (cpu_twin.load().cpu_twin_read_pass, cpu_twin.load().cpu_twin_read_pass_seq):
+        total = fn(big.ctypes.data, big.size, 3, C.byref(sec))
+        assert total == 3 * float(big.astype(np.float64).sum()) and sec.value > 0
     assert cpu_twin.read_gbps(big, threads=2, min_seconds=0.01) > 0
