@@ -136,6 +136,8 @@ def parse_args(argv=None):
     p.add_argument("--init-timeout", type=float, default=120.0, help="torch.distributed.init_process_group timeout, seconds")
     p.add_argument("--inject-fault", default=None, metavar="RANK:STAGE:KIND",
                    help="test hook: when RANK enters the record STAGE it hangs (KIND = hang) or exits with code 1 (KIND = exit)")
+    if argv is None and len(sys.argv) == 1 and os.environ.get("PG_BENCH_ARGV") and os.environ.get("WORLD_SIZE"):
+        argv = json.loads(os.environ["PG_BENCH_ARGV"])  # a rank started by self_launch: see launch_command
     return p.parse_args(argv)
 
 
@@ -159,8 +161,10 @@ def error_line(args, error, stage, **more):
 # N > 1 from a plain shell: start the ranks as a child process (never exec: see the module docstring)
 # ---------------------------------------------------------------------------------------------------------------
 def launch_command(args, port):
+    # the script's own arguments travel in PG_BENCH_ARGV (self_launch), not on the launcher's command line: torch.distributed.run
+    # parses with abbreviations and takes e.g. `--m 4096` for an ambiguous option of its own
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
 
 
 def _find_line(text):
@@ -187,6 +191,7 @@ def self_launch(args):
         port = s.getsockname()[1]
     cmd = launch_command(args, port)
     env = dict(os.environ)
+    env["PG_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True)
@@ -685,7 +690,9 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode, row_teams=Fals
     # row blocks as a row TEAM (one read of A per iteration; csrc/pg_gemv_tn4.hip): the ranks map each other's inbox through
     # IPC handles.  The context outlives this record, so the mode is switched off again for every other layout.
     teams = bool(row_teams) and layout == "rows" and D.world > 1
-    pa.attach_row_team(ctx, *((None, None) if teams else (1, 0)))
+    # (ranks SHARING one device -- the one-GPU tests -- must all be resident together: each takes its share of the compute units)
+    wgs = max(1, ctx.device_info()["compute_units"] // D.world) if (teams and getattr(D, "share_device", False)) else 0
+    pa.attach_row_team(ctx, *((None, None) if teams else (1, 0)), max_workgroups=wgs)
     zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)
     _, g0 = f.value_and_gradient(zero_n)  # = -A'b (row blocks: all-reduced; column blocks: this rank's columns)
     g0_inf = float(g0.norm_inf())
@@ -840,6 +847,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
     }
     if P.get("row_teams"):  # how the granule exchange went (sweeps, waves that had to wait, polls spent waiting), this rank
         rec["config"]["row_team_stats"] = pa.row_team_stats(ctx)
+        rec["config"]["row_team_selftest"] = getattr(ctx, "_row_team_selftest", None)  # the scalar exchange tried at attach time
     if layout != "none":
         calls = getattr(comm, "calls", 0) - calls0
         elems = getattr(comm, "elements", 0) - elems0
@@ -1293,6 +1301,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
             job.meta["collective_fallback"] = why or "another rank failed"
     job.meta["collective"] = collective
     D = Dist(world, rank, local_rank, args.backend, collective, args.overlap, args.force_comm)
+    D.share_device = bool(args.share_device)
     D.beat = wd.beat
 
     m_base, n = WORKLOADS[args.workload]
@@ -1503,7 +1512,9 @@ def row_team_records_in_a_child(args, job, wd, ctx, world, rank):
     # rank 0 a client of a server nobody runs on the new port)
     env = {k_: v for k_, v in os.environ.items() if not k_.startswith("TORCHELASTIC_")}
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29577")) + 23)
-    argv = [a for a in sys.argv[1:] if a != "--row-teams"]
+    env.pop("PG_BENCH_ARGV", None)
+    own = json.loads(os.environ["PG_BENCH_ARGV"]) if (len(sys.argv) == 1 and os.environ.get("PG_BENCH_ARGV")) else sys.argv[1:]
+    argv = [a for a in own if a != "--row-teams"]
     cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--row-teams-child"]
     out, err, note = "", "", None
     try:

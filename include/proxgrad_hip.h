@@ -161,6 +161,10 @@ pg_status pg_ctx_set_row_team(pg_ctx* ctx, int32_t nranks, int32_t rank, void* c
  * their first look; polls (one per ~64 clocks) those waves spent waiting.  late_waves / (sweeps * steps * waves) near 0 means the
  * exchange fits its lag; a large wait_polls with no fallback means the fabric's latency, not the kernel, sets the rate. */
 pg_status pg_ctx_row_team_stats(pg_ctx* ctx, int64_t* sweeps, int64_t* late_waves, int64_t* wait_polls);
+/* One scalar exchange through the inboxes, to be called by every device of the team at the same point (after
+ * pg_ctx_set_row_team and a barrier): device p contributes p + 1, *sum_out must come back as N (N + 1) / 2 on every device.
+ * PG_ERR_TIMEOUT when a peer's granules never became visible here (bounded wait): the sweeps would fall back every time. */
+pg_status pg_ctx_row_team_selftest(pg_ctx* ctx, double* sum_out);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every

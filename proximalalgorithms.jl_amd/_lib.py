@@ -85,6 +85,7 @@ SIGNATURES = {
     "pg_ctx_row_team_import": [_vp, _vp, C.POINTER(_vp)],
     "pg_ctx_set_row_team": [_vp, _i32, _i32, C.POINTER(_vp), _i32],
     "pg_ctx_row_team_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "pg_ctx_row_team_selftest": [_vp, _pf64],
     "pg_ctx_profile_reset": [_vp],
     "pg_ctx_profile_read": [_vp, _i32, C.POINTER(_i64), _pf64],
     "pg_malloc": [_vp, _sz, C.POINTER(_vp)],

@@ -252,6 +252,21 @@ pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* con
   return PG_OK;
 }
 
+pg_status pg_ctx_row_team_selftest(pg_ctx* c, double* sum_out) {
+  PG_REQUIRE(c != nullptr && sum_out != nullptr, "null argument");
+  PG_REQUIRE(c->rteam.n > 1 && c->rteam.f_local != nullptr, "the context is not a row team");
+  const double mine = (double)(c->rteam.rank + 1);
+  PG_HIP(hipMemcpyAsync(c->rteam.f_local, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  PG_HIP(hipStreamSynchronize(c->stream));
+  PG_TRY(pg_rteam_sum_scalar(c, c->rteam.f_local, c->rteam.f_local));
+  double got = 0.0;
+  PG_HIP(hipMemcpyAsync(&got, c->rteam.f_local, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  const pg_status st = pg_read_scalars(c, PG_S_TEAMERR, 1);  // (syncs; a peer that never answered shows as PG_ERR_TIMEOUT)
+  c->team_timeout = false;
+  *sum_out = got;
+  return st;
+}
+
 pg_status pg_ctx_row_team_stats(pg_ctx* c, int64_t* sweeps, int64_t* late_waves, int64_t* wait_polls) {
   PG_REQUIRE(c != nullptr, "ctx is null");
   unsigned long long h[2] = {0, 0};

@@ -472,6 +472,11 @@ function row_team_open(ctx::HIPContext, handle::Vector{UInt8})
     check(ccall((:pg_ctx_row_team_import, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx.handle, handle, p))
     p[]
 end
+function row_team_selftest(ctx::HIPContext)   # every rank, right after set_row_team! and a barrier: must return N (N + 1) / 2
+    s = Ref{Float64}(0.0)
+    check(ccall((:pg_ctx_row_team_selftest, libpg), Int32, (Ptr{Cvoid}, Ref{Float64}), ctx.handle, s))
+    s[]
+end
 function row_team_stats(ctx::HIPContext)   # (sweeps, late wave-steps, polls spent waiting) since set_row_team!
     a = Ref{Int64}(0); b = Ref{Int64}(0); c = Ref{Int64}(0)
     check(ccall((:pg_ctx_row_team_stats, libpg), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), ctx.handle, a, b, c))
@@ -501,7 +506,7 @@ end
 export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
        HIPForwardBackwardIteration, HIPFastForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve,
        hip_douglas_rachford, save_state, resume, HIPLBFGSOperator, enable_images!, images_update!, images_mul!, images_ready,
-       row_team_inbox, row_team_handle, row_team_open, set_row_team!, row_team_stats,
+       row_team_inbox, row_team_handle, row_team_open, set_row_team!, row_team_stats, row_team_selftest,
        fused_tn!, fused_dys!
 
 end # module

@@ -214,6 +214,23 @@ def _row_team_set(ctx, rank, inboxes, max_workgroups):
     ctx._row_team = (len(inboxes), int(rank), int(max_workgroups))
 
 
+def _row_team_selftest(ctx, world_size):
+    """one scalar exchange through the freshly mapped inboxes (every rank calls it at the same point): 'ok' when the sum of the
+    ranks' contributions came back, else what went wrong -- the sweeps still run (they fall back to two reads when a peer's
+    granules do not arrive), but the record says why"""
+    import ctypes as C
+
+    from ._lib import ProxGradError, call
+
+    got = C.c_double()
+    try:
+        call("pg_ctx_row_team_selftest", ctx.handle, C.byref(got))
+    except ProxGradError as e:
+        return "failed: %s" % str(e)[:160]
+    want = world_size * (world_size + 1) / 2
+    return "ok" if got.value == want else "wrong sum %r (expected %r)" % (got.value, want)
+
+
 def attach_row_team(ctx, world_size=None, rank=None, group=None, max_workgroups=0):
     """One process per GPU: make the row-sharded job on ``ctx`` a row team (pg_ctx_set_row_team).  Every rank allocates its
     inbox, the IPC handles travel with torch.distributed (any backend), every rank opens its peers' inboxes.  The collective
@@ -234,6 +251,7 @@ def attach_row_team(ctx, world_size=None, rank=None, group=None, max_workgroups=
     if cached is not None and cached[0] == (world_size, rank):  # the peers' inboxes are mapped once per context
         _row_team_set(ctx, rank, cached[1], max_workgroups)
         dist.barrier(group=group)
+        ctx._row_team_selftest = _row_team_selftest(ctx, world_size)
         return
     own = _row_team_alloc(ctx)
     handle = C.create_string_buffer(64)
@@ -251,6 +269,7 @@ def attach_row_team(ctx, world_size=None, rank=None, group=None, max_workgroups=
     _row_team_set(ctx, rank, inboxes, max_workgroups)
     ctx._row_team_inboxes = ((world_size, rank), inboxes)
     dist.barrier(group=group)  # nobody sweeps before every inbox is mapped and zeroed
+    ctx._row_team_selftest = _row_team_selftest(ctx, world_size)
 
 
 def row_team_in_process(contexts, max_workgroups=0):

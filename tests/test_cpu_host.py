@@ -151,12 +151,22 @@ def test_bench_self_launches_ranks_as_a_child(monkeypatch, capfd):
     cmd = bench.launch_command(args, 29999)
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
-    k = cmd.index(os.path.join(ROOT, "bench.py"))
-    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--launch-timeout", "4"]
+    # the script's own arguments do NOT ride on the launcher's command line (torch.distributed.run parses with abbreviations:
+    # `--m 4096` is "ambiguous" to it); the ranks read them from PG_BENCH_ARGV
+    assert cmd[-1] == os.path.join(ROOT, "bench.py")
+    monkeypatch.setenv("PG_BENCH_ARGV", json.dumps(["--gpus", "4", "--m", "4096", "--n", "512", "--steps", "7"]))
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a2 = bench.parse_args()
+    assert (a2.gpus, a2.m, a2.n, a2.steps) == (4, 4096, 512, 7)
+    monkeypatch.delenv("PG_BENCH_ARGV")
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2", "--launch-timeout", "4"])
 
     def child(code):
         # the child reports what it was given: its own process group (killpg must not reach pytest) and the IPC setting
-        pre = "import os,sys,time,json; assert os.getpgid(0) == os.getpid(); assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'; "
+        pre = ("import os,sys,time,json; assert os.getpgid(0) == os.getpid(); assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'; "
+               "assert json.loads(os.environ['PG_BENCH_ARGV'])[:2] == ['--gpus', '4']; ")
         monkeypatch.setattr(bench, "launch_command", lambda a, port: [sys.executable, "-c", pre + code])
 
     def run():

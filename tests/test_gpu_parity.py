@@ -627,13 +627,17 @@ def test_bench_self_launched_two_ranks_reports_every_layout(pa):
     assert d["rows_strong"]["config"]["lambda"] == pytest.approx(d["config"]["lambda"], rel=1e-5)
     assert d["config5_weak_rows"]["config"]["lambda"] == pytest.approx(d["config5_weak_cols"]["config"]["lambda"], rel=1e-5)
     assert d["config5_weak_rows"]["config"]["final"]["f_x"] == pytest.approx(d["config5_weak_cols"]["config"]["final"]["f_x"], rel=5e-4)
-    # the row layout as a row TEAM (one read of A per iteration), inboxes mapped through IPC handles between the two
-    # processes.  On ONE device the kernels of two processes are not run side by side, so every team sweep runs into its
-    # bounded wait and is redone with two sweeps (after three in a row the iterator stays there): what this checks is the
-    # plumbing (alloc / export / import / set across processes) and that the fallback ends at the same iterate.
+    # the row layout as a row TEAM (one read of A per iteration) between two PROCESSES: the inboxes are mapped through IPC
+    # handles (alloc / export / all-gather / import / set), the records run in a child process group of their own, and -- the
+    # ranks sharing this one device, each takes half of the compute units so that all members are resident together -- the
+    # sweeps really exchange their granules across the process boundary: the scalar-exchange self-test comes back "ok", every
+    # step is ONE read of the row block, nothing falls back, and the iterate is rows_strong's.
     for key, base in (("rows_strong_teams", "rows_strong"), ("config5_weak_rows_teams", "config5_weak_rows")):
         r = d[key]
-        assert r["config"]["row_teams"] and r["config"]["sharding"] == "rows" and r["ranks_seen_by_rccl"] == 2
+        assert r["config"]["row_teams"] and r["config"]["sharding"] == "rows" and r["ranks_seen_by_rccl"] == 2, r
+        assert r["config"]["row_team_selftest"] == "ok" and r["config"]["sweep_fallbacks"] == 0, r["config"]
+        assert r["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.15) and r["config"]["row_team_stats"]["sweeps"] >= 8
+        assert r["collective"]["allreduce_calls_per_step"] in (None, 0)
         assert r["config"]["final"]["f_x"] == pytest.approx(d[base]["config"]["final"]["f_x"], rel=1e-5)
         assert r["config"]["final"]["g_z"] == pytest.approx(d[base]["config"]["final"]["g_z"], rel=1e-5)
 
@@ -828,6 +832,7 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(out.stdout.splitlines()[-1])
     assert d["team"] and d["ranks_agree_bitwise"], d
+    assert all(v == "ok" for v in d["selftest"]), d["selftest"]  # pg_ctx_row_team_selftest: every rank saw 1 + 2 + ... + N
     tol = checks.get("tol", 1e-5)
     fault = checks.get("fault_step")
     for rows in d["steps"]:

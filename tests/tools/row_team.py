@@ -100,6 +100,12 @@ def main():
             if r == 0 and not args.no_team:
                 pa.row_team_in_process(ctxs, max_wgs)
             sync.wait(timeout=120)
+            selftest = None
+            if not args.no_team:  # one scalar exchange through the inboxes: the ranks' contributions 1 + 2 + ... + N
+                from proximalalgorithms.jl_amd.sharding import _row_team_selftest
+
+                selftest = _row_team_selftest(ctx, N)
+                sync.wait(timeout=120)
             if args.fault and r == 1:
                 _lib.call("pg_ctx_test_team_fault", ctx.handle, args.fault, 0)
             iteration = Iter(f=f, g=mk_g(), x0=pa.HIPVector.from_numpy(x0, ctx), Lf=Lf)
@@ -129,7 +135,7 @@ def main():
                     second_dz.append(float(np.max(np.abs(s.z.numpy() - ref2[k])) / max(1.0, float(np.max(np.abs(ref2[k]))))))
                 second_dz = {"max_dz_rel": max(second_dz), "a_passes": int(it2.counters.get("a_passes", 0)),
                              "fallbacks": int(it2.counters.get("sweep_fallbacks", 0))}
-            results[r] = (rows, zs, comm.calls[r], second_dz, batched)
+            results[r] = (rows, zs, comm.calls[r], second_dz, batched, selftest)
         except BaseException as e:  # noqa: BLE001 -- reported in the JSON document, the other threads are released
             import traceback
 
@@ -149,7 +155,8 @@ def main():
     print(json.dumps({"m": m, "n": n, "ranks": N, "dtype": args.dtype, "max_wgs": max_wgs, "team": not args.no_team,
                       "ranks_agree_bitwise": bool(same), "fallback_flag": _lib.PG_FLAG_SWEEP_FALLBACK,
                       "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)],
-                      "second": [results[r][3] for r in range(N)], "batched": [results[r][4] for r in range(N)]}))
+                      "second": [results[r][3] for r in range(N)], "batched": [results[r][4] for r in range(N)],
+                      "selftest": [results[r][5] for r in range(N)]}))
 
 
 def bench(args):
