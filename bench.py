@@ -691,7 +691,7 @@ def setup_lasso(pa, ctx, D, m_glob, n, dtype, seed, layout, mode, row_teams=Fals
     # IPC handles.  The context outlives this record, so the mode is switched off again for every other layout.
     teams = bool(row_teams) and layout == "rows" and D.world > 1
     # (ranks SHARING one device -- the one-GPU tests -- must all be resident together: each takes its share of the compute units)
-    wgs = max(1, ctx.device_info()["compute_units"] // D.world) if (teams and getattr(D, "share_device", False)) else 0
+    wgs = -D.world if (teams and getattr(D, "share_device", False)) else 0  # (-k: the default number of workgroups divided by k)
     pa.attach_row_team(ctx, *((None, None) if teams else (1, 0)), max_workgroups=wgs)
     zero_n = pa.HIPVector.zeros(n_loc, dtype, ctx)
     _, g0 = f.value_and_gradient(zero_n)  # = -A'b (row blocks: all-reduced; column blocks: this rank's columns)

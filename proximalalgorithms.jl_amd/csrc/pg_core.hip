@@ -236,7 +236,7 @@ pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* con
     return PG_OK;
   }
   PG_REQUIRE(nranks <= 16 && rank >= 0 && rank < nranks && inboxes != nullptr, "a row team has 2..16 devices");
-  PG_REQUIRE(max_workgroups >= 0, "negative workgroup count");
+  PG_REQUIRE(max_workgroups >= -16, "max_workgroups: a count, 0 (default), or -k when k members share this device");
   for (int q = 0; q < nranks; ++q) PG_REQUIRE(inboxes[q] != nullptr, "an inbox pointer is null");
   PG_REQUIRE(c->rteam.own != nullptr && inboxes[rank] == c->rteam.own, "inboxes[rank] must be this context's own inbox (pg_ctx_row_team_alloc)");
   c->rteam.n = nranks;

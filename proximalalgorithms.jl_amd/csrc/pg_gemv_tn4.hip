@@ -100,7 +100,9 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // measured on 2048- / 4096- / 8192-row blocks, two members sharing one device, 5.87 (four) / 6.08 (two) / 6.28 (two) TB/s
   // against 3.31 / 5.16 / 6.19 with one (profiles/r4_row_team_one_gpu.md)
   constexpr size_t PARK = (size_t)LAG * WAVES * C * U * 1024;
-  int64_t nteams = rt.max_wgs > 0 ? rt.max_wgs : (int64_t)c->num_cu * (PARK <= 32 * 1024 ? 4 : PARK <= 64 * 1024 ? 2 : 1);
+  int64_t nteams = (int64_t)c->num_cu * (PARK <= 32 * 1024 ? 4 : PARK <= 64 * 1024 ? 2 : 1);
+  if (rt.max_wgs > 0) nteams = rt.max_wgs;
+  if (rt.max_wgs < 0) nteams = nteams / -rt.max_wgs > 0 ? nteams / -rt.max_wgs : 1;  // -k: this device is shared by k members of the team
   if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
   if (nteams > ncg) nteams = ncg;
   if (nteams < 1) nteams = 1;
