@@ -557,7 +557,8 @@ def test_bench_line_contract(pa, cpu_mode):
 
 
 @pytest.mark.parametrize("mode,sharding,overlap", [("fixed", "rows", False), ("adaptive", "rows", False), ("fixed", "rows", True),
-                                                   ("fixed", "cols", False), ("fixed", "auto", False), ("adaptive", "cols", False)])
+                                                   ("fixed", "cols", False), ("fixed", "auto", False), ("adaptive", "cols", False),
+                                                   ("fixed", "rows-teams", False), ("adaptive", "rows-teams", False)])
 def test_two_ranks_one_gpu_matches_single_rank(pa, mode, sharding, overlap):
     """bench.py with 2 processes sharing cuda:0 over gloo == 1 process: same lambda / Lf (they come from all-reduced
     quantities) and the same iterate after 14 steps -- row shards (1024 rows each, two sweeps, [grad ; f] all-reduced)
@@ -568,11 +569,17 @@ def test_two_ranks_one_gpu_matches_single_rank(pa, mode, sharding, overlap):
     assert one_ss["config"]["final"]["f_x"] == pytest.approx(one["config"]["final"]["f_x"], rel=2e-4)
     assert one_ss["config"]["final"]["g_z"] == pytest.approx(one["config"]["final"]["g_z"], rel=2e-4)
     assert one_ss["roofline"]["kernel"] == "gemv_tn"
-    two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", sharding] +
-                     (["--overlap"] if overlap else []), nproc=2)
+    teams = sharding == "rows-teams"  # row blocks as a row TEAM: two processes, IPC-mapped inboxes, ONE read of A per iteration
+    two = _run_bench(["--mode", mode, "--backend", "gloo", "--share-device", "--sharding", "rows" if teams else sharding] +
+                     (["--overlap"] if overlap else []) + (["--row-teams", "--no-also"] if teams else []), nproc=2)
     assert two["n_gpus"] == 2
     cols = sharding in ("cols", "auto")
     assert two["config"]["sharding"] == ("cols" if cols else "rows")
+    if teams:
+        assert two["config"]["row_teams"] and two["config"]["row_team_selftest"] == "ok" and two["config"]["sweep_fallbacks"] == 0
+        assert two["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1) and two["roofline"]["kernel"] == "gemv_tn"
+        assert two["config"]["m_per_gpu"] * 2 == one["config"]["m"]
+        one = dict(one, config=dict(one["config"], a_passes_per_step=two["config"]["a_passes_per_step"]))  # (reads differ by design)
     if cols:
         assert two["config"]["n_per_gpu"] * 2 == one["config"]["n"] and two["config"]["m_per_gpu"] == one["config"]["m"]
         assert two["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1) and two["roofline"]["kernel"] == "gemv_tn"
