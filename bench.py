@@ -97,7 +97,7 @@ def parse_args(argv=None):
     p.add_argument("--sustain", type=float, default=None,
                    help="seconds the main record's iteration keeps running after the K timed steps (reported as `sustained`); "
                         "default: 5 for the one-GPU headline line, 0 otherwise")
-    p.add_argument("--also-budget", type=float, default=60.0, help="seconds the extra records may take in total (N = 1)")
+    p.add_argument("--also-budget", type=float, default=150.0, help="seconds the extra records may take in total (N = 1)")
     p.add_argument("--no-settle", dest="settle", action="store_false",
                    help="do not wait for the driver's background clearing of freed device memory before an extra record's set-up")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -1397,6 +1397,12 @@ def run_rank(args, job, wd, world, rank, local_rank):
         # short-column sweep, one wave per column group); the PMC passes of these sweeps were taken on exactly these shapes
         also_record("config5_column_block", lambda: ffb_record(131072, 131072, sub_steps, 3, "long_columns"), frees=131072 * 131072 * es)
         also_record("headline_row_block_n8", lambda: ffb_record(2048, 1 << 20, sub_steps, 3, "short_columns"), frees=2048 * (1 << 20) * es)
+        # north_star's ROW layout between two PROCESSES sharing this device (2 x 2048 rows, the headline's N = 8 block length; one
+        # process per rank, inboxes mapped through IPC handles): two sweeps + the all-reduce, then the same as a row TEAM (one read
+        # of A per iteration, csrc/pg_gemv_tn4.hip).  Each runs as a CHILD job of its own (`bench.py --gpus 2 --share-device ...`).
+        if dtype == np.float32:
+            also_record("rows_2proc_two_sweeps", lambda: shared_device_rows_record(4096, 1 << 20, False, sub_steps, wd.beat))
+            also_record("rows_2proc_row_team", lambda: shared_device_rows_record(4096, 1 << 20, True, sub_steps, wd.beat))
         if settled[0] > 0:
             extra["also_settle_s"] = round(settled[0], 2)
     elif world > 1:
@@ -1452,6 +1458,39 @@ def run_rank(args, job, wd, world, rank, local_rank):
     if rank == 0:
         job.write()
     return 0
+
+
+def shared_device_rows_record(m, n, teams, steps, beat=lambda: None, timeout=200.0):
+    """an N = 1 `also` record: `bench.py --gpus 2 --share-device --backend gloo --sharding rows [--row-teams]` as a child job
+    (its own launcher, two rank processes on this one device, gloo for the set-up collectives) and what its line says"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "2", "--share-device", "--backend", "gloo", "--sharding", "rows", "--m", str(m),
+           "--n", str(n), "--steps", str(steps), "--warmup", "3", "--no-also", "--no-cpu-baseline", "--no-row-teams", "--launch-timeout", str(timeout)]
+    if teams:
+        cmd.append("--row-teams")
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PG_BENCH_ARGV")
+           and not k_.startswith("TORCHELASTIC_")}
+    beat()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout + 30.0, env=env)
+    beat()
+    line = _find_line(out.stdout)
+    if line is None:
+        return {"error": "the two-process child printed no line (exit code %d)" % out.returncode, "stderr_tail": out.stderr.splitlines()[-4:]}
+    d = json.loads(line)
+    if d.get("value") is None:
+        return {"error": "child: %s (stage %s)" % (d.get("error"), d.get("stage"))}
+    cfg = d.get("config") or {}
+    passes = float(cfg.get("a_passes_per_step") or 0.0)
+    agg = d["value"] * passes * m * n * 4  # bytes of A streamed per second by the two ranks together
+    return {"value": d["value"], "unit": "it/s", "steps": d.get("steps"), "ms_per_step": d.get("ms_per_step"),
+            "config": {"workload": "FFB LASSO m=%d n=%d Float32, fixed step, rows of A over 2 PROCESSES sharing this device%s" % (
+                           m, n, " as a row team" if teams else " (two sweeps + all-reduce)"),
+                       "m": m, "n": n, "m_per_rank": m // 2, "a_passes_per_step": passes, "row_teams": bool(cfg.get("row_teams")),
+                       "sweep_fallbacks": cfg.get("sweep_fallbacks"), "row_team_selftest": cfg.get("row_team_selftest"),
+                       "row_team_stats": cfg.get("row_team_stats"), "final": cfg.get("final")},
+            "roofline": {"bound": "hbm", "kernel": "gemv_tn (row team, 2 processes)" if teams else "gemv_n_partial + gemv_t (2 processes)",
+                         "avg_launch_ms": (d.get("roofline") or {}).get("avg_launch_ms"), "achieved": round(agg / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(agg / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "aggregate over the two ranks: it/s x reads of A per iteration x m n s"}}
 
 
 ROW_TEAM_RECORDS = (("rows_strong_teams", "strong"), ("config5_weak_rows_teams", "weak"))

@@ -891,7 +891,7 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
 
     def rates_ok(d):
         """the thresholds on measured rates (everything else below is structure, checked on every line)"""
-        ad, c2, c3, c4, c5c, c5r = d["also"]
+        ad, c2, c3, c4, c5c, c5r = d["also"][:6]
         return (d["roofline"]["frac"] > 0.6  # north_star: >= 60 % of the HBM roofline
                 and abs(d["sustained"]["value"] / d["value"] - 1.0) < 0.05  # the K-step figure is not a burst
                 and c5c["roofline"]["frac"] > 0.8 and c5r["roofline"]["frac"] > 0.75 and ad["roofline"]["frac"] > 0.6
@@ -903,8 +903,16 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
         assert d["roofline"]["kernel"] == "gemv_tn" and "traffic_stale" in d["roofline"]
         assert d["sustained"]["seconds"] >= 4.5
         labels = [r["label"] for r in d["also"]]
-        assert labels == ["headline_adaptive", "config2", "config3", "config4", "config5_column_block", "headline_row_block_n8"], labels
-        ad, c2, c3, c4, c5c, c5r = d["also"]
+        assert labels == ["headline_adaptive", "config2", "config3", "config4", "config5_column_block", "headline_row_block_n8",
+                          "rows_2proc_two_sweeps", "rows_2proc_row_team"], labels
+        ad, c2, c3, c4, c5c, c5r, r2, rt = d["also"]
+        # north_star's row layout between two PROCESSES on this device: the row team reads its blocks ONCE per iteration (IPC-mapped
+        # inboxes, self-test ok, no fallback), ends at the two-sweep iterate and is faster than it
+        assert r2["config"]["a_passes_per_step"] == 2.0 and not r2["config"]["row_teams"]
+        assert rt["config"]["row_teams"] and rt["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1), rt["config"]
+        assert rt["config"]["row_team_selftest"] == "ok" and rt["config"]["sweep_fallbacks"] == 0
+        assert rt["config"]["final"]["f_x"] == pytest.approx(r2["config"]["final"]["f_x"], rel=1e-5)
+        assert rt["value"] > 1.3 * r2["value"], (rt["value"], r2["value"])
         assert c5c["config"]["m"] == 131072 and c5c["config"]["a_passes_per_step"] == 1.0 and c5c["config"]["sweep_fallbacks"] == 0
         assert c5r["config"]["m"] == 2048 and c5r["config"]["a_passes_per_step"] == 1.0
         assert ad["config"]["mode"] == "adaptive" and ad["config"]["a_passes_per_step"] <= 1.5
@@ -912,7 +920,7 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
         assert c3["stepping"]["roofline"]["kernel"] == "dr_step"
         assert c4["config"]["A_passes_per_step"] <= 3.0
         for r in d["also"]:
-            assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["avg_launch_ms"] > 0
+            assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["avg_launch_ms"] > 0, r.get("label")
 
     d = run()
     structure(d)
