@@ -146,7 +146,9 @@ pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
  * sums them in device order and goes on with the prox and A_p v while the column tile waits in LDS (csrc/pg_gemv_tn4.hip).
  * f and the bounded-wait timeout flag are exchanged the same way after the sweep, so a steady-state iteration issues no
  * collective; initialisation, the line search and the two-sweep fallback still use the registered all-reduce.
- *   _alloc   this context's inbox (fine-grained device memory, zeroed; freed with the context)
+ *   _alloc   this context's inbox (fine-grained device memory, zeroed; freed with the context -- the peers write into it
+ *            during their sweeps, so a context of a team is destroyed only after every device of the team has synchronised
+ *            (pg_ctx_sync) and left the team or stopped iterating: a barrier before pg_ctx_destroy)
  *   _export  its IPC handle (64 bytes) for the other processes of the node;  _import  opens a peer's handle here
  *   pg_ctx_set_row_team(ctx, nranks, rank, inboxes, max_workgroups): inboxes[q] = device q's inbox as mapped into THIS
  *            process (inboxes[rank] = the own one); max_workgroups = workgroups per device (0: as many per compute unit as the

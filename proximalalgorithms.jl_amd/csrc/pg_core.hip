@@ -196,11 +196,12 @@ pg_status pg_ctx_row_team_alloc(pg_ctx* c, void** inbox_out, int64_t* bytes_out)
       return PG_ERR_ALLOC;
     }
     PG_HIP(hipMemset(c->rteam.own, 0, bytes));
-    if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, sizeof(double)));
-    if (c->rteam.wait_stats == nullptr) {
-      PG_HIP(hipMalloc((void**)&c->rteam.wait_stats, 2 * sizeof(unsigned long long)));
-      PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
-    }
+  }
+  // (outside the branch above: a call that failed here is completed by the next one)
+  if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, sizeof(double)));
+  if (c->rteam.wait_stats == nullptr) {
+    PG_HIP(hipMalloc((void**)&c->rteam.wait_stats, 2 * sizeof(unsigned long long)));
+    PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
   }
   *inbox_out = c->rteam.own;
   if (bytes_out) *bytes_out = (int64_t)bytes;
