@@ -51,7 +51,8 @@ pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void*
 /* The kth_launch-th long-column (team) sweep launched on this context from now on (1-based; 0 switches the hook off) fails:
  * kind 0 -- one workgroup of one team is never started, its team-mates run into their bounded wait and the step is redone with
  * two sweeps (PG_FLAG_SWEEP_FALLBACK); kind 1 -- the launch is refused (PG_ERR_UNSUPPORTED), as a cooperative launch that
- * does not fit next to other work would be.  Nothing in the library reads the environment for this. */
+ * does not fit next to other work would be (a row-team sweep, pg_ctx_set_row_team, is a plain launch that is never refused:
+ * there kind 1 acts like kind 0).  Nothing in the library reads the environment for this. */
 pg_status pg_ctx_test_team_fault(pg_ctx* ctx, int32_t kth_launch, int32_t kind);
 
 #ifdef __cplusplus

@@ -161,11 +161,10 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   unsigned grid = (unsigned)nteams;
   c->team_launches++;
   if (c->test_team_fault > 0 && c->team_launches == c->test_team_fault && grid > 1) {
-    if (c->test_team_fault_kind == 1) {
-      pg_set_error("the row-team sweep was refused (injected by pg_ctx_test_team_fault)");
-      return PG_ERR_UNSUPPORTED;
-    }
-    grid -= 1;  // test hook: one workgroup of this device never starts; its peers on the other devices time out
+    // test hook: one workgroup of this device never starts; its peers on the other devices time out.  (Both kinds: "refused at
+    // launch" is a property of COOPERATIVE launches -- the one-device team sweep -- and this is a plain one; a device that
+    // dropped out of a step on its own would leave its peers alone in the step's exchanges.)
+    grid -= 1;
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead

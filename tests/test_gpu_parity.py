@@ -814,6 +814,7 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "16384", "--n", "4096", "--ranks", "8"], dict()),                  # 8 ranks x 2048 rows: the headline's N = 8 block
     (["--m", "6144", "--n", "4096", "--ranks", "3", "--fast", "0", "--g", "box"], dict()),  # ForwardBackward + IndBox, 3 ranks
     (["--m", "4096", "--n", "8192", "--fault", "3"], dict(fault_step=3)),       # rank 1 loses a workgroup in its 3rd sweep
+    (["--m", "4096", "--n", "8192", "--fault", "3", "--fault-kind", "1"], dict(fault_step=3)),  # "refused" on one rank: a plain launch is never refused, the hook acts like a lost workgroup (the ranks stay in step)
     (["--m", "8192", "--n", "8192", "--ranks", "4", "--adaptive"], dict(adaptive=True)),  # adaptive step: line search on the residual pair
     (["--m", "4096", "--n", "8192", "--then-n", "700"], dict(second=True)),    # a second matrix on the same contexts: another ring layout
     (["--m", "5000", "--n", "1001", "--ranks", "3", "--dtype", "f64"], dict(tol=1e-11)),  # ragged: 1667 / 1667 / 1666 rows, odd column count

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--g", choices=["l1", "box"], default="l1")
     ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
     ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
+    ap.add_argument("--fault-kind", type=int, default=0, help="0: that sweep loses a workgroup; 1: that sweep is refused at launch on rank 1")
     ap.add_argument("--no-team", action="store_true", help="plain row shards (two sweeps + all-reduce) for comparison")
     ap.add_argument("--batched", action="store_true",
                     help="afterwards the same solve through the algorithm object with device_loop=True, check_every=4 (pg_iter_run_batched: "
@@ -107,7 +108,7 @@ def main():
                 selftest = _row_team_selftest(ctx, N)
                 sync.wait(timeout=120)
             if args.fault and r == 1:
-                _lib.call("pg_ctx_test_team_fault", ctx.handle, args.fault, 0)
+                _lib.call("pg_ctx_test_team_fault", ctx.handle, args.fault, args.fault_kind)
             iteration = Iter(f=f, g=mk_g(), x0=pa.HIPVector.from_numpy(x0, ctx), Lf=Lf)
             rows, passes, zs = [], 0, []
             for k, s in enumerate(itertools.islice(iteration, args.steps + 1)):
