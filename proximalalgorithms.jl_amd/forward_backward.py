@@ -162,7 +162,9 @@ class ForwardBackwardIteration:
         `iterate(iter, state)` resumes from: state vectors, residuals, gamma, f_x, g_z, the extrapolation sequence's state.
         Engine "fused" only (pg_iter_state_download)."""
         if getattr(self, "_fused", None) is None:
-            raise ValueError("save_state needs a started iteration on the fused engine")
+            raise ValueError("save_state needs a started iteration on the fused engine (this one: engine=%r; pass engine='fused' to "
+                             "the constructor -- the automatic choice takes the composed engine for an adaptive ForwardBackward on a "
+                             "large unsharded matrix)" % (self.engine,))
         return self._fused.state_download()
 
     def resume(self, blob):
