@@ -565,6 +565,7 @@ pg_status pg_mat_destroy(pg_mat* A) {
   if (!A) return PG_OK;
   if (A->data) (void)hipFree(A->data);
   if (A->partials) (void)hipFree(A->partials);
+  for (void* q : A->retired) (void)hipFree(q);
   if (A->rpad) (void)hipFree(A->rpad);
   if (A->xch) (void)hipFree(A->xch);
   delete A;

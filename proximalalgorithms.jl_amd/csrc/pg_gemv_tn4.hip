@@ -84,6 +84,25 @@ __global__ __launch_bounds__(64) void peer_scalars_kernel(PeerScalArgs p) {
   }
 }
 
+// ensure_partials without its hipFree: a free synchronises the whole DEVICE, and where several members of a team share one
+// (the one-GPU tests: contexts of one process) a peer's kernel may already be waiting there for this rank's granules -- the
+// free would sit behind that wait until it expires (measured: the first sweep of about one solve in ten fell back to two
+// reads that way).  The outgrown buffer is kept until the matrix goes (at most a few per matrix: the buffer only grows).
+pg_status grow_partials_without_free(pg_mat* A, int S) {
+  if (A->partials && A->partials_slots >= S) return PG_OK;
+  void* grown = nullptr;
+  const size_t bytes = (size_t)S * (size_t)A->ld * pg_sizeof(A->dtype);
+  hipError_t e = hipMalloc(&grown, bytes);
+  if (e != hipSuccess) {
+    pg_set_error("hipMalloc(%zu) for GEMV partial sums failed: %s", bytes, hipGetErrorString(e));
+    return PG_ERR_ALLOC;
+  }
+  if (A->partials) A->retired.push_back(A->partials);  // kernels enqueued earlier may still read it
+  A->partials = grown;
+  A->partials_slots = S;
+  return PG_OK;
+}
+
 template <typename T, int U, int C, int LAG, int PF>
 pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   constexpr int WAVES = 4;
@@ -106,7 +125,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
   if (nteams > ncg) nteams = ncg;
   if (nteams < 1) nteams = 1;
-  PG_TRY(ensure_partials(A, (int)nteams));
+  PG_TRY(grow_partials_without_free(A, (int)nteams));
   a.partials = (T*)A->partials;
   a.team_size = 1;
   a.ueff = (a.nrg + WAVES - 1) / WAVES;

@@ -181,6 +181,7 @@ struct pg_mat {
   // workspace for y = A x partial sums (lazy)
   void* partials = nullptr;
   int64_t partials_slots = 0;
+  std::vector<void*> retired;  // outgrown partial-sum buffers of a row-team matrix, freed with the matrix (pg_gemv_tn4.hip)
   void* rpad = nullptr;  // [ld] zero-padded copy of a caller's m-vector (pg_mat_fused_tn)
   void* xch = nullptr;   // granule ring of the workgroup teams of the long-column sweep (gemv_tnt_kernel)
   size_t xch_bytes = 0;

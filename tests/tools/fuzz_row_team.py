@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Randomised runs of tests/tools/row_team.py (north_star's row layout at one read of A per iteration, the ranks as contexts of
+one process on one GPU): random rank counts, block lengths (every PEER geometry: U = 2 .. 16, ragged last row groups, blocks of
+different length on different ranks), column counts, element types, FB / FFB, fixed / adaptive step, L1 / box.  Per case the
+checks of test_row_team_iterates_match_oracle_at_one_read_of_A: every rank's iterates equal the CPU restatement on the WHOLE
+matrix, the ranks agree bit for bit, the self-test passed, and from the second step on a step that is not flagged as a
+fallback is ONE read of the row block.  Usage: python tests/tools/fuzz_row_team.py [cases] [first_seed]."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    f64 = bool(rng.random() < 0.3)
+    ranks = int(rng.choice([2, 2, 3, 4, 5, 8]))
+    cap = 8192 if f64 else 16384  # rows per rank the PEER sweep covers
+    if rng.random() < 0.5:
+        rpr = int(rng.choice([1, 100, 256, 257, 512, 1024, 2048, 2049, 4096, 5000, 8192, 12000, 16384]))
+    else:
+        rpr = int(rng.integers(1, cap + 1))
+    rpr = min(rpr, cap)
+    m = ranks * rpr - int(rng.integers(0, min(ranks, rpr)))  # ragged: the last ranks hold one row less
+    n = int(rng.choice([1, 2, 3, 31, 64, 65, 500, 1001])) if rng.random() < 0.5 else int(rng.integers(1, 1500))
+    while m * n > 2.5e7:  # the oracle runs on the whole matrix on the CPU
+        n = max(1, n // 2)
+    args = ["--m", str(m), "--n", str(n), "--ranks", str(ranks), "--steps", "8"]
+    if f64:
+        args += ["--dtype", "f64"]
+    if rng.random() < 0.35:
+        args += ["--fast", "0"]
+    adaptive = bool(rng.random() < 0.35)
+    if adaptive:
+        args += ["--adaptive"]
+    if rng.random() < 0.3:
+        args += ["--g", "box"]
+    return args, (1e-11 if f64 else 1e-5), adaptive
+
+
+def one_case(seed):
+    args, tol, adaptive = draw(seed)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "row_team.py")] + args, capture_output=True, text=True,
+                         timeout=600)
+    label = "seed=%d %s" % (seed, " ".join(args))
+    if out.returncode != 0:
+        return "exit %d: %s" % (out.returncode, (out.stdout[-600:] + out.stderr[-600:]).replace("\n", " | ")), label, 0
+    d = json.loads(out.stdout.splitlines()[-1])
+    if not d["ranks_agree_bitwise"]:
+        return "the ranks' iterates differ", label, 0
+    if not all(v == "ok" for v in d["selftest"]):
+        return "self-test: %r" % (d["selftest"],), label, 0
+    fallbacks = 0
+    for rows in d["steps"]:
+        flagged = {r["k"] for r in rows if r["flags"] & d["fallback_flag"]}
+        fallbacks += len(flagged)
+        for r in rows:
+            if not r["dz"] <= tol * r["z_scale"]:
+                return "iterate %d off by %.3g (scale %.3g)" % (r["k"], r["dz"], r["z_scale"]), label, fallbacks
+            if adaptive and abs(r["gamma"] - r["gamma_oracle"]) > 1e-6 * abs(r["gamma_oracle"]):
+                return "gamma %r against the oracle's %r at iteration %d" % (r["gamma"], r["gamma_oracle"], r["k"]), label, fallbacks
+            # one read of the block per step from the second step on -- except a step whose sweep was lost (flagged: redone with
+            # two sweeps) and the step after it (no speculative half to continue from)
+            if r["k"] >= 2 and r["k"] not in flagged and r["k"] - 1 not in flagged and r["a_passes"] != 1 and not adaptive:
+                return "iteration %d read the block %d times without a fallback flag; reads by iteration and rank: %r" % (
+                    r["k"], r["a_passes"], [[x["a_passes"] for x in rr] for rr in d["steps"]]), label, fallbacks
+    if fallbacks:
+        print("NOTE", label, "-- %d rank-steps redone with two sweeps: iterations %r" % (
+            fallbacks, sorted({r["k"] for rows in d["steps"] for r in rows if r["flags"] & d["fallback_flag"]})), flush=True)
+    return "", label, fallbacks
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    bad = fb = 0
+    for seed in range(seed0, seed0 + cases):
+        try:
+            why, label, fallbacks = one_case(seed)
+        except Exception as e:  # noqa: BLE001
+            why, label, fallbacks = "%s: %s" % (type(e).__name__, e), "seed=%d" % seed, 0
+        fb += fallbacks
+        if why:
+            bad += 1
+            print("FAIL", label, "--", why, flush=True)
+    print("%d cases, %d failing, %d rank-steps redone with two sweeps, %.1f s" % (cases, bad, fb, time.time() - t0))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
