@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised runs of tests/tools/row_team.py (north_star's row layout at one read of A per iteration, the ranks as contexts of
 one process on one GPU): random rank counts, block lengths (every PEER geometry: U = 2 .. 16, ragged last row groups, blocks of
-different length on different ranks), column counts, element types, FB / FFB, fixed / adaptive step, L1 / box.  Per case the
+different length on different ranks), column counts, element types, FB / FFB, fixed / adaptive step, L1 / box, the batched
+in-library loop, a second problem on the same contexts.  Per case the
 checks of test_row_team_iterates_match_oracle_at_one_read_of_A: every rank's iterates equal the CPU restatement on the WHOLE
 matrix, the ranks agree bit for bit, the self-test passed, and from the second step on a step that is not flagged as a
 fallback is ONE read of the row block.  Usage: python tests/tools/fuzz_row_team.py [cases] [first_seed]."""
@@ -40,6 +41,13 @@ def draw(seed):
         args += ["--adaptive"]
     if rng.random() < 0.3:
         args += ["--g", "box"]
+    # drawn last, from a generator of their own (the cases of the first campaigns keep their seeds): the in-library batched loop
+    # afterwards (FastForwardBackward, fixed step), a second problem on the same contexts (another ring layout)
+    rx = np.random.default_rng(seed + 7_000_003)
+    if "--fast" not in args and not adaptive and rx.random() < 0.3:
+        args += ["--batched"]
+    if rx.random() < 0.3:
+        args += ["--then-n", str(int(rx.integers(1, 900)))]
     return args, (1e-11 if f64 else 1e-5), adaptive
 
 
@@ -69,6 +77,14 @@ def one_case(seed):
             if r["k"] >= 2 and r["k"] not in flagged and r["k"] - 1 not in flagged and r["a_passes"] != 1 and not adaptive:
                 return "iteration %d read the block %d times without a fallback flag; reads by iteration and rank: %r" % (
                     r["k"], r["a_passes"], [[x["a_passes"] for x in rr] for rr in d["steps"]]), label, fallbacks
+    if "--batched" in args:
+        for bt in d["batched"]:
+            if not (bt["k"] == 9 and bt["dz_rel"] <= tol):
+                return "batched loop: %r" % (bt,), label, fallbacks
+    if "--then-n" in args:
+        for sec in d["second"]:
+            if not (sec["max_dz_rel"] <= tol and sec["fallbacks"] == 0):
+                return "second problem on the same contexts: %r" % (sec,), label, fallbacks
     if fallbacks:
         print("NOTE", label, "-- %d rank-steps redone with two sweeps: iterations %r" % (
             fallbacks, sorted({r["k"] for rows in d["steps"] for r in rows if r["flags"] & d["fallback_flag"]})), flush=True)
