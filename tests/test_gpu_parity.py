@@ -2098,6 +2098,43 @@ def test_fuzz_newton_type_and_douglas_rachford(pa):
     assert not bad, bad
 
 
+def test_fuzz_checkpoint_resume(pa):
+    """tests/tools/fuzz_resume.py (3400 cases in profiles/r4_fuzz_campaigns.log): random problem, random iteration options (FB / FFB,
+    every built-in sequence, fixed / adaptive, every g incl. per-element parameters, one or two sweeps, every sweep geometry),
+    k1 iterations + save + a NEW iterator + upload + k2 iterations == k1 + k2 straight, bit for bit."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_resume", os.path.join(root, "tests", "tools", "fuzz_resume.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = []
+    for seed in range(7000, 7060):
+        why, label = fz.one_case(seed)
+        if why:
+            bad.append((label, why))
+    assert not bad, bad
+
+
+def test_fuzz_row_teams_on_one_gpu(pa):
+    """tests/tools/fuzz_row_team.py (500 cases in profiles/r4_fuzz_campaigns.log): random rank counts, block lengths, element types,
+    iterations; every rank against the CPU restatement on the whole matrix, the ranks bit-identical, one read of the block per
+    step -- and NO sweep lost to the bounded wait (the campaign's finding: a device-wide hipFree behind a waiting peer)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_row_team", os.path.join(root, "tests", "tools", "fuzz_row_team.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad, lost = [], 0
+    for seed in (600022, 600023, 600027, 600032, 600042, 8001, 8002, 8003):  # the first five: cases that lost their first sweep before the fix
+        why, label, fallbacks = fz.one_case(seed)
+        lost += fallbacks
+        if why:
+            bad.append((label, why))
+    assert not bad and lost == 0, (bad, lost)
+
+
 # ------------------------------------------------------------------------------------------------
 # single-sweep pass (pg_ls_fused_pass): A' r, epilogue, next extrapolation and next residual in one read of A
 # ------------------------------------------------------------------------------------------------
