@@ -16,6 +16,11 @@ void pg_set_error(const char* fmt, ...) {
   g_last_error = buf;
 }
 
+std::mutex& pg_coop_launch_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+
 extern "C" {
 
 int32_t pg_abi_version(void) { return PG_ABI_VERSION; }

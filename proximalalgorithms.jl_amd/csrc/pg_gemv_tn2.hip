@@ -578,7 +578,11 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     PG_HIP(hipEventRecord(c->coop_probe[0], c->stream));
   }
   void* args[1] = {(void*)&a};
-  hipError_t e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(WAVES * 64), args, (unsigned)lds, c->stream);
+  hipError_t e;
+  {
+    std::lock_guard<std::mutex> lock(pg_coop_launch_mutex());  // (see pg_internal.h: concurrent cooperative launches crash the process at exit)
+    e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(WAVES * 64), args, (unsigned)lds, c->stream);
+  }
   if (probe && e == hipSuccess) {
     PG_HIP(hipEventRecord(c->coop_probe[1], c->stream));
     c->coop_probe_bytes = sweep_bytes;

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -236,6 +237,11 @@ pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out);
 // r_out = a r1 + b r2 over m elements, dscal[PG_S_F] = f_scale ||r_out||^2, optional typed mirror of f
 pg_status pg_residual_combo_async(pg_ctx* ctx, int dtype, int64_t m, void* r_out, double a, const void* r1, double b,
                                   const void* r2, double f_scale, void* f_typed, double* f_dst = nullptr);
+// One cooperative launch at a time per process: two host threads (two contexts) inside hipLaunchCooperativeKernel at once left the
+// runtime in a state that crashed the process at exit (ROCm 7.2; reproduced with two threads x three team sweeps -- one after the
+// other, or under this lock: clean).  Held for the enqueue only, not for the kernel.  (pg_core.hip)
+std::mutex& pg_coop_launch_mutex();
+
 // row teams: *out = sum over the devices of *local (device order), PG_S_TEAMERR = any device's flag; one launch, no collective
 pg_status pg_rteam_sum_scalar(pg_ctx* ctx, const double* local, double* out);
 // column sharding: global sums / max of the four epilogue scalars in dscal[PG_S_GZ..PG_S_RESSQ] (one small all-reduce)

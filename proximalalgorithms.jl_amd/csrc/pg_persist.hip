@@ -956,7 +956,11 @@ pg_status iter_run_coop(pg_iter* it, int64_t k_start, int64_t maxit, double tol,
   p.npart = p.spart + n_sp;
   p.rfull = (T*)(p.npart + n_np);
   void* args[1] = {(void*)&p};
-  hipError_t e = hipLaunchCooperativeKernel(kern, dim3((unsigned)W), dim3(SMALL_THREADS), args, (unsigned)lds, c->stream);
+  hipError_t e;
+  {
+    std::lock_guard<std::mutex> lock(pg_coop_launch_mutex());  // (see pg_internal.h)
+    e = hipLaunchCooperativeKernel(kern, dim3((unsigned)W), dim3(SMALL_THREADS), args, (unsigned)lds, c->stream);
+  }
   if (e != hipSuccess) {
     pg_set_error("cooperative launch (%d workgroups, %zu bytes of LDS) failed: %s", W, lds, hipGetErrorString(e));
     return PG_ERR_HIP;

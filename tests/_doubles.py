@@ -46,11 +46,12 @@ class ThreadAllReduce:
         self.slots = [None] * self.world_size
         self.calls = [0] * self.world_size
 
-    def view(self, rank):
+    def view(self, rank, shard="rows"):
         outer = self
+        shard_ = shard
 
         class _Rank:
-            world_size, shard = outer.world_size, "rows"
+            world_size, shard = outer.world_size, shard_
 
             def attach(self, ctx):
                 import ctypes as C
@@ -73,6 +74,6 @@ class ThreadAllReduce:
                     call("pg_memcpy_h2d", ctx.handle, C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), total.nbytes)
 
                 ctx.set_allreduce(fn)
-                ctx.set_column_sharding(0, rank)
+                ctx.set_column_sharding(outer.world_size if shard_ == "cols" else 0, rank)
 
         return _Rank()

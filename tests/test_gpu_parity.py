@@ -867,6 +867,39 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     assert all(c == (4 if fault else 3 if checks.get("adaptive") else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
 
 
+@pytest.mark.parametrize("args", [
+    ["--m", "4096", "--n", "8192", "--ranks", "2"],
+    ["--m", "40000", "--n", "50", "--ranks", "4", "--dtype", "f64", "--adaptive"],  # team sweeps (cooperative launches) from four host threads at once
+    ["--m", "2000", "--n", "501", "--ranks", "8", "--fast", "0"],
+    ["--m", "70001", "--n", "130", "--ranks", "3", "--batched"],
+])
+def test_column_shards_in_one_process_match_oracle(pa, args):
+    """COLUMN shards (bench.py's default layout for N > 1) with the ranks as contexts of one process, one host thread each
+    (tests/tools/row_team.py --cols; the collective is a host-side double): every rank's slice of every iterate against the
+    CPU restatement on the whole matrix, the iteration's scalars bit-identical on all ranks, one read of the column block per
+    step from the second step on, one all-reduce per iteration.  The process must also END cleanly: two host threads inside
+    hipLaunchCooperativeKernel at once used to leave the runtime in a state that crashed at exit (pg_coop_launch_mutex)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "row_team.py"), "--cols", "--steps", "8"] + args,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-2000:])
+    d = json.loads(out.stdout.splitlines()[-1])
+    assert d["ranks_agree_bitwise"] and not d["team"], d
+    tol = 1e-11 if "f64" in args else 1e-5
+    for rows in d["steps"]:
+        assert all(r["dz"] <= tol * r["z_scale"] and not (r["flags"] & d["fallback_flag"]) for r in rows), rows
+        assert all(r["a_passes"] == 1 for r in rows if r["k"] >= 2), rows
+    if "--batched" in args:
+        assert all(bt["k"] == 9 and bt["dz_rel"] <= tol for bt in d["batched"]), d["batched"]
+    else:
+        n_it = 8 + 1
+        assert all(c <= 2 * n_it + 2 for c in d["allreduce_calls"]), d["allreduce_calls"]
+
+
 def test_bench_default_line_carries_every_single_gpu_config(pa):
     """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`): the top-level record is the fixed-step headline
     run; `also` holds the reference benchmark's adaptive mode on the same matrix and BASELINE configs 2, 3, 4, each with its

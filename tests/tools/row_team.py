@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
     ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
     ap.add_argument("--fault-kind", type=int, default=0, help="0: that sweep loses a workgroup; 1: that sweep is refused at launch on rank 1")
+    ap.add_argument("--cols", action="store_true",
+                    help="COLUMN shards instead (rank p holds A[:, J_p] and the J_p slices of the n-vectors; one all-reduce of "
+                         "m + 8 (N + 1) elements per iteration, the single sweep on every rank): same checks, slice by slice")
     ap.add_argument("--no-team", action="store_true", help="plain row shards (two sweeps + all-reduce) for comparison")
     ap.add_argument("--batched", action="store_true",
                     help="afterwards the same solve through the algorithm object with device_loop=True, check_every=4 (pg_iter_run_batched: "
@@ -48,6 +51,8 @@ def main():
                     help="timing instead of parity: synthetic row blocks generated on the device (no host copy, no oracle), "
                          "--steps timed iterations after 3 warm-up steps; prints it/s and the aggregate bytes of A per second")
     args = ap.parse_args()
+    if args.cols:
+        args.no_team = True
     if args.bench:
         return bench(args)
     import proximalalgorithms.jl_amd as pa
@@ -94,9 +99,16 @@ def main():
         try:
             ctx = pa.Context.on_new_stream()
             ctxs[r] = ctx
-            off, cnt = pa.shard_rows(m, N, r)
-            A_loc = pa.HIPMatrix.from_numpy(np.asfortranarray(A[off:off + cnt]), ctx)
-            f = pa.LeastSquares(A_loc, pa.HIPVector.from_numpy(b[off:off + cnt], ctx), comm=comm.view(r))
+            if args.cols:
+                off, cnt = pa.shard_cols(n, N, r)
+                A_loc = pa.HIPMatrix.from_numpy(np.asfortranarray(A[:, off:off + cnt]), ctx)
+                f = pa.LeastSquares(A_loc, pa.HIPVector.from_numpy(b, ctx), comm=comm.view(r, "cols"))
+                sl = slice(off, off + cnt)
+            else:
+                off, cnt = pa.shard_rows(m, N, r)
+                A_loc = pa.HIPMatrix.from_numpy(np.asfortranarray(A[off:off + cnt]), ctx)
+                f = pa.LeastSquares(A_loc, pa.HIPVector.from_numpy(b[off:off + cnt], ctx), comm=comm.view(r))
+                sl = slice(None)
             sync.wait(timeout=120)
             if r == 0 and not args.no_team:
                 pa.row_team_in_process(ctxs, max_wgs)
@@ -109,22 +121,22 @@ def main():
                 sync.wait(timeout=120)
             if args.fault and r == 1:
                 _lib.call("pg_ctx_test_team_fault", ctx.handle, args.fault, args.fault_kind)
-            iteration = Iter(f=f, g=mk_g(), x0=pa.HIPVector.from_numpy(x0, ctx), Lf=Lf)
+            iteration = Iter(f=f, g=mk_g(), x0=pa.HIPVector.from_numpy(x0[sl], ctx), Lf=Lf)
             rows, passes, zs = [], 0, []
             for k, s in enumerate(itertools.islice(iteration, args.steps + 1)):
                 z = s.z.numpy()
                 p = iteration.counters.get("a_passes", 0)
                 rows.append({"k": k, "flags": int(getattr(s, "flags", 0)), "a_passes": int(p - passes), "f_x": float(s.f_x),
                              "gamma": float(s.gamma), "gamma_oracle": ref_states[k][1],
-                             "dz": float(np.max(np.abs(z - ref[k]))), "z_scale": float(max(1.0, np.max(np.abs(ref[k]))))})
+                             "dz": float(np.max(np.abs(z - ref[k][sl]))), "z_scale": float(max(1.0, np.max(np.abs(ref[k]))))})
                 passes = p
                 zs.append(z)
             batched = None
             if args.batched:
                 zb, kb = pa.FastForwardBackward(tol=0.0, maxit=args.steps + 1, device_loop=True, check_every=4)(
-                    x0=pa.HIPVector.from_numpy(x0, ctx), f=f, g=mk_g(), Lf=Lf)
+                    x0=pa.HIPVector.from_numpy(x0[sl], ctx), f=f, g=mk_g(), Lf=Lf)
                 zb = zb.numpy() if hasattr(zb, "numpy") else np.asarray(zb)
-                batched = {"k": int(kb), "dz_rel": float(np.max(np.abs(zb - ref[args.steps])) / max(1.0, float(np.max(np.abs(ref[args.steps])))))}
+                batched = {"k": int(kb), "dz_rel": float(np.max(np.abs(zb - ref[args.steps][sl])) / max(1.0, float(np.max(np.abs(ref[args.steps])))))}
             second_dz = None
             if second is not None:
                 A2, b2, lam2, Lf2, ref2 = second
@@ -152,7 +164,10 @@ def main():
     if errors:
         print(json.dumps({"error": errors}))
         sys.exit(1)
-    same = all(np.array_equal(results[0][1][k], results[r][1][k]) for r in range(1, N) for k in range(args.steps + 1))
+    if args.cols:  # the ranks hold different slices; what they must agree on bit for bit are the iteration's scalars
+        same = all(results[0][0][k][key] == results[r][0][k][key] for r in range(1, N) for k in range(args.steps + 1) for key in ("f_x", "gamma"))
+    else:
+        same = all(np.array_equal(results[0][1][k], results[r][1][k]) for r in range(1, N) for k in range(args.steps + 1))
     print(json.dumps({"m": m, "n": n, "ranks": N, "dtype": args.dtype, "max_wgs": max_wgs, "team": not args.no_team,
                       "ranks_agree_bitwise": bool(same), "fallback_flag": _lib.PG_FLAG_SWEEP_FALLBACK,
                       "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)],
