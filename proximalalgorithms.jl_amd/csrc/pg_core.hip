@@ -203,7 +203,7 @@ pg_status pg_ctx_row_team_alloc(pg_ctx* c, void** inbox_out, int64_t* bytes_out)
     PG_HIP(hipMemset(c->rteam.own, 0, bytes));
   }
   // (outside the branch above: a call that failed here is completed by the next one)
-  if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, sizeof(double)));
+  if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, 2 * sizeof(double)));
   if (c->rteam.wait_stats == nullptr) {
     PG_HIP(hipMalloc((void**)&c->rteam.wait_stats, 2 * sizeof(unsigned long long)));
     PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
@@ -253,6 +253,7 @@ pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* con
   c->rteam.epoch = c->rteam.scal_epoch = 0;
   c->rteam.ring_sig = 0;
   c->rteam.sweeps = 0;
+  c->rteam.gen++;
   if (c->rteam.wait_stats) PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
   PG_HIP(hipMemset(c->rteam.own, 0, pgtn::peer_inbox_bytes()));
   return PG_OK;

@@ -21,6 +21,7 @@
 
 namespace pgtn {
 pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out);
+pg_status peer_agree_max(pg_ctx* c, unsigned mine, unsigned* agreed);
 namespace {
 #include "pg_gemv_tnt.h"
 
@@ -36,6 +37,8 @@ struct PeerScalArgs {
   unsigned long long* inbox[TEAM_MAX];  // every device's scalar inbox as seen from here
   const double* f_local;                // this device's 1/2 lam ||r_p||^2
   double* f_out;                        // sum over the devices, in device order
+  unsigned aux;                         // a small integer every device contributes (the spare granule) ...
+  double* aux_max_out;                  // ... and where the largest of them goes (nullptr: nobody asked; 0 when a peer never answered)
   double* team_err;                     // in: this device's flag; out: any device's
 };
 
@@ -46,16 +49,15 @@ __global__ __launch_bounds__(64) void peer_scalars_kernel(PeerScalArgs p) {
   const unsigned long long fb = __builtin_bit_cast(unsigned long long, f);
   const unsigned err = *p.team_err != 0.0 ? 1u : 0u;
   const size_t base = (size_t)p.slot * TEAM_MAX * PEER_SCAL_GRANULES;
-  if (lane < 3) {
-    const unsigned bits = lane == 0 ? (unsigned)fb : (lane == 1 ? (unsigned)(fb >> 32) : err);
+  if (lane < 4) {
+    const unsigned bits = lane == 0 ? (unsigned)fb : (lane == 1 ? (unsigned)(fb >> 32) : (lane == 2 ? err : p.aux));
     const unsigned long long word = ((unsigned long long)p.tag << 32) | bits;
     for (int q = 0; q < p.n; ++q)
       __hip_atomic_store(p.inbox[q] + base + (size_t)p.rank * PEER_SCAL_GRANULES + lane, word, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const int npoll = p.n * PEER_SCAL_GRANULES;
-  int pl = lane < npoll ? lane : npoll - 1;
-  if ((pl & 3) == 3) pl -= 1;  // the spare granule is never written: look at the flag granule instead
+  const int pl = lane < npoll ? lane : npoll - 1;
   const unsigned long long* src = p.inbox[p.rank] + base + pl;
   unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   bool dead = false;
@@ -70,17 +72,20 @@ __global__ __launch_bounds__(64) void peer_scalars_kernel(PeerScalArgs p) {
   }
   const int lo = (int)(unsigned)w;
   double total = 0.0;
-  unsigned any = dead ? 1u : 0u;
+  unsigned any = dead ? 1u : 0u, aux_max = 0u;
   for (int q = 0; q < p.n; ++q) {
     const unsigned l0 = (unsigned)__shfl(lo, q * PEER_SCAL_GRANULES + 0);
     const unsigned l1 = (unsigned)__shfl(lo, q * PEER_SCAL_GRANULES + 1);
     const unsigned l2 = (unsigned)__shfl(lo, q * PEER_SCAL_GRANULES + 2);
+    const unsigned l3 = (unsigned)__shfl(lo, q * PEER_SCAL_GRANULES + 3);
     total += __builtin_bit_cast(double, ((unsigned long long)l1 << 32) | l0);
     any |= l2;
+    aux_max = l3 > aux_max ? l3 : aux_max;
   }
   if (lane == 0) {
     *p.f_out = total;
     if (any) *p.team_err = 1.0;
+    if (p.aux_max_out != nullptr) *p.aux_max_out = dead ? 0.0 : (double)aux_max;
   }
 }
 
@@ -204,7 +209,17 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // workgroups per compute unit: the parked bytes per compute unit are 128 KiB in every case, so the granules of a step have
   // ~5-6 us at the device's streaming rate to cross the fabric and be found.  (LAG = 4 with one workgroup per compute unit: same slack, 0.6-0.85 of
   // the rate -- one workgroup's per-step chain of barrier, post, poll and LDS round trip is not hidden by a second one.)
-  const int per_wave = (a.nrg + 3) / 4;
+  pg_ctx* c = A->ctx;
+  if (A->team_nrg == 0 || A->team_nrg_gen != c->rteam.gen) {  // the longest row block of the team (see peer_agree_max)
+    unsigned longest = 0;
+    PG_TRY(peer_agree_max(c, (unsigned)a.nrg, &longest));
+    if (longest >= (unsigned)a.nrg && tn_peer_covers((int)longest)) {
+      A->team_nrg = (int)longest;
+      A->team_nrg_gen = c->rteam.gen;
+    }
+  }
+  const int team_nrg = (A->team_nrg_gen == c->rteam.gen && A->team_nrg >= a.nrg) ? A->team_nrg : a.nrg;
+  const int per_wave = (team_nrg + 3) / 4;
   int U = 2;
   while (U < per_wave) U *= 2;
   const int C = env_int("PG_TNP_C", U >= 8 ? 1 : 2);  // (U = 2: 16 KiB tiles, four workgroups per compute unit)
@@ -236,9 +251,11 @@ template pg_status launch_tn_peer<double>(pg_mat*, TNArgs<double>&, int*);
 size_t peer_inbox_bytes() { return PEER_RING_BYTES + PEER_SCAL_BYTES; }
 
 // f_out = sum over the devices of *f_local (device order), PG_S_TEAMERR = any device's flag: one launch, no collective
-pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) {
+static pg_status peer_exchange(pg_ctx* c, const double* f_local, double* f_out, unsigned aux, double* aux_max_out) {
   pg_row_team& rt = c->rteam;
   PeerScalArgs p;
+  p.aux = aux;
+  p.aux_max_out = aux_max_out;
   p.n = rt.n;
   p.rank = rt.rank;
   rt.scal_epoch = (rt.scal_epoch % 0xFFFFFEu) + 1u;
@@ -251,6 +268,25 @@ pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) 
   p.team_err = c->dscal + PG_S_TEAMERR;
   hipLaunchKernelGGL(peer_scalars_kernel, dim3(1), dim3(64), 0, c->stream, p);
   PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) { return peer_exchange(c, f_local, f_out, 0u, nullptr); }
+
+// The geometry of a row-team sweep (row groups per wave, columns per step, workgroups per compute unit: which workgroup walks
+// which columns, and where its granules sit in the ring) must be the SAME on every device, but it follows from the length of
+// the row block, and the blocks of a team need not be equally long: 8193 rows over four devices are 2049 + 3 x 2048, nine row
+// groups on one device and eight on the others (found by tests/tools/fuzz_bench_ranks.py: every sweep ran into its bounded
+// wait and the job settled on two sweeps).  So the devices agree ONCE per matrix and team on the longest block -- one scalar
+// exchange carrying the own length in its spare granule, one read-back -- and size the sweep for that.  Every device gets here
+// at the same launch (same sequence of calls), so the exchange pairs up.  0: a peer never answered; nothing is remembered.
+pg_status peer_agree_max(pg_ctx* c, unsigned mine, unsigned* agreed) {
+  double* slot = c->rteam.f_local + 1;
+  PG_TRY(peer_exchange(c, c->rteam.f_local, c->rteam.f_local, mine, slot));
+  double got = 0.0;
+  PG_HIP(hipMemcpyAsync(&got, slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PG_HIP(hipStreamSynchronize(c->stream));
+  *agreed = (unsigned)got;
   return PG_OK;
 }
 

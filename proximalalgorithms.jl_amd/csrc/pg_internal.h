@@ -95,9 +95,10 @@ struct pg_row_team {
   int max_wgs = 0;            // workgroups per device (0: one per compute unit); must be the same on every device
   unsigned epoch = 0, scal_epoch = 0;  // launch epochs of the granule tags: advance in step on every device
   unsigned long long ring_sig = 0;     // layout of the granule ring the last sweep used (workgroups, C, G, LAG, devices)
-  double* f_local = nullptr;  // device scalar: this device's 1/2 lam ||r_p||^2 between the finish kernel and the exchange
+  double* f_local = nullptr;  // device, two doubles: [0] this device's 1/2 lam ||r_p||^2 between the finish kernel and the exchange; [1] see peer_agree_max
   unsigned long long* wait_stats = nullptr;  // device: { late waves, polls spent waiting } since pg_ctx_set_row_team (telemetry)
   long long sweeps = 0;       // row-team sweeps launched since pg_ctx_set_row_team
+  unsigned gen = 0;           // bumped by every pg_ctx_set_row_team: what a matrix agreed on with one team does not carry over
 };
 
 namespace pgtn {
@@ -182,6 +183,8 @@ struct pg_mat {
   // workspace for y = A x partial sums (lazy)
   void* partials = nullptr;
   int64_t partials_slots = 0;
+  int team_nrg = 0;        // row team: the LONGEST row block of the team in row groups, agreed once per matrix and team (pg_gemv_tn4.hip)
+  unsigned team_nrg_gen = 0;
   std::vector<void*> retired;  // outgrown partial-sum buffers of a row-team matrix, freed with the matrix (pg_gemv_tn4.hip)
   void* rpad = nullptr;  // [ld] zero-padded copy of a caller's m-vector (pg_mat_fused_tn)
   void* xch = nullptr;   // granule ring of the workgroup teams of the long-column sweep (gemv_tnt_kernel)

@@ -2168,6 +2168,26 @@ def test_fuzz_row_teams_on_one_gpu(pa):
     assert not bad and lost == 0, (bad, lost)
 
 
+def test_fuzz_ranks_as_processes_on_one_gpu(pa):
+    """tests/tools/fuzz_bench_ranks.py: the production multi-rank path (one process per rank, IPC-mapped inboxes for row teams)
+    against one rank on the same problem.  The first two seeds are the campaign's finding: 8193 rows over four ranks are blocks of
+    2049 + 3 x 2048 rows -- nine row groups on one rank, eight on the others -- and every rank sized the row-team sweep by its OWN
+    block, so the ranks walked different column maps, every sweep timed out and the job settled on two sweeps; the ranks now
+    agree on the longest block once per matrix (pg_gemv_tn4.hip::peer_agree_max)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_bench_ranks", os.path.join(root, "tests", "tools", "fuzz_bench_ranks.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = []
+    for seed in (800023, 800027, 800001, 800010):
+        why, label = fz.one_case(seed)
+        if why:
+            bad.append((label, why))
+    assert not bad, bad
+
+
 # ------------------------------------------------------------------------------------------------
 # single-sweep pass (pg_ls_fused_pass): A' r, epilogue, next extrapolation and next residual in one read of A
 # ------------------------------------------------------------------------------------------------
