@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 COLS = False
+PER_ELEMENT = False  # `pe` on the command line: per-element weights of NormL1 / bounds of IndBox instead of scalars
 
 
 def draw_cols(seed):
@@ -50,6 +51,8 @@ def draw_cols(seed):
         args += ["--g", "box"]
     if fast and not adaptive and rng.random() < 0.3:
         args += ["--batched"]
+    if PER_ELEMENT:
+        args = [a for a in args if a not in ("--g", "box")] + ["--g", str(np.random.default_rng(seed + 7_000_003).choice(["l1w", "boxv"]))]
     return args, (1e-11 if f64 else 1e-5), adaptive
 
 
@@ -82,6 +85,8 @@ def draw(seed):
     # drawn last, from a generator of their own (the cases of the first campaigns keep their seeds): the in-library batched loop
     # afterwards (FastForwardBackward, fixed step), a second problem on the same contexts (another ring layout)
     rx = np.random.default_rng(seed + 7_000_003)
+    if PER_ELEMENT:
+        args = [a for a in args if a not in ("--g", "box")] + ["--g", str(rx.choice(["l1w", "boxv"]))]
     if "--fast" not in args and not adaptive and rx.random() < 0.3:
         args += ["--batched"]
     if rx.random() < 0.3:
@@ -134,7 +139,9 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     global COLS
-    COLS = len(sys.argv) > 3 and sys.argv[3] == "cols"
+    global PER_ELEMENT
+    COLS = "cols" in sys.argv[3:]
+    PER_ELEMENT = "pe" in sys.argv[3:]
     t0 = time.time()
     bad = fb = 0
     for seed in range(seed0, seed0 + cases):

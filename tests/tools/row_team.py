@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--fast", type=int, default=1)
     ap.add_argument("--adaptive", action="store_true", help="adaptive step (no Lf): FastForwardBackward's line search with the residual pair")
-    ap.add_argument("--g", choices=["l1", "box"], default="l1")
+    ap.add_argument("--g", choices=["l1", "box", "l1w", "boxv"], default="l1", help="l1w / boxv: per-element weights / bounds (n-vectors, sliced under --cols)")
     ap.add_argument("--max-wgs", type=int, default=0, help="workgroups per rank (0: compute units / ranks)")
     ap.add_argument("--fault", type=int, default=0, help="rank 1's k-th row-team sweep loses a workgroup (0: none)")
     ap.add_argument("--fault-kind", type=int, default=0, help="0: that sweep loses a workgroup; 1: that sweep is refused at launch on rank 1")
@@ -80,8 +80,14 @@ def main():
     if args.adaptive:
         Lf = None
     x0 = np.zeros(n, dtype)
-    mk_g = (lambda: pa.NormL1(lam)) if args.g == "l1" else (lambda: pa.IndBox(dtype(-0.02), dtype(0.03)))
-    mk_go = (lambda: o.NormL1(lam)) if args.g == "l1" else (lambda: o.IndBox(dtype(-0.02), dtype(0.03)))
+    rv = np.random.default_rng(77)
+    w_all = (lam * (0.25 + 1.5 * rv.random(n))).astype(dtype)
+    lo_all = (-0.02 - 0.02 * rv.random(n)).astype(dtype)
+    hi_all = (lo_all + dtype(0.05)).astype(dtype)
+    mk_g = {"l1": lambda sl=slice(None): pa.NormL1(lam), "box": lambda sl=slice(None): pa.IndBox(dtype(-0.02), dtype(0.03)),
+            "l1w": lambda sl=slice(None): pa.NormL1(w_all[sl].copy()), "boxv": lambda sl=slice(None): pa.IndBox(lo_all[sl].copy(), hi_all[sl].copy())}[args.g]
+    mk_go = {"l1": lambda: o.NormL1(lam), "box": lambda: o.IndBox(dtype(-0.02), dtype(0.03)), "l1w": lambda: o.NormL1(w_all),
+             "boxv": lambda: o.IndBox(lo_all, hi_all)}[args.g]
     Iter = pa.FastForwardBackwardIteration if args.fast else pa.ForwardBackwardIteration
     IterO = o.FastForwardBackwardIteration if args.fast else o.ForwardBackwardIteration
     ref_states = [(s.z.copy(), float(s.gamma)) for s in itertools.islice(IterO(f=o.LeastSquares(A, b), g=mk_go(), x0=x0, Lf=Lf), args.steps + 1)]
@@ -121,7 +127,7 @@ def main():
                 sync.wait(timeout=120)
             if args.fault and r == 1:
                 _lib.call("pg_ctx_test_team_fault", ctx.handle, args.fault, args.fault_kind)
-            iteration = Iter(f=f, g=mk_g(), x0=pa.HIPVector.from_numpy(x0[sl], ctx), Lf=Lf)
+            iteration = Iter(f=f, g=mk_g(sl), x0=pa.HIPVector.from_numpy(x0[sl], ctx), Lf=Lf)
             rows, passes, zs = [], 0, []
             for k, s in enumerate(itertools.islice(iteration, args.steps + 1)):
                 z = s.z.numpy()
@@ -134,7 +140,7 @@ def main():
             batched = None
             if args.batched:
                 zb, kb = pa.FastForwardBackward(tol=0.0, maxit=args.steps + 1, device_loop=True, check_every=4)(
-                    x0=pa.HIPVector.from_numpy(x0[sl], ctx), f=f, g=mk_g(), Lf=Lf)
+                    x0=pa.HIPVector.from_numpy(x0[sl], ctx), f=f, g=mk_g(sl), Lf=Lf)
                 zb = zb.numpy() if hasattr(zb, "numpy") else np.asarray(zb)
                 batched = {"k": int(kb), "dz_rel": float(np.max(np.abs(zb - ref[args.steps][sl])) / max(1.0, float(np.max(np.abs(ref[args.steps])))))}
             second_dz = None
