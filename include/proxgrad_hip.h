@@ -153,7 +153,8 @@ pg_status pg_ctx_set_column_sharding(pg_ctx* ctx, int32_t nranks, int32_t rank);
  *   pg_ctx_set_row_team(ctx, nranks, rank, inboxes, max_workgroups): inboxes[q] = device q's inbox as mapped into THIS
  *            process (inboxes[rank] = the own one); max_workgroups = workgroups per device (0: as many per compute unit as the
  *            geometry's parked tiles allow; -k: that number divided by k, for k members sharing ONE device -- tests), the same
- *            on every device; nranks <= 1 switches the mode off.  2..16 devices, row blocks of at most 16384
+ *            on every device; nranks <= 1 switches the mode off.  2..16 devices, row blocks (of equal or unequal length: the
+ *            devices agree on the longest once per matrix and size the sweep for it) of at most 16384
  *            (Float32) / 8192 (Float64) rows per device; fixed step, or FastForwardBackward's adaptive step with
  *            reuse_residual (the line search's rejected trials use the registered all-reduce). */
 pg_status pg_ctx_row_team_alloc(pg_ctx* ctx, void** inbox_out, int64_t* bytes_out);
