@@ -2170,8 +2170,8 @@ def test_fuzz_row_teams_on_one_gpu(pa):
 
 def test_fuzz_ranks_as_processes_on_one_gpu(pa):
     """tests/tools/fuzz_bench_ranks.py: the production multi-rank path (one process per rank, IPC-mapped inboxes for row teams)
-    against one rank on the same problem.  The first two seeds are the campaign's finding: 8193 rows over four ranks are blocks of
-    2049 + 3 x 2048 rows -- nine row groups on one rank, eight on the others -- and every rank sized the row-team sweep by its OWN
+    against one rank on the same problem.  The first two cases are the campaign's finding in small: 4097 rows over two ranks are blocks of
+    2049 + 2048 rows -- nine row groups on one rank, eight on the other -- and every rank sized the row-team sweep by its OWN
     block, so the ranks walked different column maps, every sweep timed out and the job settled on two sweeps; the ranks now
     agree on the longest block once per matrix (pg_gemv_tn4.hip::peer_agree_max)."""
     import importlib.util
@@ -2181,8 +2181,13 @@ def test_fuzz_ranks_as_processes_on_one_gpu(pa):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     bad = []
-    for seed in (800023, 800027, 800001, 800010):
-        why, label = fz.one_case(seed)
+    # (at most three ranks here: with this process on the device as well, five processes would be time-sliced and the members
+    # of a team never resident together)
+    for case in ((2, "teams", 4097, 296, "fixed", False),      # 2049 + 2048 rows: nine and eight row groups
+                 (3, "teams", 6145, 500, "adaptive", True),    # 2049 + 2048 + 2048 rows, Float64: 17 / 16 / 16 row groups
+                 (3, "cols", 20000, 1129, "adaptive", False),
+                 (2, "rows", 5000, 3211, "fixed", False)):
+        why, label = fz.run_pair(*case)
         if why:
             bad.append((label, why))
     assert not bad, bad

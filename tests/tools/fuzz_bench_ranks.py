@@ -49,13 +49,18 @@ def one_case(seed):
         m = int(rng.choice([world * 300, world * 2048, world * 2048 + 1, world * 4096 - 1, 5000, 12000, cap]))
         m = min(m, cap)
         n = int(rng.integers(64, 6000))
+    return run_pair(world, layout, m, n, mode, f64, "seed=%d " % seed)
+
+
+def run_pair(world, layout, m, n, mode, f64, tag=""):
+    """one problem as one rank and as `world` ranks (processes sharing the device) in `layout`; ("", label) when they agree"""
     args = ["--m", str(m), "--n", str(n), "--mode", mode] + (["--dtype", "f64"] if f64 else [])
-    label = "seed=%d world=%d layout=%s %s" % (seed, world, layout, " ".join(args))
+    label = "%sworld=%d layout=%s %s" % (tag, world, layout, " ".join(args))
     one, why = run(args, 1, 0)
     if one is None:
         return "single rank: " + why, label
     extra = {"rows": ["--sharding", "rows"], "teams": ["--sharding", "rows", "--row-teams"], "cols": ["--sharding", "cols"]}[layout]
-    many, why = run(args + extra, world, 29700 + seed % 200)
+    many, why = run(args + extra, world, 0)
     if many is None:
         return "%d ranks: %s" % (world, why), label
     c1, c2 = one["config"], many["config"]
