@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 COLS = False
+PLAIN = False  # `plain` on the command line: row shards WITHOUT the team (two sweeps + the all-reduce of [grad ; f]: north_star's layout as rounds 1-3 ran it)
 PER_ELEMENT = False  # `pe` on the command line: per-element weights of NormL1 / bounds of IndBox instead of scalars
 
 
@@ -96,6 +97,11 @@ def draw(seed):
 
 def one_case(seed):
     args, tol, adaptive = draw(seed)
+    if PLAIN:
+        args = [a for a in args if a != "--batched"] + ["--no-team"]
+        if "--then-n" in args:
+            i = args.index("--then-n")
+            del args[i:i + 2]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "row_team.py")] + args, capture_output=True, text=True,
                          timeout=600)
     label = "seed=%d %s" % (seed, " ".join(args))
@@ -104,7 +110,7 @@ def one_case(seed):
     d = json.loads(out.stdout.splitlines()[-1])
     if not d["ranks_agree_bitwise"]:
         return "the ranks' iterates differ", label, 0
-    if not COLS and not all(v == "ok" for v in d["selftest"]):
+    if not COLS and not PLAIN and not all(v == "ok" for v in d["selftest"]):
         return "self-test: %r" % (d["selftest"],), label, 0
     fallbacks = 0
     for rows in d["steps"]:
@@ -117,6 +123,8 @@ def one_case(seed):
                 return "gamma %r against the oracle's %r at iteration %d" % (r["gamma"], r["gamma_oracle"], r["k"]), label, fallbacks
             # one read of the block per step from the second step on -- except a step whose sweep was lost (flagged: redone with
             # two sweeps) and the step after it (no speculative half to continue from)
+            if PLAIN:
+                continue  # (two reads per step by design)
             if r["k"] >= 2 and r["k"] not in flagged and r["k"] - 1 not in flagged and r["a_passes"] != 1 and not adaptive:
                 return "iteration %d read the block %d times without a fallback flag; reads by iteration and rank: %r" % (
                     r["k"], r["a_passes"], [[x["a_passes"] for x in rr] for rr in d["steps"]]), label, fallbacks
@@ -142,6 +150,8 @@ def main():
     global PER_ELEMENT
     COLS = "cols" in sys.argv[3:]
     PER_ELEMENT = "pe" in sys.argv[3:]
+    global PLAIN
+    PLAIN = "plain" in sys.argv[3:]
     t0 = time.time()
     bad = fb = 0
     for seed in range(seed0, seed0 + cases):
