@@ -213,12 +213,14 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   if (A->team_nrg == 0 || A->team_nrg_gen != c->rteam.gen) {  // the longest row block of the team (see peer_agree_max)
     unsigned longest = 0;
     PG_TRY(peer_agree_max(c, (unsigned)a.nrg, &longest));
-    if (longest >= (unsigned)a.nrg && tn_peer_covers((int)longest)) {
-      A->team_nrg = (int)longest;
-      A->team_nrg_gen = c->rteam.gen;
-    }
+    // Remembered whatever came back -- also "a peer never answered" (0: the own length then): every device makes this
+    // exchange exactly once per agreement, so the exchanges' epochs stay in step.  A timeout sets the team's flag, the step
+    // is redone with two sweeps on every device, and that path forgets the agreement (pg_iter.hip::redo_with_two_sweeps):
+    // all devices come back here together at the next sweep.
+    A->team_nrg = (longest >= (unsigned)a.nrg && tn_peer_covers((int)longest)) ? (int)longest : a.nrg;
+    A->team_nrg_gen = c->rteam.gen;
   }
-  const int team_nrg = (A->team_nrg_gen == c->rteam.gen && A->team_nrg >= a.nrg) ? A->team_nrg : a.nrg;
+  const int team_nrg = A->team_nrg >= a.nrg ? A->team_nrg : a.nrg;
   const int per_wave = (team_nrg + 3) / 4;
   int U = 2;
   while (U < per_wave) U *= 2;
@@ -279,7 +281,7 @@ pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) 
 // groups on one device and eight on the others (found by tests/tools/fuzz_bench_ranks.py: every sweep ran into its bounded
 // wait and the job settled on two sweeps).  So the devices agree ONCE per matrix and team on the longest block -- one scalar
 // exchange carrying the own length in its spare granule, one read-back -- and size the sweep for that.  Every device gets here
-// at the same launch (same sequence of calls), so the exchange pairs up.  0: a peer never answered; nothing is remembered.
+// at the same launch (same sequence of calls), so the exchange pairs up.  0: a peer never answered.
 pg_status peer_agree_max(pg_ctx* c, unsigned mine, unsigned* agreed) {
   double* slot = c->rteam.f_local + 1;
   PG_TRY(peer_exchange(c, c->rteam.f_local, c->rteam.f_local, mine, slot));

@@ -207,6 +207,9 @@ pg_status redo_with_two_sweeps(pg_iter* it, pg_status why, bool residual_intact)
   // the members of a team never run together): stay with two sweeps instead of paying the bounded wait in every step.
   // The count is the same on every rank of a sharded job (the flag is exchanged), so they leave the mode together.
   if (why == PG_ERR_TIMEOUT && ++it->timeouts_in_a_row >= 3) it->single_sweep = false;
+  // row team: what the devices agreed on for this matrix (the longest row block) is agreed again before the next sweep -- a
+  // device that missed a peer in that exchange sized its sweep differently, which is one way to get here
+  if (why == PG_ERR_TIMEOUT && c->rteam.n > 1) it->f->A->team_nrg = 0;
   if (why == PG_ERR_UNSUPPORTED) {
     // refused: nothing of the sweep ran, and it would be refused again -- also inside a batch (defer_sync): the two sweeps
     // are enqueued in its place and the batch's one read-back takes f(x) from PG_S_F like any two-sweep iteration.  With
