@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 COLS = False
+MANY = False  # `many` on the command line: 6 / 7 / 12 / 16 ranks (16 is the most a row team takes)
 PLAIN = False  # `plain` on the command line: row shards WITHOUT the team (two sweeps + the all-reduce of [grad ; f]: north_star's layout as rounds 1-3 ran it)
 PER_ELEMENT = False  # `pe` on the command line: per-element weights of NormL1 / bounds of IndBox instead of scalars
 
@@ -63,6 +64,8 @@ def draw(seed):
     rng = np.random.default_rng(seed)
     f64 = bool(rng.random() < 0.3)
     ranks = int(rng.choice([2, 2, 3, 4, 5, 8]))
+    if MANY:
+        ranks = int(np.random.default_rng(seed + 9_000_011).choice([6, 7, 12, 16]))
     cap = 8192 if f64 else 16384  # rows per rank the PEER sweep covers
     if rng.random() < 0.5:
         rpr = int(rng.choice([1, 100, 256, 257, 512, 1024, 2048, 2049, 4096, 5000, 8192, 12000, 16384]))
@@ -150,6 +153,8 @@ def main():
     global PER_ELEMENT
     COLS = "cols" in sys.argv[3:]
     PER_ELEMENT = "pe" in sys.argv[3:]
+    global MANY
+    MANY = "many" in sys.argv[3:]
     global PLAIN
     PLAIN = "plain" in sys.argv[3:]
     t0 = time.time()

@@ -17,7 +17,7 @@ import numpy as np
 
 # one HIP stream per rank, and every stream needs a hardware queue of its own: two sweeps that wait for each other on ONE
 # queue would run one after the other (the runtime's default is four queues per process)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # (16 ranks + the default stream: with 16 queues two of the streams shared one and the self-test timed out)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
