@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test of the widened rows: PANOC / ZeroFPR / PANOCplus (L-BFGS directions,
 general A, squared-distance and logistic losses) and DouglasRachford (separable quadratic + box / L1, stepping and the
-K-iterations-per-sweep loop) against the CPU restatement.  Usage: python tests/tools/fuzz_newton.py [cases] [first_seed]."""
+K-iterations-per-sweep loop) against the CPU restatement.  Usage: python tests/tools/fuzz_newton.py [cases] [first_seed] [tall].
+`tall`: PANOC / ZeroFPR / PANOCplus only, column lengths 600 .. 140000 with few columns."""
 import os
 import sys
 import time
@@ -14,12 +15,15 @@ import proximalalgorithms.jl_amd as pa  # noqa: E402
 from oracle import proxgrad_oracle as o  # noqa: E402
 
 
+TALL = False
+
+
 def one_case(seed):
     rng = np.random.default_rng(seed)
     dtype = np.float64 if rng.random() < 0.7 else np.float32
     alg = rng.choice(["panoc", "zerofpr", "panocplus", "dr"])
     fails = []
-    if alg == "dr":
+    if alg == "dr" and not TALL:
         n = int(rng.choice([1, 7, 64, 1000, 4099])) if rng.random() < 0.5 else int(rng.integers(1, 20000))
         vec = rng.random() < 0.7
         d = (0.1 + np.abs(rng.standard_normal(n))).astype(dtype) if vec else dtype(0.1 + rng.random())
@@ -38,6 +42,12 @@ def one_case(seed):
                 fails.append((loop, blk, f"k={k} k_cpu={k_o} dy={np.max(np.abs(y - y_o)) if n else 0:.2e}"))
         return f"seed={seed} DR {np.dtype(dtype).name} n={n} {'box' if box else 'l1'} tol={tol} maxit={maxit} k_cpu={k_o}", fails
     m, n = int(rng.integers(2, 300)), int(rng.integers(2, 500))
+    if TALL:  # every geometry of the single sweep (also in its A (x - z) mode, the L-BFGS image slab's feed): column lengths up to the teams'
+        m = int(rng.choice([600, 2048, 2305, 4096, 5000, 7168, 9000, 16384, 20000, 33000, 40000, 70001, 131072]))
+        if rng.random() < 0.4:
+            m = int(rng.integers(2049, 140000))
+        n = int(rng.choice([2, 7, 33, 64, 130]))
+        alg = str(rng.choice(["panoc", "zerofpr", "panocplus"]))
     A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
     xt = np.zeros(n, dtype)
     nzc = max(1, n // 10)
@@ -86,6 +96,8 @@ def one_case(seed):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    global TALL
+    TALL = "tall" in sys.argv[3:]
     pa.get_context()
     bad, t0 = 0, time.perf_counter()
     for seed in range(first, first + cases):
