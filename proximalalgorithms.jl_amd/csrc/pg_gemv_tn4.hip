@@ -124,7 +124,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // measured on 2048- / 4096- / 8192-row blocks, two members sharing one device, 5.87 (four) / 6.08 (two) / 6.28 (two) TB/s
   // against 3.31 / 5.16 / 6.19 with one (profiles/r4_row_team_one_gpu.md)
   constexpr size_t PARK = (size_t)LAG * WAVES * C * U * 1024;
-  int64_t nteams = (int64_t)c->num_cu * (PARK <= 32 * 1024 ? 4 : PARK <= 64 * 1024 ? 2 : 1);
+  // (exact-U geometries park 40 / 48 KiB: three of them fit beside the kernel's static LDS)
+  int64_t nteams = (int64_t)c->num_cu * (PARK <= 32 * 1024 ? 4 : PARK <= 48 * 1024 ? 3 : PARK <= 64 * 1024 ? 2 : 1);
   if (rt.max_wgs > 0) nteams = rt.max_wgs;
   if (rt.max_wgs < 0) nteams = nteams / -rt.max_wgs > 0 ? nteams / -rt.max_wgs : 1;  // -k: this device is shared by k members of the team
   if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
@@ -222,9 +223,15 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   }
   const int team_nrg = A->team_nrg >= a.nrg ? A->team_nrg : a.nrg;
   const int per_wave = (team_nrg + 3) / 4;
-  int U = 2;
-  while (U < per_wave) U *= 2;
-  const int C = env_int("PG_TNP_C", U >= 8 ? 1 : 2);  // (U = 2: 16 KiB tiles, four workgroups per compute unit)
+  // U fits the longest block exactly (3, 5 .. 7, 9 .. 15 beside the powers of two): a block one row past 2048 rows is three row
+  // groups per wave, not four -- 2 x 2049 rows streamed 4.0 TB/s in the next power of two's geometry where 2 x 2048 stream 5.9
+  // (PG_TNP_EXACT=0 under PG_TUNE: the powers of two only, for A/B runs)
+  int U = per_wave < 2 ? 2 : per_wave;
+  if (env_int("PG_TNP_EXACT", 1) == 0) {
+    U = 2;
+    while (U < per_wave) U *= 2;
+  }
+  const int C = env_int("PG_TNP_C", U >= 5 ? 1 : 2);  // (U = 2: 16 KiB tiles, four workgroups per compute unit)
   const int LAG = env_int("PG_TNP_LAG", 2);
 #define PG_TNP_CASE(UU, CC, LL) \
   if (U == UU && C == CC && LAG == LL) return launch_tnp<T, UU, CC, LL, 2>(A, a, blocks_out)
@@ -239,6 +246,10 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TNP_CASE(2, 2, 4);
   PG_TNP_CASE(4, 1, 2);
   PG_TNP_CASE(4, 1, 4);
+  PG_TNP_CASE(3, 2, 2);
+  PG_TNP_CASE(5, 1, 2); PG_TNP_CASE(6, 1, 2); PG_TNP_CASE(7, 1, 2);
+  PG_TNP_CASE(9, 1, 2); PG_TNP_CASE(10, 1, 2); PG_TNP_CASE(11, 1, 2); PG_TNP_CASE(12, 1, 2);
+  PG_TNP_CASE(13, 1, 2); PG_TNP_CASE(14, 1, 2); PG_TNP_CASE(15, 1, 2);
   if constexpr (sizeof(T) == 4) {
     PG_TNP_CASE(2, 8, 2);
     PG_TNP_CASE(4, 4, 2);
