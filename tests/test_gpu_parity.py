@@ -819,6 +819,12 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "4096", "--n", "8192", "--then-n", "700"], dict(second=True)),    # a second matrix on the same contexts: another ring layout
     (["--m", "5000", "--n", "1001", "--ranks", "3", "--dtype", "f64"], dict(tol=1e-11)),  # ragged: 1667 / 1667 / 1666 rows, odd column count
     (["--m", "4096", "--n", "8192", "--batched"], dict(batched=True)),          # + the in-library batched loop (one read-back per four iterations)
+    # block lengths off the powers of two: U = ceil(row groups of the longest block / 4) exactly (2049 + 2048 rows: 9 row groups, U = 3;
+    # 21 -> U = 6; 37 -> U = 10; Float64 43 -> U = 11), the two ranks holding blocks of different length
+    (["--m", "4097", "--n", "257"], dict()),
+    (["--m", "10241", "--n", "257"], dict()),
+    (["--m", "18433", "--n", "257"], dict()),
+    (["--m", "10753", "--n", "257", "--dtype", "f64"], dict(tol=1e-11)),
 ])
 def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     """north_star's ROW layout at one read of A per iteration, exercised on ONE GPU.  The ranks
