@@ -40,7 +40,11 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+/* Bumped whenever an exported signature, a struct layout the host sees, or the set of exports changes (round 5: 2 -- rounds 3
+ * and 4 added exports and fields under version 1).  Hosts compare pg_abi_version() with the value THEY were written against at
+ * load time (Python: _lib.load; Julia: __init__) and refuse a stale or mismatched build with one clear message instead of a
+ * missing symbol at some later call -- PG_LIB_PATH / PROXGRAD_HIP_LIB make pointing at another build easy. */
+#define PG_ABI_VERSION 2
 
 typedef int32_t pg_status;
 enum {

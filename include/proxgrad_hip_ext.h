@@ -54,6 +54,15 @@ pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void*
  * does not fit next to other work would be (a row-team sweep, pg_ctx_set_row_team, is a plain launch that is never refused:
  * there kind 1 acts like kind 0).  Nothing in the library reads the environment for this. */
 pg_status pg_ctx_test_team_fault(pg_ctx* ctx, int32_t kth_launch, int32_t kind);
+/* kind 2 -- LATENCY INJECTOR of the row-team sweep (the hand-off of benchmark/benchmarks.jl:16's partial sums between
+ * devices): from now on the sweep is launched in its DELAY form and a step's granules are accepted by their consumers only
+ * kth_launch NANOSECONDS after they were stored (a stamp of the device's constant 100 MHz clock travels with them), i.e. the
+ * hand-off takes max(what it takes on this device, that long).  All members of the team must share one device (one clock):
+ * the one-GPU test set-up.  0 ns: the injector's own cost.  kind 3 switches it off again.  Only the geometries the latency
+ * sweep uses are instantiated (PG_ERR_UNSUPPORTED otherwise). */
+/* Slack read-out of the injector: clock ticks (10 ns) between the stamp of a step's granules (member 0's) and their use, summed over
+ * the wave-steps counted, since pg_ctx_set_row_team -- how much later the granules could have come without a wave waiting. */
+pg_status pg_ctx_test_team_slack(pg_ctx* ctx, int64_t* ticks, int64_t* wave_steps);
 
 #ifdef __cplusplus
 }

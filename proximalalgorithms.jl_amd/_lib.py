@@ -80,6 +80,7 @@ SIGNATURES = {
     "pg_ctx_profile_select": [_vp, C.c_uint32],
     "pg_ctx_set_column_sharding": [_vp, _i32, _i32],
     "pg_ctx_test_team_fault": [_vp, _i32, _i32],
+    "pg_ctx_test_team_slack": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "pg_ctx_row_team_alloc": [_vp, C.POINTER(_vp), C.POINTER(_i64)],
     "pg_ctx_row_team_export": [_vp, _vp],
     "pg_ctx_row_team_import": [_vp, _vp, C.POINTER(_vp)],
@@ -163,6 +164,7 @@ SIGNATURES = {
 _SPECIAL = {"pg_abi_version": ([], C.c_int32), "pg_last_error": ([], C.c_char_p), "pg_comm_available": ([], C.c_int32)}
 
 _lib = None
+PG_ABI_VERSION = 2  # include/proxgrad_hip.h (tests/test_cpu_host.py compares the two)
 
 
 def load():
@@ -178,6 +180,14 @@ def load():
     import torch  # noqa: F401  (maps torch's HIP runtime before ours is resolved)
 
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    try:  # before any other symbol is looked up: a stale build fails HERE, with its version, not at some later call
+        lib.pg_abi_version.argtypes, lib.pg_abi_version.restype = [], C.c_int32
+        found = int(lib.pg_abi_version())
+    except AttributeError:
+        found = None
+    if found != PG_ABI_VERSION:
+        raise ProxGradError(f"{LIB_PATH} has ABI version {found}, this package was written against {PG_ABI_VERSION}: rebuild it "
+                            "(`python proximalalgorithms.jl_amd/_build.py --force`) or point PG_LIB_PATH at a matching build")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes

@@ -203,10 +203,10 @@ pg_status pg_ctx_row_team_alloc(pg_ctx* c, void** inbox_out, int64_t* bytes_out)
     PG_HIP(hipMemset(c->rteam.own, 0, bytes));
   }
   // (outside the branch above: a call that failed here is completed by the next one)
-  if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, 2 * sizeof(double)));
+  if (c->rteam.f_local == nullptr) PG_HIP(hipMalloc((void**)&c->rteam.f_local, 18 * sizeof(double)));
   if (c->rteam.wait_stats == nullptr) {
-    PG_HIP(hipMalloc((void**)&c->rteam.wait_stats, 2 * sizeof(unsigned long long)));
-    PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
+    PG_HIP(hipMalloc((void**)&c->rteam.wait_stats, 4 * sizeof(unsigned long long)));
+    PG_HIP(hipMemset(c->rteam.wait_stats, 0, 4 * sizeof(unsigned long long)));
   }
   *inbox_out = c->rteam.own;
   if (bytes_out) *bytes_out = (int64_t)bytes;
@@ -254,7 +254,7 @@ pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* con
   c->rteam.ring_sig = 0;
   c->rteam.sweeps = 0;
   c->rteam.gen++;
-  if (c->rteam.wait_stats) PG_HIP(hipMemset(c->rteam.wait_stats, 0, 2 * sizeof(unsigned long long)));
+  if (c->rteam.wait_stats) PG_HIP(hipMemset(c->rteam.wait_stats, 0, 4 * sizeof(unsigned long long)));
   PG_HIP(hipMemset(c->rteam.own, 0, pgtn::peer_inbox_bytes()));
   return PG_OK;
 }
@@ -287,8 +287,25 @@ pg_status pg_ctx_row_team_stats(pg_ctx* c, int64_t* sweeps, int64_t* late_waves,
   return PG_OK;
 }
 
+pg_status pg_ctx_test_team_slack(pg_ctx* c, int64_t* ticks, int64_t* wave_steps) {
+  PG_REQUIRE(c != nullptr && ticks != nullptr && wave_steps != nullptr, "null argument");
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (c->rteam.wait_stats) {
+    PG_HIP(hipStreamSynchronize(c->stream));
+    PG_HIP(hipMemcpy(h, c->rteam.wait_stats, sizeof(h), hipMemcpyDeviceToHost));
+  }
+  *ticks = (int64_t)h[2];
+  *wave_steps = (int64_t)h[3];
+  return PG_OK;
+}
+
 pg_status pg_ctx_test_team_fault(pg_ctx* c, int32_t kth_launch, int32_t kind) {
-  PG_REQUIRE(c != nullptr && kth_launch >= 0 && (kind == 0 || kind == 1), "bad argument");
+  PG_REQUIRE(c != nullptr && kth_launch >= 0 && kind >= 0 && kind <= 3, "bad argument");
+  if (kind == 2 || kind == 3) {  // latency injector of the row-team sweep: kth_launch = nanoseconds (kind 3: injector off again)
+    c->test_team_delay_on = kind == 2;
+    c->test_team_delay_ticks = kind == 2 ? (unsigned)(kth_launch / 10) : 0u;
+    return PG_OK;
+  }
   c->test_team_fault = kth_launch;
   c->test_team_fault_kind = kind;
   c->team_launches = 0;

@@ -723,9 +723,13 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   pg_mat* A = f->A;
   // row shards: only as a row TEAM (pg_ctx_set_row_team): the devices exchange the per-column partial dots inside the sweep
   const bool rteam = pg_row_sharded(c) && c->rteam.n > 1;
-  if (rteam && !tn_peer_covers((int)(A->ld / (1024 / (int64_t)sizeof(T))))) {
-    pg_set_error("a row-team sweep covers row blocks of at most %d rows per device", (int)(64 * (1024 / sizeof(T))));
-    return PG_ERR_UNSUPPORTED;
+  if (rteam) {
+    PG_TRY(pg_mat_row_team_agree(c, A));  // (a collective the first time: every device of the team makes this call)
+    if (!tn_peer_covers(A->team_nrg)) {
+      pg_set_error("a row-team sweep covers row blocks of at most %d rows per device (the team's longest has %d row groups)",
+                   (int)(64 * (1024 / sizeof(T))), A->team_nrg);
+      return PG_ERR_UNSUPPORTED;
+    }
   }
   if ((pg_row_sharded(c) && !rteam) || !tn_supported<T>(A)) {
     pg_set_error("the single-sweep pass needs an unsharded or column-sharded operator (or a row team) with at most %d rows",
@@ -975,11 +979,42 @@ pg_status pg_ls_allreduce_epilogue_scalars(pg_ls* f) {
   return f->A->dtype == PG_F32 ? col_allreduce_scalars_t<float>(f) : col_allreduce_scalars_t<double>(f);
 }
 
+// What every device of a row team must know identically before its first sweep over a matrix: the LONGEST row block of the team
+// in row groups.  It sizes the sweep (same U, same workgroups per compute unit, same column map on every device), and it decides
+// whether the team sweeps at all: a block beyond the sweep's 64 row groups on ANY device and none does.  (Round 4 decided that
+// per device from its own block: 131073 rows over eight devices are one block of 65 row groups and seven of 64 -- one device
+// would have run two sweeps and all-reduced n + 1 elements while its peers polled inboxes it never filled.)  Agreed ONCE per
+// matrix and team through the REGISTERED all-reduce -- a sum over one-hot slots, i.e. an all-gather, so no MAX reduction is
+// asked of the host's collective -- when the first iterator over the matrix is created (or at a first bare sweep): every device
+// makes the same calls in the same order, so the collective pairs up, and unlike an exchange through the inboxes it cannot come
+// back differently on different devices.
+pg_status pg_mat_row_team_agree(pg_ctx* c, pg_mat* A) {
+  if (A->team_nrg != 0 && A->team_nrg_gen == c->rteam.gen) return PG_OK;
+  PG_REQUIRE(c->rteam.n > 1 && c->rteam.f_local != nullptr && pg_row_sharded(c), "the context is not a row team with a registered all-reduce");
+  const int64_t nrg = A->ld / (1024 / (int64_t)pg_sizeof(A->dtype));
+  double hd[16] = {};
+  float hf[16] = {};
+  hd[c->rteam.rank] = (double)nrg, hf[c->rteam.rank] = (float)nrg;  // (row groups of one device: far below 2^24)
+  void* slots = (void*)(c->rteam.f_local + 2);
+  const size_t bytes = 16 * pg_sizeof(A->dtype);
+  PG_HIP(hipStreamSynchronize(c->stream));
+  PG_HIP(hipMemcpy(slots, A->dtype == PG_F64 ? (const void*)hd : (const void*)hf, bytes, hipMemcpyHostToDevice));
+  PG_TRY(do_allreduce(c, slots, 16, A->dtype));
+  PG_HIP(hipStreamSynchronize(c->stream));
+  PG_HIP(hipMemcpy(A->dtype == PG_F64 ? (void*)hd : (void*)hf, slots, bytes, hipMemcpyDeviceToHost));
+  double longest = 0.0;
+  for (int q = 0; q < c->rteam.n; ++q) longest = fmax(longest, A->dtype == PG_F64 ? hd[q] : (double)hf[q]);
+  A->team_nrg = (int)longest;
+  A->team_nrg_gen = c->rteam.gen;
+  return PG_OK;
+}
+
 bool pg_ls_fused_pass_supported(const pg_ls* f) {
-  const pg_ctx* c = f->ctx;
-  if (pg_row_sharded(c)) {  // as a row team only (pg_gemv_tn4.hip)
-    const int64_t nrg = f->A->ld / (1024 / (int64_t)pg_sizeof(f->A->dtype));
-    return c->rteam.n > 1 && f->A->m > 0 && f->A->n > 0 && tn_peer_covers((int)nrg);
+  pg_ctx* c = f->ctx;
+  if (pg_row_sharded(c)) {  // as a row team only (pg_gemv_tn4.hip), and only when EVERY device's block is covered
+    if (!(c->rteam.n > 1 && f->A->m > 0 && f->A->n > 0)) return false;
+    if (pg_mat_row_team_agree(c, f->A) != PG_OK) return false;
+    return tn_peer_covers(f->A->team_nrg);
   }
   return f->A->dtype == PG_F32 ? tn_supported<float>(f->A) : tn_supported<double>(f->A);
 }

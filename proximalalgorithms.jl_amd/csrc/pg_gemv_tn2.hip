@@ -433,7 +433,7 @@ pg_status launch_tnc(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 
 #include "pg_gemv_tnt.h"  // gemv_tnt_kernel: the team sweep (shared with pg_gemv_tn4.hip)
 
-template <typename T, int U, int C, int LAG, int PF, int WAVES>
+template <typename T, int U, int C, int LAG, int PF, int WAVES, int LAGR = 0, int OPT = 0>
 pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   constexpr int G = (int)sizeof(T) / 4;
@@ -475,7 +475,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     }
     A->xch_bytes = xch_bytes;
   }
-  const long long layout = ((long long)nteams << 20) | ((long long)TM << 8) | (long long)(C * G);
+  const long long layout = ((long long)nteams << 20) | ((long long)TM << 8) | (long long)(C * G);  // (the lag is not part of it: a slot's tag says which step it holds)
   if (layout != A->xch_layout) fresh_ring = true;
   A->xch_layout = layout;
   if (fresh_ring) PG_HIP(hipMemsetAsync(A->xch, 0, xch_bytes, c->stream));
@@ -514,7 +514,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // LDS for the parked tiles: LAG slots of WAVES * C * U KiB on top of the kernel's static LDS (the dot exchange and the grid
   // reduction's scratch); anything beyond the default 64 KiB limit is opted into once per device
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
-  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>);
+  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, false, LAGR, false, OPT>);
   if (lds + 4096 > 64 * 1024) {
     static std::mutex mu;
     static bool opted_in[64] = {};
@@ -542,7 +542,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   if (c->team_plain_launch || c->capturing) {  // (stream capture records plain launches only)
-    hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+    hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, false, LAGR, false, OPT>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
     PG_LAUNCH_CHECK();
     return PG_OK;
   }
@@ -712,8 +712,19 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int C = env_int("PG_TNT_C", U == 4 ? 2 : 1), LAG = env_int("PG_TNT_LAG", 2);
   // tiles in flight ahead of the one being consumed
   const int PF = env_int("PG_TNT_PF", U == 4 ? 1 : 2);
-#define PG_TNT_CASE(UU, CC, LL, PP, WW) \
-  if (U == UU && C == CC && LAG == LL && PF == PP && W == WW) return launch_tnt<T, UU, CC, LL, PP, WW>(A, a, blocks_out)
+  const int LAGR = env_int("PG_TNT_LAGR", 0), OPT = env_int("PG_TNT_OPT", 0);  // lag tiles in registers; poll-ahead / barrier-free dots (pg_gemv_tnt.h)
+#define PG_TNT_CASE_X(UU, CC, LL, PP, WW, RR, OO) \
+  if (U == UU && C == CC && LAG == LL && PF == PP && W == WW && LAGR == RR && OPT == OO) return launch_tnt<T, UU, CC, LL, PP, WW, RR, OO>(A, a, blocks_out)
+#define PG_TNT_CASE(UU, CC, LL, PP, WW) PG_TNT_CASE_X(UU, CC, LL, PP, WW, 0, 0)
+  if constexpr (sizeof(T) == 4) {  // round 5 experiments on the full member
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 0, 1);
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 0, 2);
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 0, 3);
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 1, 0);
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 1, 3);
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 2, 3);
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 1, 2);
+  }
   PG_TNT_CASE(16, 1, 2, 2, 4);
   PG_TNT_CASE(15, 1, 2, 2, 4);
   PG_TNT_CASE(14, 1, 2, 2, 4);
@@ -730,7 +741,8 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TNT_CASE(8, 1, 2, 1, 8);
   PG_TNT_CASE(4, 2, 2, 1, 8);
 #undef PG_TNT_CASE
-  pg_set_error("no gemv_tnt instantiation for WAVES=%d U=%d C=%d LAG=%d PF=%d", W, U, C, LAG, PF);
+#undef PG_TNT_CASE_X
+  pg_set_error("no gemv_tnt instantiation for WAVES=%d U=%d C=%d LAG=%d PF=%d LAGR=%d OPT=%d", W, U, C, LAG, PF, LAGR, OPT);
   return PG_ERR_UNSUPPORTED;
 }
 

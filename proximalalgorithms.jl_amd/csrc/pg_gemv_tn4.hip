@@ -21,7 +21,6 @@
 
 namespace pgtn {
 pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out);
-pg_status peer_agree_max(pg_ctx* c, unsigned mine, unsigned* agreed);
 namespace {
 #include "pg_gemv_tnt.h"
 
@@ -108,8 +107,8 @@ pg_status grow_partials_without_free(pg_mat* A, int S) {
   return PG_OK;
 }
 
-template <typename T, int U, int C, int LAG, int PF>
-pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
+template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int OPT = 0>
+pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   constexpr int WAVES = 4;
   constexpr int G = (int)sizeof(T) / 4;
   static_assert(C * G <= 8, "the inbox holds eight granules per member and step");
@@ -120,12 +119,18 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     pg_set_error("a row team of %d devices with %d columns per step needs more than one lane per granule", rt.n, C);
     return PG_ERR_UNSUPPORTED;
   }
+  if (DELAY && (rt.n * (C * G + 1) > 64 || rt.n * (C * G + 1) > TEAM_MAX * C * G)) {
+    pg_set_error("the latency injector's stamps do not fit beside the granules of %d devices", rt.n);
+    return PG_ERR_UNSUPPORTED;
+  }
   // as many workgroups per compute unit as the parked tiles leave room for (four of 32 KiB, two of 64 KiB, one of 128 KiB):
   // measured on 2048- / 4096- / 8192-row blocks, two members sharing one device, 5.87 (four) / 6.08 (two) / 6.28 (two) TB/s
   // against 3.31 / 5.16 / 6.19 with one (profiles/r4_row_team_one_gpu.md)
   constexpr size_t PARK = (size_t)LAG * WAVES * C * U * 1024;
-  // (exact-U geometries park 40 / 48 KiB: three of them fit beside the kernel's static LDS)
-  int64_t nteams = (int64_t)c->num_cu * (PARK <= 32 * 1024 ? 4 : PARK <= 48 * 1024 ? 3 : PARK <= 64 * 1024 ? 2 : 1);
+  // (exact-U geometries park 40 / 48 KiB: three of them fit beside the kernel's static LDS).  Tiles that wait in registers
+  // (LAGR) count against the register file instead: the caller's table says how many workgroups of this instantiation a
+  // compute unit holds (wgs_per_cu; it must be the same number on every device -- same binary, same table).
+  int64_t nteams = (int64_t)c->num_cu * (wgs_per_cu > 0 ? wgs_per_cu : (PARK <= 32 * 1024 ? 4 : PARK <= 48 * 1024 ? 3 : PARK <= 64 * 1024 ? 2 : 1));
   if (rt.max_wgs > 0) nteams = rt.max_wgs;
   if (rt.max_wgs < 0) nteams = nteams / -rt.max_wgs > 0 ? nteams / -rt.max_wgs : 1;  // -k: this device is shared by k members of the team
   if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
@@ -152,6 +157,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.xch = a.peer_ring[rt.rank];
   a.team_err = c->dscal + PG_S_TEAMERR;
   a.wait_stats = c->rteam.wait_stats;
+  a.delay_ticks = c->test_team_delay_ticks;
   c->rteam.sweeps++;
   // The tags make a slot self-describing only among launches of ONE ring layout (every launch rewrites every slot it polls, so
   // a granule of the same epoch 254 launches ago is long gone).  When the layout changes -- another matrix shape, another
@@ -161,7 +167,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // and nothing of the previous launch is still in flight, because ITS scalar exchange has completed everywhere.  All devices
   // see the change at the same launch (same sequence of calls), so the extra exchange pairs up.
   const unsigned long long sig = ((unsigned long long)nteams << 32) | ((unsigned long long)C << 24) | ((unsigned long long)G << 16) |
-                                 ((unsigned long long)LAG << 8) | (unsigned long long)rt.n;
+                                 ((unsigned long long)(LAG + LAGR) << 8) | ((unsigned long long)(DELAY ? 1 : 0) << 15) | ((unsigned long long)(OPT & 1) << 14) | (unsigned long long)rt.n;
   if (sig != c->rteam.ring_sig) {
     PG_HIP(hipMemsetAsync(rt.inbox[rt.rank], 0, PEER_RING_BYTES, c->stream));
     PG_TRY(peer_scalar_exchange(c, c->rteam.f_local, c->rteam.f_local));
@@ -172,7 +178,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   a.tag_base = c->rteam.epoch << 24;
   *blocks_out = (int)nteams;
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
-  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true>);
+  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY, OPT>);
   if (lds + 4096 > 64 * 1024) {
     static std::mutex mu;
     static bool opted_in[64] = {};
@@ -193,7 +199,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead
-  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY, OPT>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -201,6 +207,32 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 }  // namespace
 
 bool tn_peer_covers(int nrg) { return nrg >= 1 && nrg <= 64; }
+
+namespace {
+struct PeerGeom {
+  int C, LAG, LAGR, PF, WGS, OPT;
+};
+// Float32 geometries of the row-team sweep by row groups per wave (profiles/r5_row_team_latency_sweep.md)
+PeerGeom peer_geometry_f32(int U) {
+  if (U <= 4) return {2, 2, 0, 2, 0, 0};
+  return {1, 2, 0, 2, 0, 0};
+}
+}  // namespace
+
+// every Float32 instantiation: (U, C, LAG, PF, LAGR); _D: also with the latency injector
+#define PG_TNP_F32_GEOMETRIES \
+  PG_TNP_CASE_D(2, 2, 2, 2, 0, 0); PG_TNP_CASE_D(2, 2, 2, 2, 0, 1); PG_TNP_CASE_D(2, 2, 2, 2, 0, 2); \
+  PG_TNP_CASE_D(2, 2, 2, 2, 0, 3); PG_TNP_CASE_D(2, 2, 2, 2, 1, 3); PG_TNP_CASE_D(2, 2, 3, 2, 2, 0); \
+  PG_TNP_CASE_D(2, 2, 3, 2, 3, 0); PG_TNP_CASE_D(2, 2, 3, 2, 3, 3); PG_TNP_CASE_D(2, 4, 2, 2, 0, 0); \
+  PG_TNP_CASE_D(2, 4, 2, 2, 2, 0); PG_TNP_CASE_D(2, 4, 2, 2, 2, 3); PG_TNP_CASE_D(2, 4, 2, 2, 0, 3); \
+  PG_TNP_CASE_D(4, 2, 2, 2, 0, 0); PG_TNP_CASE_D(4, 2, 2, 2, 0, 3); PG_TNP_CASE_D(4, 2, 2, 2, 1, 0); \
+  PG_TNP_CASE_D(4, 2, 2, 2, 1, 3); PG_TNP_CASE_D(4, 2, 2, 2, 2, 0); PG_TNP_CASE_D(4, 1, 2, 2, 0, 0); \
+  PG_TNP_CASE_D(4, 1, 3, 2, 2, 0); PG_TNP_CASE_D(8, 1, 2, 2, 0, 0); PG_TNP_CASE_D(8, 1, 2, 2, 0, 3); \
+  PG_TNP_CASE_D(8, 1, 2, 2, 1, 0); PG_TNP_CASE_D(8, 1, 2, 2, 1, 3); PG_TNP_CASE_D(16, 1, 2, 2, 0, 0); \
+  PG_TNP_CASE_D(16, 1, 2, 2, 0, 3); PG_TNP_CASE_D(16, 1, 2, 2, 1, 0); PG_TNP_CASE_D(16, 1, 2, 2, 1, 3); \
+  PG_TNP_CASE_D(16, 1, 2, 2, 2, 0); PG_TNP_CASE_D(16, 1, 2, 2, 2, 3); \
+  PG_TNP_CASE(3, 2, 2, 2, 0, 0); PG_TNP_CASE(5, 1, 2, 2, 0, 0); PG_TNP_CASE(6, 1, 2, 2, 0, 0); PG_TNP_CASE(7, 1, 2, 2, 0, 0); PG_TNP_CASE(9, 1, 2, 2, 0, 0); PG_TNP_CASE(10, 1, 2, 2, 0, 0); \
+  PG_TNP_CASE(11, 1, 2, 2, 0, 0); PG_TNP_CASE(12, 1, 2, 2, 0, 0); PG_TNP_CASE(13, 1, 2, 2, 0, 0); PG_TNP_CASE(14, 1, 2, 2, 0, 0); PG_TNP_CASE(15, 1, 2, 2, 0, 0)
 
 // Tunables (environment, for experiments): PG_TNP_C, PG_TNP_LAG.
 template <typename T>
@@ -211,17 +243,14 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // ~5-6 us at the device's streaming rate to cross the fabric and be found.  (LAG = 4 with one workgroup per compute unit: same slack, 0.6-0.85 of
   // the rate -- one workgroup's per-step chain of barrier, post, poll and LDS round trip is not hidden by a second one.)
   pg_ctx* c = A->ctx;
-  if (A->team_nrg == 0 || A->team_nrg_gen != c->rteam.gen) {  // the longest row block of the team (see peer_agree_max)
-    unsigned longest = 0;
-    PG_TRY(peer_agree_max(c, (unsigned)a.nrg, &longest));
-    // Remembered whatever came back -- also "a peer never answered" (0: the own length then): every device makes this
-    // exchange exactly once per agreement, so the exchanges' epochs stay in step.  A timeout sets the team's flag, the step
-    // is redone with two sweeps on every device, and that path forgets the agreement (pg_iter.hip::redo_with_two_sweeps):
-    // all devices come back here together at the next sweep.
-    A->team_nrg = (longest >= (unsigned)a.nrg && tn_peer_covers((int)longest)) ? (int)longest : a.nrg;
-    A->team_nrg_gen = c->rteam.gen;
+  // the longest row block of the team, agreed once per matrix and team (pg_gemv.hip::pg_mat_row_team_agree: a collective, normally
+  // made when the iterator was created); a block beyond what the sweep covers on ANY device: no device sweeps
+  PG_TRY(pg_mat_row_team_agree(c, A));
+  if (!tn_peer_covers(A->team_nrg) || A->team_nrg < a.nrg) {
+    pg_set_error("the longest row block of the team (%d row groups) is beyond the row-team sweep's %d", A->team_nrg, 64);
+    return PG_ERR_UNSUPPORTED;
   }
-  const int team_nrg = A->team_nrg >= a.nrg ? A->team_nrg : a.nrg;
+  const int team_nrg = A->team_nrg;
   const int per_wave = (team_nrg + 3) / 4;
   // U fits the longest block exactly (3, 5 .. 7, 9 .. 15 beside the powers of two): a block one row past 2048 rows is three row
   // groups per wave, not four -- 2 x 2049 rows streamed 4.0 TB/s in the next power of two's geometry where 2 x 2048 stream 5.9
@@ -231,31 +260,39 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     U = 2;
     while (U < per_wave) U *= 2;
   }
-  const int C = env_int("PG_TNP_C", U >= 5 ? 1 : 2);  // (U = 2: 16 KiB tiles, four workgroups per compute unit)
-  const int LAG = env_int("PG_TNP_LAG", 2);
-#define PG_TNP_CASE(UU, CC, LL) \
-  if (U == UU && C == CC && LAG == LL) return launch_tnp<T, UU, CC, LL, 2>(A, a, blocks_out)
-  PG_TNP_CASE(2, 4, 4);
-  PG_TNP_CASE(4, 2, 4);
-  PG_TNP_CASE(8, 1, 4);
-  PG_TNP_CASE(16, 1, 2);
-  PG_TNP_CASE(2, 4, 2);
-  PG_TNP_CASE(8, 1, 2);
-  PG_TNP_CASE(4, 2, 2);
-  PG_TNP_CASE(2, 2, 2);
-  PG_TNP_CASE(2, 2, 4);
-  PG_TNP_CASE(4, 1, 2);
-  PG_TNP_CASE(4, 1, 4);
-  PG_TNP_CASE(3, 2, 2);
-  PG_TNP_CASE(5, 1, 2); PG_TNP_CASE(6, 1, 2); PG_TNP_CASE(7, 1, 2);
-  PG_TNP_CASE(9, 1, 2); PG_TNP_CASE(10, 1, 2); PG_TNP_CASE(11, 1, 2); PG_TNP_CASE(12, 1, 2);
-  PG_TNP_CASE(13, 1, 2); PG_TNP_CASE(14, 1, 2); PG_TNP_CASE(15, 1, 2);
+  // Geometry by U: columns per step C, lag steps in LDS (LAG) and in registers (LAGR), tiles in flight (PF), workgroups per
+  // compute unit (0: as many as the parked tiles leave LDS for).  Float64 keeps round 4's geometries (its values take two
+  // granules and twice the registers per row group).
+  int C = U >= 5 ? 1 : 2, LAG = 2, LAGR = 0, PF = 2, WGS = 0;
   if constexpr (sizeof(T) == 4) {
-    PG_TNP_CASE(2, 8, 2);
-    PG_TNP_CASE(4, 4, 2);
+    const PeerGeom g = peer_geometry_f32(U);
+    C = g.C, LAG = g.LAG, LAGR = g.LAGR, PF = g.PF, WGS = g.WGS;
+  }
+  C = env_int("PG_TNP_C", C);
+  LAG = env_int("PG_TNP_LAG", LAG);
+  LAGR = env_int("PG_TNP_LAGR", LAGR);
+  PF = env_int("PG_TNP_PF", PF);
+  WGS = env_int("PG_TNP_WGS", WGS);
+  const int OPT = env_int("PG_TNP_OPT", sizeof(T) == 4 ? peer_geometry_f32(U).OPT : 0);
+  const bool delay = c->test_team_delay_on;
+#define PG_TNP_CASE(UU, CC, LL, PP, RR, OO)                                                             \
+  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && OPT == OO && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, OO>(A, a, blocks_out, WGS)
+#define PG_TNP_CASE_D(UU, CC, LL, PP, RR, OO)                                                           \
+  PG_TNP_CASE(UU, CC, LL, PP, RR, OO);                                                                  \
+  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && OPT == OO && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, OO>(A, a, blocks_out, WGS)
+  if constexpr (sizeof(T) == 4) {
+    PG_TNP_F32_GEOMETRIES;
+  } else {
+    PG_TNP_CASE(2, 4, 4, 2, 0, 0); PG_TNP_CASE(4, 2, 4, 2, 0, 0); PG_TNP_CASE(8, 1, 4, 2, 0, 0); PG_TNP_CASE(16, 1, 2, 2, 0, 0);
+    PG_TNP_CASE(2, 4, 2, 2, 0, 0); PG_TNP_CASE(8, 1, 2, 2, 0, 0); PG_TNP_CASE(4, 2, 2, 2, 0, 0); PG_TNP_CASE(2, 2, 2, 2, 0, 0);
+    PG_TNP_CASE(4, 1, 2, 2, 0, 0); PG_TNP_CASE(3, 2, 2, 2, 0, 0);
+    PG_TNP_CASE(5, 1, 2, 2, 0, 0); PG_TNP_CASE(6, 1, 2, 2, 0, 0); PG_TNP_CASE(7, 1, 2, 2, 0, 0);
+    PG_TNP_CASE(9, 1, 2, 2, 0, 0); PG_TNP_CASE(10, 1, 2, 2, 0, 0); PG_TNP_CASE(11, 1, 2, 2, 0, 0); PG_TNP_CASE(12, 1, 2, 2, 0, 0);
+    PG_TNP_CASE(13, 1, 2, 2, 0, 0); PG_TNP_CASE(14, 1, 2, 2, 0, 0); PG_TNP_CASE(15, 1, 2, 2, 0, 0);
   }
 #undef PG_TNP_CASE
-  pg_set_error("no row-team instantiation for U=%d C=%d LAG=%d", U, C, LAG);
+#undef PG_TNP_CASE_D
+  pg_set_error("no row-team instantiation for U=%d C=%d LAG=%d PF=%d LAGR=%d OPT=%d%s", U, C, LAG, PF, LAGR, OPT, delay ? " with the latency injector" : "");
   return PG_ERR_UNSUPPORTED;
 }
 template pg_status launch_tn_peer<float>(pg_mat*, TNArgs<float>&, int*);
@@ -285,23 +322,6 @@ static pg_status peer_exchange(pg_ctx* c, const double* f_local, double* f_out, 
 }
 
 pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) { return peer_exchange(c, f_local, f_out, 0u, nullptr); }
-
-// The geometry of a row-team sweep (row groups per wave, columns per step, workgroups per compute unit: which workgroup walks
-// which columns, and where its granules sit in the ring) must be the SAME on every device, but it follows from the length of
-// the row block, and the blocks of a team need not be equally long: 8193 rows over four devices are 2049 + 3 x 2048, nine row
-// groups on one device and eight on the others (found by tests/tools/fuzz_bench_ranks.py: every sweep ran into its bounded
-// wait and the job settled on two sweeps).  So the devices agree ONCE per matrix and team on the longest block -- one scalar
-// exchange carrying the own length in its spare granule, one read-back -- and size the sweep for that.  Every device gets here
-// at the same launch (same sequence of calls), so the exchange pairs up.  0: a peer never answered.
-pg_status peer_agree_max(pg_ctx* c, unsigned mine, unsigned* agreed) {
-  double* slot = c->rteam.f_local + 1;
-  PG_TRY(peer_exchange(c, c->rteam.f_local, c->rteam.f_local, mine, slot));
-  double got = 0.0;
-  PG_HIP(hipMemcpyAsync(&got, slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  PG_HIP(hipStreamSynchronize(c->stream));
-  *agreed = (unsigned)got;
-  return PG_OK;
-}
 
 }  // namespace pgtn
 

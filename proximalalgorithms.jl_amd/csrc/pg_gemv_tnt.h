@@ -8,7 +8,7 @@
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TEAM_MEMBER_RG = 64;              // a member holds WAVES * U = 64 row groups of every column (16384 rows in Float32)
 constexpr int TEAM_MAX = 16;                    // members per team: up to 1024 row groups (262144 rows f32, 131072 f64)
-constexpr int TEAM_RING = 8;                    // granule ring slots per team (>= 2 LAG + 2, see the protocol note)
+constexpr int TEAM_RING = 16;                   // granule ring slots per team (>= 2 (LAG + LAGR) + 2, see the protocol note)
 constexpr int PEER_RING = 16;                   // ... per workgroup index of a PEER team (members on different devices: LAG up to 7)
 constexpr long long TEAM_SPIN_LIMIT = 1 << 21;  // polls before a member gives up (~ seconds): bounded, never a hang
 
@@ -48,16 +48,55 @@ struct Pending {
 // into the inbox of EVERY member (a.peer_ring[q], system-scope stores over the fabric: pushes, never remote reads).
 // (2) Every member writes the column's outputs -- the n-vectors are replicated, and all members form the same bits from the
 // same granules in the same order.  (3) The ring is PEER_RING slots deep so that LAG can cover the fabric's latency.
-template <typename T, int U, int C, int WAVES, int LAG, int PF = 1, bool PEER = false>
+//
+// Lag tiles in REGISTERS (LAGR, round 5).  The slack the exchange has is parked bytes per compute unit / streaming rate, and LDS
+// holds 128 KiB of them; the register file holds 512 KiB per compute unit.  A tile therefore waits its first LAGR steps where it
+// was loaded (PF + 1 + LAGR named register tiles rotate instead of PF + 1; the compiler places what does not fit the 256
+// architectural VGPRs of a one-wave-per-SIMD geometry in accumulation registers by itself -- on gfx950 they are one 512-entry
+// file and a load may target either half), is parked in LDS for the remaining LAG steps, and is read back for the A v
+// accumulation LAG + LAGR steps after its dots were posted.  LAG = 0 with LAGR > 0: no LDS at all, the tile is multiplied where
+// it sits.
+//
+// DELAY (tests only, PEER): a latency injector for the hand-off.  Next to its granules a member posts one more, carrying the
+// constant 100 MHz clock (s_memrealtime) at the time of the store; a consumer accepts the granules of a step only once every
+// member's stamp is a.delay_ticks old.  All members must share a clock: ranks of ONE device -- which is where the injector is
+// used (profiles/r5_row_team_latency_sweep.md): the on-chip hand-off stands in for a fabric hop of a chosen length.  The hop is
+// thus max(on-chip hand-off, a.delay_ticks), not their sum, and nobody is held up who would not have been by a real hop of
+// that length: the sender does not wait, the stamp travels with the data.
+//
+// OPT & 1, AHEAD: the poll of a step's granules (and the fetch of its x_j / z_old_j) is issued ONE STEP BEFORE they are used, so
+// that its round trip through the memory pipeline -- which is full of tile loads -- overlaps a whole step instead of the dot
+// products only.  The granules must then have arrived one step earlier to be found at the first look (a later arrival is found
+// by the retry at the point of use, as before): one step of lag is traded for a wave that does not wait for its own poll.
+//
+// OPT & 2, NOBAR: no workgroup barrier per step.  The waves leave their partial dots in an LDS ring, tagged with the step; the
+// POSTER of step i -- wave i mod WAVES, so the role rotates -- waits for the other waves' tags, sums in wave order and posts the
+// granules; everybody else goes on to the totals of step i - LT at once.  A wave can be at most LT steps ahead of the slowest
+// (it needs totals that the slowest has not contributed to yet), so a ring of LT + 1 <= 8 entries is never overwritten unread.
+// With the barrier every step ran at the pace of the workgroup's slowest wave.
+template <typename T, int U, int C, int WAVES, int LAG, int PF = 1, bool PEER = false, int LAGR = 0, bool DELAY = false, int OPT = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
   constexpr int G = (int)sizeof(T) / 4;  // granules per value
   constexpr int RING = PEER ? PEER_RING : TEAM_RING;
   constexpr int SCOPE = PEER ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT;
-  static_assert(2 * LAG + 2 <= RING, "granule ring too short for this lag");
+  constexpr int LT = LAG + LAGR;  // steps between a tile's dots and its multiply-adds
+  static_assert(2 * LT + 2 <= RING, "granule ring too short for this lag");
   static_assert(PEER || TEAM_MAX * C * G <= 64, "one lane per granule of a step");  // (PEER: peer_n * C * G <= 64, checked at launch)
-  __shared__ T sm_dot[2][C][WAVES];
+  static_assert(!DELAY || PEER, "the latency injector belongs to the row-team sweep");
+  constexpr bool AHEAD = (OPT & 1) != 0, NOBAR = (OPT & 2) != 0;
+  static_assert(!AHEAD || LT >= 2, "a poll issued one step ahead needs two steps of lag");
+  static_assert((WAVES & (WAVES - 1)) == 0, "the poster's role rotates over a power of two of waves");
+  constexpr int DQ = NOBAR ? 8 : 2;  // entries of the dot ring (NOBAR: >= LT + 1; with the barrier: two, alternating)
+  static_assert(!NOBAR || LT + 1 <= DQ, "dot ring too short for this lag");
+  using DBits = typename std::conditional<G == 1, unsigned, unsigned long long>::type;
+  __shared__ DBits sm_dot[DQ][C][WAVES];
+  __shared__ unsigned sm_tag[DQ][WAVES];  // NOBAR: step + 1 of the entry wave w left last
+  if constexpr (NOBAR) {  // (LDS keeps what the previous workgroup on this compute unit left: a stale tag could pass for a fresh one)
+    if ((int)threadIdx.x < DQ * WAVES) (&sm_tag[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
   V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][WAVES][C][U][64]
   const int lane = threadIdx.x & (WAVE - 1);
@@ -105,6 +144,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   bool dead = false;  // wave-uniform: a poll timed out, stop waiting (the launch is reported as failed)
   unsigned late_steps = 0, late_polls = 0;  // PEER telemetry: steps whose granules were not there at the first look, polls spent
+  unsigned long long age_sum = 0;            // DELAY telemetry: clock ticks between the stamp of a step's granules (member 0's) and their use (the slack that was left)
+  unsigned age_cnt = 0;
 
   struct Tile {
     V col[C][U];
@@ -123,7 +164,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   };
   // this member's partial dots of step i -> ring
   auto dot_post = [&](const Tile& t, int64_t i) __attribute__((always_inline)) {
-    const int buf = (int)(i & 1);
+    const int buf = (int)(i & (DQ - 1));
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       T d = T(0);
@@ -133,16 +174,41 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         for (int e = 0; e < VEC; ++e) d = fma(t.col[c][u][e], rk[u][e], d);
       }
       d = wave_allsum(d);
-      if (lane == 0) sm_dot[buf][c][wave] = d;
+      if (lane == 0) {
+        if constexpr (NOBAR) __hip_atomic_store(&sm_dot[buf][c][wave], __builtin_bit_cast(DBits, d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else sm_dot[buf][c][wave] = __builtin_bit_cast(DBits, d);
+      }
     }
-    __syncthreads();
-    if (wave == 0 && lane < C * G) {
+    bool poster = wave == 0;
+    if constexpr (NOBAR) {
+      if (lane == 0) __hip_atomic_store(&sm_tag[buf][wave], (unsigned)(i + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      poster = wave == (int)(i & (WAVES - 1));
+      if (poster) {  // wait for the other waves' dots of this step (they are at most LT steps behind: bounded, and only on LDS)
+        const unsigned* tg = &sm_tag[buf][lane & (WAVES - 1)];
+        long long spins = 0;
+        while (!dead && __builtin_amdgcn_ballot_w64(__hip_atomic_load(tg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(i + 1)) != ~0ull) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > 8 * TEAM_SPIN_LIMIT) {
+            dead = true;
+            if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    } else {
+      __syncthreads();
+    }
+    if (poster && lane < C * G + (DELAY ? 1 : 0)) {
       T mine = T(0);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        T s = sm_dot[buf][c][0];
+        T s = T(0);
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += sm_dot[buf][c][w];
+        for (int w = 0; w < WAVES; ++w) {
+          DBits b;
+          if constexpr (NOBAR) b = __hip_atomic_load(&sm_dot[buf][c][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else b = sm_dot[buf][c][w];
+          s = w == 0 ? __builtin_bit_cast(T, b) : s + __builtin_bit_cast(T, b);
+        }
         if (lane / G == c) mine = s;
       }
       unsigned bits;
@@ -152,8 +218,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         const unsigned long long b = __builtin_bit_cast(unsigned long long, mine);
         bits = (lane % G) == 0 ? (unsigned)b : (unsigned)(b >> 32);
       }
+      size_t off = (size_t)(i % RING) * (TEAM_MAX * C * G) + (size_t)member * (C * G) + lane;
+      if constexpr (DELAY) {
+        if (lane == C * G) {  // the stamp granule: behind the TM members' value granules, one per member
+          bits = (unsigned)__builtin_amdgcn_s_memrealtime();
+          off = (size_t)(i % RING) * (TEAM_MAX * C * G) + (size_t)TM * (C * G) + (size_t)member;
+        }
+      }
       const unsigned long long word = ((unsigned long long)(a.tag_base + (unsigned)(i + 1)) << 32) | bits;
-      const size_t off = (size_t)(i % RING) * (TEAM_MAX * C * G) + (size_t)member * (C * G) + lane;
       if constexpr (PEER) {
         for (int q = 0; q < TM; ++q)  // one 8-byte store into every member's inbox (its own included)
           __hip_atomic_store(a.peer_ring[q] + ring_off + off, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -162,7 +234,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
       }
     }
   };
-  const int poll_lane = lane < npoll ? lane : npoll - 1;  // every lane polls (no exec-masked load): lanes >= npoll repeat the last granule
+  // every lane polls (no exec-masked load): lanes >= npoll repeat the last granule (DELAY: the TM stamp granules follow the values)
+  const int npoll_all = DELAY ? npoll + TM : npoll;
+  const int poll_lane = lane < npoll_all ? lane : npoll_all - 1;
+  // all granules of the step carry its tag (DELAY: and every member's stamp is a.delay_ticks old)
+  auto arrived = [&](unsigned long long w, unsigned tag) __attribute__((always_inline)) -> bool {
+    bool ok = (unsigned)(w >> 32) == tag;
+    if constexpr (DELAY) {
+      const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+      if (lane >= npoll && lane < npoll_all) ok = ok && (now - (unsigned)w) >= a.delay_ticks;
+    }
+    return __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+  };
   auto poll_word = [&](int64_t i) __attribute__((always_inline)) -> unsigned long long {
     return __hip_atomic_load(ring + (size_t)(i % RING) * (TEAM_MAX * C * G) + poll_lane, __ATOMIC_RELAXED, SCOPE);
   };
@@ -182,12 +265,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     if (a.dbg & 1) dead = true;  // timing experiment: never wait (totals are then wrong)
 #endif
     // The first look at the granules stays OUTSIDE the retry loop (see the note above the kernel).
-    if (!dead && __builtin_amdgcn_ballot_w64((unsigned)(pd.w >> 32) == tag) != ~0ull) {
+    if (!dead && !arrived(pd.w, tag)) {
       long long spins = 0;
       for (;;) {
         __builtin_amdgcn_s_sleep(1);
         pd.w = poll_word(i);
-        if (__builtin_amdgcn_ballot_w64((unsigned)(pd.w >> 32) == tag) == ~0ull) break;
+        if (arrived(pd.w, tag)) break;
         if (++spins > TEAM_SPIN_LIMIT) {
           dead = true;
           if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -198,6 +281,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         late_steps += 1;
         late_polls += (unsigned)(spins + 1);
       }
+    }
+    if constexpr (DELAY) {  // how old the step's youngest granule is when it is consumed: the slack the pipeline had left
+      const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+      const unsigned age = now - (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pd.w, npoll);  // (member 0's stamp; wave-uniform: scalar registers)
+      if (!dead) age_sum += age, age_cnt += 1;
     }
     const int w_lo = (int)(unsigned)pd.w;
     const int64_t j0 = map.at(i) * C;
@@ -247,37 +335,44 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   };
   auto park_slot = [&](int64_t i) { return park + ((size_t)(LAG > 0 ? i % (LAG > 0 ? LAG : 1) : 0) * WAVES + wave) * (C * U * WAVE) + lane; };
 
-  // One step: [poll the totals of step i - LAG, fetch its x_j / z_old_j] [start loading tile i + 1 into `nxt`]
-  // [dot + post tile i = `cur`] [totals of step i - LAG -> v_j ; A v accumulation from the parked tile] [park `cur`].
-  // ALL = steady state: every part runs, no branch.
-  auto step = [&](auto allc, Tile& cur, Tile& nxt, int64_t i) __attribute__((always_inline)) {
+  Pending<T, C> carry{};  // AHEAD: the poll and fetch issued by the previous step for this one
+  // One step: [poll the totals of step i - LT, fetch its x_j / z_old_j] [start loading tile i + PF into `nxt`]
+  // [dot + post tile i = `cur`] [totals of step i - LT -> v_j ; A v accumulation from the parked tile] [park tile i - LAGR = `old`
+  // (LAGR = 0: `cur` itself)].  ALL = steady state: every part runs, no branch.
+  auto step = [&](auto allc, Tile& cur, Tile& nxt, Tile& old, int64_t i) __attribute__((always_inline)) {
     constexpr bool ALL = decltype(allc)::value;
-    if (!ALL && i >= cnt + LAG) return;
-    const bool has_fma = ALL || i >= LAG;
+    if (!ALL && i >= cnt + LT) return;
+    const bool has_fma = ALL || i >= LT;
     Pending<T, C> pd{};
     // scheduling fences around the load issue: `nxt` is the register tile the previous step read last; without them the
     // scheduler hoists these loads above that step's multiply-adds into fresh registers and the kernel spills
     __builtin_amdgcn_sched_barrier(0);
-    if (has_fma) {
-      if constexpr (LAG > 0) pd.w = poll_word(i - LAG);  // issued BEFORE the next tile's loads: it returns first
-      fetch_xz(pd, i - LAG);
+    if constexpr (AHEAD) {
+      pd = carry;  // polled and fetched by the previous step
+      if (ALL || (i + 1 >= LT && i + 1 - LT < cnt)) {
+        carry.w = poll_word(i + 1 - LT);
+        fetch_xz(carry, i + 1 - LT);
+      }
+    } else if (has_fma) {
+      if constexpr (LT > 0) pd.w = poll_word(i - LT);  // issued BEFORE the next tile's loads: it returns first
+      fetch_xz(pd, i - LT);
     }
     if (ALL || i + PF < cnt) load(nxt, i + PF);
     __builtin_amdgcn_sched_barrier(0);
     if (ALL || i < cnt) dot_post(cur, i);
-    if constexpr (LAG == 0) {
+    if constexpr (LT == 0) {
       if (has_fma) pd.w = poll_word(i);
     }
     if (has_fma) {
       T vj[C];
-      totals(i - LAG, pd, vj);
-      if constexpr (LAG == 0) {
+      totals(i - LT, pd, vj);
+      if constexpr (LAG == 0) {  // the tile of step i - LT is still in registers (`old`; LT = 0: `cur`)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(cur.col[c][u][e], vj[c], racc[u][e]);
+            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(old.col[c][u][e], vj[c], racc[u][e]);
           }
         }
 #ifdef PG_TNT_EXPERIMENT
@@ -296,7 +391,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         // for two columns per step, makes room by spilling the tile that is in flight.  The address of every chunk depends
         // (through an opaque v_mov that always yields 0) on an accumulator of the previous chunk, which pins the order
         // read 4 -> multiply-add 4 -> read 4 ...
-        const V* __restrict__ src = park_slot(i - LAG);
+        const V* __restrict__ src = park_slot(i - LT);
         int dep = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -327,44 +422,64 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
 #ifdef PG_TNT_EXPERIMENT
       if (!(a.dbg & 4))
 #endif
-      if (ALL || i < cnt) {  // same slot as the tile just read: this wave's region only, program order suffices
-        V* __restrict__ dst = park_slot(i);
+      if (ALL || (i >= LAGR && i - LAGR < cnt)) {  // same slot as the tile just read ((i - LAGR) % LAG == (i - LT) % LAG): this wave's region only, program order suffices
+        V* __restrict__ dst = park_slot(i - LAGR);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) dst[(c * U + u) * WAVE] = cur.col[c][u];
+          for (int u = 0; u < U; ++u) dst[(c * U + u) * WAVE] = old.col[c][u];
         }
       }
     }
   };
 
-  // PF + 1 register tiles rotate: tile i is dotted while tiles i + 1 .. i + PF are in flight.  Named variables, not an
-  // array: an array of tiles handed to the step by reference ends up in scratch memory.
-  constexpr int NR = PF + 1;
-  static_assert(NR == 2 || NR == 3, "two or three register tiles");
-  Tile ta, tb, tc;
-  if (cnt > 0) load(ta, 0);
+  // PF + 1 + LAGR register tiles rotate: tile i (in t[i % NR]) is dotted while tiles i + 1 .. i + PF are in flight and tiles
+  // i - LAGR .. i - 1 wait for their totals; the load of tile i + PF goes where tile i - LAGR - 1 sat, which the previous step
+  // parked (or multiplied).  Named variables, not an array: an array of tiles handed to the step by reference ends up in
+  // scratch memory.
+  constexpr int NR = PF + 1 + LAGR;
+  static_assert(NR >= 2 && NR <= 8, "two to eight register tiles");
+  static_assert(PF == 1 || PF == 2, "one or two tiles in flight");
+  Tile t0, t1, t2, t3, t4, t5, t6, t7;
+  auto tile = [&](auto k) __attribute__((always_inline)) -> Tile& {
+    constexpr int K = decltype(k)::value;
+    if constexpr (K == 0) return t0;
+    else if constexpr (K == 1) return t1;
+    else if constexpr (K == 2) return t2;
+    else if constexpr (K == 3) return t3;
+    else if constexpr (K == 4) return t4;
+    else if constexpr (K == 5) return t5;
+    else if constexpr (K == 6) return t6;
+    else return t7;
+  };
+  if (cnt > 0) load(t0, 0);
   if constexpr (PF > 1) {
-    if (cnt > 1) load(tb, 1);
+    if (cnt > 1) load(t1, 1);
   }
   auto round = [&](auto allc, int64_t base) __attribute__((always_inline)) {
-    if constexpr (NR == 2) {
-      step(allc, ta, tb, base);
-      step(allc, tb, ta, base + 1);
-    } else {  // tile i in t[i % 3], loading tile i + 2 into t[(i + 2) % 3]
-      step(allc, ta, tc, base);
-      step(allc, tb, ta, base + 1);
-      step(allc, tc, tb, base + 2);
-    }
+    auto one = [&](auto sc) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value;
+      if constexpr (S < NR)
+        step(allc, tile(std::integral_constant<int, S>{}), tile(std::integral_constant<int, (S + PF) % NR>{}),
+             tile(std::integral_constant<int, (S + NR - LAGR) % NR>{}), base + S);
+    };
+    one(std::integral_constant<int, 0>{});
+    one(std::integral_constant<int, 1>{});
+    one(std::integral_constant<int, 2>{});
+    one(std::integral_constant<int, 3>{});
+    one(std::integral_constant<int, 4>{});
+    one(std::integral_constant<int, 5>{});
+    one(std::integral_constant<int, 6>{});
+    one(std::integral_constant<int, 7>{});
   };
-  constexpr int64_t HEAD = (LAG + NR - 1) / NR * NR;  // first round boundary from which every step has totals to consume
+  constexpr int64_t HEAD = (LT + NR - 1) / NR * NR;  // first round boundary from which every step has totals to consume
   int64_t base = 0;
-  for (; base < HEAD && base < cnt + LAG; base += NR) round(std::false_type{}, base);
+  for (; base < HEAD && base < cnt + LT; base += NR) round(std::false_type{}, base);
   if (base + NR + PF <= cnt) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the steady loop starts from a state the compiler knows exactly
     for (; base + NR + PF <= cnt; base += NR) round(std::true_type{}, base);
   }
-  for (; base < cnt + LAG; base += NR) round(std::false_type{}, base);
+  for (; base < cnt + LT; base += NR) round(std::false_type{}, base);
   // this member's rows of the team's partial of A v
   T* part = a.partials + (int64_t)team * a.ld + lane * VEC;
 #pragma unroll
@@ -374,6 +489,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     if (lane == 0 && a.wait_stats != nullptr && late_steps != 0) {
       atomicAdd(a.wait_stats, (unsigned long long)late_steps);
       atomicAdd(a.wait_stats + 1, (unsigned long long)late_polls);
+    }
+    if constexpr (DELAY) {
+      if (lane == 0 && a.wait_stats != nullptr && age_cnt != 0) {
+        atomicAdd(a.wait_stats + 2, age_sum);
+        atomicAdd(a.wait_stats + 3, (unsigned long long)age_cnt);
+      }
     }
   }
   const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};

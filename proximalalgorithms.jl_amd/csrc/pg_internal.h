@@ -95,8 +95,8 @@ struct pg_row_team {
   int max_wgs = 0;            // workgroups per device (0: one per compute unit); must be the same on every device
   unsigned epoch = 0, scal_epoch = 0;  // launch epochs of the granule tags: advance in step on every device
   unsigned long long ring_sig = 0;     // layout of the granule ring the last sweep used (workgroups, C, G, LAG, devices)
-  double* f_local = nullptr;  // device, two doubles: [0] this device's 1/2 lam ||r_p||^2 between the finish kernel and the exchange; [1] see peer_agree_max
-  unsigned long long* wait_stats = nullptr;  // device: { late waves, polls spent waiting } since pg_ctx_set_row_team (telemetry)
+  double* f_local = nullptr;  // device, two doubles: [0] this device's 1/2 lam ||r_p||^2 between the finish kernel and the exchange; [1] spare; [2..18): the one-hot slots of pg_mat_row_team_agree
+  unsigned long long* wait_stats = nullptr;  // device: { late waves, polls spent waiting, (latency injector:) ticks of slack left, steps counted } since pg_ctx_set_row_team (telemetry)
   long long sweeps = 0;       // row-team sweeps launched since pg_ctx_set_row_team
   unsigned gen = 0;           // bumped by every pg_ctx_set_row_team: what a matrix agreed on with one team does not carry over
 };
@@ -139,6 +139,10 @@ struct pg_ctx {
   bool team_timeout = false;
   int test_team_fault = 0;
   int test_team_fault_kind = 0;  // 0: one workgroup never starts (its team times out); 1: the launch is refused
+  // pg_ctx_test_team_fault(ctx, ns, 2): latency injector of the row-team sweep -- a step's granules are accepted by their consumers
+  // only `ns` nanoseconds after they were stored (gemv_tnt_kernel<..., DELAY>, pg_gemv_tnt.h; members must share a device's clock)
+  unsigned test_team_delay_ticks = 0;  // 100 MHz ticks; 0: off
+  bool test_team_delay_on = false;     // the DELAY instantiation is launched (also with 0 ticks: the injector's own cost)
   long team_launches = 0;
   bool team_plain_launch = false;  // PG_TN_TEAM_PLAIN = 1: plain instead of cooperative launch (A/B measurements)
   // Cooperative queues of different PROCESSES are not run side by side on one device: next to any process that holds one
@@ -183,7 +187,7 @@ struct pg_mat {
   // workspace for y = A x partial sums (lazy)
   void* partials = nullptr;
   int64_t partials_slots = 0;
-  int team_nrg = 0;        // row team: the LONGEST row block of the team in row groups, agreed once per matrix and team (pg_gemv_tn4.hip)
+  int team_nrg = 0;        // row team: the LONGEST row block of the team in row groups, agreed once per matrix and team (pg_mat_row_team_agree)
   unsigned team_nrg_gen = 0;
   std::vector<void*> retired;  // outgrown partial-sum buffers of a row-team matrix, freed with the matrix (pg_gemv_tn4.hip)
   void* rpad = nullptr;  // [ld] zero-padded copy of a caller's m-vector (pg_mat_fused_tn)
@@ -235,6 +239,9 @@ pg_status pg_ls_fused_pass_async(pg_ls* f, const void* r_src /* null: f->r */, v
                                  const void* g_v0 = nullptr /* IndBox: per-element lo, hi (else the scalars g_p0, g_p1) */,
                                  const void* g_v1 = nullptr);
 bool pg_ls_fused_pass_supported(const pg_ls* f);
+// Row teams: the LONGEST row block of the team in row groups -> A->team_nrg, agreed once per matrix and team through the registered
+// all-reduce (pg_gemv.hip); every device of the team must get here at the same point of its call sequence
+pg_status pg_mat_row_team_agree(pg_ctx* c, pg_mat* A);
 // g = lam A' r (+ all-reduce) from the residual currently held in f->r; f must already be in dscal[PG_S_F]
 pg_status pg_ls_grad_stage_async(pg_ls* f, void* grad_out);
 // r_out = a r1 + b r2 over m elements, dscal[PG_S_F] = f_scale ||r_out||^2, optional typed mirror of f

@@ -207,9 +207,6 @@ pg_status redo_with_two_sweeps(pg_iter* it, pg_status why, bool residual_intact)
   // the members of a team never run together): stay with two sweeps instead of paying the bounded wait in every step.
   // The count is the same on every rank of a sharded job (the flag is exchanged), so they leave the mode together.
   if (why == PG_ERR_TIMEOUT && ++it->timeouts_in_a_row >= 3) it->single_sweep = false;
-  // row team: what the devices agreed on for this matrix (the longest row block) is agreed again before the next sweep -- a
-  // device that missed a peer in that exchange sized its sweep differently, which is one way to get here
-  if (why == PG_ERR_TIMEOUT && c->rteam.n > 1) it->f->A->team_nrg = 0;
   if (why == PG_ERR_UNSUPPORTED) {
     // refused: nothing of the sweep ran, and it would be refused again -- also inside a batch (defer_sync): the two sweeps
     // are enqueued in its place and the batch's one read-back takes f(x) from PG_S_F like any two-sweep iteration.  With
@@ -703,9 +700,19 @@ pg_status pg_iter_state_upload(pg_iter* it, const void* host_blob, int64_t bytes
              "the blob was saved for another problem size or element type");
   PG_REQUIRE(h.fast == it->o.fast && h.adaptive == (it->adaptive ? 1 : 0) && h.g_kind == it->o.g_kind,
              "the blob was saved by another iteration type (fast / adaptive / g)");
-  PG_REQUIRE(h.single_sweep == (it->single_sweep ? 1 : 0) && h.reuse == (it->rz != nullptr ? 1 : 0),
+  // A solve that LEFT the single-sweep mode at run time (three bounded waits in a row, a refused launch: redo_with_two_sweeps)
+  // saves single_sweep = 0 from an iterator that was created with it -- and a fresh iterator with the same options has it on.
+  // The blob's layout follows from x_next being allocated, not from the flag (h.bytes is checked below), so such a blob is
+  // taken and this iterator leaves the mode as well; the other direction (a blob WITH a speculative half into an iterator
+  // without the seventh vector) has no place for it.
+  PG_REQUIRE((h.single_sweep == (it->single_sweep ? 1 : 0) || (h.single_sweep == 0 && it->x_next != nullptr)) &&
+                 h.reuse == (it->rz != nullptr ? 1 : 0),
              "the blob was saved by an iterator with other sweep options (single_sweep / reuse_residual / sharding)");
   PG_REQUIRE(h.bytes == state_blob_bytes(it) && bytes >= h.bytes, "the blob is truncated");
+  if (h.single_sweep == 0 && it->single_sweep) {
+    it->single_sweep = false;
+    h.sp_ready = 0;
+  }
   pg_ctx* c = it->ctx;
   const char* src = (const char*)host_blob + sizeof(h);
   void* ptrs[12];
@@ -723,6 +730,10 @@ pg_status pg_iter_state_upload(pg_iter* it, const void* host_blob, int64_t bytes
   it->spec_t = h.spec_t, it->spec_k = h.spec_k;
   it->flags = h.flags, it->n_backtracks = h.n_backtracks, it->rz_valid = h.rz_valid != 0, it->sp_ready = h.sp_ready != 0;
   it->sp_slot = h.sp_slot;
+  // f at the speculative point lives in the scalar block too (PG_S_FNEXT + slot): a batched run after the resume takes f(x) of
+  // its first iteration from there with the batch's one read-back, and this context's block has never held it.  (The block is
+  // mapped host memory: the store below is what a kernel would have left; the stream is idle after the synchronisation above.)
+  if (it->sp_ready) c->hscal[PG_S_FNEXT + it->sp_slot] = it->sp_f;
   it->fx_src = -1;
   it->defer_sync = false;
   it->f->r_gen++;  // f->r was rewritten

@@ -32,6 +32,13 @@ function check(status::Int32)
     throw(ProxGradError(status, unsafe_string(ccall((:pg_last_error, libpg), Cstring, ()))))
 end
 
+const PG_ABI_VERSION = Int32(2)   # include/proxgrad_hip.h: the version this file was written against
+
+function __init__()   # a stale or mismatched build is refused at load, not at the first missing symbol
+    found = ccall((:pg_abi_version, libpg), Int32, ())
+    found == PG_ABI_VERSION || error("libproxgrad_hip ($libpg) has ABI version $found, ProximalAlgorithmsHIP.jl was written against $PG_ABI_VERSION: rebuild the library or point PROXGRAD_HIP_LIB at a matching build")
+end
+
 # ---------------------------------------------------------------- context ------------------------------------
 mutable struct HIPContext
     handle::Ptr{Cvoid}

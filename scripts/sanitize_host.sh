@@ -7,10 +7,10 @@
 #                                       the `not gpu` tests that call into the library (symbol table, argument validation,
 #                                       no-CPU-fallback errors, the host-side Nesterov sequences, bench.py without a GPU)
 #                                       run against it with the sanitizer runtime preloaded into python
-# Usage: scripts/sanitize_host.sh [log]      (default log: profiles/r4_host_sanitizers.log; exit code 0 = clean)
+# Usage: scripts/sanitize_host.sh [log]      (default log: profiles/r5_host_sanitizers.log; exit code 0 = clean)
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-LOG="${1:-$ROOT/profiles/r4_host_sanitizers.log}"
+LOG="${1:-$ROOT/profiles/r5_host_sanitizers.log}"
 WORK="$(mktemp -d /tmp/pg_asan.XXXXXX)"
 trap 'rm -rf "$WORK"' EXIT
 export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=97"   # (python itself leaks by design)
@@ -77,10 +77,16 @@ print(b.build(force=True, verbose=False))" )
 rc=$?; echo "build rc=$rc"; [ $rc -ne 0 ] && fail=1
 echo "instrumented: $(nm -D --undefined-only "$WORK/pkg/libproxgrad_hip.so" 2>/dev/null | grep -c -E '__asan_|__ubsan_') undefined __asan_* / __ubsan_* references in the library"
 if [ $rc -eq 0 ]; then
+  # (the status that counts is pytest's, not tail's -- round 4 read ${PIPESTATUS[0]} of a SUBSHELL, i.e. tail's 0, so this leg
+  # could not fail the gate: ADVICE r4.  The output goes to a file, the status is taken from pytest itself, and the sanitizers'
+  # own report lines fail the leg whatever the exit code.)
   ( cd "$ROOT" && LD_PRELOAD="$CLANG_RT" PG_LIB_PATH="$WORK/pkg/libproxgrad_hip.so" \
       python3 -m pytest tests/test_cpu_host.py tests/test_julia_glue.py -q -x -p no:cacheprovider \
-      -k "symbol or no_cpu_fallback or host_sequences or without_a_gpu or cli_parses or julia" 2>&1 | tail -8 )
-  rc=${PIPESTATUS[0]}; echo "rc=$rc"; [ $rc -ne 0 ] && fail=1
+      -k "symbol or no_cpu_fallback or host_sequences or without_a_gpu or cli_parses or julia" > "$WORK/leg3.out" 2>&1 )
+  rc=$?; tail -8 "$WORK/leg3.out"; echo "rc=$rc"; [ $rc -ne 0 ] && fail=1
+  if grep -q -E "ERROR: AddressSanitizer|ERROR: LeakSanitizer|runtime error:" "$WORK/leg3.out"; then
+    echo "sanitizer report in leg 3:"; grep -E "ERROR: AddressSanitizer|ERROR: LeakSanitizer|runtime error:" "$WORK/leg3.out" | head -5; fail=1
+  fi
 fi
 echo "== result: $([ $fail -eq 0 ] && echo CLEAN || echo FINDINGS)"
 } 2>&1 | tee "$LOG"

@@ -32,14 +32,17 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(boundary) >= 45 and not (boundary & ext)
     # the boundary header is SURVEY 8(b)'s table: what serves other algorithms lives in the _ext header
     assert ext == {"pg_ctx_capture_begin", "pg_ctx_capture_end", "pg_graph_launch", "pg_graph_destroy", "pg_mat_rank1_update",
-                   "pg_mat_fused_dys", "pg_ctx_test_team_fault"}
+                   "pg_mat_fused_dys", "pg_ctx_test_team_fault", "pg_ctx_test_team_slack"}
     assert {"pg_lbfgs_images_enable", "pg_lbfgs_images_update", "pg_lbfgs_images_apply", "pg_lbfgs_images_ready"} <= boundary
     declared = boundary | ext
     handle = lib.load()
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} is declared in include/*.h but not exported"
     assert declared == set(lib.exported_symbols()), declared ^ set(lib.exported_symbols())
-    assert handle.pg_abi_version() == 1
+    header_version = int(re.search(r"#define PG_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "proxgrad_hip.h")).read()).group(1))
+    assert handle.pg_abi_version() == header_version == lib.PG_ABI_VERSION == 2
+    julia = open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "julia", "ProximalAlgorithmsHIP.jl")).read()
+    assert int(re.search(r"const PG_ABI_VERSION = Int32\((\d+)\)", julia).group(1)) == header_version
 
 
 def test_column_group_assignment_covers_every_group_once(tmp_path):
@@ -279,17 +282,21 @@ def test_team_ring_protocol_model():
     between devices) as a model: every member, in its own order, POSTS step i into slot i % RING of every inbox and then CONSUMES
     step i - LAG (waiting until all members have posted it).  Claim checked here under random interleavings: a slot is never
     overwritten before its previous content (step i - RING) was consumed by the inbox's owner iff RING >= 2 LAG + 2 -- so the
-    constants in the source (TEAM_RING for LAG <= 3, PEER_RING for the PEER instantiations' LAG) are deep enough, and one slot
+    constants in the source (TEAM_RING, PEER_RING for the instantiations' total lag LAG + LAGR) are deep enough, and one slot
     less is not."""
     import random
 
     src = open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "csrc", "pg_gemv_tnt.h")).read()
     team_ring = int(re.search(r"constexpr int TEAM_RING = (\d+);", src).group(1))
     peer_ring = int(re.search(r"constexpr int PEER_RING = (\d+);", src).group(1))
-    assert "static_assert(2 * LAG + 2 <= RING" in src
+    # (round 5: a tile waits LAG steps in LDS and LAGR in registers -- LT = LAG + LAGR is the lag the ring must cover.  The
+    # barrier-free dot exchange, OPT & 2, keeps the invariant the bound rests on: the poster of step i posts only after EVERY wave
+    # of its workgroup has left its dots of step i, i.e. has consumed step i - 1 - LT.)
+    assert "constexpr int LT = LAG + LAGR;" in src and "static_assert(2 * LT + 2 <= RING" in src
     tn4 = open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "csrc", "pg_gemv_tn4.hip")).read()
-    peer_lags = {int(m.group(3)) for m in re.finditer(r"PG_TNP_CASE\((\d+), (\d+), (\d+)\)", tn4)}
-    assert peer_lags and max(peer_lags) * 2 + 2 <= peer_ring and 2 * 2 + 2 <= team_ring
+    # PG_TNP_CASE[_D](U, C, LAG, PF, LAGR, OPT)
+    peer_lags = {int(m.group(3)) + int(m.group(5)) for m in re.finditer(r"PG_TNP_CASE(?:_D)?\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", tn4)}
+    assert peer_lags and max(peer_lags) * 2 + 2 <= peer_ring and 2 * 4 + 2 <= team_ring
 
     def run(members, lag, ring, steps, seed):
         """returns True when some post overwrote an unconsumed slot.  seed None: adversarial schedule -- member 0 runs whenever it

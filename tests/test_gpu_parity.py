@@ -787,6 +787,78 @@ def test_saved_state_resumes_bit_identically(pa, fast, adaptive, g):
         next(make().resume(blob[: len(blob) // 2]))
 
 
+def test_resume_into_a_batched_run_and_of_a_solve_that_left_the_single_sweep(pa):
+    """ADVICE r4 (low), the two gaps of pg_iter_state_upload.  (b) A saved single-sweep state carries f at its speculative point
+    in the scalar block (PG_S_FNEXT + slot) as well; pg_iter_run_batched takes f(x) of the first iteration after a resume from
+    THERE with the batch's one read-back -- a fresh context never held it, so a batch that ended on that iteration reported a
+    wrong f_x.  (a) A solve that left the single-sweep mode at run time (here: a refused team sweep, pg_ctx_test_team_fault kind
+    1) saves single_sweep = 0; a fresh iterator with the same options has it on and refused the blob."""
+    import gc
+
+    from proximalalgorithms.jl_amd import _lib
+    from proximalalgorithms.jl_amd._fused import FusedIteration
+
+    dtype = np.float32
+    # (b) fixed-step FastForwardBackward, one wave per column group (1500 rows); the stepped solve is the reference
+    m, n = 1500, 2600
+    A, b, lam = synthetic_problem(m, n, dtype, seed=11)
+    Lf = dtype(power_Lf(A))
+    f = pa.LeastSquares(A, b)
+    x0 = pa.HIPVector.from_numpy(np.zeros(n, dtype))
+    mk = lambda: FusedIteration(f, pa.NormL1(lam), fast=True, Lf=Lf, gamma=None, adaptive=False, minimum_gamma=1e-7, reduce_gamma=0.5,
+                                increase_gamma=1.0, mf=0.0, seq_kind=_lib.PG_SEQ_ADAPTIVE, seq_p0=0.0, seq_p1=0.0,
+                                reuse_residual=True, single_sweep=True)
+    ref = mk()
+    ref.init(x0)
+    fx = []
+    for _ in range(14):
+        sc = ref.step()
+        fx.append(float(sc.f_x))
+    z_ref = ref.view()["z"].numpy().copy()
+    first = mk()
+    first.init(x0)
+    for _ in range(9):
+        first.step()
+    blob = first.state_download()
+    del first
+    gc.collect()
+    for first_batch in (1, 2, 5):  # iterations the first batch after the resume holds (1: it ends on the resumed iteration itself)
+        again = mk()
+        again.state_upload(blob)
+        k, sc = again.run(0, first_batch, 0.0, check_every=4)
+        assert k == first_batch and float(sc.f_x) == fx[9 + first_batch - 1], (first_batch, float(sc.f_x), fx[9 + first_batch - 1])
+        if first_batch == 5:
+            assert np.array_equal(again.view()["z"].numpy(), z_ref)
+        del again
+    # (a) a team sweep (40000 rows) whose third launch is refused: the iterator redoes that step with two sweeps and stays there
+    m, n = 40000, 64
+    A, b, lam = synthetic_problem(m, n, dtype, seed=5)
+    Lf = dtype(power_Lf(A))
+    f = pa.LeastSquares(A, b)
+    ctx = f.ctx
+    make = lambda: pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=np.zeros(n, dtype), Lf=Lf, engine="fused")
+
+    def degraded(steps):
+        _lib.call("pg_ctx_test_team_fault", ctx.handle, 3, 1)
+        itn = make()
+        states = []
+        for s in itertools.islice(itn, steps):
+            states.append((s.z.numpy().copy(), float(s.f_x), int(s.flags)))
+        _lib.call("pg_ctx_test_team_fault", ctx.handle, 0, 0)
+        return itn, states
+
+    _, straight = degraded(12)
+    assert any(fl & pa.PG_FLAG_SWEEP_FALLBACK for _, _, fl in straight), [fl for _, _, fl in straight]
+    itn, head = degraded(7)
+    blob = itn.save_state()
+    del itn
+    gc.collect()
+    resumed = make()  # single_sweep on, as created -- the blob says the saved solve had left it
+    for k, s in enumerate(itertools.islice(resumed.resume(blob), 5), start=7):
+        assert np.array_equal(s.z.numpy(), straight[k][0]) and float(s.f_x) == straight[k][1], k
+    assert resumed.counters["a_passes"] >= 2 * 4, resumed.counters  # two reads of A per resumed iteration
+
+
 @pytest.mark.parametrize("cols,batched", [(True, False), (False, True), (True, True)])
 def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_fault_runs, cols, batched):
     """a REFUSED cooperative launch (injected: pg_ctx_test_team_fault kind 1) must be survivable where a
@@ -825,6 +897,10 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "10241", "--n", "257"], dict()),
     (["--m", "18433", "--n", "257"], dict()),
     (["--m", "10753", "--n", "257", "--dtype", "f64"], dict(tol=1e-11)),
+    # 16385 + 16384 rows: 65 row groups on rank 0 (beyond the sweep's 64), 64 on rank 1.  ADVICE r4: eligibility was decided per
+    # rank -- rank 1 would have swept and polled an inbox rank 0 never filled.  Now the TEAM agrees (pg_mat_row_team_agree): no
+    # rank sweeps, every step is two reads + the all-reduce of n + 1 on both, nothing is lost to a bounded wait
+    (["--m", "32769", "--n", "257"], dict(ineligible=True)),
 ])
 def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     """north_star's ROW layout at one read of A per iteration, exercised on ONE GPU.  The ranks
@@ -833,7 +909,7 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     8-byte granules into every rank's inbox and are summed in rank order (csrc/pg_gemv_tn4.hip).  Asserted: the iterates
     of EVERY rank equal the CPU restatement on the whole matrix (1e-5 max(1, |z|) in Float32), the ranks agree
     bit for bit, from the second step on every step is ONE read of the row block, and the whole solve issues two
-    all-reduces (initialisation; three with the adaptive step's estimate of the step size) -- none in the steady state.  fault: a member that never starts makes its peers' bounded
+    all-reduces (initialisation; three with the adaptive step's estimate of the step size) after the one that agrees on the team's longest block -- none in the steady state.  fault: a member that never starts makes its peers' bounded
     waits expire; the flag travels with the scalar exchange, every rank redoes THAT step with two sweeps + the registered
     all-reduce and returns to one read of A."""
     import json
@@ -857,6 +933,9 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
         if checks.get("adaptive"):  # the same backtracking decisions as the oracle on the whole matrix
             assert all(r["gamma"] == pytest.approx(r["gamma_oracle"], rel=1e-6) for r in rows), rows
         by_k = {r["k"]: r["a_passes"] for r in rows}
+        if checks.get("ineligible"):
+            assert all(by_k[k] == 2 for k in by_k if k >= 1), by_k
+            continue
         steady = [k for k in by_k if k >= 2 and (not fault or k not in (fault, fault + 1))]
         assert all(by_k[k] == 1 for k in steady), by_k
         if fault:
@@ -870,7 +949,12 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
         return
     if checks.get("batched"):
         return
-    assert all(c == (4 if fault else 3 if checks.get("adaptive") else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
+    if checks.get("ineligible"):  # the agreement, the initialisation's two, then one per iteration -- the same on both ranks
+        assert d["allreduce_calls"][0] == d["allreduce_calls"][1] >= 1 + 2 + 12, d["allreduce_calls"]
+        return
+    # one more when the first iterator over the matrix is created: the team agrees on its longest row block (and with it on
+    # whether it sweeps at all) through the registered all-reduce (pg_mat_row_team_agree)
+    assert all(c == 1 + (4 if fault else 3 if checks.get("adaptive") else 2) for c in d["allreduce_calls"]), d["allreduce_calls"]
 
 
 @pytest.mark.parametrize("args", [
@@ -2179,7 +2263,7 @@ def test_fuzz_ranks_as_processes_on_one_gpu(pa):
     against one rank on the same problem.  The first two cases are the campaign's finding in small: 4097 rows over two ranks are blocks of
     2049 + 2048 rows -- nine row groups on one rank, eight on the other -- and every rank sized the row-team sweep by its OWN
     block, so the ranks walked different column maps, every sweep timed out and the job settled on two sweeps; the ranks now
-    agree on the longest block once per matrix (pg_gemv_tn4.hip::peer_agree_max)."""
+    agree on the longest block once per matrix (pg_gemv.hip::pg_mat_row_team_agree)."""
     import importlib.util
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

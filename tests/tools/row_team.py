@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--then-n", type=int, default=0,
                     help="afterwards a SECOND problem with this many columns on the same contexts (another ring layout: the "
                          "devices clear their inboxes and meet in one exchange before its first sweep)")
+    ap.add_argument("--delay-ns", type=int, default=-1,
+                    help="latency injector (pg_ctx_test_team_fault kind 2): the sweep's DELAY form, a step's granules accepted only "
+                         "this many nanoseconds after they were stored (0: the injector's own cost; -1: off)")
     ap.add_argument("--bench", action="store_true",
                     help="timing instead of parity: synthetic row blocks generated on the device (no host copy, no oracle), "
                          "--steps timed iterations after 3 warm-up steps; prints it/s and the aggregate bytes of A per second")
@@ -127,6 +130,8 @@ def main():
                 sync.wait(timeout=120)
             if args.fault and r == 1:
                 _lib.call("pg_ctx_test_team_fault", ctx.handle, args.fault, args.fault_kind)
+            if args.delay_ns >= 0 and not args.no_team:
+                _lib.call("pg_ctx_test_team_fault", ctx.handle, args.delay_ns, 2)
             iteration = Iter(f=f, g=mk_g(sl), x0=pa.HIPVector.from_numpy(x0[sl], ctx), Lf=Lf)
             rows, passes, zs = [], 0, []
             for k, s in enumerate(itertools.islice(iteration, args.steps + 1)):
@@ -214,6 +219,10 @@ def bench(args):
             if r == 0 and not args.no_team:
                 pa.row_team_in_process(ctxs, max_wgs)
             sync.wait(timeout=300)
+            if args.delay_ns >= 0 and not args.no_team:
+                from proximalalgorithms.jl_amd import _lib
+
+                _lib.call("pg_ctx_test_team_fault", ctx.handle, args.delay_ns, 2)
             iteration = pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(dtype(0.05)), x0=pa.HIPVector.zeros(n, dtype, ctx), Lf=Lf)
             it = iter(iteration)
             for _ in range(4):
@@ -230,7 +239,14 @@ def bench(args):
             sync.wait(timeout=300)
             dt = time.perf_counter() - t0
             prof = ctx.profile_read()
-            out[r] = {"seconds": dt, "a_passes_per_step": (iteration.counters.get("a_passes", 0) - p0) / args.steps,
+            slack = None
+            if args.delay_ns >= 0 and not args.no_team:
+                import ctypes as C
+
+                tk, ws = C.c_int64(), C.c_int64()
+                _lib.call("pg_ctx_test_team_slack", ctx.handle, C.byref(tk), C.byref(ws))
+                slack = {"mean_us_between_store_and_use": (tk.value / max(ws.value, 1)) / 100.0, "wave_steps": ws.value}
+            out[r] = {"seconds": dt, "slack": slack, "a_passes_per_step": (iteration.counters.get("a_passes", 0) - p0) / args.steps,
                       "row_team_stats": None if args.no_team else pa.row_team_stats(ctx),
                       "fallbacks": iteration.counters.get("sweep_fallbacks", 0), "res_inf": float(s.res_inf),
                       "kernels": {k: [v[0], round(v[1] / max(v[0], 1), 4)] for k, v in prof.items() if v[0]}}
@@ -252,7 +268,7 @@ def bench(args):
     dt = max(o_["seconds"] for o_ in out)
     es = np.dtype(dtype).itemsize
     print(json.dumps({"bench": True, "m": m, "n": n, "ranks": N, "dtype": args.dtype, "team": not args.no_team, "max_wgs": max_wgs,
-                      "it_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+                      "delay_ns": args.delay_ns, "it_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
                       "A_bytes_per_s_all_ranks": m * n * es * out[0]["a_passes_per_step"] * args.steps / dt, "ranks_out": out}))
 
 
