@@ -12,12 +12,19 @@ single-sweep iteration: A' r, prox, next extrapolation and next residual per col
 N > 1: one process per GPU over RCCL (torch.distributed backend "nccl").  Started as plain `python bench.py --gpus N`
 the script launches `python -m torch.distributed.run --nproc-per-node N` itself as a CHILD process (before anything
 touches the GPU), relays the child's JSON line and exits with its code; under torch.distributed.run it is a rank.
-Rank 0 prints ONE JSON line.  Its top-level value is the STRONG-scaled headline problem with COLUMN blocks of A per
-rank (every GPU keeps the single sweep; one all-reduce of m + 8 N floats per iteration); the line also carries
-  rows_strong        the same problem with ROW blocks (north_star's layout: two sweeps, one all-reduce of n + 1 floats
-                     per gradient evaluation),
+Rank 0 prints ONE JSON line.  Its top-level value is the STRONG-scaled headline problem in north_star's layout: ROW blocks of
+A per rank.  It is measured first in the form that cannot fail on a new fabric -- two sweeps per iteration and one RCCL
+all-reduce of [grad (n) ; f] per gradient evaluation (benchmark/benchmarks.jl:15-16 per shard) -- and then UPGRADED to the
+row-team form (one read of A per iteration: the ranks exchange per-column partial dots through each other's inbox inside the
+sweep) when that form, run for the same K steps in a process group of its own, passes its attach-time self-test on every
+rank and loses no sweep to a bounded wait; `config.row_layout` says which form the value is ("row_teams" | "two_sweeps") and
+`config.row_layout_reason` why.  The line also carries
+  rows_two_sweeps    (after an upgrade) the two-sweep record the line would have had,
+  cols_strong        the same problem with COLUMN blocks (not the contract layout: every GPU keeps the single sweep, one
+                     all-reduce of m + 8 (N + 1) floats per iteration),
   config5_weak_rows  BASELINE config 5 and its smaller twins: 16384 rows PER GPU (131072 x 2^20 at N = 8), row blocks,
   config5_weak_cols  the same global problem with column blocks (each GPU: m x n/N, the long-column single sweep),
+  config5_weak_rows_teams  config 5 as a row team,
 each with its own roofline, the world size RCCL reports and the all-reduce payload.
 
 N = 1: the line also carries `also`: the reference benchmark's own adaptive mode on the headline matrix
@@ -85,12 +92,12 @@ def parse_args(argv=None):
                    help="one: the single-sweep iteration (A read once per iteration) -- two: A x and A' r as "
                         "separate sweeps like the reference (always the case when rows are sharded)")
     p.add_argument("--sharding", choices=["auto", "rows", "cols"], default="auto",
-                   help="N > 1: layout of the TOP-LEVEL record (auto: column blocks for the fixed-step single-sweep run, row "
-                        "blocks otherwise); the other layout is reported as a sub-record")
+                   help="N > 1: layout of the TOP-LEVEL record (auto = rows: north_star's contract, upgraded to row teams when they "
+                        "run clean -- see the module docstring); the other layout is reported as a sub-record")
     p.add_argument("--row-teams", action="store_true",
-                   help="with --sharding rows: the ranks exchange per-column partial dots through each other's inbox inside the "
-                        "sweep (one read of A per iteration) instead of all-reducing A'r between two sweeps")
-    p.add_argument("--no-row-teams", action="store_true", help="N > 1: skip the two row-team records at the end of the line")
+                   help="with --sharding rows: the top-level record itself runs as a row team, in this process group (the ranks "
+                        "exchange per-column partial dots through each other's inbox inside the sweep: one read of A per iteration)")
+    p.add_argument("--no-row-teams", action="store_true", help="N > 1: no row-team records (the top-level row record stays on two sweeps)")
     p.add_argument("--row-teams-child", action="store_true", help=argparse.SUPPRESS)  # the isolated process of those two records
     p.add_argument("--no-also", action="store_true",
                    help="skip the extra records (N = 1: adaptive headline + configs 2 / 3 / 4; N > 1: the other layouts)")
@@ -118,7 +125,6 @@ def parse_args(argv=None):
     p.add_argument("--overlap", action="store_true",
                    help="pipeline the [grad ; f] all-reduce with pass T in column chunks (N > 1, row blocks). Off by default: at "
                         "the headline shard shape the chunking costs ~60 us/step, about what it can hide (DESIGN.md section 6)")
-    p.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     p.add_argument("--force-comm", action="store_true",
                    help="diagnostic: attach the collective even with one rank (measures the cost of the sharded code path)")
     p.add_argument("--share-device", action="store_true",
@@ -833,14 +839,16 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
     rec = {
         "value": round(its, 4), "unit": "it/s", "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 4),
         "scaling": scaling,
+        # The driver's record keeps the first ~22 SCALAR keys of `config` and drops nested values: what identifies the record comes
+        # first, everything else about the problem sits under `problem` (kept in profiles/, dropped by the driver)
         "config": {"workload": "FFB LASSO m=%d n=%d %s, %s step, %s" % (
             m_glob, n, dname, mode, "one GPU" if layout == "none" else
             "%s of A sharded over %d GPU(s)" % ("columns" if cols else "rows", D.world)),
             "m": m_glob, "n": n, "mode": mode, "sharding": layout, "shards": D.world if layout != "none" else 1,
-            "m_per_gpu": m_loc, "n_per_gpu": n_loc, "lambda": float(P["lam"]), "Lf": float(Lf) if Lf is not None else None,
-            "seed": P["seed"], "a_passes_per_step": a_passes / max(steps, 1), "sweep_fallbacks": fallbacks,
+            "a_passes_per_step": a_passes / max(steps, 1), "sweep_fallbacks": fallbacks,
             "sweeps": sweeps if (layout != "rows" or P.get("row_teams")) else "two", "row_teams": bool(P.get("row_teams")),
-            "setup_s": round(P["setup_s"], 2),
+            "problem": {"m_per_gpu": m_loc, "n_per_gpu": n_loc, "lambda": float(P["lam"]), "Lf": float(Lf) if Lf is not None else None,
+                        "seed": P["seed"], "setup_s": round(P["setup_s"], 2)},
             "final": {"gamma": float(state.gamma), "f_x": float(state.f_x), "g_z": float(state.g_z),
                       "res_inf_over_gamma": float(state.res_inf) / float(state.gamma)}},
         "roofline": roofline,
@@ -848,6 +856,11 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
     if P.get("row_teams"):  # how the granule exchange went (sweeps, waves that had to wait, polls spent waiting), this rank
         rec["config"]["row_team_stats"] = pa.row_team_stats(ctx)
         rec["config"]["row_team_selftest"] = getattr(ctx, "_row_team_selftest", None)  # the scalar exchange tried at attach time
+        if D.world > 1:  # ... and whether EVERY rank's came back right (what an upgrade of the top-level record asks)
+            import torch.distributed as dist
+
+            rec["config"]["row_team_selftest_all_ranks"] = bool(D.reduce_scalar(1.0 if rec["config"]["row_team_selftest"] == "ok" else 0.0,
+                                                                                dist.ReduceOp.MIN) > 0.5)
     if layout != "none":
         calls = getattr(comm, "calls", 0) - calls0
         elems = getattr(comm, "elements", 0) - elems0
@@ -1114,21 +1127,58 @@ def extrapolate_ledger(d, m_full, n_full, steps_full=50, warmup_full=5, gen_rate
     return out, total
 
 
-def flat_summary(prefix, r):
-    """a record as scalar keys of `config` (<prefix>_it_s, _ms, _frac, _kernel, _a_passes; _error when it failed): the form the
-    driver's BENCH_rNN.json keeps (it drops nested values under `config`)"""
-    if not isinstance(r, dict) or "value" not in r:
-        return {prefix + "_error": str((r or {}).get("error", "not measured"))[:120] if isinstance(r, dict) else "not measured"}
-    roof = r.get("roofline") or {}
-    cfg = r.get("config") or {}
-    out = {prefix + "_it_s": r.get("value"), prefix + "_ms": r.get("ms_per_step"), prefix + "_frac": roof.get("frac"),
-           prefix + "_kernel": roof.get("kernel")}
-    passes = cfg.get("a_passes_per_step", cfg.get("A_passes_per_step"))
-    if passes is not None:
-        out[prefix + "_a_passes"] = passes
-    if isinstance(r.get("stepping"), dict):  # config 3: the reference-API stepping rate beside the in-library loop's
-        out[prefix + "_stepping_it_s"] = r["stepping"].get("value")
-        out[prefix + "_stepping_frac"] = (r["stepping"].get("roofline") or {}).get("frac")
+SHORT_LABELS = {"headline_adaptive": "adaptive", "config2": "cfg2", "config3": "cfg3", "config4": "cfg4",
+                "config5_column_block": "cfg5blk", "headline_row_block_n8": "row8", "rows_2proc_two_sweeps": "rows2p",
+                "rows_2proc_row_team": "rows2pteam", "rows_two_sweeps": "rows2s", "cols_strong": "cols", "rows_strong": "rows",
+                "config5_weak_rows": "cfg5rows", "config5_weak_cols": "cfg5cols", "rows_strong_teams": "teams",
+                "config5_weak_rows_teams": "cfg5teams"}
+
+
+def summary_string(records):
+    """Every further record of the line in ONE scalar string, `label=it/s@frac/reads-of-A` joined by `;` (config 3:
+    `cfg3=<in-library it/s>(step <stepped it/s>@frac)`; a failed record: `label=!<reason>`): the driver's BENCH_rNN.json keeps
+    about twenty scalar keys of `config` and nothing nested, so this is the form in which configs 2 / 3 / 4, the block shapes and
+    the other layouts reach it.  parse_summary_string is its inverse."""
+    parts = []
+    for label, r in records:
+        key = SHORT_LABELS.get(label, label)
+        if not isinstance(r, dict) or "value" not in r:
+            why = str((r or {}).get("error", "not measured")) if isinstance(r, dict) else "not measured"
+            parts.append("%s=!%s" % (key, "".join(ch if ch not in ";=@/()" else " " for ch in why)[:40].strip()))
+            continue
+        roof, cfg = r.get("roofline") or {}, r.get("config") or {}
+        frac = roof.get("frac")
+        passes = cfg.get("a_passes_per_step", cfg.get("A_passes_per_step"))
+        if isinstance(r.get("stepping"), dict):
+            st = r["stepping"]
+            txt = "%.6g(step %.6g@%s)" % (r["value"], st.get("value") or 0.0, _g3((st.get("roofline") or {}).get("frac")))
+        else:
+            txt = "%.6g@%s" % (r["value"], _g3(frac))
+            if passes is not None:
+                txt += "/%s" % _g3(passes)
+        parts.append("%s=%s" % (key, txt))
+    return ";".join(parts)
+
+
+def _g3(v):
+    return "?" if v is None else ("%.3g" % float(v))
+
+
+def parse_summary_string(text):
+    """{label: {"it_s", "frac", "a_passes"} | {"it_s", "stepping_it_s", "stepping_frac"} | {"error"}} of a summary_string"""
+    out = {}
+    for part in filter(None, text.split(";")):
+        key, _, val = part.partition("=")
+        if val.startswith("!"):
+            out[key] = {"error": val[1:]}
+        elif "(step " in val:
+            head, _, rest = val.partition("(step ")
+            st, _, fr = rest.rstrip(")").partition("@")
+            out[key] = {"it_s": float(head), "stepping_it_s": float(st), "stepping_frac": None if fr == "?" else float(fr)}
+        else:
+            its, _, rest = val.partition("@")
+            fr, _, ps = rest.partition("/")
+            out[key] = {"it_s": float(its), "frac": None if fr in ("", "?") else float(fr), "a_passes": None if ps in ("", "?") else float(ps)}
     return out
 
 
@@ -1138,6 +1188,7 @@ class Job:
     def __init__(self, args, world, rank):
         self.args, self.world, self.rank = args, world, rank
         self.main_rec, self.extra, self.cpu, self.meta = None, {}, None, {}
+        self.layout_note = {}  # N > 1, row blocks on top: {"row_layout": "row_teams" | "two_sweeps", "row_layout_reason": ...}
         self.json_fd = None
 
     def line(self, error=None, stage=None):
@@ -1148,26 +1199,29 @@ class Job:
             d["n_gpus"] = self.world
         else:
             r = self.main_rec
-            config = dict(r["config"])
+            src = dict(r["config"])
+            # scalars first, in the order of what a reader of the driver's record needs; nested values (dropped there) last
+            config = {k_: v for k_, v in src.items() if not isinstance(v, (dict, list))}
+            config.update(self.layout_note)
             also = self.extra.get("also")
-            if also is not None:  # the driver keeps `config` whole and drops unknown top-level keys
-                config["also_summary"] = {a.get("label", "?"): summary_row(a) for a in also}
-                for a in also:  # ... and, as round 3's record showed, nested values under `config` too: the same as flat scalars
-                    config.update(flat_summary("also_%s" % a.get("label", "?"), a))
-            subs = {k_: summary_row(v) for k_, v in self.extra.items() if k_ != "also" and isinstance(v, dict) and ("value" in v or "error" in v)}
+            if also is not None:
+                config["also"] = summary_string([(a.get("label", "?"), a) for a in also])
+            subs = [(k_, v) for k_, v in self.extra.items() if k_ != "also" and isinstance(v, dict) and ("value" in v or "error" in v)]
             if subs:
-                config["layouts_summary"] = subs
-                for k_, v in self.extra.items():
-                    if k_ != "also" and isinstance(v, dict) and ("value" in v or "error" in v):
-                        config.update(flat_summary("layout_%s" % k_, v))
+                config["layouts"] = summary_string(subs)
             if "sustained" in r:
                 config["sustained_it_s"] = r["sustained"]["value"]
+            if "in_library_loop" in r and "value" in r["in_library_loop"]:
+                config["in_library_loop_it_s"] = r["in_library_loop"]["value"]
+            config.update({k_: v for k_, v in src.items() if isinstance(v, (dict, list))})
+            if also is not None:
+                config["also_summary"] = {a.get("label", "?"): summary_row(a) for a in also}
+            if subs:
+                config["layouts_summary"] = {k_: summary_row(v) for k_, v in subs}
             d = {"metric": metric_name(args, self.world), "value": r["value"], "unit": "it/s", "n_gpus": self.world,
                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
                  "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": config,
                  "roofline": r["roofline"], "cpu_baseline": self.cpu}
-            if "in_library_loop" in r and "value" in r["in_library_loop"]:
-                config["in_library_loop_it_s"] = r["in_library_loop"]["value"]
             for k_ in ("ranks_seen_by_rccl", "collective", "sustained", "in_library_loop", "wall_s"):
                 if k_ in r:
                     d[k_] = r[k_]
@@ -1309,11 +1363,14 @@ def run_rank(args, job, wd, world, rank, local_rank):
     n = args.n or n
     m_glob = m_base * world if args.scaling == "weak" else m_base
     dtype = np.float32 if args.dtype == "f32" else np.float64
-    # N > 1: column blocks keep the single-sweep iteration on every GPU (one all-reduce of m + 8 N elements per
-    # iteration); row blocks (north_star's layout) iterate with two sweeps and all-reduce [grad ; f] (n + 1 elements)
+    # N > 1: ROW blocks are the contract (north_star): in this process group with two sweeps per iteration and
+    # the all-reduce of [grad ; f] (n + 1 elements) -- the form that needs nothing but RCCL -- and afterwards, in a process group
+    # of its own, as a row team (one read of A per iteration), which becomes the top-level record when it runs clean.  Column
+    # blocks (every GPU keeps the single sweep, one all-reduce of m + 8 (N + 1) elements) are a sub-record, labelled as not the
+    # contract layout.
     layout = args.sharding
     if layout == "auto":
-        layout = "cols" if D.sharded and args.sweeps == "one" and args.scaling == "strong" else "rows"
+        layout = "rows"
     if not D.sharded:
         layout = "none"
     named = args.workload if (args.m is None and args.n is None) else None
@@ -1378,7 +1435,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
             settle()
             try:
                 r = fn()
-            except (pa.ProxGradError, MemoryError, RuntimeError) as e:
+            except (pa.ProxGradError, MemoryError, RuntimeError, OSError, ValueError, subprocess.SubprocessError) as e:
                 r = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             r["label"] = label
             also.append(r)
@@ -1401,8 +1458,10 @@ def run_rank(args, job, wd, world, rank, local_rank):
         # process per rank, inboxes mapped through IPC handles): two sweeps + the all-reduce, then the same as a row TEAM (one read
         # of A per iteration, csrc/pg_gemv_tn4.hip).  Each runs as a CHILD job of its own (`bench.py --gpus 2 --share-device ...`).
         if dtype == np.float32:
-            also_record("rows_2proc_two_sweeps", lambda: shared_device_rows_record(4096, 1 << 20, False, sub_steps, wd.beat))
-            also_record("rows_2proc_row_team", lambda: shared_device_rows_record(4096, 1 << 20, True, sub_steps, wd.beat))
+            # (the child's own limit + the kill margin + the settle wait stay below the stage's deadline)
+            t_child = max(30.0, args.sub_record_timeout - 45.0)
+            also_record("rows_2proc_two_sweeps", lambda: shared_device_rows_record(4096, 1 << 20, False, sub_steps, wd.beat, timeout=t_child))
+            also_record("rows_2proc_row_team", lambda: shared_device_rows_record(4096, 1 << 20, True, sub_steps, wd.beat, timeout=t_child))
         if settled[0] > 0:
             extra["also_settle_s"] = round(settled[0], 2)
     elif world > 1:
@@ -1433,18 +1492,38 @@ def run_rank(args, job, wd, world, rank, local_rank):
                 extra[key] = {"error": str(e)[:300]}
             extra[key]["wall_s"] = round(time.perf_counter() - t_sub, 2)
 
+        if layout == "rows":
+            job.layout_note = {"row_layout": "row_teams" if args.row_teams else "two_sweeps",
+                               "row_layout_reason": "--row-teams: the top-level record itself ran as a row team" if args.row_teams else
+                               "the row-team upgrade has not run yet"}
         if args.scaling == "strong":
-            # the same global problem in the other layout (row blocks = north_star's contract)
+            # the same global problem in the other layout (column blocks: not the contract layout)
             extra_record("%s_strong" % other, m_base, other, "strong")
+            if other == "cols" and isinstance(extra.get("cols_strong"), dict) and "config" in extra["cols_strong"]:
+                extra["cols_strong"]["config"]["note"] = "not the contract layout (north_star prescribes row blocks): reported beside it"
         # BASELINE config 5 and its twins: m_base rows PER GPU (131072 x 2^20 at N = 8), both layouts
         for lay in ("rows", "cols"):
             if args.scaling == "weak" and lay == layout:
                 continue
             extra_record("config5_weak_%s" % lay, m_base * world, lay, "weak")
-        # north_star's row layout at ONE read of A per iteration (row teams).  Last: never run on real xGMI before the first
-        # SCALE collection, and a record that fails or times out here costs none of the ones above.
-        if not args.no_row_teams:
+        # north_star's row layout at ONE read of A per iteration (row teams), in a process group of its own: it has never run on
+        # real xGMI before the first SCALE collection, and whatever happens in there costs none of the records above.  Its record
+        # of the top-level problem, run for the same K steps, REPLACES the two-sweep record on top when it is clean.
+        why_not = None
+        if args.no_row_teams:
+            why_not = "--no-row-teams"
+        elif layout != "rows" or args.row_teams:
+            why_not = "the top-level record is not the two-sweep row layout"
+        elif args.share_device and world > 4:
+            # (profiles/r4_row_team_one_gpu.md: five and more processes on one device are time-sliced, their kernels are not all
+            # resident, every wave polls -- ~1 it/s; a one-GPU rehearsal artefact, no configuration anyone runs)
+            why_not = "more than four rank processes share one device: their sweeps would be time-sliced, not co-resident"
+        if why_not is None:
             row_team_records_in_a_child(args, job, wd, ctx, world, rank)
+            if rank == 0:
+                promote_row_team_record(args, job)
+        elif layout == "rows" and not args.row_teams:
+            job.layout_note = {"row_layout": "two_sweeps", "row_layout_reason": "row teams not tried: " + why_not}
 
     if rank == 0 and job.cpu is None and world == 1 and not args.no_cpu_baseline and P is not None:
         wd.enter("cpu_baseline", 600.0, stall=False)
@@ -1463,7 +1542,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
     return 0
 
 
-def shared_device_rows_record(m, n, teams, steps, beat=lambda: None, timeout=200.0):
+def shared_device_rows_record(m, n, teams, steps, beat=lambda: None, timeout=170.0):
     """an N = 1 `also` record: `bench.py --gpus 2 --share-device --backend gloo --sharding rows [--row-teams]` as a child job
     (its own launcher, two rank processes on this one device, gloo for the set-up collectives) and what its line says"""
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "2", "--share-device", "--backend", "gloo", "--sharding", "rows", "--m", str(m),
@@ -1473,12 +1552,27 @@ def shared_device_rows_record(m, n, teams, steps, beat=lambda: None, timeout=200
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PG_BENCH_ARGV")
            and not k_.startswith("TORCHELASTIC_")}
     beat()
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout + 30.0, env=env)
-    beat()
-    line = _find_line(out.stdout)
-    if line is None:
-        return {"error": "the two-process child printed no line (exit code %d)" % out.returncode, "stderr_tail": out.stderr.splitlines()[-4:]}
-    d = json.loads(line)
+    # Whatever the child does -- no line, a broken line, a hang -- this is an EXTRA record: it returns {"error": ...} and the
+    # headline line stands (TimeoutExpired / ValueError / OSError escaped to main() and turned a measured line into a
+    # failure; and subprocess.run's timeout killed the launcher only, leaving the rank processes on the GPU).
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        try:
+            out_s, err_s = proc.communicate(timeout=timeout + 15.0)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)  # the launcher AND its ranks (one session)
+            except ProcessLookupError:
+                pass
+            out_s, err_s = proc.communicate()
+            return {"error": "the two-process child did not finish within %.0f s" % (timeout + 15.0)}
+        beat()
+        line = _find_line(out_s)
+        if line is None:
+            return {"error": "the two-process child printed no line (exit code %d)" % proc.returncode, "stderr_tail": err_s.splitlines()[-4:]}
+        d = json.loads(line)
+    except Exception as e:  # noqa: BLE001
+        return {"error": "the two-process child failed: %s: %s" % (type(e).__name__, str(e)[:200])}
     if d.get("value") is None:
         return {"error": "child: %s (stage %s)" % (d.get("error"), d.get("stage"))}
     cfg = d.get("config") or {}
@@ -1499,6 +1593,45 @@ def shared_device_rows_record(m, n, teams, steps, beat=lambda: None, timeout=200
 ROW_TEAM_RECORDS = (("rows_strong_teams", "strong"), ("config5_weak_rows_teams", "weak"))
 
 
+def row_team_record_is_clean(r):
+    """(ok, reason): may this row-team record stand as the top-level record?  It must have been measured, as a row team, with the
+    attach-time scalar exchange right on EVERY rank, one read of the block per step and no sweep redone with two."""
+    if not isinstance(r, dict) or "value" not in r:
+        return False, "the row-team record was not measured: %s" % str((r or {}).get("error", "no record"))[:160]
+    cfg = r.get("config") or {}
+    if not cfg.get("row_teams"):
+        return False, "the record did not run as a row team"
+    if cfg.get("row_team_selftest_all_ranks") is not True:
+        return False, "the attach-time self-test of the inboxes failed on some rank (rank 0: %s)" % cfg.get("row_team_selftest")
+    if cfg.get("sweep_fallbacks"):
+        return False, "%d step(s) of the row-team run fell back to two sweeps (a bounded wait expired)" % cfg["sweep_fallbacks"]
+    passes = cfg.get("a_passes_per_step")
+    if passes is None or passes > 1.05:
+        return False, "the row-team run read its block %.2f times per step" % (passes or 0.0)
+    return True, "self-test ok on every rank, %d steps at %.2f reads of the block per step, no fallback" % (r.get("steps", 0), passes)
+
+
+def promote_row_team_record(args, job):
+    """The contract layout's top-level record: the row-team record of the SAME problem and the same K steps when it is clean
+    (row_team_record_is_clean), else the two-sweep record measured in this process group; `config.row_layout` /
+    `config.row_layout_reason` say which and why, and after an upgrade the two-sweep record stays in the line as
+    `rows_two_sweeps`."""
+    key = "rows_strong_teams" if args.scaling == "strong" else "config5_weak_rows_teams"
+    cand = job.extra.get(key)
+    ok, why = row_team_record_is_clean(cand)
+    if ok and cand.get("steps") != args.steps:
+        ok, why = False, "the row-team record ran %s steps, not the line's %d" % (cand.get("steps"), args.steps)
+    if not ok:
+        job.layout_note = {"row_layout": "two_sweeps", "row_layout_reason": why}
+        return False
+    two = job.main_rec
+    job.extra = dict([("rows_two_sweeps", two)] + [(k_, v) for k_, v in job.extra.items() if k_ != key])
+    job.main_rec = cand
+    job.layout_note = {"row_layout": "row_teams", "row_layout_reason": why,
+                       "rows_two_sweeps_it_s": two.get("value")}
+    return True
+
+
 def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
     """`--row-teams-child`: the two row-team records (north_star's row layout at ONE read of A per iteration: the ranks push
     per-column partial dots into each other's IPC-mapped inbox inside the sweep, csrc/pg_gemv_tn4.hip) in a process group of
@@ -1510,11 +1643,15 @@ def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
     records = {}
     sub_steps = max(4, min(args.steps, 20))
     for key, scaling in ROW_TEAM_RECORDS:
-        wd.enter(key, args.sub_record_timeout)
+        # the record of the line's own top-level problem runs the line's K steps after W warm-up steps (it may become the
+        # top-level record: promote_row_team_record), the other one the short form of every sub-record
+        top = scaling == args.scaling
+        wd.enter(key, (args.record_timeout if top else args.sub_record_timeout))
         t_sub = time.perf_counter()
         try:
             P2 = setup_lasso(pa, ctx, D, m_base * world if scaling == "weak" else m_base, n, dtype, args.seed, "rows", "fixed", row_teams=True)
-            records[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", sub_steps, 3, args.kernel_events, scaling=scaling)
+            records[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", args.steps if top else sub_steps, args.warmup if top else 3,
+                                   args.kernel_events, scaling=scaling)
             del P2
         except Exception as e:  # noqa: BLE001 -- reported in the record; the ranks may be out of step now, so the other one is skipped
             traceback.print_exc()
@@ -1547,7 +1684,7 @@ def row_team_records_in_a_child(args, job, wd, ctx, world, rank):
 
     gc.collect()
     ctx.sync()
-    budget = 2.0 * args.sub_record_timeout + args.init_timeout + 60.0
+    budget = args.record_timeout + args.sub_record_timeout + args.init_timeout + 60.0
     wd.enter("row_teams_child", budget + 30.0, stall=False)
     t0 = time.perf_counter()
     # the child ranks rendezvous on a store of their own: not the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE would make

@@ -433,7 +433,7 @@ pg_status launch_tnc(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 
 #include "pg_gemv_tnt.h"  // gemv_tnt_kernel: the team sweep (shared with pg_gemv_tn4.hip)
 
-template <typename T, int U, int C, int LAG, int PF, int WAVES, int LAGR = 0, int OPT = 0>
+template <typename T, int U, int C, int LAG, int PF, int WAVES, int LAGR = 0>
 pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   pg_ctx* c = A->ctx;
   constexpr int G = (int)sizeof(T) / 4;
@@ -514,7 +514,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // LDS for the parked tiles: LAG slots of WAVES * C * U KiB on top of the kernel's static LDS (the dot exchange and the grid
   // reduction's scratch); anything beyond the default 64 KiB limit is opted into once per device
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
-  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, false, LAGR, false, OPT>);
+  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, false, LAGR>);
   if (lds + 4096 > 64 * 1024) {
     static std::mutex mu;
     static bool opted_in[64] = {};
@@ -542,7 +542,7 @@ pg_status launch_tnt(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   if (c->team_plain_launch || c->capturing) {  // (stream capture records plain launches only)
-    hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, false, LAGR, false, OPT>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+    hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, false, LAGR>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
     PG_LAUNCH_CHECK();
     return PG_OK;
   }
@@ -712,18 +712,13 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int C = env_int("PG_TNT_C", U == 4 ? 2 : 1), LAG = env_int("PG_TNT_LAG", 2);
   // tiles in flight ahead of the one being consumed
   const int PF = env_int("PG_TNT_PF", U == 4 ? 1 : 2);
-  const int LAGR = env_int("PG_TNT_LAGR", 0), OPT = env_int("PG_TNT_OPT", 0);  // lag tiles in registers; poll-ahead / barrier-free dots (pg_gemv_tnt.h)
-#define PG_TNT_CASE_X(UU, CC, LL, PP, WW, RR, OO) \
-  if (U == UU && C == CC && LAG == LL && PF == PP && W == WW && LAGR == RR && OPT == OO) return launch_tnt<T, UU, CC, LL, PP, WW, RR, OO>(A, a, blocks_out)
-#define PG_TNT_CASE(UU, CC, LL, PP, WW) PG_TNT_CASE_X(UU, CC, LL, PP, WW, 0, 0)
-  if constexpr (sizeof(T) == 4) {  // round 5 experiments on the full member
-    PG_TNT_CASE_X(16, 1, 2, 2, 4, 0, 1);
-    PG_TNT_CASE_X(16, 1, 2, 2, 4, 0, 2);
-    PG_TNT_CASE_X(16, 1, 2, 2, 4, 0, 3);
-    PG_TNT_CASE_X(16, 1, 2, 2, 4, 1, 0);
-    PG_TNT_CASE_X(16, 1, 2, 2, 4, 1, 3);
-    PG_TNT_CASE_X(16, 1, 2, 2, 4, 2, 3);
-    PG_TNT_CASE_X(16, 1, 2, 2, 4, 1, 2);
+  const int LAGR = env_int("PG_TNT_LAGR", 0);  // lag tiles in registers (pg_gemv_tnt.h; measured +0.2 % at 131072 rows: not the default here)
+#define PG_TNT_CASE_X(UU, CC, LL, PP, WW, RR) \
+  if (U == UU && C == CC && LAG == LL && PF == PP && W == WW && LAGR == RR) return launch_tnt<T, UU, CC, LL, PP, WW, RR>(A, a, blocks_out)
+#define PG_TNT_CASE(UU, CC, LL, PP, WW) PG_TNT_CASE_X(UU, CC, LL, PP, WW, 0)
+  if constexpr (sizeof(T) == 4) {
+    PG_TNT_CASE_X(16, 1, 2, 2, 4, 1);
+    PG_TNT_CASE_X(16, 1, 0, 2, 4, 2);  // no LDS round trip at all: the two waiting tiles stay in registers
   }
   PG_TNT_CASE(16, 1, 2, 2, 4);
   PG_TNT_CASE(15, 1, 2, 2, 4);
@@ -742,7 +737,7 @@ pg_status launch_tn_team(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TNT_CASE(4, 2, 2, 1, 8);
 #undef PG_TNT_CASE
 #undef PG_TNT_CASE_X
-  pg_set_error("no gemv_tnt instantiation for WAVES=%d U=%d C=%d LAG=%d PF=%d LAGR=%d OPT=%d", W, U, C, LAG, PF, LAGR, OPT);
+  pg_set_error("no gemv_tnt instantiation for WAVES=%d U=%d C=%d LAG=%d PF=%d LAGR=%d", W, U, C, LAG, PF, LAGR);
   return PG_ERR_UNSUPPORTED;
 }
 

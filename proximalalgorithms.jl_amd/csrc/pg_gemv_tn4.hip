@@ -107,9 +107,8 @@ pg_status grow_partials_without_free(pg_mat* A, int S) {
   return PG_OK;
 }
 
-template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int OPT = 0>
+template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int WAVES = 4>
 pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
-  constexpr int WAVES = 4;
   constexpr int G = (int)sizeof(T) / 4;
   static_assert(C * G <= 8, "the inbox holds eight granules per member and step");
   pg_ctx* c = A->ctx;
@@ -167,7 +166,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   // and nothing of the previous launch is still in flight, because ITS scalar exchange has completed everywhere.  All devices
   // see the change at the same launch (same sequence of calls), so the extra exchange pairs up.
   const unsigned long long sig = ((unsigned long long)nteams << 32) | ((unsigned long long)C << 24) | ((unsigned long long)G << 16) |
-                                 ((unsigned long long)(LAG + LAGR) << 8) | ((unsigned long long)(DELAY ? 1 : 0) << 15) | ((unsigned long long)(OPT & 1) << 14) | (unsigned long long)rt.n;
+                                 ((unsigned long long)(LAG + LAGR) << 8) | ((unsigned long long)(DELAY ? 1 : 0) << 15) | (unsigned long long)rt.n;
   if (sig != c->rteam.ring_sig) {
     PG_HIP(hipMemsetAsync(rt.inbox[rt.rank], 0, PEER_RING_BYTES, c->stream));
     PG_TRY(peer_scalar_exchange(c, c->rteam.f_local, c->rteam.f_local));
@@ -178,7 +177,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   a.tag_base = c->rteam.epoch << 24;
   *blocks_out = (int)nteams;
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
-  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY, OPT>);
+  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>);
   if (lds + 4096 > 64 * 1024) {
     static std::mutex mu;
     static bool opted_in[64] = {};
@@ -199,7 +198,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead
-  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY, OPT>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -210,31 +209,32 @@ bool tn_peer_covers(int nrg) { return nrg >= 1 && nrg <= 64; }
 
 namespace {
 struct PeerGeom {
-  int C, LAG, LAGR, PF, WGS, OPT;
+  int C, LAG, LAGR, PF, WGS, W, U;
 };
-// Float32 geometries of the row-team sweep by row groups per wave (profiles/r5_row_team_latency_sweep.md)
-PeerGeom peer_geometry_f32(int U) {
-  if (U <= 4) return {2, 2, 0, 2, 0, 0};
-  return {1, 2, 0, 2, 0, 0};
+// Float32 geometries of the row-team sweep by the team's longest block in row groups (profiles/r5_row_team_latency_sweep.md)
+PeerGeom peer_geometry_f32(int nrg) {
+  const int U = (nrg + 3) / 4 < 2 ? 2 : (nrg + 3) / 4;
+  if (U <= 4) return {2, 2, 0, 2, 0, 4, U};
+  return {1, 2, 0, 2, 0, 4, U};
 }
 }  // namespace
 
-// every Float32 instantiation: (U, C, LAG, PF, LAGR); _D: also with the latency injector
+// every Float32 instantiation: (U, C, LAG, PF, LAGR, W); _D: also with the latency injector
 #define PG_TNP_F32_GEOMETRIES \
-  PG_TNP_CASE_D(2, 2, 2, 2, 0, 0); PG_TNP_CASE_D(2, 2, 2, 2, 0, 1); PG_TNP_CASE_D(2, 2, 2, 2, 0, 2); \
-  PG_TNP_CASE_D(2, 2, 2, 2, 0, 3); PG_TNP_CASE_D(2, 2, 2, 2, 1, 3); PG_TNP_CASE_D(2, 2, 3, 2, 2, 0); \
-  PG_TNP_CASE_D(2, 2, 3, 2, 3, 0); PG_TNP_CASE_D(2, 2, 3, 2, 3, 3); PG_TNP_CASE_D(2, 4, 2, 2, 0, 0); \
-  PG_TNP_CASE_D(2, 4, 2, 2, 2, 0); PG_TNP_CASE_D(2, 4, 2, 2, 2, 3); PG_TNP_CASE_D(2, 4, 2, 2, 0, 3); \
-  PG_TNP_CASE_D(4, 2, 2, 2, 0, 0); PG_TNP_CASE_D(4, 2, 2, 2, 0, 3); PG_TNP_CASE_D(4, 2, 2, 2, 1, 0); \
-  PG_TNP_CASE_D(4, 2, 2, 2, 1, 3); PG_TNP_CASE_D(4, 2, 2, 2, 2, 0); PG_TNP_CASE_D(4, 1, 2, 2, 0, 0); \
-  PG_TNP_CASE_D(4, 1, 3, 2, 2, 0); PG_TNP_CASE_D(8, 1, 2, 2, 0, 0); PG_TNP_CASE_D(8, 1, 2, 2, 0, 3); \
-  PG_TNP_CASE_D(8, 1, 2, 2, 1, 0); PG_TNP_CASE_D(8, 1, 2, 2, 1, 3); PG_TNP_CASE_D(16, 1, 2, 2, 0, 0); \
-  PG_TNP_CASE_D(16, 1, 2, 2, 0, 3); PG_TNP_CASE_D(16, 1, 2, 2, 1, 0); PG_TNP_CASE_D(16, 1, 2, 2, 1, 3); \
-  PG_TNP_CASE_D(16, 1, 2, 2, 2, 0); PG_TNP_CASE_D(16, 1, 2, 2, 2, 3); \
-  PG_TNP_CASE(3, 2, 2, 2, 0, 0); PG_TNP_CASE(5, 1, 2, 2, 0, 0); PG_TNP_CASE(6, 1, 2, 2, 0, 0); PG_TNP_CASE(7, 1, 2, 2, 0, 0); PG_TNP_CASE(9, 1, 2, 2, 0, 0); PG_TNP_CASE(10, 1, 2, 2, 0, 0); \
-  PG_TNP_CASE(11, 1, 2, 2, 0, 0); PG_TNP_CASE(12, 1, 2, 2, 0, 0); PG_TNP_CASE(13, 1, 2, 2, 0, 0); PG_TNP_CASE(14, 1, 2, 2, 0, 0); PG_TNP_CASE(15, 1, 2, 2, 0, 0)
+  PG_TNP_CASE_D(2, 2, 2, 2, 0, 4); PG_TNP_CASE_D(2, 2, 3, 2, 2, 4); PG_TNP_CASE_D(2, 2, 3, 2, 3, 4); \
+  PG_TNP_CASE_D(2, 4, 2, 2, 0, 4); PG_TNP_CASE_D(2, 4, 2, 2, 2, 4); PG_TNP_CASE_D(4, 2, 2, 2, 0, 4); \
+  PG_TNP_CASE_D(4, 2, 2, 2, 1, 4); PG_TNP_CASE_D(4, 2, 2, 2, 2, 4); PG_TNP_CASE_D(4, 1, 2, 2, 0, 4); \
+  PG_TNP_CASE_D(4, 1, 3, 2, 2, 4); PG_TNP_CASE_D(8, 1, 2, 2, 0, 4); PG_TNP_CASE_D(8, 1, 2, 2, 1, 4); \
+  PG_TNP_CASE_D(16, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 1, 4); PG_TNP_CASE_D(16, 1, 2, 2, 2, 4); \
+  PG_TNP_CASE_D(16, 1, 0, 2, 2, 4); PG_TNP_CASE_D(8, 2, 2, 2, 0, 1); PG_TNP_CASE_D(8, 2, 2, 2, 1, 1); \
+  PG_TNP_CASE_D(8, 2, 2, 2, 2, 1); PG_TNP_CASE_D(8, 2, 2, 2, 3, 1); PG_TNP_CASE_D(8, 2, 2, 1, 2, 1); \
+  PG_TNP_CASE_D(16, 1, 2, 2, 0, 1); PG_TNP_CASE_D(16, 1, 2, 2, 1, 1); \
+  PG_TNP_CASE_D(16, 1, 2, 2, 2, 1); PG_TNP_CASE_D(8, 2, 2, 2, 0, 2); PG_TNP_CASE_D(8, 2, 2, 2, 2, 2); \
+  PG_TNP_CASE_D(16, 1, 2, 2, 0, 2); PG_TNP_CASE_D(16, 1, 2, 2, 1, 2); PG_TNP_CASE_D(16, 1, 2, 2, 2, 2); \
+  PG_TNP_CASE(3, 2, 2, 2, 0, 4); PG_TNP_CASE(5, 1, 2, 2, 0, 4); PG_TNP_CASE(6, 1, 2, 2, 0, 4); PG_TNP_CASE(7, 1, 2, 2, 0, 4); PG_TNP_CASE(9, 1, 2, 2, 0, 4); PG_TNP_CASE(10, 1, 2, 2, 0, 4); \
+  PG_TNP_CASE(11, 1, 2, 2, 0, 4); PG_TNP_CASE(12, 1, 2, 2, 0, 4); PG_TNP_CASE(13, 1, 2, 2, 0, 4); PG_TNP_CASE(14, 1, 2, 2, 0, 4); PG_TNP_CASE(15, 1, 2, 2, 0, 4)
 
-// Tunables (environment, for experiments): PG_TNP_C, PG_TNP_LAG.
+// Tunables (environment, under PG_TUNE, for experiments): PG_TNP_W, PG_TNP_C, PG_TNP_LAG, PG_TNP_LAGR, PG_TNP_PF, PG_TNP_WGS.
 template <typename T>
 pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // One tile (C columns of this device's rows) per step and workgroup is 16 KiB on 2048-row blocks, 32 KiB on 4096 / 8192 rows,
@@ -251,48 +251,42 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     return PG_ERR_UNSUPPORTED;
   }
   const int team_nrg = A->team_nrg;
-  const int per_wave = (team_nrg + 3) / 4;
-  // U fits the longest block exactly (3, 5 .. 7, 9 .. 15 beside the powers of two): a block one row past 2048 rows is three row
-  // groups per wave, not four -- 2 x 2049 rows streamed 4.0 TB/s in the next power of two's geometry where 2 x 2048 stream 5.9
-  // (PG_TNP_EXACT=0 under PG_TUNE: the powers of two only, for A/B runs)
-  int U = per_wave < 2 ? 2 : per_wave;
+  // Geometry by the team's longest block: waves per workgroup W (the rows of a column are split over them), row groups per wave
+  // U = ceil(row groups / W) EXACTLY (3, 5 .. 7, 9 .. 15 beside the powers of two: a block one row past 2048 rows is three row
+  // groups per wave, not four -- 2 x 2049 rows streamed 4.0 TB/s in the next power of two's geometry where 2 x 2048 stream 5.9;
+  // PG_TNP_EXACT=0 under PG_TUNE: the powers of two only, for A/B runs), columns per step C, lag steps in LDS (LAG) and in
+  // registers (LAGR), tiles in flight (PF), workgroups per compute unit (0: as many as the parked tiles leave LDS for).
+  // Float64 keeps round 4's geometries (its values take two granules and twice the registers per row group).
+  PeerGeom g = {(team_nrg + 3) / 4 >= 5 ? 1 : 2, 2, 0, 2, 0, 4};
+  if constexpr (sizeof(T) == 4) g = peer_geometry_f32(team_nrg);
+  const int W = env_int("PG_TNP_W", g.W);
+  const int per_wave = (team_nrg + W - 1) / W;
+  int U = per_wave < 2 && W == 4 ? 2 : per_wave;
   if (env_int("PG_TNP_EXACT", 1) == 0) {
     U = 2;
     while (U < per_wave) U *= 2;
   }
-  // Geometry by U: columns per step C, lag steps in LDS (LAG) and in registers (LAGR), tiles in flight (PF), workgroups per
-  // compute unit (0: as many as the parked tiles leave LDS for).  Float64 keeps round 4's geometries (its values take two
-  // granules and twice the registers per row group).
-  int C = U >= 5 ? 1 : 2, LAG = 2, LAGR = 0, PF = 2, WGS = 0;
-  if constexpr (sizeof(T) == 4) {
-    const PeerGeom g = peer_geometry_f32(U);
-    C = g.C, LAG = g.LAG, LAGR = g.LAGR, PF = g.PF, WGS = g.WGS;
-  }
-  C = env_int("PG_TNP_C", C);
-  LAG = env_int("PG_TNP_LAG", LAG);
-  LAGR = env_int("PG_TNP_LAGR", LAGR);
-  PF = env_int("PG_TNP_PF", PF);
-  WGS = env_int("PG_TNP_WGS", WGS);
-  const int OPT = env_int("PG_TNP_OPT", sizeof(T) == 4 ? peer_geometry_f32(U).OPT : 0);
+  const int C = env_int("PG_TNP_C", g.C), LAG = env_int("PG_TNP_LAG", g.LAG), LAGR = env_int("PG_TNP_LAGR", g.LAGR);
+  const int PF = env_int("PG_TNP_PF", g.PF), WGS = env_int("PG_TNP_WGS", g.WGS);
   const bool delay = c->test_team_delay_on;
-#define PG_TNP_CASE(UU, CC, LL, PP, RR, OO)                                                             \
-  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && OPT == OO && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, OO>(A, a, blocks_out, WGS)
-#define PG_TNP_CASE_D(UU, CC, LL, PP, RR, OO)                                                           \
-  PG_TNP_CASE(UU, CC, LL, PP, RR, OO);                                                                  \
-  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && OPT == OO && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, OO>(A, a, blocks_out, WGS)
+#define PG_TNP_CASE(UU, CC, LL, PP, RR, WW)                                                             \
+  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, WW>(A, a, blocks_out, WGS)
+#define PG_TNP_CASE_D(UU, CC, LL, PP, RR, WW)                                                           \
+  PG_TNP_CASE(UU, CC, LL, PP, RR, WW);                                                                  \
+  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, WW>(A, a, blocks_out, WGS)
   if constexpr (sizeof(T) == 4) {
     PG_TNP_F32_GEOMETRIES;
   } else {
-    PG_TNP_CASE(2, 4, 4, 2, 0, 0); PG_TNP_CASE(4, 2, 4, 2, 0, 0); PG_TNP_CASE(8, 1, 4, 2, 0, 0); PG_TNP_CASE(16, 1, 2, 2, 0, 0);
-    PG_TNP_CASE(2, 4, 2, 2, 0, 0); PG_TNP_CASE(8, 1, 2, 2, 0, 0); PG_TNP_CASE(4, 2, 2, 2, 0, 0); PG_TNP_CASE(2, 2, 2, 2, 0, 0);
-    PG_TNP_CASE(4, 1, 2, 2, 0, 0); PG_TNP_CASE(3, 2, 2, 2, 0, 0);
-    PG_TNP_CASE(5, 1, 2, 2, 0, 0); PG_TNP_CASE(6, 1, 2, 2, 0, 0); PG_TNP_CASE(7, 1, 2, 2, 0, 0);
-    PG_TNP_CASE(9, 1, 2, 2, 0, 0); PG_TNP_CASE(10, 1, 2, 2, 0, 0); PG_TNP_CASE(11, 1, 2, 2, 0, 0); PG_TNP_CASE(12, 1, 2, 2, 0, 0);
-    PG_TNP_CASE(13, 1, 2, 2, 0, 0); PG_TNP_CASE(14, 1, 2, 2, 0, 0); PG_TNP_CASE(15, 1, 2, 2, 0, 0);
+    PG_TNP_CASE(2, 4, 4, 2, 0, 4); PG_TNP_CASE(4, 2, 4, 2, 0, 4); PG_TNP_CASE(8, 1, 4, 2, 0, 4); PG_TNP_CASE(16, 1, 2, 2, 0, 4);
+    PG_TNP_CASE(2, 4, 2, 2, 0, 4); PG_TNP_CASE(8, 1, 2, 2, 0, 4); PG_TNP_CASE(4, 2, 2, 2, 0, 4); PG_TNP_CASE(2, 2, 2, 2, 0, 4);
+    PG_TNP_CASE(4, 1, 2, 2, 0, 4); PG_TNP_CASE(3, 2, 2, 2, 0, 4);
+    PG_TNP_CASE(5, 1, 2, 2, 0, 4); PG_TNP_CASE(6, 1, 2, 2, 0, 4); PG_TNP_CASE(7, 1, 2, 2, 0, 4);
+    PG_TNP_CASE(9, 1, 2, 2, 0, 4); PG_TNP_CASE(10, 1, 2, 2, 0, 4); PG_TNP_CASE(11, 1, 2, 2, 0, 4); PG_TNP_CASE(12, 1, 2, 2, 0, 4);
+    PG_TNP_CASE(13, 1, 2, 2, 0, 4); PG_TNP_CASE(14, 1, 2, 2, 0, 4); PG_TNP_CASE(15, 1, 2, 2, 0, 4);
   }
 #undef PG_TNP_CASE
 #undef PG_TNP_CASE_D
-  pg_set_error("no row-team instantiation for U=%d C=%d LAG=%d PF=%d LAGR=%d OPT=%d%s", U, C, LAG, PF, LAGR, OPT, delay ? " with the latency injector" : "");
+  pg_set_error("no row-team instantiation for W=%d U=%d C=%d LAG=%d PF=%d LAGR=%d%s", W, U, C, LAG, PF, LAGR, delay ? " with the latency injector" : "");
   return PG_ERR_UNSUPPORTED;
 }
 template pg_status launch_tn_peer<float>(pg_mat*, TNArgs<float>&, int*);

@@ -64,17 +64,9 @@ struct Pending {
 // thus max(on-chip hand-off, a.delay_ticks), not their sum, and nobody is held up who would not have been by a real hop of
 // that length: the sender does not wait, the stamp travels with the data.
 //
-// OPT & 1, AHEAD: the poll of a step's granules (and the fetch of its x_j / z_old_j) is issued ONE STEP BEFORE they are used, so
-// that its round trip through the memory pipeline -- which is full of tile loads -- overlaps a whole step instead of the dot
-// products only.  The granules must then have arrived one step earlier to be found at the first look (a later arrival is found
-// by the retry at the point of use, as before): one step of lag is traded for a wave that does not wait for its own poll.
-//
-// OPT & 2, NOBAR: no workgroup barrier per step.  The waves leave their partial dots in an LDS ring, tagged with the step; the
-// POSTER of step i -- wave i mod WAVES, so the role rotates -- waits for the other waves' tags, sums in wave order and posts the
-// granules; everybody else goes on to the totals of step i - LT at once.  A wave can be at most LT steps ahead of the slowest
-// (it needs totals that the slowest has not contributed to yet), so a ring of LT + 1 <= 8 entries is never overwritten unread.
-// With the barrier every step ran at the pace of the workgroup's slowest wave.
-template <typename T, int U, int C, int WAVES, int LAG, int PF = 1, bool PEER = false, int LAGR = 0, bool DELAY = false, int OPT = 0>
+// Tried on top and not kept (profiles/r5_team_options_not_kept.md): polling a step ahead (-17 %), a barrier-free dot exchange
+// through a tagged LDS ring with a rotating poster (+0.4 %).
+template <typename T, int U, int C, int WAVES, int LAG, int PF = 1, bool PEER = false, int LAGR = 0, bool DELAY = false>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -85,18 +77,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   static_assert(2 * LT + 2 <= RING, "granule ring too short for this lag");
   static_assert(PEER || TEAM_MAX * C * G <= 64, "one lane per granule of a step");  // (PEER: peer_n * C * G <= 64, checked at launch)
   static_assert(!DELAY || PEER, "the latency injector belongs to the row-team sweep");
-  constexpr bool AHEAD = (OPT & 1) != 0, NOBAR = (OPT & 2) != 0;
-  static_assert(!AHEAD || LT >= 2, "a poll issued one step ahead needs two steps of lag");
-  static_assert((WAVES & (WAVES - 1)) == 0, "the poster's role rotates over a power of two of waves");
-  constexpr int DQ = NOBAR ? 8 : 2;  // entries of the dot ring (NOBAR: >= LT + 1; with the barrier: two, alternating)
-  static_assert(!NOBAR || LT + 1 <= DQ, "dot ring too short for this lag");
-  using DBits = typename std::conditional<G == 1, unsigned, unsigned long long>::type;
-  __shared__ DBits sm_dot[DQ][C][WAVES];
-  __shared__ unsigned sm_tag[DQ][WAVES];  // NOBAR: step + 1 of the entry wave w left last
-  if constexpr (NOBAR) {  // (LDS keeps what the previous workgroup on this compute unit left: a stale tag could pass for a fresh one)
-    if ((int)threadIdx.x < DQ * WAVES) (&sm_tag[0][0])[threadIdx.x] = 0u;
-    __syncthreads();
-  }
+  __shared__ T sm_dot[2][C][WAVES];
   extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
   V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][WAVES][C][U][64]
   const int lane = threadIdx.x & (WAVE - 1);
@@ -164,7 +145,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   };
   // this member's partial dots of step i -> ring
   auto dot_post = [&](const Tile& t, int64_t i) __attribute__((always_inline)) {
-    const int buf = (int)(i & (DQ - 1));
+    const int buf = (int)(i & 1);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       T d = T(0);
@@ -174,41 +155,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         for (int e = 0; e < VEC; ++e) d = fma(t.col[c][u][e], rk[u][e], d);
       }
       d = wave_allsum(d);
-      if (lane == 0) {
-        if constexpr (NOBAR) __hip_atomic_store(&sm_dot[buf][c][wave], __builtin_bit_cast(DBits, d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else sm_dot[buf][c][wave] = __builtin_bit_cast(DBits, d);
-      }
+      if (lane == 0) sm_dot[buf][c][wave] = d;
     }
-    bool poster = wave == 0;
-    if constexpr (NOBAR) {
-      if (lane == 0) __hip_atomic_store(&sm_tag[buf][wave], (unsigned)(i + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      poster = wave == (int)(i & (WAVES - 1));
-      if (poster) {  // wait for the other waves' dots of this step (they are at most LT steps behind: bounded, and only on LDS)
-        const unsigned* tg = &sm_tag[buf][lane & (WAVES - 1)];
-        long long spins = 0;
-        while (!dead && __builtin_amdgcn_ballot_w64(__hip_atomic_load(tg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(i + 1)) != ~0ull) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > 8 * TEAM_SPIN_LIMIT) {
-            dead = true;
-            if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      }
-    } else {
-      __syncthreads();
-    }
-    if (poster && lane < C * G + (DELAY ? 1 : 0)) {
+    if constexpr (WAVES > 1) __syncthreads();  // (a one-wave workgroup reads back what it wrote itself: program order)
+    if (wave == 0 && lane < C * G + (DELAY ? 1 : 0)) {
       T mine = T(0);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        T s = T(0);
+        T s = sm_dot[buf][c][0];
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-          DBits b;
-          if constexpr (NOBAR) b = __hip_atomic_load(&sm_dot[buf][c][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else b = sm_dot[buf][c][w];
-          s = w == 0 ? __builtin_bit_cast(T, b) : s + __builtin_bit_cast(T, b);
-        }
+        for (int w = 1; w < WAVES; ++w) s += sm_dot[buf][c][w];
         if (lane / G == c) mine = s;
       }
       unsigned bits;
@@ -335,7 +291,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   };
   auto park_slot = [&](int64_t i) { return park + ((size_t)(LAG > 0 ? i % (LAG > 0 ? LAG : 1) : 0) * WAVES + wave) * (C * U * WAVE) + lane; };
 
-  Pending<T, C> carry{};  // AHEAD: the poll and fetch issued by the previous step for this one
   // One step: [poll the totals of step i - LT, fetch its x_j / z_old_j] [start loading tile i + PF into `nxt`]
   // [dot + post tile i = `cur`] [totals of step i - LT -> v_j ; A v accumulation from the parked tile] [park tile i - LAGR = `old`
   // (LAGR = 0: `cur` itself)].  ALL = steady state: every part runs, no branch.
@@ -347,13 +302,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     // scheduling fences around the load issue: `nxt` is the register tile the previous step read last; without them the
     // scheduler hoists these loads above that step's multiply-adds into fresh registers and the kernel spills
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (AHEAD) {
-      pd = carry;  // polled and fetched by the previous step
-      if (ALL || (i + 1 >= LT && i + 1 - LT < cnt)) {
-        carry.w = poll_word(i + 1 - LT);
-        fetch_xz(carry, i + 1 - LT);
-      }
-    } else if (has_fma) {
+    if (has_fma) {
       if constexpr (LT > 0) pd.w = poll_word(i - LT);  // issued BEFORE the next tile's loads: it returns first
       fetch_xz(pd, i - LT);
     }

@@ -8,42 +8,47 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_OPT")
+VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W")
 CASES = [
-    # (row_team.py arguments, geometry C:LAG:LAGR:PF:WGS:OPT)
-    (["--m", "4096", "--n", "8192"], "2:2:0:2:4:0"),
+    # (row_team.py arguments, geometry C:LAG:LAGR:PF:WGS:W)
+    (["--m", "4096", "--n", "8192"], "default"),
+    (["--m", "4096", "--n", "8192"], "2:3:3:2:3:4"),
+    (["--m", "4096", "--n", "8192"], "4:2:2:2:2:4"),
     (["--m", "4096", "--n", "8192"], "2:2:0:2:4:1"),
-    (["--m", "4096", "--n", "8192"], "2:2:0:2:4:2"),
-    (["--m", "4096", "--n", "8192"], "2:2:0:2:4:3"),
-    (["--m", "4096", "--n", "8192"], "2:2:1:2:3:3"),
-    (["--m", "4096", "--n", "8192"], "2:3:2:2:3:0"),
-    (["--m", "4096", "--n", "8192"], "2:3:3:2:3:0"),
-    (["--m", "4096", "--n", "8192"], "2:3:3:2:3:3"),
-    (["--m", "4096", "--n", "8192"], "4:2:0:2:2:3"),
-    (["--m", "4096", "--n", "8192"], "4:2:2:2:2:0"),
-    (["--m", "4096", "--n", "8192"], "4:2:2:2:2:3"),
-    (["--m", "4096", "--n", "8192", "--delay-ns", "0"], "2:2:0:2:4:3"),
-    (["--m", "4096", "--n", "8192", "--delay-ns", "5000"], "2:3:3:2:3:3"),
-    (["--m", "4096", "--n", "8192", "--adaptive", "--delay-ns", "3000"], "4:2:2:2:2:3"),
-    (["--m", "4096", "--n", "8192", "--ranks", "4"], "2:3:3:2:3:3"),
-    (["--m", "16384", "--n", "4096", "--ranks", "8"], "2:2:0:2:4:3"),
-    (["--m", "4000", "--n", "1001", "--ranks", "3"], "2:2:0:2:4:3"),
+    (["--m", "4096", "--n", "8192"], "2:2:1:2:4:1"),
+    (["--m", "4096", "--n", "8192"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192"], "2:2:3:2:4:1"),
+    (["--m", "4096", "--n", "8192"], "2:2:2:1:4:1"),
+    (["--m", "4096", "--n", "8192", "--delay-ns", "0"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192", "--delay-ns", "7000"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192", "--adaptive", "--delay-ns", "3000"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192", "--ranks", "4"], "2:2:2:2:4:1"),
+    (["--m", "16384", "--n", "4096", "--ranks", "8"], "2:2:2:2:4:1"),
+    (["--m", "3900", "--n", "1001", "--ranks", "2"], "2:2:2:2:4:1"),
+    (["--m", "3000", "--n", "1001", "--ranks", "2"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192", "--fault", "3"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192", "--batched"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192", "--g", "boxv", "--fast", "0"], "2:2:2:2:4:1"),
+    (["--m", "4096", "--n", "8192", "--then-n", "700"], "2:2:2:2:4:1"),
     (["--m", "2048", "--n", "8192", "--dtype", "f64"], "default"),
-    (["--m", "4096", "--n", "8192", "--fault", "3"], "2:2:0:2:4:3"),
-    (["--m", "4096", "--n", "8192", "--batched"], "2:2:0:2:4:3"),
-    (["--m", "8192", "--n", "4096"], "2:2:0:2:2:3"),
-    (["--m", "8192", "--n", "4096"], "2:2:1:2:2:0"),
-    (["--m", "8192", "--n", "4096"], "2:2:1:2:2:3"),
-    (["--m", "8192", "--n", "4096"], "2:2:2:2:2:0"),
-    (["--m", "8192", "--n", "4096"], "1:3:2:2:3:0"),
-    (["--m", "16384", "--n", "4096"], "1:2:0:2:2:3"),
-    (["--m", "16384", "--n", "4096"], "1:2:1:2:2:0"),
-    (["--m", "16384", "--n", "4096"], "1:2:1:2:2:3"),
-    (["--m", "32768", "--n", "4096"], "1:2:0:2:1:3"),
-    (["--m", "32768", "--n", "4096"], "1:2:1:2:1:0"),
-    (["--m", "32768", "--n", "4096"], "1:2:1:2:1:3"),
-    (["--m", "32768", "--n", "4096"], "1:2:2:2:1:0"),
-    (["--m", "32768", "--n", "4096", "--delay-ns", "6000"], "1:2:2:2:1:3"),
+    (["--m", "8192", "--n", "4096"], "default"),
+    (["--m", "8192", "--n", "4096"], "2:2:1:2:2:4"),
+    (["--m", "8192", "--n", "4096"], "2:2:2:2:2:4"),
+    (["--m", "8192", "--n", "4096"], "1:2:0:2:4:1"),
+    (["--m", "8192", "--n", "4096"], "1:2:1:2:4:1"),
+    (["--m", "8192", "--n", "4096"], "1:2:2:2:4:1"),
+    (["--m", "8192", "--n", "4096"], "2:2:0:2:2:2"),
+    (["--m", "8192", "--n", "4096"], "2:2:2:2:2:2"),
+    (["--m", "16384", "--n", "4096"], "default"),
+    (["--m", "16384", "--n", "4096"], "1:2:1:2:2:4"),
+    (["--m", "16384", "--n", "4096"], "1:2:0:2:2:2"),
+    (["--m", "16384", "--n", "4096"], "1:2:1:2:2:2"),
+    (["--m", "16384", "--n", "4096"], "1:2:2:2:2:2"),
+    (["--m", "32768", "--n", "4096"], "default"),
+    (["--m", "32768", "--n", "4096"], "1:2:1:2:1:4"),
+    (["--m", "32768", "--n", "4096"], "1:2:2:2:1:4"),
+    (["--m", "32768", "--n", "4096"], "1:0:2:2:1:4"),
+    (["--m", "32768", "--n", "4096", "--delay-ns", "6000"], "1:2:2:2:1:4"),
 ]
 
 

@@ -367,43 +367,91 @@ def _bench_module():
     return bench
 
 
-def test_bench_config_carries_every_other_record_as_scalars():
-    """the driver's BENCH_rNN.json keeps the scalar keys of `config` and drops nested ones, so every further
-    record (N = 1: adaptive, configs 2 / 3 / 4, the per-GPU block shapes; N > 1: the other layouts) is ALSO written as flat
-    scalars `config.also_<label>_{it_s, ms, frac, kernel, a_passes}` / `config.layout_<key>_...`; a failed record as
-    `..._error`.  Everything under `config` except the two documented summary dicts and `final` is a scalar."""
+def test_bench_config_carries_every_other_record_in_one_string():
+    """the driver's BENCH_rNN.json keeps about the first twenty SCALAR keys of `config` and
+    nothing nested -- round 4's sixteen flat keys per record pushed configs 3 / 4 / the block shapes out of it.  Every further
+    record now travels in ONE scalar string (`config.also` at N = 1, `config.layouts` at N > 1: label=it/s@frac/reads-of-A,
+    joined by `;`), the problem's parameters are nested under `config.problem`, and `config` holds at most twenty scalars."""
     bench = _bench_module()
     args = bench.parse_args(["--workload", "small"])
     job = bench.Job(args, 1, 0)
-    job.main_rec = {"value": 105.0, "ms_per_step": 9.5, "config": {"workload": "w", "m": 16, "final": {"gamma": 0.1}},
-                    "roofline": {"kernel": "gemv_tn", "frac": 0.91}, "sustained": {"value": 104.0}}
+    job.main_rec = {"value": 105.0, "ms_per_step": 9.5,
+                    "config": {"workload": "w", "m": 16, "n": 32, "mode": "fixed", "sharding": "none", "shards": 1, "a_passes_per_step": 1.0,
+                               "sweep_fallbacks": 0, "sweeps": "one", "row_teams": False,
+                               "problem": {"lambda": 0.1, "Lf": 2.0, "seed": 0, "setup_s": 1.0, "m_per_gpu": 16, "n_per_gpu": 32},
+                               "final": {"gamma": 0.1}},
+                    "roofline": {"kernel": "gemv_tn", "frac": 0.91}, "sustained": {"value": 104.0}, "in_library_loop": {"value": 106.0}}
     job.extra["also"] = [
+        {"label": "headline_adaptive", "value": 105.4, "ms_per_step": 9.49, "roofline": {"kernel": "gemv_tn", "frac": 0.909},
+         "config": {"a_passes_per_step": 1.0}},
         {"label": "config2", "value": 811.0, "ms_per_step": 1.23, "roofline": {"kernel": "gemv_tn", "frac": 0.89},
          "config": {"a_passes_per_step": 1.0}},
         {"label": "config3", "value": 3e5, "ms_per_step": 0.0033, "roofline": {"kernel": "dr_step", "frac": 0.73},
          "stepping": {"value": 2e4, "roofline": {"frac": 0.73}}, "config": {}},
-        {"label": "config4", "value": 107.0, "ms_per_step": 9.3, "roofline": {"kernel": "gemv_tn", "frac": 0.9},
+        {"label": "config4", "value": 107.1, "ms_per_step": 9.3, "roofline": {"kernel": "gemv_tn", "frac": 0.91},
          "config": {"A_passes_per_step": 1.0}},
-        {"label": "config5_column_block", "error": "MemoryError: out of memory"},
+        {"label": "config5_column_block", "error": "MemoryError: out of memory; (a = b)"},
+        {"label": "rows_2proc_row_team", "value": 372.0, "ms_per_step": 2.7, "roofline": {"kernel": "gemv_tn (row team, 2 processes)", "frac": 0.8},
+         "config": {"a_passes_per_step": 1.0}},
     ]
     cfg = job.line()["config"]
-    assert cfg["also_config2_it_s"] == 811.0 and cfg["also_config2_ms"] == 1.23 and cfg["also_config2_frac"] == 0.89
-    assert cfg["also_config2_kernel"] == "gemv_tn" and cfg["also_config2_a_passes"] == 1.0
-    assert cfg["also_config3_it_s"] == 3e5 and cfg["also_config3_stepping_it_s"] == 2e4 and cfg["also_config3_stepping_frac"] == 0.73
-    assert cfg["also_config4_it_s"] == 107.0 and cfg["also_config4_a_passes"] == 1.0
-    assert "out of memory" in cfg["also_config5_column_block_error"]
-    assert cfg["sustained_it_s"] == 104.0
-    nested = {k for k, v in cfg.items() if isinstance(v, (dict, list))}
-    assert nested == {"also_summary", "final"}, nested
-    # N > 1: the other layouts
+    scalars = [k for k, v in cfg.items() if not isinstance(v, (dict, list))]
+    assert len(scalars) <= 20, scalars
+    assert list(cfg)[:len(scalars)] == scalars  # the scalars come first: the driver cuts from the end
+    assert scalars.index("also") < 12
+    got = bench.parse_summary_string(cfg["also"])
+    assert got["adaptive"] == {"it_s": 105.4, "frac": 0.909, "a_passes": 1.0}
+    assert got["cfg2"] == {"it_s": 811.0, "frac": 0.89, "a_passes": 1.0}
+    assert got["cfg3"] == {"it_s": 3e5, "stepping_it_s": 2e4, "stepping_frac": 0.73}
+    assert got["cfg4"] == {"it_s": 107.1, "frac": 0.91, "a_passes": 1.0}
+    assert "out of memory" in got["cfg5blk"]["error"]
+    assert got["rows2pteam"]["it_s"] == 372.0 and got["rows2pteam"]["frac"] == 0.8
+    assert cfg["sustained_it_s"] == 104.0 and cfg["in_library_loop_it_s"] == 106.0
+    assert {k for k, v in cfg.items() if isinstance(v, (dict, list))} == {"problem", "final", "also_summary"}
+    assert len(cfg["also"]) < 400
+    # N > 1: the other layouts, and which form of the row layout the top-level value is
     job2 = bench.Job(bench.parse_args(["--gpus", "8"]), 8, 0)
     job2.main_rec = dict(job.main_rec)
-    job2.extra["rows_strong"] = {"value": 405.0, "ms_per_step": 2.47, "roofline": {"kernel": "gemv_t", "frac": 0.9},
-                                 "config": {"a_passes_per_step": 2.0}}
+    job2.layout_note = {"row_layout": "two_sweeps", "row_layout_reason": "the row-team record was not measured: timed out"}
+    job2.extra["cols_strong"] = {"value": 810.0, "ms_per_step": 1.23, "roofline": {"kernel": "gemv_tn", "frac": 0.89},
+                                 "config": {"a_passes_per_step": 1.0}}
     job2.extra["rows_strong_teams"] = {"error": "timed out"}
     cfg2 = job2.line()["config"]
-    assert cfg2["layout_rows_strong_it_s"] == 405.0 and cfg2["layout_rows_strong_a_passes"] == 2.0
-    assert cfg2["layout_rows_strong_teams_error"] == "timed out"
+    lay = bench.parse_summary_string(cfg2["layouts"])
+    assert lay["cols"] == {"it_s": 810.0, "frac": 0.89, "a_passes": 1.0} and lay["teams"] == {"error": "timed out"}
+    assert cfg2["row_layout"] == "two_sweeps" and "timed out" in cfg2["row_layout_reason"]
+    assert len([k for k, v in cfg2.items() if not isinstance(v, (dict, list))]) <= 20
+
+
+def test_bench_row_team_record_replaces_the_two_sweep_record_only_when_clean():
+    """the N > 1 top-level record is north_star's ROW layout -- measured with two sweeps + the all-reduce of
+    [grad ; f] in the job's own process group, then replaced by the row-team record of the same problem and the same K steps
+    (run in a process group of its own) when that one is clean: measured, as a row team, self-test ok on every rank, one read of
+    the block per step, no fallback.  Anything else leaves the two-sweep record on top and says why."""
+    bench = _bench_module()
+    args = bench.parse_args(["--gpus", "8", "--steps", "50"])
+    two = {"value": 405.0, "ms_per_step": 2.47, "steps": 50, "roofline": {"kernel": "gemv_t", "frac": 0.9},
+           "config": {"workload": "w", "sharding": "rows", "a_passes_per_step": 2.0, "row_teams": False}}
+    team = lambda **kw: {"value": 683.0, "ms_per_step": 1.46, "steps": 50, "roofline": {"kernel": "gemv_tn", "frac": 0.8},
+                         "config": dict({"workload": "w", "sharding": "rows", "a_passes_per_step": 1.0, "row_teams": True, "sweep_fallbacks": 0,
+                                         "row_team_selftest": "ok", "row_team_selftest_all_ranks": True}, **kw)}
+    job = bench.Job(args, 8, 0)
+    job.main_rec = two
+    job.extra = {"cols_strong": {"value": 810.0}, "rows_strong_teams": team()}
+    assert bench.promote_row_team_record(args, job)
+    d = job.line()
+    assert d["value"] == 683.0 and d["config"]["row_layout"] == "row_teams" and d["config"]["sharding"] == "rows"
+    assert d["rows_two_sweeps"]["value"] == 405.0 and "rows_strong_teams" not in d and d["config"]["rows_two_sweeps_it_s"] == 405.0
+    assert list(job.extra)[0] == "rows_two_sweeps"
+    for bad, word in ((team(sweep_fallbacks=2), "fell back"), (team(row_team_selftest_all_ranks=False), "self-test"),
+                      (team(a_passes_per_step=2.0), "read its block"), ({"error": "the row-team child did not finish within 600 s"}, "did not finish"),
+                      (dict(team(), steps=20), "20 steps")):
+        job = bench.Job(args, 8, 0)
+        job.main_rec = two
+        job.extra = {"rows_strong_teams": bad}
+        assert not bench.promote_row_team_record(args, job)
+        d = job.line()
+        assert d["value"] == 405.0 and d["config"]["row_layout"] == "two_sweeps" and word in d["config"]["row_layout_reason"], d["config"]
 
 
 def test_bench_wall_clock_ledger_and_its_extrapolation():
@@ -413,15 +461,15 @@ def test_bench_wall_clock_ledger_and_its_extrapolation():
     bench = _bench_module()
     rec = lambda m, n, scaling, wall, passes: {"value": 1.0, "scaling": scaling, "wall_s": wall,
                                                "config": {"m": m, "n": n, "a_passes_per_step": passes}}
-    d = {"n_gpus": 8, "dtype": "f32", "wall_s": 6.0, "scaling": "strong", "config": {"m": 2048, "n": 131072, "a_passes_per_step": 1.0},
+    d = {"n_gpus": 8, "dtype": "f32", "wall_s": 6.0, "scaling": "strong", "config": {"m": 2048, "n": 131072, "a_passes_per_step": 2.0},
          "job": {"wall": {"import_s": 40.0, "init_s": 8.0, "total_s": 75.0}},
-         "rows_strong": rec(2048, 131072, "strong", 5.0, 2.0), "config5_weak_rows": rec(16384, 131072, "weak", 6.0, 2.0),
+         "cols_strong": rec(2048, 131072, "strong", 5.0, 1.0), "config5_weak_rows": rec(16384, 131072, "weak", 6.0, 2.0),
          "config5_weak_cols": rec(16384, 131072, "weak", 7.0, 1.0)}
     led = bench.wall_ledger(d)
-    assert led["import"] == 40.0 and led["main"] == 6.0 and led["rows_strong"] == 5.0 and led["total"] == 75.0
+    assert led["import"] == 40.0 and led["main"] == 6.0 and led["cols_strong"] == 5.0 and led["total"] == 75.0
     assert led["other"] == pytest.approx(75.0 - (40 + 8 + 6 + 5 + 6 + 7))
     full, total = bench.extrapolate_ledger(d, 16384, 1 << 20)
-    assert full["import"] == 40.0 and full["main"] > led["main"] and full["config5_weak_rows"] > full["rows_strong"] > led["rows_strong"]
+    assert full["import"] == 40.0 and full["main"] > led["main"] and full["config5_weak_rows"] > full["cols_strong"] > led["cols_strong"]
     # config 5's 64 GiB blocks: 31 two-pass evaluations + 25 iterations of two passes at 7 TB/s + generation + settling
     blk = 131072 * (1 << 20) * 4 / 8
     expect = 6.0 + blk / 2.4e12 + 62 * blk / 7e12 + 25 * 2 * blk / 7e12 + min(6.0, blk / 30e9 + 0.3)

@@ -65,8 +65,9 @@ def run_pair(world, layout, m, n, mode, f64, tag=""):
         return "%d ranks: %s" % (world, why), label
     c1, c2 = one["config"], many["config"]
     rel = 1e-9 if f64 else 3e-4
-    if not close(c1["lambda"], c2["lambda"], 1e-5 if not f64 else 1e-12):
-        return "lambda %r / %r" % (c1["lambda"], c2["lambda"]), label
+    l1, l2 = c1["problem"]["lambda"], c2["problem"]["lambda"]
+    if not close(l1, l2, 1e-5 if not f64 else 1e-12):
+        return "lambda %r / %r" % (l1, l2), label
     f1, f2 = c1["final"], c2["final"]
     # (the stopping measure is a difference of nearly equal vectors: near convergence it sits on the rounding floor of the element type)
     floor = {"res_inf_over_gamma": 1e-11 if f64 else 3e-6}

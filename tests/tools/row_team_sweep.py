@@ -3,12 +3,12 @@
 
 The ranks of a row team are contexts of this process (as in tests/tools/row_team.py --bench); the row blocks are generated
 once, then every (geometry, injected latency) pair of the plan is timed on them: the geometry through the tuning variables
-(PG_TUNE=1: PG_TNP_C / _LAG / _LAGR / _PF / _WGS, read by the library at every launch), the latency through
+(PG_TUNE=1: PG_TNP_C / _LAG / _LAGR / _PF / _WGS / _W, read by the library at every launch), the latency through
 pg_ctx_test_team_fault(ctx, ns, 2) -- the sweep's DELAY form accepts a step's granules only `ns` after they were stored, so
 the on-chip hand-off stands in for a fabric hop of that length (pg_gemv_tnt.h).  One JSON line per pair.
 
     python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --geoms default,2:2:3:2:2:3 --delays off,0,2000,4000,8000
-geometry = C:LAG:LAGR:PF:WGS (columns per step, lag steps in LDS, lag steps in registers, tiles in flight, workgroups per CU)."""
+geometry = C:LAG:LAGR:PF:WGS:W (columns per step, lag steps in LDS, lag steps in registers, tiles in flight, workgroups per CU, waves per workgroup)."""
 import argparse
 import ctypes as C
 import json
@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-GEOM_VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_OPT")
+GEOM_VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W")
 
 
 def set_geometry(spec):
