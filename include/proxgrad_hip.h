@@ -230,6 +230,17 @@ pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma,
  * (fb_tools.jl:43) shares its rounding with the A x that f(A x) was taken at. */
 pg_status pg_mat_fused_tn_res(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
                               void* At_r, void* y, void* z, void* res, void* Ares, double* scalars_out);
+/* TWO instances of pg_mat_fused_tn in ONE read of A: the same gamma and g, two pairs (r, x), every output twice.  ZeroFPR's line
+ * search (zerofpr.jl:200-217: x = xbar_prev + tau d; A' grad f(A x); y; xbar = prox(y); res; and A xbar for the next iteration,
+ * :167) evaluates its trial points one sweep each; with the points of tau and tau / 2 carried through the same pass a rejected
+ * first trial costs no second read of A.  Per column each instance's results equal pg_mat_fused_tn's bit for bit; the images
+ * A z differ from it in the last bits only where the sweep's column map deals its final incomplete round differently.
+ * scalars_out (host, may be NULL): the four scalars of the first instance, then of the second.
+ * Columns of 33 .. 64 row groups of 1 KiB (8193 .. 16384 rows in Float32: BASELINE config 4's 16384; 4097 .. 8192 in Float64);
+ * PG_ERR_UNSUPPORTED otherwise (the caller falls back to one trial point per sweep). */
+pg_status pg_mat_fused_tn_pair(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
+                               double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Az1, void* At_r2, void* y2,
+                               void* z2, void* res2, void* Az2, double* scalars_out);
 /* ------------------------------------------------------------------ LeastSquares -------- */
 /* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the
  * value_and_gradient method of benchmark/benchmarks.jl:11-17.  `b` is a device m-vector

@@ -590,6 +590,7 @@ pg_status pg_mat_destroy(pg_mat* A) {
   if (A->partials) (void)hipFree(A->partials);
   for (void* q : A->retired) (void)hipFree(q);
   if (A->rpad) (void)hipFree(A->rpad);
+  if (A->rpad2) (void)hipFree(A->rpad2);
   if (A->xch) (void)hipFree(A->xch);
   delete A;
   return PG_OK;

@@ -880,6 +880,69 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
   return PG_OK;
 }
 
+// TWO instances of mat_fused_tn_t on ONE read of A (gemv_tnm_pair_kernel, pg_gemv_tn3.hip): the same gamma and g, two pairs
+// (r, x); every output twice; scalars -> dscal[PG_S_PAIR .. + 8).  ZeroFPR's line search (zerofpr.jl:200-217) evaluates its
+// trial points x = xbar_prev + tau d one sweep each; this carries tau and tau / 2 through the same pass over A.
+template <typename T>
+pg_status mat_fused_tn_pair_t(pg_mat* A, const T* r1, const T* x1, const T* r2, const T* x2, double gamma, int g_kind, double g_p0, double g_p1,
+                              T* g1, T* y1, T* z1, T* res1, T* Az1, T* g2, T* y2, T* z2, T* res2, T* Az2) {
+  pg_ctx* c = A->ctx;
+  const int nrg = (int)(A->ld / (1024 / (int64_t)sizeof(T)));
+  if (pg_row_sharded(c) || pg_col_sharded(c) || !tn_supported<T>(A) || !tn_pair_covers(nrg)) {
+    pg_set_error("the two-point sweep needs an unsharded operator with %d .. %d rows", (int)(32 * (1024 / sizeof(T)) + 1), (int)(64 * (1024 / sizeof(T))));
+    return PG_ERR_UNSUPPORTED;
+  }
+  for (void** pad : {&A->rpad, &A->rpad2}) {
+    if (*pad == nullptr) {
+      PG_HIP(hipMalloc(pad, (size_t)A->ld * sizeof(T)));
+      PG_HIP(hipMemsetAsync(*pad, 0, (size_t)A->ld * sizeof(T), c->stream));
+    }
+  }
+  PG_HIP(hipMemcpyAsync(A->rpad, r1, (size_t)A->m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  PG_HIP(hipMemcpyAsync(A->rpad2, r2, (size_t)A->m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+  TNArgs<T> a;
+  a.A = (const T*)A->data;
+  a.ld = A->ld;
+  a.n = A->n;
+  a.m = A->m;
+  a.nrg = nrg;
+  a.r = (const T*)A->rpad;
+  a.x = x1;
+  a.z_old = x1;
+  const T gm = (T)gamma;
+  a.gamma = gm;
+  a.beta = T(0);
+  a.v_is_res = 0;
+  a.p0 = g_kind == PG_G_NORML1 ? (T)(gm * (T)g_p0) : (T)g_p0;
+  a.p1 = (T)g_p1;
+  a.lam_ls = T(1);
+  a.g_kind = g_kind;
+  a.gscale = g_kind == PG_G_NORML1 ? (double)(T)g_p0 : 0.0;
+  a.g_out = g1;
+  a.y = y1;
+  a.z_new = z1;
+  a.res = res1;
+  a.v_out = nullptr;
+  a.partials = nullptr;
+  a.red_partials = c->red_partials;
+  a.red_counter = c->red_counter;
+  a.scal_out = c->dscal + PG_S_PAIR;
+  a.line_cols = 32;
+  int blocks = 0;
+  T* partials2 = nullptr;
+  PG_TRY(launch_tn_pair<T>(A, a, (const T*)A->rpad2, x2, g2, y2, z2, res2, &blocks, &partials2));
+  int64_t fb = (A->ld + 63) / 64;
+  if (fb > 1024) fb = 1024;
+  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+  for (int k = 0; k < 2; ++k) {
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream,
+                       k == 0 ? (const T*)A->partials : (const T*)partials2, A->ld, A->m, blocks, (const T*)nullptr, k == 0 ? Az1 : Az2, A->m,
+                       0.0, (double*)nullptr, (unsigned*)nullptr, (double*)nullptr, (T*)nullptr, ColPack<T>{});
+    PG_LAUNCH_CHECK();
+  }
+  return PG_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ v, int64_t n, T a) {
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) v[j] *= a;
@@ -1124,6 +1187,27 @@ pg_status pg_mat_fused_tn(pg_mat* A, const void* r, const void* x, double gamma,
 pg_status pg_mat_fused_tn_res(pg_mat* A, const void* r, const void* x, double gamma, int32_t g_kind, double g_p0, double g_p1,
                               void* At_r, void* y, void* z, void* res, void* Ares, double* scalars_out) {
   return mat_fused_tn_any(A, r, x, gamma, g_kind, g_p0, g_p1, At_r, y, z, res, Ares, scalars_out, true);
+}
+
+pg_status pg_mat_fused_tn_pair(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
+                               double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Az1, void* At_r2, void* y2,
+                               void* z2, void* res2, void* Az2, double* scalars_out) {
+  PG_REQUIRE(A != nullptr, "matrix is null");
+  PG_REQUIRE(r1 && x1 && r2 && x2 && At_r1 && y1 && z1 && res1 && Az1 && At_r2 && y2 && z2 && res2 && Az2, "null vector");
+  PG_REQUIRE(g_kind == PG_G_ZERO || g_kind == PG_G_NORML1 || g_kind == PG_G_INDBOX, "unknown g_kind");
+  PG_REQUIRE(gamma > 0, "gamma must be positive");
+  PG_TRY(A->dtype == PG_F32
+             ? mat_fused_tn_pair_t<float>(A, (const float*)r1, (const float*)x1, (const float*)r2, (const float*)x2, gamma, g_kind, g_p0, g_p1,
+                                          (float*)At_r1, (float*)y1, (float*)z1, (float*)res1, (float*)Az1, (float*)At_r2, (float*)y2,
+                                          (float*)z2, (float*)res2, (float*)Az2)
+             : mat_fused_tn_pair_t<double>(A, (const double*)r1, (const double*)x1, (const double*)r2, (const double*)x2, gamma, g_kind, g_p0,
+                                           g_p1, (double*)At_r1, (double*)y1, (double*)z1, (double*)res1, (double*)Az1, (double*)At_r2,
+                                           (double*)y2, (double*)z2, (double*)res2, (double*)Az2));
+  if (scalars_out) {
+    PG_TRY(pg_read_scalars(A->ctx, PG_S_PAIR, 8));
+    for (int k = 0; k < 8; ++k) scalars_out[k] = A->ctx->hscal[PG_S_PAIR + k];
+  }
+  return PG_OK;
 }
 
 pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,

@@ -465,6 +465,10 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out);
 pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out);
 // gemv_tnm_kernel: 29 .. 128 row groups, the headline's 64 among them (pg_gemv_tn3.hip)
 bool tn_mid_covers(int nrg);
+bool tn_pair_covers(int nrg);
+// two instances of the sweep on one read of A (gemv_tnm_pair_kernel, pg_gemv_tn3.hip): the second instance's inputs / outputs
+template <typename T>
+pg_status launch_tn_pair(pg_mat* A, TNArgs<T>& a, const T* r2, const T* x2, T* g2, T* y2, T* z2, T* res2, int* blocks_out, T** partials2_out);
 template <typename T>
 pg_status launch_tn_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int U, int C, int W, int nt, int bpc);
 template <typename T>

@@ -209,39 +209,37 @@ bool tn_peer_covers(int nrg) { return nrg >= 1 && nrg <= 64; }
 
 namespace {
 struct PeerGeom {
-  int C, LAG, LAGR, PF, WGS, W, U;
+  int W, C, LAG, LAGR, PF, WGS;
 };
-// Float32 geometries of the row-team sweep by the team's longest block in row groups (profiles/r5_row_team_latency_sweep.md)
+// Float32 geometry of the row-team sweep by the team's longest block in row groups (profiles/r5_row_team_latency_sweep.md).
+// One rule for every length: a WAVE streams 16 KiB tiles of its rows (U <= 8 row groups of C = 2 columns, or U <= 16 of one
+// column), four waves per compute unit (one per SIMD, the whole 512-entry register file each), so W = ceil(row groups / 16)
+// waves share a column -- ONE up to 2048 rows: no barrier, no cross-wave sum, the wave posts and polls for itself -- and 4 / W
+// workgroups sit on a compute unit; two tiles in flight (PF), two waiting in LDS (LAG: 128 KiB per compute unit) and two more
+// in registers (LAGR): 256 KiB of parked tiles per compute unit, 10-11 us for a step's granules to arrive where round 4's
+// geometries (four waves per column at every length, LAG = 2 only) had 5-6.
 PeerGeom peer_geometry_f32(int nrg) {
-  const int U = (nrg + 3) / 4 < 2 ? 2 : (nrg + 3) / 4;
-  if (U <= 4) return {2, 2, 0, 2, 0, 4, U};
-  return {1, 2, 0, 2, 0, 4, U};
+  const int W = nrg <= 8 ? 1 : nrg <= 32 ? 2 : 4;
+  const int U = (nrg + W - 1) / W;
+  return {W, U <= 4 ? 4 : U <= 8 ? 2 : 1, 2, 2, 2, 4 / W};
 }
 }  // namespace
 
-// every Float32 instantiation: (U, C, LAG, PF, LAGR, W); _D: also with the latency injector
+// every Float32 instantiation: (U, C, LAG, PF, LAGR, W); _D: also with the latency injector (the geometries of the latency sweep)
 #define PG_TNP_F32_GEOMETRIES \
-  PG_TNP_CASE_D(2, 2, 2, 2, 0, 4); PG_TNP_CASE_D(2, 2, 3, 2, 2, 4); PG_TNP_CASE_D(2, 2, 3, 2, 3, 4); \
-  PG_TNP_CASE_D(2, 4, 2, 2, 0, 4); PG_TNP_CASE_D(2, 4, 2, 2, 2, 4); PG_TNP_CASE_D(4, 2, 2, 2, 0, 4); \
-  PG_TNP_CASE_D(4, 2, 2, 2, 1, 4); PG_TNP_CASE_D(4, 2, 2, 2, 2, 4); PG_TNP_CASE_D(4, 1, 2, 2, 0, 4); \
-  PG_TNP_CASE_D(4, 1, 3, 2, 2, 4); PG_TNP_CASE_D(8, 1, 2, 2, 0, 4); PG_TNP_CASE_D(8, 1, 2, 2, 1, 4); \
-  PG_TNP_CASE_D(16, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 1, 4); PG_TNP_CASE_D(16, 1, 2, 2, 2, 4); \
-  PG_TNP_CASE_D(16, 1, 0, 2, 2, 4); PG_TNP_CASE_D(8, 2, 2, 2, 0, 1); PG_TNP_CASE_D(8, 2, 2, 2, 1, 1); \
-  PG_TNP_CASE_D(8, 2, 2, 2, 2, 1); PG_TNP_CASE_D(8, 2, 2, 2, 3, 1); PG_TNP_CASE_D(8, 2, 2, 1, 2, 1); \
-  PG_TNP_CASE_D(16, 1, 2, 2, 0, 1); PG_TNP_CASE_D(16, 1, 2, 2, 1, 1); \
-  PG_TNP_CASE_D(16, 1, 2, 2, 2, 1); PG_TNP_CASE_D(8, 2, 2, 2, 0, 2); PG_TNP_CASE_D(8, 2, 2, 2, 2, 2); \
-  PG_TNP_CASE_D(16, 1, 2, 2, 0, 2); PG_TNP_CASE_D(16, 1, 2, 2, 1, 2); PG_TNP_CASE_D(16, 1, 2, 2, 2, 2); \
-  PG_TNP_CASE(3, 2, 2, 2, 0, 4); PG_TNP_CASE(5, 1, 2, 2, 0, 4); PG_TNP_CASE(6, 1, 2, 2, 0, 4); PG_TNP_CASE(7, 1, 2, 2, 0, 4); PG_TNP_CASE(9, 1, 2, 2, 0, 4); PG_TNP_CASE(10, 1, 2, 2, 0, 4); \
-  PG_TNP_CASE(11, 1, 2, 2, 0, 4); PG_TNP_CASE(12, 1, 2, 2, 0, 4); PG_TNP_CASE(13, 1, 2, 2, 0, 4); PG_TNP_CASE(14, 1, 2, 2, 0, 4); PG_TNP_CASE(15, 1, 2, 2, 0, 4)
+  PG_TNP_CASE_D(8, 2, 2, 2, 2, 1); PG_TNP_CASE_D(8, 2, 2, 2, 2, 2); PG_TNP_CASE_D(16, 1, 2, 2, 2, 2); \
+  PG_TNP_CASE_D(16, 1, 2, 2, 2, 4); PG_TNP_CASE_D(2, 2, 2, 2, 0, 4); PG_TNP_CASE_D(4, 2, 2, 2, 0, 4); \
+  PG_TNP_CASE_D(8, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 1, 4); \
+  PG_TNP_CASE(1, 4, 2, 2, 2, 1); PG_TNP_CASE(2, 4, 2, 2, 2, 1); PG_TNP_CASE(3, 4, 2, 2, 2, 1); PG_TNP_CASE(4, 4, 2, 2, 2, 1); \
+  PG_TNP_CASE(5, 2, 2, 2, 2, 1); PG_TNP_CASE(6, 2, 2, 2, 2, 1); PG_TNP_CASE(7, 2, 2, 2, 2, 1); PG_TNP_CASE(5, 2, 2, 2, 2, 2); \
+  PG_TNP_CASE(6, 2, 2, 2, 2, 2); PG_TNP_CASE(7, 2, 2, 2, 2, 2); PG_TNP_CASE(9, 1, 2, 2, 2, 2); PG_TNP_CASE(10, 1, 2, 2, 2, 2); \
+  PG_TNP_CASE(11, 1, 2, 2, 2, 2); PG_TNP_CASE(12, 1, 2, 2, 2, 2); PG_TNP_CASE(13, 1, 2, 2, 2, 2); PG_TNP_CASE(14, 1, 2, 2, 2, 2); \
+  PG_TNP_CASE(15, 1, 2, 2, 2, 2); PG_TNP_CASE(9, 1, 2, 2, 2, 4); PG_TNP_CASE(10, 1, 2, 2, 2, 4); PG_TNP_CASE(11, 1, 2, 2, 2, 4); \
+  PG_TNP_CASE(12, 1, 2, 2, 2, 4); PG_TNP_CASE(13, 1, 2, 2, 2, 4); PG_TNP_CASE(14, 1, 2, 2, 2, 4); PG_TNP_CASE(15, 1, 2, 2, 2, 4)
 
 // Tunables (environment, under PG_TUNE, for experiments): PG_TNP_W, PG_TNP_C, PG_TNP_LAG, PG_TNP_LAGR, PG_TNP_PF, PG_TNP_WGS.
 template <typename T>
 pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
-  // One tile (C columns of this device's rows) per step and workgroup is 16 KiB on 2048-row blocks, 32 KiB on 4096 / 8192 rows,
-  // 64 KiB on 16384 rows (config 5 on 8 devices), and LAG = 2 tiles wait in LDS, which leaves room for four / two / one
-  // workgroups per compute unit: the parked bytes per compute unit are 128 KiB in every case, so the granules of a step have
-  // ~5-6 us at the device's streaming rate to cross the fabric and be found.  (LAG = 4 with one workgroup per compute unit: same slack, 0.6-0.85 of
-  // the rate -- one workgroup's per-step chain of barrier, post, poll and LDS round trip is not hidden by a second one.)
   pg_ctx* c = A->ctx;
   // the longest row block of the team, agreed once per matrix and team (pg_gemv.hip::pg_mat_row_team_agree: a collective, normally
   // made when the iterator was created); a block beyond what the sweep covers on ANY device: no device sweeps
@@ -251,13 +249,13 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     return PG_ERR_UNSUPPORTED;
   }
   const int team_nrg = A->team_nrg;
-  // Geometry by the team's longest block: waves per workgroup W (the rows of a column are split over them), row groups per wave
-  // U = ceil(row groups / W) EXACTLY (3, 5 .. 7, 9 .. 15 beside the powers of two: a block one row past 2048 rows is three row
-  // groups per wave, not four -- 2 x 2049 rows streamed 4.0 TB/s in the next power of two's geometry where 2 x 2048 stream 5.9;
-  // PG_TNP_EXACT=0 under PG_TUNE: the powers of two only, for A/B runs), columns per step C, lag steps in LDS (LAG) and in
-  // registers (LAGR), tiles in flight (PF), workgroups per compute unit (0: as many as the parked tiles leave LDS for).
-  // Float64 keeps round 4's geometries (its values take two granules and twice the registers per row group).
-  PeerGeom g = {(team_nrg + 3) / 4 >= 5 ? 1 : 2, 2, 0, 2, 0, 4};
+  // Geometry by the team's longest block (peer_geometry_f32): waves per workgroup W (the rows of a column are split over them), row
+  // groups per wave U = ceil(row groups / W) EXACTLY (a block one row past a boundary is one more row group per wave, not the next
+  // power of two's geometry: 2 x 2049 rows streamed 4.0 TB/s that way in round 4 where 2 x 2048 streamed 5.9; PG_TNP_EXACT=0
+  // under PG_TUNE: the powers of two only, for A/B runs), columns per step C, lag steps in LDS (LAG) and in registers (LAGR),
+  // tiles in flight (PF), workgroups per compute unit (0: as many as the parked tiles leave LDS for).
+  // Float64 keeps round 4's geometries (four waves per column; its values take two granules each).
+  PeerGeom g = {4, (team_nrg + 3) / 4 >= 5 ? 1 : 2, 2, 0, 2, 0};
   if constexpr (sizeof(T) == 4) g = peer_geometry_f32(team_nrg);
   const int W = env_int("PG_TNP_W", g.W);
   const int per_wave = (team_nrg + W - 1) / W;

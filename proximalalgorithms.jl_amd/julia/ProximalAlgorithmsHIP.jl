@@ -154,6 +154,19 @@ function fused_tn!(A::HIPMatrix{T}, r, x, gamma, g_kind, p0, p1, At_r, y, z, res
     (sc[1], sc[2], sc[3], sc[4])
 end
 
+# TWO instances of fused_tn! on ONE read of A (pg_mat_fused_tn_pair): the trial points of tau and tau / 2 of ZeroFPR's line search
+# (zerofpr.jl:200-217).  out1 / out2 = (At_r, y, z, res, Az); returns the two scalar quadruples.  Columns of 33 .. 64 KiB only
+# (config 4's 16384 Float32 rows); a ProxGradError with code PG_ERR_UNSUPPORTED means: one trial point per sweep.
+function fused_tn_pair!(A::HIPMatrix{T}, r1, x1, r2, x2, gamma, g_kind, p0, p1, out1, out2) where {T}
+    sc = zeros(Float64, 8)
+    check(ccall((:pg_mat_fused_tn_pair, libpg), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64,
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),
+                A.handle, r1.ptr, x1.ptr, r2.ptr, x2.ptr, gamma, g_kind, p0, p1,
+                out1[1].ptr, out1[2].ptr, out1[3].ptr, out1[4].ptr, out1[5].ptr, out2[1].ptr, out2[2].ptr, out2[3].ptr, out2[4].ptr, out2[5].ptr, sc))
+    ((sc[1], sc[2], sc[3], sc[4]), (sc[5], sc[6], sc[7], sc[8]))
+end
+
 # One Davis-Yin iteration (davis_yin.jl:73-83) in ONE read of A; prox kinds as above plus 3 = SqrNormL2(p0 = lam)
 function fused_dys!(A::HIPMatrix{T}, r, xg, z, gamma, relax, g_spec, h_spec, grad, z_half, xh, res, z_next, xg_next, A_xg_next) where {T}
     sc = zeros(Float64, 4)

@@ -10,45 +10,60 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W")
 CASES = [
-    # (row_team.py arguments, geometry C:LAG:LAGR:PF:WGS:W)
-    (["--m", "4096", "--n", "8192"], "default"),
-    (["--m", "4096", "--n", "8192"], "2:3:3:2:3:4"),
-    (["--m", "4096", "--n", "8192"], "4:2:2:2:2:4"),
-    (["--m", "4096", "--n", "8192"], "2:2:0:2:4:1"),
-    (["--m", "4096", "--n", "8192"], "2:2:1:2:4:1"),
-    (["--m", "4096", "--n", "8192"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192"], "2:2:3:2:4:1"),
-    (["--m", "4096", "--n", "8192"], "2:2:2:1:4:1"),
-    (["--m", "4096", "--n", "8192", "--delay-ns", "0"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192", "--delay-ns", "7000"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192", "--adaptive", "--delay-ns", "3000"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192", "--ranks", "4"], "2:2:2:2:4:1"),
-    (["--m", "16384", "--n", "4096", "--ranks", "8"], "2:2:2:2:4:1"),
-    (["--m", "3900", "--n", "1001", "--ranks", "2"], "2:2:2:2:4:1"),
-    (["--m", "3000", "--n", "1001", "--ranks", "2"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192", "--fault", "3"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192", "--batched"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192", "--g", "boxv", "--fast", "0"], "2:2:2:2:4:1"),
-    (["--m", "4096", "--n", "8192", "--then-n", "700"], "2:2:2:2:4:1"),
+    # (row_team.py arguments, geometry C:LAG:LAGR:PF:WGS:W | default).  Defaults (peer_geometry_f32): one wave per column up to 2048
+    # rows, two up to 8192, four up to 16384; 16 KiB tiles per wave, LAG = 2 in LDS + LAGR = 2 in registers.
+    (["--m", "4096", "--n", "8192"], "default"),                                   # 2 x 2048 rows: W = 1, U = 8, C = 2
+    (["--m", "4096", "--n", "8192", "--delay-ns", "0"], "default"),
+    (["--m", "4096", "--n", "8192", "--delay-ns", "7000"], "default"),
+    (["--m", "4096", "--n", "8192", "--adaptive", "--delay-ns", "3000"], "default"),
+    (["--m", "4096", "--n", "8192", "--ranks", "4"], "default"),                   # 4 x 1024 rows: U = 4, C = 4
+    (["--m", "4096", "--n", "8192", "--ranks", "8"], "default"),                   # 8 x 512 rows: U = 2, C = 4
+    (["--m", "2048", "--n", "4096", "--ranks", "8"], "default"),                   # 8 x 256 rows: U = 1
+    (["--m", "16384", "--n", "4096", "--ranks", "8"], "default"),                  # the headline's N = 8 block
+    (["--m", "3900", "--n", "1001", "--ranks", "2"], "default"),                   # 1950 rows: U = 8 with a ragged last row group
+    (["--m", "3000", "--n", "1001", "--ranks", "2"], "default"),                   # 1500 rows: U = 6
+    (["--m", "2305", "--n", "1001", "--ranks", "3"], "default"),                   # 769 / 768 / 768 rows: U = 4 (3 + 1 row groups on rank 0)
+    (["--m", "2700", "--n", "513", "--ranks", "2"], "default"),                    # 1350 rows: U = 6 (5.3 row groups)
+    (["--m", "2500", "--n", "513", "--ranks", "2"], "default"),                    # 1250 rows: U = 5
+    (["--m", "3500", "--n", "513", "--ranks", "2"], "default"),                    # 1750 rows: U = 7
+    (["--m", "1400", "--n", "513", "--ranks", "2"], "default"),                    # 700 rows: U = 3
+    (["--m", "4096", "--n", "8192", "--fault", "3"], "default"),
+    (["--m", "4096", "--n", "8192", "--batched"], "default"),
+    (["--m", "4096", "--n", "8192", "--g", "boxv", "--fast", "0"], "default"),
+    (["--m", "4096", "--n", "8192", "--g", "l1w"], "default"),
+    (["--m", "4096", "--n", "8192", "--then-n", "700"], "default"),
     (["--m", "2048", "--n", "8192", "--dtype", "f64"], "default"),
-    (["--m", "8192", "--n", "4096"], "default"),
-    (["--m", "8192", "--n", "4096"], "2:2:1:2:2:4"),
-    (["--m", "8192", "--n", "4096"], "2:2:2:2:2:4"),
-    (["--m", "8192", "--n", "4096"], "1:2:0:2:4:1"),
-    (["--m", "8192", "--n", "4096"], "1:2:1:2:4:1"),
-    (["--m", "8192", "--n", "4096"], "1:2:2:2:4:1"),
-    (["--m", "8192", "--n", "4096"], "2:2:0:2:2:2"),
-    (["--m", "8192", "--n", "4096"], "2:2:2:2:2:2"),
-    (["--m", "16384", "--n", "4096"], "default"),
-    (["--m", "16384", "--n", "4096"], "1:2:1:2:2:4"),
-    (["--m", "16384", "--n", "4096"], "1:2:0:2:2:2"),
-    (["--m", "16384", "--n", "4096"], "1:2:1:2:2:2"),
-    (["--m", "16384", "--n", "4096"], "1:2:2:2:2:2"),
-    (["--m", "32768", "--n", "4096"], "default"),
+    (["--m", "4097", "--n", "257"], "default"),                                    # 2049 + 2048 rows: nine row groups -> W = 2, U = 5
+    (["--m", "5000", "--n", "257"], "default"),                                    # 2500 rows: W = 2, U = 5
+    (["--m", "6100", "--n", "257"], "default"),                                    # 3050 rows: W = 2, U = 6
+    (["--m", "7000", "--n", "257"], "default"),                                    # 3500 rows: W = 2, U = 7
+    (["--m", "8192", "--n", "4096"], "default"),                                   # 2 x 4096: W = 2, U = 8, C = 2
+    (["--m", "8192", "--n", "4096", "--delay-ns", "5000"], "default"),
+    (["--m", "10241", "--n", "257"], "default"),                                   # 5121 rows, 21 row groups: W = 2, U = 11
+    (["--m", "9000", "--n", "257"], "default"),                                    # U = 9
+    (["--m", "10000", "--n", "257"], "default"),                                   # U = 10
+    (["--m", "12000", "--n", "257"], "default"),                                   # U = 12
+    (["--m", "13000", "--n", "257"], "default"),                                   # U = 13
+    (["--m", "14000", "--n", "257"], "default"),                                   # U = 14
+    (["--m", "15000", "--n", "257"], "default"),                                   # U = 15
+    (["--m", "16384", "--n", "4096"], "default"),                                  # 2 x 8192: W = 2, U = 16
+    (["--m", "16384", "--n", "4096", "--delay-ns", "5000"], "default"),
+    (["--m", "18433", "--n", "257"], "default"),                                   # 9217 rows, 37 row groups: W = 4, U = 10
+    (["--m", "17000", "--n", "257"], "default"),                                   # W = 4, U = 9
+    (["--m", "21000", "--n", "257"], "default"),                                   # U = 11
+    (["--m", "24000", "--n", "257"], "default"),                                   # U = 12
+    (["--m", "26000", "--n", "257"], "default"),                                   # U = 13
+    (["--m", "28000", "--n", "257"], "default"),                                   # U = 14
+    (["--m", "30000", "--n", "257"], "default"),                                   # U = 15
+    (["--m", "32768", "--n", "4096"], "default"),                                  # 2 x 16384 (config 5's block): W = 4, U = 16
+    (["--m", "32768", "--n", "4096", "--delay-ns", "6000"], "default"),
+    (["--m", "49152", "--n", "1024", "--ranks", "3", "--adaptive"], "default"),
+    # round 4's geometries (four waves per column, LAG = 2 only): still instantiated for the "before" curve
+    (["--m", "4096", "--n", "8192"], "2:2:0:2:4:4"),
+    (["--m", "8192", "--n", "4096"], "2:2:0:2:2:4"),
+    (["--m", "16384", "--n", "4096"], "1:2:0:2:2:4"),
+    (["--m", "32768", "--n", "4096"], "1:2:0:2:1:4"),
     (["--m", "32768", "--n", "4096"], "1:2:1:2:1:4"),
-    (["--m", "32768", "--n", "4096"], "1:2:2:2:1:4"),
-    (["--m", "32768", "--n", "4096"], "1:0:2:2:1:4"),
-    (["--m", "32768", "--n", "4096", "--delay-ns", "6000"], "1:2:2:2:1:4"),
 ]
 
 
