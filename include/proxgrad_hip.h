@@ -233,8 +233,8 @@ pg_status pg_mat_fused_tn_res(pg_mat* A, const void* r, const void* x, double ga
 /* TWO instances of pg_mat_fused_tn in ONE read of A: the same gamma and g, two pairs (r, x), every output twice.  ZeroFPR's line
  * search (zerofpr.jl:200-217: x = xbar_prev + tau d; A' grad f(A x); y; xbar = prox(y); res; and A xbar for the next iteration,
  * :167) evaluates its trial points one sweep each; with the points of tau and tau / 2 carried through the same pass a rejected
- * first trial costs no second read of A.  Per column each instance's results equal pg_mat_fused_tn's bit for bit; the images
- * A z differ from it in the last bits only where the sweep's column map deals its final incomplete round differently.
+ * first trial costs no second read of A.  Each instance's results equal pg_mat_fused_tn's to the last bits of the working
+ * precision (eight waves share a column here, four there: the same fma chains, another grouping of the partial sums).
  * scalars_out (host, may be NULL): the four scalars of the first instance, then of the second.
  * Columns of 33 .. 64 row groups of 1 KiB (8193 .. 16384 rows in Float32: BASELINE config 4's 16384; 4097 .. 8192 in Float64);
  * PG_ERR_UNSUPPORTED otherwise (the caller falls back to one trial point per sweep). */

@@ -175,9 +175,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_kernel(TNArgs<T> a) {
 // ZeroFPR's line search (zerofpr.jl:200-217) evaluates x = xbar_prev + tau d for tau = 1, 1/2, ... and every trial point is a
 // sweep of its own (A' grad f(A x), the forward-backward step, and A xbar for the next iteration): with the trial points of tau
 // and tau / 2 carried through the same register tile a rejected first trial costs no second read.  Per
-// column and instance the arithmetic is gemv_tnm_kernel's, statement for statement and in the same order (per-wave fma chain,
-// fixed-order wave sum, the waves' partials in wave order), so each instance's per-column results equal a single sweep's bit
-// for bit; the image A z is accumulated per workgroup in the order this kernel's column map visits the columns (C = 1).
+// column and instance the arithmetic is gemv_tnm_kernel's, statement for statement (per-wave fma chain, fixed-order wave sum, the
+// waves' partials in wave order); with eight waves per column where the single sweep has four the partial sums group differently,
+// so an instance's results equal a single sweep's to the last bits of the working precision, not bit for bit.
 // Second instance: TNPair (its r, x and outputs); the first one's are TNArgs' own.  Scalars: eight slots from a.scal_out.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -428,9 +428,8 @@ pg_status launch_tn_mid(pg_mat* A, TNArgs<T>& a, int* blocks_out, int U, int C, 
 
 bool tn_mid_covers(int nrg) { return nrg >= 29 && nrg <= 128; }
 
-// The pair sweep: columns of 33 .. 64 row groups (config 4's 16384 rows among them) -- four waves of U = ceil(nrg / 4), ONE column
-// per step, two tiles: both instances' r slices and image accumulators (4 x 64 registers at U = 16) beside two 64-register tiles
-// fit the 512-entry file of a one-wave-per-SIMD kernel; with two columns per step (the single sweep's geometry) they do not.
+// The pair sweep: columns of 33 .. 64 row groups (config 4's 16384 rows among them); both instances' r slices in LDS (128 KiB at
+// 64 row groups), both image accumulator sets and the tile in registers.
 bool tn_pair_covers(int nrg) { return nrg >= 33 && nrg <= 64; }
 
 template <typename T>
@@ -441,12 +440,15 @@ pg_status launch_tn_pair(pg_mat* A, TNArgs<T>& a, const T* r2, const T* x2, T* g
   }
   TNPair<T> b;
   b.r = r2, b.x = x2, b.g_out = g2, b.y = y2, b.z_new = z2, b.res = res2, b.partials = nullptr;
-  const int W = 4;  // (eight waves of U = 8, two per SIMD with 256 registers each: spills)
-  const int U = (a.nrg + W - 1) / W;
+  // Eight waves of U = ceil(nrg / 8) row groups, TWO columns per step, ONE register tile (two waves per SIMD cover each other's
+  // loads): measured at config 4's size (scripts/r5_pair_sweep_rate.py, profiles/r5_pair_sweep_rate.log) 9.26 ms against the single
+  // sweep's 9.09 -- both instances for 1.02 single sweeps, 0.885 of 8 TB/s -- where four waves of U = 16, one column per step and
+  // two tiles take 10.66 ms (1.17), eight waves with one column and two tiles 9.75 (1.07), four waves, two columns, one tile 9.62.
+  const int U = (a.nrg + 7) / 8;
   pg_status st = PG_ERR_UNSUPPORTED;
-#define PG_TNMP(UU, WW) \
-  if (U == UU && W == WW) st = launch_tnm_pair<T, UU, 1, WW, 2>(A, a, b, blocks_out)
-  PG_TNMP(9, 4); PG_TNMP(10, 4); PG_TNMP(11, 4); PG_TNMP(12, 4); PG_TNMP(13, 4); PG_TNMP(14, 4); PG_TNMP(15, 4); PG_TNMP(16, 4);
+#define PG_TNMP(UU) \
+  if (U == UU) st = launch_tnm_pair<T, UU, 2, 8, 1>(A, a, b, blocks_out)
+  PG_TNMP(5); PG_TNMP(6); PG_TNMP(7); PG_TNMP(8);
 #undef PG_TNMP
   *partials2_out = b.partials;
   return st;

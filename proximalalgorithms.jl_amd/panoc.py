@@ -53,7 +53,7 @@ class PANOCIteration:
 
     def __init__(self, *, f=None, A=None, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
                  minimum_gamma=1e-7, max_backtracks=20, directions=None, single_sweep=True, images=True,
-                 refresh_every=0):
+                 refresh_every=0, pair_trials=True):
         self.f = f if f is not None else Zero()
         if A is None:
             A = _Identity()
@@ -71,6 +71,10 @@ class PANOCIteration:
         self.max_backtracks = int(max_backtracks)
         self.directions = directions if directions is not None else LBFGS(5)  # :51
         self.counters = {"A_passes": 0}
+        # ZeroFPR: two trial points of the line search per sweep of A (zerofpr.py).  True = "every": every sweep of the line search
+        # carries its trial point and the next one; "always": only an iteration's first sweep (tau = 1 and 1/2); "hint": that, and
+        # only after an iteration that rejected tau = 1; False: one trial point per sweep (the reference's count)
+        self.pair_trials = pair_trials if isinstance(pair_trials, str) else bool(pair_trials)
         # A' grad f(A x) (:184), the forward-backward step (:197-199) and the A z of the next line search (fb_tools.jl:43)
         # in ONE read of A (pg_mat_fused_tn) when A is a device matrix and g one of the fused prox kinds
         self._fused_tn = bool(single_sweep) and isinstance(A, HIPMatrix) and hasattr(self.g, "g_kind") and \

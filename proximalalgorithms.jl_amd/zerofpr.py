@@ -43,6 +43,9 @@ class ZeroFPRIteration(PANOCIteration):
         for name in ("Axbar", "grad_f_Axbar", "Ad", "Az_next"):
             setattr(s, name, s.Ax.similar())
         s.Az_next_valid, s.Az_next_of, s.Az_next_is_res = False, None, False
+        # Two trial points of the line search per sweep (pg_mat_fused_tn_pair): a second set of everything a trial point writes.
+        # Allocated at the first use; `pair_hint` = the previous iteration rejected tau = 1 (then this one probably will too).
+        s.pair, s.pair_hint, s.pair_sweeps = bool(self._fused_tn) and bool(getattr(self, "pair_trials", True)), True, 0
         s.is_prev_set = False
         s.img = self._images and self._fused_tn and isinstance(s.H, LBFGSOperator)
         s.img_prev_set = False
@@ -119,22 +122,64 @@ class ZeroFPRIteration(PANOCIteration):
             s.Ad.axpby_(-1.0, s.Ad)
         else:
             self._mul(s.Ad, s.d)  # :194
-        for k in range(1, self.max_backtracks + 1):  # :200-217
-            s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :201
-            s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :202
-            s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :204-205
+        # :200-217.  Every trial point tau is a sweep of its own in the reference (A' grad f(A x), the forward-backward step; here
+        # also A xbar for the next iteration).  Here a sweep carries the trial point of tau AND of tau / 2 (two r slices, two
+        # accumulator sets on one register tile, pg_mat_fused_tn_pair): a rejected trial costs no further read of A, the one after
+        # it a sweep that again carries two.  The decisions are the reference's -- the second point is only looked at after the
+        # first was rejected.
+        TRIAL = ("x", "Ax", "grad_f_Ax", "At_grad_f_Ax", "y", "xbar", "res", "Az_next")
+        spec = None  # (tau, f_Ax, scalars) of a trial point the last pair sweep evaluated ahead
+        first_rejected = False
+        for k in range(1, self.max_backtracks + 1):
+            tau_next = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))  # :216
             fused = False
-            if self._fused_tn:  # :206-209 and the A xbar of the next iteration (fb_tools.jl:43 / :167) in one read of A
-                try:
-                    sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)
-                    s.g_xbar = sc[0]
-                    fused = True
-                except ProxGradError as e:
-                    if e.code != _lib.PG_ERR_UNSUPPORTED:
-                        raise
-                    self._fused_tn = False
+            if spec is not None and spec[0] == s.tau:  # evaluated ahead: the second set becomes the state, no sweep
+                for name in TRIAL:
+                    a_, b_ = getattr(s, name), getattr(s, name + "_sp")
+                    setattr(s, name, b_), setattr(s, name + "_sp", a_)
+                s.f_Ax, sc = spec[1], spec[2]
+                spec = None
+                fused = True
+            else:
+                spec = None
+                s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :201
+                s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :202
+                s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :204-205
+                # (measured at config 4's size, profiles/r5_pair_sweep_rate.log: a pair sweep costs 1.02 single sweeps, so the
+                # second point is carried whenever there is one -- "every"; "always" / "hint" restrict it to an iteration's first sweep /
+                # to the first sweep after an iteration that rejected tau = 1)
+                policy = self.pair_trials if isinstance(self.pair_trials, str) else "every"
+                want = (k == 1 and (s.pair_hint or policy != "hint")) or (policy == "every" and k > 1)
+                if self._fused_tn and s.pair and want and tau_next > 0:
+                    if not hasattr(s, "x_sp"):
+                        for name in TRIAL:
+                            setattr(s, name + "_sp", getattr(s, name).similar())
+                    s.x_sp.axpby_(1.0, s.xbar_prev, tau_next, s.d)
+                    s.Ax_sp.axpby_(1.0, s.Axbar, tau_next, s.Ad)
+                    f_sp, _ = value_and_gradient_into(self.f, s.Ax_sp, s.grad_f_Ax_sp)
+                    try:
+                        sc, sc2 = self.A.fused_tn_pair(s.grad_f_Ax, s.x, s.grad_f_Ax_sp, s.x_sp, s.gamma, self.g,
+                                                       (s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next),
+                                                       (s.At_grad_f_Ax_sp, s.y_sp, s.xbar_sp, s.res_sp, s.Az_next_sp))
+                        spec = (tau_next, f_sp, sc2)
+                        s.pair_sweeps += 1
+                        fused = True
+                    except ProxGradError as e:
+                        if e.code != _lib.PG_ERR_UNSUPPORTED:
+                            raise
+                        s.pair = False  # this column length has no two-point sweep: one trial point per sweep
+                if not fused and self._fused_tn:  # :206-209 and the A xbar of the next iteration (fb_tools.jl:43 / :167) in one read of A
+                    try:
+                        sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)
+                        fused = True
+                    except ProxGradError as e:
+                        if e.code != _lib.PG_ERR_UNSUPPORTED:
+                            raise
+                        self._fused_tn = False
+                if fused:
+                    self.counters["A_passes"] += 1
             if fused:
-                self.counters["A_passes"] += 1
+                s.g_xbar = sc[0]
                 s.Az_next_valid, s.Az_next_of = True, s.xbar
                 s.res_stats, s.res_inf = (sc[1], sc[2], sc[3]), sc[1]  # the sweep's own reductions of (At_grad, res)
             else:
@@ -147,7 +192,9 @@ class ZeroFPRIteration(PANOCIteration):
             FBE_x = R(self._model(s) + s.g_xbar)  # :210
             if FBE_x <= threshold:
                 break
-            s.tau = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))  # :216
+            first_rejected = first_rejected or k == 1
+            s.tau = tau_next  # :216
+        s.pair_hint = first_rejected
         return s
 
 

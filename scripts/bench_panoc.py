@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--loss", choices=["logistic", "sqdist"], default="logistic")
     ap.add_argument("--images", type=int, default=1, help="0: the explicit product A d (panoc.jl:180) instead of the L-BFGS image slab")
+    ap.add_argument("--pair-trials", default="1", help="ZeroFPR: 0 = one trial point of the line search per sweep (round 4); 1 = every (default); always; hint")
     ap.add_argument("--algo", choices=["panoc", "zerofpr", "panocplus", "ffb", "ffb-generic"], default="panoc",
                     help="ffb: FastForwardBackward (adaptive) on Composed(loss, A), engine 'composed' (one read of A per "
                          "iteration); ffb-generic: the same with separate GEMV passes")
@@ -42,7 +43,8 @@ def main():
     lam = dtype(0.1) * A.mul_adjoint(g0).norm_inf()
     newton = {"panoc": "PANOCIteration", "zerofpr": "ZeroFPRIteration", "panocplus": "PANOCplusIteration"}
     if args.algo in newton:
-        iteration = getattr(pa, newton[args.algo])(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype), images=bool(args.images))
+        iteration = getattr(pa, newton[args.algo])(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype), images=bool(args.images),
+                                                   pair_trials=args.pair_trials if args.pair_trials in ("always", "every", "hint") else bool(int(args.pair_trials)))
     else:
         iteration = pa.FastForwardBackwardIteration(f=pa.Composed(f, A), g=pa.NormL1(lam), x0=np.zeros(n, dtype),
                                                     engine="composed" if args.algo == "ffb" else "generic")
@@ -56,9 +58,12 @@ def main():
     ctx.profile_reset()
     ctx.sync()
     t0 = time.perf_counter()
+    taus = {}
     for _ in range(args.steps):
         s = next(it)
         float(s.res_inf if getattr(s, "res_inf", None) is not None else s.res.norm_inf()) / float(s.gamma) <= 1e-8
+        if hasattr(s, "tau"):
+            taus[str(float(s.tau))] = taus.get(str(float(s.tau)), 0) + 1
     ctx.sync()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
@@ -76,7 +81,8 @@ def main():
                         "achieved": passes * m * n * 4 / (gemv_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": passes * m * n * 4 / (gemv_ms * 1e-3) / 1e9 / 8000.0,
                         "gemv_time_fraction_of_step": gemv_ms * 1e-3 / dt},
-           "whole_iteration_GBps": passes * m * n * 4 / dt / 1e9,
+           "whole_iteration_GBps": passes * m * n * 4 / dt / 1e9, "accepted_tau_histogram": taus,
+           "pair_sweeps": int(getattr(s, "pair_sweeps", 0)),
            "final": {"gamma": float(s.gamma), "tau": float(getattr(s, "tau", 0.0)), "res_inf_over_gamma": float(s.res.norm_inf()) / float(s.gamma)}}
     print(json.dumps(out))
 

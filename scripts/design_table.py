@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Write the "Measured" table of DESIGN.md from the bench lines under profiles/ (run after
-scripts/publish_round4_profiles.sh): the table is transcribed by a program, not by hand.  Every line is taken from the NEWEST
-round that collected it (profiles/r4_<name>, else profiles/r3_<name>); the source column names the file actually used.
+scripts/publish_round5_profiles.sh): the table is transcribed by a program, not by hand.  Every line is taken from the NEWEST
+round that collected it (profiles/r5_<name>, else r4_, else r3_); the source column names the file actually used.
     python scripts/design_table.py           print the table
     python scripts/design_table.py --apply   replace the block between the <!-- measured:begin/end --> markers of DESIGN.md"""
 import json
@@ -17,8 +17,8 @@ USED = {}
 
 
 def pick(name):
-    """profiles/r4_<name> when this round collected it, else round 3's"""
-    for rnd in ("r4", "r3"):
+    """the newest round that collected <name>"""
+    for rnd in ("r5", "r4", "r3"):
         if os.path.exists(os.path.join(P, f"{rnd}_{name}")):
             USED[name] = rnd
             return f"{rnd}_{name}"
