@@ -91,6 +91,26 @@ def main():
         ", ".join(("sweep" if k == "gemv_tn" else f"`{k}`") + f" {pk[k]['avg_ms']:.2f} ms" for k in ks),
         " / ".join(f"{pk[k]['GBps'] / 1e3:.2f}" for k in ks) + " TB/s", " / ".join(f"{pk[k]['GBps'] / 8e3:.3f}" for k in ks),
         "`also[3]`, " + src("bench_panoc.json"))
+    try:  # round 5: ZeroFPR with two trial points of its line search per sweep, beside one per sweep (round 4) and PANOCplus
+        zf, z1, pp = line("r3_bench_zerofpr.json"), line("r3_bench_zerofpr_single_trials.json"), line("r3_bench_panocplus.json")
+        add("config 4's family, first 23 iterations: ZeroFPR with two trial points per sweep / one per sweep (round 4) / PANOCplus",
+            f"**{zf['value']:.1f}** / {z1['value']:.1f} / {pp['value']:.1f}",
+            f"reads of A per iteration {zf['A_passes_per_step']:.2f} / {z1['A_passes_per_step']:.2f} / {pp['A_passes_per_step']:.2f}",
+            " / ".join(f"{x['roofline']['achieved'] / 1e3:.2f}" for x in (zf, z1, pp)) + " TB/s (all sweeps)",
+            " / ".join(f"{x['roofline']['frac']:.3f}" for x in (zf, z1, pp)), src("bench_zerofpr.json", "bench_zerofpr_single_trials.json", "bench_panocplus.json"))
+    except SystemExit:
+        pass
+    try:  # round 5: north_star's row layout as `bench.py --gpus 2` reports it (two rank PROCESSES on this one device, gloo)
+        for key, nrows in (("2rank_rows_2048", 2048), ("2rank_rows_16384", 16384)):
+            t = line(f"r3_bench_{key}.json")
+            two = t.get("rows_two_sweeps") or {}
+            cfg = t["config"]
+            agg = t["value"] * cfg["m"] * cfg["n"] * 4 / 1e12
+            add(f"row layout, 2 processes x {nrows} rows on this device: top-level record (`row_layout` = {cfg.get('row_layout')}) / the two-sweep record it replaced",
+                f"**{t['value']:.1f}** / {two.get('value', float('nan')):.1f}", f"sweep {t['roofline']['avg_launch_ms']:.2f} ms per rank",
+                f"{agg:.2f} TB/s (A per iteration, both ranks)", f"{agg / 8:.3f}", src(f"bench_{key}.json") + ", `r5_row_team_latency_sweep.md`")
+    except (SystemExit, KeyError):
+        pass
     lf, la, l6 = line("r3_bench_long_131072.json"), line("r3_bench_long_131072_adaptive.json"), line("r3_bench_long_65536.json")
     add("long columns 131072 × 131072 (config 5's per-GPU block under column shards), fixed / adaptive",
         f"**{lf['value']:.1f} / {la['value']:.1f}** with ONE read of A", f"`gemv_tnt<16,1,4,2,2>` (cooperative launch) {lf['roofline']['avg_launch_ms']:.2f} ms",

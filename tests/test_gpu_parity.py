@@ -556,6 +556,9 @@ def test_bench_line_contract(pa, cpu_mode):
     assert ("full workload" in c["sample"]) == (cpu_mode == "full")
 
 
+_ONE_RANK_LINES = {}
+
+
 @pytest.mark.parametrize("mode,sharding,overlap", [("fixed", "rows", False), ("adaptive", "rows", False), ("fixed", "rows", True),
                                                    ("fixed", "cols", False), ("fixed", "auto", False), ("adaptive", "cols", False),
                                                    ("fixed", "rows-teams", False), ("adaptive", "rows-teams", False)])
@@ -563,8 +566,10 @@ def test_two_ranks_one_gpu_matches_single_rank(pa, mode, sharding, overlap):
     """bench.py with 2 processes sharing cuda:0 over gloo == 1 process: same lambda / Lf (they come from all-reduced
     quantities) and the same iterate after 14 steps -- row shards (1024 rows each, two sweeps, [grad ; f] all-reduced)
     and column shards (8192 columns each, the single-sweep iteration with one all-reduce of m + 8 elements)."""
-    one = _run_bench(["--mode", mode, "--sweeps", "two"])
-    one_ss = _run_bench(["--mode", mode])  # single sweep (default): same problem, same answers, half the reads of A
+    # (the single-rank lines are the same for every layout: measured once per mode -- eight cases used to start sixteen of them)
+    if mode not in _ONE_RANK_LINES:
+        _ONE_RANK_LINES[mode] = (_run_bench(["--mode", mode, "--sweeps", "two"]), _run_bench(["--mode", mode]))
+    one, one_ss = _ONE_RANK_LINES[mode]  # two sweeps / single sweep (default): same problem, same answers, half the reads of A
     assert one_ss["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1) and one["config"]["a_passes_per_step"] >= 2
     assert one_ss["config"]["final"]["f_x"] == pytest.approx(one["config"]["final"]["f_x"], rel=2e-4)
     assert one_ss["config"]["final"]["g_z"] == pytest.approx(one["config"]["final"]["g_z"], rel=2e-4)
@@ -1037,14 +1042,18 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
         assert len(lines) == 1, lines
         return json.loads(lines[0])
 
+    failed = []
+
     def rates_ok(d):
         """the thresholds on measured rates (everything else below is structure, checked on every line)"""
         ad, c2, c3, c4, c5c, c5r = d["also"][:6]
-        return (d["roofline"]["frac"] > 0.6  # north_star: >= 60 % of the HBM roofline
-                and abs(d["sustained"]["value"] / d["value"] - 1.0) < 0.05  # the K-step figure is not a burst
-                and c5c["roofline"]["frac"] > 0.8 and c5r["roofline"]["frac"] > 0.75 and ad["roofline"]["frac"] > 0.6
-                and c2["roofline"]["frac"] > 0.6 and c4["roofline"]["frac"] > 0.5
-                and c3["device_loop"]["value"] > c3["stepping"]["value"])
+        checks = {"headline frac > 0.6 (north_star)": d["roofline"]["frac"] > 0.6,
+                  "sustained within 5 % of the K-step figure": abs(d["sustained"]["value"] / d["value"] - 1.0) < 0.05,
+                  "config5_column_block frac > 0.8": c5c["roofline"]["frac"] > 0.8, "headline_row_block_n8 frac > 0.75": c5r["roofline"]["frac"] > 0.75,
+                  "adaptive frac > 0.6": ad["roofline"]["frac"] > 0.6, "config2 frac > 0.6": c2["roofline"]["frac"] > 0.6,
+                  "config4 frac > 0.5": c4["roofline"]["frac"] > 0.5, "config3 loop faster than stepping": c3["device_loop"]["value"] > c3["stepping"]["value"]}
+        failed[:] = [k for k, ok in checks.items() if not ok]
+        return not failed
 
     def structure(d):
         assert d["config"]["m"] == 16384 and d["config"]["n"] == 1 << 20 and d["config"]["mode"] == "fixed" and d["steps"] == 6
@@ -1089,7 +1098,7 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
             shared = c5c["roofline"]["frac"] < 0.6 and plain["roofline"]["frac"] > 0.8
             if shared:
                 c5c["roofline"]["frac"] = plain["roofline"]["frac"]  # the sweep itself is fine: judge the rest of the line
-            assert rates_ok(d), (first, {r["label"]: (r.get("roofline") or {}).get("frac") for r in d["also"]}, d["roofline"]["frac"], d["sustained"])
+            assert rates_ok(d), (failed, first, {r["label"]: (r.get("roofline") or {}).get("frac") for r in d["also"]}, d["roofline"]["frac"], d["sustained"])
             if shared:
                 import warnings
 
@@ -2013,24 +2022,25 @@ def test_two_point_sweep_equals_two_single_sweeps(pa, dtype):
 def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy):
     """ZeroFPR's line search with two trial points per sweep (zerofpr.py over pg_mat_fused_tn_pair): the
     trial point of tau / 2 is evaluated speculatively in the sweep of tau and looked at only after tau was rejected, so the
-    DECISIONS are the reference's.  Float64, logistic + L1 on 6000 x 400 (47 row groups: inside the pair kernel's range), adaptive
+    DECISIONS are the reference's.  Float64, logistic + L1 on 6000 x 24000 (47 row groups: inside the pair kernel's range), adaptive
     step: the same gamma and tau at every iteration as the oracle (zerofpr.jl:142-220 restated), iterates to 1e-8, fewer reads of A
     than with one trial point per sweep -- under all three policies (every first sweep / the first sweep after a rejected tau = 1 /
     True = every sweep of the search, the default)."""
     dtype = np.float64
     rng = np.random.default_rng(4)
-    m, n = 6000, 400
+    m, n = 6000, 24000  # (under-determined like config 4: on tall problems the search never leaves tau = 1)
     A = np.asfortranarray(rng.standard_normal((m, n)) / np.sqrt(m))
     xt = np.zeros(n)
-    xt[rng.choice(n, 20, replace=False)] = 3.0 * rng.standard_normal(20)
-    b = np.sign(A @ xt + 0.1 * rng.standard_normal(m))
-    lam = dtype(0.002 * m)
+    xt[rng.choice(n, n // 1000, replace=False)] = rng.standard_normal(n // 1000)
+    b = A @ xt + 0.01 * rng.standard_normal(m)
+    _, g0 = o.LogisticLoss(b).value_and_gradient(np.zeros(m))
+    lam = dtype(0.1 * np.max(np.abs(A.T @ g0)))
     x0 = np.zeros(n, dtype)
     it_g = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=policy)
     it_1 = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=False)
     it_o = o.ZeroFPRIteration(f=o.LogisticLoss(b), A=A, g=o.NormL1(lam), x0=x0)
     taus = []
-    for k, (sg, s1, so) in enumerate(itertools.islice(zip(it_g, it_1, it_o), 30)):
+    for k, (sg, s1, so) in enumerate(itertools.islice(zip(it_g, it_1, it_o), 25)):
         assert float(sg.gamma) == pytest.approx(float(so.gamma), rel=1e-12), k
         assert float(sg.tau) == float(so.tau) == float(s1.tau), (k, float(sg.tau), float(so.tau))
         assert np.max(np.abs(sg.xbar.numpy() - so.xbar)) <= 1e-8 * max(1.0, np.max(np.abs(so.xbar))), k
