@@ -1519,7 +1519,7 @@ def run_rank(args, job, wd, world, rank, local_rank):
             # resident, every wave polls -- ~1 it/s; a one-GPU rehearsal artefact, no configuration anyone runs)
             why_not = "more than four rank processes share one device: their sweeps would be time-sliced, not co-resident"
         if why_not is None:
-            row_team_records_in_a_child(args, job, wd, ctx, world, rank)
+            row_team_records_in_a_child(args, job, wd, ctx, world, rank, freed_bytes=freed[0] if args.settle else 0)
             if rank == 0:
                 promote_row_team_record(args, job)
         elif layout == "rows" and not args.row_teams:
@@ -1676,7 +1676,7 @@ def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
     return 0
 
 
-def row_team_records_in_a_child(args, job, wd, ctx, world, rank):
+def row_team_records_in_a_child(args, job, wd, ctx, world, rank, freed_bytes=0):
     """parent side of row_team_child: free this rank's blocks, start the child (same ranks, another rendezvous port), wait,
     merge rank 0's records into the line.  Whatever the child does -- refuses, times out, dies of a GPU fault -- the records
     measured before it stand and the exit code is not its business."""
@@ -1684,6 +1684,8 @@ def row_team_records_in_a_child(args, job, wd, ctx, world, rank):
 
     gc.collect()
     ctx.sync()
+    if freed_bytes > (1 << 30):  # the block this rank just gave back is still being cleared in the background: kernels running
+        time.sleep(min(6.0, freed_bytes / 30e9 + 0.3))  # meanwhile lose a few percent (see `settle` in run_rank) -- the child's would
     budget = args.record_timeout + args.sub_record_timeout + args.init_timeout + 60.0
     wd.enter("row_teams_child", budget + 30.0, stall=False)
     t0 = time.perf_counter()

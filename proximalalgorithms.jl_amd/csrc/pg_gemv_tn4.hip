@@ -205,28 +205,32 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
 
 }  // namespace
 
+#ifndef PG_TN4_FLOAT64_UNIT
 bool tn_peer_covers(int nrg) { return nrg >= 1 && nrg <= 64; }
+#endif
 
 namespace {
 struct PeerGeom {
   int W, C, LAG, LAGR, PF, WGS;
 };
-// Float32 geometry of the row-team sweep by the team's longest block in row groups (profiles/r5_row_team_latency_sweep.md).
+// Geometry of the row-team sweep by the team's longest block in row groups of 1 KiB (profiles/r5_row_team_latency_sweep.md; measured
+// in Float32 -- Float64 takes the same table by row groups: 128 rows each, the same registers per row group, two granules per value).
 // One rule for every length: a WAVE streams 16 KiB tiles of its rows (U <= 8 row groups of C = 2 columns, or U <= 16 of one
 // column), four waves per compute unit (one per SIMD, the whole 512-entry register file each), so W = ceil(row groups / 16)
 // waves share a column -- ONE up to 2048 rows: no barrier, no cross-wave sum, the wave posts and polls for itself -- and 4 / W
 // workgroups sit on a compute unit; two tiles in flight (PF), two waiting in LDS (LAG: 128 KiB per compute unit) and two more
 // in registers (LAGR): 256 KiB of parked tiles per compute unit, 10-11 us for a step's granules to arrive where round 4's
 // geometries (four waves per column at every length, LAG = 2 only) had 5-6.
-PeerGeom peer_geometry_f32(int nrg) {
+PeerGeom peer_geometry(int nrg, bool f64) {
   const int W = nrg <= 8 ? 1 : nrg <= 32 ? 2 : 4;
   const int U = (nrg + W - 1) / W;
-  return {W, U <= 4 ? 4 : U <= 8 ? 2 : 1, 2, 2, 2, 4 / W};
+  // (Float64: C = 2 also for the shortest blocks -- 16 devices x C columns x two granules must fit the 64 lanes that poll them)
+  return {W, U <= 4 && !f64 ? 4 : U <= 8 ? 2 : 1, 2, 2, 2, 4 / W};
 }
 }  // namespace
 
-// every Float32 instantiation: (U, C, LAG, PF, LAGR, W); _D: also with the latency injector (the geometries of the latency sweep)
-#define PG_TNP_F32_GEOMETRIES \
+// every instantiation (both element types): (U, C, LAG, PF, LAGR, W); _D: also with the latency injector (the geometries of the latency sweep)
+#define PG_TNP_GEOMETRIES \
   PG_TNP_CASE_D(8, 2, 2, 2, 2, 1); PG_TNP_CASE_D(8, 2, 2, 2, 2, 2); PG_TNP_CASE_D(16, 1, 2, 2, 2, 2); \
   PG_TNP_CASE_D(16, 1, 2, 2, 2, 4); PG_TNP_CASE_D(2, 2, 2, 2, 0, 4); PG_TNP_CASE_D(4, 2, 2, 2, 0, 4); \
   PG_TNP_CASE_D(8, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 1, 4); \
@@ -254,9 +258,7 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // power of two's geometry: 2 x 2049 rows streamed 4.0 TB/s that way in round 4 where 2 x 2048 streamed 5.9; PG_TNP_EXACT=0
   // under PG_TUNE: the powers of two only, for A/B runs), columns per step C, lag steps in LDS (LAG) and in registers (LAGR),
   // tiles in flight (PF), workgroups per compute unit (0: as many as the parked tiles leave LDS for).
-  // Float64 keeps round 4's geometries (four waves per column; its values take two granules each).
-  PeerGeom g = {4, (team_nrg + 3) / 4 >= 5 ? 1 : 2, 2, 0, 2, 0};
-  if constexpr (sizeof(T) == 4) g = peer_geometry_f32(team_nrg);
+  const PeerGeom g = peer_geometry(team_nrg, sizeof(T) == 8);
   const int W = env_int("PG_TNP_W", g.W);
   const int per_wave = (team_nrg + W - 1) / W;
   int U = per_wave < 2 && W == 4 ? 2 : per_wave;
@@ -272,24 +274,22 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 #define PG_TNP_CASE_D(UU, CC, LL, PP, RR, WW)                                                           \
   PG_TNP_CASE(UU, CC, LL, PP, RR, WW);                                                                  \
   if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, WW>(A, a, blocks_out, WGS)
-  if constexpr (sizeof(T) == 4) {
-    PG_TNP_F32_GEOMETRIES;
-  } else {
-    PG_TNP_CASE(2, 4, 4, 2, 0, 4); PG_TNP_CASE(4, 2, 4, 2, 0, 4); PG_TNP_CASE(8, 1, 4, 2, 0, 4); PG_TNP_CASE(16, 1, 2, 2, 0, 4);
-    PG_TNP_CASE(2, 4, 2, 2, 0, 4); PG_TNP_CASE(8, 1, 2, 2, 0, 4); PG_TNP_CASE(4, 2, 2, 2, 0, 4); PG_TNP_CASE(2, 2, 2, 2, 0, 4);
-    PG_TNP_CASE(4, 1, 2, 2, 0, 4); PG_TNP_CASE(3, 2, 2, 2, 0, 4);
-    PG_TNP_CASE(5, 1, 2, 2, 0, 4); PG_TNP_CASE(6, 1, 2, 2, 0, 4); PG_TNP_CASE(7, 1, 2, 2, 0, 4);
-    PG_TNP_CASE(9, 1, 2, 2, 0, 4); PG_TNP_CASE(10, 1, 2, 2, 0, 4); PG_TNP_CASE(11, 1, 2, 2, 0, 4); PG_TNP_CASE(12, 1, 2, 2, 0, 4);
-    PG_TNP_CASE(13, 1, 2, 2, 0, 4); PG_TNP_CASE(14, 1, 2, 2, 0, 4); PG_TNP_CASE(15, 1, 2, 2, 0, 4);
+  PG_TNP_GEOMETRIES;
+  if constexpr (sizeof(T) == 8) {
+    PG_TNP_CASE(1, 2, 2, 2, 2, 1); PG_TNP_CASE(2, 2, 2, 2, 2, 1); PG_TNP_CASE(3, 2, 2, 2, 2, 1); PG_TNP_CASE(4, 2, 2, 2, 2, 1);
   }
 #undef PG_TNP_CASE
 #undef PG_TNP_CASE_D
   pg_set_error("no row-team instantiation for W=%d U=%d C=%d LAG=%d PF=%d LAGR=%d%s", W, U, C, LAG, PF, LAGR, delay ? " with the latency injector" : "");
   return PG_ERR_UNSUPPORTED;
 }
-template pg_status launch_tn_peer<float>(pg_mat*, TNArgs<float>&, int*);
+#ifdef PG_TN4_FLOAT64_UNIT  // (the instantiations are compiled in two translation units, side by side: pg_gemv_tn4d.hip is this file again)
 template pg_status launch_tn_peer<double>(pg_mat*, TNArgs<double>&, int*);
+#else
+template pg_status launch_tn_peer<float>(pg_mat*, TNArgs<float>&, int*);
+#endif
 
+#ifndef PG_TN4_FLOAT64_UNIT
 size_t peer_inbox_bytes() { return PEER_RING_BYTES + PEER_SCAL_BYTES; }
 
 // f_out = sum over the devices of *f_local (device order), PG_S_TEAMERR = any device's flag: one launch, no collective
@@ -315,6 +315,10 @@ static pg_status peer_exchange(pg_ctx* c, const double* f_local, double* f_out, 
 
 pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out) { return peer_exchange(c, f_local, f_out, 0u, nullptr); }
 
+#endif
+
 }  // namespace pgtn
 
+#ifndef PG_TN4_FLOAT64_UNIT
 pg_status pg_rteam_sum_scalar(pg_ctx* c, const double* local, double* out) { return pgtn::peer_scalar_exchange(c, local, out); }
+#endif

@@ -73,8 +73,8 @@ if want misc; then
   rocprofv3 --kernel-trace --stats -d $O/prof_zerofpr -- python3 scripts/bench_panoc.py --algo zerofpr --steps 23 --warmup 0 > $O/prof_zerofpr.log 2>&1
   python scripts/rocpd_summary.py $O/prof_zerofpr/*/*_results.db > $O/prof_zerofpr.md 2>&1
   # north_star's layout as the driver's N > 1 command runs it, two rank processes on this one device (gloo): rows on top, upgraded to the row team
-  python bench.py --gpus 2 --share-device --backend gloo --m 4096 --n 1048576 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_2rank_rows_2048.json 2> $O/bench_2rank_rows_2048.err
-  python bench.py --gpus 2 --share-device --backend gloo --m 32768 --n 131072 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_2rank_rows_16384.json 2> $O/bench_2rank_rows_16384.err
+  python bench.py --gpus 2 --share-device --backend gloo --m 4096 --n 1048576 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_rows_2048.json 2> $O/bench_2rank_rows_2048.err
+  python bench.py --gpus 2 --share-device --backend gloo --m 32768 --n 131072 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_rows_16384.json 2> $O/bench_2rank_rows_16384.err
   hipcc -O3 --offload-arch=gfx950 scripts/stream_ceiling.hip -o /tmp/stream_ceiling && /tmp/stream_ceiling 64 > $O/stream_ceiling.log 2>&1
 fi
 ls -la $O | head -100

@@ -58,6 +58,23 @@ CASES = [
     (["--m", "32768", "--n", "4096"], "default"),                                  # 2 x 16384 (config 5's block): W = 4, U = 16
     (["--m", "32768", "--n", "4096", "--delay-ns", "6000"], "default"),
     (["--m", "49152", "--n", "1024", "--ranks", "3", "--adaptive"], "default"),
+    # Float64: the same table by row groups of 128 rows (two granules per value)
+    (["--m", "2048", "--n", "4096", "--dtype", "f64"], "default"),                 # 2 x 1024 rows = 8 row groups: W = 1, U = 8
+    (["--m", "2048", "--n", "4096", "--dtype", "f64", "--ranks", "4"], "default"), # 4 row groups: U = 4, C = 2
+    (["--m", "1500", "--n", "1001", "--dtype", "f64", "--ranks", "3"], "default"), # 500 rows: U = 4 ragged
+    (["--m", "700", "--n", "513", "--dtype", "f64", "--ranks", "2"], "default"),   # 350 rows: U = 3
+    (["--m", "400", "--n", "513", "--dtype", "f64", "--ranks", "2"], "default"),   # 200 rows: U = 2
+    (["--m", "200", "--n", "513", "--dtype", "f64", "--ranks", "2"], "default"),   # 100 rows: U = 1
+    (["--m", "1600", "--n", "513", "--dtype", "f64"], "default"),                  # 800 rows: U = 7
+    (["--m", "3000", "--n", "513", "--dtype", "f64"], "default"),                  # 1500 rows, 12 row groups: W = 2, U = 6
+    (["--m", "4096", "--n", "4096", "--dtype", "f64"], "default"),                 # 2 x 2048 rows = 16 row groups: W = 2, U = 8
+    (["--m", "4096", "--n", "4096", "--dtype", "f64", "--delay-ns", "5000", "--adaptive"], "default"),
+    (["--m", "6000", "--n", "513", "--dtype", "f64"], "default"),                  # 24 row groups: W = 2, U = 12
+    (["--m", "8192", "--n", "2048", "--dtype", "f64"], "default"),                 # 32 row groups: W = 2, U = 16
+    (["--m", "10753", "--n", "257", "--dtype", "f64"], "default"),                 # 5377 rows, 43 row groups: W = 4, U = 11
+    (["--m", "16384", "--n", "2048", "--dtype", "f64"], "default"),                # 2 x 8192 rows = 64 row groups: W = 4, U = 16
+    (["--m", "16384", "--n", "2048", "--dtype", "f64", "--delay-ns", "6000"], "default"),
+    (["--m", "5000", "--n", "1001", "--ranks", "3", "--dtype", "f64", "--g", "boxv", "--fast", "0"], "default"),
     # round 4's geometries (four waves per column, LAG = 2 only): still instantiated for the "before" curve
     (["--m", "4096", "--n", "8192"], "2:2:0:2:4:4"),
     (["--m", "8192", "--n", "4096"], "2:2:0:2:2:4"),
