@@ -1048,7 +1048,9 @@ def test_bench_default_line_carries_every_single_gpu_config(pa):
         """the thresholds on measured rates (everything else below is structure, checked on every line)"""
         ad, c2, c3, c4, c5c, c5r = d["also"][:6]
         checks = {"headline frac > 0.6 (north_star)": d["roofline"]["frac"] > 0.6,
-                  "sustained within 5 % of the K-step figure": abs(d["sustained"]["value"] / d["value"] - 1.0) < 0.05,
+                  # (the K-step figure is not a BURST: at most 5 % above what the same iteration sustains for 5 s; six timed steps
+                  # right after two warm-up steps may well be a little below it)
+                  "K-step figure within -10 % .. +5 % of the sustained one": -0.10 < d["value"] / d["sustained"]["value"] - 1.0 < 0.05,
                   "config5_column_block frac > 0.8": c5c["roofline"]["frac"] > 0.8, "headline_row_block_n8 frac > 0.75": c5r["roofline"]["frac"] > 0.75,
                   "adaptive frac > 0.6": ad["roofline"]["frac"] > 0.6, "config2 frac > 0.6": c2["roofline"]["frac"] > 0.6,
                   "config4 frac > 0.5": c4["roofline"]["frac"] > 0.5, "config3 loop faster than stepping": c3["device_loop"]["value"] > c3["stepping"]["value"]}
