@@ -253,7 +253,7 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
     return PG_ERR_UNSUPPORTED;
   }
   const int team_nrg = A->team_nrg;
-  // Geometry by the team's longest block (peer_geometry_f32): waves per workgroup W (the rows of a column are split over them), row
+  // Geometry by the team's longest block (peer_geometry): waves per workgroup W (the rows of a column are split over them), row
   // groups per wave U = ceil(row groups / W) EXACTLY (a block one row past a boundary is one more row group per wave, not the next
   // power of two's geometry: 2 x 2049 rows streamed 4.0 TB/s that way in round 4 where 2 x 2048 streamed 5.9; PG_TNP_EXACT=0
   // under PG_TUNE: the powers of two only, for A/B runs), columns per step C, lag steps in LDS (LAG) and in registers (LAGR),
