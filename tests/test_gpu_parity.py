@@ -816,78 +816,6 @@ def test_saved_state_resumes_bit_identically(pa, fast, adaptive, g):
         next(make().resume(blob[: len(blob) // 2]))
 
 
-def test_resume_into_a_batched_run_and_of_a_solve_that_left_the_single_sweep(pa):
-    """ADVICE r4 (low), the two gaps of pg_iter_state_upload.  (b) A saved single-sweep state carries f at its speculative point
-    in the scalar block (PG_S_FNEXT + slot) as well; pg_iter_run_batched takes f(x) of the first iteration after a resume from
-    THERE with the batch's one read-back -- a fresh context never held it, so a batch that ended on that iteration reported a
-    wrong f_x.  (a) A solve that left the single-sweep mode at run time (here: a refused team sweep, pg_ctx_test_team_fault kind
-    1) saves single_sweep = 0; a fresh iterator with the same options has it on and refused the blob."""
-    import gc
-
-    from proximalalgorithms.jl_amd import _lib
-    from proximalalgorithms.jl_amd._fused import FusedIteration
-
-    dtype = np.float32
-    # (b) fixed-step FastForwardBackward, one wave per column group (1500 rows); the stepped solve is the reference
-    m, n = 1500, 2600
-    A, b, lam = synthetic_problem(m, n, dtype, seed=11)
-    Lf = dtype(power_Lf(A))
-    f = pa.LeastSquares(A, b)
-    x0 = pa.HIPVector.from_numpy(np.zeros(n, dtype))
-    mk = lambda: FusedIteration(f, pa.NormL1(lam), fast=True, Lf=Lf, gamma=None, adaptive=False, minimum_gamma=1e-7, reduce_gamma=0.5,
-                                increase_gamma=1.0, mf=0.0, seq_kind=_lib.PG_SEQ_ADAPTIVE, seq_p0=0.0, seq_p1=0.0,
-                                reuse_residual=True, single_sweep=True)
-    ref = mk()
-    ref.init(x0)
-    fx = []
-    for _ in range(14):
-        sc = ref.step()
-        fx.append(float(sc.f_x))
-    z_ref = ref.view()["z"].numpy().copy()
-    first = mk()
-    first.init(x0)
-    for _ in range(9):
-        first.step()
-    blob = first.state_download()
-    del first
-    gc.collect()
-    for first_batch in (1, 2, 5):  # iterations the first batch after the resume holds (1: it ends on the resumed iteration itself)
-        again = mk()
-        again.state_upload(blob)
-        k, sc = again.run(0, first_batch, 0.0, check_every=4)
-        assert k == first_batch and float(sc.f_x) == fx[9 + first_batch - 1], (first_batch, float(sc.f_x), fx[9 + first_batch - 1])
-        if first_batch == 5:
-            assert np.array_equal(again.view()["z"].numpy(), z_ref)
-        del again
-    # (a) a team sweep (40000 rows) whose third launch is refused: the iterator redoes that step with two sweeps and stays there
-    m, n = 40000, 64
-    A, b, lam = synthetic_problem(m, n, dtype, seed=5)
-    Lf = dtype(power_Lf(A))
-    f = pa.LeastSquares(A, b)
-    ctx = f.ctx
-    make = lambda: pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=np.zeros(n, dtype), Lf=Lf, engine="fused")
-
-    def degraded(steps):
-        _lib.call("pg_ctx_test_team_fault", ctx.handle, 3, 1)
-        itn = make()
-        states = []
-        for s in itertools.islice(itn, steps):
-            states.append((s.z.numpy().copy(), float(s.f_x), int(s.flags)))
-        _lib.call("pg_ctx_test_team_fault", ctx.handle, 0, 0)
-        return itn, states
-
-    _, straight = degraded(12)
-    assert any(fl & pa.PG_FLAG_SWEEP_FALLBACK for _, _, fl in straight), [fl for _, _, fl in straight]
-    itn, head = degraded(7)
-    blob = itn.save_state()
-    del itn
-    gc.collect()
-    resumed = make()  # single_sweep on, as created -- the blob says the saved solve had left it
-    for k, s in enumerate(itertools.islice(resumed.resume(blob), 5), start=7):
-        assert np.array_equal(s.z.numpy(), straight[k][0]) and float(s.f_x) == straight[k][1], k
-    assert resumed.counters["a_passes"] >= 2 * 4, resumed.counters  # two reads of A per resumed iteration
-
-
 @pytest.mark.parametrize("cols,batched", [(True, False), (False, True), (True, True)])
 def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_fault_runs, cols, batched):
     """a REFUSED cooperative launch (injected: pg_ctx_test_team_fault kind 1) must be survivable where a
@@ -2744,3 +2672,79 @@ def test_destroy_gives_the_device_memory_back(pa):
     assert base - after < (32 << 20), (base, after)  # nothing accumulates (a leaked matrix alone would be 512 MiB per round)
     del ctx
     assert free_bytes() >= after
+
+
+def test_resume_into_a_batched_run_and_of_a_solve_that_left_the_single_sweep(pa):
+    """ADVICE r4 (low), the two gaps of pg_iter_state_upload.  (b) A saved single-sweep state carries f at its speculative point
+    in the scalar block (PG_S_FNEXT + slot) as well; pg_iter_run_batched takes f(x) of the first iteration after a resume from
+    THERE with the batch's one read-back -- a fresh context never held it, so a batch that ended on that iteration reported a
+    wrong f_x.  (a) A solve that left the single-sweep mode at run time (here: a refused team sweep, pg_ctx_test_team_fault kind
+    1) saves single_sweep = 0; a fresh iterator with the same options has it on and refused the blob.
+    (At the END of the file on purpose: part (a) launches a team sweep COOPERATIVELY from this pytest process, and from then on
+    every cooperative kernel of another process on the device -- the bench.py subprocesses of the tests above -- alternates with this
+    process's idle cooperative queue: test_bench_default_line... measured its 2048-row record below 0.75 behind it, found by
+    scripts/r5_bisect_default_line.py; profiles/r3_team_coop_vs_plain.md.)"""
+    import gc
+
+    from proximalalgorithms.jl_amd import _lib
+    from proximalalgorithms.jl_amd._fused import FusedIteration
+
+    dtype = np.float32
+    # (b) fixed-step FastForwardBackward, one wave per column group (1500 rows); the stepped solve is the reference
+    m, n = 1500, 2600
+    A, b, lam = synthetic_problem(m, n, dtype, seed=11)
+    Lf = dtype(power_Lf(A))
+    f = pa.LeastSquares(A, b)
+    x0 = pa.HIPVector.from_numpy(np.zeros(n, dtype))
+    mk = lambda: FusedIteration(f, pa.NormL1(lam), fast=True, Lf=Lf, gamma=None, adaptive=False, minimum_gamma=1e-7, reduce_gamma=0.5,
+                                increase_gamma=1.0, mf=0.0, seq_kind=_lib.PG_SEQ_ADAPTIVE, seq_p0=0.0, seq_p1=0.0,
+                                reuse_residual=True, single_sweep=True)
+    ref = mk()
+    ref.init(x0)
+    fx = []
+    for _ in range(14):
+        sc = ref.step()
+        fx.append(float(sc.f_x))
+    z_ref = ref.view()["z"].numpy().copy()
+    first = mk()
+    first.init(x0)
+    for _ in range(9):
+        first.step()
+    blob = first.state_download()
+    del first
+    gc.collect()
+    for first_batch in (1, 2, 5):  # iterations the first batch after the resume holds (1: it ends on the resumed iteration itself)
+        again = mk()
+        again.state_upload(blob)
+        k, sc = again.run(0, first_batch, 0.0, check_every=4)
+        assert k == first_batch and float(sc.f_x) == fx[9 + first_batch - 1], (first_batch, float(sc.f_x), fx[9 + first_batch - 1])
+        if first_batch == 5:
+            assert np.array_equal(again.view()["z"].numpy(), z_ref)
+        del again
+    # (a) a team sweep (40000 rows) whose third launch is refused: the iterator redoes that step with two sweeps and stays there
+    m, n = 40000, 64
+    A, b, lam = synthetic_problem(m, n, dtype, seed=5)
+    Lf = dtype(power_Lf(A))
+    f = pa.LeastSquares(A, b)
+    ctx = f.ctx
+    make = lambda: pa.FastForwardBackwardIteration(f=f, g=pa.NormL1(lam), x0=np.zeros(n, dtype), Lf=Lf, engine="fused")
+
+    def degraded(steps):
+        _lib.call("pg_ctx_test_team_fault", ctx.handle, 3, 1)
+        itn = make()
+        states = []
+        for s in itertools.islice(itn, steps):
+            states.append((s.z.numpy().copy(), float(s.f_x), int(s.flags)))
+        _lib.call("pg_ctx_test_team_fault", ctx.handle, 0, 0)
+        return itn, states
+
+    _, straight = degraded(12)
+    assert any(fl & pa.PG_FLAG_SWEEP_FALLBACK for _, _, fl in straight), [fl for _, _, fl in straight]
+    itn, head = degraded(7)
+    blob = itn.save_state()
+    del itn
+    gc.collect()
+    resumed = make()  # single_sweep on, as created -- the blob says the saved solve had left it
+    for k, s in enumerate(itertools.islice(resumed.resume(blob), 5), start=7):
+        assert np.array_equal(s.z.numpy(), straight[k][0]) and float(s.f_x) == straight[k][1], k
+    assert resumed.counters["a_passes"] >= 2 * 4, resumed.counters  # two reads of A per resumed iteration
