@@ -17,15 +17,20 @@ class LBFGSOperator:
         call("pg_lbfgs_create", self.ctx.handle, pg_dtype(self.dtype), self.M, self.n, C.byref(h))
         self._h = h
         self._finalizer = weakref.finalize(self, _lib.load().pg_lbfgs_destroy, h)
+        # update_ calls since the last reset_: 0 means the memory is certainly EMPTY (then mul! is the identity: lbfgs.jl:52-55,
+        # 64-71 with currmem = 0 and H = 1); > 0 means "perhaps not" (an update with <s, y> <= 0 is skipped on the device, :33)
+        self.updates_since_reset = 0
 
     def update_(self, s, y):
         """update!(L, s, y)  lbfgs.jl:30-50"""
         call("pg_lbfgs_update", self._h, s.vp, y.vp)
+        self.updates_since_reset += 1
         return self
 
     def reset_(self):
         """reset!(L)  lbfgs.jl:52-55"""
         call("pg_lbfgs_reset", self._h)
+        self.updates_since_reset = 0
         return self
 
     def mul_(self, d, v):

@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from ._lib import ProxGradError
 from .algorithm import IterativeAlgorithm
-from .device import HIPMatrix, as_hipvector
+from .device import HIPMatrix, HIPVector, as_hipvector
 from .lbfgs import LBFGS, LBFGSOperator
 from .operators import Zero, prox_, value_and_gradient
 
@@ -97,6 +97,13 @@ class PANOCIteration:
         self.counters["A_passes"] += 1
         return self.A.mul_adjoint(r, out)
 
+    def _mul_start(self, x):
+        """`mul!(state.Ax, iter.A, state.x)` at the start (panoc.jl:89, zerofpr.jl:87, panocplus.jl:89): A 0 = 0 exactly, so a start
+        from zero -- the usual one -- does not read A for it (one n-vector reduction to see that it is zero)."""
+        if isinstance(self.A, HIPMatrix) and float(x.norm_inf()) == 0.0:
+            return HIPVector.zeros(self.A.m, x.dtype, x.ctx)
+        return self._mul(None, x)
+
     def _model(self, s, gamma=None):  # :84-85
         """f_model at the current (At_grad_f_Ax, res) pair.  When the pair comes out of the single sweep, the sweep's own
         reductions <At_grad, res> and ||res||^2 are reused (no further kernels, no host round trips)."""
@@ -162,7 +169,7 @@ class PANOCIteration:
         R = self.x0.dtype.type
         s = PANOCState()
         s.x = self.x0.copy()  # :88
-        s.Ax = self._mul(None, s.x)  # :89
+        s.Ax = self._mul_start(s.x)  # :89
         s.grad_f_Ax = s.Ax.similar()
         s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :90
         if self.gamma is None:  # :91-94

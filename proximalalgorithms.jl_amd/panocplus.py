@@ -24,7 +24,7 @@ class PANOCplusIteration(PANOCIteration):
         R = self.x0.dtype.type
         s = PANOCplusState()
         s.x = self.x0.copy()  # :86
-        s.Ax = self._mul(None, s.x)
+        s.Ax = self._mul_start(s.x)
         s.grad_f_Ax = s.Ax.similar()
         s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)
         if self.gamma is None:

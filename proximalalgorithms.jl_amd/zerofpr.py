@@ -24,25 +24,42 @@ class ZeroFPRIteration(PANOCIteration):
         R = self.x0.dtype.type
         s = ZeroFPRState()
         s.x = self.x0.copy()  # :86
-        s.Ax = self._mul(None, s.x)
+        s.Ax = self._mul_start(s.x)  # :87 (a start from zero reads nothing)
         s.grad_f_Ax = s.Ax.similar()
         s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :88
         if self.gamma is None:  # :89-92
             s.gamma = R(self.alpha / self._lower_bound_smoothness_constant(s.x, s.grad_f_Ax))
         else:
             s.gamma = R(self.gamma)
-        s.At_grad_f_Ax = self._mul_adj(None, s.grad_f_Ax)  # :93
-        s.y = s.x.similar().axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :94
-        s.xbar = s.x.similar()
-        s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :95
-        s.res = s.x.similar().axpby_(1.0, s.x, -1.0, s.xbar)
+        s.Az_next = s.Ax.similar()
+        s.Az_next_valid, s.Az_next_of, s.Az_next_is_res = False, None, False
+        s.res_stats = s.res_inf = None
+        start_fused = False
+        if self._fused_tn:  # :93-96 in ONE read of A, which also leaves A xbar for the first iteration's :167 / fb_tools.jl:43
+            s.At_grad_f_Ax, s.y, s.xbar, s.res = (s.x.similar() for _ in range(4))
+            try:
+                sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next)
+                self.counters["A_passes"] += 1
+                s.g_xbar = sc[0]
+                s.Az_next_valid, s.Az_next_of = True, s.xbar
+                s.res_stats, s.res_inf = (sc[1], sc[2], sc[3]), sc[1]
+                start_fused = True
+            except ProxGradError as e:
+                if e.code != _lib.PG_ERR_UNSUPPORTED:
+                    raise
+                self._fused_tn = False
+        if not start_fused:
+            s.At_grad_f_Ax = self._mul_adj(None, s.grad_f_Ax)  # :93
+            s.y = s.x.similar().axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :94
+            s.xbar = s.x.similar()
+            s.g_xbar = prox_(s.xbar, self.g, s.y, s.gamma)  # :95
+            s.res = s.x.similar().axpby_(1.0, s.x, -1.0, s.xbar)
         s.H = self.directions.initialize(s.x)
         s.tau = R(0)
         for name in ("At_grad_f_Axbar", "xbarbar", "res_xbar", "xbar_prev", "res_xbar_prev", "d"):
             setattr(s, name, s.x.similar())
-        for name in ("Axbar", "grad_f_Axbar", "Ad", "Az_next"):
+        for name in ("Axbar", "grad_f_Axbar", "Ad"):
             setattr(s, name, s.Ax.similar())
-        s.Az_next_valid, s.Az_next_of, s.Az_next_is_res = False, None, False
         # Two trial points of the line search per sweep (pg_mat_fused_tn_pair): a second set of everything a trial point writes.
         # Allocated at the first use; `pair_hint` = the previous iteration rejected tau = 1 (then this one probably will too).
         s.pair, s.pair_hint, s.pair_sweeps = bool(self._fused_tn) and bool(getattr(self, "pair_trials", True)), True, 0
@@ -120,6 +137,10 @@ class ZeroFPRIteration(PANOCIteration):
         if use_img:  # :194 without reading A: d = -(H res_xbar)
             s.H.images_mul_(s.Ad, s.Ares)
             s.Ad.axpby_(-1.0, s.Ad)
+        elif fused_res and s.H is not None and getattr(s.H, "updates_since_reset", 1) == 0:
+            # an EMPTY memory (the first iteration, and the one after every reset!): mul! is the identity (lbfgs.jl:64-71 with
+            # currmem = 0, H = 1), d = -res_xbar, and A d = -A res_xbar is what the sweep above just left
+            s.Ad.axpby_(-1.0, s.Ares)
         else:
             self._mul(s.Ad, s.d)  # :194
         # :200-217.  Every trial point tau is a sweep of its own in the reference (A' grad f(A x), the forward-backward step; here
