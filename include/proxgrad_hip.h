@@ -241,6 +241,13 @@ pg_status pg_mat_fused_tn_res(pg_mat* A, const void* r, const void* x, double ga
 pg_status pg_mat_fused_tn_pair(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
                                double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Az1, void* At_r2, void* y2,
                                void* z2, void* res2, void* Az2, double* scalars_out);
+/* The same with the images of the residuals, Ares_k = A (x_k - z_k), in place of A z_k (cf. pg_mat_fused_tn_res).  PANOCplus uses it to
+ * fold its second pass over A -- `mul!(state.At_grad_f_Az, adjoint(iter.A), state.grad_f_Az)` (panocplus.jl:225), needed by the
+ * stopping criterion alone (:243) -- into the FIRST sweep of the next iteration (:199-210 at tau = 1), taken speculatively: one
+ * read of A per iteration instead of two. */
+pg_status pg_mat_fused_tn_pair_res(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
+                                   double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Ares1, void* At_r2, void* y2,
+                                   void* z2, void* res2, void* Ares2, double* scalars_out);
 /* ------------------------------------------------------------------ LeastSquares -------- */
 /* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the
  * value_and_gradient method of benchmark/benchmarks.jl:11-17.  `b` is a device m-vector

@@ -109,6 +109,7 @@ SIGNATURES = {
     "pg_mat_fused_tn": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_mat_fused_tn_res": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_mat_fused_tn_pair": [_vp, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pf64],
+    "pg_mat_fused_tn_pair_res": [_vp, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_mat_fused_dys": [_vp, _vp, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _pf64],
     "pg_ls_create": [_vp, _vp, _vp, _f64, C.POINTER(_vp)],

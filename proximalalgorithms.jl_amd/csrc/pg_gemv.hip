@@ -885,7 +885,7 @@ pg_status mat_fused_tn_t(pg_mat* A, const T* r, const T* x, double gamma, int g_
 // trial points x = xbar_prev + tau d one sweep each; this carries tau and tau / 2 through the same pass over A.
 template <typename T>
 pg_status mat_fused_tn_pair_t(pg_mat* A, const T* r1, const T* x1, const T* r2, const T* x2, double gamma, int g_kind, double g_p0, double g_p1,
-                              T* g1, T* y1, T* z1, T* res1, T* Az1, T* g2, T* y2, T* z2, T* res2, T* Az2) {
+                              T* g1, T* y1, T* z1, T* res1, T* Az1, T* g2, T* y2, T* z2, T* res2, T* Az2, bool image_of_res) {
   pg_ctx* c = A->ctx;
   const int nrg = (int)(A->ld / (1024 / (int64_t)sizeof(T)));
   if (pg_row_sharded(c) || pg_col_sharded(c) || !tn_supported<T>(A) || !tn_pair_covers(nrg)) {
@@ -912,7 +912,7 @@ pg_status mat_fused_tn_pair_t(pg_mat* A, const T* r1, const T* x1, const T* r2, 
   const T gm = (T)gamma;
   a.gamma = gm;
   a.beta = T(0);
-  a.v_is_res = 0;
+  a.v_is_res = image_of_res ? 1 : 0;  // both instances: Az = A z  |  A (x - z)
   a.p0 = g_kind == PG_G_NORML1 ? (T)(gm * (T)g_p0) : (T)g_p0;
   a.p1 = (T)g_p1;
   a.lam_ls = T(1);
@@ -1189,9 +1189,9 @@ pg_status pg_mat_fused_tn_res(pg_mat* A, const void* r, const void* x, double ga
   return mat_fused_tn_any(A, r, x, gamma, g_kind, g_p0, g_p1, At_r, y, z, res, Ares, scalars_out, true);
 }
 
-pg_status pg_mat_fused_tn_pair(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
-                               double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Az1, void* At_r2, void* y2,
-                               void* z2, void* res2, void* Az2, double* scalars_out) {
+static pg_status mat_fused_tn_pair_any(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
+                                       double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Az1, void* At_r2, void* y2,
+                                       void* z2, void* res2, void* Az2, double* scalars_out, bool image_of_res) {
   PG_REQUIRE(A != nullptr, "matrix is null");
   PG_REQUIRE(r1 && x1 && r2 && x2 && At_r1 && y1 && z1 && res1 && Az1 && At_r2 && y2 && z2 && res2 && Az2, "null vector");
   PG_REQUIRE(g_kind == PG_G_ZERO || g_kind == PG_G_NORML1 || g_kind == PG_G_INDBOX, "unknown g_kind");
@@ -1199,15 +1199,27 @@ pg_status pg_mat_fused_tn_pair(pg_mat* A, const void* r1, const void* x1, const 
   PG_TRY(A->dtype == PG_F32
              ? mat_fused_tn_pair_t<float>(A, (const float*)r1, (const float*)x1, (const float*)r2, (const float*)x2, gamma, g_kind, g_p0, g_p1,
                                           (float*)At_r1, (float*)y1, (float*)z1, (float*)res1, (float*)Az1, (float*)At_r2, (float*)y2,
-                                          (float*)z2, (float*)res2, (float*)Az2)
+                                          (float*)z2, (float*)res2, (float*)Az2, image_of_res)
              : mat_fused_tn_pair_t<double>(A, (const double*)r1, (const double*)x1, (const double*)r2, (const double*)x2, gamma, g_kind, g_p0,
                                            g_p1, (double*)At_r1, (double*)y1, (double*)z1, (double*)res1, (double*)Az1, (double*)At_r2,
-                                           (double*)y2, (double*)z2, (double*)res2, (double*)Az2));
+                                           (double*)y2, (double*)z2, (double*)res2, (double*)Az2, image_of_res));
   if (scalars_out) {
     PG_TRY(pg_read_scalars(A->ctx, PG_S_PAIR, 8));
     for (int k = 0; k < 8; ++k) scalars_out[k] = A->ctx->hscal[PG_S_PAIR + k];
   }
   return PG_OK;
+}
+
+pg_status pg_mat_fused_tn_pair(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
+                               double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Az1, void* At_r2, void* y2,
+                               void* z2, void* res2, void* Az2, double* scalars_out) {
+  return mat_fused_tn_pair_any(A, r1, x1, r2, x2, gamma, g_kind, g_p0, g_p1, At_r1, y1, z1, res1, Az1, At_r2, y2, z2, res2, Az2, scalars_out, false);
+}
+
+pg_status pg_mat_fused_tn_pair_res(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
+                                   double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Ares1, void* At_r2, void* y2,
+                                   void* z2, void* res2, void* Ares2, double* scalars_out) {
+  return mat_fused_tn_pair_any(A, r1, x1, r2, x2, gamma, g_kind, g_p0, g_p1, At_r1, y1, z1, res1, Ares1, At_r2, y2, z2, res2, Ares2, scalars_out, true);
 }
 
 pg_status pg_ls_fused_pass(pg_ls* f, const void* x, const void* z_old, double gamma, double beta, int32_t g_kind,

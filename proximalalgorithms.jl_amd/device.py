@@ -457,12 +457,13 @@ class HIPMatrix:
         R = self.dtype.type
         return tuple(R(v) for v in sc)
 
-    def fused_tn_pair(self, r1, x1, r2, x2, gamma, g, out1, out2):
+    def fused_tn_pair(self, r1, x1, r2, x2, gamma, g, out1, out2, image_of_res=False):
         """TWO instances of fused_tn on ONE read of A (pg_mat_fused_tn_pair): out1 / out2 = (At_r, y, z, res, Az) of the pair
-        (r1, x1) / (r2, x2).  Returns the two scalar quadruples (g(z), norm(res, Inf), dot(At_r, res), norm(res)^2)."""
+        (r1, x1) / (r2, x2); image_of_res: Az = A (x - z) for both (pg_mat_fused_tn_pair_res).  Returns the two scalar quadruples
+        (g(z), norm(res, Inf), dot(At_r, res), norm(res)^2)."""
         p0, p1 = g.g_params()
         sc = (C.c_double * 8)()
-        call("pg_mat_fused_tn_pair", self._h, r1.vp, x1.vp, r2.vp, x2.vp, float(gamma), g.g_kind, p0, p1, *[v.vp for v in out1],
+        call("pg_mat_fused_tn_pair_res" if image_of_res else "pg_mat_fused_tn_pair", self._h, r1.vp, x1.vp, r2.vp, x2.vp, float(gamma), g.g_kind, p0, p1, *[v.vp for v in out1],
              *[v.vp for v in out2], sc)
         R = self.dtype.type
         return tuple(R(v) for v in sc[:4]), tuple(R(v) for v in sc[4:])

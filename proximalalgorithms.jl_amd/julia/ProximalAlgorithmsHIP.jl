@@ -157,8 +157,16 @@ end
 # TWO instances of fused_tn! on ONE read of A (pg_mat_fused_tn_pair): the trial points of tau and tau / 2 of ZeroFPR's line search
 # (zerofpr.jl:200-217).  out1 / out2 = (At_r, y, z, res, Az); returns the two scalar quadruples.  Columns of 33 .. 64 KiB only
 # (config 4's 16384 Float32 rows); a ProxGradError with code PG_ERR_UNSUPPORTED means: one trial point per sweep.
-function fused_tn_pair!(A::HIPMatrix{T}, r1, x1, r2, x2, gamma, g_kind, p0, p1, out1, out2) where {T}
+function fused_tn_pair!(A::HIPMatrix{T}, r1, x1, r2, x2, gamma, g_kind, p0, p1, out1, out2; image_of_res::Bool = false) where {T}
     sc = zeros(Float64, 8)
+    if image_of_res   # the last output of each instance is A (x - z): PANOCplus' speculative first sweep (pg_mat_fused_tn_pair_res)
+        check(ccall((:pg_mat_fused_tn_pair_res, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64,
+                     Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),
+                    A.handle, r1.ptr, x1.ptr, r2.ptr, x2.ptr, gamma, g_kind, p0, p1,
+                    out1[1].ptr, out1[2].ptr, out1[3].ptr, out1[4].ptr, out1[5].ptr, out2[1].ptr, out2[2].ptr, out2[3].ptr, out2[4].ptr, out2[5].ptr, sc))
+        return ((sc[1], sc[2], sc[3], sc[4]), (sc[5], sc[6], sc[7], sc[8]))
+    end
     check(ccall((:pg_mat_fused_tn_pair, libpg), Int32,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64,
                  Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}),

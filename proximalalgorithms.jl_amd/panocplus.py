@@ -52,12 +52,57 @@ class PANOCplusIteration(PANOCIteration):
         # becomes A x_prev + (image of A (-res_prev)), A res_prev = A x_prev - A z_prev being held (:199, :210)
         s.img = self._images and isinstance(s.H, LBFGSOperator)
         s.img_steps = 0
+        s.sp = None  # the next iteration's first pass, when the previous step took it ahead (_speculate)
         if s.img:
             s.H.images_enable(s.Ax.n)
             for name in ("Ax_prev", "Ad", "Ares", "Ares_prev", "As", "Ay"):
                 setattr(s, name, s.Ax.similar())
             s.Ares.axpby_(1.0, s.Ax, -1.0, s.Az)  # A res at the initial point
         return s
+
+    # what a first pass of the inner loop (direction, x = x_prev + d, its images, the sweep) writes: these are what the speculative
+    # half iteration keeps in a second set of buffers until the next step takes them
+    SPEC = ("d", "Ad", "x", "Ax", "grad_f_Ax", "At_grad_f_Ax", "y", "z", "res", "Ares", "Az")
+
+    def _speculate(self, s):
+        """`mul!(state.At_grad_f_Az, adjoint(iter.A), state.grad_f_Az)` (:225) is needed by the stopping criterion alone (:243) and
+        nothing else depends on it -- but it is a read of A.  The FIRST pass of the next iteration's loop (:185-210 at tau = 1:
+        direction from the memory updated at :237, x = x_prev + d, A x from the image slab, A' grad f(A x), the forward-backward
+        step and A res) depends on nothing this one does not have either.  So both go through ONE sweep (pg_mat_fused_tn_pair_res:
+        two r slices, two accumulator sets on one register tile; 1.02 single sweeps): this iteration's A' grad f(A z), and the next
+        iteration's first pass into a second set of buffers, which the next step takes if nothing has changed -- one read of A
+        per iteration instead of two.  The state the caller sees after this iteration is this iteration's.  Returns False (nothing
+        done) where the pair sweep, the image slab or a complete set of images is not available: the plain product follows."""
+        R = s.x.dtype.type
+        if not (self._fused_tn and self.speculate and s.img and s.H is not None and s.H.images_ready()):
+            return False
+        if self.refresh_every > 0 and (s.img_steps + 1) % self.refresh_every == 0:
+            return False  # the next pass is due a product A x: not from the slab
+        if not hasattr(s, "sp_x"):
+            for name in self.SPEC:
+                setattr(s, "sp_" + name, getattr(s, name).similar())
+            s.sp_junk_n = [s.x.similar() for _ in range(3)]
+            s.sp_junk_m = s.Ax.similar()
+        s.H.mul_(s.sp_d, s.res)  # set_next_direction! (:130-138) of the NEXT iteration: res becomes its res_prev
+        s.sp_d.axpby_(-1.0, s.sp_d)
+        s.H.images_mul_(s.sp_Ad, s.Ares)
+        s.sp_Ad.axpby_(-1.0, s.sp_Ad)
+        s.sp_x.axpby_(1.0, s.x, 1.0, s.sp_d)  # :190
+        s.sp_Ax.axpby_(1.0, s.Ax, R(1), s.sp_Ad)  # :199 from m-vectors (tau = 1)
+        sp_f_Ax, _ = value_and_gradient_into(self.f, s.sp_Ax, s.sp_grad_f_Ax)  # :200-201
+        try:
+            sc, _ = self.A.fused_tn_pair(s.sp_grad_f_Ax, s.sp_x, s.grad_f_Az, s.z, s.gamma, self.g,
+                                         (s.sp_At_grad_f_Ax, s.sp_y, s.sp_z, s.sp_res, s.sp_Ares),
+                                         (s.At_grad_f_Az, s.sp_junk_n[0], s.sp_junk_n[1], s.sp_junk_n[2], s.sp_junk_m), image_of_res=True)
+        except ProxGradError as e:
+            if e.code != _lib.PG_ERR_UNSUPPORTED:
+                raise
+            self.speculate = False  # no pair sweep at this column length
+            return False
+        self.counters["A_passes"] += 1
+        s.sp_Az.axpby_(1.0, s.sp_Ax, -1.0, s.sp_Ares)  # :210 as A x - A res
+        s.sp = {"f_Ax": sp_f_Ax, "g_z": sc[0], "res_stats": (sc[1], sc[2], sc[3]), "gamma": s.gamma}
+        return True
 
     def _step(self, s):
         R = s.x.dtype.type
@@ -75,8 +120,23 @@ class PANOCplusIteration(PANOCIteration):
         tau_backtracks = 0
         can_update_direction = True
         use_img = False
+        spec = getattr(s, "sp", None)
+        s.sp = None
+        if spec is not None and spec["gamma"] != s.gamma:
+            spec = None
         while True:  # :183-234
-            if can_update_direction:
+            taken = False
+            if can_update_direction and spec is not None:
+                # the first pass was taken ahead by the previous step (_speculate): its buffers become the state's
+                for name in self.SPEC:
+                    a_, b_ = getattr(s, name), getattr(s, "sp_" + name)
+                    setattr(s, name, b_), setattr(s, "sp_" + name, a_)
+                s.tau, tau_backtracks, use_img = R(1), 0, True
+                s.img_steps += 1
+                s.f_Ax, s.g_z, s.res_stats = spec["f_Ax"], spec["g_z"], spec["res_stats"]
+                spec = None
+                taken = fused = True
+            elif can_update_direction:
                 use_img = s.img and s.H.images_ready()
                 if s.H is not None:  # set_next_direction! :130-138
                     s.H.mul_(s.d, s.res_prev)
@@ -93,36 +153,38 @@ class PANOCplusIteration(PANOCIteration):
                 s.x.axpby_(1.0, s.x_prev, -(R(1) - s.tau), s.res_prev)
                 s.x.axpby_(1.0, s.x, s.tau, s.d)
                 tau_backtracks += 1
-            s.img_steps += 1
-            if use_img and not (self.refresh_every > 0 and s.img_steps % self.refresh_every == 0):
-                # :199 from m-vectors: A x = A x_prev - (1 - tau) A res_prev + tau A d
-                s.Ax.axpby_(1.0, s.Ax_prev, s.tau, s.Ad)
-                if s.tau != R(1):
-                    s.Ax.axpby_(1.0, s.Ax, -(R(1) - s.tau), s.Ares_prev)
-            else:
-                self._mul(s.Ax, s.x)  # :199
-            s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :200-201
-            fused = False
-            if self._fused_tn:  # :202-206 and :210 in one read of A (pg_mat_fused_tn)
-                try:
-                    sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res,
-                                         s.Ares if s.img else s.Az, image_of_res=s.img)
-                    if s.img:  # :210 as A x - A res, A res being the sweep's product of the residual itself
-                        s.Az.axpby_(1.0, s.Ax, -1.0, s.Ares)
-                    s.g_z = sc[0]
-                    s.res_stats = (sc[1], sc[2], sc[3])  # the sweep's own reductions of this (At_grad, res) pair
-                    fused = True
-                    self.counters["A_passes"] += 1
-                except ProxGradError as e:
-                    if e.code != _lib.PG_ERR_UNSUPPORTED:
-                        raise
-                    self._fused_tn = False
-            if not fused:
-                self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :202
-                s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :204
-                s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :205
-                s.res.axpby_(1.0, s.x, -1.0, s.z)  # :206
-                s.res_stats = None
+            spec = None  # (only the very first pass can be the one taken ahead)
+            if not taken:
+                s.img_steps += 1
+                if use_img and not (self.refresh_every > 0 and s.img_steps % self.refresh_every == 0):
+                    # :199 from m-vectors: A x = A x_prev - (1 - tau) A res_prev + tau A d
+                    s.Ax.axpby_(1.0, s.Ax_prev, s.tau, s.Ad)
+                    if s.tau != R(1):
+                        s.Ax.axpby_(1.0, s.Ax, -(R(1) - s.tau), s.Ares_prev)
+                else:
+                    self._mul(s.Ax, s.x)  # :199
+                s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :200-201
+                fused = False
+                if self._fused_tn:  # :202-206 and :210 in one read of A (pg_mat_fused_tn)
+                    try:
+                        sc = self.A.fused_tn(s.grad_f_Ax, s.x, s.gamma, self.g, s.At_grad_f_Ax, s.y, s.z, s.res,
+                                             s.Ares if s.img else s.Az, image_of_res=s.img)
+                        if s.img:  # :210 as A x - A res, A res being the sweep's product of the residual itself
+                            s.Az.axpby_(1.0, s.Ax, -1.0, s.Ares)
+                        s.g_z = sc[0]
+                        s.res_stats = (sc[1], sc[2], sc[3])  # the sweep's own reductions of this (At_grad, res) pair
+                        fused = True
+                        self.counters["A_passes"] += 1
+                    except ProxGradError as e:
+                        if e.code != _lib.PG_ERR_UNSUPPORTED:
+                            raise
+                        self._fused_tn = False
+                if not fused:
+                    self._mul_adj(s.At_grad_f_Ax, s.grad_f_Ax)  # :202
+                    s.y.axpby_(1.0, s.x, -s.gamma, s.At_grad_f_Ax)  # :204
+                    s.g_z = prox_(s.z, self.g, s.y, s.gamma)  # :205
+                    s.res.axpby_(1.0, s.x, -1.0, s.z)  # :206
+                    s.res_stats = None
             f_Az_upp = self._model(s)  # :208
             if not fused:
                 self._mul(s.Az, s.z)  # :210
@@ -139,7 +201,7 @@ class PANOCplusIteration(PANOCIteration):
                     if s.H is not None:
                         s.H.reset_()
                     continue
-            self._mul_adj(s.At_grad_f_Az, s.grad_f_Az)  # :225
+            # (:225, `mul!(state.At_grad_f_Az, adjoint(iter.A), state.grad_f_Az)`, follows the loop: only the last pass's survives)
             FBE_x_new = R(f_Az_upp + s.g_z)  # :227
             if FBE_x_new <= threshold or tau_backtracks >= self.max_backtracks:
                 break
@@ -156,6 +218,9 @@ class PANOCplusIteration(PANOCIteration):
                     s.As.axpby_(1.0, s.Ax, -1.0, s.Ax_prev)
                 s.Ay.axpby_(1.0, s.Ares, -1.0, s.Ares_prev)
                 s.H.images_update_(s.As, s.Ay)
+        # :225 -- together with the next iteration's first pass where that can be taken ahead, else as the product it is
+        if not self._speculate(s):
+            self._mul_adj(s.At_grad_f_Az, s.grad_f_Az)
         return s
 
 

@@ -1979,6 +1979,52 @@ def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy):
     assert sg.pair_sweeps > 0 and it_g.counters["A_passes"] < it_1.counters["A_passes"], (sg.pair_sweeps, it_g.counters, it_1.counters)
 
 
+def test_panocplus_second_pass_rides_in_the_next_first_sweep(pa):
+    """PANOCplus reads A twice per iteration in the reference: A' grad f(A x) with the forward-backward step (panocplus.jl:202-210) and
+    `mul!(state.At_grad_f_Az, adjoint(iter.A), state.grad_f_Az)` (:225), which only the stopping criterion uses (:243).  Here the
+    second rides in the NEXT iteration's first sweep, taken ahead into a second set of buffers (panocplus.py::_speculate over
+    pg_mat_fused_tn_pair_res).  Float64, logistic + L1 on 6000 x 24000 (inside the pair kernel's range), adaptive step: gamma, tau, z,
+    At_grad_f_Az and the stopping measure of EVERY iteration equal the oracle's and the non-speculating run's; about one read of A
+    per iteration instead of two; a solve to the stopping rule ends within a few iterations of the oracle's at the same minimiser."""
+    dtype = np.float64
+    rng = np.random.default_rng(4)
+    m, n = 6000, 24000
+    A = np.asfortranarray(rng.standard_normal((m, n)) / np.sqrt(m))
+    xt = np.zeros(n)
+    xt[rng.choice(n, n // 1000, replace=False)] = rng.standard_normal(n // 1000)
+    b = A @ xt + 0.01 * rng.standard_normal(m)
+    _, g0 = o.LogisticLoss(b).value_and_gradient(np.zeros(m))
+    lam = dtype(0.1 * np.max(np.abs(A.T @ g0)))
+    x0 = np.zeros(n, dtype)
+    Ad = pa.HIPMatrix.from_numpy(A)
+    it_s = pa.PANOCplusIteration(f=pa.LogisticLoss(b), A=Ad, g=pa.NormL1(lam), x0=x0)
+    it_2 = pa.PANOCplusIteration(f=pa.LogisticLoss(b), A=Ad, g=pa.NormL1(lam), x0=x0, speculate=False)
+    it_o = o.PANOCplusIteration(f=o.LogisticLoss(b), A=A, g=o.NormL1(lam), x0=x0)
+
+    def measure(st):  # panocplus.jl:243
+        g = lambda v: v.numpy() if hasattr(v, "numpy") else v
+        return float(np.max(np.abs(g(st.res) / float(st.gamma) - g(st.At_grad_f_Ax) + g(st.At_grad_f_Az))))
+
+    its = 25
+    for k, (ss, s2, so) in enumerate(itertools.islice(zip(it_s, it_2, it_o), its)):
+        assert float(ss.gamma) == pytest.approx(float(so.gamma), rel=1e-12) and float(ss.tau) == float(so.tau) == float(s2.tau), k
+        scale = max(1.0, np.max(np.abs(so.z)))
+        assert np.max(np.abs(ss.z.numpy() - so.z)) <= 1e-8 * scale and np.max(np.abs(ss.z.numpy() - s2.z.numpy())) <= 1e-9 * scale, k
+        assert np.max(np.abs(ss.At_grad_f_Az.numpy() - so.At_grad_f_Az)) <= 1e-8 * max(1.0, np.max(np.abs(so.At_grad_f_Az))), k
+        assert measure(ss) == pytest.approx(measure(so), rel=1e-6, abs=1e-9), k
+    ps, p2 = it_s.counters["A_passes"], it_2.counters["A_passes"]
+    assert p2 >= 2 * (its - 1) and ps <= p2 - (its - 6), (ps, p2)  # one read per iteration where the other run takes two
+    zs, ks = pa.PANOCplus(tol=1e-6, maxit=300)(x0=x0, f=pa.LogisticLoss(b), A=Ad, g=pa.NormL1(lam))
+    zo, ko = o.panocplus(tol=1e-6, maxit=300, x0=x0, f=o.LogisticLoss(b), A=A, g=o.NormL1(lam))
+    # (170 quasi-Newton iterations amplify the rounding of the two summation orders: the trajectories end within a few
+    # iterations of each other at the same minimiser, not at the same iteration)
+    assert abs(ks - ko) <= 0.1 * ko + 2 and ks < 300, (ks, ko)
+    assert np.max(np.abs(zs.numpy() - zo)) <= 1e-5 * max(1.0, np.max(np.abs(zo))), (ks, ko)
+    A64, b64 = A, b
+    obj = lambda z: float(np.sum(np.log1p(np.exp(-(A64 @ z - b64)))) + float(lam) * np.sum(np.abs(z)))
+    assert abs(obj(zs.numpy()) - obj(zo)) <= 1e-9 * abs(obj(zo)), (obj(zs.numpy()), obj(zo))
+
+
 # ------------------------------------------------------------------------------------------------
 # verbose driver loop (test/problems/test_verbose.jl:36-78): the display path does not change results
 # ------------------------------------------------------------------------------------------------
