@@ -1016,8 +1016,8 @@ def run_config3(pa, ctx, n=10_000_000, steps=200, beat=lambda: None):
     return out
 
 
-def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3, beat=lambda: None):
-    """PANOC (panoc.jl:138-255; L-BFGS memory 5, adaptive step) on logistic loss + L1, m = 16384, n = 10^6, Float32."""
+def config4_problem(pa, ctx, m=16384, n=1_000_000):
+    """BASELINE config 4's instance: logistic loss + L1 on the synthetic 16384 x 10^6 Float32 matrix (resident once for the family)"""
     import numpy as np
 
     dtype = np.float32
@@ -1031,7 +1031,18 @@ def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3, beat=lambda: 
     f = pa.LogisticLoss(b)
     _, g0 = f.value_and_gradient(pa.HIPVector.zeros(m, dtype, ctx))
     lam = dtype(0.1) * A.mul_adjoint(g0).norm_inf()
-    iteration = pa.PANOCIteration(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype))
+    return {"A": A, "f": f, "lam": lam, "m": m, "n": n}
+
+
+def run_config4(pa, ctx, prob, algo="PANOC", steps=20, warmup=3, beat=lambda: None):
+    """PANOC (panoc.jl:138-255), ZeroFPR (zerofpr.jl:142-220) or PANOCplus (panocplus.jl:168-240) -- L-BFGS memory 5, adaptive step -- on
+    config 4's instance.  PANOC is BASELINE config 4 itself (K timed iterations after W warm-up steps); the other two are its family
+    (SURVEY 8(f) row 4), timed over their FIRST iterations (no warm-up: that is where their line searches backtrack)."""
+    import numpy as np
+
+    A, f, lam, m, n = prob["A"], prob["f"], prob["lam"], prob["m"], prob["n"]
+    dtype = np.float32
+    iteration = getattr(pa, algo + "Iteration")(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype))
     it = iter(iteration)
     beat()
     s = next(it)
@@ -1055,12 +1066,12 @@ def run_config4(pa, ctx, m=16384, n=1_000_000, steps=20, warmup=3, beat=lambda: 
     per = {k_: {"launches": prof[k_][0], "avg_ms": round(prof[k_][1] / prof[k_][0], 4),
                 "GBps": round(m * n * 4 / (prof[k_][1] / prof[k_][0] * 1e-3) / 1e9, 1)}
            for k_ in ("gemv_n_partial", "gemv_t", "gemv_tn") if prof[k_][0]}
-    dom = max(per, key=lambda k_: per[k_]["avg_ms"])
+    dom = max(per, key=lambda k_: per[k_]["avg_ms"] * per[k_]["launches"])
     gemv_ms = sum(prof[k_][1] for k_ in per)
-    return {"label": "config4", "value": round(steps / dt, 3), "unit": "it/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": round(1e3 * dt / steps, 4),
-            "config": {"workload": "PANOC logistic + L1, m=%d n=%d Float32, LBFGS(5), adaptive step" % (m, n),
-                       "A_passes_per_step": passes / steps, "lambda": float(lam),
+    return {"label": "config4" if algo == "PANOC" else "config4_" + algo.lower(), "value": round(steps / dt, 3), "unit": "it/s", "steps": steps,
+            "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 4),
+            "config": {"workload": "%s logistic + L1, m=%d n=%d Float32, LBFGS(5), adaptive step" % (algo, m, n),
+                       "A_passes_per_step": round(passes / steps, 4), "lambda": float(lam),
                        "final": {"gamma": float(s.gamma), "res_inf_over_gamma": float(s.res.norm_inf()) / float(s.gamma)}},
             "roofline": {"bound": "hbm", "kernel": dom, "avg_launch_ms": per[dom]["avg_ms"],
                          "algorithmic_bytes_per_launch": m * n * 4, "achieved": per[dom]["GBps"], "peak": HBM_PEAK_GBS,
@@ -1127,7 +1138,7 @@ def extrapolate_ledger(d, m_full, n_full, steps_full=50, warmup_full=5, gen_rate
     return out, total
 
 
-SHORT_LABELS = {"headline_adaptive": "adaptive", "config2": "cfg2", "config3": "cfg3", "config4": "cfg4",
+SHORT_LABELS = {"headline_adaptive": "adaptive", "config2": "cfg2", "config3": "cfg3", "config4": "cfg4", "config4_zerofpr": "zfpr", "config4_panocplus": "pplus",
                 "config5_column_block": "cfg5blk", "headline_row_block_n8": "row8", "rows_2proc_two_sweeps": "rows2p",
                 "rows_2proc_row_team": "rows2pteam", "rows_two_sweeps": "rows2s", "cols_strong": "cols", "rows_strong": "rows",
                 "config5_weak_rows": "cfg5rows", "config5_weak_cols": "cfg5cols", "rows_strong_teams": "teams",
@@ -1448,7 +1459,19 @@ def run_rank(args, job, wd, world, rank, local_rank):
         m2_, n2_ = WORKLOADS["config2"]
         also_record("config2", lambda: ffb_record(m2_, n2_, max(sub_steps, 50), 5, "config2"), frees=m2_ * n2_ * es)
         also_record("config3", lambda: run_config3(pa, ctx, beat=wd.beat))
-        also_record("config4", lambda: run_config4(pa, ctx, beat=wd.beat), frees=16384 * 1_000_000 * 4)
+        # config 4 (PANOC) and its family on ONE resident instance: ZeroFPR (two trial points of its line search per sweep) and
+        # PANOCplus (its second pass taken in the next first sweep), each over its first 23 iterations
+        c4 = {}
+
+        def config4_record(algo, steps_, warm_):
+            if "prob" not in c4:
+                c4["prob"] = config4_problem(pa, ctx)
+            return run_config4(pa, ctx, c4["prob"], algo, steps=steps_, warmup=warm_, beat=wd.beat)
+
+        also_record("config4", lambda: config4_record("PANOC", 20, 3))
+        also_record("config4_zerofpr", lambda: config4_record("ZeroFPR", 23, 0))
+        also_record("config4_panocplus", lambda: config4_record("PANOCplus", 23, 0), frees=16384 * 1_000_000 * 4)
+        c4.clear()
         # per-GPU block shapes at N = 8, run as problems of their own on one GPU: BASELINE config 5 under the column layout
         # (131072 x 131072: one team sweep per iteration) and the headline under north_star's row layout (2048 x 2^20: the
         # short-column sweep, one wave per column group); the PMC passes of these sweeps were taken on exactly these shapes
