@@ -40,11 +40,11 @@
 extern "C" {
 #endif
 
-/* Bumped whenever an exported signature, a struct layout the host sees, or the set of exports changes (round 5: 2 -- rounds 3
- * and 4 added exports and fields under version 1).  Hosts compare pg_abi_version() with the value THEY were written against at
+/* Bumped whenever an exported signature, a struct layout the host sees, or the set of exports changes (round 5: 2, then 3 with pg_mat_fused_tn_trio --
+ * rounds 3 and 4 added exports and fields under version 1).  Hosts compare pg_abi_version() with the value THEY were written against at
  * load time (Python: _lib.load; Julia: __init__) and refuse a stale or mismatched build with one clear message instead of a
  * missing symbol at some later call -- PG_LIB_PATH / PROXGRAD_HIP_LIB make pointing at another build easy. */
-#define PG_ABI_VERSION 2
+#define PG_ABI_VERSION 3
 
 typedef int32_t pg_status;
 enum {
@@ -248,6 +248,13 @@ pg_status pg_mat_fused_tn_pair(pg_mat* A, const void* r1, const void* x1, const 
 pg_status pg_mat_fused_tn_pair_res(pg_mat* A, const void* r1, const void* x1, const void* r2, const void* x2, double gamma, int32_t g_kind,
                                    double g_p0, double g_p1, void* At_r1, void* y1, void* z1, void* res1, void* Ares1, void* At_r2, void* y2,
                                    void* z2, void* res2, void* Ares2, double* scalars_out);
+/* THREE instances of pg_mat_fused_tn in ONE read of A (gemv_tnm_trio_kernel): the trial points tau, tau / 2 and tau / 4 of
+ * zerofpr.jl:200-217 through the same pass.  r, x: three device pointers each (host arrays of pointers); At_r, y, z, res, Az: the
+ * outputs of instance k at index k; image_of_res != 0: Az[k] = A (x_k - z_k).  scalars_out (host, may be NULL): twelve values, the
+ * four of pg_mat_fused_tn per instance.  Same column lengths as pg_mat_fused_tn_pair; PG_ERR_UNSUPPORTED otherwise. */
+pg_status pg_mat_fused_tn_trio(pg_mat* A, const void* const r[3], const void* const x[3], double gamma, int32_t g_kind, double g_p0,
+                               double g_p1, void* const At_r[3], void* const y[3], void* const z[3], void* const res[3],
+                               void* const Az[3], int32_t image_of_res, double* scalars_out);
 /* ------------------------------------------------------------------ LeastSquares -------- */
 /* f(x) = lam/2 ||A x - b||^2 -- ProximalOperators.LeastSquares(A, b[, lam]) with the
  * value_and_gradient method of benchmark/benchmarks.jl:11-17.  `b` is a device m-vector

@@ -110,6 +110,7 @@ SIGNATURES = {
     "pg_mat_fused_tn_res": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_mat_fused_tn_pair": [_vp, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pf64],
     "pg_mat_fused_tn_pair_res": [_vp, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pf64],
+    "pg_mat_fused_tn_trio": [_vp, _vp, _vp, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _i32, _pf64],
     "pg_mat_fused_dys": [_vp, _vp, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _pf64],
     "pg_ls_create": [_vp, _vp, _vp, _f64, C.POINTER(_vp)],
@@ -166,7 +167,7 @@ SIGNATURES = {
 _SPECIAL = {"pg_abi_version": ([], C.c_int32), "pg_last_error": ([], C.c_char_p), "pg_comm_available": ([], C.c_int32)}
 
 _lib = None
-PG_ABI_VERSION = 2  # include/proxgrad_hip.h (tests/test_cpu_host.py compares the two)
+PG_ABI_VERSION = 3  # include/proxgrad_hip.h (tests/test_cpu_host.py compares the two)
 
 
 def load():

@@ -591,6 +591,7 @@ pg_status pg_mat_destroy(pg_mat* A) {
   for (void* q : A->retired) (void)hipFree(q);
   if (A->rpad) (void)hipFree(A->rpad);
   if (A->rpad2) (void)hipFree(A->rpad2);
+  if (A->rpad3) (void)hipFree(A->rpad3);
   if (A->xch) (void)hipFree(A->xch);
   delete A;
   return PG_OK;

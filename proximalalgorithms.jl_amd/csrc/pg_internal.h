@@ -71,8 +71,8 @@ enum {
   PG_S_DRRUN2 = 82,  // second set of the same (two blocks of pg_dr_run are in flight)
   PG_S_DRA = 148,    // pg_dr_step_async, slot 0: { ||res||_inf, f(y), g(z) }
   PG_S_DRB = 151,    // ... slot 1 (the iteration launched while slot 0's is being looked at)
-  PG_S_PAIR = 154,   // pg_mat_fused_tn_pair: { g(z), ||res||_inf, <At_r, res>, ||res||^2 } of the first and of the second instance
-  PG_S_COUNT = 162
+  PG_S_PAIR = 154,   // pg_mat_fused_tn_pair: { g(z), ||res||_inf, <At_r, res>, ||res||^2 } of the first and of the second instance (pg_mat_fused_tn_trio: and of the third)
+  PG_S_COUNT = 166
 };
 
 constexpr int PG_RED_MAX_BLOCKS = 4096;  // max grid of any kernel that uses grid_reduce_finalize
@@ -193,6 +193,7 @@ struct pg_mat {
   std::vector<void*> retired;  // outgrown partial-sum buffers of a row-team matrix, freed with the matrix (pg_gemv_tn4.hip)
   void* rpad = nullptr;  // [ld] zero-padded copy of a caller's m-vector (pg_mat_fused_tn)
   void* rpad2 = nullptr; // ... of the second instance's (pg_mat_fused_tn_pair)
+  void* rpad3 = nullptr; // ... of the third's (pg_mat_fused_tn_trio)
   void* xch = nullptr;   // granule ring of the workgroup teams of the long-column sweep (gemv_tnt_kernel)
   size_t xch_bytes = 0;
   unsigned xch_epoch = 0;     // launch epoch of the ring (1 .. 255, the high byte of every granule tag: no memset per launch)

@@ -468,6 +468,17 @@ class HIPMatrix:
         R = self.dtype.type
         return tuple(R(v) for v in sc[:4]), tuple(R(v) for v in sc[4:])
 
+    def fused_tn_trio(self, rs, xs, gamma, g, outs, image_of_res=False):
+        """THREE instances of fused_tn on ONE read of A (pg_mat_fused_tn_trio): outs[k] = (At_r, y, z, res, Az) of the pair
+        (rs[k], xs[k]).  Returns the three scalar quadruples (g(z), norm(res, Inf), dot(At_r, res), norm(res)^2)."""
+        p0, p1 = g.g_params()
+        sc = (C.c_double * 12)()
+        arr = lambda vs: (C.c_void_p * 3)(*[v.vp for v in vs])  # noqa: E731
+        call("pg_mat_fused_tn_trio", self._h, arr(rs), arr(xs), float(gamma), g.g_kind, p0, p1, *[arr([o[i] for o in outs]) for i in range(5)],
+             1 if image_of_res else 0, sc)
+        R = self.dtype.type
+        return tuple(tuple(R(v) for v in sc[4 * k:4 * k + 4]) for k in range(3))
+
     def fused_dys(self, r, xg, z, gamma, relax, g_spec, h_spec, grad, z_half, xh, res, z_next, xg_next, A_xg_next):
         """ONE read of A for a Davis-Yin iteration (pg_mat_fused_dys); g_spec / h_spec = (kind, p0, p1).
         Returns (norm(res, Inf), dot(grad, res), norm(res)^2)."""

@@ -32,7 +32,7 @@ function check(status::Int32)
     throw(ProxGradError(status, unsafe_string(ccall((:pg_last_error, libpg), Cstring, ()))))
 end
 
-const PG_ABI_VERSION = Int32(2)   # include/proxgrad_hip.h: the version this file was written against
+const PG_ABI_VERSION = Int32(3)   # include/proxgrad_hip.h: the version this file was written against
 
 function __init__()   # a stale or mismatched build is refused at load, not at the first missing symbol
     found = ccall((:pg_abi_version, libpg), Int32, ())
@@ -173,6 +173,20 @@ function fused_tn_pair!(A::HIPMatrix{T}, r1, x1, r2, x2, gamma, g_kind, p0, p1, 
                 A.handle, r1.ptr, x1.ptr, r2.ptr, x2.ptr, gamma, g_kind, p0, p1,
                 out1[1].ptr, out1[2].ptr, out1[3].ptr, out1[4].ptr, out1[5].ptr, out2[1].ptr, out2[2].ptr, out2[3].ptr, out2[4].ptr, out2[5].ptr, sc))
     ((sc[1], sc[2], sc[3], sc[4]), (sc[5], sc[6], sc[7], sc[8]))
+end
+
+# THREE instances on ONE read of A (pg_mat_fused_tn_trio): tau, tau / 2 and tau / 4 of the same line search.  rs, xs: three vectors
+# each; outs[k] = (At_r, y, z, res, Az) of instance k; returns the three scalar quadruples.  Same column lengths as fused_tn_pair!.
+function fused_tn_trio!(A::HIPMatrix{T}, rs, xs, gamma, g_kind, p0, p1, outs; image_of_res::Bool = false) where {T}
+    sc = zeros(Float64, 12)
+    ptrs(vs) = Ptr{Cvoid}[v.ptr for v in vs]
+    cols = [ptrs([outs[k][i] for k in 1:3]) for i in 1:5]
+    rp, xp = ptrs(rs), ptrs(xs)
+    GC.@preserve rp xp cols check(ccall((:pg_mat_fused_tn_trio, libpg), Int32,
+                (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Float64, Int32, Float64, Float64,
+                 Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}),
+                A.handle, rp, xp, gamma, g_kind, p0, p1, cols[1], cols[2], cols[3], cols[4], cols[5], Int32(image_of_res), sc))
+    ((sc[1], sc[2], sc[3], sc[4]), (sc[5], sc[6], sc[7], sc[8]), (sc[9], sc[10], sc[11], sc[12]))
 end
 
 # One Davis-Yin iteration (davis_yin.jl:73-83) in ONE read of A; prox kinds as above plus 3 = SqrNormL2(p0 = lam)

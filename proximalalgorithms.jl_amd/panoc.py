@@ -53,7 +53,7 @@ class PANOCIteration:
 
     def __init__(self, *, f=None, A=None, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
                  minimum_gamma=1e-7, max_backtracks=20, directions=None, single_sweep=True, images=True,
-                 refresh_every=0, pair_trials=True, speculate=True):
+                 refresh_every=0, pair_trials=True, trio_trials=True, speculate=True):
         self.f = f if f is not None else Zero()
         if A is None:
             A = _Identity()
@@ -75,6 +75,8 @@ class PANOCIteration:
         # carries its trial point and the next one; "always": only an iteration's first sweep (tau = 1 and 1/2); "hint": that, and
         # only after an iteration that rejected tau = 1; False: one trial point per sweep (the reference's count)
         self.pair_trials = pair_trials if isinstance(pair_trials, str) else bool(pair_trials)
+        # ... and three per sweep (tau, tau / 2, tau / 4: pg_mat_fused_tn_trio) under "every"; False: two
+        self.trio_trials = bool(trio_trials)
         # PANOCplus: its second pass over A (panocplus.jl:225) rides in the next iteration's first sweep, taken ahead (panocplus.py)
         self.speculate = bool(speculate)
         # A' grad f(A x) (:184), the forward-backward step (:197-199) and the A z of the next line search (fb_tools.jl:43)

@@ -63,6 +63,7 @@ class ZeroFPRIteration(PANOCIteration):
         # Two trial points of the line search per sweep (pg_mat_fused_tn_pair): a second set of everything a trial point writes.
         # Allocated at the first use; `pair_hint` = the previous iteration rejected tau = 1 (then this one probably will too).
         s.pair, s.pair_hint, s.pair_sweeps = bool(self._fused_tn) and bool(getattr(self, "pair_trials", True)), True, 0
+        s.trio, s.trio_sweeps = s.pair and bool(getattr(self, "trio_trials", True)), 0
         s.is_prev_set = False
         s.img = self._images and self._fused_tn and isinstance(s.H, LBFGSOperator)
         s.img_prev_set = False
@@ -144,45 +145,64 @@ class ZeroFPRIteration(PANOCIteration):
         else:
             self._mul(s.Ad, s.d)  # :194
         # :200-217.  Every trial point tau is a sweep of its own in the reference (A' grad f(A x), the forward-backward step; here
-        # also A xbar for the next iteration).  Here a sweep carries the trial point of tau AND of tau / 2 (two r slices, two
-        # accumulator sets on one register tile, pg_mat_fused_tn_pair): a rejected trial costs no further read of A, the one after
-        # it a sweep that again carries two.  The decisions are the reference's -- the second point is only looked at after the
-        # first was rejected.
+        # also A xbar for the next iteration).  Here a sweep carries the trial points of tau, tau / 2 AND tau / 4 (three r slices,
+        # three accumulator sets on one register tile, pg_mat_fused_tn_trio; two where only the pair sweep applies): rejected
+        # trials cost no further read of A until the points carried are used up.  The decisions are the reference's -- a point
+        # evaluated ahead is only looked at after the one before it was rejected.
         TRIAL = ("x", "Ax", "grad_f_Ax", "At_grad_f_Ax", "y", "xbar", "res", "Az_next")
-        spec = None  # (tau, f_Ax, scalars) of a trial point the last pair sweep evaluated ahead
+        spec = []  # (tau, f_Ax, scalars, suffix of the buffer set) of the trial points the last sweep evaluated ahead
         first_rejected = False
         for k in range(1, self.max_backtracks + 1):
             tau_next = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))  # :216
             fused = False
-            if spec is not None and spec[0] == s.tau:  # evaluated ahead: the second set becomes the state, no sweep
+            if spec and spec[0][0] == s.tau:  # evaluated ahead: that buffer set becomes the state, no sweep
+                _, s.f_Ax, sc, sfx = spec.pop(0)
                 for name in TRIAL:
-                    a_, b_ = getattr(s, name), getattr(s, name + "_sp")
-                    setattr(s, name, b_), setattr(s, name + "_sp", a_)
-                s.f_Ax, sc = spec[1], spec[2]
-                spec = None
+                    a_, b_ = getattr(s, name), getattr(s, name + sfx)
+                    setattr(s, name, b_), setattr(s, name + sfx, a_)
                 fused = True
             else:
-                spec = None
+                spec = []
                 s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :201
                 s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :202
                 s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :204-205
-                # (measured at config 4's size, profiles/r5_pair_sweep_rate.log: a pair sweep costs 1.02 single sweeps, so the
-                # second point is carried whenever there is one -- "every"; "always" / "hint" restrict it to an iteration's first sweep /
-                # to the first sweep after an iteration that rejected tau = 1)
+                # (measured at config 4's size, profiles/r5_pair_sweep_rate.log: a pair sweep costs 1.02 single sweeps, so further
+                # points are carried whenever there are any -- "every"; "always" / "hint" restrict it to an iteration's first sweep /
+                # to the first sweep after an iteration that rejected tau = 1, with two points)
                 policy = self.pair_trials if isinstance(self.pair_trials, str) else "every"
                 want = (k == 1 and (s.pair_hint or policy != "hint")) or (policy == "every" and k > 1)
+                ahead = []  # the trial points behind this one: (tau, buffer set)
                 if self._fused_tn and s.pair and want and tau_next > 0:
-                    if not hasattr(s, "x_sp"):
+                    ahead.append((tau_next, "_sp"))
+                    tau_next2 = R(0) if k + 1 >= self.max_backtracks - 1 else R(tau_next / R(2))
+                    if s.trio and policy == "every" and tau_next2 > 0:
+                        ahead.append((tau_next2, "_sp2"))
+                f_ahead = []
+                for t_, sfx in ahead:
+                    if not hasattr(s, "x" + sfx):
                         for name in TRIAL:
-                            setattr(s, name + "_sp", getattr(s, name).similar())
-                    s.x_sp.axpby_(1.0, s.xbar_prev, tau_next, s.d)
-                    s.Ax_sp.axpby_(1.0, s.Axbar, tau_next, s.Ad)
-                    f_sp, _ = value_and_gradient_into(self.f, s.Ax_sp, s.grad_f_Ax_sp)
+                            setattr(s, name + sfx, getattr(s, name).similar())
+                    getattr(s, "x" + sfx).axpby_(1.0, s.xbar_prev, t_, s.d)
+                    getattr(s, "Ax" + sfx).axpby_(1.0, s.Axbar, t_, s.Ad)
+                    f_ahead.append(value_and_gradient_into(self.f, getattr(s, "Ax" + sfx), getattr(s, "grad_f_Ax" + sfx))[0])
+                outs = lambda sfx: tuple(getattr(s, n + sfx) for n in ("At_grad_f_Ax", "y", "xbar", "res", "Az_next"))  # noqa: E731
+                if len(ahead) == 2:
                     try:
-                        sc, sc2 = self.A.fused_tn_pair(s.grad_f_Ax, s.x, s.grad_f_Ax_sp, s.x_sp, s.gamma, self.g,
-                                                       (s.At_grad_f_Ax, s.y, s.xbar, s.res, s.Az_next),
-                                                       (s.At_grad_f_Ax_sp, s.y_sp, s.xbar_sp, s.res_sp, s.Az_next_sp))
-                        spec = (tau_next, f_sp, sc2)
+                        scs = self.A.fused_tn_trio((s.grad_f_Ax, s.grad_f_Ax_sp, s.grad_f_Ax_sp2), (s.x, s.x_sp, s.x_sp2), s.gamma, self.g,
+                                                   (outs(""), outs("_sp"), outs("_sp2")))
+                        sc = scs[0]
+                        spec = [(ahead[0][0], f_ahead[0], scs[1], "_sp"), (ahead[1][0], f_ahead[1], scs[2], "_sp2")]
+                        s.trio_sweeps += 1
+                        fused = True
+                    except ProxGradError as e:
+                        if e.code != _lib.PG_ERR_UNSUPPORTED:
+                            raise
+                        s.trio = False  # no three-point sweep for this column length: two points
+                        ahead = ahead[:1]
+                if not fused and len(ahead) == 1:
+                    try:
+                        sc, sc2 = self.A.fused_tn_pair(s.grad_f_Ax, s.x, s.grad_f_Ax_sp, s.x_sp, s.gamma, self.g, outs(""), outs("_sp"))
+                        spec = [(ahead[0][0], f_ahead[0], sc2, "_sp")]
                         s.pair_sweeps += 1
                         fused = True
                     except ProxGradError as e:

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--images", type=int, default=1, help="0: the explicit product A d (panoc.jl:180) instead of the L-BFGS image slab")
     ap.add_argument("--speculate", type=int, default=1, help="PANOCplus: 0 = two reads of A per iteration (round 4)")
     ap.add_argument("--pair-trials", default="1", help="ZeroFPR: 0 = one trial point of the line search per sweep (round 4); 1 = every (default); always; hint")
+    ap.add_argument("--trio-trials", type=int, default=1, help="ZeroFPR: 0 = at most two trial points per sweep")
     ap.add_argument("--algo", choices=["panoc", "zerofpr", "panocplus", "ffb", "ffb-generic"], default="panoc",
                     help="ffb: FastForwardBackward (adaptive) on Composed(loss, A), engine 'composed' (one read of A per "
                          "iteration); ffb-generic: the same with separate GEMV passes")
@@ -46,7 +47,7 @@ def main():
     if args.algo in newton:
         iteration = getattr(pa, newton[args.algo])(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype), images=bool(args.images),
                                                    pair_trials=args.pair_trials if args.pair_trials in ("always", "every", "hint") else bool(int(args.pair_trials)),
-                                                   speculate=bool(args.speculate))
+                                                   trio_trials=bool(args.trio_trials), speculate=bool(args.speculate))
     else:
         iteration = pa.FastForwardBackwardIteration(f=pa.Composed(f, A), g=pa.NormL1(lam), x0=np.zeros(n, dtype),
                                                     engine="composed" if args.algo == "ffb" else "generic")
@@ -84,7 +85,7 @@ def main():
                         "frac": passes * m * n * 4 / (gemv_ms * 1e-3) / 1e9 / 8000.0,
                         "gemv_time_fraction_of_step": gemv_ms * 1e-3 / dt},
            "whole_iteration_GBps": passes * m * n * 4 / dt / 1e9, "accepted_tau_histogram": taus,
-           "pair_sweeps": int(getattr(s, "pair_sweeps", 0)),
+           "pair_sweeps": int(getattr(s, "pair_sweeps", 0)), "trio_sweeps": int(getattr(s, "trio_sweeps", 0)),
            "final": {"gamma": float(s.gamma), "tau": float(getattr(s, "tau", 0.0)), "res_inf_over_gamma": float(s.res.norm_inf()) / float(s.gamma)}}
     print(json.dumps(out))
 

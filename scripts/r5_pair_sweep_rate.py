@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--m", type=int, default=16384)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=12)
-    ap.add_argument("--variants", default="4:1,8:1,8:3,4:2")
+    ap.add_argument("--variants", default="8:3")
     args = ap.parse_args()
     import proximalalgorithms.jl_amd as pa
 
@@ -27,11 +27,12 @@ def main():
     ctx = pa.get_context()
     A = pa.HIPMatrix.synthetic(m, n, dtype, seed=0)
     rng = np.random.default_rng(1)
-    r = [pa.HIPVector.from_numpy(rng.standard_normal(m).astype(dtype)) for _ in range(2)]
-    x = [pa.HIPVector.from_numpy(rng.standard_normal(n).astype(dtype)) for _ in range(2)]
+    r = [pa.HIPVector.from_numpy(rng.standard_normal(m).astype(dtype)) for _ in range(3)]
+    x = [pa.HIPVector.from_numpy(rng.standard_normal(n).astype(dtype)) for _ in range(3)]
     g = pa.NormL1(dtype(0.05))
     o1 = [x[0].similar() for _ in range(4)] + [r[0].similar()]
     o2 = [x[0].similar() for _ in range(4)] + [r[0].similar()]
+    o3 = [x[0].similar() for _ in range(4)] + [r[0].similar()]
     bytes_a = m * n * 4
 
     def timed(fn):
@@ -58,6 +59,9 @@ def main():
             continue
         print(json.dumps({"kernel": "pair sweep W=%s C-code=%s" % (w, c), "ms": round(t2, 4), "TBps": round(bytes_a / t2 / 1e9, 3),
                           "of_8TBps": round(bytes_a / t2 / 8e9, 4), "cost_in_single_sweeps": round(t2 / t1, 3)}), flush=True)
+    t3 = timed(lambda: A.fused_tn_trio(r, x, 0.3, g, (o1, o2, o3)))
+    print(json.dumps({"kernel": "three-point sweep (gemv_tnm_trio<8,2,8,3>)", "ms": round(t3, 4), "TBps": round(bytes_a / t3 / 1e9, 3),
+                      "of_8TBps": round(bytes_a / t3 / 8e9, 4), "cost_in_single_sweeps": round(t3 / t1, 3)}), flush=True)
 
 
 if __name__ == "__main__":

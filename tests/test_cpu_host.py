@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(handle, name), f"{name} is declared in include/*.h but not exported"
     assert declared == set(lib.exported_symbols()), declared ^ set(lib.exported_symbols())
     header_version = int(re.search(r"#define PG_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "proxgrad_hip.h")).read()).group(1))
-    assert handle.pg_abi_version() == header_version == lib.PG_ABI_VERSION == 2
+    assert handle.pg_abi_version() == header_version == lib.PG_ABI_VERSION == 3
     julia = open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "julia", "ProximalAlgorithmsHIP.jl")).read()
     assert int(re.search(r"const PG_ABI_VERSION = Int32\((\d+)\)", julia).group(1)) == header_version
 

@@ -1954,14 +1954,57 @@ def test_two_point_sweep_equals_two_single_sweeps(pa, dtype):
         assert e.value.code == pa.PG_ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("policy", ["always", "hint", True])
-def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_three_point_sweep_equals_three_single_sweeps(pa, dtype):
+    """pg_mat_fused_tn_trio (gemv_tnm_trio_kernel): three instances of pg_mat_fused_tn on ONE read of A -- the trial points tau,
+    tau / 2, tau / 4 of zerofpr.jl:200-217.  Same bar as the pair sweep: per column each instance's At_r, y, z, res equal the single
+    sweep's to the last bits, the images to rounding (A z and, image_of_res, A (x - z)), the twelve scalars are the three
+    quadruples.  Every U of the kernel (5 .. 8: 33 .. 64 row groups; at U = 8 part of the third slice of r sits in LDS), ragged last
+    row group, odd column counts, both g; outside the range PG_ERR_UNSUPPORTED."""
+    rng = np.random.default_rng(23)
+    rows_per_rg = 256 if dtype == np.float32 else 128
+    for nrg, extra, n, of_res in ((64, 0, 700, False), (33, 0, 513, True), (40, -5, 300, False), (47, -100, 1001, True), (48, 0, 64, False),
+                                  (57, -1, 257, True), (60, 0, 129, False), (63, -7, 95, True), (41, 0, 33, False), (56, 0, 2, True)):
+        m = nrg * rows_per_rg + extra
+        A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
+        M = pa.HIPMatrix.from_numpy(A)
+        g = pa.NormL1(dtype(0.05)) if nrg % 2 else pa.IndBox(dtype(-0.2), dtype(0.3))
+        gamma = dtype(0.37)
+        rs = [rng.standard_normal(m).astype(dtype) for _ in range(3)]
+        xs = [rng.standard_normal(n).astype(dtype) for _ in range(3)]
+        rd, xd = [pa.HIPVector.from_numpy(v) for v in rs], [pa.HIPVector.from_numpy(v) for v in xs]
+        single, scs = [], []
+        for k in range(3):
+            outs = [xd[0].similar() for _ in range(4)] + [rd[0].similar()]
+            scs.append(M.fused_tn(rd[k], xd[k], gamma, g, *outs, image_of_res=of_res))
+            single.append([v.numpy().copy() for v in outs])
+        o3 = [[xd[0].similar() for _ in range(4)] + [rd[0].similar()] for _ in range(3)]
+        sc3 = M.fused_tn_trio(rd, xd, gamma, g, o3, image_of_res=of_res)
+        for k, (outs, sc) in enumerate(zip(o3, sc3)):
+            gb = np.abs(A.astype(np.float64)).T @ np.abs(rs[k].astype(np.float64)) + 1e-30
+            for name, got, ref in zip(("At_r", "y", "z", "res"), outs[:4], single[k][:4]):
+                assert np.all(np.abs(got.numpy().astype(np.float64) - ref) <= 16 * np.finfo(dtype).eps * (gb + np.abs(xs[k]))), (nrg, k, name)
+            Az, Az_ref = outs[4].numpy().astype(np.float64), single[k][4].astype(np.float64)
+            bound = np.abs(A.astype(np.float64)) @ np.abs(single[k][3 if of_res else 2].astype(np.float64)) + 1e-30
+            assert np.all(np.abs(Az - Az_ref) <= 64 * np.finfo(dtype).eps * bound), (nrg, k)
+            for a_, b_ in zip(sc, scs[k]):
+                assert float(a_) == pytest.approx(float(b_), rel=1e-5 if dtype == np.float32 else 1e-12, abs=1e-30), (nrg, k)
+    for m in (32 * rows_per_rg, 65 * rows_per_rg, 300):  # outside the range: refused, the caller carries two points or one
+        M = pa.HIPMatrix.from_numpy(np.asfortranarray(rng.standard_normal((m, 8)).astype(dtype)))
+        r_, x_ = pa.HIPVector.from_numpy(rng.standard_normal(m).astype(dtype)), pa.HIPVector.from_numpy(rng.standard_normal(8).astype(dtype))
+        with pytest.raises(pa.ProxGradError) as e:
+            M.fused_tn_trio([r_] * 3, [x_] * 3, 0.5, pa.NormL1(dtype(0.1)), [[x_.similar() for _ in range(4)] + [r_.similar()] for _ in range(3)])
+        assert e.value.code == pa.PG_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("policy,trio", [("always", False), ("hint", False), (True, False), (True, True)], ids=["always", "hint", "True", "three"])
+def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy, trio):
     """ZeroFPR's line search with two trial points per sweep (zerofpr.py over pg_mat_fused_tn_pair): the
     trial point of tau / 2 is evaluated speculatively in the sweep of tau and looked at only after tau was rejected, so the
     DECISIONS are the reference's.  Float64, logistic + L1 on 6000 x 24000 (47 row groups: inside the pair kernel's range), adaptive
     step: the same gamma and tau at every iteration as the oracle (zerofpr.jl:142-220 restated), iterates to 1e-8, fewer reads of A
     than with one trial point per sweep -- under all three policies (every first sweep / the first sweep after a rejected tau = 1 /
-    True = every sweep of the search, the default)."""
+    True = every sweep of the search) and with THREE points per sweep (pg_mat_fused_tn_trio, the default: fewer reads again)."""
     dtype = np.float64
     rng = np.random.default_rng(4)
     m, n = 6000, 24000  # (under-determined like config 4: on tall problems the search never leaves tau = 1)
@@ -1972,7 +2015,7 @@ def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy):
     _, g0 = o.LogisticLoss(b).value_and_gradient(np.zeros(m))
     lam = dtype(0.1 * np.max(np.abs(A.T @ g0)))
     x0 = np.zeros(n, dtype)
-    it_g = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=policy)
+    it_g = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=policy, trio_trials=trio)
     it_1 = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=False)
     it_o = o.ZeroFPRIteration(f=o.LogisticLoss(b), A=A, g=o.NormL1(lam), x0=x0)
     taus = []
@@ -1982,7 +2025,16 @@ def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy):
         assert np.max(np.abs(sg.xbar.numpy() - so.xbar)) <= 1e-8 * max(1.0, np.max(np.abs(so.xbar))), k
         taus.append(float(so.tau))
     assert any(t < 1.0 for t in taus[1:]), taus  # the search did backtrack: the second trial points were used
-    assert sg.pair_sweeps > 0 and it_g.counters["A_passes"] < it_1.counters["A_passes"], (sg.pair_sweeps, it_g.counters, it_1.counters)
+    assert sg.pair_sweeps + sg.trio_sweeps > 0 and it_g.counters["A_passes"] < it_1.counters["A_passes"], (sg.pair_sweeps, it_g.counters, it_1.counters)
+    assert (sg.trio_sweeps > 0) == trio, (sg.trio_sweeps, sg.pair_sweeps)
+    if trio and "True" in _ZFPR_PASSES:  # a search of k trial points takes ceil(k / 3) sweeps where pairs take ceil(k / 2)
+        trials = [int(round(np.log2(1.0 / t))) + 1 for t in taus if t > 0]
+        saved = sum(-(-k // 2) - -(-k // 3) for k in trials)
+        assert it_g.counters["A_passes"] == _ZFPR_PASSES["True"] - saved, (it_g.counters, _ZFPR_PASSES, taus)
+    _ZFPR_PASSES[str(policy) if not trio else "three"] = it_g.counters["A_passes"]
+
+
+_ZFPR_PASSES = {}
 
 
 def test_panocplus_second_pass_rides_in_the_next_first_sweep(pa):
