@@ -91,15 +91,15 @@ def main():
         ", ".join(("sweep" if k == "gemv_tn" else f"`{k}`") + f" {pk[k]['avg_ms']:.2f} ms" for k in ks),
         " / ".join(f"{pk[k]['GBps'] / 1e3:.2f}" for k in ks) + " TB/s", " / ".join(f"{pk[k]['GBps'] / 8e3:.3f}" for k in ks),
         "`also[3]`, " + src("bench_panoc.json"))
-    try:  # round 5: ZeroFPR with two trial points of its line search per sweep, beside one per sweep (round 4) and PANOCplus
-        zf, z1, pp = line("r3_bench_zerofpr.json"), line("r3_bench_zerofpr_single_trials.json"), line("r3_bench_panocplus.json")
-        p2 = line("r3_bench_panocplus_two_reads.json")
-        add("config 4's family, first 23 iterations: ZeroFPR with two trial points per sweep / one per sweep (round 4); PANOCplus with its second pass in the next first sweep / as a pass of its own (round 4)",
-            f"**{zf['value']:.1f}** / {z1['value']:.1f}; **{pp['value']:.1f}** / {p2['value']:.1f}",
-            f"reads of A per iteration {zf['A_passes_per_step']:.2f} / {z1['A_passes_per_step']:.2f}; {pp['A_passes_per_step']:.2f} / {p2['A_passes_per_step']:.2f}",
-            " / ".join(f"{x['roofline']['achieved'] / 1e3:.2f}" for x in (zf, z1, pp, p2)) + " TB/s (all sweeps)",
-            " / ".join(f"{x['roofline']['frac']:.3f}" for x in (zf, z1, pp, p2)),
-            src("bench_zerofpr.json", "bench_zerofpr_single_trials.json", "bench_panocplus.json", "bench_panocplus_two_reads.json"))
+    try:  # round 5: ZeroFPR with three / two trial points of its line search per sweep, beside one per sweep (round 4), and PANOCplus
+        zf, z2, z1 = line("r3_bench_zerofpr.json"), line("r3_bench_zerofpr_two_points.json"), line("r3_bench_zerofpr_single_trials.json")
+        pp, p2 = line("r3_bench_panocplus.json"), line("r3_bench_panocplus_two_reads.json")
+        add("config 4's family, first 23 iterations: ZeroFPR with three / two trial points per sweep / one per sweep (round 4); PANOCplus with its second pass in the next first sweep / as a pass of its own (round 4)",
+            f"**{zf['value']:.1f}** / {z2['value']:.1f} / {z1['value']:.1f}; **{pp['value']:.1f}** / {p2['value']:.1f}",
+            f"reads of A per iteration {zf['A_passes_per_step']:.2f} / {z2['A_passes_per_step']:.2f} / {z1['A_passes_per_step']:.2f}; {pp['A_passes_per_step']:.2f} / {p2['A_passes_per_step']:.2f}",
+            " / ".join(f"{x['roofline']['achieved'] / 1e3:.2f}" for x in (zf, z2, z1, pp, p2)) + " TB/s (all sweeps)",
+            " / ".join(f"{x['roofline']['frac']:.3f}" for x in (zf, z2, z1, pp, p2)),
+            src("bench_zerofpr.json", "bench_zerofpr_two_points.json", "bench_zerofpr_single_trials.json", "bench_panocplus.json", "bench_panocplus_two_reads.json"))
     except SystemExit:
         pass
     try:  # round 5: north_star's row layout as `bench.py --gpus 2` reports it (two rank PROCESSES on this one device, gloo)
