@@ -7,7 +7,8 @@
 // registers and 160 KiB of LDS.  The slices of instances 0 and 1 live in LDS (128 KiB), the third's in registers except its first
 // R3L row groups per wave (LDS again: 8 R3L KiB), and the twelve fp64 scalar accumulators, which only the writer lanes of wave 0
 // touch, in LDS as well (in registers they cost every lane 24 and the kernel spilled); the three image accumulator sets and
-// the tile in registers.  Per column and instance the arithmetic is gemv_tnm_pair_kernel's, statement for statement.
+// the tile in registers.  Per column and instance the arithmetic is gemv_tnm_pair_kernel's except that a lane's part of a dot runs as
+// two partial sums (even / odd elements, v_pk_fma_f32 in Float32): results equal the single sweep's to rounding, like the pair's.
 #include <mutex>
 
 #include "pg_gemv_tn.h"
@@ -28,9 +29,10 @@ template <typename T, int U, int C, int WAVES, int R3L>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, TNTrio<T> b) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
+  typedef T T2 __attribute__((ext_vector_type(2)));
   constexpr int UL = 2 * U + R3L;  // row groups of LDS per wave
-  __shared__ T sm_dot[2][3][C][WAVES];
-  __shared__ double sm_acc[C][12];
+  __shared__ __attribute__((aligned(16))) T sm_dot[2][3][C][WAVES];
+  __shared__ double sm_acc[3 * C][4];
   extern __shared__ __attribute__((aligned(16))) unsigned char r_raw[];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -61,24 +63,31 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
     if (u < R3L) r3s[u * WAVE] = rv[2];
     else r3[u - R3L] = rv[2];
   }
-  if (threadIdx.x < C) {
+  // The epilogues of a step's 3 C (instance, column) pairs run in PARALLEL LANES, pair q = p C + c in lane q of every wave (its own
+  // sum of the waves' partial dots, its own x_j, prox and residual; lane q of wave 0 writes the pair's outputs and keeps its four
+  // scalars), and the 3 C values v come back to all lanes by v_readlane.  One after the other in every lane they were six
+  // branchy chains of an LDS read, seven adds and the prox between the barrier and the image fmas of every step, with nothing of
+  // this workgroup in flight: 9.92 ms per sweep at config 4's size against 9.28 this way (profiles/r5_pair_sweep_rate.log).
+  const int ql = lane % (3 * C), pl = ql / C, cl = ql % C;
+  const T* const xb = pl == 0 ? b.x[0] : (pl == 1 ? b.x[1] : b.x[2]);
+  T* const gob = pl == 0 ? b.g_out[0] : (pl == 1 ? b.g_out[1] : b.g_out[2]);
+  T* const yb = pl == 0 ? b.y[0] : (pl == 1 ? b.y[1] : b.y[2]);
+  T* const zb = pl == 0 ? b.z_new[0] : (pl == 1 ? b.z_new[1] : b.z_new[2]);
+  T* const rb = pl == 0 ? b.res[0] : (pl == 1 ? b.res[1] : b.res[2]);
+  const bool owner = wave == 0 && lane < 3 * C;
+  if (owner) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) sm_acc[threadIdx.x][k] = 0.0;
+    for (int k = 0; k < 4; ++k) sm_acc[lane][k] = 0.0;
   }
 
   struct Tile {
     V col[C][U];
-    T xs[3][C];
+    T xl;  // x_j of this lane's (instance, column) pair
   };
   auto load = [&](Tile& t, int64_t cg) __attribute__((always_inline)) {
     const int64_t j0 = cg * C;
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) t.xs[p][c] = b.x[p][jc];
-    }
+    t.xl = xb[(j0 + cl < a.n) ? (j0 + cl) : (a.n - 1)];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int64_t jc = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
@@ -88,8 +97,55 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // forward-backward step of instance p for column j (gemv_tnm_pair_kernel's, statement for statement); the scalars in LDS
-  auto epilogue = [&](T g, T xj, int64_t j, bool valid, bool writer, int p, int c) __attribute__((always_inline)) -> T {
+  auto process = [&](const Tile& t, int64_t cg, int buf) __attribute__((always_inline)) {
+    const int64_t j0 = cg * C;
+    T dot[3][C];
+    // two partial sums per instance, column and lane (even / odd elements): Float32 runs them as v_pk_fma_f32, half the issue
+    // slots of the single sweep's one chain -- with three instances on a tile the dots are what the step waits for.  Row groups
+    // outermost: a slice entry is read from LDS once for the C columns of the step.
+    T2 dd[3][C];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) dd[p][c] = T2{T(0), T(0)};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      V rv[3];
+      rv[0] = r1s[u * WAVE];
+      rv[1] = r2s[u * WAVE];
+      if constexpr (R3L > 0) rv[2] = u < R3L ? r3s[u * WAVE] : r3[u < R3L ? 0 : u - R3L];
+      else rv[2] = r3[u];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int e = 0; e < VEC; e += 2) dd[p][c] = T2{t.col[c][u][e], t.col[c][u][e + 1]} * T2{rv[p][e], rv[p][e + 1]} + dd[p][c];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dot[p][c] = wave_allsum(dd[p][c][0] + dd[p][c][1]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) sm_dot[buf][p][c][wave] = dot[p][c];
+      }
+    }
+    __syncthreads();
+    // forward-backward step of this lane's pair (gemv_tnm_pair_kernel's statements); the scalars in LDS
+    const T* sp = &sm_dot[buf][pl][cl][0];
+    T g = sp[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) g += sp[w];
+    const int64_t j = j0 + cl;
+    const bool valid = j < a.n;
+    const T xj = t.xl;
     const T yj = xj - a.gamma * g;
     T zj;
     if (a.g_kind == PG_G_NORML1) {
@@ -103,78 +159,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
     } else
       zj = yj;
     const T rj = xj - zj;
-    if (wave == 0) {
-      if (writer && valid) {
-        b.g_out[p][j] = g;
-        b.y[p][j] = yj;
-        b.z_new[p][j] = zj;
-        b.res[p][j] = rj;
-        double* ac = &sm_acc[c][4 * p];
-        if (a.g_kind == PG_G_NORML1) ac[0] += a.p0v != nullptr ? (double)a.p0v[j] * fabs((double)zj) : fabs((double)zj);
-        ac[1] = fmax(ac[1], fabs((double)rj));
-        ac[2] += (double)g * (double)rj;
-        ac[3] += (double)rj * (double)rj;
-      }
+    if (owner && valid) {
+      gob[j] = g;
+      yb[j] = yj;
+      zb[j] = zj;
+      rb[j] = rj;
+      double* ac = &sm_acc[lane][0];
+      if (a.g_kind == PG_G_NORML1) ac[0] += a.p0v != nullptr ? (double)a.p0v[j] * fabs((double)zj) : fabs((double)zj);
+      ac[1] = fmax(ac[1], fabs((double)rj));
+      ac[2] += (double)g * (double)rj;
+      ac[3] += (double)rj * (double)rj;
     }
-    return valid ? (a.v_is_res ? rj : zj) : T(0);
-  };
-  auto process = [&](const Tile& t, int64_t cg, int buf) __attribute__((always_inline)) {
-    const int64_t j0 = cg * C;
-    T dot[3][C];
+    const T vl = valid ? (a.v_is_res ? rj : zj) : T(0);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      T d0 = T(0), d1 = T(0), d2 = T(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const V rv = r1s[u * WAVE];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) d0 = fma(t.col[c][u][e], rv[e], d0);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const V rv = r2s[u * WAVE];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) d1 = fma(t.col[c][u][e], rv[e], d1);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        V rv;
-        if constexpr (R3L > 0) rv = u < R3L ? r3s[u * WAVE] : r3[u < R3L ? 0 : u - R3L];
-        else rv = r3[u];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) d2 = fma(t.col[c][u][e], rv[e], d2);
-      }
-      dot[0][c] = wave_allsum(d0);
-      dot[1][c] = wave_allsum(d1);
-      dot[2][c] = wave_allsum(d2);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) sm_dot[buf][p][c][wave] = dot[p][c];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t j = j0 + c;
-      const bool valid = j < a.n;
-      const bool writer = (int)threadIdx.x == c;
-      T v[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        T g = sm_dot[buf][p][c][0];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) g += sm_dot[buf][p][c][w];
-        v[p] = epilogue(g, t.xs[p][c], j, valid, writer, p, c);
-      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
+        const T vk = pg_readlane(vl, k * C + c);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) racc[k][u][e] = fma(t.col[c][u][e], v[k], racc[k][u][e]);
+          for (int e = 0; e < VEC; ++e) racc[k][u][e] = fma(t.col[c][u][e], vk, racc[k][u][e]);
         }
       }
     }
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
   }
   double acc[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) acc[k] = threadIdx.x < C ? sm_acc[threadIdx.x < C ? threadIdx.x : 0][k] : 0.0;
+  for (int k = 0; k < 12; ++k) acc[k] = (owner && pl == k / 4) ? sm_acc[owner ? lane : 0][k % 4] : 0.0;
   const double ps[12] = {a.gscale, 1.0, 1.0, 1.0, a.gscale, 1.0, 1.0, 1.0, a.gscale, 1.0, 1.0, 1.0};
   grid_reduce_finalize<12, 0x222u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
 }
