@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5/bench_default.json 2> gpurun_out/r5/bench_default.err
+mkdir -p gpurun_out/r5; python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5/bench_default.json 2> gpurun_out/r5/bench_default.err
 timeout 3000 python -m pytest tests -m gpu -q --durations=30 > gpurun_out/r5_gpu_suite_final.log 2>&1; echo "rc $?" >> gpurun_out/r5_gpu_suite_final.log
 tail -5 gpurun_out/r5_gpu_suite_final.log; python - <<'PY'
 import json

@@ -1964,7 +1964,7 @@ def test_three_point_sweep_equals_three_single_sweeps(pa, dtype):
     rng = np.random.default_rng(23)
     rows_per_rg = 256 if dtype == np.float32 else 128
     for nrg, extra, n, of_res in ((64, 0, 700, False), (33, 0, 513, True), (40, -5, 300, False), (47, -100, 1001, True), (48, 0, 64, False),
-                                  (57, -1, 257, True), (60, 0, 129, False), (63, -7, 95, True), (41, 0, 33, False), (56, 0, 2, True)):
+                                  (57, -1, 257, True), (60, 0, 129, False), (63, -7, 95, True), (41, 0, 33, False), (56, 0, 2, True), (50, 0, 1, False)):
         m = nrg * rows_per_rg + extra
         A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
         M = pa.HIPMatrix.from_numpy(A)
