@@ -71,11 +71,10 @@ class PANOCIteration:
         self.max_backtracks = int(max_backtracks)
         self.directions = directions if directions is not None else LBFGS(5)  # :51
         self.counters = {"A_passes": 0}
-        # ZeroFPR: two trial points of the line search per sweep of A (zerofpr.py).  True = "every": every sweep of the line search
-        # carries its trial point and the next one; "always": only an iteration's first sweep (tau = 1 and 1/2); "hint": that, and
-        # only after an iteration that rejected tau = 1; False: one trial point per sweep (the reference's count)
-        self.pair_trials = pair_trials if isinstance(pair_trials, str) else bool(pair_trials)
-        # ... and three per sweep (tau, tau / 2, tau / 4: pg_mat_fused_tn_trio) under "every"; False: two
+        # ZeroFPR: further trial points of the line search in the sweep of A that evaluates one (zerofpr.py): pair_trials: the next one
+        # (pg_mat_fused_tn_pair); trio_trials: the next two (pg_mat_fused_tn_trio, the default where the kernel applies).  Both False:
+        # one trial point per sweep, the reference's count.
+        self.pair_trials = bool(pair_trials)
         self.trio_trials = bool(trio_trials)
         # PANOCplus: its second pass over A (panocplus.jl:225) rides in the next iteration's first sweep, taken ahead (panocplus.py)
         self.speculate = bool(speculate)

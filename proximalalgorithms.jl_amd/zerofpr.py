@@ -61,8 +61,8 @@ class ZeroFPRIteration(PANOCIteration):
         for name in ("Axbar", "grad_f_Axbar", "Ad"):
             setattr(s, name, s.Ax.similar())
         # Two trial points of the line search per sweep (pg_mat_fused_tn_pair): a second set of everything a trial point writes.
-        # Allocated at the first use; `pair_hint` = the previous iteration rejected tau = 1 (then this one probably will too).
-        s.pair, s.pair_hint, s.pair_sweeps = bool(self._fused_tn) and bool(getattr(self, "pair_trials", True)), True, 0
+        # Allocated at the first use.
+        s.pair, s.pair_sweeps = bool(self._fused_tn) and bool(getattr(self, "pair_trials", True)), 0
         s.trio, s.trio_sweeps = s.pair and bool(getattr(self, "trio_trials", True)), 0
         s.is_prev_set = False
         s.img = self._images and self._fused_tn and isinstance(s.H, LBFGSOperator)
@@ -151,7 +151,6 @@ class ZeroFPRIteration(PANOCIteration):
         # evaluated ahead is only looked at after the one before it was rejected.
         TRIAL = ("x", "Ax", "grad_f_Ax", "At_grad_f_Ax", "y", "xbar", "res", "Az_next")
         spec = []  # (tau, f_Ax, scalars, suffix of the buffer set) of the trial points the last sweep evaluated ahead
-        first_rejected = False
         for k in range(1, self.max_backtracks + 1):
             tau_next = R(0) if k >= self.max_backtracks - 1 else R(s.tau / R(2))  # :216
             fused = False
@@ -166,16 +165,13 @@ class ZeroFPRIteration(PANOCIteration):
                 s.x.axpby_(1.0, s.xbar_prev, s.tau, s.d)  # :201
                 s.Ax.axpby_(1.0, s.Axbar, s.tau, s.Ad)  # :202
                 s.f_Ax, _ = value_and_gradient_into(self.f, s.Ax, s.grad_f_Ax)  # :204-205
-                # (measured at config 4's size, profiles/r5_pair_sweep_rate.log: a pair sweep costs 1.02 single sweeps, so further
-                # points are carried whenever there are any -- "every"; "always" / "hint" restrict it to an iteration's first sweep /
-                # to the first sweep after an iteration that rejected tau = 1, with two points)
-                policy = self.pair_trials if isinstance(self.pair_trials, str) else "every"
-                want = (k == 1 and (s.pair_hint or policy != "hint")) or (policy == "every" and k > 1)
+                # (measured at config 4's size, profiles/r5_pair_sweep_rate.log: a pair sweep and a three-point sweep both cost 1.01-1.03
+                # single sweeps, so further points are carried whenever there are any)
                 ahead = []  # the trial points behind this one: (tau, buffer set)
-                if self._fused_tn and s.pair and want and tau_next > 0:
+                if self._fused_tn and s.pair and tau_next > 0:
                     ahead.append((tau_next, "_sp"))
                     tau_next2 = R(0) if k + 1 >= self.max_backtracks - 1 else R(tau_next / R(2))
-                    if s.trio and policy == "every" and tau_next2 > 0:
+                    if s.trio and tau_next2 > 0:
                         ahead.append((tau_next2, "_sp2"))
                 f_ahead = []
                 for t_, sfx in ahead:
@@ -233,9 +229,7 @@ class ZeroFPRIteration(PANOCIteration):
             FBE_x = R(self._model(s) + s.g_xbar)  # :210
             if FBE_x <= threshold:
                 break
-            first_rejected = first_rejected or k == 1
             s.tau = tau_next  # :216
-        s.pair_hint = first_rejected
         return s
 
 

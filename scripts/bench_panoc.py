@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--loss", choices=["logistic", "sqdist"], default="logistic")
     ap.add_argument("--images", type=int, default=1, help="0: the explicit product A d (panoc.jl:180) instead of the L-BFGS image slab")
     ap.add_argument("--speculate", type=int, default=1, help="PANOCplus: 0 = two reads of A per iteration (round 4)")
-    ap.add_argument("--pair-trials", default="1", help="ZeroFPR: 0 = one trial point of the line search per sweep (round 4); 1 = every (default); always; hint")
+    ap.add_argument("--pair-trials", type=int, default=1, help="ZeroFPR: 0 = one trial point of the line search per sweep (round 4)")
     ap.add_argument("--trio-trials", type=int, default=1, help="ZeroFPR: 0 = at most two trial points per sweep")
     ap.add_argument("--algo", choices=["panoc", "zerofpr", "panocplus", "ffb", "ffb-generic"], default="panoc",
                     help="ffb: FastForwardBackward (adaptive) on Composed(loss, A), engine 'composed' (one read of A per "
@@ -46,7 +46,7 @@ def main():
     newton = {"panoc": "PANOCIteration", "zerofpr": "ZeroFPRIteration", "panocplus": "PANOCplusIteration"}
     if args.algo in newton:
         iteration = getattr(pa, newton[args.algo])(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype), images=bool(args.images),
-                                                   pair_trials=args.pair_trials if args.pair_trials in ("always", "every", "hint") else bool(int(args.pair_trials)),
+                                                   pair_trials=bool(args.pair_trials),
                                                    trio_trials=bool(args.trio_trials), speculate=bool(args.speculate))
     else:
         iteration = pa.FastForwardBackwardIteration(f=pa.Composed(f, A), g=pa.NormL1(lam), x0=np.zeros(n, dtype),

@@ -1997,14 +1997,14 @@ def test_three_point_sweep_equals_three_single_sweeps(pa, dtype):
         assert e.value.code == pa.PG_ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("policy,trio", [("always", False), ("hint", False), (True, False), (True, True)], ids=["always", "hint", "True", "three"])
-def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy, trio):
-    """ZeroFPR's line search with two trial points per sweep (zerofpr.py over pg_mat_fused_tn_pair): the
-    trial point of tau / 2 is evaluated speculatively in the sweep of tau and looked at only after tau was rejected, so the
-    DECISIONS are the reference's.  Float64, logistic + L1 on 6000 x 24000 (47 row groups: inside the pair kernel's range), adaptive
-    step: the same gamma and tau at every iteration as the oracle (zerofpr.jl:142-220 restated), iterates to 1e-8, fewer reads of A
-    than with one trial point per sweep -- under all three policies (every first sweep / the first sweep after a rejected tau = 1 /
-    True = every sweep of the search) and with THREE points per sweep (pg_mat_fused_tn_trio, the default: fewer reads again)."""
+@pytest.mark.parametrize("trio", [False, True], ids=["two", "three"])
+def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, trio):
+    """ZeroFPR's line search with two / three trial points per sweep (zerofpr.py over pg_mat_fused_tn_pair / pg_mat_fused_tn_trio;
+    VERDICT r4 next-round 4): the points of tau / 2 (and tau / 4) are evaluated ahead in the sweep of tau and looked at only after
+    the one before was rejected, so the DECISIONS are the reference's.  Float64, logistic + L1 on 6000 x 24000 (47 row groups: inside
+    the kernels' range), adaptive step: the same gamma and tau at every iteration as the oracle (zerofpr.jl:142-220 restated),
+    iterates to 1e-8, fewer reads of A than with one trial point per sweep, and with three points exactly ceil(k / 2) - ceil(k / 3)
+    fewer than with two for every search of k trial points."""
     dtype = np.float64
     rng = np.random.default_rng(4)
     m, n = 6000, 24000  # (under-determined like config 4: on tall problems the search never leaves tau = 1)
@@ -2015,7 +2015,7 @@ def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy, trio):
     _, g0 = o.LogisticLoss(b).value_and_gradient(np.zeros(m))
     lam = dtype(0.1 * np.max(np.abs(A.T @ g0)))
     x0 = np.zeros(n, dtype)
-    it_g = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=policy, trio_trials=trio)
+    it_g = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=True, trio_trials=trio)
     it_1 = pa.ZeroFPRIteration(f=pa.LogisticLoss(b), A=A, g=pa.NormL1(lam), x0=x0, pair_trials=False)
     it_o = o.ZeroFPRIteration(f=o.LogisticLoss(b), A=A, g=o.NormL1(lam), x0=x0)
     taus = []
@@ -2027,11 +2027,11 @@ def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, policy, trio):
     assert any(t < 1.0 for t in taus[1:]), taus  # the search did backtrack: the second trial points were used
     assert sg.pair_sweeps + sg.trio_sweeps > 0 and it_g.counters["A_passes"] < it_1.counters["A_passes"], (sg.pair_sweeps, it_g.counters, it_1.counters)
     assert (sg.trio_sweeps > 0) == trio, (sg.trio_sweeps, sg.pair_sweeps)
-    if trio and "True" in _ZFPR_PASSES:  # a search of k trial points takes ceil(k / 3) sweeps where pairs take ceil(k / 2)
+    if trio and "two" in _ZFPR_PASSES:  # a search of k trial points takes ceil(k / 3) sweeps where pairs take ceil(k / 2)
         trials = [int(round(np.log2(1.0 / t))) + 1 for t in taus if t > 0]
         saved = sum(-(-k // 2) - -(-k // 3) for k in trials)
-        assert it_g.counters["A_passes"] == _ZFPR_PASSES["True"] - saved, (it_g.counters, _ZFPR_PASSES, taus)
-    _ZFPR_PASSES[str(policy) if not trio else "three"] = it_g.counters["A_passes"]
+        assert it_g.counters["A_passes"] == _ZFPR_PASSES["two"] - saved, (it_g.counters, _ZFPR_PASSES, taus)
+    _ZFPR_PASSES["three" if trio else "two"] = it_g.counters["A_passes"]
 
 
 _ZFPR_PASSES = {}
@@ -2043,7 +2043,7 @@ def test_panocplus_second_pass_rides_in_the_next_first_sweep(pa):
     second rides in the NEXT iteration's first sweep, taken ahead into a second set of buffers (panocplus.py::_speculate over
     pg_mat_fused_tn_pair_res).  Float64, logistic + L1 on 6000 x 24000 (inside the pair kernel's range), adaptive step: gamma, tau, z,
     At_grad_f_Az and the stopping measure of EVERY iteration equal the oracle's and the non-speculating run's; about one read of A
-    per iteration instead of two; a solve to the stopping rule ends within a few iterations of the oracle's at the same minimiser."""
+    per iteration instead of two.  (The solve to the stopping rule: test_newton_family_final_objective_at_config4_column_length[PANOCplus].)"""
     dtype = np.float64
     rng = np.random.default_rng(4)
     m, n = 6000, 24000
@@ -2072,16 +2072,6 @@ def test_panocplus_second_pass_rides_in_the_next_first_sweep(pa):
         assert measure(ss) == pytest.approx(measure(so), rel=1e-6, abs=1e-9), k
     ps, p2 = it_s.counters["A_passes"], it_2.counters["A_passes"]
     assert p2 >= 2 * (its - 1) and ps <= p2 - (its - 6), (ps, p2)  # one read per iteration where the other run takes two
-    zs, ks = pa.PANOCplus(tol=1e-6, maxit=300)(x0=x0, f=pa.LogisticLoss(b), A=Ad, g=pa.NormL1(lam))
-    zs = zs.numpy() if hasattr(zs, "numpy") else np.asarray(zs)
-    zo, ko = o.panocplus(tol=1e-6, maxit=300, x0=x0, f=o.LogisticLoss(b), A=A, g=o.NormL1(lam))
-    # (170 quasi-Newton iterations amplify the rounding of the two summation orders: the trajectories end within a few
-    # iterations of each other at the same minimiser, not at the same iteration)
-    assert abs(ks - ko) <= 0.1 * ko + 2 and ks < 300, (ks, ko)
-    assert np.max(np.abs(zs - zo)) <= 1e-5 * max(1.0, np.max(np.abs(zo))), (ks, ko)
-    A64, b64 = A, b
-    obj = lambda z: float(np.sum(np.log1p(np.exp(-(A64 @ z - b64)))) + float(lam) * np.sum(np.abs(z)))
-    assert abs(obj(zs) - obj(zo)) <= 1e-9 * abs(obj(zo)), (obj(zs), obj(zo))
 
 
 # ------------------------------------------------------------------------------------------------
