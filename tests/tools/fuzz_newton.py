@@ -2,7 +2,8 @@
 """Randomised differential test of the widened rows: PANOC / ZeroFPR / PANOCplus (L-BFGS directions,
 general A, squared-distance and logistic losses) and DouglasRachford (separable quadratic + box / L1, stepping and the
 K-iterations-per-sweep loop) against the CPU restatement.  Usage: python tests/tools/fuzz_newton.py [cases] [first_seed] [tall].
-`tall`: PANOC / ZeroFPR / PANOCplus only, column lengths 600 .. 140000 with few columns."""
+`tall`: PANOC / ZeroFPR / PANOCplus only, column lengths 600 .. 140000 with few columns.  `wide`: ZeroFPR / PANOCplus on under-determined
+problems whose columns are 33 .. 64 row groups long (the two- and three-point sweeps' range; the line searches backtrack there)."""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ from oracle import proxgrad_oracle as o  # noqa: E402
 
 
 TALL = False
+WIDE = False
 
 
 def one_case(seed):
@@ -23,7 +25,7 @@ def one_case(seed):
     dtype = np.float64 if rng.random() < 0.7 else np.float32
     alg = rng.choice(["panoc", "zerofpr", "panocplus", "dr"])
     fails = []
-    if alg == "dr" and not TALL:
+    if alg == "dr" and not TALL and not WIDE:
         n = int(rng.choice([1, 7, 64, 1000, 4099])) if rng.random() < 0.5 else int(rng.integers(1, 20000))
         vec = rng.random() < 0.7
         d = (0.1 + np.abs(rng.standard_normal(n))).astype(dtype) if vec else dtype(0.1 + rng.random())
@@ -48,9 +50,13 @@ def one_case(seed):
             m = int(rng.integers(2049, 140000))
         n = int(rng.choice([2, 7, 33, 64, 130]))
         alg = str(rng.choice(["panoc", "zerofpr", "panocplus"]))
+    if WIDE:  # columns of 33 .. 64 row groups of 1 KiB, more columns than rows, a sparse solution: ZeroFPR's search goes to tau / 4
+        m = int(rng.integers(33 * 1024 // np.dtype(dtype).itemsize - 200, 64 * 1024 // np.dtype(dtype).itemsize + 1))
+        n = int(m * rng.uniform(1.2, 2.0))
+        alg = str(rng.choice(["zerofpr", "zerofpr", "panocplus"]))
     A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype) / dtype(np.sqrt(m)))
     xt = np.zeros(n, dtype)
-    nzc = max(1, n // 10)
+    nzc = max(1, n // (1000 if WIDE else 10))
     xt[rng.choice(n, nzc, replace=False)] = rng.standard_normal(nzc).astype(dtype)
     b = (A @ xt + dtype(0.01) * rng.standard_normal(m).astype(dtype)).astype(dtype)
     loss = rng.choice(["sqdist", "logistic"])
@@ -96,8 +102,9 @@ def one_case(seed):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    global TALL
+    global TALL, WIDE
     TALL = "tall" in sys.argv[3:]
+    WIDE = "wide" in sys.argv[3:]
     pa.get_context()
     bad, t0 = 0, time.perf_counter()
     for seed in range(first, first + cases):
