@@ -1,3 +1,6 @@
+"""Per-iteration trace of ZeroFPR / PANOCplus / PANOC at BASELINE config 4's size: (iteration, gamma, tau, reads of A in the iteration, cumulative launches of
+gemv_n / gemv_t / the sweeps).  What it showed (round 5): gamma goes 2.10 -> 0.0657 (five halvings) inside the FIRST iteration -- the products of the start-up --
+and stays; ZeroFPR then reads A twice per iteration whatever tau its search accepts.    python scripts/r5_trace_gamma.py"""
 import sys, json
 sys.path.insert(0, ".")
 import numpy as np
