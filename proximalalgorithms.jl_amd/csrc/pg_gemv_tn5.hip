@@ -25,7 +25,7 @@ struct TNTrio {
   T* partials[3];                          // [gridDim.x][ld] each
 };
 
-template <typename T, int U, int C, int WAVES, int R3L>
+template <typename T, int U, int C, int WAVES, int R3L, int NT>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, TNTrio<T> b) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
   V* const r2s = r1s + U * WAVE;
   V* const r3s = r2s + U * WAVE;
   const int64_t ncg = (a.n + C - 1) / C;
-  V racc[3][U], r3[U - R3L];
+  V racc[3][U], r3[U - R3L > 0 ? U - R3L : 1];  // (R3L = U: the third slice whole in LDS)
   int rgo[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
     r1s[u * WAVE] = rv[0];
     r2s[u * WAVE] = rv[1];
     if (u < R3L) r3s[u * WAVE] = rv[2];
-    else r3[u - R3L] = rv[2];
+    else r3[u < R3L ? 0 : u - R3L] = rv[2];
   }
   // The epilogues of a step's 3 C (instance, column) pairs run in PARALLEL LANES, pair q = p C + c in lane q of every wave (its own
   // sum of the waves' partial dots, its own x_j, prox and residual; lane q of wave 0 writes the pair's outputs and keeps its four
@@ -192,12 +192,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
 
   const CgMap map(ncg, C, a.line_cols, blockIdx.x, gridDim.x);
   const int64_t cnt = map.cnt;
-  Tile t;
-  int buf = 0;
-  for (int64_t i = 0; i < cnt; ++i) {
-    load(t, map.at(i));
-    process(t, map.at(i), buf);
-    buf ^= 1;
+  if constexpr (NT == 2) {  // shorter columns leave the registers for it: the next tile's loads in flight while this one is consumed
+    Tile ta, tb;
+    int64_t i = 0;
+    if (i < cnt) load(ta, map.at(i));
+    while (i < cnt) {
+      if (i + 1 < cnt) load(tb, map.at(i + 1));
+      process(ta, map.at(i), 0);
+      if (i + 1 >= cnt) break;
+      if (i + 2 < cnt) load(ta, map.at(i + 2));
+      process(tb, map.at(i + 1), 1);
+      i += 2;
+    }
+  } else {
+    Tile t;
+    int buf = 0;
+    for (int64_t i = 0; i < cnt; ++i) {
+      load(t, map.at(i));
+      process(t, map.at(i), buf);
+      buf ^= 1;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
   grid_reduce_finalize<12, 0x222u, WAVES>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
 }
 
-template <typename T, int U, int C, int WAVES, int R3L>
+template <typename T, int U, int C, int WAVES, int R3L, int NT>
 pg_status launch_tnm_trio(pg_mat* A, TNArgs<T>& a, TNTrio<T>& b, int* blocks_out) {
   pg_ctx* c = A->ctx;
   const int64_t ncg = (A->n + C - 1) / C;
@@ -234,24 +248,27 @@ pg_status launch_tnm_trio(pg_mat* A, TNArgs<T>& a, TNTrio<T>& b, int* blocks_out
     std::lock_guard<std::mutex> lock(mu);
     const int dev = c->device & 63;
     if (!opted_in[dev]) {
-      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnm_trio_kernel<T, U, C, WAVES, R3L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_tnm_trio_kernel<T, U, C, WAVES, R3L, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       opted_in[dev] = true;
     }
   }
-  hipLaunchKernelGGL((gemv_tnm_trio_kernel<T, U, C, WAVES, R3L>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, c->stream, a, b);
+  hipLaunchKernelGGL((gemv_tnm_trio_kernel<T, U, C, WAVES, R3L, NT>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, c->stream, a, b);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
 
 template <typename T>
 pg_status launch_tn_trio(pg_mat* A, TNArgs<T>& a, TNTrio<T>& b, int* blocks_out) {
-  // eight waves of U = ceil(nrg / 8) row groups, two columns per step, one register tile: the pair sweep's geometry.  At U = 8
+  // eight waves of U = ceil(nrg / 8) row groups, two columns per step, one register tile (two at U = 5): the pair sweep's geometry.  At U = 8
   // the third slice keeps three of its eight row groups per wave in LDS (152 KiB with the two whole slices): 238 registers in
   // Float32, 252 in Float64, nothing in scratch (all of it in registers: 228 / 240 bytes per lane spilled).
   const int U = (a.nrg + 7) / 8;
-#define PG_TNMT(UU, LL) \
-  if (U == UU) return launch_tnm_trio<T, UU, 2, 8, LL>(A, a, b, blocks_out)
-  PG_TNMT(5, 0); PG_TNMT(6, 0); PG_TNMT(7, 0); PG_TNMT(8, 3);
+  // U = 5 (33 .. 40 row groups) leaves the registers for a second tile -- 244 / 248 registers, nothing in scratch; 9216 rows: 1.13 -> 1.05
+  // single sweeps, 10240 rows: 1.07 -> 1.01 (profiles/r5_pair_sweep_rate.log); at U = 6 it spills 32 / 56 bytes per lane and gains 0.5 %: one tile
+  const int nt = U == 5 ? 2 : 1;
+#define PG_TNMT(UU, LL, NN) \
+  if (U == UU && nt == NN) return launch_tnm_trio<T, UU, 2, 8, LL, NN>(A, a, b, blocks_out)
+  PG_TNMT(5, 0, 2); PG_TNMT(6, 0, 1); PG_TNMT(7, 0, 1); PG_TNMT(8, 3, 1);
 #undef PG_TNMT
   pg_set_error("no three-point sweep for %d row groups", a.nrg);
   return PG_ERR_UNSUPPORTED;
