@@ -440,15 +440,19 @@ pg_status launch_tn_pair(pg_mat* A, TNArgs<T>& a, const T* r2, const T* x2, T* g
   }
   TNPair<T> b;
   b.r = r2, b.x = x2, b.g_out = g2, b.y = y2, b.z_new = z2, b.res = res2, b.partials = nullptr;
-  // Eight waves of U = ceil(nrg / 8) row groups, TWO columns per step, ONE register tile (two waves per SIMD cover each other's
+  // Eight waves of U = ceil(nrg / 8) row groups, TWO columns per step, ONE register tile at U = 7, 8 (two waves per SIMD cover each other's
   // loads): measured at config 4's size (scripts/r5_pair_sweep_rate.py, profiles/r5_pair_sweep_rate.log) 9.26 ms against the single
   // sweep's 9.09 -- both instances for 1.02 single sweeps, 0.885 of 8 TB/s -- where four waves of U = 16, one column per step and
   // two tiles take 10.66 ms (1.17), eight waves with one column and two tiles 9.75 (1.07), four waves, two columns, one tile 9.62.
   const int U = (a.nrg + 7) / 8;
   pg_status st = PG_ERR_UNSUPPORTED;
-#define PG_TNMP(UU) \
-  if (U == UU) st = launch_tnm_pair<T, UU, 2, 8, 1>(A, a, b, blocks_out)
-  PG_TNMP(5); PG_TNMP(6); PG_TNMP(7); PG_TNMP(8);
+  // U <= 6 (33 .. 48 row groups) leaves the registers for a second tile (215 / 245 registers in Float32, 225 / 256 in Float64, nothing in
+  // scratch): 9216 rows 1.17 -> 1.08 single sweeps, 10240 rows 1.10 -> 1.03, 12288 rows 1.06 -> 1.02; at U = 7 it spills and costs 14 %
+  // (profiles/r5_pair_sweep_rate.log, seventh collection)
+  const int nt = U <= 6 ? 2 : 1;
+#define PG_TNMP(UU, NN) \
+  if (U == UU && nt == NN) st = launch_tnm_pair<T, UU, 2, 8, NN>(A, a, b, blocks_out)
+  PG_TNMP(5, 2); PG_TNMP(6, 2); PG_TNMP(7, 1); PG_TNMP(8, 1);
 #undef PG_TNMP
   *partials2_out = b.partials;
   return st;
