@@ -10,7 +10,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libproxgrad_hip.so")
 SOURCES = ["pg_core.hip", "pg_gemv.hip", "pg_gemv_tn2.hip", "pg_gemv_tn3.hip", "pg_gemv_tn4.hip", "pg_gemv_tn4d.hip", "pg_gemv_tn5.hip", "pg_gemv_dys.hip", "pg_vec.hip", "pg_iter.hip", "pg_persist.hip", "pg_lbfgs.hip", "pg_comm.hip"]
-HEADERS = [os.path.join(CSRC, "pg_internal.h"), os.path.join(CSRC, "pg_iter_internal.h"), os.path.join(CSRC, "pg_ew.h"), os.path.join(CSRC, "pg_gemv_tn.h"), os.path.join(CSRC, "pg_gemv_tnt.h"), os.path.join(CSRC, "pg_cgmap.h"), os.path.join(CSRC, "pg_gemv_tn4.hip"), os.path.join(INCLUDE, "proxgrad_hip.h"), os.path.join(INCLUDE, "proxgrad_hip_ext.h")]
+# every header under csrc/ and include/ (pg_gemv_tn4.hip is also compiled a second time, as pg_gemv_tn4d.hip's body)
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(CSRC, "pg_gemv_tn4.hip"), os.path.join(INCLUDE, "proxgrad_hip.h"), os.path.join(INCLUDE, "proxgrad_hip_ext.h")]
 ARCH = "gfx950"
 
 

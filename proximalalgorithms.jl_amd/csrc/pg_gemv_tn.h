@@ -16,18 +16,23 @@ __device__ __forceinline__ V nt_load(const V* p) {
   return __builtin_nontemporal_load(p);
 }
 
-// Wave-wide sum in every lane.  The four intra-row steps are DPP moves (no LDS round trip): quad_perm xor 1 and
+#include "pg_lanes.h"
+
+// Wave-wide sum in every lane, no LDS round trip.  The four intra-row steps are DPP moves: quad_perm xor 1 and
 // xor 2, then row_half_mirror / row_mirror (lane i <-> 7-i / 15-i: after the quad steps every lane of a quad holds
 // the quad sum, so the mirrored partner contributes exactly the other quad / the other half-row); the two
-// cross-row steps (xor 16, xor 32) go through ds_bpermute.  Fixed order => deterministic.
+// cross-row steps (xor 16, xor 32) are v_permlane16_swap / v_permlane32_swap exchanges (pg_lanes.h) -- the same pairs
+// and, addition being commutative, the same bits as the ds_bpermute shuffles they replace (rounds 1-5: two LDS round
+// trips per column and step, ~200 cycles nobody hides where a compute unit runs one wave per SIMD).  Fixed order =>
+// deterministic.
 template <typename T>
 __device__ __forceinline__ T wave_allsum(T v) {
   v += pg_dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  (xor 1)
   v += pg_dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  (xor 2)
   v += pg_dpp_mov<0x141>(v);  // row_half_mirror
   v += pg_dpp_mov<0x140>(v);  // row_mirror
-  v += pg_shfl_xor(v, 16);
-  v += pg_shfl_xor(v, 32);
+  v = swap16_add(v, v);       // rows 0 <-> 1, 2 <-> 3  (xor 16)
+  v = swap32_add(v, v);       // lanes l <-> l + 32     (xor 32)
   return v;
 }
 

@@ -23,6 +23,7 @@ namespace pgtn {
 pg_status peer_scalar_exchange(pg_ctx* c, const double* f_local, double* f_out);
 namespace {
 #include "pg_gemv_tnt.h"
+#include "pg_gemv_tnp1.h"
 
 constexpr int PEER_TEAMS_MAX = 1024;  // workgroups per device the inbox has ring space for (up to four per compute unit)
 constexpr size_t PEER_RING_BYTES = (size_t)PEER_TEAMS_MAX * PEER_RING * (size_t)(TEAM_MAX * 8) * sizeof(unsigned long long);  // C * G <= 8
@@ -107,7 +108,8 @@ pg_status grow_partials_without_free(pg_mat* A, int S) {
   return PG_OK;
 }
 
-template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int WAVES = 4>
+// K1: gemv_tnp1_kernel (pg_gemv_tnp1.h, one wave per column: WAVES = 1) instead of gemv_tnt_kernel<..., PEER>; same protocol
+template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int WAVES = 4, bool K1 = false>
 pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   constexpr int G = (int)sizeof(T) / 4;
   static_assert(C * G <= 8, "the inbox holds eight granules per member and step");
@@ -177,7 +179,10 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   a.tag_base = c->rteam.epoch << 24;
   *blocks_out = (int)nteams;
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
-  const void* kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>);
+  static_assert(!K1 || WAVES == 1, "gemv_tnp1_kernel is the one-wave sweep");
+  const void* kern;
+  if constexpr (K1) kern = reinterpret_cast<const void*>(&gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY>);
+  else kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>);
   if (lds + 4096 > 64 * 1024) {
     static std::mutex mu;
     static bool opted_in[64] = {};
@@ -198,7 +203,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead
-  hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+  if constexpr (K1) hipLaunchKernelGGL((gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY>), dim3(grid), dim3(64), lds, c->stream, a);
+  else hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -234,12 +240,18 @@ PeerGeom peer_geometry(int nrg, bool f64) {
   PG_TNP_CASE_D(8, 2, 2, 2, 2, 1); PG_TNP_CASE_D(8, 2, 2, 2, 2, 2); PG_TNP_CASE_D(16, 1, 2, 2, 2, 2); \
   PG_TNP_CASE_D(16, 1, 2, 2, 2, 4); PG_TNP_CASE_D(2, 2, 2, 2, 0, 4); PG_TNP_CASE_D(4, 2, 2, 2, 0, 4); \
   PG_TNP_CASE_D(8, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 0, 4); PG_TNP_CASE_D(16, 1, 2, 2, 1, 4); \
-  PG_TNP_CASE(1, 4, 2, 2, 2, 1); PG_TNP_CASE(2, 4, 2, 2, 2, 1); PG_TNP_CASE(3, 4, 2, 2, 2, 1); PG_TNP_CASE(4, 4, 2, 2, 2, 1); \
-  PG_TNP_CASE(5, 2, 2, 2, 2, 1); PG_TNP_CASE(6, 2, 2, 2, 2, 1); PG_TNP_CASE(7, 2, 2, 2, 2, 1); PG_TNP_CASE(5, 2, 2, 2, 2, 2); \
+  PG_TNP_CASE(5, 2, 2, 2, 2, 2); \
   PG_TNP_CASE(6, 2, 2, 2, 2, 2); PG_TNP_CASE(7, 2, 2, 2, 2, 2); PG_TNP_CASE(9, 1, 2, 2, 2, 2); PG_TNP_CASE(10, 1, 2, 2, 2, 2); \
   PG_TNP_CASE(11, 1, 2, 2, 2, 2); PG_TNP_CASE(12, 1, 2, 2, 2, 2); PG_TNP_CASE(13, 1, 2, 2, 2, 2); PG_TNP_CASE(14, 1, 2, 2, 2, 2); \
   PG_TNP_CASE(15, 1, 2, 2, 2, 2); PG_TNP_CASE(9, 1, 2, 2, 2, 4); PG_TNP_CASE(10, 1, 2, 2, 2, 4); PG_TNP_CASE(11, 1, 2, 2, 2, 4); \
   PG_TNP_CASE(12, 1, 2, 2, 2, 4); PG_TNP_CASE(13, 1, 2, 2, 2, 4); PG_TNP_CASE(14, 1, 2, 2, 2, 4); PG_TNP_CASE(15, 1, 2, 2, 2, 4)
+// ... of gemv_tnp1_kernel, the one-wave sweep of blocks up to 8 row groups (round 6; W = 1): (U, C, LAG, PF, LAGR)
+#define PG_TNP1_GEOMETRIES_F32 \
+  PG_TNP1_CASE(1, 4, 2, 2, 2); PG_TNP1_CASE(2, 4, 2, 2, 2); PG_TNP1_CASE(3, 4, 2, 2, 2); PG_TNP1_CASE(4, 4, 2, 2, 2); \
+  PG_TNP1_CASE(5, 2, 2, 2, 2); PG_TNP1_CASE(6, 2, 2, 2, 2); PG_TNP1_CASE(7, 2, 2, 2, 2); PG_TNP1_CASE_D(8, 2, 2, 2, 2)
+#define PG_TNP1_GEOMETRIES_F64 \
+  PG_TNP1_CASE(1, 2, 2, 2, 2); PG_TNP1_CASE(2, 2, 2, 2, 2); PG_TNP1_CASE(3, 2, 2, 2, 2); PG_TNP1_CASE(4, 2, 2, 2, 2); \
+  PG_TNP1_CASE(5, 2, 2, 2, 2); PG_TNP1_CASE(6, 2, 2, 2, 2); PG_TNP1_CASE(7, 2, 2, 2, 2); PG_TNP1_CASE_D(8, 2, 2, 2, 2)
 
 // Tunables (environment, under PG_TUNE, for experiments): PG_TNP_W, PG_TNP_C, PG_TNP_LAG, PG_TNP_LAGR, PG_TNP_PF, PG_TNP_WGS.
 template <typename T>
@@ -269,15 +281,26 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const int C = env_int("PG_TNP_C", g.C), LAG = env_int("PG_TNP_LAG", g.LAG), LAGR = env_int("PG_TNP_LAGR", g.LAGR);
   const int PF = env_int("PG_TNP_PF", g.PF), WGS = env_int("PG_TNP_WGS", g.WGS);
   const bool delay = c->test_team_delay_on;
+  // one wave per column (W = 1): gemv_tnp1_kernel; PG_TNP_K1=0 under PG_TUNE: round 5's gemv_tnt_kernel<..., W = 1> (kept at U = 8 for the A/B)
+  const bool k1 = W == 1 && env_int("PG_TNP_K1", 1) != 0;
+#define PG_TNP1_CASE(UU, CC, LL, PP, RR) \
+  if (k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, 1, true>(A, a, blocks_out, WGS)
+#define PG_TNP1_CASE_D(UU, CC, LL, PP, RR) \
+  PG_TNP1_CASE(UU, CC, LL, PP, RR);        \
+  if (k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, 1, true>(A, a, blocks_out, WGS)
+  if constexpr (sizeof(T) == 8) {
+    PG_TNP1_GEOMETRIES_F64;
+  } else {
+    PG_TNP1_GEOMETRIES_F32;
+  }
+#undef PG_TNP1_CASE
+#undef PG_TNP1_CASE_D
 #define PG_TNP_CASE(UU, CC, LL, PP, RR, WW)                                                             \
-  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, WW>(A, a, blocks_out, WGS)
+  if (!k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, WW>(A, a, blocks_out, WGS)
 #define PG_TNP_CASE_D(UU, CC, LL, PP, RR, WW)                                                           \
   PG_TNP_CASE(UU, CC, LL, PP, RR, WW);                                                                  \
-  if (U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, WW>(A, a, blocks_out, WGS)
+  if (!k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, WW>(A, a, blocks_out, WGS)
   PG_TNP_GEOMETRIES;
-  if constexpr (sizeof(T) == 8) {
-    PG_TNP_CASE(1, 2, 2, 2, 2, 1); PG_TNP_CASE(2, 2, 2, 2, 2, 1); PG_TNP_CASE(3, 2, 2, 2, 2, 1); PG_TNP_CASE(4, 2, 2, 2, 2, 1);
-  }
 #undef PG_TNP_CASE
 #undef PG_TNP_CASE_D
   pg_set_error("no row-team instantiation for W=%d U=%d C=%d LAG=%d PF=%d LAGR=%d%s", W, U, C, LAG, PF, LAGR, delay ? " with the latency injector" : "");

@@ -1,0 +1,396 @@
+// The row-team sweep of SHORT row blocks (round 6): gemv_tnp1_kernel -- one WAVE per workgroup holds the whole column of its
+// device's block (up to 8 row groups of 1 KiB: 2048 rows of Float32, 1024 of Float64; the headline's block at N = 8).  Included
+// inside `namespace pgtn { namespace {` by pg_gemv_tn4.hip after pg_gemv_tnt.h, whose PROTOCOL it speaks unchanged (ring layout,
+// tagged 8-byte granules, epochs, PEER_RING slots, the DELAY stamps, the telemetry words): a device running this kernel and
+// gemv_tnt_kernel<..., WAVES = 1, PEER> produce the same granules.  What changed is the instruction stream.
+//
+// Why.  With one wave per SIMD a wave issues at most one instruction every four cycles and nothing hides what it waits for.
+// Round 5's sweep spent ~950 instructions per 16 KiB step (profiles/r6_peer_sweep_counters.md): the epilogue of every column ran
+// in every lane, one column after the other, with its branches; the member-order sum was a v_readlane + v_add per member and
+// column behind a jump table; the column map was evaluated three times; the wave sum crossed LDS twice per column and the
+// partial dots once more (five exposed LDS round trips per step).  Here:
+//   * dots as packed partial sums (v_pk_fma_f32: two multiply-adds per instruction), reduced ACROSS the C columns at once
+//     (cr_stage, pg_lanes.h: permlane swaps and DPP moves, no LDS);
+//   * the step's granules are summed over the members by DPP row shifts -- lane c*G of every 16-lane row adds the lanes
+//     c*G + k*C*G of its row, k ascending (= member order), rows combined by two permlane swaps -- TM - 1 adds for all columns
+//     together, the same order on every device;
+//   * ONE epilogue per step, lane-parallel (lane c*G works on column c): one load each of x, z_old (and the per-element
+//     parameters), one store per output vector, no per-column branch;
+//   * v_j returns through v_readlane (a scalar operand of the multiply-adds), as in gemv_tnw_kernel.
+// Reference statements as for gemv_tnt_kernel: benchmark/benchmarks.jl:15-16, fast_forward_backward.jl:135-142
+// (forward_backward.jl:113-120).
+#pragma once
+
+template <typename T>
+struct Pair2;
+template <>
+struct Pair2<float> {
+  typedef float type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Pair2<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+
+// lane l <- lane l + K of the same 16-lane row (0 past the end of the row): DPP row_shl
+template <int K, typename T>
+__device__ __forceinline__ T row_from_above(T v) {
+  static_assert(K >= 1 && K <= 15, "a shift inside one row");
+  return pg_dpp_mov<0x100 + K>(v);
+}
+
+// acc += sum over k = 1 .. N - 1 of the lanes S * k above (ascending): the members of one row, in member order
+template <int S, int K, typename T>
+__device__ __forceinline__ void row_member_sum(T& acc, const T val) {
+  if constexpr (S * K <= 15) {
+    acc += row_from_above<S * K>(val);
+    row_member_sum<S, K + 1>(acc, val);
+  }
+}
+
+template <typename T, int U, int C, int LAG, int PF, int LAGR, bool DELAY>
+__global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
+  using V = typename VecOf<T>::type;
+  using T2 = typename Pair2<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int G = (int)sizeof(T) / 4;  // granules per value
+  constexpr int S = C * G;               // granules a member posts per step
+  constexpr int GL = 64 / C;             // lanes that hold the same column after the column-parallel reduction
+  constexpr int RING = PEER_RING;
+  constexpr int LT = LAG + LAGR;
+  static_assert(LT > 0 && 2 * LT + 2 <= RING, "the totals of a step are consumed LT > 0 steps later; the ring holds 2 LT + 2 steps");
+  static_assert(S <= 8 && (C & (C - 1)) == 0 && C >= 1, "C a power of two, at most eight granules per member and step");
+  extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
+  V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][C][U][64]
+  const int lane = threadIdx.x;
+  const int team = (int)blockIdx.x;
+  const int member = a.peer_rank;
+  const int TM = a.peer_n;
+  const int npoll = TM * S;
+  const int64_t ncg = (a.n + C - 1) / C;
+  const CgMap map(ncg, C, a.line_cols, team, a.nteams);
+  const int64_t cnt = map.cnt;
+  const size_t ring_off = (size_t)team * RING * (size_t)(TEAM_MAX * S);
+  unsigned long long* const ring = a.xch + ring_off;
+
+  V rk[U], racc[U];
+  int rgc[U];  // row groups past the end of this device's block are clamped to its last one; their r is zero
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    rgc[u] = max(0, min(u, a.nrg - 1));
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) racc[u][e] = T(0);
+    if (u < a.nrg) {
+      rk[u] = *reinterpret_cast<const V*>(a.r + (int64_t)u * (WAVE * VEC) + lane * VEC);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rk[u][e] = T(0);
+    }
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  bool dead = false;
+  unsigned late_steps = 0, late_polls = 0;
+  unsigned long long age_sum = 0;
+  unsigned age_cnt = 0;
+  // the epilogue's lanes: lane c * G works on column c of the step (the other lanes compute along on a clamped column, store nothing)
+  const int c_lane = min(lane / G, C - 1);
+  const bool ep_lane = lane < S && (lane % G) == 0;
+  // per-element parameters of g: always two loads (a branch around a load inside the steady loop makes the compiler wait for ALL
+  // loads in flight, pg_gemv_tnt.h); without them the loads read x, and nothing uses what they return
+  const T* const pv0 = a.p0v != nullptr ? a.p0v : a.x;
+  const T* const pv1 = a.p1v != nullptr ? a.p1v : a.x;
+  const bool has_pv = a.p0v != nullptr;
+
+  // where this lane posts: lane q * S + s (q < TM, s < S) writes granule s of this device's step into member q's inbox (its own
+  // included) -- the step's granules reach every inbox with ONE store instruction, 8 * S contiguous bytes per inbox
+  // (DELAY: the lanes behind them carry this device's stamp, one per inbox)
+  const int npoll_all = DELAY ? npoll + TM : npoll;
+  const int post_s = lane % S;
+  unsigned long long* post_ptr = nullptr;
+  {
+    const int q_of_lane = lane < npoll ? lane / S : lane - npoll;
+#pragma unroll
+    for (int q = 0; q < TEAM_MAX; ++q)
+      if (q < TM && q_of_lane == q) post_ptr = a.peer_ring[q];
+    post_ptr += ring_off + (lane < npoll ? (size_t)member * S + post_s : (size_t)TM * S + (size_t)member);
+  }
+
+  struct Tile {
+    V col[C][U];
+  };
+  struct Pend {
+    unsigned long long w;  // this lane's granule of the awaited step
+    T xs, zos, q0, q1;     // x_j, z_old_j and the per-element parameters of this lane's column
+  };
+  auto load = [&](Tile& t, int64_t i) __attribute__((always_inline)) {
+    const int64_t j0 = map.at(i) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t j = (j0 + c < a.n) ? (j0 + c) : (a.n - 1);
+      const T* __restrict__ p = a.A + j * a.ld;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        t.col[c][u] = nt_load(reinterpret_cast<const V*>(p + (int64_t)rgc[u] * (WAVE * VEC)) + lane);
+    }
+  };
+  // this device's partial dots of step i -> the inbox of every device
+  auto dot_post = [&](const Tile& t, int64_t i) __attribute__((always_inline)) {
+    T d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      T2 s2 = {T(0), T(0)};
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VEC; e += 2) {
+          const T2 x2 = {t.col[c][u][e], t.col[c][u][e + 1]}, r2 = {rk[u][e], rk[u][e + 1]};
+          s2 = __builtin_elementwise_fma(x2, r2, s2);
+        }
+      }
+      d[c] = s2[0] + s2[1];
+    }
+    cr_stage<T, C, 0>(d, lane);  // d[0] = the total of column lane / GL, in every lane of that group
+    // ONE store for all inboxes: lane q * S + s carries granule s (half s % G of column s / G) to member q
+    T mine = d[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+      const T tc = pg_readlane(d[0], c * GL);
+      if (post_s / G == c) mine = tc;
+    }
+    unsigned bits;
+    if constexpr (G == 1) {
+      bits = __builtin_bit_cast(unsigned, mine);
+    } else {
+      const unsigned long long b = __builtin_bit_cast(unsigned long long, mine);
+      bits = (post_s % G) == 0 ? (unsigned)b : (unsigned)(b >> 32);
+    }
+    if constexpr (DELAY) {
+      if (lane >= npoll) bits = (unsigned)__builtin_amdgcn_s_memrealtime();  // the stamp granules: behind the TM members' values, one per member
+    }
+    const unsigned long long word = ((unsigned long long)(a.tag_base + (unsigned)(i + 1)) << 32) | bits;
+    if (lane < npoll_all)
+      __hip_atomic_store(post_ptr + (size_t)(i % RING) * (TEAM_MAX * S), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  const int poll_lane = lane < npoll_all ? lane : npoll_all - 1;
+  const bool adds = lane < npoll && (lane % G) == 0;  // this lane's granule (pair) is a member's value of some column
+  auto arrived = [&](unsigned long long w, unsigned tag) __attribute__((always_inline)) -> bool {
+    bool ok = (unsigned)(w >> 32) == tag;
+    if constexpr (DELAY) {
+      const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+      if (lane >= npoll && lane < npoll_all) ok = ok && (now - (unsigned)w) >= a.delay_ticks;
+    }
+    return __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+  };
+  auto poll_word = [&](int64_t i) __attribute__((always_inline)) -> unsigned long long {
+    return __hip_atomic_load(ring + (size_t)(i % RING) * (TEAM_MAX * S) + poll_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  // the small loads of step i's epilogue, issued with the poll (before the tile loads: they return first)
+  auto fetch = [&](Pend& pd, int64_t i) __attribute__((always_inline)) {
+    const int64_t j = map.at(i) * C + c_lane;
+    const int64_t jc = j < a.n ? j : a.n - 1;
+    pd.xs = a.x[jc];
+    pd.zos = a.z_old[jc];
+    pd.q0 = pv0[jc];
+    pd.q1 = pv1[jc];
+  };
+  // totals of step i (all members have posted, or will shortly) -> epilogue -> v_j (0 for columns past the end)
+  auto totals = [&](int64_t i, Pend& pd, T (&vj)[C]) __attribute__((always_inline)) {
+    const unsigned tag = a.tag_base + (unsigned)(i + 1);
+    // The first look at the granules stays OUTSIDE the retry loop (pg_gemv_tnt.h).
+    if (!dead && !arrived(pd.w, tag)) {
+      long long spins = 0;
+#pragma nounroll
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        pd.w = poll_word(i);
+        if (arrived(pd.w, tag)) break;
+        if (++spins > TEAM_SPIN_LIMIT) {
+          dead = true;
+          if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      late_steps += 1;
+      late_polls += (unsigned)(spins + 1);
+    }
+    if constexpr (DELAY) {
+      const unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+      const unsigned age = now - (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pd.w, npoll);
+      if (!dead) age_sum += age, age_cnt += 1;
+    }
+    // this lane's value (lanes that hold no member's value: zero), then the sum over the members
+    T val;
+    if constexpr (G == 1) {
+      val = __builtin_bit_cast(float, (unsigned)pd.w);
+    } else {
+      const unsigned lo = (unsigned)pd.w;
+      const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x101, 0xF, 0xF, true);  // the odd lane's half
+      val = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    val = adds ? val : T(0);
+    T g = val;
+    row_member_sum<S, 1>(g, val);           // the members of this lane's row, ascending
+    if (npoll > 16) g = swap16_add(g, g);   // (wave-uniform) rows 0 + 1, 2 + 3
+    if (npoll > 32) g = swap32_add(g, g);   // (rows 0 + 1) + (rows 2 + 3): the same order on every device
+    const int64_t j = map.at(i) * C + c_lane;
+    const bool valid = j < a.n;
+    if (a.lam_ls != T(1)) g = a.lam_ls * g;
+    const T xj = pd.xs, zo = pd.zos;
+    const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
+    T zj;                            // :118 / :141
+    if (a.g_kind == PG_G_NORML1) {
+      const T th = has_pv ? pg_l1w_threshold(a.gamma, pd.q0) : a.p0;  // per-element weights lam_j
+      zj = yj <= -th ? yj + th : (yj >= th ? yj - th : T(0));
+    } else if (a.g_kind == PG_G_INDBOX) {
+      const T lo = has_pv ? pd.q0 : a.p0, hi = has_pv ? pd.q1 : a.p1;  // per-element bounds
+      zj = fmin(hi, fmax(lo, yj));
+    } else
+      zj = yj;
+    const T rj = xj - zj;                                                   // :120 / :142
+    const T vl = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);  // fast_forward_backward.jl:135 of the next iteration
+    if (ep_lane && valid) {
+      a.g_out[j] = g;
+      a.y[j] = yj;
+      a.z_new[j] = zj;
+      a.res[j] = rj;
+      if (a.v_out != nullptr) a.v_out[j] = vl;
+      if (a.g_kind == PG_G_NORML1) acc[0] += has_pv ? (double)pd.q0 * fabs((double)zj) : fabs((double)zj);
+      acc[1] = fmax(acc[1], fabs((double)rj));
+      acc[2] += (double)g * (double)rj;
+      acc[3] += (double)rj * (double)rj;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) vj[c] = pg_readlane(vl, c * G);
+  };
+  auto park_slot = [&](int64_t i) { return park + (size_t)(LAG > 0 ? i % (LAG > 0 ? LAG : 1) : 0) * (C * U * WAVE) + lane; };
+
+  // One step, as in gemv_tnt_kernel: [poll the totals of step i - LT, fetch its x_j / z_old_j] [start loading tile i + PF]
+  // [dot + post tile i] [totals of step i - LT -> v_j ; A v accumulation from the parked tile] [park tile i - LAGR].
+  auto step = [&](auto allc, Tile& cur, Tile& nxt, Tile& old, int64_t i) __attribute__((always_inline)) {
+    constexpr bool ALL = decltype(allc)::value;
+    if (!ALL && i >= cnt + LT) return;
+    const bool has_fma = ALL || i >= LT;
+    Pend pd{};
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_fma) {
+      pd.w = poll_word(i - LT);  // issued BEFORE the next tile's loads: it returns first
+      fetch(pd, i - LT);
+    }
+    // (the small loads first, pinned: loads return in issue order, and behind the tile's sixteen the epilogue would wait for them too)
+    __builtin_amdgcn_sched_barrier(0);
+    if (ALL || i + PF < cnt) load(nxt, i + PF);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ALL || i < cnt) dot_post(cur, i);
+    if (has_fma) {
+      T vj[C];
+      totals(i - LT, pd, vj);
+      if constexpr (LAG == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(old.col[c][u][e], vj[c], racc[u][e]);
+          }
+        }
+      } else {
+        // Four 16-byte reads at a time, their order pinned (pg_gemv_tnt.h: left alone the compiler issues all C * U reads up
+        // front and spills the tile that is in flight).
+        const V* __restrict__ src = park_slot(i - LT);
+        int dep = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u0 = 0; u0 < U; u0 += 4) {
+            const V* __restrict__ sp = src + dep;
+            V col[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (u0 + k < U) col[k] = sp[(c * U + u0 + k) * WAVE];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (u0 + k < U) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) racc[u0 + k][e] = fma(col[k][e], vj[c], racc[u0 + k][e]);
+              }
+            }
+            asm volatile("v_mov_b32 %0, 0" : "=v"(dep) : "v"(racc[u0][0]));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(racc[u]));
+    if constexpr (LAG > 0) {
+      if (ALL || (i >= LAGR && i - LAGR < cnt)) {
+        V* __restrict__ dst = park_slot(i - LAGR);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) dst[(c * U + u) * WAVE] = old.col[c][u];
+        }
+      }
+    }
+  };
+
+  constexpr int NR = PF + 1 + LAGR;
+  static_assert(NR >= 2 && NR <= 8, "two to eight register tiles");
+  static_assert(PF == 1 || PF == 2, "one or two tiles in flight");
+  Tile t0, t1, t2, t3, t4, t5, t6, t7;
+  auto tile = [&](auto k) __attribute__((always_inline)) -> Tile& {
+    constexpr int K = decltype(k)::value;
+    if constexpr (K == 0) return t0;
+    else if constexpr (K == 1) return t1;
+    else if constexpr (K == 2) return t2;
+    else if constexpr (K == 3) return t3;
+    else if constexpr (K == 4) return t4;
+    else if constexpr (K == 5) return t5;
+    else if constexpr (K == 6) return t6;
+    else return t7;
+  };
+  if (cnt > 0) load(t0, 0);
+  if constexpr (PF > 1) {
+    if (cnt > 1) load(t1, 1);
+  }
+  auto round = [&](auto allc, int64_t base) __attribute__((always_inline)) {
+    auto one = [&](auto sc) __attribute__((always_inline)) {
+      constexpr int SS = decltype(sc)::value;
+      if constexpr (SS < NR)
+        step(allc, tile(std::integral_constant<int, SS>{}), tile(std::integral_constant<int, (SS + PF) % NR>{}),
+             tile(std::integral_constant<int, (SS + NR - LAGR) % NR>{}), base + SS);
+    };
+    one(std::integral_constant<int, 0>{});
+    one(std::integral_constant<int, 1>{});
+    one(std::integral_constant<int, 2>{});
+    one(std::integral_constant<int, 3>{});
+    one(std::integral_constant<int, 4>{});
+    one(std::integral_constant<int, 5>{});
+    one(std::integral_constant<int, 6>{});
+    one(std::integral_constant<int, 7>{});
+  };
+  constexpr int64_t HEAD = (LT + NR - 1) / NR * NR;
+  int64_t base = 0;
+  for (; base < HEAD && base < cnt + LT; base += NR) round(std::false_type{}, base);
+  if (base + NR + PF <= cnt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the steady loop starts from a state the compiler knows exactly
+    for (; base + NR + PF <= cnt; base += NR) round(std::true_type{}, base);
+  }
+  for (; base < cnt + LT; base += NR) round(std::false_type{}, base);
+  // this device's rows of the workgroup's partial of A v
+  T* part = a.partials + (int64_t)team * a.ld + lane * VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (u < a.nrg) *reinterpret_cast<V*>(part + (int64_t)u * (WAVE * VEC)) = racc[u];
+  if (lane == 0 && a.wait_stats != nullptr && late_steps != 0) {
+    atomicAdd(a.wait_stats, (unsigned long long)late_steps);
+    atomicAdd(a.wait_stats + 1, (unsigned long long)late_polls);
+  }
+  if constexpr (DELAY) {
+    if (lane == 0 && a.wait_stats != nullptr && age_cnt != 0) {
+      atomicAdd(a.wait_stats + 2, age_sum);
+      atomicAdd(a.wait_stats + 3, (unsigned long long)age_cnt);
+    }
+  }
+  const double ps[4] = {a.gscale, 1.0, 1.0, 1.0};
+  grid_reduce_finalize<4, 0x2u, 1>(acc, a.red_partials, a.red_counter, a.scal_out, ps);
+}

@@ -260,8 +260,113 @@ function ProximalCore.prox!(y::HIPVector{T}, g::HIPIndBox, x::HIPVector{T}, gamm
     T(0)
 end
 ProximalCore.prox(g::Union{HIPNormL1,HIPIndBox}, x::HIPVector, gamma) = (y = similar(x); (y, ProximalCore.prox!(y, g, x, gamma)))
-# With these methods the reference's own ForwardBackwardIteration / FastForwardBackwardIteration run unchanged
-# on HIPVector once the broadcasts in their bodies are routed to axpby! (Base.Broadcast style for HIPVector).
+
+# ---------------------------------------------------------------- operator-level drop-in: broadcasts ---------
+# With the methods above AND this section the reference's OWN ForwardBackwardIteration / FastForwardBackwardIteration
+# (src/algorithms/forward_backward.jl, fast_forward_backward.jl, src/utilities/fb_tools.jl) run unmodified on HIPVector:
+#
+#     x, it = ProximalAlgorithms.FastForwardBackward(tol = 1e-6)(x0 = HIPVector(x0), f = HIPLeastSquares(A, b), g = HIPNormL1(lam))
+#
+# Every vector statement of those bodies is either a ProximalCore / LinearAlgebra call bound above (prox!, value_and_gradient,
+# dot, norm, copy, similar) or a broadcast.  A broadcast over HIPVectors carries the style HIPStyle; `copyto!(dest, bc)` matches
+# the tree of the EXACT shapes the path uses -- BROADCAST_TABLE below lists every such statement of the reference with the shape
+# it lowers to and the C entry point that runs it -- and anything else is an error (never a scalar getindex loop).
+# UNEXECUTED like the rest of this file; tests/test_julia_glue.py checks the table against the reference's source text, that every
+# shape named there has a `lower!` method here, and that every broadcast statement of the path's files is in the table.
+using Base.Broadcast: Broadcasted, AbstractArrayStyle
+
+struct HIPStyle <: AbstractArrayStyle{1} end
+HIPStyle(::Val{N}) where {N} = HIPStyle()
+Base.BroadcastStyle(::Type{<:HIPVector}) = HIPStyle()
+
+Base.getindex(::HIPVector, ::Int) =
+    error("scalar indexing of a HIPVector is not supported (it would be one device read per element): copy it to the host with Array(v)")
+Base.setindex!(::HIPVector, ::Any, ::Int) =
+    error("scalar indexing of a HIPVector is not supported: build the vector on the host and upload it with HIPVector(x)")
+Base.show(io::IO, ::MIME"text/plain", v::HIPVector{T}) where {T} = print(io, v.n, "-element HIPVector{", T, "} (device memory)")
+Base.show(io::IO, v::HIPVector{T}) where {T} = print(io, "HIPVector{", T, "}(n = ", v.n, ")")
+
+first_vector(v::HIPVector) = v
+first_vector(::Any) = nothing
+first_vector(bc::Broadcasted) = first_vector(bc.args)
+first_vector(args::Tuple) = (v = first_vector(args[1]); v === nothing ? first_vector(Base.tail(args)) : v)
+first_vector(::Tuple{}) = nothing
+function Base.similar(bc::Broadcasted{HIPStyle}, ::Type{T}) where {T}
+    v = first_vector(bc)
+    HIPVector{T}(undef, v.n; ctx = v.ctx)
+end
+
+function add_scalar!(out::HIPVector{T}, x::HIPVector{T}, c) where {T}
+    check(ccall((:pg_add_scalar, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64),
+                out.ctx.handle, pg_dtype(T), out.n, out.ptr, x.ptr, c))
+    out
+end
+# x .= z .+ beta .* (z .- z_prev)
+function extrapolate!(x::HIPVector{T}, z::HIPVector{T}, z_prev::HIPVector{T}, beta) where {T}
+    check(ccall((:pg_extrapolate, libpg), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64),
+                x.ctx.handle, pg_dtype(T), x.n, x.ptr, z.ptr, z_prev.ptr, beta))
+    x
+end
+
+# the shapes, as types of the Broadcasted tree (V: a HIPVector leaf, S: a scalar leaf)
+const BcNode{F,Args} = Broadcasted{HIPStyle,<:Any,F,Args}
+const V = HIPVector
+const S = Number
+const ScaledV = BcNode{typeof(*),<:Tuple{S,V}}                       # a .* x
+const DiffVV = BcNode{typeof(-),<:Tuple{V,V}}                        # x .- y
+
+shape_string(x::HIPVector) = "V"
+shape_string(x::Number) = "S"
+shape_string(x) = string(typeof(x))
+shape_string(bc::Broadcasted) = "(" * join(map(shape_string, bc.args), " ." * string(bc.f) * " ") * ")"
+
+lower!(dest, bc) =
+    error("unsupported broadcast on HIPVector: ", shape_string(bc), " -- the shapes of the proximal-gradient path are listed in BROADCAST_TABLE; ",
+          "compute anything else on the host (Array(v)) or add a kernel for it")
+lower!(dest::V, bc::BcNode{typeof(identity),<:Tuple{V}}) = copyto!(dest, bc.args[1])                          # :copy         x
+lower!(dest::V, bc::BcNode{typeof(*),<:Tuple{S,V}}) = axpby!(dest, bc.args[1], bc.args[2], 0, bc.args[2])     # :scale        a .* x
+lower!(dest::V, bc::BcNode{typeof(*),<:Tuple{V,S}}) = axpby!(dest, bc.args[2], bc.args[1], 0, bc.args[1])     # :scale_right  x .* a
+lower!(dest::V, bc::BcNode{typeof(-),<:Tuple{V,V}}) = axpby!(dest, 1, bc.args[1], -1, bc.args[2])             # :sub          x .- y
+lower!(dest::V, bc::BcNode{typeof(+),<:Tuple{V,S}}) = add_scalar!(dest, bc.args[1], bc.args[2])               # :add_scalar   x .+ c
+lower!(dest::V, bc::BcNode{typeof(-),<:Tuple{V,<:ScaledV}}) =                                                  # :axmy         x .- a .* y
+    axpby!(dest, 1, bc.args[1], -bc.args[2].args[1], bc.args[2].args[2])
+lower!(dest::V, bc::BcNode{typeof(+),<:Tuple{V,<:ScaledV}}) =                                                  # :axpy         x .+ a .* y
+    axpby!(dest, 1, bc.args[1], bc.args[2].args[1], bc.args[2].args[2])
+function lower!(dest::V, bc::BcNode{typeof(+),<:Tuple{V,<:BcNode{typeof(*),<:Tuple{S,<:DiffVV}}}})             # :extrapolate  z .+ b .* (z .- w)
+    z, beta, d = bc.args[1], bc.args[2].args[1], bc.args[2].args[2]
+    d.args[1] === z || error("unsupported broadcast on HIPVector: x .+ b .* (y .- w) with x !== y (the path has z .+ beta .* (z .- z_prev))")
+    extrapolate!(dest, z, d.args[2], beta)
+end
+Base.copyto!(dest::HIPVector, bc::Broadcasted{HIPStyle}) = (length(dest) == length(first_vector(bc)) || throw(DimensionMismatch()); lower!(dest, bc))
+
+# Every broadcast statement of the reference's files on the path: (file, line, statement, shape(s) it lowers to, C entry point).
+# A statement with an un-dotted operator materialises its dotted part first (`x - gamma .* g` is `t = gamma .* g; x - t`).
+const BROADCAST_TABLE = [
+    ("src/algorithms/forward_backward.jl", 71, "y = x - gamma .* grad_f_x", (:scale, :sub), :pg_axpby),
+    ("src/algorithms/forward_backward.jl", 114, "state.grad_f_x .= grad_f_x", (:copy,), :pg_memcpy_d2d),
+    ("src/algorithms/forward_backward.jl", 117, "state.y .= state.x .- state.gamma .* state.grad_f_x", (:axmy,), :pg_axpby),
+    ("src/algorithms/forward_backward.jl", 120, "state.res .= state.x .- state.z", (:sub,), :pg_axpby),
+    ("src/algorithms/fast_forward_backward.jl", 79, "y = x - gamma .* grad_f_x", (:scale, :sub), :pg_axpby),
+    ("src/algorithms/fast_forward_backward.jl", 135, "state.x .= state.z .+ beta .* (state.z .- state.z_prev)", (:extrapolate,), :pg_extrapolate),
+    ("src/algorithms/fast_forward_backward.jl", 139, "state.grad_f_x .= grad_f_x", (:copy,), :pg_memcpy_d2d),
+    ("src/algorithms/fast_forward_backward.jl", 140, "state.y .= state.x .- state.gamma .* state.grad_f_x", (:axmy,), :pg_axpby),
+    ("src/algorithms/fast_forward_backward.jl", 142, "state.res .= state.x .- state.z", (:sub,), :pg_axpby),
+    ("src/utilities/fb_tools.jl", 9, "xeps = x .+ 1", (:add_scalar,), :pg_add_scalar),
+    ("src/utilities/fb_tools.jl", 48, "y .= x .- gamma .* At_grad_f_Ax", (:axmy,), :pg_axpby),
+    ("src/utilities/fb_tools.jl", 50, "res .= x .- z", (:sub,), :pg_axpby),
+    ("src/utilities/fb_tools.jl", 57, "grad_f_Az .= grad_f_Az_tmp", (:copy,), :pg_memcpy_d2d),
+    ("src/utilities/fb_tools.jl", 78, "y = x - gamma .* At_grad_f_Ax", (:scale, :sub), :pg_axpby),
+    ("src/accel/lbfgs.jl", 31, "L.s .= s", (:copy,), :pg_memcpy_d2d),
+    ("src/accel/lbfgs.jl", 32, "L.y .= y", (:copy,), :pg_memcpy_d2d),
+    ("src/accel/lbfgs.jl", 65, "d .= v", (:copy,), :pg_memcpy_d2d),
+    ("src/accel/lbfgs.jl", 67, "d .*= L.H", (:scale_right,), :pg_axpby),
+    ("src/accel/lbfgs.jl", 76, "d .-= L.alphas[idx] .* L.y_M[idx]", (:axmy,), :pg_axpby),
+    ("src/accel/lbfgs.jl", 92, "d .+= (L.alphas[idx] - beta) .* L.s_M[idx]", (:axpy,), :pg_axpby),
+]
+# Un-dotted array arithmetic of the same files goes through Base's `-(::AbstractArray, ::AbstractArray)` and
+# `*(::UniformScaling, ::AbstractVector)`, i.e. through the same broadcasts: `res = x - z` (forward_backward.jl:81,
+# fast_forward_backward.jl:89) is :sub; `A * xeps` and `A' * (grad_f_Axeps - grad_f_Ax)` with `A === I` (fb_tools.jl:10-11) are
+# :scale with a = true and :sub.
 
 # ---------------------------------------------------------------- fused iterators ----------------------------
 # C structs of include/proxgrad_hip.h
@@ -545,7 +650,7 @@ function hip_douglas_rachford(d, q, g, x0::Vector{T}; gamma, maxit = 1_000, tol 
     return Array(y), Int(k[])                              # solution = state.y (douglas_rachford.jl:70)
 end
 
-export HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
+export HIPStyle, BROADCAST_TABLE, HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
        HIPForwardBackwardIteration, HIPFastForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve,
        hip_douglas_rachford, save_state, resume, HIPLBFGSOperator, enable_images!, images_update!, images_mul!, images_ready,
        row_team_inbox, row_team_handle, row_team_open, set_row_team!, row_team_stats, row_team_selftest,

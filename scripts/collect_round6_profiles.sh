@@ -1,0 +1,68 @@
+#!/bin/bash
+# Round 6's measurements on a GPU box (run through gpurun): outputs under gpurun_out/r6/, summaries are copied into profiles/r6_* by hand
+# or by scripts/publish_round6_profiles.sh.  PMC passes are separate runs with --kernel-trace only, the program directly after `--`.
+# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench suite
+cd "$GRAFT_REPO_ROOT" || exit 1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r6; mkdir -p $O
+want() { for p in $PARTS; do [ "$p" = "$1" ] && return 0; done; return 1; }
+PARTS="$*"
+RT="python3 tests/tools/row_team.py --bench --m 4096 --n 1048576 --steps 20 --max-wgs -2"
+if want parity; then
+  timeout 2400 python scripts/peer_geometry_parity.py > $O/geometry_parity.log 2>&1; tail -3 $O/geometry_parity.log
+fi
+if want ranks; then
+  timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=15 -k "row_team or two_ranks_one_gpu or fuzz_row_teams or fuzz_ranks_as_processes or self_launched or four_ranks or rank_failure" > $O/pytest_ranks.log 2>&1; echo "rc $?" >> $O/pytest_ranks.log; tail -25 $O/pytest_ranks.log
+fi
+if want ab; then
+  # round 5's kernel (K1 = 0) against round 6's one-wave sweep on 2 x 2048 rows, and the other block lengths' defaults, injector off / 0 / 4 / 8 / 12 us
+  timeout 900 python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --two-sweeps --repeat 2 --delays off,0,4000,8000,12000 --geoms 2:2:2:2:4:1:0,default > $O/ab_2048.jsonl 2> $O/ab_2048.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 2048 --n 1048576 --ranks 2 --repeat 1 --delays off,0,8000 --geoms 4:2:2:2:4:1:0,default > $O/ab_1024.jsonl 2> $O/ab_1024.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 8192 --n 524288 --repeat 1 --delays off,0,8000 --geoms default > $O/ab_4096.jsonl 2> $O/ab_4096.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 32768 --n 131072 --repeat 1 --delays off,0,8000 --geoms default > $O/ab_16384.jsonl 2> $O/ab_16384.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 2048 --n 1048576 --dtype f64 --repeat 1 --delays off,0,8000 --geoms default > $O/ab_f64_1024.jsonl 2> $O/ab_f64_1024.err
+  cat $O/ab_2048.jsonl | cut -c1-260
+fi
+if want calib; then
+  # the same shapes with NO exchange, kernels of two contexts / two processes side by side (what "two ranks share one device" can reach at all)
+  timeout 600 python scripts/side_by_side.py --m 2048 --n 1048576 --ranks 1 --mode threads > $O/side_by_side.jsonl 2> $O/side_by_side.err
+  timeout 600 python scripts/side_by_side.py --m 2048 --n 1048576 --ranks 2 --mode threads >> $O/side_by_side.jsonl 2>> $O/side_by_side.err
+  timeout 600 python scripts/side_by_side.py --m 2048 --n 1048576 --ranks 2 --mode processes >> $O/side_by_side.jsonl 2>> $O/side_by_side.err
+  cat $O/side_by_side.jsonl
+fi
+if want counters; then
+  # counter rows of the row-team sweep on 2 x 2048 rows (round 5's kernel, round 6's) next to gemv_tnw<8,4,4> on 2048 x 2^20
+  rocprofv3 -L > $O/counters_available.txt 2>&1
+  pick() { out=""; for c in "$@"; do if grep -qw "$c" $O/counters_available.txt; then out="$out $c"; fi; done; echo $out; }
+  P1=$(pick SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU)
+  P2=$(pick SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA)
+  P3=$(pick SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_LEVEL_WAVES GRBM_GUI_ACTIVE)
+  run() { key=$1; shift
+    rocprofv3 --kernel-trace --stats -d $O/c_${key}_stats -- "$@" > $O/c_${key}_stats.log 2>&1
+    [ -n "$P1" ] && rocprofv3 --kernel-trace --pmc $P1 -d $O/c_${key}_p1 -- "$@" > $O/c_${key}_p1.log 2>&1
+    [ -n "$P2" ] && rocprofv3 --kernel-trace --pmc $P2 -d $O/c_${key}_p2 -- "$@" > $O/c_${key}_p2.log 2>&1
+    [ -n "$P3" ] && rocprofv3 --kernel-trace --pmc $P3 -d $O/c_${key}_p3 -- "$@" > $O/c_${key}_p3.log 2>&1
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/c_${key}_fetch -- "$@" > $O/c_${key}_fetch.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c_${key}_write -- "$@" > $O/c_${key}_write.log 2>&1
+    for p in stats p1 p2 p3 fetch write; do python scripts/rocpd_summary.py --sum-per-dispatch --match gemv_tn $O/c_${key}_$p/*/*_results.db > $O/c_${key}_$p.md 2>&1; done; }
+  run k1 $RT
+  PG_TUNE=1 PG_TNP_K1=0 run r5 $RT
+  run tnw python3 bench.py --m 2048 --n 1048576 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also
+  head -30 $O/c_k1_p1.md
+fi
+if want latency; then
+  D=off,0,2000,4000,6000,8000,12000,16000
+  timeout 600 python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --two-sweeps --repeat 2 --delays $D --geoms 2:2:2:2:4:1:0,default > $O/sweep_2048.jsonl 2> $O/sweep_2048.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 8192 --n 524288 --two-sweeps --repeat 2 --delays $D --geoms default > $O/sweep_4096.jsonl 2> $O/sweep_4096.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 32768 --n 131072 --two-sweeps --repeat 2 --delays $D --geoms default > $O/sweep_16384.jsonl 2> $O/sweep_16384.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 16384 --n 262144 --ranks 4 --repeat 1 --delays off,0,4000,8000 --geoms default > $O/sweep_4x4096.jsonl 2> $O/sweep_4x4096.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 16384 --n 131072 --ranks 8 --repeat 1 --delays off,0,4000,8000 --geoms default > $O/sweep_8x2048.jsonl 2> $O/sweep_8x2048.err
+fi
+if want bench; then
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 1500 $O/bench_default.json
+  python bench.py --gpus 2 --share-device --backend gloo --m 4096 --n 1048576 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_rows_2048.json 2> $O/bench_2rank_rows_2048.err
+fi
+if want suite; then
+  timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 > $O/gpu_suite.log 2>&1; echo "rc $?" >> $O/gpu_suite.log; tail -40 $O/gpu_suite.log
+fi
+ls $O | head -80

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Parity of row-team sweep geometries chosen through the tuning variables (round 5: lag tiles in registers, latency injector):
+"""Parity of row-team sweep geometries chosen through the tuning variables (round 5: lag tiles in registers, latency injector; round 6: the one-wave sweep gemv_tnp1_kernel):
 runs tests/tools/row_team.py (iterates of every rank against the CPU restatement on the whole matrix) once per case and prints
-one summary line each.   python scripts/r5_peer_geometry_parity.py [case-filter]"""
+one summary line each.   python scripts/peer_geometry_parity.py [case-filter]"""
 import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W")
+VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W", "PG_TNP_K1")
 CASES = [
     # (row_team.py arguments, geometry C:LAG:LAGR:PF:WGS:W | default).  Defaults (peer_geometry_f32): one wave per column up to 2048
     # rows, two up to 8192, four up to 16384; 16 KiB tiles per wave, LAG = 2 in LDS + LAGR = 2 in registers.
@@ -81,6 +81,19 @@ CASES = [
     (["--m", "16384", "--n", "4096"], "1:2:0:2:2:4"),
     (["--m", "32768", "--n", "4096"], "1:2:0:2:1:4"),
     (["--m", "32768", "--n", "4096"], "1:2:1:2:1:4"),
+    # round 5's one-wave kernel (gemv_tnt_kernel<..., W = 1>), kept at U = 8 beside round 6's gemv_tnp1_kernel (K1 = 0)
+    (["--m", "4096", "--n", "8192"], "2:2:2:2:4:1:0"),
+    (["--m", "4096", "--n", "8192", "--delay-ns", "5000"], "2:2:2:2:4:1:0"),
+    # round 6's one-wave sweep sums a step's granules over the members by DPP row shifts and, beyond one 16-lane row, permlane swaps:
+    # teams whose granules fill two rows (32 lanes) and four (64)
+    (["--m", "32768", "--n", "1024", "--ranks", "16"], "default"),                 # 16 x 2048 rows: U = 8, C = 2 -> 32 granules per step
+    (["--m", "4096", "--n", "2048", "--ranks", "16"], "default"),                  # 16 x 256 rows: U = 1, C = 4 -> 64 granules
+    (["--m", "8192", "--n", "2048", "--ranks", "16", "--adaptive"], "default"),    # 16 x 512 rows: U = 2, C = 4 -> 64
+    (["--m", "2048", "--n", "1024", "--dtype", "f64", "--ranks", "8"], "default"), # 8 x 256 rows of Float64: U = 2, C = 2, two granules per value -> 32
+    (["--m", "2048", "--n", "1024", "--dtype", "f64", "--ranks", "16"], "default"),# 16 x 128 rows: U = 1 -> 64
+    (["--m", "16384", "--n", "1024", "--dtype", "f64", "--ranks", "16", "--g", "l1w"], "default"),  # 16 x 1024 rows: U = 8 -> 64
+    (["--m", "4096", "--n", "8192", "--g", "box"], "default"),
+    (["--m", "4096", "--n", "8192", "--g", "boxv", "--adaptive"], "default"),
 ]
 
 

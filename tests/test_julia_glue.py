@@ -190,3 +190,108 @@ def test_glue_carries_the_reference_iterator_surface():
     # fast_forward_backward.jl:152: the solution is the ALIASED state vector, not a host copy (VERDICT r2 missing 3)
     assert re.search(r"^default_solution\(::HIPIteration, st::HIPIterState\) = st\.z$", text, flags=re.M)
     assert "host_solution" in text and "Array(st.z)" not in text
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Operator-level drop-in: the broadcasts of the reference's own iteration bodies on HIPVector.
+# The glue lists every broadcast statement of the path's files in BROADCAST_TABLE; here the table is checked against the
+# reference's source text (the line exists and reads exactly so), every statement's shape is derived AGAIN from its text by the
+# classifier below and compared with the table's, every shape has a `lower!` method whose body reaches the entry point the
+# table names, that entry point is declared in the header, and no broadcast statement of those files is missing from the table.
+# ---------------------------------------------------------------------------------------------------------------------
+REFERENCE = "/root/reference"
+PATH_FILES = ["src/algorithms/forward_backward.jl", "src/algorithms/fast_forward_backward.jl", "src/utilities/fb_tools.jl",
+              "src/accel/lbfgs.jl", "src/accel/nesterov.jl"]
+# scalar operands of the path's broadcast statements (everything else that is an identifier / field / index is a vector)
+SCALARS = {"gamma", "state.gamma", "beta", "L.H", "L.alphas[idx]", "(L.alphas[idx] - beta)", "1"}
+
+
+def broadcast_table():
+    text = open(JL).read()
+    body = re.search(r"^const BROADCAST_TABLE = \[\n(.*?)^\]", text, flags=re.S | re.M).group(1)
+    rows = []
+    for m in re.finditer(r'\("([^"]+)",\s*(\d+),\s*"([^"]+)",\s*\(([^)]*)\),\s*:(\w+)\)', body):
+        shapes = tuple(x.strip().lstrip(":") for x in m.group(4).split(",") if x.strip())
+        rows.append((m.group(1), int(m.group(2)), m.group(3), shapes, m.group(5)))
+    return rows
+
+
+def _operand_kind(tok):
+    return "S" if tok in SCALARS else "V"
+
+
+def classify(statement):
+    """shape(s) of one broadcast statement of the path, from its text alone"""
+    lhs, op, rhs = re.match(r"^(.*?)\s*(\.[-+*]?=|=)\s*(.*)$", statement).groups()
+    if op in (".*=", ".-=", ".+="):  # d .op= e  is  d .= d .op e
+        rhs = f"{lhs} .{op[1]} {rhs}"
+    # z .+ b .* (z .- w)
+    m = re.match(r"^(\S+) \.\+ (\S+) \.\* \((\S+) \.- (\S+)\)$", rhs)
+    if m and m.group(1) == m.group(3) and _operand_kind(m.group(2)) == "S":
+        return ("extrapolate",)
+    # operands: parenthesised scalar expressions count as one token
+    toks = re.findall(r"\([^()]*\)|[^\s]+", rhs)
+    kinds = [t if t in (".-", ".+", ".*", "-", "+", "*") else _operand_kind(t) for t in toks]
+    pat = " ".join(kinds)
+    table = {"V": ("copy",), "V .- V": ("sub",), "V .+ S": ("add_scalar",), "V .- S .* V": ("axmy",), "V .+ S .* V": ("axpy",),
+             "V .* S": ("scale_right",), "S .* V": ("scale",),
+             "V - S .* V": ("scale", "sub")}  # un-dotted minus: the dotted product is materialised first
+    assert pat in table, (statement, pat)
+    return table[pat]
+
+
+def test_broadcast_table_matches_the_reference_source():
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference tree is not on this machine")
+    rows = broadcast_table()
+    assert len(rows) >= 20
+    listed = set()
+    for f, line, stmt, shapes, sym in rows:
+        src = open(os.path.join(REFERENCE, f)).read().split("\n")
+        assert src[line - 1].strip().rstrip(",") == stmt, (f, line, src[line - 1].strip(), stmt)
+        assert classify(stmt) == shapes, (f, line, stmt, classify(stmt), shapes)
+        listed.add((f, line))
+    # completeness: every dotted statement of the path's files is in the table
+    dotted = re.compile(r"\.[-+*/]?=|\s\.[-+*/]\s")
+    for f in PATH_FILES:
+        for k, ln in enumerate(open(os.path.join(REFERENCE, f)).read().split("\n"), 1):
+            code = ln.split("#")[0]
+            if dotted.search(code):
+                assert (f, k) in listed, f"{f}:{k}: `{ln.strip()}` is a broadcast statement of the path and not in BROADCAST_TABLE"
+
+
+def test_every_shape_of_the_table_has_a_lowering_that_reaches_its_entry_point():
+    text = open(JL).read()
+    protos = c_prototypes()
+    # `lower!(dest::V, bc::...) = <body>   # :shape  pattern`   (one-line and function-block forms)
+    lowerings = {}
+    for m in re.finditer(r"^(?:function )?lower!\(dest::V, bc::[^\n]*?#\s*:(\w+)[^\n]*\n((?:    [^\n]*\n)*)", text, flags=re.M):
+        lowerings[m.group(1)] = m.group(0)
+    helper_symbol = {"axpby!": "pg_axpby", "add_scalar!": "pg_add_scalar", "extrapolate!": "pg_extrapolate", "copyto!": "pg_memcpy_d2d"}
+    for name, sym in helper_symbol.items():  # each helper really is a ccall of that symbol
+        if name == "copyto!":
+            blk = re.search(r"function Base\.copyto!\(dst::HIPVector\{T\}, src::HIPVector\{T\}\).*?^end", text, flags=re.S | re.M).group(0)
+        else:
+            blk = re.search(r"function %s\(.*?^end" % re.escape(name), text, flags=re.S | re.M).group(0)
+        assert f"(:{sym}, libpg)" in blk, (name, sym)
+        assert sym in protos, sym
+    for f, line, stmt, shapes, sym in broadcast_table():
+        assert sym in protos, (sym, "not declared in include/proxgrad_hip.h")
+        for sh in shapes:
+            assert sh in lowerings, f"{f}:{line}: shape :{sh} has no lower! method in the glue"
+        # the LAST shape of the statement is the one that produces its result: its lowering calls the helper bound to `sym`
+        body = lowerings[shapes[-1]]
+        helpers = [h for h, s_ in helper_symbol.items() if s_ == sym]
+        assert any(h + "(" in body for h in helpers), (f, line, shapes[-1], sym, body)
+    # the style and the refusal of everything else
+    assert re.search(r"^struct HIPStyle <: AbstractArrayStyle\{1\} end$", text, flags=re.M)
+    assert "Base.BroadcastStyle(::Type{<:HIPVector}) = HIPStyle()" in text
+    assert "Base.similar(bc::Broadcasted{HIPStyle}, ::Type{T})" in text
+    assert re.search(r"^Base\.copyto!\(dest::HIPVector, bc::Broadcasted\{HIPStyle\}\)", text, flags=re.M)
+    assert 'error("unsupported broadcast on HIPVector: "' in text
+    assert re.search(r"^Base\.getindex\(::HIPVector, ::Int\) =\n\s+error\(", text, flags=re.M)  # never a scalar loop
+
+
+def test_classifier_refuses_a_shape_outside_the_table():
+    with pytest.raises(AssertionError):
+        classify("y .= x .* z")  # an elementwise product of two vectors: not on the path, no lowering

@@ -8,7 +8,8 @@ pg_ctx_test_team_fault(ctx, ns, 2) -- the sweep's DELAY form accepts a step's gr
 the on-chip hand-off stands in for a fabric hop of that length (pg_gemv_tnt.h).  One JSON line per pair.
 
     python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --geoms default,2:2:3:2:2:3 --delays off,0,2000,4000,8000
-geometry = C:LAG:LAGR:PF:WGS:W (columns per step, lag steps in LDS, lag steps in registers, tiles in flight, workgroups per CU, waves per workgroup)."""
+geometry = C:LAG:LAGR:PF:WGS:W[:K1] (columns per step, lag steps in LDS, lag steps in registers, tiles in flight, workgroups per CU, waves per
+workgroup; K1 = 0: round 5's kernel where round 6's one-wave sweep is the default)."""
 import argparse
 import ctypes as C
 import json
@@ -27,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-GEOM_VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W")
+GEOM_VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W", "PG_TNP_K1")
 
 
 def set_geometry(spec):
