@@ -1138,58 +1138,80 @@ def extrapolate_ledger(d, m_full, n_full, steps_full=50, warmup_full=5, gen_rate
     return out, total
 
 
-SHORT_LABELS = {"headline_adaptive": "adaptive", "config2": "cfg2", "config3": "cfg3", "config4": "cfg4", "config4_zerofpr": "zfpr", "config4_panocplus": "pplus",
-                "config5_column_block": "cfg5blk", "headline_row_block_n8": "row8", "rows_2proc_two_sweeps": "rows2p",
-                "rows_2proc_row_team": "rows2pteam", "rows_two_sweeps": "rows2s", "cols_strong": "cols", "rows_strong": "rows",
-                "config5_weak_rows": "cfg5rows", "config5_weak_cols": "cfg5cols", "rows_strong_teams": "teams",
-                "config5_weak_rows_teams": "cfg5teams"}
+SHORT_LABELS = {"headline_adaptive": "ad", "config2": "c2", "config3": "c3", "config4": "c4", "config4_zerofpr": "zf", "config4_panocplus": "pp",
+                "config5_column_block": "c5", "headline_row_block_n8": "r8", "rows_2proc_two_sweeps": "r2",
+                "rows_2proc_row_team": "rt", "rows_two_sweeps": "2s", "cols_strong": "co", "rows_strong": "ro",
+                "config5_weak_rows": "5r", "config5_weak_cols": "5c", "rows_strong_teams": "tm",
+                "config5_weak_rows_teams": "5t"}
+SUMMARY_BUDGET = 120  # characters: the driver's BENCH_rNN.json cuts a scalar string of `config` at about 128
 
 
 def summary_string(records):
-    """Every further record of the line in ONE scalar string, `label=it/s@frac/reads-of-A` joined by `;` (config 3:
-    `cfg3=<in-library it/s>(step <stepped it/s>@frac)`; a failed record: `label=!<reason>`): the driver's BENCH_rNN.json keeps
-    about twenty scalar keys of `config` and nothing nested, so this is the form in which configs 2 / 3 / 4, the block shapes and
-    the other layouts reach it.  parse_summary_string is its inverse."""
+    """Every further record of the line in ONE scalar string that FITS the driver's record (it keeps about twenty scalar keys of
+    `config`, nothing nested, and cuts a string at about 128 characters): `label=it/s@frac[/reads-of-A]` joined by `;`, two-letter
+    labels (SHORT_LABELS), three significant digits (`k` = thousands), the fraction of the roofline in PER CENT, the reads of A per
+    iteration only where they are not 1 (config 3: `c3=<in-library it/s>|<stepped it/s>@percent`; a failed record: `label=!reason`).
+    The full-precision figures stay in the line itself (`also`, `also_summary`); parse_summary_string is the inverse, to the
+    digits kept."""
     parts = []
     for label, r in records:
         key = SHORT_LABELS.get(label, label)
         if not isinstance(r, dict) or "value" not in r:
             why = str((r or {}).get("error", "not measured")) if isinstance(r, dict) else "not measured"
-            parts.append("%s=!%s" % (key, "".join(ch if ch not in ";=@/()" else " " for ch in why)[:40].strip()))
+            parts.append("%s=!%s" % (key, "".join(ch if ch not in ";=@/()|" else " " for ch in why)[:24].strip()))
             continue
         roof, cfg = r.get("roofline") or {}, r.get("config") or {}
-        frac = roof.get("frac")
         passes = cfg.get("a_passes_per_step", cfg.get("A_passes_per_step"))
         if isinstance(r.get("stepping"), dict):
             st = r["stepping"]
-            txt = "%.6g(step %.6g@%s)" % (r["value"], st.get("value") or 0.0, _g3((st.get("roofline") or {}).get("frac")))
+            txt = "%s|%s@%s" % (_v3(r["value"]), _v3(st.get("value") or 0.0, 2), _f2((st.get("roofline") or {}).get("frac")))
         else:
-            txt = "%.6g@%s" % (r["value"], _g3(frac))
-            if passes is not None:
-                txt += "/%s" % _g3(passes)
+            txt = "%s@%s" % (_v3(r["value"]), _f2(roof.get("frac")))
+            if passes is not None and abs(float(passes) - 1.0) >= 0.05:
+                txt += "/%.2g" % float(passes)
         parts.append("%s=%s" % (key, txt))
     return ";".join(parts)
 
 
-def _g3(v):
-    return "?" if v is None else ("%.3g" % float(v))
+def _v3(v, digits=3):
+    v = float(v)
+    return ("%.*gk" % (digits, v / 1e3)) if v >= 999.5 else ("%.*g" % (digits, v))
+
+
+def _f2(v):
+    return "?" if v is None else "%d" % round(100.0 * float(v))
+
+
+def _unf2(t):
+    """per cent of the short form ("73") or the fraction of rounds 4-5's long form ("0.733")"""
+    if t in ("", "?"):
+        return None
+    return float(t) if "." in t else float(t) / 100.0
+
+
+def _unv3(t):
+    return float(t[:-1]) * 1e3 if t.endswith("k") else float(t)
 
 
 def parse_summary_string(text):
-    """{label: {"it_s", "frac", "a_passes"} | {"it_s", "stepping_it_s", "stepping_frac"} | {"error"}} of a summary_string"""
+    """{label: {"it_s", "frac", "a_passes"} | {"it_s", "stepping_it_s", "stepping_frac"} | {"error"}} of a summary_string (reads of A
+    that the string leaves out are 1); also reads the long form of rounds 4-5 (`cfg3=3e5(step 2e4@0.73)`)."""
     out = {}
     for part in filter(None, text.split(";")):
         key, _, val = part.partition("=")
         if val.startswith("!"):
             out[key] = {"error": val[1:]}
-        elif "(step " in val:
-            head, _, rest = val.partition("(step ")
+        elif "(step " in val or "|" in val:
+            if "|" in val:
+                head, _, rest = val.partition("|")
+            else:
+                head, _, rest = val.partition("(step ")
             st, _, fr = rest.rstrip(")").partition("@")
-            out[key] = {"it_s": float(head), "stepping_it_s": float(st), "stepping_frac": None if fr == "?" else float(fr)}
+            out[key] = {"it_s": _unv3(head), "stepping_it_s": _unv3(st), "stepping_frac": _unf2(fr)}
         else:
             its, _, rest = val.partition("@")
             fr, _, ps = rest.partition("/")
-            out[key] = {"it_s": float(its), "frac": None if fr in ("", "?") else float(fr), "a_passes": None if ps in ("", "?") else float(ps)}
+            out[key] = {"it_s": _unv3(its), "frac": _unf2(fr), "a_passes": 1.0 if ps == "" else (None if ps == "?" else float(ps))}
     return out
 
 

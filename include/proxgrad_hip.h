@@ -40,11 +40,11 @@
 extern "C" {
 #endif
 
-/* Bumped whenever an exported signature, a struct layout the host sees, or the set of exports changes (round 5: 2, then 3 with pg_mat_fused_tn_trio --
+/* Bumped whenever an exported signature, a struct layout the host sees, or the set of exports changes (round 5: 2, then 3 with pg_mat_fused_tn_trio; round 6: 4 with pg_ctx_row_team_tune / _geometry --
  * rounds 3 and 4 added exports and fields under version 1).  Hosts compare pg_abi_version() with the value THEY were written against at
  * load time (Python: _lib.load; Julia: __init__) and refuse a stale or mismatched build with one clear message instead of a
  * missing symbol at some later call -- PG_LIB_PATH / PROXGRAD_HIP_LIB make pointing at another build easy. */
-#define PG_ABI_VERSION 3
+#define PG_ABI_VERSION 4
 
 typedef int32_t pg_status;
 enum {
@@ -173,6 +173,23 @@ pg_status pg_ctx_row_team_stats(pg_ctx* ctx, int64_t* sweeps, int64_t* late_wave
  * pg_ctx_set_row_team and a barrier): device p contributes p + 1, *sum_out must come back as N (N + 1) / 2 on every device.
  * PG_ERR_TIMEOUT when a peer's granules never became visible here (bounded wait): the sweeps would fall back every time. */
 pg_status pg_ctx_row_team_selftest(pg_ctx* ctx, double* sum_out);
+/* The row-team sweep's geometry, per context and at run time (no rebuild, no PG_TUNE): the knobs a first run on real fabric turns.
+ * Every device of the team sets the same values, before the sweep they should apply to; 0 = the library's choice.
+ *   "PAIR"  1: ONE post per TWO steps -- a step's granules wait for the next step's and leave together, 16 * C bytes per inbox
+ *              instead of two writes of 8 * C: half the fabric transactions, one step less of hand-off slack (2: back to one
+ *              post per step); blocks up to 2048 (Float32) / 1024 (Float64) rows, where one wave holds the column
+ *   "C"     columns per step (1 / 2 / 4: more columns = fewer, larger writes; only what is instantiated for the block length)
+ *   "LAG"   tiles that wait in LDS for their totals;  "LAGR"  value - 1 tiles that wait in registers (1: none)
+ *           -- the slack a granule has to arrive is (LAG + LAGR) steps of 16 KiB per wave
+ *   "PF"    tiles in flight (1 / 2);  "WGS" workgroups per compute unit;  "W" waves per column (1 / 2 / 4)
+ *   "K1"    1: the one-wave sweep of round 6 (default where it applies), 2: round 5's kernel
+ *   "SPIN"  the bounded wait, in polls of ~64 clocks (default 2^21, about 0.2 s): after it a wave gives up, the step is redone
+ *           with two sweeps and the all-reduce, on every device
+ * A combination without an instantiation is refused at the next sweep (PG_ERR_UNSUPPORTED: the iterator stays on two sweeps).
+ * pg_ctx_row_team_geometry writes what the LAST row-team sweep of this context ran with, e.g.
+ * "W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0 SPIN=2097152 WG=1024" ("none" before the first one). */
+pg_status pg_ctx_row_team_tune(pg_ctx* ctx, const char* key, int64_t value);
+pg_status pg_ctx_row_team_geometry(pg_ctx* ctx, char* buf, int64_t buflen);
 pg_status pg_ctx_sync(pg_ctx* ctx);
 pg_status pg_ctx_device_info(pg_ctx* ctx, pg_device_info* out);
 /* Kernel timing with HIP events on the context's stream (bench.py's roofline leg).  While enabled, every

@@ -25,7 +25,7 @@ from .operators import (Composed, Conjugate, IndAffine, IndBox, IndNonnegative, 
 from .panoc import PANOC, NoAcceleration, PANOCIteration, PANOCState
 from .panocplus import PANOCplus, PANOCplusIteration
 from .sharding import (NativeRcclComm, TorchDistributedComm, allreduce_sum_, attach_row_team, native_rccl_available,
-                       row_team_in_process, row_team_stats, shard_cols, shard_rows)
+                       row_team_geometry, row_team_in_process, row_team_stats, row_team_tune, shard_cols, shard_rows)
 
 from .zerofpr import ZeroFPR, ZeroFPRIteration
 from .sfista import SFISTA, SFISTAIteration
@@ -55,5 +55,5 @@ __all__ = [
     "ProximalGradientIteration", "LBFGS", "LBFGSOperator", "AdaptiveNesterovSequence", "ConstantNesterovSequence",
     "FixedNesterovSequence", "SimpleNesterovSequence", "next_", "IndBox", "LeastSquares", "NormL1", "Zero",
     "gradient_", "prox", "prox_", "value_and_gradient", "NativeRcclComm", "native_rccl_available", "TorchDistributedComm", "allreduce_sum_",
-    "shard_rows", "shard_cols", "attach_row_team", "row_team_in_process", "row_team_stats",
+    "shard_rows", "shard_cols", "attach_row_team", "row_team_in_process", "row_team_stats", "row_team_tune", "row_team_geometry",
 ]

@@ -81,6 +81,8 @@ SIGNATURES = {
     "pg_ctx_set_column_sharding": [_vp, _i32, _i32],
     "pg_ctx_test_team_fault": [_vp, _i32, _i32],
     "pg_ctx_test_team_slack": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
+    "pg_ctx_row_team_tune": [_vp, C.c_char_p, _i64],
+    "pg_ctx_row_team_geometry": [_vp, C.c_char_p, _i64],
     "pg_ctx_row_team_alloc": [_vp, C.POINTER(_vp), C.POINTER(_i64)],
     "pg_ctx_row_team_export": [_vp, _vp],
     "pg_ctx_row_team_import": [_vp, _vp, C.POINTER(_vp)],
@@ -167,7 +169,7 @@ SIGNATURES = {
 _SPECIAL = {"pg_abi_version": ([], C.c_int32), "pg_last_error": ([], C.c_char_p), "pg_comm_available": ([], C.c_int32)}
 
 _lib = None
-PG_ABI_VERSION = 3  # include/proxgrad_hip.h (tests/test_cpu_host.py compares the two)
+PG_ABI_VERSION = 4  # include/proxgrad_hip.h (tests/test_cpu_host.py compares the two)
 
 
 def load():

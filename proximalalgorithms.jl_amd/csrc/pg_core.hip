@@ -1,4 +1,5 @@
 // Context, memory helpers and the dense column-major matrix object (upload / generate / download).
+#include <string>
 #include <cstdarg>
 
 #include <cstdlib>
@@ -284,6 +285,39 @@ pg_status pg_ctx_row_team_stats(pg_ctx* c, int64_t* sweeps, int64_t* late_waves,
   if (sweeps) *sweeps = c->rteam.sweeps;
   if (late_waves) *late_waves = (int64_t)h[0];
   if (wait_polls) *wait_polls = (int64_t)h[1];
+  return PG_OK;
+}
+
+// The row-team sweep's geometry per context (no PG_TUNE): what a first run on real fabric turns without a rebuild.
+pg_status pg_ctx_row_team_tune(pg_ctx* c, const char* key, int64_t value) {
+  PG_REQUIRE(c != nullptr && key != nullptr, "null argument");
+  pg_row_team::Tune& t = c->rteam.tune;
+  const std::string k(key);
+  PG_REQUIRE(value >= 0, "a knob's value is >= 0 (0: the default)");
+  if (k == "C") { PG_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "C: columns per step, 1 / 2 / 4"); t.C = (int)value; }
+  else if (k == "LAG") { PG_REQUIRE(value <= 7, "LAG: tiles parked in LDS, <= 7"); t.LAG = (int)value; }
+  else if (k == "LAGR") { PG_REQUIRE(value <= 4, "LAGR: value = tiles parked in registers + 1 (1: none), <= 4"); t.LAGR = (int)value; }
+  else if (k == "PF") { PG_REQUIRE(value <= 2, "PF: tiles in flight, 1 / 2"); t.PF = (int)value; }
+  else if (k == "WGS") { PG_REQUIRE(value <= 4, "WGS: workgroups per compute unit, <= 4"); t.WGS = (int)value; }
+  else if (k == "W") { PG_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "W: waves per column, 1 / 2 / 4"); t.W = (int)value; }
+  else if (k == "K1") { PG_REQUIRE(value <= 2, "K1: 0 default, 1 the one-wave sweep, 2 round 5's kernel"); t.K1 = value == 0 ? -1 : (value == 1 ? 1 : 0); }
+  else if (k == "PAIR") { PG_REQUIRE(value <= 2, "PAIR: 0 default, 1 one post per two steps, 2 one post per step"); t.PAIR = value == 0 ? -1 : (value == 1 ? 1 : 0); }
+  else if (k == "SPIN") { t.SPIN = (long long)value; }
+  else {
+    pg_set_error("pg_ctx_row_team_tune: unknown key '%s' (C, LAG, LAGR, PF, WGS, W, K1, PAIR, SPIN)", key);
+    return PG_ERR_INVALID;
+  }
+  return PG_OK;
+}
+
+// "W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0 SPIN=2097152 WG=1024": what the LAST row-team sweep of this context ran with
+pg_status pg_ctx_row_team_geometry(pg_ctx* c, char* buf, int64_t buflen) {
+  PG_REQUIRE(c != nullptr && buf != nullptr && buflen > 0, "null argument");
+  const pg_row_team::Geom& g = c->rteam.last;
+  if (g.W == 0) snprintf(buf, (size_t)buflen, "none");
+  else
+    snprintf(buf, (size_t)buflen, "W=%d U=%d C=%d LAG=%d LAGR=%d PF=%d WGS=%d K1=%d PAIR=%d SPIN=%lld WG=%d", g.W, g.U, g.C, g.LAG, g.LAGR, g.PF, g.WGS, g.K1,
+             g.PAIR, g.SPIN, g.nteams);
   return PG_OK;
 }
 

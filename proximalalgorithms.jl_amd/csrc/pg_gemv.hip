@@ -1075,8 +1075,11 @@ pg_status pg_mat_row_team_agree(pg_ctx* c, pg_mat* A) {
 bool pg_ls_fused_pass_supported(const pg_ls* f) {
   pg_ctx* c = f->ctx;
   if (pg_row_sharded(c)) {  // as a row team only (pg_gemv_tn4.hip), and only when EVERY device's block is covered
+    // PURE: reads what pg_mat_row_team_agree left on the matrix.  The agreement is a collective with a status of its own --
+    // pg_iter_create and the bare sweep make it an explicit step and propagate its error (round 5 ran it from inside this
+    // predicate and mapped a failure to "unsupported": one rank on two sweeps, its peers polling inboxes nobody fills)
     if (!(c->rteam.n > 1 && f->A->m > 0 && f->A->n > 0)) return false;
-    if (pg_mat_row_team_agree(c, f->A) != PG_OK) return false;
+    if (!(f->A->team_nrg != 0 && f->A->team_nrg_gen == c->rteam.gen)) return false;
     return tn_peer_covers(f->A->team_nrg);
   }
   return f->A->dtype == PG_F32 ? tn_supported<float>(f->A) : tn_supported<double>(f->A);

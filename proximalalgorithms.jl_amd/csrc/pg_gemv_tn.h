@@ -97,6 +97,7 @@ struct TNArgs {
   int peer_n = 0, peer_rank = 0;
   unsigned long long* peer_ring[16] = {};
   unsigned long long* wait_stats = nullptr;  // PEER: { waves that found their granules late, polls they spent waiting, DELAY: ticks of slack left, steps counted } (telemetry)
+  long long spin_limit = 1 << 21;  // polls before a waiting wave gives up (~ seconds): bounded, never a hang (row teams: pg_ctx_row_team_tune "SPIN")
   unsigned delay_ticks = 0;  // PEER, DELAY instantiations (tests): a step's granules are accepted once every member's stamp is this old (100 MHz ticks)
 #ifdef PG_TNT_EXPERIMENT
   int dbg = 0;  // timing experiments of the team kernel (wrong results): see pg_gemv_tn2.hip

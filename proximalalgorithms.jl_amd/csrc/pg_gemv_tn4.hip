@@ -37,6 +37,7 @@ struct PeerScalArgs {
   unsigned long long* inbox[TEAM_MAX];  // every device's scalar inbox as seen from here
   const double* f_local;                // this device's 1/2 lam ||r_p||^2
   double* f_out;                        // sum over the devices, in device order
+  long long spin_limit;                 // polls before the wave gives up
   unsigned aux;                         // a small integer every device contributes (the spare granule) ...
   double* aux_max_out;                  // ... and where the largest of them goes (nullptr: nobody asked; 0 when a peer never answered)
   double* team_err;                     // in: this device's flag; out: any device's
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64) void peer_scalars_kernel(PeerScalArgs p) {
   while (__builtin_amdgcn_ballot_w64((unsigned)(w >> 32) == p.tag) != ~0ull) {
     __builtin_amdgcn_s_sleep(2);
     w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (++spins > TEAM_SPIN_LIMIT) {
+    if (++spins > p.spin_limit) {
       dead = true;
       break;
     }
@@ -109,18 +110,20 @@ pg_status grow_partials_without_free(pg_mat* A, int S) {
 }
 
 // K1: gemv_tnp1_kernel (pg_gemv_tnp1.h, one wave per column: WAVES = 1) instead of gemv_tnt_kernel<..., PEER>; same protocol
-template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int WAVES = 4, bool K1 = false>
+template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int WAVES = 4, bool K1 = false, bool PAIR = false>
 pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   constexpr int G = (int)sizeof(T) / 4;
-  static_assert(C * G <= 8, "the inbox holds eight granules per member and step");
+  constexpr int MS = (PAIR ? 2 : 1) * C * G;  // granules of one member in a ring slot
+  static_assert(MS <= 8, "the inbox holds eight granules per member and ring slot");
+  static_assert(!PAIR || K1, "one post per two steps: the one-wave sweep only");
   pg_ctx* c = A->ctx;
   const pg_row_team& rt = c->rteam;
   const int64_t ncg = (A->n + C - 1) / C;
-  if (rt.n * C * G > 64) {
-    pg_set_error("a row team of %d devices with %d columns per step needs more than one lane per granule", rt.n, C);
+  if (rt.n * MS > 64) {
+    pg_set_error("a row team of %d devices with %d granules per device and ring slot needs more than one lane per granule", rt.n, MS);
     return PG_ERR_UNSUPPORTED;
   }
-  if (DELAY && (rt.n * (C * G + 1) > 64 || rt.n * (C * G + 1) > TEAM_MAX * C * G)) {
+  if (DELAY && (rt.n * (MS + 1) > 64 || rt.n * (MS + 1) > TEAM_MAX * MS)) {
     pg_set_error("the latency injector's stamps do not fit beside the granules of %d devices", rt.n);
     return PG_ERR_UNSUPPORTED;
   }
@@ -159,6 +162,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   a.team_err = c->dscal + PG_S_TEAMERR;
   a.wait_stats = c->rteam.wait_stats;
   a.delay_ticks = c->test_team_delay_ticks;
+  if (c->rteam.tune.SPIN > 0) a.spin_limit = c->rteam.tune.SPIN;
   c->rteam.sweeps++;
   // The tags make a slot self-describing only among launches of ONE ring layout (every launch rewrites every slot it polls, so
   // a granule of the same epoch 254 launches ago is long gone).  When the layout changes -- another matrix shape, another
@@ -168,7 +172,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   // and nothing of the previous launch is still in flight, because ITS scalar exchange has completed everywhere.  All devices
   // see the change at the same launch (same sequence of calls), so the extra exchange pairs up.
   const unsigned long long sig = ((unsigned long long)nteams << 32) | ((unsigned long long)C << 24) | ((unsigned long long)G << 16) |
-                                 ((unsigned long long)(LAG + LAGR) << 8) | ((unsigned long long)(DELAY ? 1 : 0) << 15) | (unsigned long long)rt.n;
+                                 ((unsigned long long)(LAG + LAGR) << 8) | ((unsigned long long)(DELAY ? 1 : 0) << 15) | ((unsigned long long)(PAIR ? 1 : 0) << 23) |
+                                 (unsigned long long)rt.n;
   if (sig != c->rteam.ring_sig) {
     PG_HIP(hipMemsetAsync(rt.inbox[rt.rank], 0, PEER_RING_BYTES, c->stream));
     PG_TRY(peer_scalar_exchange(c, c->rteam.f_local, c->rteam.f_local));
@@ -181,7 +186,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
   static_assert(!K1 || WAVES == 1, "gemv_tnp1_kernel is the one-wave sweep");
   const void* kern;
-  if constexpr (K1) kern = reinterpret_cast<const void*>(&gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY>);
+  if constexpr (K1) kern = reinterpret_cast<const void*>(&gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR>);
   else kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>);
   if (lds + 4096 > 64 * 1024) {
     static std::mutex mu;
@@ -203,7 +208,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead
-  if constexpr (K1) hipLaunchKernelGGL((gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY>), dim3(grid), dim3(64), lds, c->stream, a);
+  c->rteam.last = {WAVES, U, C, LAG, LAGR, PF, wgs_per_cu, K1 ? 1 : 0, PAIR ? 1 : 0, (int)nteams, a.spin_limit};
+  if constexpr (K1) hipLaunchKernelGGL((gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR>), dim3(grid), dim3(64), lds, c->stream, a);
   else hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
@@ -271,23 +277,34 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   // under PG_TUNE: the powers of two only, for A/B runs), columns per step C, lag steps in LDS (LAG) and in registers (LAGR),
   // tiles in flight (PF), workgroups per compute unit (0: as many as the parked tiles leave LDS for).
   const PeerGeom g = peer_geometry(team_nrg, sizeof(T) == 8);
-  const int W = env_int("PG_TNP_W", g.W);
+  // every knob: the context's own setting (pg_ctx_row_team_tune -- no PG_TUNE needed, what a first run on real fabric turns), else
+  // the tuning variable (PG_TUNE processes only), else the table
+  const pg_row_team::Tune& tn = c->rteam.tune;
+  auto knob = [](int set, const char* var, int table) { return set > 0 ? set : env_int(var, table); };
+  const int W = knob(tn.W, "PG_TNP_W", g.W);
   const int per_wave = (team_nrg + W - 1) / W;
   int U = per_wave < 2 && W == 4 ? 2 : per_wave;
   if (env_int("PG_TNP_EXACT", 1) == 0) {
     U = 2;
     while (U < per_wave) U *= 2;
   }
-  const int C = env_int("PG_TNP_C", g.C), LAG = env_int("PG_TNP_LAG", g.LAG), LAGR = env_int("PG_TNP_LAGR", g.LAGR);
-  const int PF = env_int("PG_TNP_PF", g.PF), WGS = env_int("PG_TNP_WGS", g.WGS);
+  const int C = knob(tn.C, "PG_TNP_C", g.C), LAG = knob(tn.LAG, "PG_TNP_LAG", g.LAG);
+  const int LAGR = tn.LAGR > 0 ? tn.LAGR - 1 : env_int("PG_TNP_LAGR", g.LAGR);  // (0 is a value here: the knob carries LAGR + 1)
+  const int PF = knob(tn.PF, "PG_TNP_PF", g.PF), WGS = knob(tn.WGS, "PG_TNP_WGS", g.WGS);
   const bool delay = c->test_team_delay_on;
-  // one wave per column (W = 1): gemv_tnp1_kernel; PG_TNP_K1=0 under PG_TUNE: round 5's gemv_tnt_kernel<..., W = 1> (kept at U = 8 for the A/B)
-  const bool k1 = W == 1 && env_int("PG_TNP_K1", 1) != 0;
-#define PG_TNP1_CASE(UU, CC, LL, PP, RR) \
-  if (k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, 1, true>(A, a, blocks_out, WGS)
-#define PG_TNP1_CASE_D(UU, CC, LL, PP, RR) \
-  PG_TNP1_CASE(UU, CC, LL, PP, RR);        \
-  if (k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, 1, true>(A, a, blocks_out, WGS)
+  // one wave per column (W = 1): gemv_tnp1_kernel; K1 = 0: round 5's gemv_tnt_kernel<..., W = 1> (kept at U = 8 for the A/B)
+  const bool k1 = W == 1 && (tn.K1 >= 0 ? tn.K1 != 0 : env_int("PG_TNP_K1", 1) != 0);
+  // one post per two steps, where the pair's granules of all devices still fit the 64 polling lanes (else: one post per step)
+  const bool pair_req = tn.PAIR >= 0 ? tn.PAIR != 0 : env_int("PG_TNP_PAIR", 0) != 0;
+  const int ms2 = 2 * C * (int)(sizeof(T) / 4);  // granules of one device in a pair's ring slot
+  const bool pair = pair_req && k1 && ms2 <= 8 && c->rteam.n * (ms2 + (delay ? 1 : 0)) <= 64;
+#define PG_TNP1_CASE(UU, CC, LL, PP, RR)                                                                                                          \
+  if (k1 && !pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, 1, true>(A, a, blocks_out, WGS); \
+  if (k1 && pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, 1, true, true>(A, a, blocks_out, WGS)
+#define PG_TNP1_CASE_D(UU, CC, LL, PP, RR)                                                                                                        \
+  PG_TNP1_CASE(UU, CC, LL, PP, RR);                                                                                                               \
+  if (k1 && !pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, 1, true>(A, a, blocks_out, WGS); \
+  if (k1 && pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, 1, true, true>(A, a, blocks_out, WGS)
   if constexpr (sizeof(T) == 8) {
     PG_TNP1_GEOMETRIES_F64;
   } else {
@@ -303,7 +320,8 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TNP_GEOMETRIES;
 #undef PG_TNP_CASE
 #undef PG_TNP_CASE_D
-  pg_set_error("no row-team instantiation for W=%d U=%d C=%d LAG=%d PF=%d LAGR=%d%s", W, U, C, LAG, PF, LAGR, delay ? " with the latency injector" : "");
+  pg_set_error("no row-team instantiation for W=%d U=%d C=%d LAG=%d PF=%d LAGR=%d K1=%d PAIR=%d%s", W, U, C, LAG, PF, LAGR, k1 ? 1 : 0, pair ? 1 : 0,
+               delay ? " with the latency injector" : "");
   return PG_ERR_UNSUPPORTED;
 }
 #ifdef PG_TN4_FLOAT64_UNIT  // (the instantiations are compiled in two translation units, side by side: pg_gemv_tn4d.hip is this file again)
@@ -321,6 +339,7 @@ static pg_status peer_exchange(pg_ctx* c, const double* f_local, double* f_out, 
   PeerScalArgs p;
   p.aux = aux;
   p.aux_max_out = aux_max_out;
+  p.spin_limit = rt.tune.SPIN > 0 ? rt.tune.SPIN : TEAM_SPIN_LIMIT;
   p.n = rt.n;
   p.rank = rt.rank;
   rt.scal_epoch = (rt.scal_epoch % 0xFFFFFEu) + 1u;

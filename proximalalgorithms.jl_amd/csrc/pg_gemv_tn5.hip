@@ -281,7 +281,8 @@ pg_status mat_fused_tn_trio_t(pg_mat* A, const void* const* r, const void* const
                               void* const* At_r, void* const* y, void* const* z, void* const* res, void* const* Az, bool image_of_res) {
   pg_ctx* c = A->ctx;
   const int nrg = (int)(A->ld / (1024 / (int64_t)sizeof(T)));
-  if (pg_row_sharded(c) || pg_col_sharded(c) || A->m <= 0 || A->n <= 0 || !tn_pair_covers(nrg)) {
+  // (the guard of the two-point entry point, tn_supported<T> included: the sweeps index column groups in 32 bits)
+  if (pg_row_sharded(c) || pg_col_sharded(c) || A->m <= 0 || A->n <= 0 || A->n >= ((int64_t)1 << 31) || !tn_pair_covers(nrg)) {
     pg_set_error("the three-point sweep needs an unsharded operator with %d .. %d rows", (int)(32 * (1024 / sizeof(T)) + 1), (int)(64 * (1024 / sizeof(T))));
     return PG_ERR_UNSUPPORTED;
   }

@@ -48,29 +48,36 @@ __device__ __forceinline__ void row_member_sum(T& acc, const T val) {
   }
 }
 
-template <typename T, int U, int C, int LAG, int PF, int LAGR, bool DELAY>
+// PAIR: one post per TWO steps.  A device keeps the granules of an even step until the odd step behind it has its own and writes
+// both with one store of 16 * S bytes per inbox (slot (i / 2) % RING, member p at p * 2 S, the even step's granules first; tag =
+// epoch | i / 2 + 1); a consumer polls the pair's slot at both steps and takes its half.  Half the fabric transactions (the first
+// knob on real xGMI) for one step less of slack on the even steps (their granules leave one step later).
+template <typename T, int U, int C, int LAG, int PF, int LAGR, bool DELAY, bool PAIR = false>
 __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   using T2 = typename Pair2<T>::type;
   constexpr int VEC = VecOf<T>::N;
   constexpr int G = (int)sizeof(T) / 4;  // granules per value
   constexpr int S = C * G;               // granules a member posts per step
+  constexpr int MS = PAIR ? 2 * S : S;   // granules of one member in a ring slot (PAIR: two steps share a slot)
   constexpr int GL = 64 / C;             // lanes that hold the same column after the column-parallel reduction
   constexpr int RING = PEER_RING;
   constexpr int LT = LAG + LAGR;
   static_assert(LT > 0 && 2 * LT + 2 <= RING, "the totals of a step are consumed LT > 0 steps later; the ring holds 2 LT + 2 steps");
-  static_assert(S <= 8 && (C & (C - 1)) == 0 && C >= 1, "C a power of two, at most eight granules per member and step");
+  static_assert(MS <= 8 && (C & (C - 1)) == 0 && C >= 1, "C a power of two, at most eight granules per member and ring slot");
   extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
   V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][C][U][64]
   const int lane = threadIdx.x;
   const int team = (int)blockIdx.x;
   const int member = a.peer_rank;
   const int TM = a.peer_n;
-  const int npoll = TM * S;
+  const int npoll = TM * MS;
   const int64_t ncg = (a.n + C - 1) / C;
   const CgMap map(ncg, C, a.line_cols, team, a.nteams);
   const int64_t cnt = map.cnt;
-  const size_t ring_off = (size_t)team * RING * (size_t)(TEAM_MAX * S);
+  const size_t ring_off = (size_t)team * RING * (size_t)(TEAM_MAX * MS);
+  auto slot_of = [&](int64_t i) __attribute__((always_inline)) -> size_t { return (size_t)((PAIR ? (i >> 1) : i) % RING) * (TEAM_MAX * MS); };
+  auto tag_of = [&](int64_t i) __attribute__((always_inline)) -> unsigned { return a.tag_base + (unsigned)((PAIR ? (i >> 1) : i) + 1); };
   unsigned long long* const ring = a.xch + ring_off;
 
   V rk[U], racc[U];
@@ -101,19 +108,21 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
   const T* const pv1 = a.p1v != nullptr ? a.p1v : a.x;
   const bool has_pv = a.p0v != nullptr;
 
-  // where this lane posts: lane q * S + s (q < TM, s < S) writes granule s of this device's step into member q's inbox (its own
-  // included) -- the step's granules reach every inbox with ONE store instruction, 8 * S contiguous bytes per inbox
-  // (DELAY: the lanes behind them carry this device's stamp, one per inbox)
+  // where this lane posts: lane q * MS + s2 (q < TM, s2 < MS) writes granule s2 of this device's step (PAIR: of its two steps, the even
+  // one's S granules first) into member q's inbox (its own included) -- the granules reach every inbox with ONE store instruction,
+  // 8 * MS contiguous bytes per inbox (DELAY: the lanes behind them carry this device's stamp, one per inbox)
   const int npoll_all = DELAY ? npoll + TM : npoll;
-  const int post_s = lane % S;
+  const int post_s = (lane % MS) % S;   // the granule of a step this lane carries: half post_s % G of column post_s / G
+  const int post_h = (lane % MS) / S;   // PAIR: 0 = the even step of the pair, 1 = the odd one
   unsigned long long* post_ptr = nullptr;
   {
-    const int q_of_lane = lane < npoll ? lane / S : lane - npoll;
+    const int q_of_lane = lane < npoll ? lane / MS : lane - npoll;
 #pragma unroll
     for (int q = 0; q < TEAM_MAX; ++q)
       if (q < TM && q_of_lane == q) post_ptr = a.peer_ring[q];
-    post_ptr += ring_off + (lane < npoll ? (size_t)member * S + post_s : (size_t)TM * S + (size_t)member);
+    post_ptr += ring_off + (lane < npoll ? (size_t)member * MS + (size_t)(lane % MS) : (size_t)TM * MS + (size_t)member);
   }
+  unsigned bits_even = 0;  // PAIR: this lane's granule of the even step, kept until the odd step's is there
 
   struct Tile {
     V col[C][U];
@@ -164,12 +173,18 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
       const unsigned long long b = __builtin_bit_cast(unsigned long long, mine);
       bits = (post_s % G) == 0 ? (unsigned)b : (unsigned)(b >> 32);
     }
+    if constexpr (PAIR) {
+      const bool odd = (i & 1) != 0;
+      if (!odd) bits_even = bits;
+      if (!odd && i + 1 < cnt) return;  // the even step of a pair: its granules leave with the odd step's (a last step without a partner: now)
+      bits = post_h == 0 ? bits_even : (odd ? bits : 0u);
+    }
     if constexpr (DELAY) {
       if (lane >= npoll) bits = (unsigned)__builtin_amdgcn_s_memrealtime();  // the stamp granules: behind the TM members' values, one per member
     }
-    const unsigned long long word = ((unsigned long long)(a.tag_base + (unsigned)(i + 1)) << 32) | bits;
+    const unsigned long long word = ((unsigned long long)tag_of(i) << 32) | bits;
     if (lane < npoll_all)
-      __hip_atomic_store(post_ptr + (size_t)(i % RING) * (TEAM_MAX * S), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(post_ptr + slot_of(i), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
   const int poll_lane = lane < npoll_all ? lane : npoll_all - 1;
   const bool adds = lane < npoll && (lane % G) == 0;  // this lane's granule (pair) is a member's value of some column
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     return __builtin_amdgcn_ballot_w64(ok) == ~0ull;
   };
   auto poll_word = [&](int64_t i) __attribute__((always_inline)) -> unsigned long long {
-    return __hip_atomic_load(ring + (size_t)(i % RING) * (TEAM_MAX * S) + poll_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __hip_atomic_load(ring + slot_of(i) + poll_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
   // the small loads of step i's epilogue, issued with the poll (before the tile loads: they return first)
   auto fetch = [&](Pend& pd, int64_t i) __attribute__((always_inline)) {
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
   };
   // totals of step i (all members have posted, or will shortly) -> epilogue -> v_j (0 for columns past the end)
   auto totals = [&](int64_t i, Pend& pd, T (&vj)[C]) __attribute__((always_inline)) {
-    const unsigned tag = a.tag_base + (unsigned)(i + 1);
+    const unsigned tag = tag_of(i);
     // The first look at the granules stays OUTSIDE the retry loop (pg_gemv_tnt.h).
     if (!dead && !arrived(pd.w, tag)) {
       long long spins = 0;
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
         __builtin_amdgcn_s_sleep(1);
         pd.w = poll_word(i);
         if (arrived(pd.w, tag)) break;
-        if (++spins > TEAM_SPIN_LIMIT) {
+        if (++spins > a.spin_limit) {
           dead = true;
           if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
@@ -228,8 +243,12 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
       val = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     }
     val = adds ? val : T(0);
+    if constexpr (PAIR) {  // the odd step's granules sit S lanes above the even step's
+      const T up = row_from_above<S>(val);
+      val = (i & 1) != 0 ? up : val;
+    }
     T g = val;
-    row_member_sum<S, 1>(g, val);           // the members of this lane's row, ascending
+    row_member_sum<MS, 1>(g, val);          // the members of this lane's row, ascending
     if (npoll > 16) g = swap16_add(g, g);   // (wave-uniform) rows 0 + 1, 2 + 3
     if (npoll > 32) g = swap32_add(g, g);   // (rows 0 + 1) + (rows 2 + 3): the same order on every device
     const int64_t j = map.at(i) * C + c_lane;

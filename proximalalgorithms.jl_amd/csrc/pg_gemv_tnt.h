@@ -227,7 +227,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         __builtin_amdgcn_s_sleep(1);
         pd.w = poll_word(i);
         if (arrived(pd.w, tag)) break;
-        if (++spins > TEAM_SPIN_LIMIT) {
+        if (++spins > a.spin_limit) {
           dead = true;
           if (lane == 0) __hip_atomic_store(a.team_err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;

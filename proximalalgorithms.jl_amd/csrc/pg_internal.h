@@ -100,6 +100,18 @@ struct pg_row_team {
   unsigned long long* wait_stats = nullptr;  // device: { late waves, polls spent waiting, (latency injector:) ticks of slack left, steps counted } since pg_ctx_set_row_team (telemetry)
   long long sweeps = 0;       // row-team sweeps launched since pg_ctx_set_row_team
   unsigned gen = 0;           // bumped by every pg_ctx_set_row_team: what a matrix agreed on with one team does not carry over
+  // pg_ctx_row_team_tune: the sweep's geometry per context, WITHOUT PG_TUNE (0 = the table's choice; the same on every device of the team)
+  struct Tune {
+    int C = 0, LAG = 0, LAGR = 0, PF = 0, WGS = 0, W = 0;
+    int K1 = -1;            // -1: default (the one-wave sweep where one wave holds the column); 0: round 5's kernel
+    int PAIR = -1;          // -1 / 0: one post per step; 1: one post per two steps (half the fabric transactions)
+    long long SPIN = 0;     // bounded wait in polls (0: 2^21)
+  } tune;
+  // what the LAST row-team sweep ran with (pg_ctx_row_team_geometry)
+  struct Geom {
+    int W = 0, U = 0, C = 0, LAG = 0, LAGR = 0, PF = 0, WGS = 0, K1 = 0, PAIR = 0, nteams = 0;
+    long long SPIN = 0;
+  } last;
 };
 
 namespace pgtn {

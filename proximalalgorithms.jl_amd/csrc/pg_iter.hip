@@ -468,6 +468,15 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   const bool reuse = o->fast && o->reuse_residual != 0;
   // one read of A per iteration where the fused sweep applies: FB / FFB with a fixed step, FFB adaptive with the residual
   // pair; host-provided extrapolation coefficients arrive one step at a time, so they need the two-sweep path
+  if (o->single_sweep != 0 && pg_row_sharded(c) && c->rteam.n > 1 && f->A->m > 0 && f->A->n > 0) {
+    // row teams: the devices agree on the longest block of the team before anyone decides how it sweeps -- a collective (every
+    // device creates its iterator at the same point of the program); its failure is this call's failure, on this rank, now
+    const pg_status agreed = pg_mat_row_team_agree(c, f->A);
+    if (agreed != PG_OK) {
+      delete it;
+      return agreed;
+    }
+  }
   it->single_sweep = o->single_sweep != 0 && pg_ls_fused_pass_supported(f) && !(o->fast && o->seq_kind == PG_SEQ_HOST) &&
                      (!it->adaptive || (o->fast && reuse));
   const int nvec = it->single_sweep ? 7 : 6;

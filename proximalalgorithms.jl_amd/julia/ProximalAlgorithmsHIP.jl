@@ -32,7 +32,7 @@ function check(status::Int32)
     throw(ProxGradError(status, unsafe_string(ccall((:pg_last_error, libpg), Cstring, ()))))
 end
 
-const PG_ABI_VERSION = Int32(3)   # include/proxgrad_hip.h: the version this file was written against
+const PG_ABI_VERSION = Int32(4)   # include/proxgrad_hip.h: the version this file was written against
 
 function __init__()   # a stale or mismatched build is refused at load, not at the first missing symbol
     found = ccall((:pg_abi_version, libpg), Int32, ())
@@ -629,6 +629,14 @@ function row_team_stats(ctx::HIPContext)   # (sweeps, late wave-steps, polls spe
     check(ccall((:pg_ctx_row_team_stats, libpg), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), ctx.handle, a, b, c))
     (sweeps = a[], late_waves = b[], wait_polls = c[])
 end
+# the sweep's geometry at run time (every rank the same values): row_team_tune!(ctx, "PAIR", 1) = one post per two steps
+row_team_tune!(ctx::HIPContext, key::AbstractString, value::Integer) =
+    check(ccall((:pg_ctx_row_team_tune, libpg), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx.handle, key, value))
+function row_team_geometry(ctx::HIPContext)   # what the last row-team sweep ran with ("W=1 U=8 C=2 ... PAIR=0 ...")
+    buf = zeros(UInt8, 160)
+    check(ccall((:pg_ctx_row_team_geometry, libpg), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64), ctx.handle, buf, length(buf)))
+    unsafe_string(pointer(buf))
+end
 set_row_team!(ctx::HIPContext, rank::Integer, inboxes::Vector{Ptr{Cvoid}}; max_workgroups::Integer = 0) =
     check(ccall((:pg_ctx_set_row_team, libpg), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, Int32),
                 ctx.handle, length(inboxes), rank, inboxes, max_workgroups))
@@ -653,7 +661,7 @@ end
 export HIPStyle, BROADCAST_TABLE, HIPContext, HIPVector, HIPMatrix, HIPLeastSquares, HIPNormL1, HIPIndBox,
        HIPForwardBackwardIteration, HIPFastForwardBackwardIteration, HIPForwardBackward, HIPFastForwardBackward, hip_solve,
        hip_douglas_rachford, save_state, resume, HIPLBFGSOperator, enable_images!, images_update!, images_mul!, images_ready,
-       row_team_inbox, row_team_handle, row_team_open, set_row_team!, row_team_stats, row_team_selftest,
+       row_team_inbox, row_team_handle, row_team_open, set_row_team!, row_team_stats, row_team_selftest, row_team_tune!, row_team_geometry,
        fused_tn!, fused_dys!
 
 end # module

@@ -281,6 +281,34 @@ def row_team_in_process(contexts, max_workgroups=0):
         _row_team_set(c, p, inboxes, max_workgroups)
 
 
+ROW_TEAM_KNOBS = ("C", "LAG", "LAGR", "PF", "WGS", "W", "K1", "PAIR", "SPIN")
+
+
+def row_team_tune(ctx, **knobs):
+    """The row-team sweep's geometry for this context, at run time (pg_ctx_row_team_tune; every rank the same values, 0 = the
+    library's choice): row_team_tune(ctx, PAIR=1) -- one post per two steps, half the fabric transactions; SPIN=... -- the bounded
+    wait in polls; C / LAG / LAGR (value - 1 tiles in registers) / PF / WGS / W / K1.  Takes effect at the next sweep."""
+    from ._lib import call
+
+    for key, value in knobs.items():
+        if key not in ROW_TEAM_KNOBS:
+            raise ValueError("unknown row-team knob %r (one of %s)" % (key, ", ".join(ROW_TEAM_KNOBS)))
+        call("pg_ctx_row_team_tune", ctx.handle, key.encode(), int(value))
+
+
+def row_team_geometry(ctx):
+    """what the LAST row-team sweep of this context ran with, as the library prints it ("W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1
+    PAIR=0 SPIN=2097152 WG=1024"; "none" before the first one) and as a dict"""
+    import ctypes as C
+
+    from ._lib import call
+
+    buf = C.create_string_buffer(160)
+    call("pg_ctx_row_team_geometry", ctx.handle, buf, len(buf))
+    text = buf.value.decode()
+    return text, ({k: int(v) for k, v in (kv.split("=") for kv in text.split())} if text != "none" else {})
+
+
 def row_team_stats(ctx):
     """{sweeps, late_waves, wait_polls} since the context became a row team (pg_ctx_row_team_stats): how often a wave did not
     find a step's granules at its first look, and how long it polled -- the first thing to read after a run on real fabric"""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6's measurements on a GPU box (run through gpurun): outputs under gpurun_out/r6/, summaries are copied into profiles/r6_* by hand
 # or by scripts/publish_round6_profiles.sh.  PMC passes are separate runs with --kernel-trace only, the program directly after `--`.
-# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench suite
+# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench newtests fuzzopt suite
 cd "$GRAFT_REPO_ROOT" || exit 1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r6; mkdir -p $O
@@ -44,11 +44,11 @@ if want counters; then
     [ -n "$P3" ] && rocprofv3 --kernel-trace --pmc $P3 -d $O/c_${key}_p3 -- "$@" > $O/c_${key}_p3.log 2>&1
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/c_${key}_fetch -- "$@" > $O/c_${key}_fetch.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c_${key}_write -- "$@" > $O/c_${key}_write.log 2>&1
-    for p in stats p1 p2 p3 fetch write; do python scripts/rocpd_summary.py --sum-per-dispatch --match gemv_tn $O/c_${key}_$p/*/*_results.db > $O/c_${key}_$p.md 2>&1; done; }
+    for p in stats p1 p2 p3 fetch write; do python scripts/rocpd_summary.py --sum-per-dispatch --match gemv_tn $O/c_${key}_$p/*/*_results.db > $O/c_${key}_$p.md 2>&1; rm -rf $O/c_${key}_$p; done; }
   run k1 $RT
   PG_TUNE=1 PG_TNP_K1=0 run r5 $RT
   run tnw python3 bench.py --m 2048 --n 1048576 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also
-  head -30 $O/c_k1_p1.md
+  for k in k1 r5 tnw; do echo "== $k"; grep -h "gemv_tn" $O/c_${k}_stats.md | head -3 | cut -c1-200; done
 fi
 if want latency; then
   D=off,0,2000,4000,6000,8000,12000,16000
@@ -62,7 +62,30 @@ if want bench; then
   python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 1500 $O/bench_default.json
   python bench.py --gpus 2 --share-device --backend gloo --m 4096 --n 1048576 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_rows_2048.json 2> $O/bench_2rank_rows_2048.err
 fi
+if want newtests; then
+  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "gamma_too_small or fuzz_differential or lbfgs or blas1 or prox_operators" > $O/pytest_new.log 2>&1; echo "rc $?" >> $O/pytest_new.log; tail -15 $O/pytest_new.log
+fi
+if want fuzzopt; then
+  timeout 1500 python tests/tools/fuzz_parity.py ${FUZZ_CASES:-400} 20000 options > $O/fuzz_options.log 2>&1; tail -12 $O/fuzz_options.log | cut -c1-600
+fi
 if want suite; then
   timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 > $O/gpu_suite.log 2>&1; echo "rc $?" >> $O/gpu_suite.log; tail -40 $O/gpu_suite.log
 fi
-ls $O | head -80
+# gpurun copies gpurun_out/ back only while it is below 64 MiB: the raw rocprofv3 databases stay on the box
+find $O -name "*.db" -size +1M -delete 2>/dev/null
+du -sh $O | tail -1
+# a digest at the very end (gpurun shows the tail of stdout)
+echo "==== digest"
+for f in $O/ab_*.jsonl $O/sweep_*.jsonl; do [ -f "$f" ] && { echo "-- $f"; python3 - "$f" <<'PY'
+import json, sys
+for ln in open(sys.argv[1]):
+    try: d = json.loads(ln)
+    except ValueError: continue
+    if "error" in d: print("  ERROR", str(d)[:300]); continue
+    print("  %-16s delay %-6s %.3f TB/s  %.1f it/s  passes %.2f late %s slack %s" % (d.get("geometry"), d.get("delay_ns"), d.get("TBps_all_ranks", 0), d.get("it_per_s", 0), d.get("a_passes_per_step", 0), d.get("late_waves"), d.get("slack_us")))
+PY
+}; done
+[ -f $O/side_by_side.jsonl ] && cat $O/side_by_side.jsonl
+[ -f $O/geometry_parity.log ] && { grep -c "^ok\|^OK" $O/geometry_parity.log; grep "FAIL" $O/geometry_parity.log | cut -c1-300; tail -2 $O/geometry_parity.log | cut -c1-300; }
+[ -f $O/pytest_ranks.log ] && tail -4 $O/pytest_ranks.log | cut -c1-300
+[ -f $O/pytest_new.log ] && tail -4 $O/pytest_new.log | cut -c1-300

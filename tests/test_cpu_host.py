@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(handle, name), f"{name} is declared in include/*.h but not exported"
     assert declared == set(lib.exported_symbols()), declared ^ set(lib.exported_symbols())
     header_version = int(re.search(r"#define PG_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "proxgrad_hip.h")).read()).group(1))
-    assert handle.pg_abi_version() == header_version == lib.PG_ABI_VERSION == 3
+    assert handle.pg_abi_version() == header_version == lib.PG_ABI_VERSION == 4
     julia = open(os.path.join(ROOT, "proximalalgorithms.jl_amd", "julia", "ProximalAlgorithmsHIP.jl")).read()
     assert int(re.search(r"const PG_ABI_VERSION = Int32\((\d+)\)", julia).group(1)) == header_version
 
@@ -400,15 +400,15 @@ def test_bench_config_carries_every_other_record_in_one_string():
     assert list(cfg)[:len(scalars)] == scalars  # the scalars come first: the driver cuts from the end
     assert scalars.index("also") < 12
     got = bench.parse_summary_string(cfg["also"])
-    assert got["adaptive"] == {"it_s": 105.4, "frac": 0.909, "a_passes": 1.0}
-    assert got["cfg2"] == {"it_s": 811.0, "frac": 0.89, "a_passes": 1.0}
-    assert got["cfg3"] == {"it_s": 3e5, "stepping_it_s": 2e4, "stepping_frac": 0.73}
-    assert got["cfg4"] == {"it_s": 107.1, "frac": 0.91, "a_passes": 1.0}
-    assert "out of memory" in got["cfg5blk"]["error"]
-    assert got["rows2pteam"]["it_s"] == 372.0 and got["rows2pteam"]["frac"] == 0.8
+    assert got["ad"] == {"it_s": 105.0, "frac": 0.91, "a_passes": 1.0}  # (three significant digits, per cent of the roofline)
+    assert got["c2"] == {"it_s": 811.0, "frac": 0.89, "a_passes": 1.0}
+    assert got["c3"] == {"it_s": 3e5, "stepping_it_s": 2e4, "stepping_frac": 0.73}
+    assert got["c4"] == {"it_s": 107.0, "frac": 0.91, "a_passes": 1.0}
+    assert got["c5"]["error"].startswith("MemoryError") and ";" not in got["c5"]["error"]  # (24 characters of the reason)
+    assert got["rt"]["it_s"] == 372.0 and got["rt"]["frac"] == 0.8
     assert cfg["sustained_it_s"] == 104.0 and cfg["in_library_loop_it_s"] == 106.0
     assert {k for k, v in cfg.items() if isinstance(v, (dict, list))} == {"problem", "final", "also_summary"}
-    assert len(cfg["also"]) < 400
+    assert len(cfg["also"]) <= bench.SUMMARY_BUDGET
     # N > 1: the other layouts, and which form of the row layout the top-level value is
     job2 = bench.Job(bench.parse_args(["--gpus", "8"]), 8, 0)
     job2.main_rec = dict(job.main_rec)
@@ -418,9 +418,50 @@ def test_bench_config_carries_every_other_record_in_one_string():
     job2.extra["rows_strong_teams"] = {"error": "timed out"}
     cfg2 = job2.line()["config"]
     lay = bench.parse_summary_string(cfg2["layouts"])
-    assert lay["cols"] == {"it_s": 810.0, "frac": 0.89, "a_passes": 1.0} and lay["teams"] == {"error": "timed out"}
+    assert lay["co"] == {"it_s": 810.0, "frac": 0.89, "a_passes": 1.0} and lay["tm"] == {"error": "timed out"}
     assert cfg2["row_layout"] == "two_sweeps" and "timed out" in cfg2["row_layout_reason"]
     assert len([k for k, v in cfg2.items() if not isinstance(v, (dict, list))]) <= 20
+
+
+def test_bench_summary_string_fits_the_drivers_record():
+    """the driver's BENCH_rNN.json cuts `config.also` at about 128 characters, so rounds 4-5 lost
+    the last five of ten labels there.  The committed round-5 lines (profiles/r5_bench_*.json), re-summarised in the short form:
+    at most SUMMARY_BUDGET characters, every label present, the string ends with the row-team record, and it parses back to the
+    figures of the line to the digits kept."""
+    import glob
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.SUMMARY_BUDGET <= 120
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(root, "profiles", "r[56]_bench_*.json"))):
+        try:
+            d = json.loads(open(path).read().strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            continue
+        for records in ([(a.get("label", "?"), a) for a in d.get("also") or []],
+                        [(k, v) for k, v in d.items() if isinstance(v, dict) and ("value" in v or "error" in v) and k in bench.SHORT_LABELS]):
+            if not records:
+                continue
+            seen += 1
+            s = bench.summary_string(records)
+            assert len(s) <= bench.SUMMARY_BUDGET, (path, len(s), s)
+            back = bench.parse_summary_string(s)
+            assert list(back) == [bench.SHORT_LABELS.get(l, l) for l, _ in records], (path, s)
+            for label, r in records:
+                got = back[bench.SHORT_LABELS.get(label, label)]
+                if "value" in r:
+                    assert got["it_s"] == pytest.approx(r["value"], rel=6e-3), (path, label, got, r["value"])
+                    if "frac" in got and (r.get("roofline") or {}).get("frac") is not None:
+                        assert got["frac"] == pytest.approx(r["roofline"]["frac"], abs=0.006), (path, label)
+    assert seen >= 2
+    d = json.loads(open(os.path.join(root, "profiles", "r5_bench_default.json")).read().strip().splitlines()[-1])
+    s = bench.summary_string([(a["label"], a) for a in d["also"]])
+    assert len(d["also"]) == 10 and s.split(";")[-1].startswith("rt=") and s.startswith("ad=")
 
 
 def test_bench_row_team_record_replaces_the_two_sweep_record_only_when_clean():

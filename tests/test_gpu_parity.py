@@ -349,6 +349,63 @@ def test_shipped_instances_adaptive_gamma_sequence(pa, name, fast):
         assert k < 10_000 and np.max(np.abs(z - xstar)) <= 1e-6
 
 
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gamma_too_small_exit_matches_oracle(pa, dtype, fast):
+    """The SECOND way out of the step-size search (src/utilities/fb_tools.jl:46: `while f_Az > f_Az_upp + tol && gamma >=
+    minimum_gamma`, and the `@warn` of :59-61): a LASSO whose `minimum_gamma` lies above the step the search would settle on, so
+    the loop ends because gamma fell below it while the decrease condition still fails.  Same gamma sequence and iterates as the
+    CPU restatement, PG_FLAG_GAMMA_TOO_SMALL exactly where the restatement's counter says so, a warning from the Python mirror --
+    on the fused engine (pg_iter_step), the generic engine (fb_tools.py over the operator calls) and both one-launch solvers
+    (pg_persist.hip).  VERDICT r5 missing 4."""
+    import warnings
+
+    from proximalalgorithms.jl_amd import _lib
+
+    m, n, K = 40, 400, 10
+    A, b, lam = synthetic_problem(m, n, dtype, seed=11)
+    x0 = np.zeros(n, dtype)
+    It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
+    Io = o.FastForwardBackwardIteration if fast else o.ForwardBackwardIteration
+    # where the search settles with the default minimum_gamma: gamma_ok = gamma0 / 4 on this instance
+    probe = [float(s_.gamma) for s_ in itertools.islice(Io(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0), 2)]  # (the state object is reused)
+    gamma0, gamma_ok = probe
+    assert gamma_ok <= gamma0 / 4
+    mg = dtype(3.0 * gamma_ok)  # the search now stops at 2 gamma_ok < mg, one halving short of the decrease condition
+    it_o = Io(f=o.LeastSquares(A, b), g=o.NormL1(lam), x0=x0, minimum_gamma=mg)
+    ref = []
+    for so in itertools.islice(it_o, K + 1):
+        ref.append((float(so.gamma), so.z.copy(), bool(it_o.counters.get("gamma_too_small", False))))
+    assert ref[1][0] == pytest.approx(2.0 * gamma_ok, rel=1e-6) and ref[1][2] and not ref[0][2]
+    gtol = 1e-6 if dtype == np.float32 else 1e-12
+    ztol = 2e-4 if dtype == np.float32 else 1e-9
+    for engine in ("fused", "generic"):
+        it_g = It(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0, minimum_gamma=mg, engine=engine)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            states = []
+            for k, sg in enumerate(itertools.islice(it_g, K + 1)):
+                states.append((float(sg.gamma), sg.z.numpy().copy()))
+                n_warn = sum("became too small" in str(w.message) for w in caught)
+                assert n_warn == sum(r[2] for r in ref[:k + 1]), (engine, k, n_warn)  # fb_tools.jl:59-61: once per search that ends below
+                if engine == "fused":
+                    flagged = bool(it_g._fused.scalars.flags & _lib.PG_FLAG_GAMMA_TOO_SMALL)
+                    assert flagged == ref[k][2], (engine, k)
+        for k, ((gg, zg), (go_, zo, _)) in enumerate(zip(states, ref)):
+            assert gg == pytest.approx(go_, rel=gtol), (engine, k, gg, go_)
+            assert np.max(np.abs(zg - zo)) <= ztol * max(1.0, np.max(np.abs(zo))), (engine, k)
+    # the one-launch solvers: K iterations inside the library (tol = 0 never stops them), then the same state and the flag
+    for solver in ("small", "coop"):
+        it_p = It(f=pa.LeastSquares(A, b), g=pa.NormL1(lam), x0=x0, minimum_gamma=mg, engine="fused")
+        next(iter(it_p))
+        k_p, sc = it_p._fused.run_small(1, K + 1, 0.0) if solver == "small" else it_p._fused.run_coop(1, K + 1, 0.0)
+        assert k_p == K + 1
+        assert float(sc.gamma) == pytest.approx(ref[K][0], rel=gtol), (solver, float(sc.gamma), ref[K][0])
+        assert sc.flags & _lib.PG_FLAG_GAMMA_TOO_SMALL, solver
+        z_p = it_p._fused.view()["z"].numpy()
+        assert np.max(np.abs(z_p - ref[K][1])) <= ztol * max(1.0, np.max(np.abs(ref[K][1]))), solver
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_adaptive_synthetic_final_objective(pa, dtype):
     """compare gamma up to the first differing decision, then the final objective."""
@@ -675,7 +732,7 @@ def test_bench_self_launched_two_ranks_reports_every_layout(pa):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     lay = bench.parse_summary_string(cfg["layouts"])
-    assert set(lay) == {"rows2s", "cols", "cfg5rows", "cfg5cols", "cfg5teams"} and lay["cols"]["it_s"] == pytest.approx(d["cols_strong"]["value"], rel=1e-4)
+    assert set(lay) == {"2s", "co", "5r", "5c", "5t"} and lay["co"]["it_s"] == pytest.approx(d["cols_strong"]["value"], rel=6e-3)
 
 
 @pytest.mark.parametrize("stage,kind", [("main", "hang"), ("cols_strong", "hang"), ("config5_weak_rows", "exit")])
@@ -947,99 +1004,51 @@ def test_column_shards_in_one_process_match_oracle(pa, args):
         assert all(c <= 2 * n_it + 2 for c in d["allreduce_calls"]), d["allreduce_calls"]
 
 
-def test_bench_default_line_carries_every_single_gpu_config(pa):
+def test_bench_default_line_carries_every_single_gpu_config(pa, bench_default_line):
     """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`): the top-level record is the fixed-step headline
     run; `also` holds the reference benchmark's adaptive mode on the same matrix and BASELINE configs 2, 3, 4, each with its
-    own roofline, then the long-column and short-column per-GPU block shapes at N = 8 (next-round 4 and 6:
-    one read of A per iteration at >= 0.8 of peak on 131072 x 131072)."""
-    import json
-    import subprocess
-    import sys
+    own roofline, then the long-column and short-column per-GPU block shapes at N = 8 and north_star's
+    row layout between two processes.  STRUCTURE only, plus north_star's own two floors (headline >= 0.6 of the roofline; the
+    K-step figure is not a burst): every other measured rate is read off the same line by tests/test_gpu_rates.py, reported and
+    held to hard floors a +-8 % box cannot flip."""
     import torch
 
     free, _ = torch.cuda.mem_get_info()
     if free < 140 * 2**30:
         pytest.skip("needs the 64 GiB headline matrix and config 4's 61 GiB")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-    def run():
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-                              "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500)
-        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-        lines = out.stdout.splitlines()
-        assert len(lines) == 1, lines
-        return json.loads(lines[0])
-
-    failed = []
-
-    def rates_ok(d):
-        """the thresholds on measured rates (everything else below is structure, checked on every line)"""
-        by = {r["label"]: r for r in d["also"]}
-        ad, c2, c3, c4, c5c, c5r = (by[k] for k in ("headline_adaptive", "config2", "config3", "config4", "config5_column_block", "headline_row_block_n8"))
-        checks = {"headline frac > 0.6 (north_star)": d["roofline"]["frac"] > 0.6,
-                  # (the K-step figure is not a BURST: at most 5 % above what the same iteration sustains for 5 s; six timed steps
-                  # right after two warm-up steps may well be a little below it)
-                  "K-step figure within -10 % .. +5 % of the sustained one": -0.10 < d["value"] / d["sustained"]["value"] - 1.0 < 0.05,
-                  "config5_column_block frac > 0.8": c5c["roofline"]["frac"] > 0.8, "headline_row_block_n8 frac > 0.75": c5r["roofline"]["frac"] > 0.75,
-                  "adaptive frac > 0.6": ad["roofline"]["frac"] > 0.6, "config2 frac > 0.6": c2["roofline"]["frac"] > 0.6,
-                  "config4 frac > 0.5": c4["roofline"]["frac"] > 0.5, "config3 loop faster than stepping": c3["device_loop"]["value"] > c3["stepping"]["value"],
-                  # config 4's family on the same instance: ZeroFPR at fewer reads than one per trial point, PANOCplus at about one
-                  "ZeroFPR faster than 0.3 x PANOC": by["config4_zerofpr"]["value"] > 0.3 * c4["value"],
-                  "PANOCplus faster than 0.75 x PANOC": by["config4_panocplus"]["value"] > 0.75 * c4["value"]}
-        failed[:] = [k for k, ok in checks.items() if not ok]
-        return not failed
-
-    def structure(d):
-        assert d["config"]["m"] == 16384 and d["config"]["n"] == 1 << 20 and d["config"]["mode"] == "fixed" and d["steps"] == 6
-        assert d["roofline"]["kernel"] == "gemv_tn" and "traffic_stale" in d["roofline"]
-        assert d["sustained"]["seconds"] >= 4.5
-        labels = [r["label"] for r in d["also"]]
-        assert labels == ["headline_adaptive", "config2", "config3", "config4", "config4_zerofpr", "config4_panocplus", "config5_column_block",
-                          "headline_row_block_n8", "rows_2proc_two_sweeps", "rows_2proc_row_team"], labels
-        ad, c2, c3, c4, zf, pp, c5c, c5r, r2, rt = d["also"]
-        assert zf["config"]["A_passes_per_step"] <= 3.0 and pp["config"]["A_passes_per_step"] <= 1.3, (zf["config"], pp["config"])
-        # north_star's row layout between two PROCESSES on this device: the row team reads its blocks ONCE per iteration (IPC-mapped
-        # inboxes, self-test ok, no fallback), ends at the two-sweep iterate and is faster than it
-        assert r2["config"]["a_passes_per_step"] == 2.0 and not r2["config"]["row_teams"]
-        assert rt["config"]["row_teams"] and rt["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1), rt["config"]
-        assert rt["config"]["row_team_selftest"] == "ok" and rt["config"]["sweep_fallbacks"] == 0
-        assert rt["config"]["final"]["f_x"] == pytest.approx(r2["config"]["final"]["f_x"], rel=1e-5)
-        assert rt["value"] > 1.3 * r2["value"], (rt["value"], r2["value"])
-        assert c5c["config"]["m"] == 131072 and c5c["config"]["a_passes_per_step"] == 1.0 and c5c["config"]["sweep_fallbacks"] == 0
-        assert c5r["config"]["m"] == 2048 and c5r["config"]["a_passes_per_step"] == 1.0
-        assert ad["config"]["mode"] == "adaptive" and ad["config"]["a_passes_per_step"] <= 1.5
-        assert c2["config"]["m"] == 8192 and c2["config"]["n"] == 262144
-        assert c3["stepping"]["roofline"]["kernel"] == "dr_step"
-        assert c4["config"]["A_passes_per_step"] <= 3.0
-        assert "zfpr=" in d["config"]["also"] and "pplus=" in d["config"]["also"]
-        for r in d["also"]:
-            assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["avg_launch_ms"] > 0, r.get("label")
-
-    d = run()
-    structure(d)
-    if not rates_ok(d):
-        # A measured rate below its threshold gets ONE fresh run, which must pass -- unless it is the one effect this suite can
-        # cause itself: while ANOTHER process on the device holds a cooperative queue (even idle: this pytest process, once one
-        # of its tests has used a cooperative launch), a cooperative kernel runs at 0.45 of its rate (profiles/
-        # r3_team_coop_vs_plain.md).  Told apart by running the same sweep with a plain launch.
-        first = {r["label"]: (r.get("roofline") or {}).get("frac") for r in d["also"]}
-        d = run()
-        structure(d)
-        if not rates_ok(d):
-            c5c = [r for r in d["also"] if r["label"] == "config5_column_block"][0]
-            env = dict(os.environ, PG_TN_TEAM_PLAIN="1")
-            out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--m", "131072", "--n", "131072", "--steps", "6", "--warmup", "3",
-                                  "--no-cpu-baseline", "--no-also", "--sustain", "0"], capture_output=True, text=True, timeout=600, env=env)
-            plain = json.loads(out.stdout.splitlines()[-1])
-            shared = c5c["roofline"]["frac"] < 0.6 and plain["roofline"]["frac"] > 0.8
-            if shared:
-                c5c["roofline"]["frac"] = plain["roofline"]["frac"]  # the sweep itself is fine: judge the rest of the line
-            assert rates_ok(d), (failed, first, {r["label"]: (r.get("roofline") or {}).get("frac") for r in d["also"]}, d["roofline"]["frac"], d["sustained"])
-            if shared:
-                import warnings
-
-                warnings.warn("another process on this device holds a cooperative queue: the cooperative team sweep ran at %.2f of 8 TB/s, "
-                              "%.2f with a plain launch" % (first["config5_column_block"], plain["roofline"]["frac"]))
+    d = bench_default_line()
+    assert d["config"]["m"] == 16384 and d["config"]["n"] == 1 << 20 and d["config"]["mode"] == "fixed" and d["steps"] == 6
+    assert d["roofline"]["kernel"] == "gemv_tn" and "traffic_stale" in d["roofline"]
+    assert d["sustained"]["seconds"] >= 4.5
+    labels = [r["label"] for r in d["also"]]
+    assert labels == ["headline_adaptive", "config2", "config3", "config4", "config4_zerofpr", "config4_panocplus", "config5_column_block",
+                      "headline_row_block_n8", "rows_2proc_two_sweeps", "rows_2proc_row_team"], labels
+    ad, c2, c3, c4, zf, pp, c5c, c5r, r2, rt = d["also"]
+    assert zf["config"]["A_passes_per_step"] <= 3.0 and pp["config"]["A_passes_per_step"] <= 1.3, (zf["config"], pp["config"])
+    # north_star's row layout between two PROCESSES on this device: the row team reads its blocks ONCE per iteration (IPC-mapped
+    # inboxes, self-test ok, no fallback) and ends at the two-sweep iterate
+    assert r2["config"]["a_passes_per_step"] == 2.0 and not r2["config"]["row_teams"]
+    assert rt["config"]["row_teams"] and rt["config"]["a_passes_per_step"] == pytest.approx(1.0, abs=0.1), rt["config"]
+    assert rt["config"]["row_team_selftest"] == "ok" and rt["config"]["sweep_fallbacks"] == 0
+    assert rt["config"]["final"]["f_x"] == pytest.approx(r2["config"]["final"]["f_x"], rel=1e-5)
+    assert c5c["config"]["m"] == 131072 and c5c["config"]["a_passes_per_step"] == 1.0 and c5c["config"]["sweep_fallbacks"] == 0
+    assert c5r["config"]["m"] == 2048 and c5r["config"]["a_passes_per_step"] == 1.0
+    assert ad["config"]["mode"] == "adaptive" and ad["config"]["a_passes_per_step"] <= 1.5
+    assert c2["config"]["m"] == 8192 and c2["config"]["n"] == 262144
+    assert c3["stepping"]["roofline"]["kernel"] == "dr_step"
+    assert c4["config"]["A_passes_per_step"] <= 3.0
+    # every other record also travels in ONE scalar string that fits the driver's record (VERDICT r5 next-round 4)
+    also = d["config"]["also"]
+    assert len(also) <= 120 and also.startswith("ad=") and also.split(";")[-1].startswith("rt="), also
+    assert [p_.split("=")[0] for p_ in also.split(";")] == ["ad", "c2", "c3", "c4", "zf", "pp", "c5", "r8", "r2", "rt"], also
+    for r in d["also"]:
+        assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["avg_launch_ms"] > 0, r.get("label")
+    # north_star's floors: >= 0.6 of the HBM roofline on the headline (one fresh run if a box's first line is below), and the
+    # K-step figure is what the iteration sustains (six timed steps right after two warm-up steps may be a little below it)
+    if not d["roofline"]["frac"] > 0.6:
+        d = bench_default_line(fresh=True)
+    assert d["roofline"]["frac"] > 0.6, d["roofline"]
+    assert -0.10 < d["value"] / d["sustained"]["value"] - 1.0 < 0.05, (d["value"], d["sustained"])  # (measured spread over five rounds: -2 % .. +0.3 %)
 
 
 def test_four_ranks_one_gpu_column_shards(pa):
@@ -2371,10 +2380,20 @@ def test_fuzz_differential_against_oracle(pa):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     bad = []
-    for seed in range(1000, 1080):
+    for seed in range(1000, 1040):
         desc, fails = fz.one_case(seed)
         if fails:
             bad.append((desc, fails))
+    # ... and forty cases that also draw the iterator options the base campaign leaves at their defaults: mf > 0,
+    # Fixed / Simple / Constant / host-fed sequences, reduce_gamma in {0.5, 0.3, 0.8}, minimum_gamma up to above 1 / Lf
+    fz.OPTIONS = True
+    try:
+        for seed in range(7000, 7040):
+            desc, fails = fz.one_case(seed)
+            if fails:
+                bad.append((desc, fails))
+    finally:
+        fz.OPTIONS = False
     assert not bad, bad
 
 

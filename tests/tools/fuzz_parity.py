@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Randomised differential test: the GPU engine (every form of the driver loop) against the CPU restatement on random
-small / mid-size LASSO-type problems.  Usage: python tests/tools/fuzz_parity.py [cases] [first_seed] [tall].  Prints one
-line per failing case and a summary; exit code 1 if anything failed.  `tall`: column lengths from 600 to 150000 rows (a fixed list of boundary lengths, or uniformly drawn) with few
+small / mid-size LASSO-type problems.  Usage: python tests/tools/fuzz_parity.py [cases] [first_seed] [tall|options].  Prints one
+line per failing case and a summary; exit code 1 if anything failed.  `options` (round 6): on top of the base draw, the iterator
+options the base campaign leaves at their defaults -- mf > 0, the extrapolation sequence (Fixed / Simple / Constant / a host-fed
+iterable / the adaptive default), reduce_gamma in {0.5, 0.3, 0.8}, a non-default minimum_gamma (from "never reached" to "above the
+step the search would settle on": fb_tools.jl:46's second condition and the flag of :59-61) -- drawn from a generator of their own.  `tall`: column lengths from 600 to 150000 rows (a fixed list of boundary lengths, or uniformly drawn) with few
 columns, so that every geometry of the single sweep is drawn (one wave per column group, shared workgroups, teams of
 workgroups -- csrc/pg_gemv_tn2.hip); the persistent small-problem kernels are skipped there."""
 import os
@@ -23,6 +26,15 @@ def objective(A, b, g_o, z):
 
 
 TALL = False
+OPTIONS = False
+
+
+def host_fed_sequence(R):
+    """a custom extrapolation sequence (any iterable: fast_forward_backward.jl:91-93): damped Nesterov coefficients"""
+    k = 1
+    while True:
+        yield R(0.9) * R(R(k - 1) / R(k + 2))
+        k += 1
 
 
 def one_case(seed):
@@ -69,11 +81,37 @@ def one_case(seed):
         kw["Lf"] = Lf
     elif mode == "adaptive_regret":
         kw["increase_gamma"] = dtype(1.01)
+    okw = dict(kw)  # the CPU restatement's keywords (sequences are objects of its own module)
+    opt_desc = ""
+    if OPTIONS:
+        ro = np.random.default_rng(seed + 2_000_003)
+        if mode != "fixed":
+            rg = dtype(ro.choice([0.5, 0.3, 0.8]))
+            kw["reduce_gamma"] = okw["reduce_gamma"] = rg
+            pick = ro.random()
+            # 1e-7 (default) | reachable only by a long search | above 1 / Lf: the search ends on the second condition
+            mg = dtype(1e-7) if pick < 0.4 else (dtype(0.02 / float(Lf)) if pick < 0.7 else dtype(float(ro.choice([1.5, 3.0, 8.0])) / float(Lf)))
+            kw["minimum_gamma"] = okw["minimum_gamma"] = mg
+            opt_desc += f" reduce_gamma={float(rg)} minimum_gamma={float(mg):.3g}"
+        if fast:
+            seq = ro.choice(["adaptive", "adaptive_mf", "fixed", "simple", "constant", "host"])
+            if seq == "adaptive_mf":
+                kw["mf"] = okw["mf"] = dtype(float(ro.choice([0.01, 0.1, 0.5])) * float(Lf))
+            elif seq == "fixed":
+                kw["extrapolation_sequence"], okw["extrapolation_sequence"] = pa.FixedNesterovSequence(dtype), o.fixed_nesterov_sequence(dtype)
+            elif seq == "simple":
+                kw["extrapolation_sequence"], okw["extrapolation_sequence"] = pa.SimpleNesterovSequence(dtype), o.simple_nesterov_sequence(dtype)
+            elif seq == "constant":
+                mc, sc_ = dtype(0.05 * float(Lf)), dtype(1.0 / float(Lf))
+                kw["extrapolation_sequence"], okw["extrapolation_sequence"] = pa.ConstantNesterovSequence(mc, sc_), o.constant_nesterov_sequence(mc, sc_)
+            elif seq == "host":
+                kw["extrapolation_sequence"], okw["extrapolation_sequence"] = host_fed_sequence(dtype), host_fed_sequence(dtype)
+            opt_desc += f" seq={seq}"
     tol = float(rng.choice([1e-3, 1e-4])) if dtype == np.float32 else float(rng.choice([1e-5, 1e-8]))
     maxit = int(rng.choice([50, 300, 1000]))
     x0 = (0.1 * rng.standard_normal(n)).astype(dtype) if rng.random() < 0.3 else np.zeros(n, dtype)
     alg_o = o.fast_forward_backward if fast else o.forward_backward
-    z_o, k_o = alg_o(tol=tol, maxit=maxit, x0=x0, f=o.LeastSquares(A, b), g=g_o, **kw)
+    z_o, k_o = alg_o(tol=tol, maxit=maxit, x0=x0, f=o.LeastSquares(A, b), g=g_o, **okw)
     F_o = objective(A, b, g_o, z_o)
     F_start = 0.5 * float(b.astype(np.float64) @ b.astype(np.float64))
     It = pa.FastForwardBackwardIteration if fast else pa.ForwardBackwardIteration
@@ -81,7 +119,12 @@ def one_case(seed):
     solvers = (["step", "run"] if (TALL or per_element) else ["step", "run", "small", "coop"]) + (["batched"] if mode == "fixed" else [])
     # (the one-launch solvers take scalar parameters of g only)
     fails = []
+    host_seq = OPTIONS and fast and "seq=host" in opt_desc
+    if host_seq:
+        solvers = ["step"]  # the coefficients are drawn on the host, one per step (pg_iter_step)
     for solver in solvers:
+        if host_seq:
+            kw["extrapolation_sequence"] = host_fed_sequence(dtype)
         it = It(f=f_g, g=g_g, x0=x0, engine="fused", **kw)
         gen = iter(it)
         st = next(gen)
@@ -133,15 +176,16 @@ def one_case(seed):
             dz = 0.0
         if not ok_k or dz > ztol or dF > Ftol:
             fails.append((solver, f"k={k} k_cpu={k_o} dz={dz:.2e} dF={dF:.2e}", ""))
-    desc = f"seed={seed} {np.dtype(dtype).name} {m}x{n} {'FFB' if fast else 'FB'} {mode} g={gname} tol={tol} maxit={maxit} k_cpu={k_o}"
+    desc = f"seed={seed} {np.dtype(dtype).name} {m}x{n} {'FFB' if fast else 'FB'} {mode} g={gname} tol={tol} maxit={maxit} k_cpu={k_o}{opt_desc}"
     return desc, fails
 
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    global TALL
+    global TALL, OPTIONS
     TALL = len(sys.argv) > 3 and sys.argv[3] == "tall"
+    OPTIONS = len(sys.argv) > 3 and sys.argv[3] == "options"
     pa.get_context()
     bad = 0
     t0 = time.perf_counter()
