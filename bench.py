@@ -855,6 +855,12 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
     }
     if P.get("row_teams"):  # how the granule exchange went (sweeps, waves that had to wait, polls spent waiting), this rank
         rec["config"]["row_team_stats"] = pa.row_team_stats(ctx)
+        # every knob that was in force, as the library reports it for its last sweep ("W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0
+        # SPIN=2097152 WG=1024"), and the share of wave-steps that did not find their granules at the first look
+        geom_text, geom = pa.row_team_geometry(ctx)
+        late = late_fraction(rec["config"]["row_team_stats"], geom, n)
+        rec["config"]["row_team_stats"]["late_fraction"] = late
+        rec["config"]["row_team_geometry"] = geom_text + ("" if late is None else " late=%.4f" % late)  # (one scalar: the driver's record keeps ~20)
         rec["config"]["row_team_selftest"] = getattr(ctx, "_row_team_selftest", None)  # the scalar exchange tried at attach time
         if D.world > 1:  # ... and whether EVERY rank's came back right (what an upgrade of the top-level record asks)
             import torch.distributed as dist
@@ -1628,7 +1634,8 @@ def shared_device_rows_record(m, n, teams, steps, beat=lambda: None, timeout=170
                            m, n, " as a row team" if teams else " (two sweeps + all-reduce)"),
                        "m": m, "n": n, "m_per_rank": m // 2, "a_passes_per_step": passes, "row_teams": bool(cfg.get("row_teams")),
                        "sweep_fallbacks": cfg.get("sweep_fallbacks"), "row_team_selftest": cfg.get("row_team_selftest"),
-                       "row_team_stats": cfg.get("row_team_stats"), "final": cfg.get("final")},
+                       "row_team_stats": cfg.get("row_team_stats"), "row_team_geometry": cfg.get("row_team_geometry"),
+                       "row_team_geometries_tried": cfg.get("row_team_geometries_tried"), "final": cfg.get("final")},
             "roofline": {"bound": "hbm", "kernel": "gemv_tn (row team, 2 processes)" if teams else "gemv_n_partial + gemv_t (2 processes)",
                          "avg_launch_ms": (d.get("roofline") or {}).get("avg_launch_ms"), "achieved": round(agg / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(agg / 1e9 / HBM_PEAK_GBS, 4),
@@ -1677,6 +1684,18 @@ def promote_row_team_record(args, job):
     return True
 
 
+LATE_THRESHOLD = 0.05  # of the wave-steps of a row-team record: above it the child tries the fewest-transactions geometry as well
+
+
+def late_fraction(stats, geom, n):
+    """late wave-steps / wave-steps of the row-team sweeps counted in `stats` (pg_ctx_row_team_stats): every sweep visits each of the
+    ceil(n / C) column groups once, with W waves"""
+    if not stats or not geom or not stats.get("sweeps"):
+        return None
+    wave_steps = stats["sweeps"] * geom.get("W", 1) * -(-n // max(geom.get("C", 1), 1))
+    return round(stats.get("late_waves", 0) / max(wave_steps, 1), 5)
+
+
 def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
     """`--row-teams-child`: the two row-team records (north_star's row layout at ONE read of A per iteration: the ranks push
     per-column partial dots into each other's IPC-mapped inbox inside the sweep, csrc/pg_gemv_tn4.hip) in a process group of
@@ -1697,6 +1716,26 @@ def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
             P2 = setup_lasso(pa, ctx, D, m_base * world if scaling == "weak" else m_base, n, dtype, args.seed, "rows", "fixed", row_teams=True)
             records[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", args.steps if top else sub_steps, args.warmup if top else 3,
                                    args.kernel_events, scaling=scaling)
+            if top:
+                # AT MOST two geometries, the second only when the first one's granules came late: one post per two steps (half the
+                # fabric transactions, pg_ctx_row_team_tune "PAIR").  The ranks decide together (the largest late fraction of any).
+                late = (records[key]["config"].get("row_team_stats") or {}).get("late_fraction") or 0.0
+                late = D.reduce_scalar(float(late), dist.ReduceOp.MAX) if world > 1 else late
+                threshold = float(os.environ.get("PG_BENCH_LATE_THRESHOLD", LATE_THRESHOLD))  # (tests force the second try with -1)
+                first = records[key]
+                if late > threshold and "PAIR=1" not in str(first["config"].get("row_team_geometry")):
+                    pa.row_team_tune(ctx, PAIR=1)
+                    try:
+                        second = run_ffb(pa, ctx, D, P2, "fixed", "one", args.steps, args.warmup, args.kernel_events, scaling=scaling)
+                    finally:
+                        pa.row_team_tune(ctx, PAIR=2)  # (back to one post per step for the record that follows)
+                    late2 = (second["config"].get("row_team_stats") or {}).get("late_fraction") or 0.0
+                    late2 = D.reduce_scalar(float(late2), dist.ReduceOp.MAX) if world > 1 else late2
+                    tried = "one post per step: %.4g it/s, %.2f %% of the wave-steps late; one post per two steps: %.4g it/s, %.2f %% late" % (
+                        first["value"], 100.0 * late, second["value"], 100.0 * late2)
+                    keep_second = D.reduce_scalar(1.0 if second["value"] > first["value"] else 0.0, dist.ReduceOp.MIN) > 0.5 if world > 1 else second["value"] > first["value"]
+                    records[key] = second if keep_second else first
+                    records[key]["config"]["row_team_geometries_tried"] = tried
             del P2
         except Exception as e:  # noqa: BLE001 -- reported in the record; the ranks may be out of step now, so the other one is skipped
             traceback.print_exc()

@@ -183,11 +183,14 @@ pg_status pg_ctx_row_team_selftest(pg_ctx* ctx, double* sum_out);
  *           -- the slack a granule has to arrive is (LAG + LAGR) steps of 16 KiB per wave
  *   "PF"    tiles in flight (1 / 2);  "WGS" workgroups per compute unit;  "W" waves per column (1 / 2 / 4)
  *   "K1"    1: the one-wave sweep of round 6 (default where it applies), 2: round 5's kernel
+ *   "AHEAD" 1 (default): a step's granules are looked at one step before their use (the poll then returns with a tile that is waited
+ *           for anyway: two tiles stay in flight), 2: at the start of the step that uses them (one step more of hand-off slack, half
+ *           the streaming depth: what a fabric slower than LAG + LAGR - 1 steps might prefer)
  *   "SPIN"  the bounded wait, in polls of ~64 clocks (default 2^21, about 0.2 s): after it a wave gives up, the step is redone
  *           with two sweeps and the all-reduce, on every device
  * A combination without an instantiation is refused at the next sweep (PG_ERR_UNSUPPORTED: the iterator stays on two sweeps).
  * pg_ctx_row_team_geometry writes what the LAST row-team sweep of this context ran with, e.g.
- * "W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0 SPIN=2097152 WG=1024" ("none" before the first one). */
+ * "W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0 AHEAD=1 SPIN=2097152 WG=1024" ("none" before the first one). */
 pg_status pg_ctx_row_team_tune(pg_ctx* ctx, const char* key, int64_t value);
 pg_status pg_ctx_row_team_geometry(pg_ctx* ctx, char* buf, int64_t buflen);
 pg_status pg_ctx_sync(pg_ctx* ctx);

@@ -52,7 +52,11 @@ pg_status pg_mat_fused_dys(pg_mat* A, const void* r, const void* xg, const void*
  * kind 0 -- one workgroup of one team is never started, its team-mates run into their bounded wait and the step is redone with
  * two sweeps (PG_FLAG_SWEEP_FALLBACK); kind 1 -- the launch is refused (PG_ERR_UNSUPPORTED), as a cooperative launch that
  * does not fit next to other work would be (a row-team sweep, pg_ctx_set_row_team, is a plain launch that is never refused:
- * there kind 1 acts like kind 0).  Nothing in the library reads the environment for this. */
+ * there kind 1 acts like kind 0).  Nothing in the library reads the environment for this.
+ * kind 4 (profiling): kth_launch != 0 makes a "team" of ONE device a row team from the next pg_ctx_set_row_team(ctx, 1, 0, {own
+ * inbox}, ...) on: the sweep posts to and polls its own inbox, so the whole instruction stream of the exchange runs with the
+ * kernel ALONE on the device -- what rocprofv3 --pmc needs, which serialises kernels (two ranks' sweeps would wait for each other
+ * until their bounded wait expires). */
 pg_status pg_ctx_test_team_fault(pg_ctx* ctx, int32_t kth_launch, int32_t kind);
 /* kind 2 -- LATENCY INJECTOR of the row-team sweep (the hand-off of benchmark/benchmarks.jl:16's partial sums between
  * devices): from now on the sweep is launched in its DELAY form and a step's granules are accepted by their consumers only

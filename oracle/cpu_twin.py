@@ -43,6 +43,13 @@ def build(force=False):
         tmp = path + ".tmp%d" % os.getpid()
         subprocess.run(["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", SRC, "-o", tmp, "-lm"], check=True)
         os.replace(tmp, path)
+    # builds of other hosts / of earlier versions of the source are dead weight (git-ignored, but pushed to the GPU box every run)
+    for name in os.listdir(OUT_DIR):
+        if name.startswith("libcpu_twin_") and name.endswith(".so") and os.path.join(OUT_DIR, name) != path:
+            try:
+                os.remove(os.path.join(OUT_DIR, name))
+            except OSError:
+                pass
     return path
 
 

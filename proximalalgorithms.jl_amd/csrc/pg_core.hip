@@ -238,7 +238,7 @@ pg_status pg_ctx_row_team_import(pg_ctx* c, const void* handle, void** inbox_out
 
 pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* const* inboxes, int32_t max_workgroups) {
   PG_REQUIRE(c != nullptr, "ctx is null");
-  if (nranks <= 1) {
+  if (nranks <= 1 && !(nranks == 1 && c->rteam.solo && inboxes != nullptr)) {
     c->rteam.n = 0;
     return PG_OK;
   }
@@ -262,7 +262,7 @@ pg_status pg_ctx_set_row_team(pg_ctx* c, int32_t nranks, int32_t rank, void* con
 
 pg_status pg_ctx_row_team_selftest(pg_ctx* c, double* sum_out) {
   PG_REQUIRE(c != nullptr && sum_out != nullptr, "null argument");
-  PG_REQUIRE(c->rteam.n > 1 && c->rteam.f_local != nullptr, "the context is not a row team");
+  PG_REQUIRE(pg_rteam_active(c) && c->rteam.f_local != nullptr, "the context is not a row team");
   const double mine = (double)(c->rteam.rank + 1);
   PG_HIP(hipMemcpyAsync(c->rteam.f_local, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
   PG_HIP(hipStreamSynchronize(c->stream));
@@ -302,22 +302,23 @@ pg_status pg_ctx_row_team_tune(pg_ctx* c, const char* key, int64_t value) {
   else if (k == "W") { PG_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "W: waves per column, 1 / 2 / 4"); t.W = (int)value; }
   else if (k == "K1") { PG_REQUIRE(value <= 2, "K1: 0 default, 1 the one-wave sweep, 2 round 5's kernel"); t.K1 = value == 0 ? -1 : (value == 1 ? 1 : 0); }
   else if (k == "PAIR") { PG_REQUIRE(value <= 2, "PAIR: 0 default, 1 one post per two steps, 2 one post per step"); t.PAIR = value == 0 ? -1 : (value == 1 ? 1 : 0); }
+  else if (k == "AHEAD") { PG_REQUIRE(value <= 2, "AHEAD: 0 default, 1 the poll one step ahead of its use, 2 at the start of its own step"); t.AHEAD = value == 0 ? -1 : (value == 1 ? 1 : 0); }
   else if (k == "SPIN") { t.SPIN = (long long)value; }
   else {
-    pg_set_error("pg_ctx_row_team_tune: unknown key '%s' (C, LAG, LAGR, PF, WGS, W, K1, PAIR, SPIN)", key);
+    pg_set_error("pg_ctx_row_team_tune: unknown key '%s' (C, LAG, LAGR, PF, WGS, W, K1, PAIR, AHEAD, SPIN)", key);
     return PG_ERR_INVALID;
   }
   return PG_OK;
 }
 
-// "W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0 SPIN=2097152 WG=1024": what the LAST row-team sweep of this context ran with
+// "W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0 AHEAD=1 SPIN=2097152 WG=1024": what the LAST row-team sweep of this context ran with
 pg_status pg_ctx_row_team_geometry(pg_ctx* c, char* buf, int64_t buflen) {
   PG_REQUIRE(c != nullptr && buf != nullptr && buflen > 0, "null argument");
   const pg_row_team::Geom& g = c->rteam.last;
   if (g.W == 0) snprintf(buf, (size_t)buflen, "none");
   else
-    snprintf(buf, (size_t)buflen, "W=%d U=%d C=%d LAG=%d LAGR=%d PF=%d WGS=%d K1=%d PAIR=%d SPIN=%lld WG=%d", g.W, g.U, g.C, g.LAG, g.LAGR, g.PF, g.WGS, g.K1,
-             g.PAIR, g.SPIN, g.nteams);
+    snprintf(buf, (size_t)buflen, "W=%d U=%d C=%d LAG=%d LAGR=%d PF=%d WGS=%d K1=%d PAIR=%d AHEAD=%d SPIN=%lld WG=%d", g.W, g.U, g.C, g.LAG, g.LAGR, g.PF, g.WGS, g.K1,
+             g.PAIR, g.AHEAD, g.SPIN, g.nteams);
   return PG_OK;
 }
 
@@ -334,7 +335,11 @@ pg_status pg_ctx_test_team_slack(pg_ctx* c, int64_t* ticks, int64_t* wave_steps)
 }
 
 pg_status pg_ctx_test_team_fault(pg_ctx* c, int32_t kth_launch, int32_t kind) {
-  PG_REQUIRE(c != nullptr && kth_launch >= 0 && kind >= 0 && kind <= 3, "bad argument");
+  PG_REQUIRE(c != nullptr && kth_launch >= 0 && kind >= 0 && kind <= 4, "bad argument");
+  if (kind == 4) {  // a team of ONE device counts as a team from the next pg_ctx_set_row_team on (kth_launch != 0): profiling the sweep alone
+    c->rteam.solo = kth_launch != 0;
+    return PG_OK;
+  }
   if (kind == 2 || kind == 3) {  // latency injector of the row-team sweep: kth_launch = nanoseconds (kind 3: injector off again)
     c->test_team_delay_on = kind == 2;
     c->test_team_delay_ticks = kind == 2 ? (unsigned)(kth_launch / 10) : 0u;

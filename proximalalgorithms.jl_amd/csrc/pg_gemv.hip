@@ -722,7 +722,7 @@ pg_status ls_fused_pass_t(pg_ls* f, const T* r_src, T* r_dst, double* f_dst, con
   pg_ctx* c = f->ctx;
   pg_mat* A = f->A;
   // row shards: only as a row TEAM (pg_ctx_set_row_team): the devices exchange the per-column partial dots inside the sweep
-  const bool rteam = pg_row_sharded(c) && c->rteam.n > 1;
+  const bool rteam = pg_row_sharded(c) && pg_rteam_active(c);
   if (rteam) {
     PG_TRY(pg_mat_row_team_agree(c, A));  // (a collective the first time: every device of the team makes this call)
     if (!tn_peer_covers(A->team_nrg)) {
@@ -1053,7 +1053,7 @@ pg_status pg_ls_allreduce_epilogue_scalars(pg_ls* f) {
 // back differently on different devices.
 pg_status pg_mat_row_team_agree(pg_ctx* c, pg_mat* A) {
   if (A->team_nrg != 0 && A->team_nrg_gen == c->rteam.gen) return PG_OK;
-  PG_REQUIRE(c->rteam.n > 1 && c->rteam.f_local != nullptr && pg_row_sharded(c), "the context is not a row team with a registered all-reduce");
+  PG_REQUIRE(pg_rteam_active(c) && c->rteam.f_local != nullptr && pg_row_sharded(c), "the context is not a row team with a registered all-reduce");
   const int64_t nrg = A->ld / (1024 / (int64_t)pg_sizeof(A->dtype));
   double hd[16] = {};
   float hf[16] = {};
@@ -1078,7 +1078,7 @@ bool pg_ls_fused_pass_supported(const pg_ls* f) {
     // PURE: reads what pg_mat_row_team_agree left on the matrix.  The agreement is a collective with a status of its own --
     // pg_iter_create and the bare sweep make it an explicit step and propagate its error (round 5 ran it from inside this
     // predicate and mapped a failure to "unsupported": one rank on two sweeps, its peers polling inboxes nobody fills)
-    if (!(c->rteam.n > 1 && f->A->m > 0 && f->A->n > 0)) return false;
+    if (!(pg_rteam_active(c) && f->A->m > 0 && f->A->n > 0)) return false;
     if (!(f->A->team_nrg != 0 && f->A->team_nrg_gen == c->rteam.gen)) return false;
     return tn_peer_covers(f->A->team_nrg);
   }

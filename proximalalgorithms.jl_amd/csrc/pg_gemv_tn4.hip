@@ -110,7 +110,7 @@ pg_status grow_partials_without_free(pg_mat* A, int S) {
 }
 
 // K1: gemv_tnp1_kernel (pg_gemv_tnp1.h, one wave per column: WAVES = 1) instead of gemv_tnt_kernel<..., PEER>; same protocol
-template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int WAVES = 4, bool K1 = false, bool PAIR = false>
+template <typename T, int U, int C, int LAG, int PF, int LAGR = 0, bool DELAY = false, int WAVES = 4, bool K1 = false, bool PAIR = false, bool AHEAD = false>
 pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   constexpr int G = (int)sizeof(T) / 4;
   constexpr int MS = (PAIR ? 2 : 1) * C * G;  // granules of one member in a ring slot
@@ -186,8 +186,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   const size_t lds = (size_t)LAG * WAVES * C * U * 1024;
   static_assert(!K1 || WAVES == 1, "gemv_tnp1_kernel is the one-wave sweep");
   const void* kern;
-  if constexpr (K1) kern = reinterpret_cast<const void*>(&gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR>);
-  else kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>);
+  if constexpr (K1) kern = reinterpret_cast<const void*>(&gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR, AHEAD>);
+  else kern = reinterpret_cast<const void*>(&gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY, AHEAD>);
   if (lds + 4096 > 64 * 1024) {
     static std::mutex mu;
     static bool opted_in[64] = {};
@@ -208,9 +208,9 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   }
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead
-  c->rteam.last = {WAVES, U, C, LAG, LAGR, PF, wgs_per_cu, K1 ? 1 : 0, PAIR ? 1 : 0, (int)nteams, a.spin_limit};
-  if constexpr (K1) hipLaunchKernelGGL((gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR>), dim3(grid), dim3(64), lds, c->stream, a);
-  else hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
+  c->rteam.last = {WAVES, U, C, LAG, LAGR, PF, wgs_per_cu, K1 ? 1 : 0, PAIR ? 1 : 0, AHEAD ? 1 : 0, (int)nteams, a.spin_limit};
+  if constexpr (K1) hipLaunchKernelGGL((gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR, AHEAD>), dim3(grid), dim3(64), lds, c->stream, a);
+  else hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY, AHEAD>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
 }
@@ -296,15 +296,18 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   const bool k1 = W == 1 && (tn.K1 >= 0 ? tn.K1 != 0 : env_int("PG_TNP_K1", 1) != 0);
   // one post per two steps, where the pair's granules of all devices still fit the 64 polling lanes (else: one post per step)
   const bool pair_req = tn.PAIR >= 0 ? tn.PAIR != 0 : env_int("PG_TNP_PAIR", 0) != 0;
+  // the poll of a step's totals one step ahead of its use (pg_gemv_tnp1.h): default; AHEAD = 2 (tune) / PG_TNP_AHEAD=0: at the start of its own step
+  const bool ahead = tn.AHEAD >= 0 ? tn.AHEAD != 0 : env_int("PG_TNP_AHEAD", 1) != 0;
   const int ms2 = 2 * C * (int)(sizeof(T) / 4);  // granules of one device in a pair's ring slot
   const bool pair = pair_req && k1 && ms2 <= 8 && c->rteam.n * (ms2 + (delay ? 1 : 0)) <= 64;
-#define PG_TNP1_CASE(UU, CC, LL, PP, RR)                                                                                                          \
-  if (k1 && !pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, 1, true>(A, a, blocks_out, WGS); \
-  if (k1 && pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, 1, true, true>(A, a, blocks_out, WGS)
-#define PG_TNP1_CASE_D(UU, CC, LL, PP, RR)                                                                                                        \
-  PG_TNP1_CASE(UU, CC, LL, PP, RR);                                                                                                               \
-  if (k1 && !pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, 1, true>(A, a, blocks_out, WGS); \
-  if (k1 && pair && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, 1, true, true>(A, a, blocks_out, WGS)
+#define PG_TNP1_ONE(UU, CC, LL, PP, RR, DD, PR, AH) \
+  if (k1 && pair == PR && ahead == AH && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && delay == DD) return launch_tnp<T, UU, CC, LL, PP, RR, DD, 1, true, PR, AH>(A, a, blocks_out, WGS)
+#define PG_TNP1_CASE(UU, CC, LL, PP, RR) \
+  PG_TNP1_ONE(UU, CC, LL, PP, RR, false, false, true); PG_TNP1_ONE(UU, CC, LL, PP, RR, false, true, true)
+  // _D: also with the latency injector, and with the poll at the start of its own step (AHEAD = 0: round 6's first form, for the A/B)
+#define PG_TNP1_CASE_D(UU, CC, LL, PP, RR) \
+  PG_TNP1_CASE(UU, CC, LL, PP, RR); PG_TNP1_ONE(UU, CC, LL, PP, RR, true, false, true); PG_TNP1_ONE(UU, CC, LL, PP, RR, true, true, true); \
+  PG_TNP1_ONE(UU, CC, LL, PP, RR, false, false, false); PG_TNP1_ONE(UU, CC, LL, PP, RR, true, false, false)
   if constexpr (sizeof(T) == 8) {
     PG_TNP1_GEOMETRIES_F64;
   } else {
@@ -312,15 +315,21 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   }
 #undef PG_TNP1_CASE
 #undef PG_TNP1_CASE_D
-#define PG_TNP_CASE(UU, CC, LL, PP, RR, WW)                                                             \
-  if (!k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && !delay) return launch_tnp<T, UU, CC, LL, PP, RR, false, WW>(A, a, blocks_out, WGS)
-#define PG_TNP_CASE_D(UU, CC, LL, PP, RR, WW)                                                           \
-  PG_TNP_CASE(UU, CC, LL, PP, RR, WW);                                                                  \
-  if (!k1 && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && delay) return launch_tnp<T, UU, CC, LL, PP, RR, true, WW>(A, a, blocks_out, WGS)
+#undef PG_TNP1_ONE
+#define PG_TNP_ONE(UU, CC, LL, PP, RR, WW, DD, AH) \
+  if (!k1 && ahead_w == AH && U == UU && C == CC && LAG == LL && PF == PP && LAGR == RR && W == WW && delay == DD) return launch_tnp<T, UU, CC, LL, PP, RR, DD, WW, false, false, AH>(A, a, blocks_out, WGS)
+#define PG_TNP_CASE(UU, CC, LL, PP, RR, WW) PG_TNP_ONE(UU, CC, LL, PP, RR, WW, false, false)
+#define PG_TNP_CASE_D(UU, CC, LL, PP, RR, WW) PG_TNP_CASE(UU, CC, LL, PP, RR, WW); PG_TNP_ONE(UU, CC, LL, PP, RR, WW, true, false)
+  // ... with the poll one step ahead (LT = 4 geometries of several waves per column; A/B: PG_TNP_AHEAD)
+#define PG_TNP_CASE_A(UU, CC, LL, PP, RR, WW) PG_TNP_ONE(UU, CC, LL, PP, RR, WW, false, true); PG_TNP_ONE(UU, CC, LL, PP, RR, WW, true, true)
+  const bool ahead_w = ahead && W > 1 && LAG + LAGR >= 4 && ((U == 8 && C == 2 && W == 2) || (U == 16 && C == 1 && (W == 2 || W == 4))) && PF == 2;
+  PG_TNP_CASE_A(8, 2, 2, 2, 2, 2); PG_TNP_CASE_A(16, 1, 2, 2, 2, 2); PG_TNP_CASE_A(16, 1, 2, 2, 2, 4);
   PG_TNP_GEOMETRIES;
 #undef PG_TNP_CASE
 #undef PG_TNP_CASE_D
-  pg_set_error("no row-team instantiation for W=%d U=%d C=%d LAG=%d PF=%d LAGR=%d K1=%d PAIR=%d%s", W, U, C, LAG, PF, LAGR, k1 ? 1 : 0, pair ? 1 : 0,
+#undef PG_TNP_CASE_A
+#undef PG_TNP_ONE
+  pg_set_error("no row-team instantiation for W=%d U=%d C=%d LAG=%d PF=%d LAGR=%d K1=%d PAIR=%d AHEAD=%d%s", W, U, C, LAG, PF, LAGR, k1 ? 1 : 0, pair ? 1 : 0, ahead ? 1 : 0,
                delay ? " with the latency injector" : "");
   return PG_ERR_UNSUPPORTED;
 }

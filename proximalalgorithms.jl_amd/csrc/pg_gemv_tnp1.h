@@ -52,7 +52,13 @@ __device__ __forceinline__ void row_member_sum(T& acc, const T val) {
 // both with one store of 16 * S bytes per inbox (slot (i / 2) % RING, member p at p * 2 S, the even step's granules first; tag =
 // epoch | i / 2 + 1); a consumer polls the pair's slot at both steps and takes its half.  Half the fabric transactions (the first
 // knob on real xGMI) for one step less of slack on the even steps (their granules leave one step later).
-template <typename T, int U, int C, int LAG, int PF, int LAGR, bool DELAY, bool PAIR = false>
+//
+// AHEAD: the poll of a step's totals (and the fetch of its x_j, z_old_j) is issued ONE STEP before its use, ahead of that step's tile
+// loads.  Vector loads return in issue order: a poll issued at the start of the step that consumes it sits BEHIND the loads of the
+// tile the next step will dot, so reading it waits for that tile too -- one of the two tiles "in flight" is then always complete
+// when the multiply-adds run, and the wave streams with half its depth.  Issued a step earlier the poll returns with a tile that
+// is needed anyway; the price is a first look one step sooner after the post (LT - 1 steps of slack instead of LT).
+template <typename T, int U, int C, int LAG, int PF, int LAGR, bool DELAY, bool PAIR = false, bool AHEAD = false>
 __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   using T2 = typename Pair2<T>::type;
@@ -131,6 +137,7 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     unsigned long long w;  // this lane's granule of the awaited step
     T xs, zos, q0, q1;     // x_j, z_old_j and the per-element parameters of this lane's column
   };
+  Pend pn{};  // AHEAD: the poll and the small loads of the NEXT step's totals, in flight across a step
   auto load = [&](Tile& t, int64_t i) __attribute__((always_inline)) {
     const int64_t j0 = map.at(i) * C;
 #pragma unroll
@@ -291,7 +298,13 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     const bool has_fma = ALL || i >= LT;
     Pend pd{};
     __builtin_amdgcn_sched_barrier(0);
-    if (has_fma) {
+    if constexpr (AHEAD) {
+      pd = pn;  // what the previous step asked for
+      if (ALL || (i + 1 >= LT && i + 1 < cnt + LT)) {  // the next step has totals to consume: ask now
+        pn.w = poll_word(i + 1 - LT);
+        fetch(pn, i + 1 - LT);
+      }
+    } else if (has_fma) {
       pd.w = poll_word(i - LT);  // issued BEFORE the next tile's loads: it returns first
       fetch(pd, i - LT);
     }

@@ -66,7 +66,13 @@ struct Pending {
 //
 // Tried on top and not kept (profiles/r5_team_options_not_kept.md): polling a step ahead (-17 %), a barrier-free dot exchange
 // through a tagged LDS ring with a rotating poster (+0.4 %).
-template <typename T, int U, int C, int WAVES, int LAG, int PF = 1, bool PEER = false, int LAGR = 0, bool DELAY = false>
+//
+// AHEAD (round 6, PEER): the poll of a step's totals and the fetch of its x_j / z_old_j are issued ONE STEP before their use.  Vector
+// loads return in issue order, so a poll issued at the start of the step that consumes it sits behind the loads of the tile the NEXT
+// step will dot: reading it waits for that tile as well, and only one of the two tiles "in flight" ever is.  Issued a step earlier it
+// returns with a tile that is waited for anyway.  Price: the first look comes one step sooner after the post (LT - 1 steps of slack).
+// (Round 5 tried this at LT = 2 -- one step of slack left, -17 % -- and dropped it; at LT = 4 it is what keeps two tiles in flight.)
+template <typename T, int U, int C, int WAVES, int LAG, int PF = 1, bool PEER = false, int LAGR = 0, bool DELAY = false, bool AHEAD = false>
 __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -77,6 +83,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
   static_assert(2 * LT + 2 <= RING, "granule ring too short for this lag");
   static_assert(PEER || TEAM_MAX * C * G <= 64, "one lane per granule of a step");  // (PEER: peer_n * C * G <= 64, checked at launch)
   static_assert(!DELAY || PEER, "the latency injector belongs to the row-team sweep");
+  static_assert(!AHEAD || (PEER && LT > 0), "the poll one step ahead: row-team sweeps with a lag");
   __shared__ T sm_dot[2][C][WAVES];
   extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
   V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][WAVES][C][U][64]
@@ -290,6 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     }
   };
   auto park_slot = [&](int64_t i) { return park + ((size_t)(LAG > 0 ? i % (LAG > 0 ? LAG : 1) : 0) * WAVES + wave) * (C * U * WAVE) + lane; };
+  Pending<T, C> pn{};  // AHEAD: the poll and the small loads of the NEXT step's totals, in flight across a step
 
   // One step: [poll the totals of step i - LT, fetch its x_j / z_old_j] [start loading tile i + PF into `nxt`]
   // [dot + post tile i = `cur`] [totals of step i - LT -> v_j ; A v accumulation from the parked tile] [park tile i - LAGR = `old`
@@ -302,7 +310,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
     // scheduling fences around the load issue: `nxt` is the register tile the previous step read last; without them the
     // scheduler hoists these loads above that step's multiply-adds into fresh registers and the kernel spills
     __builtin_amdgcn_sched_barrier(0);
-    if (has_fma) {
+    if constexpr (AHEAD) {
+      pd = pn;  // what the previous step asked for
+      if (ALL || (i + 1 >= LT && i + 1 < cnt + LT)) {  // the next step has totals to consume: ask now
+        pn.w = poll_word(i + 1 - LT);
+        fetch_xz(pn, i + 1 - LT);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (the small loads first, pinned: loads return in issue order)
+    } else if (has_fma) {
       if constexpr (LT > 0) pd.w = poll_word(i - LT);  // issued BEFORE the next tile's loads: it returns first
       fetch_xz(pd, i - LT);
     }

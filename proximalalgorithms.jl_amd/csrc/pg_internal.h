@@ -100,16 +100,19 @@ struct pg_row_team {
   unsigned long long* wait_stats = nullptr;  // device: { late waves, polls spent waiting, (latency injector:) ticks of slack left, steps counted } since pg_ctx_set_row_team (telemetry)
   long long sweeps = 0;       // row-team sweeps launched since pg_ctx_set_row_team
   unsigned gen = 0;           // bumped by every pg_ctx_set_row_team: what a matrix agreed on with one team does not carry over
+  bool solo = false;          // tests / profiling (pg_ctx_test_team_fault kind 4): a team of ONE device is a team -- the sweep posts to and polls its own
+                              // inbox, so the kernel can run ALONE under a profiler that serialises kernels (rocprofv3 --pmc)
   // pg_ctx_row_team_tune: the sweep's geometry per context, WITHOUT PG_TUNE (0 = the table's choice; the same on every device of the team)
   struct Tune {
     int C = 0, LAG = 0, LAGR = 0, PF = 0, WGS = 0, W = 0;
     int K1 = -1;            // -1: default (the one-wave sweep where one wave holds the column); 0: round 5's kernel
     int PAIR = -1;          // -1 / 0: one post per step; 1: one post per two steps (half the fabric transactions)
+    int AHEAD = -1;         // -1 / 1: the poll of a step's totals is issued one step ahead of its use; 0: at the start of its own step
     long long SPIN = 0;     // bounded wait in polls (0: 2^21)
   } tune;
   // what the LAST row-team sweep ran with (pg_ctx_row_team_geometry)
   struct Geom {
-    int W = 0, U = 0, C = 0, LAG = 0, LAGR = 0, PF = 0, WGS = 0, K1 = 0, PAIR = 0, nteams = 0;
+    int W = 0, U = 0, C = 0, LAG = 0, LAGR = 0, PF = 0, WGS = 0, K1 = 0, PAIR = 0, AHEAD = 0, nteams = 0;
     long long SPIN = 0;
   } last;
 };
@@ -226,6 +229,7 @@ struct pg_ls {
 };
 
 // which way a registered collective is used
+static inline bool pg_rteam_active(const pg_ctx* c) { return c->rteam.n > 1 || (c->rteam.n == 1 && c->rteam.solo); }
 static inline bool pg_row_sharded(const pg_ctx* c) { return (c->allreduce != nullptr || c->allreduce_begin != nullptr) && !c->shard_cols; }
 static inline bool pg_col_sharded(const pg_ctx* c) { return (c->allreduce != nullptr || c->allreduce_begin != nullptr) && c->shard_cols; }
 

@@ -336,7 +336,7 @@ pg_status iter_step_single_sweep(pg_iter* it) {
   std::swap(it->z_prev, it->z);                                                                     // :136
   // A x - b = (1 + beta)(A z - b) - beta (A z_prev - b)   (:138 without reading A)
   // (row teams: the combination covers this device's rows; f = the sum over the devices, exchanged like the sweep's own f)
-  const bool rteam = pg_row_sharded(c) && c->rteam.n > 1;
+  const bool rteam = pg_row_sharded(c) && pg_rteam_active(c);
   PG_TRY(pg_residual_combo_async(c, it->dtype, f->A->m, f->r, (double)(T(1) + (T)it->beta), it->rz,
                                  (double)(-(T)it->beta), it->rz_prev, 0.5 * f->lam, nullptr, rteam ? c->rteam.f_local : nullptr));
   if (rteam) PG_TRY(pg_rteam_sum_scalar(c, c->rteam.f_local, c->dscal + PG_S_F));
@@ -468,7 +468,7 @@ pg_status pg_iter_create(pg_ctx* c, pg_ls* f, const pg_iter_opts* o, pg_iter** o
   const bool reuse = o->fast && o->reuse_residual != 0;
   // one read of A per iteration where the fused sweep applies: FB / FFB with a fixed step, FFB adaptive with the residual
   // pair; host-provided extrapolation coefficients arrive one step at a time, so they need the two-sweep path
-  if (o->single_sweep != 0 && pg_row_sharded(c) && c->rteam.n > 1 && f->A->m > 0 && f->A->n > 0) {
+  if (o->single_sweep != 0 && pg_row_sharded(c) && pg_rteam_active(c) && f->A->m > 0 && f->A->n > 0) {
     // row teams: the devices agree on the longest block of the team before anyone decides how it sweeps -- a collective (every
     // device creates its iterator at the same point of the program); its failure is this call's failure, on this rank, now
     const pg_status agreed = pg_mat_row_team_agree(c, f->A);

@@ -100,6 +100,7 @@ class PANOCplusIteration(PANOCIteration):
             self.speculate = False  # no pair sweep at this column length
             return False
         self.counters["A_passes"] += 1
+        self.counters["spec_issued"] = self.counters.get("spec_issued", 0) + 1  # first passes taken ahead (make the one-read claim checkable)
         s.sp_Az.axpby_(1.0, s.sp_Ax, -1.0, s.sp_Ares)  # :210 as A x - A res
         s.sp = {"f_Ax": sp_f_Ax, "g_z": sc[0], "res_stats": (sc[1], sc[2], sc[3]), "gamma": s.gamma}
         return True
@@ -124,6 +125,7 @@ class PANOCplusIteration(PANOCIteration):
         s.sp = None
         if spec is not None and spec["gamma"] != s.gamma:
             spec = None
+            self.counters["spec_discarded"] = self.counters.get("spec_discarded", 0) + 1  # (gamma moved since: the pass is redone)
         while True:  # :183-234
             taken = False
             if can_update_direction and spec is not None:
@@ -134,6 +136,7 @@ class PANOCplusIteration(PANOCIteration):
                 s.tau, tau_backtracks, use_img = R(1), 0, True
                 s.img_steps += 1
                 s.f_Ax, s.g_z, s.res_stats = spec["f_Ax"], spec["g_z"], spec["res_stats"]
+                self.counters["spec_taken"] = self.counters.get("spec_taken", 0) + 1
                 spec = None
                 taken = fused = True
             elif can_update_direction:

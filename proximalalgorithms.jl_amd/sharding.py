@@ -247,6 +247,9 @@ def attach_row_team(ctx, world_size=None, rank=None, group=None, max_workgroups=
     if world_size <= 1:
         call("pg_ctx_set_row_team", ctx.handle, 0, 0, None, 0)
         return
+    env_knobs = row_team_knobs_from_env()
+    if env_knobs:  # PG_ROW_TEAM_TUNE="PAIR=1,SPIN=4194304": the sweep's knobs for a whole job, every rank the same environment
+        row_team_tune(ctx, **env_knobs)
     cached = getattr(ctx, "_row_team_inboxes", None)
     if cached is not None and cached[0] == (world_size, rank):  # the peers' inboxes are mapped once per context
         _row_team_set(ctx, rank, cached[1], max_workgroups)
@@ -281,7 +284,22 @@ def row_team_in_process(contexts, max_workgroups=0):
         _row_team_set(c, p, inboxes, max_workgroups)
 
 
-ROW_TEAM_KNOBS = ("C", "LAG", "LAGR", "PF", "WGS", "W", "K1", "PAIR", "SPIN")
+ROW_TEAM_KNOBS = ("C", "LAG", "LAGR", "PF", "WGS", "W", "K1", "PAIR", "AHEAD", "SPIN")
+
+
+def row_team_knobs_from_env(text=None):
+    """{knob: value} of the environment variable PG_ROW_TEAM_TUNE ("PAIR=1,LAG=2,SPIN=4194304"; read by attach_row_team on every rank --
+    a job's launcher exports it to all of them): the run-time form of pg_ctx_row_team_tune, no rebuild and no PG_TUNE."""
+    import os
+
+    text = os.environ.get("PG_ROW_TEAM_TUNE", "") if text is None else text
+    out = {}
+    for part in filter(None, (p.strip() for p in text.replace(";", ",").split(","))):
+        key, _, value = part.partition("=")
+        if key.strip() not in ROW_TEAM_KNOBS or not value.strip().isdigit():
+            raise ValueError("PG_ROW_TEAM_TUNE: %r is not <knob>=<non-negative integer> with a knob of %s" % (part, ", ".join(ROW_TEAM_KNOBS)))
+        out[key.strip()] = int(value)
+    return out
 
 
 def row_team_tune(ctx, **knobs):

@@ -12,16 +12,17 @@ if want parity; then
   timeout 2400 python scripts/peer_geometry_parity.py > $O/geometry_parity.log 2>&1; tail -3 $O/geometry_parity.log
 fi
 if want ranks; then
-  timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=15 -k "row_team or two_ranks_one_gpu or fuzz_row_teams or fuzz_ranks_as_processes or self_launched or four_ranks or rank_failure" > $O/pytest_ranks.log 2>&1; echo "rc $?" >> $O/pytest_ranks.log; tail -25 $O/pytest_ranks.log
+  timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=15 -k "row_team or two_ranks or fuzz_row_teams or fuzz_ranks_as_processes or self_launched or four_ranks or rank_failure" > $O/pytest_ranks.log 2>&1; echo "rc $?" >> $O/pytest_ranks.log; tail -25 $O/pytest_ranks.log
 fi
 if want ab; then
-  # round 5's kernel (K1 = 0) against round 6's one-wave sweep on 2 x 2048 rows, and the other block lengths' defaults, injector off / 0 / 4 / 8 / 12 us
-  timeout 900 python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --two-sweeps --repeat 2 --delays off,0,4000,8000,12000 --geoms 2:2:2:2:4:1:0,default > $O/ab_2048.jsonl 2> $O/ab_2048.err
-  timeout 600 python tests/tools/row_team_sweep.py --m 2048 --n 1048576 --ranks 2 --repeat 1 --delays off,0,8000 --geoms 4:2:2:2:4:1:0,default > $O/ab_1024.jsonl 2> $O/ab_1024.err
-  timeout 600 python tests/tools/row_team_sweep.py --m 8192 --n 524288 --repeat 1 --delays off,0,8000 --geoms default > $O/ab_4096.jsonl 2> $O/ab_4096.err
-  timeout 600 python tests/tools/row_team_sweep.py --m 32768 --n 131072 --repeat 1 --delays off,0,8000 --geoms default > $O/ab_16384.jsonl 2> $O/ab_16384.err
-  timeout 600 python tests/tools/row_team_sweep.py --m 2048 --n 1048576 --dtype f64 --repeat 1 --delays off,0,8000 --geoms default > $O/ab_f64_1024.jsonl 2> $O/ab_f64_1024.err
-  cat $O/ab_2048.jsonl | cut -c1-260
+  # 2 x 2048 rows: round 5's kernel (K1 = 0) | round 6's one-wave sweep with the poll at the start of its own step (AHEAD = 0) | the default
+  # (poll one step ahead) | one post per two steps on top; injector off / 0 / 4 / 8 / 12 us.  geometry = C:LAG:LAGR:PF:WGS:W:K1:PAIR:AHEAD
+  timeout 1200 python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --two-sweeps --repeat 2 --delays off,0,4000,8000,12000 --geoms 2:2:2:2:4:1:0,2:2:2:2:4:1:1:0:0,default,2:2:2:2:4:1:1:1:1 > $O/ab_2048.jsonl 2> $O/ab_2048.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 2048 --n 1048576 --ranks 2 --repeat 1 --delays off,0,8000 --geoms default,4:2:2:2:4:1:1:1:1 > $O/ab_1024.jsonl 2> $O/ab_1024.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 8192 --n 524288 --repeat 1 --delays off,0,8000,12000 --geoms 2:2:2:2:2:2:1:0:0,default > $O/ab_4096.jsonl 2> $O/ab_4096.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 32768 --n 131072 --repeat 1 --delays off,0,8000,12000 --geoms 1:2:2:2:1:4:1:0:0,default > $O/ab_16384.jsonl 2> $O/ab_16384.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 2048 --n 1048576 --dtype f64 --repeat 1 --delays off,0,8000 --geoms 2:2:2:2:4:1:1:0:0,default > $O/ab_f64_1024.jsonl 2> $O/ab_f64_1024.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 16384 --n 262144 --ranks 8 --repeat 1 --delays off,0,8000 --geoms 2:2:2:2:4:1:1:0:0,default,2:2:2:2:4:1:1:1:1 > $O/ab_8x2048.jsonl 2> $O/ab_8x2048.err
 fi
 if want calib; then
   # the same shapes with NO exchange, kernels of two contexts / two processes side by side (what "two ranks share one device" can reach at all)
@@ -45,10 +46,16 @@ if want counters; then
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/c_${key}_fetch -- "$@" > $O/c_${key}_fetch.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c_${key}_write -- "$@" > $O/c_${key}_write.log 2>&1
     for p in stats p1 p2 p3 fetch write; do python scripts/rocpd_summary.py --sum-per-dispatch --match gemv_tn $O/c_${key}_$p/*/*_results.db > $O/c_${key}_$p.md 2>&1; rm -rf $O/c_${key}_$p; done; }
-  run k1 $RT
-  PG_TUNE=1 PG_TNP_K1=0 run r5 $RT
+  # ONE rank as a team of one (pg_ctx_test_team_fault kind 4): the sweep exchanges its granules with itself and runs ALONE on the device --
+  # rocprofv3 --pmc serialises kernels, two ranks' sweeps would only wait for each other
+  RT1="python3 tests/tools/row_team.py --bench --solo --ranks 1 --m 2048 --n 1048576 --steps 20 --max-wgs -1"
+  run k1 $RT1
+  PG_TUNE=1 PG_TNP_AHEAD=0 run k1_own_step $RT1
+  PG_TUNE=1 PG_TNP_K1=0 run r5 $RT1
   run tnw python3 bench.py --m 2048 --n 1048576 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 --no-also
-  for k in k1 r5 tnw; do echo "== $k"; grep -h "gemv_tn" $O/c_${k}_stats.md | head -3 | cut -c1-200; done
+  $RT1 > $O/solo_k1.json 2>/dev/null; PG_TUNE=1 PG_TNP_AHEAD=0 $RT1 > $O/solo_k1_own_step.json 2>/dev/null; PG_TUNE=1 PG_TNP_K1=0 $RT1 > $O/solo_r5.json 2>/dev/null
+  cut -c1-200 $O/solo_k1.json $O/solo_k1_own_step.json $O/solo_r5.json
+  for k in k1 k1_own_step r5 tnw; do echo "== $k"; grep -h "gemv_tn" $O/c_${k}_stats.md | head -3 | cut -c1-200; done
 fi
 if want latency; then
   D=off,0,2000,4000,6000,8000,12000,16000
@@ -86,6 +93,7 @@ for ln in open(sys.argv[1]):
 PY
 }; done
 [ -f $O/side_by_side.jsonl ] && cat $O/side_by_side.jsonl
+for f in $O/solo_*.json; do [ -f "$f" ] && { echo "-- $f"; cut -c1-230 $f; }; done
 [ -f $O/geometry_parity.log ] && { grep -c "^ok\|^OK" $O/geometry_parity.log; grep "FAIL" $O/geometry_parity.log | cut -c1-300; tail -2 $O/geometry_parity.log | cut -c1-300; }
 [ -f $O/pytest_ranks.log ] && tail -4 $O/pytest_ranks.log | cut -c1-300
 [ -f $O/pytest_new.log ] && tail -4 $O/pytest_new.log | cut -c1-300

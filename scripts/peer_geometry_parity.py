@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W", "PG_TNP_K1")
+VARS = ("PG_TNP_C", "PG_TNP_LAG", "PG_TNP_LAGR", "PG_TNP_PF", "PG_TNP_WGS", "PG_TNP_W", "PG_TNP_K1", "PG_TNP_PAIR", "PG_TNP_AHEAD")
 CASES = [
     # (row_team.py arguments, geometry C:LAG:LAGR:PF:WGS:W | default).  Defaults (peer_geometry_f32): one wave per column up to 2048
     # rows, two up to 8192, four up to 16384; 16 KiB tiles per wave, LAG = 2 in LDS + LAGR = 2 in registers.

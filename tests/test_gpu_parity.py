@@ -735,6 +735,44 @@ def test_bench_self_launched_two_ranks_reports_every_layout(pa):
     assert set(lay) == {"2s", "co", "5r", "5c", "5t"} and lay["co"]["it_s"] == pytest.approx(d["cols_strong"]["value"], rel=6e-3)
 
 
+@pytest.mark.parametrize("how", ["late_granules", "environment"])
+def test_bench_two_ranks_both_row_team_geometries_give_the_two_sweep_iterate(pa, how):
+    """the row-team sweep's fabric knobs are run-time (pg_ctx_row_team_tune; PG_ROW_TEAM_TUNE for a whole
+    job) and every value in force is echoed in `config.row_team_geometry`.  `bench.py --gpus N` tries AT MOST two geometries in its
+    row-team child -- the default, then one post per two steps (half the fabric transactions) -- and the second only when the first
+    reports more than 5 % of its wave-steps late; here that is forced (threshold -1), and, second case, the whole job runs with
+    PAIR=1 from the environment.  Both geometries end at the two-sweep iterate, at one read of the block per step."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PG_TUNE")}
+    env.update({"PG_BENCH_LATE_THRESHOLD": "-1"} if how == "late_granules" else {"PG_ROW_TEAM_TUNE": "PAIR=1,SPIN=4194304"})
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--workload", "small",
+           "--steps", "8", "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.splitlines()[-1])
+    cfg, two = d["config"], d["rows_two_sweeps"]
+    assert cfg["row_layout"] == "row_teams", (cfg["row_layout"], cfg["row_layout_reason"])
+    assert cfg["a_passes_per_step"] == pytest.approx(1.0, abs=0.15) and cfg["sweep_fallbacks"] == 0
+    geom = dict(kv.split("=") for kv in cfg["row_team_geometry"].split())
+    assert set(geom) >= {"W", "U", "C", "LAG", "LAGR", "PF", "WGS", "K1", "PAIR", "AHEAD", "SPIN", "WG", "late"}, cfg["row_team_geometry"]
+    assert geom["W"] == "1" and geom["K1"] == "1" and 0.0 <= float(geom["late"]) <= 1.0
+    if how == "late_granules":
+        tried = cfg["row_team_geometries_tried"]
+        assert "one post per step:" in tried and "one post per two steps:" in tried, tried
+        assert geom["SPIN"] == str(1 << 21)
+    else:
+        assert geom["PAIR"] == "1" and geom["SPIN"] == "4194304" and "row_team_geometries_tried" not in cfg
+    # whichever geometry the line kept: the two-sweep iterate
+    assert cfg["final"]["f_x"] == pytest.approx(two["config"]["final"]["f_x"], rel=1e-5)
+    assert cfg["final"]["g_z"] == pytest.approx(two["config"]["final"]["g_z"], rel=1e-5)
+    assert cfg["final"]["res_inf_over_gamma"] == pytest.approx(two["config"]["final"]["res_inf_over_gamma"], rel=1e-3)
+    assert len([k for k, v in cfg.items() if not isinstance(v, (dict, list))]) <= 20
+
+
 @pytest.mark.parametrize("stage,kind", [("main", "hang"), ("cols_strong", "hang"), ("config5_weak_rows", "exit")])
 def test_bench_rank_failure_still_prints_a_line(pa, stage, kind):
     """A rank that hangs forever or dies inside a record: stdout still carries ONE JSON line with
@@ -2081,6 +2119,11 @@ def test_panocplus_second_pass_rides_in_the_next_first_sweep(pa):
         assert measure(ss) == pytest.approx(measure(so), rel=1e-6, abs=1e-9), k
     ps, p2 = it_s.counters["A_passes"], it_2.counters["A_passes"]
     assert p2 >= 2 * (its - 1) and ps <= p2 - (its - 6), (ps, p2)  # one read per iteration where the other run takes two
+    # ... and the speculation is what did it: first passes taken ahead, nearly all of them used by the next step; a run
+    # that silently stopped speculating (an UNSUPPORTED from the pair sweep sets speculate = False) fails here, not in a bench
+    c = it_s.counters
+    assert it_s.speculate and c.get("spec_issued", 0) >= its - 6 and c.get("spec_taken", 0) >= c["spec_issued"] - 1 - c.get("spec_discarded", 0), c
+    assert "spec_issued" not in it_2.counters
 
 
 # ------------------------------------------------------------------------------------------------

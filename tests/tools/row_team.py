@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--delay-ns", type=int, default=-1,
                     help="latency injector (pg_ctx_test_team_fault kind 2): the sweep's DELAY form, a step's granules accepted only "
                          "this many nanoseconds after they were stored (0: the injector's own cost; -1: off)")
+    ap.add_argument("--solo", action="store_true",
+                    help="--bench --ranks 1: a team of ONE rank (pg_ctx_test_team_fault kind 4) -- the sweep exchanges its granules with itself, the "
+                         "kernel runs alone on the device: for rocprofv3 --pmc, which serialises kernels")
     ap.add_argument("--bench", action="store_true",
                     help="timing instead of parity: synthetic row blocks generated on the device (no host copy, no oracle), "
                          "--steps timed iterations after 3 warm-up steps; prints it/s and the aggregate bytes of A per second")
@@ -216,6 +219,10 @@ def bench(args):
             b = A_loc.mul(pa.HIPVector.from_numpy(xt, ctx))
             f = pa.LeastSquares(A_loc, b, comm=comm.view(r))
             sync.wait(timeout=300)
+            if args.solo:
+                from proximalalgorithms.jl_amd import _lib as _l
+
+                _l.call("pg_ctx_test_team_fault", ctx.handle, 1, 4)
             if r == 0 and not args.no_team:
                 pa.row_team_in_process(ctxs, max_wgs)
             sync.wait(timeout=300)
