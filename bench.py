@@ -74,7 +74,7 @@ WORKLOADS = {
     "small": (2048, 16384),  # quick functional check
 }
 # the sources the sweep kernels are built from: the PMC passes in profiles/pmc_traffic.json are tied to their hash
-KERNEL_SOURCES = ("pg_gemv_tn.h", "pg_gemv_tnt.h", "pg_cgmap.h", "pg_gemv.hip", "pg_gemv_tn2.hip", "pg_gemv_tn3.hip")
+KERNEL_SOURCES = ("pg_gemv_tn.h", "pg_gemv_tnt.h", "pg_cgmap.h", "pg_lanes.h", "pg_gemv.hip", "pg_gemv_tn2.hip", "pg_gemv_tn3.hip")
 
 
 def parse_args(argv=None):

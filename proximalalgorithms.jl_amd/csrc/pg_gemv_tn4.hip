@@ -163,6 +163,9 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   a.wait_stats = c->rteam.wait_stats;
   a.delay_ticks = c->test_team_delay_ticks;
   if (c->rteam.tune.SPIN > 0) a.spin_limit = c->rteam.tune.SPIN;
+#ifdef PG_TNT_EXPERIMENT
+  a.dbg = env_int("PG_TNT_DBG", 0);
+#endif
   c->rteam.sweeps++;
   // The tags make a slot self-describing only among launches of ONE ring layout (every launch rewrites every slot it polls, so
   // a granule of the same epoch 254 launches ago is long gone).  When the layout changes -- another matrix shape, another
@@ -322,7 +325,10 @@ pg_status launch_tn_peer(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
 #define PG_TNP_CASE_D(UU, CC, LL, PP, RR, WW) PG_TNP_CASE(UU, CC, LL, PP, RR, WW); PG_TNP_ONE(UU, CC, LL, PP, RR, WW, true, false)
   // ... with the poll one step ahead (LT = 4 geometries of several waves per column; A/B: PG_TNP_AHEAD)
 #define PG_TNP_CASE_A(UU, CC, LL, PP, RR, WW) PG_TNP_ONE(UU, CC, LL, PP, RR, WW, false, true); PG_TNP_ONE(UU, CC, LL, PP, RR, WW, true, true)
-  const bool ahead_w = ahead && W > 1 && LAG + LAGR >= 4 && ((U == 8 && C == 2 && W == 2) || (U == 16 && C == 1 && (W == 2 || W == 4))) && PF == 2;
+  // (measured, two ranks on one device: +1.5 % at 2 x 4096 rows, +1.3 % at 2 x 16384, where U = 16 spills four registers -- so only on request:
+  // pg_ctx_row_team_tune(ctx, "AHEAD", 1) or PG_TNP_AHEAD_W=1 under PG_TUNE; the one-wave sweep has it by default)
+  const bool ahead_w = (tn.AHEAD == 1 || env_int("PG_TNP_AHEAD_W", 0) != 0) && W > 1 && LAG + LAGR >= 4 &&
+                       ((U == 8 && C == 2 && W == 2) || (U == 16 && C == 1 && (W == 2 || W == 4))) && PF == 2;
   PG_TNP_CASE_A(8, 2, 2, 2, 2, 2); PG_TNP_CASE_A(16, 1, 2, 2, 2, 2); PG_TNP_CASE_A(16, 1, 2, 2, 2, 4);
   PG_TNP_GEOMETRIES;
 #undef PG_TNP_CASE

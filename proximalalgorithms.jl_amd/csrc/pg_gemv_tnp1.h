@@ -69,6 +69,11 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
   constexpr int GL = 64 / C;             // lanes that hold the same column after the column-parallel reduction
   constexpr int RING = PEER_RING;
   constexpr int LT = LAG + LAGR;
+#ifdef PG_TNP1_LOADS_AFTER_DOTS
+  constexpr bool LOADS_FIRST = false;  // (experiment, not kept: 6.15 TB/s against 6.44 with the loads first -- an early issue is worth more than counter headroom)
+#else
+  constexpr bool LOADS_FIRST = true;
+#endif
   static_assert(LT > 0 && 2 * LT + 2 <= RING, "the totals of a step are consumed LT > 0 steps later; the ring holds 2 LT + 2 steps");
   static_assert(MS <= 8 && (C & (C - 1)) == 0 && C >= 1, "C a power of two, at most eight granules per member and ring slot");
   extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
@@ -105,13 +110,6 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
   unsigned late_steps = 0, late_polls = 0;
   unsigned long long age_sum = 0;
   unsigned age_cnt = 0;
-  // the epilogue's lanes: lane c * G works on column c of the step (the other lanes compute along on a clamped column, store nothing)
-  const int c_lane = min(lane / G, C - 1);
-  const bool ep_lane = lane < S && (lane % G) == 0;
-  // per-element parameters of g: always two loads (a branch around a load inside the steady loop makes the compiler wait for ALL
-  // loads in flight, pg_gemv_tnt.h); without them the loads read x, and nothing uses what they return
-  const T* const pv0 = a.p0v != nullptr ? a.p0v : a.x;
-  const T* const pv1 = a.p1v != nullptr ? a.p1v : a.x;
   const bool has_pv = a.p0v != nullptr;
 
   // where this lane posts: lane q * MS + s2 (q < TM, s2 < MS) writes granule s2 of this device's step (PAIR: of its two steps, the even
@@ -167,7 +165,9 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     }
     cr_stage<T, C, 0>(d, lane);  // d[0] = the total of column lane / GL, in every lane of that group
     // ONE store for all inboxes: lane q * S + s carries granule s (half s % G of column s / G) to member q
-    T mine = d[0];
+    // (every posting lane takes its column's total from that column's lane group -- its own d[0] is the total of column lane / GL,
+    // which is the column it carries only while all posting lanes sit in group 0)
+    T mine = pg_readlane(d[0], 0);
 #pragma unroll
     for (int c = 1; c < C; ++c) {
       const T tc = pg_readlane(d[0], c * GL);
@@ -190,6 +190,17 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
       if (lane >= npoll) bits = (unsigned)__builtin_amdgcn_s_memrealtime();  // the stamp granules: behind the TM members' values, one per member
     }
     const unsigned long long word = ((unsigned long long)tag_of(i) << 32) | bits;
+#ifdef PG_TNT_EXPERIMENT
+    if (a.dbg & (8 | 256)) return;  // timing experiment: no post
+    if (a.dbg & 64) {  // timing experiment (solo): a FULL 64-byte line per post instead of 8 * MS bytes
+      if (lane < 8) __hip_atomic_store(a.peer_ring[0] + ring_off + slot_of(i) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    if (a.dbg & 128) {  // timing experiment: the post as a plain (cached, write-back) store
+      if (lane < npoll_all) post_ptr[slot_of(i)] = word;
+      return;
+    }
+#endif
     if (lane < npoll_all)
       __hip_atomic_store(post_ptr + slot_of(i), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
@@ -204,20 +215,42 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     return __builtin_amdgcn_ballot_w64(ok) == ~0ull;
   };
   auto poll_word = [&](int64_t i) __attribute__((always_inline)) -> unsigned long long {
+#ifdef PG_TNT_EXPERIMENT
+    if (a.dbg & (8 | 512)) return 0ull;  // timing experiment: no poll
+#endif
     return __hip_atomic_load(ring + slot_of(i) + poll_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
-  // the small loads of step i's epilogue, issued with the poll (before the tile loads: they return first)
+  // Whole lines of the output vectors.  A wave works through CHUNKS of line_cols = 32 consecutive columns (CgMap: K = 32 / C steps in
+  // a row, then a jump); its epilogue of step k of a chunk runs in lanes k * C + c, which have loaded x, z_old (and the per-element
+  // parameters) of THEIR column of the chunk, and what it produces (g, y, z, res, v) is collected lane by lane until the chunk's
+  // last step writes five full 128-byte lines with 32 lanes -- round 6's first form stored five 8-byte pieces per step, eighty
+  // partial writes per chunk, and took its scalar reductions (double precision) every step instead of once per chunk:
+  // 5 % of the sweep (profiles/r6_peer_sweep_counters.md).  The steps behind the chunked part of a unit's work (CgMap's tail: single groups)
+  // are chunks of one step.
+  const int KC = 1 << map.shift;  // steps per chunk
+  auto chunk_pos = [&](int64_t i) __attribute__((always_inline)) -> int { return i < (int64_t)map.head ? (int)(i & (int64_t)(KC - 1)) : 0; };
+  auto chunk_cols = [&](int64_t i) __attribute__((always_inline)) -> int { return i < (int64_t)map.head ? KC * C : C; };
+  T out_g = T(0), out_y = T(0), out_z = T(0), out_r = T(0), out_v = T(0);
+  // the small loads of step i's epilogue, issued with the poll (before the tile loads: they return first): lane l asks for x and z_old of
+  // column l of step i's chunk -- every step of the chunk asks for the same addresses again (cache hits; no state to carry and NO
+  // BRANCH: a load behind a branch inside the steady loop makes the compiler give up counting the loads in flight -- tried here
+  // as "once per chunk": its waits fell from vmcnt(34..51) to vmcnt(17), one tile in flight instead of two)
   auto fetch = [&](Pend& pd, int64_t i) __attribute__((always_inline)) {
-    const int64_t j = map.at(i) * C + c_lane;
+#ifdef PG_TNT_EXPERIMENT
+    if (a.dbg & 32) return;  // timing experiment: no small loads
+#endif
+    const int k = chunk_pos(i);
+    const int64_t j = map.at(i - k) * C + min(lane, chunk_cols(i) - 1);
     const int64_t jc = j < a.n ? j : a.n - 1;
     pd.xs = a.x[jc];
     pd.zos = a.z_old[jc];
-    pd.q0 = pv0[jc];
-    pd.q1 = pv1[jc];
   };
   // totals of step i (all members have posted, or will shortly) -> epilogue -> v_j (0 for columns past the end)
   auto totals = [&](int64_t i, Pend& pd, T (&vj)[C]) __attribute__((always_inline)) {
     const unsigned tag = tag_of(i);
+#ifdef PG_TNT_EXPERIMENT
+    if (a.dbg & 1) dead = true;  // timing experiment: never wait (totals are then wrong)
+#endif
     // The first look at the granules stays OUTSIDE the retry loop (pg_gemv_tnt.h).
     if (!dead && !arrived(pd.w, tag)) {
       long long spins = 0;
@@ -254,13 +287,31 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
       const T up = row_from_above<S>(val);
       val = (i & 1) != 0 ? up : val;
     }
-    T g = val;
-    row_member_sum<MS, 1>(g, val);          // the members of this lane's row, ascending
-    if (npoll > 16) g = swap16_add(g, g);   // (wave-uniform) rows 0 + 1, 2 + 3
-    if (npoll > 32) g = swap32_add(g, g);   // (rows 0 + 1) + (rows 2 + 3): the same order on every device
-    const int64_t j = map.at(i) * C + c_lane;
-    const bool valid = j < a.n;
+    T gs = val;
+    row_member_sum<MS, 1>(gs, val);           // the members of this lane's row, ascending
+    if (npoll > 16) gs = swap16_add(gs, gs);  // (wave-uniform) rows 0 + 1, 2 + 3
+    if (npoll > 32) gs = swap32_add(gs, gs);  // (rows 0 + 1) + (rows 2 + 3): the same order on every device
+    // lane c * G (c < C) of row 0 holds column c's total: hand it to every lane whose column of the chunk is column c of a step
+    T g = pg_readlane(gs, 0);
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+      const T tc = pg_readlane(gs, c * G);
+      if (lane % C == c) g = tc;
+    }
+    const int k = chunk_pos(i), ncols = chunk_cols(i);
+    const int64_t j = map.at(i - k) * C + min(lane, ncols - 1);
+    const bool valid = lane < ncols && j < a.n;
+    const bool mine_now = lane / C == k;  // this lane's column is one of THIS step's
     if (a.lam_ls != T(1)) g = a.lam_ls * g;
+    // per-element parameters of g: loaded HERE, late and behind a (wave-uniform) branch -- a wave may have at most 63 vector-memory
+    // operations in flight (the counter has six bits), and with three 16-load tiles under way every small load issued ahead with
+    // the poll is one the next tile's loads wait for at ISSUE; the weighted / per-element-bound forms pay with a wait for
+    // everything in flight instead (they are the rare case)
+    if (has_pv) {
+      const int64_t jq = j < a.n ? j : a.n - 1;
+      pd.q0 = a.p0v[jq];
+      if (a.p1v != nullptr) pd.q1 = a.p1v[jq];
+    }
     const T xj = pd.xs, zo = pd.zos;
     const T yj = xj - a.gamma * g;  // forward_backward.jl:117 / fast_forward_backward.jl:140
     T zj;                            // :118 / :141
@@ -274,19 +325,26 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
       zj = yj;
     const T rj = xj - zj;                                                   // :120 / :142
     const T vl = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);  // fast_forward_backward.jl:135 of the next iteration
-    if (ep_lane && valid) {
-      a.g_out[j] = g;
-      a.y[j] = yj;
-      a.z_new[j] = zj;
-      a.res[j] = rj;
-      if (a.v_out != nullptr) a.v_out[j] = vl;
-      if (a.g_kind == PG_G_NORML1) acc[0] += has_pv ? (double)pd.q0 * fabs((double)zj) : fabs((double)zj);
-      acc[1] = fmax(acc[1], fabs((double)rj));
-      acc[2] += (double)g * (double)rj;
-      acc[3] += (double)rj * (double)rj;
+    out_g = mine_now ? g : out_g, out_y = mine_now ? yj : out_y, out_z = mine_now ? zj : out_z, out_r = mine_now ? rj : out_r,
+    out_v = mine_now ? vl : out_v;
+#ifdef PG_TNT_EXPERIMENT
+    if (!(a.dbg & 16))  // timing experiment: no output stores
+#endif
+    if (k == ncols / C - 1) {  // the chunk's last step: whole lines
+      if (valid) {
+        a.g_out[j] = out_g;
+        a.y[j] = out_y;
+        a.z_new[j] = out_z;
+        a.res[j] = out_r;
+        if (a.v_out != nullptr) a.v_out[j] = out_v;
+        if (a.g_kind == PG_G_NORML1) acc[0] += has_pv ? (double)pd.q0 * fabs((double)out_z) : fabs((double)out_z);
+        acc[1] = fmax(acc[1], fabs((double)out_r));
+        acc[2] += (double)out_g * (double)out_r;
+        acc[3] += (double)out_r * (double)out_r;
+      }
     }
 #pragma unroll
-    for (int c = 0; c < C; ++c) vj[c] = pg_readlane(vl, c * G);
+    for (int c = 0; c < C; ++c) vj[c] = pg_readlane(vl, k * C + c);
   };
   auto park_slot = [&](int64_t i) { return park + (size_t)(LAG > 0 ? i % (LAG > 0 ? LAG : 1) : 0) * (C * U * WAVE) + lane; };
 
@@ -310,9 +368,18 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     }
     // (the small loads first, pinned: loads return in issue order, and behind the tile's sixteen the epilogue would wait for them too)
     __builtin_amdgcn_sched_barrier(0);
-    if (ALL || i + PF < cnt) load(nxt, i + PF);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LOADS_FIRST) {
+      if (ALL || i + PF < cnt) load(nxt, i + PF);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (ALL || i < cnt) dot_post(cur, i);
+    if constexpr (!LOADS_FIRST) {
+      // (experiment: the next tile's loads AFTER the dots, when tile i has retired from the 63 vector-memory operations a wave may
+      // have in flight)
+      __builtin_amdgcn_sched_barrier(0);
+      if (ALL || i + PF < cnt) load(nxt, i + PF);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (has_fma) {
       T vj[C];
       totals(i - LT, pd, vj);
@@ -325,6 +392,17 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
             for (int e = 0; e < VEC; ++e) racc[u][e] = fma(old.col[c][u][e], vj[c], racc[u][e]);
           }
         }
+#ifdef PG_TNT_EXPERIMENT
+      } else if (a.dbg & 2) {  // timing experiment: no LDS read-back (wrong tile)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) racc[u][e] = fma(cur.col[c][u][e], vj[c], racc[u][e]);
+          }
+        }
+#endif
       } else {
         // Four 16-byte reads at a time, their order pinned (pg_gemv_tnt.h: left alone the compiler issues all C * U reads up
         // front and spills the tile that is in flight).
@@ -354,6 +432,9 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(racc[u]));
     if constexpr (LAG > 0) {
+#ifdef PG_TNT_EXPERIMENT
+      if (!(a.dbg & 4))  // timing experiment: no parking
+#endif
       if (ALL || (i >= LAGR && i - LAGR < cnt)) {
         V* __restrict__ dst = park_slot(i - LAGR);
 #pragma unroll

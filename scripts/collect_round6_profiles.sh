@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6's measurements on a GPU box (run through gpurun): outputs under gpurun_out/r6/, summaries are copied into profiles/r6_* by hand
 # or by scripts/publish_round6_profiles.sh.  PMC passes are separate runs with --kernel-trace only, the program directly after `--`.
-# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench newtests fuzzopt suite
+# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench pmc newtests fuzzopt fuzzteam suite
 cd "$GRAFT_REPO_ROOT" || exit 1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r6; mkdir -p $O
@@ -58,22 +58,59 @@ if want counters; then
   for k in k1 k1_own_step r5 tnw; do echo "== $k"; grep -h "gemv_tn" $O/c_${k}_stats.md | head -3 | cut -c1-200; done
 fi
 if want latency; then
+  # the latency curve (geometry = C:LAG:LAGR:PF:WGS:W:K1:PAIR:AHEAD): round 5's kernel | round 6's one-wave sweep (default: poll one step ahead) | with
+  # the poll in its own step | one post per two steps; the longer blocks' defaults (several waves per column: wave_allsum without LDS)
   D=off,0,2000,4000,6000,8000,12000,16000
-  timeout 600 python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --two-sweeps --repeat 2 --delays $D --geoms 2:2:2:2:4:1:0,default > $O/sweep_2048.jsonl 2> $O/sweep_2048.err
+  timeout 900 python tests/tools/row_team_sweep.py --m 4096 --n 1048576 --two-sweeps --repeat 2 --delays $D --geoms 2:2:2:2:4:1:0,default,2:2:2:2:4:1:1:0:0,2:2:2:2:4:1:1:1:1 > $O/sweep_2048.jsonl 2> $O/sweep_2048.err
   timeout 600 python tests/tools/row_team_sweep.py --m 8192 --n 524288 --two-sweeps --repeat 2 --delays $D --geoms default > $O/sweep_4096.jsonl 2> $O/sweep_4096.err
   timeout 600 python tests/tools/row_team_sweep.py --m 32768 --n 131072 --two-sweeps --repeat 2 --delays $D --geoms default > $O/sweep_16384.jsonl 2> $O/sweep_16384.err
   timeout 600 python tests/tools/row_team_sweep.py --m 16384 --n 262144 --ranks 4 --repeat 1 --delays off,0,4000,8000 --geoms default > $O/sweep_4x4096.jsonl 2> $O/sweep_4x4096.err
-  timeout 600 python tests/tools/row_team_sweep.py --m 16384 --n 131072 --ranks 8 --repeat 1 --delays off,0,4000,8000 --geoms default > $O/sweep_8x2048.jsonl 2> $O/sweep_8x2048.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 16384 --n 262144 --ranks 8 --repeat 1 --delays off,0,4000,8000 --geoms default,2:2:2:2:4:1:1:1:1 > $O/sweep_8x2048.jsonl 2> $O/sweep_8x2048.err
+  timeout 600 python tests/tools/row_team_sweep.py --m 2048 --n 1048576 --dtype f64 --repeat 1 --delays off,0,4000,8000,12000 --geoms 2:2:2:2:4:1:0,default > $O/sweep_f64_1024.jsonl 2> $O/sweep_f64_1024.err
 fi
 if want bench; then
-  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 1500 $O/bench_default.json
+  B="--no-cpu-baseline --no-also"
+  # the driver's command: headline + also[] + CPU leg; then the kernel stats of the same command and of the headline alone
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 1200 $O/bench_default.json
+  rocprofv3 --kernel-trace --stats -d $O/prof_default -- python3 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --sustain 0 > $O/prof_default.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/prof_headline -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --sustain 0 $B > $O/prof_headline.log 2>&1
+  for d in prof_default prof_headline; do python scripts/rocpd_summary.py $O/$d/*/*_results.db > $O/$d.md 2>&1; rm -rf $O/$d; done
+  # north_star's layout as the driver's N > 1 command runs it, two rank processes on this one device (gloo): rows on top, upgraded to the row team
   python bench.py --gpus 2 --share-device --backend gloo --m 4096 --n 1048576 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_rows_2048.json 2> $O/bench_2rank_rows_2048.err
+  python bench.py --gpus 2 --share-device --backend gloo --m 32768 --n 131072 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_2rank_rows_16384.json 2> $O/bench_2rank_rows_16384.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_row_team -- python3 tests/tools/row_team.py --bench --m 4096 --n 1048576 --steps 20 --max-wgs -2 > $O/prof_row_team.log 2>&1
+  python scripts/rocpd_summary.py $O/prof_row_team/*/*_results.db > $O/prof_row_team.md 2>&1; rm -rf $O/prof_row_team
+  for mn in "2048 1048576 short_2048" "4096 1048576 short_4096" "131072 131072 long_131072"; do
+    set -- $mn; python bench.py --m $1 --n $2 --steps 30 --warmup 5 $B > $O/bench_$3.json 2>/dev/null
+  done
+  python bench.py --workload config2 --steps 50 --warmup 5 $B > $O/bench_config2.json 2>/dev/null
+fi
+if want pmc; then
+  # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the four sweep families at the shapes the bench line names: the sources of
+  # these kernels changed in round 6 (wave_allsum without LDS), so profiles/pmc_traffic.json is re-taken on them
+  B="--no-cpu-baseline --no-also"
+  pmc() { key=$1; tkey=$2; shift 2
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_${key}_fetch -- python3 bench.py "$@" --steps 10 --warmup 2 --sustain 0 $B > $O/prof_${key}_fetch.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_${key}_write -- python3 bench.py "$@" --steps 10 --warmup 2 --sustain 0 $B > $O/prof_${key}_write.log 2>&1
+    python scripts/rocpd_summary.py --match gemv_tn $O/prof_${key}_fetch/*/*_results.db $O/prof_${key}_write/*/*_results.db > $O/prof_${key}_pmc.md 2>&1
+    python scripts/pmc_to_traffic.py $tkey $O/prof_${key}_fetch/*/*_results.db $O/prof_${key}_write/*/*_results.db profiles/r6_sweeps_pmc_fetch_write.md $O/pmc_traffic.json > /dev/null
+    rm -rf $O/prof_${key}_fetch $O/prof_${key}_write; }
+  pmc headline headline
+  pmc config2 config2 --workload config2
+  pmc long long_columns --m 131072 --n 131072
+  pmc short short_columns --m 2048 --n 1048576
+  python3 -c "
+import json; d=json.load(open('$O/pmc_traffic.json'))
+for k,v in d.items(): print(k, v['kernel_source_sha256'][:12], {n: round(r['hbm_bytes']/1e9,3) for n,r in v['kernels'].items()})"
 fi
 if want newtests; then
   timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "gamma_too_small or fuzz_differential or lbfgs or blas1 or prox_operators" > $O/pytest_new.log 2>&1; echo "rc $?" >> $O/pytest_new.log; tail -15 $O/pytest_new.log
 fi
 if want fuzzopt; then
-  timeout 1500 python tests/tools/fuzz_parity.py ${FUZZ_CASES:-400} 20000 options > $O/fuzz_options.log 2>&1; tail -12 $O/fuzz_options.log | cut -c1-600
+  timeout 2400 python tests/tools/fuzz_parity.py ${FUZZ_CASES:-2000} 20000 options > $O/fuzz_options.log 2>&1; tail -12 $O/fuzz_options.log | cut -c1-600
+fi
+if want fuzzteam; then
+  timeout 1500 python tests/tools/fuzz_row_team.py 150 9000 > $O/fuzz_row_team.log 2>&1; tail -5 $O/fuzz_row_team.log | cut -c1-400
 fi
 if want suite; then
   timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 > $O/gpu_suite.log 2>&1; echo "rc $?" >> $O/gpu_suite.log; tail -40 $O/gpu_suite.log
