@@ -1427,6 +1427,9 @@ def run_rank(args, job, wd, world, rank, local_rank):
     P = setup_lasso(pa, ctx, D, m_glob, n, dtype, args.seed, layout, args.mode, row_teams=args.row_teams)
     job.main_rec = run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
                            workload_name=named, scaling=args.scaling, sustain=args.sustain)
+    if P.get("row_teams") and args.mode == "fixed":  # (`--row-teams` in the job's own process group: the same two-geometry rule as the child's)
+        job.main_rec = row_team_second_geometry(job.main_rec, lambda: run_ffb(pa, ctx, D, P, args.mode, args.sweeps, args.steps, args.warmup, args.kernel_events,
+                                                                               workload_name=named, scaling=args.scaling, sustain=args.sustain), pa, ctx, D, world)
     job.main_rec["wall_s"] = round(time.perf_counter() - t_rec, 2)
     wd.main_done = True
     extra = job.extra
@@ -1696,6 +1699,35 @@ def late_fraction(stats, geom, n):
     return round(stats.get("late_waves", 0) / max(wave_steps, 1), 5)
 
 
+def row_team_second_geometry(first, rerun, pa, ctx, D, world):
+    """AT MOST two geometries for a row-team record, the second only when the first one's granules came late (more than LATE_THRESHOLD
+    of its wave-steps): one post per two steps -- half the fabric transactions, pg_ctx_row_team_tune "PAIR" -- where the sweep has
+    that form (the one-wave sweep, K1=1).  The ranks decide together (the largest late fraction of any rank; the faster record by
+    rank 0's clock).  Returns the record to keep; `config.row_team_geometries_tried` says what both did."""
+    import torch.distributed as dist
+
+    late = (first["config"].get("row_team_stats") or {}).get("late_fraction") or 0.0
+    late = D.reduce_scalar(float(late), dist.ReduceOp.MAX) if world > 1 else late
+    threshold = float(os.environ.get("PG_BENCH_LATE_THRESHOLD", LATE_THRESHOLD))  # (tests force the second try with -1)
+    geom = str(first["config"].get("row_team_geometry"))
+    if not (late > threshold and "K1=1" in geom and "PAIR=1" not in geom):
+        return first
+    pa.row_team_tune(ctx, PAIR=1)
+    try:
+        second = rerun()
+    finally:
+        pa.row_team_tune(ctx, PAIR=2)  # (back to one post per step for whatever follows)
+    late2 = (second["config"].get("row_team_stats") or {}).get("late_fraction") or 0.0
+    late2 = D.reduce_scalar(float(late2), dist.ReduceOp.MAX) if world > 1 else late2
+    faster = second["value"] > first["value"]
+    if world > 1:
+        faster = D.reduce_scalar(1.0 if faster else 0.0, dist.ReduceOp.MIN) > 0.5
+    keep = second if faster else first
+    keep["config"]["row_team_geometries_tried"] = ("one post per step: %.4g it/s, %.2f %% of the wave-steps late; one post per two steps: %.4g it/s, %.2f %% late"
+                                                  % (first["value"], 100.0 * late, second["value"], 100.0 * late2))
+    return keep
+
+
 def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
     """`--row-teams-child`: the two row-team records (north_star's row layout at ONE read of A per iteration: the ranks push
     per-column partial dots into each other's IPC-mapped inbox inside the sweep, csrc/pg_gemv_tn4.hip) in a process group of
@@ -1717,25 +1749,8 @@ def row_team_child(args, job, wd, pa, ctx, D, world, rank, m_base, n, dtype):
             records[key] = run_ffb(pa, ctx, D, P2, "fixed", "one", args.steps if top else sub_steps, args.warmup if top else 3,
                                    args.kernel_events, scaling=scaling)
             if top:
-                # AT MOST two geometries, the second only when the first one's granules came late: one post per two steps (half the
-                # fabric transactions, pg_ctx_row_team_tune "PAIR").  The ranks decide together (the largest late fraction of any).
-                late = (records[key]["config"].get("row_team_stats") or {}).get("late_fraction") or 0.0
-                late = D.reduce_scalar(float(late), dist.ReduceOp.MAX) if world > 1 else late
-                threshold = float(os.environ.get("PG_BENCH_LATE_THRESHOLD", LATE_THRESHOLD))  # (tests force the second try with -1)
-                first = records[key]
-                if late > threshold and "PAIR=1" not in str(first["config"].get("row_team_geometry")):
-                    pa.row_team_tune(ctx, PAIR=1)
-                    try:
-                        second = run_ffb(pa, ctx, D, P2, "fixed", "one", args.steps, args.warmup, args.kernel_events, scaling=scaling)
-                    finally:
-                        pa.row_team_tune(ctx, PAIR=2)  # (back to one post per step for the record that follows)
-                    late2 = (second["config"].get("row_team_stats") or {}).get("late_fraction") or 0.0
-                    late2 = D.reduce_scalar(float(late2), dist.ReduceOp.MAX) if world > 1 else late2
-                    tried = "one post per step: %.4g it/s, %.2f %% of the wave-steps late; one post per two steps: %.4g it/s, %.2f %% late" % (
-                        first["value"], 100.0 * late, second["value"], 100.0 * late2)
-                    keep_second = D.reduce_scalar(1.0 if second["value"] > first["value"] else 0.0, dist.ReduceOp.MIN) > 0.5 if world > 1 else second["value"] > first["value"]
-                    records[key] = second if keep_second else first
-                    records[key]["config"]["row_team_geometries_tried"] = tried
+                records[key] = row_team_second_geometry(records[key], lambda: run_ffb(pa, ctx, D, P2, "fixed", "one", args.steps, args.warmup, args.kernel_events,
+                                                                                       scaling=scaling), pa, ctx, D, world)
             del P2
         except Exception as e:  # noqa: BLE001 -- reported in the record; the ranks may be out of step now, so the other one is skipped
             traceback.print_exc()

@@ -606,7 +606,7 @@ __device__ __forceinline__ void col_unpack(const T* __restrict__ slots, int nran
   for (int p = 0; p < nranks; ++p) {
     const T* q = slots + COL_SLOTS * p;
     gz += (double)q[0] + (double)q[1];
-    ri = fmax(ri, (double)q[2] + (double)q[3]);
+    ri = pg_maxn(ri, (double)q[2] + (double)q[3]);
     dg += (double)q[4] + (double)q[5];
     rs += (double)q[6] + (double)q[7];
   }

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnm_trio_kernel(TNArgs<T> a, 
       rb[j] = rj;
       double* ac = &sm_acc[lane][0];
       if (a.g_kind == PG_G_NORML1) ac[0] += a.p0v != nullptr ? (double)a.p0v[j] * fabs((double)zj) : fabs((double)zj);
-      ac[1] = fmax(ac[1], fabs((double)rj));
+      ac[1] = pg_maxn(ac[1], fabs((double)rj));
       ac[2] += (double)g * (double)rj;
       ac[3] += (double)rj * (double)rj;
     }

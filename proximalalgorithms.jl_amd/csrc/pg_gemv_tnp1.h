@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
         a.res[j] = out_r;
         if (a.v_out != nullptr) a.v_out[j] = out_v;
         if (a.g_kind == PG_G_NORML1) acc[0] += has_pv ? (double)pd.q0 * fabs((double)out_z) : fabs((double)out_z);
-        acc[1] = fmax(acc[1], fabs((double)out_r));
+        acc[1] = pg_maxn(acc[1], fabs((double)out_r));
         acc[2] += (double)out_g * (double)out_r;
         acc[3] += (double)out_r * (double)out_r;
       }

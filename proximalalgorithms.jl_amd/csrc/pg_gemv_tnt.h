@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_tnt_kernel(TNArgs<T> a) {
         a.res[j] = rj;
         if (a.v_out != nullptr) a.v_out[j] = vj[c];
         if (a.g_kind == PG_G_NORML1) acc[0] += a.p0v != nullptr ? (double)a.p0v[j] * fabs((double)zj) : fabs((double)zj);
-        acc[1] = fmax(acc[1], fabs((double)rj));
+        acc[1] = pg_maxn(acc[1], fabs((double)rj));
         acc[2] += (double)g * (double)rj;
         acc[3] += (double)rj * (double)rj;
       }

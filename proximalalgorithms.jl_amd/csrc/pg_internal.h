@@ -299,6 +299,11 @@ struct VecOf<double> {
   static constexpr int N = 2;
 };
 
+// max that PROPAGATES NaN, like Julia's `max` and therefore `norm(x, Inf)` (forward_backward.jl:126, fast_forward_backward.jl:151: the
+// stopping rule): fmax drops a NaN operand, and an iteration that has diverged to NaN then shows norm(res, Inf) = 0 and "converges"
+// (found by the option-drawing fuzzer of round 6: minimum_gamma above the stable step).  Every max REDUCTION uses this one.
+__host__ __device__ __forceinline__ double pg_maxn(double a, double b) { return (a != a || b != b) ? (a + b) : fmax(a, b); }
+__host__ __device__ __forceinline__ float pg_maxn(float a, float b) { return (a != a || b != b) ? (a + b) : fmaxf(a, b); }
 __device__ __forceinline__ double pg_shfl_down(double v, int off) { return __shfl_down(v, off, 64); }
 __device__ __forceinline__ float pg_shfl_down(float v, int off) { return __shfl_down(v, off, 64); }
 __device__ __forceinline__ double pg_shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
@@ -341,13 +346,13 @@ __device__ __forceinline__ double pg_readlane(double v, int lane) {
 template <bool MAX, typename T>
 __device__ __forceinline__ T pg_row_allreduce(T v) {
   T o = pg_dpp_mov<0xB1>(v);
-  v = MAX ? fmax(v, o) : (v + o);
+  v = MAX ? pg_maxn(v, o) : (v + o);
   o = pg_dpp_mov<0x4E>(v);
-  v = MAX ? fmax(v, o) : (v + o);
+  v = MAX ? pg_maxn(v, o) : (v + o);
   o = pg_dpp_mov<0x141>(v);
-  v = MAX ? fmax(v, o) : (v + o);
+  v = MAX ? pg_maxn(v, o) : (v + o);
   o = pg_dpp_mov<0x140>(v);
-  v = MAX ? fmax(v, o) : (v + o);
+  v = MAX ? pg_maxn(v, o) : (v + o);
   return v;
 }
 // whole-wave reduction, result (wave-uniform) in every lane: row reductions, then the four row totals travel through
@@ -356,8 +361,8 @@ template <bool MAX, typename T>
 __device__ __forceinline__ T pg_wave_allreduce(T v) {
   v = pg_row_allreduce<MAX, T>(v);
   const T r0 = pg_readlane(v, 0), r1 = pg_readlane(v, 16), r2 = pg_readlane(v, 32), r3 = pg_readlane(v, 48);
-  const T a = MAX ? fmax(r0, r1) : (r0 + r1), b = MAX ? fmax(r2, r3) : (r2 + r3);
-  return MAX ? fmax(a, b) : (a + b);
+  const T a = MAX ? pg_maxn(r0, r1) : (r0 + r1), b = MAX ? pg_maxn(r2, r3) : (r2 + r3);
+  return MAX ? pg_maxn(a, b) : (a + b);
 }
 
 // Deterministic grid-wide reduction of NS doubles per thread (bit k of MAXMASK: slot k is a max, else a
@@ -384,7 +389,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
         double o = pg_shfl_down(v[k], off);
-        v[k] = pg_red_is_max(MAXMASK, k) ? fmax(v[k], o) : (v[k] + o);
+        v[k] = pg_red_is_max(MAXMASK, k) ? pg_maxn(v[k], o) : (v[k] + o);
       }
     }
   }
@@ -401,7 +406,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double a = sm[k];
-      for (int w = 1; w < NW; ++w) a = pg_red_is_max(MAXMASK, k) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      for (int w = 1; w < NW; ++w) a = pg_red_is_max(MAXMASK, k) ? pg_maxn(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
       __hip_atomic_store(&partials[(size_t)blockIdx.x * NS + k], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -417,7 +422,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double p = __hip_atomic_load(&partials[(size_t)b * NS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      acc[k] = pg_red_is_max(MAXMASK, k) ? fmax(acc[k], p) : (acc[k] + p);
+      acc[k] = pg_red_is_max(MAXMASK, k) ? pg_maxn(acc[k], p) : (acc[k] + p);
     }
   }
 #pragma unroll
@@ -425,7 +430,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       double o = pg_shfl_down(acc[k], off);
-      acc[k] = pg_red_is_max(MAXMASK, k) ? fmax(acc[k], o) : (acc[k] + o);
+      acc[k] = pg_red_is_max(MAXMASK, k) ? pg_maxn(acc[k], o) : (acc[k] + o);
     }
   }
   __syncthreads();  // sm reuse
@@ -438,7 +443,7 @@ __device__ __forceinline__ bool grid_reduce_finalize(double (&v)[NS], double* __
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double a = sm[k];
-      for (int w = 1; w < NW; ++w) a = pg_red_is_max(MAXMASK, k) ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+      for (int w = 1; w < NW; ++w) a = pg_red_is_max(MAXMASK, k) ? pg_maxn(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
       out[k] = a * post_scale[k];
       if (final_vals != nullptr) final_vals[k] = a * post_scale[k];  // valid on thread 0 of the finalizing block
     }
@@ -469,7 +474,7 @@ __device__ __forceinline__ bool grid_reduce_finalize_streamed(WaveVal wave_val, 
   for (int k = threadIdx.x; k < NS; k += NW * 64) {  // one slot per thread: publish this workgroup's partial
     const bool is_max = pg_red_is_max(MAXMASK, k);
     double a = sm[k];
-    for (int w = 1; w < NW; ++w) a = is_max ? fmax(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
+    for (int w = 1; w < NW; ++w) a = is_max ? pg_maxn(a, sm[w * NS + k]) : (a + sm[w * NS + k]);
     __hip_atomic_store(&partials[(size_t)blockIdx.x * NS + k], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -489,7 +494,7 @@ __device__ __forceinline__ bool grid_reduce_finalize_streamed(WaveVal wave_val, 
       for (int q = 0; q < CH; ++q) {
         if (k0 + q < NS) {
           const double p = __hip_atomic_load(&partials[(size_t)b * NS + k0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[q] = pg_red_is_max(MAXMASK, k0 + q) ? fmax(acc[q], p) : (acc[q] + p);
+          acc[q] = pg_red_is_max(MAXMASK, k0 + q) ? pg_maxn(acc[q], p) : (acc[q] + p);
         }
       }
     }
@@ -498,7 +503,7 @@ __device__ __forceinline__ bool grid_reduce_finalize_streamed(WaveVal wave_val, 
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
         const double o = pg_shfl_down(acc[q], off);
-        acc[q] = pg_red_is_max(MAXMASK, k0 + q) ? fmax(acc[q], o) : (acc[q] + o);
+        acc[q] = pg_red_is_max(MAXMASK, k0 + q) ? pg_maxn(acc[q], o) : (acc[q] + o);
       }
     }
     __syncthreads();  // sm reuse
@@ -511,7 +516,7 @@ __device__ __forceinline__ bool grid_reduce_finalize_streamed(WaveVal wave_val, 
       const int k = k0 + threadIdx.x;
       const bool is_max = pg_red_is_max(MAXMASK, k);
       double a = sm[threadIdx.x];
-      for (int w = 1; w < NW; ++w) a = is_max ? fmax(a, sm[w * CH + threadIdx.x]) : (a + sm[w * CH + threadIdx.x]);
+      for (int w = 1; w < NW; ++w) a = is_max ? pg_maxn(a, sm[w * CH + threadIdx.x]) : (a + sm[w * CH + threadIdx.x]);
       out[k] = k == NS - 1 ? a * scale_last : a;
     }
   }

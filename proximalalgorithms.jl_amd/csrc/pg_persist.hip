@@ -102,7 +102,7 @@ __device__ __forceinline__ void small_epilogue_elem(const SmallParams<T>& p, T x
     zv = yv;
   rv = xv - zv;
   if (p.g_kind == PG_G_NORML1) acc[0] += fabs((double)zv);
-  acc[1] = fmax(acc[1], fabs((double)rv));
+  acc[1] = pg_maxn(acc[1], fabs((double)rv));
   acc[2] += (double)gv * (double)rv;
   acc[3] += (double)rv * (double)rv;
 }
@@ -380,7 +380,7 @@ struct CoopOps {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const double o = ld_ag(slot + (size_t)w * 4 + k);
-        v[k] = ((MAXMASK >> k) & 1u) ? fmax(v[k], o) : (v[k] + o);
+        v[k] = ((MAXMASK >> k) & 1u) ? pg_maxn(v[k], o) : (v[k] + o);
       }
     }
     PG_MARK(*this, 20);

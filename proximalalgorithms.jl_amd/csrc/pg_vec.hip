@@ -91,7 +91,7 @@ struct NrmInfF {  // acc[0] = max |x|
   __device__ __forceinline__ void apply(int64_t i, double* acc) const {
     Pack<T, N> xv = ld<T, N>(x, i);
 #pragma unroll
-    for (int e = 0; e < N; ++e) acc[0] = fmax(acc[0], fabs((double)xv.v[e]));
+    for (int e = 0; e < N; ++e) acc[0] = pg_maxn(acc[0], fabs((double)xv.v[e]));
   }
   __device__ double post_scale(int) const { return 1.0; }
 };
@@ -229,7 +229,7 @@ struct EpilogueF {
       rv.v[e] = xv.v[e] - zv.v[e];
       if constexpr (GKIND == PG_G_NORML1)
         acc[0] += p0v != nullptr ? (double)lov.v[e] * fabs((double)zv.v[e]) : fabs((double)zv.v[e]);
-      acc[1] = fmax(acc[1], fabs((double)rv.v[e]));
+      acc[1] = pg_maxn(acc[1], fabs((double)rv.v[e]));
       acc[2] += (double)gv.v[e] * (double)rv.v[e];
       acc[3] += (double)rv.v[e] * (double)rv.v[e];
     }
@@ -346,7 +346,7 @@ struct DRStepF {
         zv.v[e] = rv.v[e];
       sv.v[e] = yv.v[e] - zv.v[e];
       xv.v[e] = xv.v[e] - sv.v[e];
-      acc[0] = fmax(acc[0], fabs((double)sv.v[e]));
+      acc[0] = pg_maxn(acc[0], fabs((double)sv.v[e]));
       if constexpr (GKIND == PG_G_NORML1) acc[2] += fabs((double)zv.v[e]);
     }
     st<T, N>(x, i, xv);  // re-read by the next iteration: regular store

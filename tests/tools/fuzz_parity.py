@@ -155,6 +155,15 @@ def one_case(seed):
         # (one- and two-row problems make the line-search test an exact tie in exact arithmetic; so does ONE variable: the
         # estimated 1 / L is then exact and f(z) equals its quadratic model -- seed 51461: the device accepts gamma and is done
         # at k = 2, the oracle halves it and takes 40 iterations to the same z, 2e-9 apart)
+        # A run the OPTIONS made diverge (minimum_gamma above the stable step: the search ends on fb_tools.jl:46's second condition with
+        # a step that is too long, the iterates grow until they overflow) has no solution to compare -- but it must not look CONVERGED:
+        # norm(res, Inf) of an iterate with NaN is NaN in the reference (Julia's max propagates it), the stopping rule stays false and
+        # the loop runs to maxit.  The device's max reductions propagate NaN for that reason (pg_maxn); here: the same k, nothing else.
+        diverged = not np.isfinite(F_o) or F_o > 1e3 * max(F_start, 1e-30)
+        if diverged:
+            if k != k_o:
+                fails.append((solver, f"diverged run: k={k} k_cpu={k_o} (the device must not stop where the reference does not)", ""))
+            continue
         exact_k = dtype == np.float64 and mode != "adaptive_regret" and solver != "batched" and m > 2 and n > 1
         ok_k = (k == k_o) if exact_k else True
         if solver == "batched" and dtype == np.float64 and k < maxit:
