@@ -40,6 +40,13 @@ inline size_t vec_bytes(const pg_iter* it) {
   return (size_t)pg_round_up((int64_t)((size_t)(it->n > 0 ? it->n : 1) * pg_sizeof(it->dtype)), 256);
 }
 
+// norm(res, Inf) as the stopping rule sees it (forward_backward.jl:126): a state whose <grad f(x), res> is NaN has not converged, whatever
+// its res says.  After an overflow the one-read iteration can sit at x = z = 0 with a NaN gradient (its residual A x - b is carried
+// along, not recomputed from x as in the reference: NaN stays), y = NaN, z = prox(NaN) = 0, res = 0 -- and "stop" (found by the
+// option-drawing fuzzer of round 6 on runs whose minimum_gamma forces a diverging step).  NaN / gamma <= tol is false: such a run goes
+// on to maxit like the reference's, which cycles through overflow and restart without ever meeting the rule.
+static inline double res_inf_guarded(double res_inf, double dot_gr) { return dot_gr != dot_gr ? dot_gr : res_inf; }
+
 // epilogue + read back {g_z, res_inf, <grad,res>, ||res||^2} and f (slot 0) in one copy
 template <typename T>
 pg_status epilogue_and_read(pg_iter* it, bool read_f) {
@@ -51,7 +58,7 @@ pg_status epilogue_and_read(pg_iter* it, bool read_f) {
   PG_TRY(pg_read_scalars(c, PG_S_F, 5));
   if (read_f) it->f_x = Arith<T>::r(c->hscal[PG_S_F]);
   it->g_z = Arith<T>::r(c->hscal[PG_S_GZ]);
-  it->res_inf = Arith<T>::r(c->hscal[PG_S_RESINF]);
+  it->res_inf = res_inf_guarded(Arith<T>::r(c->hscal[PG_S_RESINF]), c->hscal[PG_S_DOT]);
   it->dot_gr = Arith<T>::r(c->hscal[PG_S_DOT]);
   it->res_sq = Arith<T>::r(c->hscal[PG_S_RESSQ]);
   return PG_OK;
@@ -183,7 +190,7 @@ pg_status read_sweep_scalars(pg_iter* it) {
   pg_ctx* c = it->ctx;
   PG_TRY(pg_read_scalars(c, PG_S_F, PG_S_COUNT));
   it->g_z = Arith<T>::r(c->hscal[PG_S_GZ]);
-  it->res_inf = Arith<T>::r(c->hscal[PG_S_RESINF]);
+  it->res_inf = res_inf_guarded(Arith<T>::r(c->hscal[PG_S_RESINF]), c->hscal[PG_S_DOT]);
   it->dot_gr = Arith<T>::r(c->hscal[PG_S_DOT]);
   it->res_sq = Arith<T>::r(c->hscal[PG_S_RESSQ]);
   it->sp_f = Arith<T>::r(c->hscal[PG_S_FNEXT + it->sp_slot]);
@@ -607,7 +614,7 @@ pg_status pg_iter_run_batched(pg_iter* it, int64_t k_start, int64_t maxit, doubl
     } else
       it->f_x = f32 ? (double)(float)c->hscal[PG_S_F] : c->hscal[PG_S_F];
     it->g_z = f32 ? (double)(float)c->hscal[PG_S_GZ] : c->hscal[PG_S_GZ];
-    it->res_inf = f32 ? (double)(float)c->hscal[PG_S_RESINF] : c->hscal[PG_S_RESINF];
+    it->res_inf = res_inf_guarded(f32 ? (double)(float)c->hscal[PG_S_RESINF] : c->hscal[PG_S_RESINF], c->hscal[PG_S_DOT]);
     it->dot_gr = f32 ? (double)(float)c->hscal[PG_S_DOT] : c->hscal[PG_S_DOT];
     it->res_sq = f32 ? (double)(float)c->hscal[PG_S_RESSQ] : c->hscal[PG_S_RESSQ];
   }

@@ -612,7 +612,7 @@ __device__ void solver_loop(const SmallParams<T>& p, Ops& ops) {
   };
   auto set_epilogue = [&]() {
     g_z = (T)e4[0];
-    res_inf = (T)e4[1];
+    res_inf = e4[2] != e4[2] ? (T)e4[2] : (T)e4[1];  // (a NaN <grad, res> is not a converged state: pg_iter.hip::res_inf_guarded)
     dot_gr = (T)e4[2];
     res_sq = (T)e4[3];
   };

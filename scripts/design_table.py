@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Write the "Measured" table of DESIGN.md from the bench lines under profiles/ (run after
-scripts/publish_round5_profiles.sh): the table is transcribed by a program, not by hand.  Every line is taken from the NEWEST
-round that collected it (profiles/r5_<name>, else r4_, else r3_); the source column names the file actually used.
+scripts/publish_round6_profiles.sh): the table is transcribed by a program, not by hand.  Every line is taken from the NEWEST
+round that collected it (profiles/r6_<name>, else r5_, r4_, r3_); the source column names the file actually used, and the
+rounds used are printed in the table's first line.
     python scripts/design_table.py           print the table
     python scripts/design_table.py --apply   replace the block between the <!-- measured:begin/end --> markers of DESIGN.md"""
 import json
@@ -18,7 +19,7 @@ USED = {}
 
 def pick(name):
     """the newest round that collected <name>"""
-    for rnd in ("r5", "r4", "r3"):
+    for rnd in ("r6", "r5", "r4", "r3"):
         if os.path.exists(os.path.join(P, f"{rnd}_{name}")):
             USED[name] = rnd
             return f"{rnd}_{name}"
@@ -110,7 +111,7 @@ def main():
             agg = t["value"] * cfg["m"] * cfg["n"] * 4 / 1e12
             add(f"row layout, 2 processes x {nrows} rows on this device: top-level record (`row_layout` = {cfg.get('row_layout')}) / the two-sweep record it replaced",
                 f"**{t['value']:.1f}** / {two.get('value', float('nan')):.1f}", f"sweep {t['roofline']['avg_launch_ms']:.2f} ms per rank",
-                f"{agg:.2f} TB/s (A per iteration, both ranks)", f"{agg / 8:.3f}", src(f"bench_{key}.json") + ", `r5_row_team_latency_sweep.md`")
+                f"{agg:.2f} TB/s (A per iteration, both ranks)", f"{agg / 8:.3f}", src(f"bench_{key}.json") + ", `r6_row_team_latency_sweep.md`")
     except (SystemExit, KeyError):
         pass
     lf, la, l6 = line("r3_bench_long_131072.json"), line("r3_bench_long_131072_adaptive.json"), line("r3_bench_long_65536.json")
