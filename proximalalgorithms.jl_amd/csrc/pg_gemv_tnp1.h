@@ -331,6 +331,15 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     if (!(a.dbg & 16))  // timing experiment: no output stores
 #endif
     if (k == ncols / C - 1) {  // the chunk's last step: whole lines
+#ifdef PG_TNT_EXPERIMENT
+      if (valid && (a.dbg & 1024)) {  // timing experiment: the outputs as non-temporal stores
+        __builtin_nontemporal_store(out_g, &a.g_out[j]);
+        __builtin_nontemporal_store(out_y, &a.y[j]);
+        __builtin_nontemporal_store(out_z, &a.z_new[j]);
+        __builtin_nontemporal_store(out_r, &a.res[j]);
+        if (a.v_out != nullptr) __builtin_nontemporal_store(out_v, &a.v_out[j]);
+      } else
+#endif
       if (valid) {
         a.g_out[j] = out_g;
         a.y[j] = out_y;

@@ -159,7 +159,7 @@ def one_case(seed):
         # a step that is too long, the iterates grow until they overflow) has no solution to compare -- but it must not look CONVERGED:
         # norm(res, Inf) of an iterate with NaN is NaN in the reference (Julia's max propagates it), the stopping rule stays false and
         # the loop runs to maxit.  The device's max reductions propagate NaN for that reason (pg_maxn); here: the same k, nothing else.
-        diverged = not np.isfinite(F_o) or F_o > 1e3 * max(F_start, 1e-30)
+        diverged = not np.isfinite(F_o) or F_o > 1e3 * max(F_start, 1e-30) or not np.isfinite(F) or F > 1e3 * max(F_start, 1e-30)  # (either run)
         if diverged:
             if k != k_o:
                 fails.append((solver, f"diverged run: k={k} k_cpu={k_o} (the device must not stop where the reference does not)", ""))
