@@ -115,9 +115,6 @@ __global__ __launch_bounds__(WPB * 64) void gemv_tnw_kernel(TNArgs<T> a) {
       zj = yj;
     const T rj = xj - zj;                                     // :120 / :142
     const T vj = valid ? (a.v_is_res ? rj : zj + a.beta * (zj - zo)) : T(0);      // fast_forward_backward.jl:135 of the next iteration
-#ifdef PG_TNT_EXPERIMENT
-    if (!(a.dbg & 16))  // timing experiment: no output stores
-#endif
     if (lead && valid) {
       a.g_out[j] = g;
       a.y[j] = yj;
@@ -204,9 +201,6 @@ pg_status launch_tnw(pg_mat* A, TNArgs<T>& a, int* blocks_out) {
   PG_TRY(ensure_partials(A, (int)blocks));
   a.partials = (T*)A->partials;
   *blocks_out = (int)blocks;
-#ifdef PG_TNT_EXPERIMENT
-  a.dbg = env_int("PG_TNT_DBG", 0);
-#endif
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   hipLaunchKernelGGL((gemv_tnw_kernel<T, U, C, WPB, DB>), dim3((unsigned)blocks), dim3(WPB * 64), 0, c->stream, a);
   PG_LAUNCH_CHECK();

@@ -7,10 +7,10 @@
 #                                       the `not gpu` tests that call into the library (symbol table, argument validation,
 #                                       no-CPU-fallback errors, the host-side Nesterov sequences, bench.py without a GPU)
 #                                       run against it with the sanitizer runtime preloaded into python
-# Usage: scripts/sanitize_host.sh [log]      (default log: profiles/r5_host_sanitizers.log; exit code 0 = clean)
+# Usage: scripts/sanitize_host.sh [log]      (default log: profiles/r6_host_sanitizers.log; exit code 0 = clean)
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-LOG="${1:-$ROOT/profiles/r5_host_sanitizers.log}"
+LOG="${1:-$ROOT/profiles/r6_host_sanitizers.log}"
 WORK="$(mktemp -d /tmp/pg_asan.XXXXXX)"
 trap 'rm -rf "$WORK"' EXIT
 export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=97"   # (python itself leaks by design)

@@ -83,6 +83,7 @@ def one_case(seed):
         kw["increase_gamma"] = dtype(1.01)
     okw = dict(kw)  # the CPU restatement's keywords (sequences are objects of its own module)
     opt_desc = ""
+    mg_above = False
     if OPTIONS:
         ro = np.random.default_rng(seed + 2_000_003)
         if mode != "fixed":
@@ -91,6 +92,7 @@ def one_case(seed):
             pick = ro.random()
             # 1e-7 (default) | reachable only by a long search | above 1 / Lf: the search ends on the second condition
             mg = dtype(1e-7) if pick < 0.4 else (dtype(0.02 / float(Lf)) if pick < 0.7 else dtype(float(ro.choice([1.5, 3.0, 8.0])) / float(Lf)))
+            mg_above = pick >= 0.7  # above 1 / Lf: the step may be forced too long
             kw["minimum_gamma"] = okw["minimum_gamma"] = mg
             opt_desc += f" reduce_gamma={float(rg)} minimum_gamma={float(mg):.3g}"
         if fast:
@@ -160,6 +162,8 @@ def one_case(seed):
         # norm(res, Inf) of an iterate with NaN is NaN in the reference (Julia's max propagates it), the stopping rule stays false and
         # the loop runs to maxit.  The device's max reductions propagate NaN for that reason (pg_maxn); here: the same k, nothing else.
         diverged = not np.isfinite(F_o) or F_o > 1e3 * max(F_start, 1e-30) or not np.isfinite(F) or F > 1e3 * max(F_start, 1e-30)  # (either run)
+        # ... and a run held at a step above 1 / Lf that never met the stopping rule oscillates without blowing up: not a solution either
+        diverged = diverged or (mg_above and k_o >= maxit)
         if diverged:
             if k != k_o:
                 fails.append((solver, f"diverged run: k={k} k_cpu={k_o} (the device must not stop where the reference does not)", ""))
