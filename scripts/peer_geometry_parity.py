@@ -92,6 +92,16 @@ CASES = [
     (["--m", "2048", "--n", "1024", "--dtype", "f64", "--ranks", "8"], "default"), # 8 x 256 rows of Float64: U = 2, C = 2, two granules per value -> 32
     (["--m", "2048", "--n", "1024", "--dtype", "f64", "--ranks", "16"], "default"),# 16 x 128 rows: U = 1 -> 64
     (["--m", "16384", "--n", "1024", "--dtype", "f64", "--ranks", "16", "--g", "l1w"], "default"),  # 16 x 1024 rows: U = 8 -> 64
+    # one post per two steps (PAIR) in every shape of the pair's slot: C = 2 / C = 4 / Float64 (8 granules per device), an odd step count, the injector
+    (["--m", "4096", "--n", "8192"], "2:2:2:2:4:1:1:1:1"),
+    (["--m", "4096", "--n", "8193", "--delay-ns", "5000"], "2:2:2:2:4:1:1:1:1"),
+    (["--m", "4096", "--n", "8192", "--ranks", "4", "--tune", "PAIR=1"], "default"),                 # U = 4, C = 4: 8 granules per device and pair
+    (["--m", "16384", "--n", "4096", "--ranks", "8", "--tune", "PAIR=1"], "default"),                # 8 x 4 = 32 polling lanes
+    (["--m", "32768", "--n", "1024", "--ranks", "16", "--tune", "PAIR=1"], "default"),               # 16 x 4 = 64
+    (["--m", "2048", "--n", "4096", "--dtype", "f64", "--tune", "PAIR=1", "--adaptive"], "default"), # Float64: 8 granules per device and pair
+    (["--m", "2048", "--n", "1024", "--dtype", "f64", "--ranks", "8", "--tune", "PAIR=1"], "default"),# 8 x 8 = 64
+    (["--m", "2048", "--n", "1024", "--dtype", "f64", "--ranks", "16", "--tune", "PAIR=1"], "default"),# 16 devices: the pair does not fit 64 lanes -> one post per step
+    (["--m", "4096", "--n", "8192", "--tune", "AHEAD=2", "--g", "l1w"], "default"),
     (["--m", "4096", "--n", "8192", "--g", "box"], "default"),
     (["--m", "4096", "--n", "8192", "--g", "boxv", "--adaptive"], "default"),
 ]

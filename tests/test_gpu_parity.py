@@ -886,6 +886,11 @@ def test_team_sweep_refused_at_launch_leaves_the_single_sweep_mode(pa, team_faul
     (["--m", "4096", "--n", "8192", "--then-n", "700"], dict(second=True)),    # a second matrix on the same contexts: another ring layout
     (["--m", "5000", "--n", "1001", "--ranks", "3", "--dtype", "f64"], dict(tol=1e-11)),  # ragged: 1667 / 1667 / 1666 rows, odd column count
     (["--m", "4096", "--n", "8192", "--batched"], dict(batched=True)),          # + the in-library batched loop (one read-back per four iterations)
+    # round 6: the fewest-transactions geometry through the run-time knob (pg_ctx_row_team_tune, no PG_TUNE): one post per two steps
+    (["--m", "4096", "--n", "8193", "--tune", "PAIR=1"], dict(geometry="PAIR=1")),                      # odd step count per workgroup: a last step without a partner
+    (["--m", "16384", "--n", "4096", "--ranks", "8", "--tune", "PAIR=1,SPIN=4194304"], dict(geometry="PAIR=1 AHEAD=1 SPIN=4194304")),
+    (["--m", "2048", "--n", "4096", "--dtype", "f64", "--ranks", "4", "--adaptive", "--tune", "PAIR=1"], dict(tol=1e-11, adaptive=True, geometry="PAIR=1")),
+    (["--m", "4096", "--n", "8192", "--tune", "AHEAD=2"], dict(geometry="AHEAD=0")),                     # the poll in its own step
     # block lengths off the powers of two: U = ceil(row groups of the longest block / 4) exactly (2049 + 2048 rows: 9 row groups, U = 3;
     # 21 -> U = 6; 37 -> U = 10; Float64 43 -> U = 11), the two ranks holding blocks of different length
     (["--m", "4097", "--n", "257"], dict()),
@@ -918,6 +923,8 @@ def test_row_team_iterates_match_oracle_at_one_read_of_A(pa, args, checks):
     d = json.loads(out.stdout.splitlines()[-1])
     assert d["team"] and d["ranks_agree_bitwise"], d
     assert all(v == "ok" for v in d["selftest"]), d["selftest"]  # pg_ctx_row_team_selftest: every rank saw 1 + 2 + ... + N
+    if checks.get("geometry"):  # the knobs that were in force, as the library reports them for its last sweep
+        assert all(checks["geometry"] in g_ and "K1=1" in g_ for g_ in d["geometry"]), d["geometry"]
     tol = checks.get("tol", 1e-5)
     fault = checks.get("fault_step")
     for rows in d["steps"]:

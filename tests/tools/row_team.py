@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--delay-ns", type=int, default=-1,
                     help="latency injector (pg_ctx_test_team_fault kind 2): the sweep's DELAY form, a step's granules accepted only "
                          "this many nanoseconds after they were stored (0: the injector's own cost; -1: off)")
+    ap.add_argument("--tune", default="", help='run-time knobs of the row-team sweep for every rank, through pg_ctx_row_team_tune (no PG_TUNE): "PAIR=1,SPIN=4194304"')
     ap.add_argument("--solo", action="store_true",
                     help="--bench --ranks 1: a team of ONE rank (pg_ctx_test_team_fault kind 4) -- the sweep exchanges its granules with itself, the "
                          "kernel runs alone on the device: for rocprofv3 --pmc, which serialises kernels")
@@ -124,6 +125,10 @@ def main():
             sync.wait(timeout=120)
             if r == 0 and not args.no_team:
                 pa.row_team_in_process(ctxs, max_wgs)
+            if args.tune and not args.no_team:
+                from proximalalgorithms.jl_amd.sharding import row_team_knobs_from_env
+
+                pa.row_team_tune(ctx, **row_team_knobs_from_env(args.tune))
             sync.wait(timeout=120)
             selftest = None
             if not args.no_team:  # one scalar exchange through the inboxes: the ranks' contributions 1 + 2 + ... + N
@@ -162,7 +167,7 @@ def main():
                     second_dz.append(float(np.max(np.abs(s.z.numpy() - ref2[k])) / max(1.0, float(np.max(np.abs(ref2[k]))))))
                 second_dz = {"max_dz_rel": max(second_dz), "a_passes": int(it2.counters.get("a_passes", 0)),
                              "fallbacks": int(it2.counters.get("sweep_fallbacks", 0))}
-            results[r] = (rows, zs, comm.calls[r], second_dz, batched, selftest)
+            results[r] = (rows, zs, comm.calls[r], second_dz, batched, selftest, None if args.no_team else pa.row_team_geometry(ctx)[0])
         except BaseException as e:  # noqa: BLE001 -- reported in the JSON document, the other threads are released
             import traceback
 
@@ -186,7 +191,7 @@ def main():
                       "ranks_agree_bitwise": bool(same), "fallback_flag": _lib.PG_FLAG_SWEEP_FALLBACK,
                       "allreduce_calls": [results[r][2] for r in range(N)], "steps": [results[r][0] for r in range(N)],
                       "second": [results[r][3] for r in range(N)], "batched": [results[r][4] for r in range(N)],
-                      "selftest": [results[r][5] for r in range(N)]}))
+                      "selftest": [results[r][5] for r in range(N)], "geometry": [results[r][6] for r in range(N)]}))
 
 
 def bench(args):
@@ -225,6 +230,10 @@ def bench(args):
                 _l.call("pg_ctx_test_team_fault", ctx.handle, 1, 4)
             if r == 0 and not args.no_team:
                 pa.row_team_in_process(ctxs, max_wgs)
+            if args.tune and not args.no_team:
+                from proximalalgorithms.jl_amd.sharding import row_team_knobs_from_env
+
+                pa.row_team_tune(ctx, **row_team_knobs_from_env(args.tune))
             sync.wait(timeout=300)
             if args.delay_ns >= 0 and not args.no_team:
                 from proximalalgorithms.jl_amd import _lib
