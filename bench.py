@@ -749,6 +749,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
     passes0 = iteration.counters.get("a_passes", 0)
     comm = P["comm"]
     calls0, elems0 = (getattr(comm, "calls", 0), getattr(comm, "elements", 0)) if comm is not None else (0, 0)
+    team_stats0 = pa.row_team_stats(ctx) if P.get("row_teams") else None  # (the telemetry counts since pg_ctx_set_row_team: the record reports ITS share)
     ctx.profile(kernel_events != "none", kernels=None if kernel_events == "all" else ("gemv_n_partial", "gemv_t", "gemv_tn"))
     ctx.profile_reset()
     D.barrier()
@@ -854,7 +855,7 @@ def run_ffb(pa, ctx, D, P, mode, sweeps, steps, warmup, kernel_events, workload_
         "roofline": roofline,
     }
     if P.get("row_teams"):  # how the granule exchange went (sweeps, waves that had to wait, polls spent waiting), this rank
-        rec["config"]["row_team_stats"] = pa.row_team_stats(ctx)
+        rec["config"]["row_team_stats"] = {k_: v - team_stats0.get(k_, 0) for k_, v in pa.row_team_stats(ctx).items()}  # the timed steps (and the sustain window)
         # every knob that was in force, as the library reports it for its last sweep ("W=1 U=8 C=2 LAG=2 LAGR=2 PF=2 WGS=4 K1=1 PAIR=0
         # SPIN=2097152 WG=1024"), and the share of wave-steps that did not find their granules at the first look
         geom_text, geom = pa.row_team_geometry(ctx)
