@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-/* Bumped whenever an exported signature, a struct layout the host sees, or the set of exports changes (round 5: 2, then 3 with pg_mat_fused_tn_trio; round 6: 4 with pg_ctx_row_team_tune / _geometry --
+/* Bumped whenever an exported signature, a struct layout the host sees, or the set of exports changes (round 5: 2, then 3 with pg_mat_fused_tn_trio; round 6: 4 with pg_ctx_row_team_tune / _geometry / pg_mat_mul_multi --
  * rounds 3 and 4 added exports and fields under version 1).  Hosts compare pg_abi_version() with the value THEY were written against at
  * load time (Python: _lib.load; Julia: __init__) and refuse a stale or mismatched build with one clear message instead of a
  * missing symbol at some later call -- PG_LIB_PATH / PROXGRAD_HIP_LIB make pointing at another build easy. */
@@ -234,6 +234,11 @@ pg_status pg_mat_info(const pg_mat* A, int64_t* m, int64_t* n, int64_t* ld, int3
 /* y = A x  (mul!(y, A, x)) and g = A' r  (mul!(g, A', r)) -- the two GEMV orientations on the
  * column-major store; used by LeastSquares and (later) PANOC's `mul!` with A: panoc.jl:150-190 */
 pg_status pg_mat_mul(pg_mat* A, const void* x, void* y);
+/* ys[k] = A xs[k] for nv <= 3 vectors on ONE read of A, each ys[k] bit-identical to pg_mat_mul's (the same multiply-adds in the same
+ * order): the step-size search of src/utilities/fb_tools.jl:46-55 forms `mul!(Az, A, z)` once per halving of gamma, and its next
+ * candidates gamma / 2, gamma / 4, gamma / 8 differ in z only -- their images are taken together, the decisions stay the reference's.
+ * PG_ERR_UNSUPPORTED for sharded operators and below 16 row groups (4096 Float32 / 2048 Float64 rows): one product at a time there. */
+pg_status pg_mat_mul_multi(pg_mat* A, int32_t nv, const void* const* xs, void* const* ys);
 pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
 /* The single sweep for x -> f(A x) compositions (PANOC: panoc.jl:186, :199-201, and the `mul!(Az, A, z)` of the next line
  * search, fb_tools.jl:43): for a caller-supplied m-vector r (= grad f(A x)),

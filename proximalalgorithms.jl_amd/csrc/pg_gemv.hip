@@ -101,6 +101,74 @@ __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const T* __restrict
   }
 }
 
+// Pass N for up to THREE vectors on ONE read of A: y_k = A x_k, k < 3 (pg_mat_mul_multi).  The step-size search of
+// fb_tools.jl:46-55 forms A z once per halving of gamma; its candidates gamma / 2, gamma / 4, gamma / 8 differ in the n-vector z
+// only, so their images can be taken together.  This is gemv_n_partial_kernel<T, 4, 2, 1> (the plan of every matrix of >= 16 row
+// groups) with three x and three accumulator sets: per vector the SAME multiply-adds in the SAME order over the same slots, so each
+// y_k is bit-identical to pg_mat_mul's -- the search takes the decisions it would have taken one product at a time.
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_n3_partial_kernel(const T* __restrict__ A, int64_t ld, int64_t n, int n_rowgroups, int n_tile_groups,
+                                                              int S, const T* __restrict__ x0, const T* __restrict__ x1,
+                                                              const T* __restrict__ x2, T* __restrict__ partials, int64_t part_stride) {
+  using V = typename VecOf<T>::type;
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int R = 4, U = 2, TB = 4;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tb = wave % TB;
+  const int tg = (int)(blockIdx.x % (unsigned)n_tile_groups);
+  const int64_t slot = blockIdx.x / (unsigned)n_tile_groups;
+  const int rg0 = (tg * TB + tb) * R;
+  const int r_eff = max(0, min(R, n_rowgroups - rg0));
+  if (!(slot < S && r_eff > 0)) return;
+  V acc[3][R];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[k][r] = (V)(T(0));
+  }
+  const int64_t ncb = (n + U - 1) / U;
+  const T* __restrict__ a_base = A + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
+  for (int64_t cb = slot; cb < ncb; cb += S) {
+    const int64_t j0 = cb * U;
+    T xs[3][U];
+    int64_t jc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = j0 + u;
+      jc[u] = j < n ? j : n - 1;
+      const T v0 = x0[jc[u]], v1 = x1[jc[u]], v2 = x2[jc[u]];
+      xs[0][u] = j < n ? v0 : T(0), xs[1][u] = j < n ? v1 : T(0), xs[2][u] = j < n ? v2 : T(0);
+    }
+    V a[U][R];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r < r_eff) a[u][r] = nt_load(reinterpret_cast<const V*>(a_base + jc[u] * ld + r * (WAVE * VEC)));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (r < r_eff) acc[k][r] += a[u][r] * xs[k][u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    T* __restrict__ p = partials + (int64_t)k * part_stride + slot * ld + (int64_t)rg0 * (WAVE * VEC) + lane * VEC;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < r_eff) *reinterpret_cast<V*>(p + r * (WAVE * VEC)) = acc[k][r];
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // pass T: g[j] = sum_{i in row chunk} A[i, j] * r[i]
 // r chunk staged in LDS; each wave streams C adjacent columns, UR row groups per step.
@@ -346,6 +414,37 @@ pg_status gemv_n(pg_mat* A, const T* x, const T* b, T* y, int64_t y_len, bool wi
                        (const T*)A->partials, A->ld, A->m, p.S_eff, b, y, y_len, 0.0, (double*)nullptr,
                        (unsigned*)nullptr, (double*)nullptr, (T*)nullptr, ColPack<T>{});
   PG_LAUNCH_CHECK();
+  return PG_OK;
+}
+
+// y_k = A x_k for nv <= 3 vectors in one read of A (see gemv_n3_partial_kernel); a missing third / second vector repeats the first
+template <typename T>
+pg_status gemv_n_multi(pg_mat* A, int nv, const void* const* xs, void* const* ys) {
+  pg_ctx* c = A->ctx;
+  PlanN p = plan_n(A);
+  if (pg_row_sharded(c) || pg_col_sharded(c) || A->m <= 0 || A->n <= 0 || !(p.R == 4 && p.U == 2 && p.TW == 1)) {
+    pg_set_error("the multi-vector product needs an unsharded matrix of at least 16 row groups (its pass-N plan is R=%d U=%d TW=%d)", p.R, p.U, p.TW);
+    return PG_ERR_UNSUPPORTED;
+  }
+  PG_TRY(ensure_partials(A, 3 * p.S_eff));
+  const int64_t stride = (int64_t)p.S_eff * A->ld;
+  const unsigned blocks = (unsigned)((int64_t)p.n_tile_groups * p.S);
+  const T* x[3] = {(const T*)xs[0], (const T*)xs[nv > 1 ? 1 : 0], (const T*)xs[nv > 2 ? 2 : 0]};
+  {
+    pg_prof_scope prof(c, PG_K_GEMV_N);
+    hipLaunchKernelGGL((gemv_n3_partial_kernel<T>), dim3(blocks), dim3(256), 0, c->stream, (const T*)A->data, A->ld, A->n, p.n_rowgroups,
+                       p.n_tile_groups, p.S, x[0], x[1], x[2], (T*)A->partials, stride);
+    PG_LAUNCH_CHECK();
+  }
+  int64_t fb = (A->ld + 63) / 64;
+  if (fb > 1024) fb = 1024;
+  pg_prof_scope prof(c, PG_K_GEMV_N_FINISH);
+  for (int k = 0; k < nv; ++k) {
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, false>), dim3((unsigned)fb), dim3(1024), 0, c->stream, (const T*)A->partials + k * stride, A->ld,
+                       A->m, p.S_eff, (const T*)nullptr, (T*)ys[k], A->m, 0.0, (double*)nullptr, (unsigned*)nullptr, (double*)nullptr,
+                       (T*)nullptr, ColPack<T>{});
+    PG_LAUNCH_CHECK();
+  }
   return PG_OK;
 }
 
@@ -1107,6 +1206,13 @@ pg_status pg_mat_mul(pg_mat* A, const void* x, void* y) {
   if (A->dtype == PG_F32)
     return gemv_n<float>(A, (const float*)x, nullptr, (float*)y, A->m, false, 0.0, nullptr);
   return gemv_n<double>(A, (const double*)x, nullptr, (double*)y, A->m, false, 0.0, nullptr);
+}
+
+pg_status pg_mat_mul_multi(pg_mat* A, int32_t nv, const void* const* xs, void* const* ys) {
+  PG_REQUIRE(A != nullptr && xs != nullptr && ys != nullptr, "null argument");
+  PG_REQUIRE(nv >= 1 && nv <= 3, "one to three vectors");
+  for (int k = 0; k < nv; ++k) PG_REQUIRE(xs[k] != nullptr && ys[k] != nullptr, "null vector");
+  return A->dtype == PG_F32 ? gemv_n_multi<float>(A, nv, xs, ys) : gemv_n_multi<double>(A, nv, xs, ys);
 }
 
 pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g) {

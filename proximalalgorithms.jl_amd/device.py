@@ -447,6 +447,15 @@ class HIPMatrix:
         call("pg_mat_mul", self._h, x.vp, out.vp)
         return out
 
+    def mul_multi(self, xs, outs):
+        """outs[k] = A xs[k] for up to three vectors on ONE read of A, each bit-identical to mul's (pg_mat_mul_multi); ProxGradError
+        with code PG_ERR_UNSUPPORTED where only single products exist (sharded operators, fewer than 16 row groups)"""
+        nv = len(xs)
+        xp = (C.c_void_p * nv)(*[v.vp for v in xs])
+        yp = (C.c_void_p * nv)(*[v.vp for v in outs])
+        call("pg_mat_mul_multi", self._h, nv, xp, yp)
+        return outs
+
     def fused_tn(self, r, x, gamma, g, At_r, y, z, res, Az, image_of_res=False):
         """ONE read of A: At_r = A' r ; y = x - gamma At_r ; z = prox_{gamma g}(y) ; res = x - z ; Az = A z
         (pg_mat_fused_tn) -- or, with image_of_res, Az = A res (pg_mat_fused_tn_res).  Returns (g(z), norm(res, Inf),

@@ -135,6 +135,14 @@ function LinearAlgebra.mul!(g::HIPVector{T}, At::Adjoint{T,HIPMatrix{T}}, r::HIP
     check(ccall((:pg_mat_mul_adjoint, libpg), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), parent(At).handle, r.ptr, g.ptr)); g
 end
 
+# ys[k] = A xs[k] for up to three vectors on ONE read of A (pg_mat_mul_multi; each bit-identical to mul!'s): the candidates of the
+# step-size search (fb_tools.jl:46-55) evaluated ahead
+function mul_multi!(ys::Vector{HIPVector{T}}, A::HIPMatrix{T}, xs::Vector{HIPVector{T}}) where {T}
+    xp = Ptr{Cvoid}[x.ptr for x in xs]; yp = Ptr{Cvoid}[y.ptr for y in ys]
+    GC.@preserve xp yp check(ccall((:pg_mat_mul_multi, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), A.handle, length(xs), xp, yp))
+    ys
+end
+
 # The single sweep for x -> loss(A x) terms: At_r = A'r, y = x - gamma At_r, z = prox_{gamma g}(y), res = x - z and Az = A z in
 # ONE read of A (g_kind: 0 Zero, 1 NormL1(p0 = lam), 2 IndBox(p0 = lo, p1 = hi)); returns (g(z), norm(res, Inf), dot(At_r, res),
 # norm(res)^2).  This is what lets FB / FFB / Vu-Condat / LiLin on such terms run at one read of A per iteration.

@@ -53,7 +53,7 @@ class PANOCIteration:
 
     def __init__(self, *, f=None, A=None, g=None, x0, alpha=0.95, beta=0.5, Lf=None, gamma=None, adaptive=None,
                  minimum_gamma=1e-7, max_backtracks=20, directions=None, single_sweep=True, images=True,
-                 refresh_every=0, pair_trials=True, trio_trials=True, speculate=True):
+                 refresh_every=0, pair_trials=True, trio_trials=True, speculate=True, gamma_candidates=3):
         self.f = f if f is not None else Zero()
         if A is None:
             A = _Identity()
@@ -78,6 +78,9 @@ class PANOCIteration:
         self.trio_trials = bool(trio_trials)
         # PANOCplus: its second pass over A (panocplus.jl:225) rides in the next iteration's first sweep, taken ahead (panocplus.py)
         self.speculate = bool(speculate)
+        # the step-size search (_backtrack_stepsize): up to this many candidates gamma r, gamma r^2, ... per read of A (1: the reference's
+        # one product per candidate)
+        self._gamma_multi = int(gamma_candidates) >= 3 and isinstance(A, HIPMatrix) and hasattr(A, "mul_multi")
         # A' grad f(A x) (:184), the forward-backward step (:197-199) and the A z of the next line search (fb_tools.jl:43)
         # in ONE read of A (pg_mat_fused_tn) when A is a device matrix and g one of the fused prox kinds
         self._fused_tn = bool(single_sweep) and isinstance(A, HIPMatrix) and hasattr(self.g, "g_kind") and \
@@ -143,6 +146,13 @@ class PANOCIteration:
         self._mul(Az, z)
         return False
 
+    def _gamma_buffers(self, s, k, z, Az):
+        """(y, z, res, Az) of the k-th candidate evaluated ahead by the step-size search (allocated on first use)"""
+        store = s.__dict__.setdefault("_gamma_ahead", {})
+        if k not in store:
+            store[k] = (s.y.similar(), z.similar(), s.res.similar(), Az.similar())
+        return store[k]
+
     def _backtrack_stepsize(self, s, z, g_z, Az, grad_f_Az):
         """backtrack_stepsize!  fb_tools.jl:24-63 with the linear map A and alpha = iter.alpha; z / Az / grad_f_Az
         are the forward-backward point and its images (state.z | state.xbar ...).  Returns (gamma, g_z, f_Az, f_Az_upp)."""
@@ -153,15 +163,48 @@ class PANOCIteration:
         self._take_Az(s, z, Az)  # :43
         f_Az, _ = value_and_gradient_into(self.f, Az, grad_f_Az)  # :44 (grad kept: :56-58)
         tol = R(10) * eps * (R(1) + abs(f_Az))
+        # Every halving of gamma costs the reference one product `mul!(Az, A, z)` (:52) -- a read of A -- and its candidates gamma / 2,
+        # gamma / 4, gamma / 8 differ in the n-vector z alone.  So the first halving of a search forms the next two candidates as well
+        # (two more forward-backward steps on n-vectors) and takes the three images in ONE read of A (pg_mat_mul_multi: per vector the
+        # same multiply-adds in the same order as the single product, bit-identical images); a candidate evaluated ahead is looked at
+        # only after the one before it was rejected, exactly where the reference would have formed it: the same decisions, bit for bit.
+        ahead = []  # [(gamma_k, g(z_k), (y_k, z_k, res_k, Az_k))]: candidates behind the current one whose images are already there
         while f_Az > f_Az_upp + tol and gamma >= self.minimum_gamma:  # :46
             s.Az_next_valid = False
             gamma = R(gamma * reduce_gamma)
-            s.y.axpby_(1.0, s.x, -gamma, s.At_grad_f_Ax)
-            g_z = prox_(z, self.g, s.y, gamma)
-            s.res.axpby_(1.0, s.x, -1.0, z)
+            if ahead and ahead[0][0] == gamma:  # evaluated ahead: its vectors become the state's, no read of A
+                _, g_z, (y_k, z_k, res_k, Az_k) = ahead.pop(0)
+                s.y.copy_from(y_k), z.copy_from(z_k), s.res.copy_from(res_k), Az.copy_from(Az_k)
+                self.counters["gamma_candidates_taken"] = self.counters.get("gamma_candidates_taken", 0) + 1
+            else:
+                ahead = []
+                s.y.axpby_(1.0, s.x, -gamma, s.At_grad_f_Ax)
+                g_z = prox_(z, self.g, s.y, gamma)
+                s.res.axpby_(1.0, s.x, -1.0, z)
+                g_k = gamma
+                for k in range(2 if self._gamma_multi else 0):
+                    if not g_k >= self.minimum_gamma:  # (the loop would not get to a further candidate)
+                        break
+                    g_k = R(g_k * reduce_gamma)
+                    bufs = self._gamma_buffers(s, k, z, Az)
+                    bufs[0].axpby_(1.0, s.x, -g_k, s.At_grad_f_Ax)
+                    gz_k = prox_(bufs[1], self.g, bufs[0], g_k)
+                    bufs[2].axpby_(1.0, s.x, -1.0, bufs[1])
+                    ahead.append((g_k, gz_k, bufs))
+                if ahead:
+                    try:
+                        self.A.mul_multi([z] + [b_[1] for _, _, b_ in ahead], [Az] + [b_[3] for _, _, b_ in ahead])
+                        self.counters["A_passes"] += 1
+                        self.counters["gamma_candidates_ahead"] = self.counters.get("gamma_candidates_ahead", 0) + len(ahead)
+                    except ProxGradError as e:
+                        if e.code != _lib.PG_ERR_UNSUPPORTED:
+                            raise
+                        self._gamma_multi, ahead = False, []  # single products only for this operator
+                        self._mul(Az, z)
+                else:
+                    self._mul(Az, z)
             s.res_stats = s.res_inf = None
             f_Az_upp = _f_model(s.f_Ax, s.At_grad_f_Ax, s.res, self.alpha / gamma)
-            self._mul(Az, z)
             f_Az, _ = value_and_gradient_into(self.f, Az, grad_f_Az)
             tol = R(10) * eps * (R(1) + abs(f_Az))
         if gamma < self.minimum_gamma:

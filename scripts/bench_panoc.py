@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--speculate", type=int, default=1, help="PANOCplus: 0 = two reads of A per iteration (round 4)")
     ap.add_argument("--pair-trials", type=int, default=1, help="ZeroFPR: 0 = one trial point of the line search per sweep (round 4)")
     ap.add_argument("--trio-trials", type=int, default=1, help="ZeroFPR: 0 = at most two trial points per sweep")
+    ap.add_argument("--gamma-candidates", type=int, default=3, help="1 = one product A z per candidate of the step-size search (round 5)")
     ap.add_argument("--algo", choices=["panoc", "zerofpr", "panocplus", "ffb", "ffb-generic"], default="panoc",
                     help="ffb: FastForwardBackward (adaptive) on Composed(loss, A), engine 'composed' (one read of A per "
                          "iteration); ffb-generic: the same with separate GEMV passes")
@@ -47,7 +48,8 @@ def main():
     if args.algo in newton:
         iteration = getattr(pa, newton[args.algo])(f=f, A=A, g=pa.NormL1(lam), x0=np.zeros(n, dtype), images=bool(args.images),
                                                    pair_trials=bool(args.pair_trials),
-                                                   trio_trials=bool(args.trio_trials), speculate=bool(args.speculate))
+                                                   trio_trials=bool(args.trio_trials), speculate=bool(args.speculate),
+                                                   gamma_candidates=args.gamma_candidates)
     else:
         iteration = pa.FastForwardBackwardIteration(f=pa.Composed(f, A), g=pa.NormL1(lam), x0=np.zeros(n, dtype),
                                                     engine="composed" if args.algo == "ffb" else "generic")
@@ -80,6 +82,7 @@ def main():
     out = {"metric": name % (args.loss, m, n),
            "value": args.steps / dt, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,
            "dtype": "f32", "data": "synthetic", "A_passes_per_step": passes / args.steps,
+           "A_passes_with_first_iteration": iteration.counters.get(key, 0), "gamma_candidates_ahead": iteration.counters.get("gamma_candidates_ahead", 0),
            "roofline": {"bound": "hbm", "kernels": "gemv_n_partial + gemv_t + gemv_tn",
                         "achieved": passes * m * n * 4 / (gemv_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": passes * m * n * 4 / (gemv_ms * 1e-3) / 1e9 / 8000.0,

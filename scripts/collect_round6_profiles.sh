@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6's measurements on a GPU box (run through gpurun): outputs under gpurun_out/r6/, summaries are copied into profiles/r6_* by hand
 # or by scripts/publish_round6_profiles.sh.  PMC passes are separate runs with --kernel-trace only, the program directly after `--`.
-# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench pmc newtests fuzzopt fuzzteam suite
+# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench pmc newtests startup fuzzopt fuzzteam suite
 cd "$GRAFT_REPO_ROOT" || exit 1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r6; mkdir -p $O
@@ -106,6 +106,13 @@ fi
 if want newtests; then
   timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "gamma_too_small or fuzz_differential or lbfgs or blas1 or prox_operators" > $O/pytest_new.log 2>&1; echo "rc $?" >> $O/pytest_new.log; tail -15 $O/pytest_new.log
 fi
+if want startup; then
+  # the step-size search with three candidates per read of A against one product per candidate
+  timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=8 -k "mul_multi or three_candidates or zerofpr or panoc or newton_family" > $O/pytest_startup.log 2>&1; echo "rc $?" >> $O/pytest_startup.log; tail -12 $O/pytest_startup.log
+  for algo in zerofpr panoc; do for gc in 1 3; do
+    timeout 600 python scripts/bench_panoc.py --algo $algo --steps 23 --warmup 0 --gamma-candidates $gc > $O/startup_${algo}_gc$gc.json 2> $O/startup_${algo}_gc$gc.err
+  done; done
+fi
 if want fuzzopt; then
   timeout 2400 python tests/tools/fuzz_parity.py ${FUZZ_CASES:-2000} 20000 options > $O/fuzz_options.log 2>&1; tail -12 $O/fuzz_options.log | cut -c1-600
 fi
@@ -134,3 +141,7 @@ for f in $O/solo_*.json; do [ -f "$f" ] && { echo "-- $f"; cut -c1-230 $f; }; do
 [ -f $O/geometry_parity.log ] && { grep -c "^ok\|^OK" $O/geometry_parity.log; grep "FAIL" $O/geometry_parity.log | cut -c1-300; tail -2 $O/geometry_parity.log | cut -c1-300; }
 [ -f $O/pytest_ranks.log ] && tail -4 $O/pytest_ranks.log | cut -c1-300
 [ -f $O/pytest_new.log ] && tail -4 $O/pytest_new.log | cut -c1-300
+for f in $O/startup_*.json; do [ -f "$f" ] && { echo "-- $f"; python3 -c "
+import json,sys
+d=json.load(open('$f')); print({k: d[k] for k in ('value','A_passes_per_step','A_passes_with_first_iteration','gamma_candidates_ahead','ms_per_step')}, d['final'])" 2>&1 | cut -c1-400; }; done
+[ -f $O/pytest_startup.log ] && tail -4 $O/pytest_startup.log | cut -c1-300

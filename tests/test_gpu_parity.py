@@ -2034,6 +2034,65 @@ def test_zerofpr_two_trial_points_per_sweep_follow_the_oracle(pa, trio):
 _ZFPR_PASSES = {}
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_mul_multi_images_are_bitwise_the_single_products(pa, dtype):
+    """pg_mat_mul_multi: up to three products A x_k on ONE read of A, each BIT-identical to pg_mat_mul's --
+    the step-size search (fb_tools.jl:46-55) may then take its candidates' images together and still decide as it would one product at a
+    time.  Ragged shapes (rows not a multiple of the row group, odd column counts), 1 / 2 / 3 vectors; too few row groups:
+    PG_ERR_UNSUPPORTED, which the search answers with single products."""
+    rng = np.random.default_rng(21)
+    for m, n in ((5000, 701), (3400, 33), (16384, 1500)):
+        A = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype))
+        M = pa.HIPMatrix.from_numpy(A)
+        xs = [pa.HIPVector.from_numpy(rng.standard_normal(n).astype(dtype) * dtype(10.0 ** k)) for k in range(3)]
+        singles = [M.mul(x).numpy() for x in xs]
+        assert np.allclose(singles[0], A @ xs[0].numpy(), rtol=0, atol=(1e-3 if dtype == np.float32 else 1e-10) * np.sqrt(n))
+        for nv in (1, 2, 3):
+            outs = [pa.HIPVector.zeros(m, dtype) for _ in range(nv)]
+            M.mul_multi(xs[:nv], outs)
+            for k in range(nv):
+                assert np.array_equal(outs[k].numpy(), singles[k]), (m, n, nv, k)
+    small = pa.HIPMatrix.from_numpy(np.asfortranarray(rng.standard_normal((700, 50)).astype(dtype)))
+    v = pa.HIPVector.from_numpy(rng.standard_normal(50).astype(dtype))
+    with pytest.raises(pa.ProxGradError) as e:
+        small.mul_multi([v, v], [pa.HIPVector.zeros(700, dtype) for _ in range(2)])
+    assert e.value.code == pa.PG_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("alg", ["PANOCIteration", "ZeroFPRIteration"])
+def test_step_size_search_takes_three_candidates_per_read(pa, alg):
+    """The start-up of the PANOC family: the step-size search halves gamma several times in a row and the
+    reference reads A once per halving (`mul!(Az, A, z)`, fb_tools.jl:52).  With gamma_candidates = 3 the first halving of a search
+    carries the next two candidates through the same read (pg_mat_mul_multi; a candidate is looked at only after the one before it
+    was rejected).  Float64, logistic + L1 on 6000 x 24000, adaptive: gamma, tau and the iterate BIT-identical at every iteration to
+    the run with one product per candidate, the same gamma as the oracle, and a search of k halvings costs ceil(k / 3) reads, not k."""
+    dtype = np.float64
+    rng = np.random.default_rng(4)
+    m, n = 6000, 24000
+    A = np.asfortranarray(rng.standard_normal((m, n)) / np.sqrt(m))
+    xt = np.zeros(n)
+    xt[rng.choice(n, n // 1000, replace=False)] = rng.standard_normal(n // 1000)
+    b = A @ xt + 0.01 * rng.standard_normal(m)
+    _, g0 = o.LogisticLoss(b).value_and_gradient(np.zeros(m))
+    lam = dtype(0.1 * np.max(np.abs(A.T @ g0)))
+    x0 = np.zeros(n, dtype)
+    M = pa.HIPMatrix.from_numpy(A)
+    it_3, it_1 = (getattr(pa, alg)(f=pa.LogisticLoss(b), A=M, g=pa.NormL1(lam), x0=x0, gamma_candidates=k) for k in (3, 1))
+    it_o = getattr(o, alg)(f=o.LogisticLoss(b), A=A, g=o.NormL1(lam), x0=x0)
+    sol = "xbar" if alg == "ZeroFPRIteration" else "z"
+    gammas, saved_expected = [], 0
+    for k, (s3, s1, so) in enumerate(itertools.islice(zip(it_3, it_1, it_o), 12)):
+        assert float(s3.gamma) == float(s1.gamma) and float(s3.tau) == float(s1.tau), (k, float(s3.gamma), float(s1.gamma))
+        assert float(s3.gamma) == pytest.approx(float(so.gamma), rel=1e-12), k
+        assert np.array_equal(getattr(s3, sol).numpy(), getattr(s1, sol).numpy()), k
+        gammas.append(float(s3.gamma))
+    assert gammas[-1] < gammas[0], gammas  # the search did halve
+    ahead = it_3.counters.get("gamma_candidates_ahead", 0)
+    assert ahead > 0 and it_1.counters.get("gamma_candidates_ahead", 0) == 0, (it_3.counters, it_1.counters)
+    # every candidate taken from an earlier read is one read of A the reference's count has and this one has not
+    assert it_1.counters["A_passes"] - it_3.counters["A_passes"] == it_3.counters.get("gamma_candidates_taken", 0) > 0, (it_3.counters, it_1.counters)
+
+
 def test_panocplus_second_pass_rides_in_the_next_first_sweep(pa):
     """PANOCplus reads A twice per iteration in the reference: A' grad f(A x) with the forward-backward step (panocplus.jl:202-210) and
     `mul!(state.At_grad_f_Az, adjoint(iter.A), state.grad_f_Az)` (:225), which only the stopping criterion uses (:243).  Here the
