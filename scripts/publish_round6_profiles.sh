@@ -25,14 +25,21 @@ done
   echo "# headline 16384 x 2^20 (gemv_tnm<16,2,4>), config 2 8192 x 2^18 (gemv_tnm<4,4,8>), 131072 x 131072 (gemv_tnt), 2048 x 2^20 (gemv_tnw)"
   cat $O/prof_headline_pmc.md $O/prof_config2_pmc.md $O/prof_long_pmc.md $O/prof_short_pmc.md; } > $P/r6_sweeps_pmc_fetch_write.md
 [ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json $P/pmc_traffic.json
+[ -s $O/startup_zerofpr_gc3.json ] && {
+  echo "# scripts/bench_panoc.py --algo {zerofpr,panoc} --steps 23 --warmup 0 --gamma-candidates {1,3}: config 4's instance (16384 x 10^6 f32, logistic + L1),"
+  echo "# the first 24 iterations; gc1 = one product A z per candidate of the step-size search (round 5), gc3 = three candidates per read (pg_mat_mul_multi)."
+  echo "# One box, back to back.  Same final gamma / tau / residual to the last bit: the decisions are the same."
+  for a in zerofpr panoc; do for g in 1 3; do echo "## $a gamma_candidates=$g"; line $O/startup_${a}_gc$g.json; done; done; } > $P/r6_startup_step_size_search.md
 [ -s $O/geometry_parity.log ] && cp $O/geometry_parity.log $P/r6_row_team_geometry_parity.log
 [ -s $O/gpu_suite.log ] && cp $O/gpu_suite.log $P/r6_gpu_suite_final.log
 [ -s gpurun_out/gpu_rates.json ] && cp gpurun_out/gpu_rates.json $P/r6_gpu_rates.json
+HIST=$(sed -n '/^## history/,$p' $P/r6_fuzz_campaigns.log 2>/dev/null)  # (the hand-written history below the summary lines is kept)
 {
   echo "# Randomised campaigns of round 6 (summary lines; every campaign also lists its failing cases, none below unless said)"
   [ -s $O/fuzz_options.log ] && { echo "## tests/tools/fuzz_parity.py 2000 20000 options (iterator options drawn: mf, sequences, reduce_gamma, minimum_gamma)"; grep -c "^FAIL" $O/fuzz_options.log | sed 's/^/failing cases: /'; grep "^FAIL" $O/fuzz_options.log | cut -c1-400; tail -1 $O/fuzz_options.log; }
   [ -s $O/fuzz_row_team.log ] && { echo "## tests/tools/fuzz_row_team.py 150 9000 (row teams, ranks as threads of one process)"; tail -1 $O/fuzz_row_team.log; }
-} > $P/r6_fuzz_campaigns.log
+  [ -n "$HIST" ] && { echo; echo "$HIST"; }
+} > $P/r6_fuzz_campaigns.log.new && mv $P/r6_fuzz_campaigns.log.new $P/r6_fuzz_campaigns.log
 python scripts/r6_counter_table.py > /dev/null && echo "counters: profiles/r6_peer_sweep_counters.md is written by hand around scripts/r6_counter_table.py's table"
 python scripts/r6_latency_table.py > /dev/null
 python scripts/design_table.py --apply
