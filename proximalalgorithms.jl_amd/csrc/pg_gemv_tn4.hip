@@ -137,7 +137,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   int64_t nteams = (int64_t)c->num_cu * (wgs_per_cu > 0 ? wgs_per_cu : (PARK <= 32 * 1024 ? 4 : PARK <= 48 * 1024 ? 3 : PARK <= 64 * 1024 ? 2 : 1));
   if (rt.max_wgs > 0) nteams = rt.max_wgs;
   if (rt.max_wgs < 0) nteams = nteams / -rt.max_wgs > 0 ? nteams / -rt.max_wgs : 1;  // -k: this device is shared by k members of the team
-  if (nteams > PEER_TEAMS_MAX) nteams = PEER_TEAMS_MAX;
+  if (nteams * MS > (int64_t)PEER_TEAMS_MAX * 8) nteams = (int64_t)PEER_TEAMS_MAX * 8 / MS;  // the inbox's ring space: nteams x RING x TEAM_MAX x MS granules
+  if (nteams > PG_RED_MAX_BLOCKS) nteams = PG_RED_MAX_BLOCKS;
   if (nteams > ncg) nteams = ncg;
   if (nteams < 1) nteams = 1;
   PG_TRY(grow_partials_without_free(A, (int)nteams));
@@ -165,6 +166,7 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   if (c->rteam.tune.SPIN > 0) a.spin_limit = c->rteam.tune.SPIN;
 #ifdef PG_TNT_EXPERIMENT
   a.dbg = env_int("PG_TNT_DBG", 0);
+  if (a.dbg & 2048) a.delay_ticks = (unsigned)env_int("PG_TNT_PACE", 250);
 #endif
   c->rteam.sweeps++;
   // The tags make a slot self-describing only among launches of ONE ring layout (every launch rewrites every slot it polls, so
@@ -212,7 +214,12 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
   pg_prof_scope prof(c, PG_K_GEMV_TN);
   // a plain launch: co-residency across devices is nobody's promise, the members' waits are bounded instead
   c->rteam.last = {WAVES, U, C, LAG, LAGR, PF, wgs_per_cu, K1 ? 1 : 0, PAIR ? 1 : 0, AHEAD ? 1 : 0, (int)nteams, a.spin_limit};
-  if constexpr (K1) hipLaunchKernelGGL((gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR, AHEAD>), dim3(grid), dim3(64), lds, c->stream, a);
+#ifdef PG_TNT_EXPERIMENT
+  const unsigned k1_block = (a.dbg & 2048) ? 128u : 64u;
+#else
+  const unsigned k1_block = 64u;
+#endif
+  if constexpr (K1) hipLaunchKernelGGL((gemv_tnp1_kernel<T, U, C, LAG, PF, LAGR, DELAY, PAIR, AHEAD>), dim3(grid), dim3(k1_block), lds, c->stream, a);
   else hipLaunchKernelGGL((gemv_tnt_kernel<T, U, C, WAVES, LAG, PF, true, LAGR, DELAY, AHEAD>), dim3(grid), dim3(WAVES * 64), lds, c->stream, a);
   PG_LAUNCH_CHECK();
   return PG_OK;
@@ -257,7 +264,12 @@ PeerGeom peer_geometry(int nrg, bool f64) {
 // ... of gemv_tnp1_kernel, the one-wave sweep of blocks up to 8 row groups (round 6; W = 1): (U, C, LAG, PF, LAGR)
 #define PG_TNP1_GEOMETRIES_F32 \
   PG_TNP1_CASE(1, 4, 2, 2, 2); PG_TNP1_CASE(2, 4, 2, 2, 2); PG_TNP1_CASE(3, 4, 2, 2, 2); PG_TNP1_CASE(4, 4, 2, 2, 2); \
-  PG_TNP1_CASE(5, 2, 2, 2, 2); PG_TNP1_CASE(6, 2, 2, 2, 2); PG_TNP1_CASE(7, 2, 2, 2, 2); PG_TNP1_CASE_D(8, 2, 2, 2, 2)
+  PG_TNP1_CASE(5, 2, 2, 2, 2); PG_TNP1_CASE(6, 2, 2, 2, 2); PG_TNP1_CASE(7, 2, 2, 2, 2); PG_TNP1_CASE_D(8, 2, 2, 2, 2); PG_TNP1_DENSE
+#ifdef PG_TNT_EXPERIMENT
+#define PG_TNP1_DENSE PG_TNP1_CASE(8, 1, 2, 2, 1); PG_TNP1_CASE(8, 1, 2, 2, 2); PG_TNP1_CASE(8, 1, 3, 2, 1)
+#else
+#define PG_TNP1_DENSE
+#endif
 #define PG_TNP1_GEOMETRIES_F64 \
   PG_TNP1_CASE(1, 2, 2, 2, 2); PG_TNP1_CASE(2, 2, 2, 2, 2); PG_TNP1_CASE(3, 2, 2, 2, 2); PG_TNP1_CASE(4, 2, 2, 2, 2); \
   PG_TNP1_CASE(5, 2, 2, 2, 2); PG_TNP1_CASE(6, 2, 2, 2, 2); PG_TNP1_CASE(7, 2, 2, 2, 2); PG_TNP1_CASE_D(8, 2, 2, 2, 2)

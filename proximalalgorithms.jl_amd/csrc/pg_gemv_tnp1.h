@@ -58,8 +58,21 @@ __device__ __forceinline__ void row_member_sum(T& acc, const T val) {
 // tile the next step will dot, so reading it waits for that tile too -- one of the two tiles "in flight" is then always complete
 // when the multiply-adds run, and the wave streams with half its depth.  Issued a step earlier the poll returns with a tile that
 // is needed anyway; the price is a first look one step sooner after the post (LT - 1 steps of slack instead of LT).
+#ifndef PG_TNP1_ATTR
+#ifdef PG_TNT_EXPERIMENT
+// (experiment: the C = 1 geometries are compiled for TWO waves per SIMD -- half the register file each)
+#define PG_TNP1_ATTR __attribute__((amdgpu_waves_per_eu((C == 1 ? 2 : 1), (C == 1 ? 2 : 8))))
+#else
+#define PG_TNP1_ATTR  // (kernel lab: e.g. -DPG_TNP1_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))')
+#endif
+#endif
+#ifdef PG_TNT_EXPERIMENT
+#define PG_TNP1_BLOCK 128  // (timing experiment dbg & 2048: a second wave that does the stores)
+#else
+#define PG_TNP1_BLOCK 64
+#endif
 template <typename T, int U, int C, int LAG, int PF, int LAGR, bool DELAY, bool PAIR = false, bool AHEAD = false>
-__global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
+__global__ __launch_bounds__(PG_TNP1_BLOCK) PG_TNP1_ATTR void gemv_tnp1_kernel(TNArgs<T> a) {
   using V = typename VecOf<T>::type;
   using T2 = typename Pair2<T>::type;
   constexpr int VEC = VecOf<T>::N;
@@ -78,7 +91,11 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
   static_assert(MS <= 8 && (C & (C - 1)) == 0 && C >= 1, "C a power of two, at most eight granules per member and ring slot");
   extern __shared__ __attribute__((aligned(16))) unsigned char park_raw[];
   V* const park = reinterpret_cast<V*>(park_raw);  // [LAG][C][U][64]
+#ifdef PG_TNT_EXPERIMENT
+  const int lane = threadIdx.x & 63;
+#else
   const int lane = threadIdx.x;
+#endif
   const int team = (int)blockIdx.x;
   const int member = a.peer_rank;
   const int TM = a.peer_n;
@@ -127,6 +144,42 @@ __global__ __launch_bounds__(64) void gemv_tnp1_kernel(TNArgs<T> a) {
     post_ptr += ring_off + (lane < npoll ? (size_t)member * MS + (size_t)(lane % MS) : (size_t)TM * MS + (size_t)member);
   }
   unsigned bits_even = 0;  // PAIR: this lane's granule of the even step, kept until the odd step's is there
+#ifdef PG_TNT_EXPERIMENT
+  if (threadIdx.x >= 64) {
+    // timing experiment (dbg & 2048, with 1 | 8 | 16 in the sweeping wave): a FREE-RUNNING second wave issues the sweep's stores -- one post
+    // per step, five output lines per chunk, paced by the clock at a.delay_ticks per step (values are garbage; the sweeping wave never
+    // waits).  Does the sweep keep the rate it has without stores (then the stores cost QUEUE ORDER in the sweeping wave and a writer wave
+    // fed through LDS recovers it), or does it fall back (then they cost on the memory side and nothing in the kernel helps)?
+    if (!(a.dbg & 2048)) return;
+    const int wl = (int)threadIdx.x - 64;
+    unsigned long long* wp = nullptr;
+    {
+      const int q_of_lane = wl < npoll ? wl / MS : wl - npoll;
+#pragma unroll
+      for (int q = 0; q < TEAM_MAX; ++q)
+        if (q < TM && q_of_lane == q) wp = a.peer_ring[q];
+      wp += ring_off + (wl < npoll ? (size_t)member * MS + (size_t)(wl % MS) : (size_t)TM * MS + (size_t)member);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int KCw = 1 << map.shift;
+    for (int64_t i = 0; i < cnt; ++i) {
+      while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)i * a.delay_ticks) __builtin_amdgcn_s_sleep(8);
+      if (a.dbg & 4096) continue;  // (control: the second wave is there and stores nothing)
+      if (wl < npoll_all) __hip_atomic_store(wp + slot_of(i), (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const bool chunked = i < (int64_t)map.head;
+      const int k = chunked ? (int)(i & (int64_t)(KCw - 1)) : 0, ncols = chunked ? KCw * C : C;
+      if (k == ncols / C - 1) {
+        const int64_t j = map.at(i - k) * C + min(wl, ncols - 1);
+        if (wl < ncols && j < a.n) {
+          const T v = (T)(float)i;
+          a.g_out[j] = v, a.y[j] = v, a.z_new[j] = v, a.res[j] = v;
+          if (a.v_out != nullptr) a.v_out[j] = v;
+        }
+      }
+    }
+    return;
+  }
+#endif
 
   struct Tile {
     V col[C][U];

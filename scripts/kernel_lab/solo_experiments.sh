@@ -16,6 +16,23 @@ except Exception as e:
 PY
 }
 for d in ${DBGS:-0 257 16 25}; do run dbg_$d PG_TNT_DBG=$d; done
+if [ -n "$DENSE" ]; then
+  # two sweeping waves per SIMD: C = 1 (8 KiB tiles), half the register file per wave, eight workgroups per compute unit
+  E="env PG_LIB_PATH=$PWD/build/libproxgrad_hip_exp.so PG_TUNE=1"
+  for g in "1 2 1 8" "1 2 2 8" "1 3 1 6" "1 2 1 6"; do set -- $g
+    $E PG_TNP_C=$1 PG_TNP_LAG=$2 PG_TNP_LAGR=$3 PG_TNP_WGS=$4 timeout 300 python3 tests/tools/row_team.py --m 4096 --n 3001 --ranks 2 --steps 12 2>&1 | tail -2 | cut -c1-300
+    run dense_C$1_LAG$2_LAGR$3_WGS$4 PG_TNP_C=$1 PG_TNP_LAG=$2 PG_TNP_LAGR=$3 PG_TNP_WGS=$4
+    run dense_C$1_LAG$2_LAGR$3_WGS$4_nostores PG_TNP_C=$1 PG_TNP_LAG=$2 PG_TNP_LAGR=$3 PG_TNP_WGS=$4 PG_TNT_DBG=25
+  done
+  # two ranks sharing the device (threads of one process), default against the densest
+  RT2="python3 tests/tools/row_team.py --bench --ranks 2 --m 4096 --n 1048576 --steps 20 --max-wgs -2"
+  for g in "2 2 2 4" "1 2 1 8" "2 2 2 4" "1 2 1 8"; do set -- $g
+    $E PG_TNP_C=$1 PG_TNP_LAG=$2 PG_TNP_LAGR=$3 PG_TNP_WGS=$4 $RT2 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('two ranks C=$1 LAG=$2 LAGR=$3 WGS=$4', {k: d.get(k) for k in ('it_per_s','TBps_all_ranks','late_waves','geometry','a_passes_per_step')})"
+  done
+fi
+[ -n "$ONLY_DBGS" ] && exit 0
 run pair PG_TNP_PAIR=1
 run pair_dbg16 PG_TNP_PAIR=1 PG_TNT_DBG=16
 run own_step PG_TNP_AHEAD=0
