@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6's measurements on a GPU box (run through gpurun): outputs under gpurun_out/r6/, summaries are copied into profiles/r6_* by hand
 # or by scripts/publish_round6_profiles.sh.  PMC passes are separate runs with --kernel-trace only, the program directly after `--`.
-# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench pmc newtests startup fuzzopt fuzzteam suite
+# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench pmc newtests startup fuzzopt fuzzgamma fuzzteam suite
 cd "$GRAFT_REPO_ROOT" || exit 1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r6; mkdir -p $O
@@ -115,6 +115,9 @@ if want startup; then
 fi
 if want fuzzopt; then
   timeout 2400 python tests/tools/fuzz_parity.py ${FUZZ_CASES:-2000} 20000 options > $O/fuzz_options.log 2>&1; tail -12 $O/fuzz_options.log | cut -c1-600
+fi
+if want fuzzgamma; then
+  timeout 1500 python tests/tools/fuzz_gamma_search.py ${GAMMA_CASES:-150} 31000 > $O/fuzz_gamma_search.log 2>&1; tail -6 $O/fuzz_gamma_search.log | cut -c1-400
 fi
 if want fuzzteam; then
   timeout 1500 python tests/tools/fuzz_row_team.py 150 9000 > $O/fuzz_row_team.log 2>&1; tail -5 $O/fuzz_row_team.log | cut -c1-400

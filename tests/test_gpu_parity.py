@@ -2563,6 +2563,26 @@ def test_fuzz_row_teams_on_one_gpu(pa):
     assert not bad and lost == 0, (bad, lost)
 
 
+def test_fuzz_step_size_search_three_candidates_per_read(pa):
+    """tests/tools/fuzz_gamma_search.py (150 cases in profiles/r6_fuzz_campaigns.log): random shapes on both sides of the multi-vector
+    product's range, element types, losses, g, PANOC / ZeroFPR, scales of A and minimum_gamma -- the search with three candidates per
+    read of A against one product per candidate: gamma, tau and iterate bit-identical at every iteration, reads saved = candidates
+    taken, Float64 gamma = the oracle's."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_gamma_search", os.path.join(root, "tests", "tools", "fuzz_gamma_search.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad, ahead = [], 0
+    for seed in range(31000, 31012):
+        why, label, counters = fz.one_case(seed)
+        ahead += counters.get("gamma_candidates_ahead", 0)
+        if why:
+            bad.append((label, why))
+    assert not bad and ahead > 0, (bad, ahead)
+
+
 def test_fuzz_ranks_as_processes_on_one_gpu(pa):
     """tests/tools/fuzz_bench_ranks.py: the production multi-rank path (one process per rank, IPC-mapped inboxes for row teams)
     against one rank on the same problem.  The first two cases are the campaign's finding in small: 4097 rows over two ranks are blocks of
