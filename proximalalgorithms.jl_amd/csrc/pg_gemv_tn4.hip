@@ -167,6 +167,8 @@ pg_status launch_tnp(pg_mat* A, TNArgs<T>& a, int* blocks_out, int wgs_per_cu) {
 #ifdef PG_TNT_EXPERIMENT
   a.dbg = env_int("PG_TNT_DBG", 0);
   if (a.dbg & 2048) a.delay_ticks = (unsigned)env_int("PG_TNT_PACE", 250);
+  if (a.dbg & 8192) a.delay_ticks = (unsigned)env_int("PG_TNT_FAKE", 8);
+  if (K1) a.line_cols = env_int("PG_TNT_LINE_COLS", a.line_cols);  // (experiment: chunks of 16 / 64 columns -- twice / half the output store instructions)
 #endif
   c->rteam.sweeps++;
   // The tags make a slot self-describing only among launches of ONE ring layout (every launch rewrites every slot it polls, so

@@ -249,6 +249,19 @@ __global__ __launch_bounds__(PG_TNP1_BLOCK) PG_TNP1_ATTR void gemv_tnp1_kernel(T
       if (lane < 8) __hip_atomic_store(a.peer_ring[0] + ring_off + slot_of(i) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
+    if (a.dbg & 8192) {
+      // timing experiment (solo): the LANDING traffic of a team of a.delay_ticks devices -- this device's inbox receives that many 8 * MS-byte
+      // pieces per step, each in another line (member q's piece of step i + q, as arrivals spread over time would be); bit 16384: the same
+      // bytes as ONE contiguous store (what a merged arrival would be)
+      const int fake = (int)a.delay_ticks;
+      if (a.dbg & 16384) {
+        if (lane < fake * MS) __hip_atomic_store(a.peer_ring[0] + ring_off + slot_of(i) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      for (int q = 0; q < fake; ++q)
+        if (lane < MS) __hip_atomic_store(a.peer_ring[0] + ring_off + slot_of(i + q) + (size_t)q * MS + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
     if (a.dbg & 128) {  // timing experiment: the post as a plain (cached, write-back) store
       if (lane < npoll_all) post_ptr[slot_of(i)] = word;
       return;

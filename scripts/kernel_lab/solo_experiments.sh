@@ -16,9 +16,9 @@ except Exception as e:
 PY
 }
 for d in ${DBGS:-0 257 16 25}; do run dbg_$d PG_TNT_DBG=$d; done
+E="env PG_LIB_PATH=$PWD/build/libproxgrad_hip_exp.so PG_TUNE=1"
 if [ -n "$DENSE" ]; then
   # two sweeping waves per SIMD: C = 1 (8 KiB tiles), half the register file per wave, eight workgroups per compute unit
-  E="env PG_LIB_PATH=$PWD/build/libproxgrad_hip_exp.so PG_TUNE=1"
   for g in "1 2 1 8" "1 2 2 8" "1 3 1 6" "1 2 1 6"; do set -- $g
     $E PG_TNP_C=$1 PG_TNP_LAG=$2 PG_TNP_LAGR=$3 PG_TNP_WGS=$4 timeout 300 python3 tests/tools/row_team.py --m 4096 --n 3001 --ranks 2 --steps 12 2>&1 | tail -2 | cut -c1-300
     run dense_C$1_LAG$2_LAGR$3_WGS$4 PG_TNP_C=$1 PG_TNP_LAG=$2 PG_TNP_LAGR=$3 PG_TNP_WGS=$4
@@ -31,6 +31,21 @@ if [ -n "$DENSE" ]; then
 import json,sys
 d=json.loads(sys.stdin.read()); print('two ranks C=$1 LAG=$2 LAGR=$3 WGS=$4', {k: d.get(k) for k in ('it_per_s','TBps_all_ranks','late_waves','geometry','a_passes_per_step')})"
   done
+fi
+if [ -n "$LANDING" ]; then
+  # what lands in a device's inbox in a team of N: N pieces of 16 bytes per step (dbg 8193 = never wait + N separate stores into N lines; 24577: as one store)
+  run landing_base PG_TNT_DBG=1
+  run landing_none PG_TNT_DBG=257
+  for nf in 1 2 4 8 16; do run landing_$nf PG_TNT_DBG=8193 PG_TNT_FAKE=$nf; done
+  for nf in 2 8 16; do run landing_${nf}_one_store PG_TNT_DBG=24577 PG_TNT_FAKE=$nf; done
+  run landing_base PG_TNT_DBG=1
+fi
+if [ -n "$LINES" ]; then
+  # chunks of 16 / 32 / 64 columns: the same bytes stored with twice / once / half the store instructions
+  for l in 32 64 16 32 64 16; do run line_cols_$l PG_TNT_LINE_COLS=$l; done
+  run line_cols_64_pair PG_TNT_LINE_COLS=64 PG_TNP_PAIR=1
+  run line_cols_64_nopost PG_TNT_LINE_COLS=64 PG_TNT_DBG=257
+  $E PG_TNT_LINE_COLS=64 timeout 300 python3 tests/tools/row_team.py --m 4096 --n 3001 --ranks 2 --steps 12 2>&1 | tail -1 | cut -c1-200
 fi
 [ -n "$ONLY_DBGS" ] && exit 0
 run pair PG_TNP_PAIR=1
