@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6's measurements on a GPU box (run through gpurun): outputs under gpurun_out/r6/, summaries are copied into profiles/r6_* by hand
 # or by scripts/publish_round6_profiles.sh.  PMC passes are separate runs with --kernel-trace only, the program directly after `--`.
-# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench pmc newtests startup fuzzopt fuzzgamma fuzzteam suite
+# Usage: collect_round6_profiles.sh part [part ...]   parts: parity ranks ab counters calib latency bench pmc newtests startup fuzzopt fuzzgamma fuzzteam finalfuzz suite
 cd "$GRAFT_REPO_ROOT" || exit 1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r6; mkdir -p $O
@@ -118,6 +118,24 @@ if want fuzzopt; then
 fi
 if want fuzzgamma; then
   timeout 1500 python tests/tools/fuzz_gamma_search.py ${GAMMA_CASES:-150} 31000 > $O/fuzz_gamma_search.log 2>&1; tail -6 $O/fuzz_gamma_search.log | cut -c1-400
+fi
+if want finalfuzz; then
+  # every randomised tool once more on the round's last build (seeds no earlier campaign used); one log, the summary lines are published
+  F=$O/fuzz_final.log; : > $F
+  ff() { echo "## python $*" >> $F; timeout 1500 python "$@" > $O/fuzz_final_one.log 2>&1; grep "^FAIL" $O/fuzz_final_one.log | cut -c1-400 >> $F; tail -1 $O/fuzz_final_one.log | cut -c1-300 >> $F; }
+  ff tests/tools/fuzz_parity.py 1500 1000000
+  ff tests/tools/fuzz_parity.py 300 1010000 tall
+  ff tests/tools/fuzz_newton.py 1500 1020000
+  ff tests/tools/fuzz_newton.py 600 1030000 tall
+  ff tests/tools/fuzz_newton.py 20 1040000 wide
+  ff tests/tools/fuzz_resume.py 800 1050000
+  ff tests/tools/fuzz_gamma_search.py 300 1060000
+  ff tests/tools/fuzz_row_team.py 60 1070000
+  ff tests/tools/fuzz_row_team.py 20 1080000 many
+  ff tests/tools/fuzz_row_team.py 40 1090000 pe
+  ff tests/tools/fuzz_row_team.py 40 1100000 cols
+  ff tests/tools/fuzz_bench_ranks.py 30 1110000
+  rm -f $O/fuzz_final_one.log; cat $F
 fi
 if want fuzzteam; then
   timeout 1500 python tests/tools/fuzz_row_team.py 150 9000 > $O/fuzz_row_team.log 2>&1; tail -5 $O/fuzz_row_team.log | cut -c1-400

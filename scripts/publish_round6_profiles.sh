@@ -39,6 +39,7 @@ HIST=$(sed -n '/^## history/,$p' $P/r6_fuzz_campaigns.log 2>/dev/null)  # (the h
   [ -s $O/fuzz_options.log ] && { echo "## tests/tools/fuzz_parity.py 2000 20000 options (iterator options drawn: mf, sequences, reduce_gamma, minimum_gamma)"; grep -c "^FAIL" $O/fuzz_options.log | sed 's/^/failing cases: /'; grep "^FAIL" $O/fuzz_options.log | cut -c1-400; tail -1 $O/fuzz_options.log; }
   [ -s $O/fuzz_row_team.log ] && { echo "## tests/tools/fuzz_row_team.py 150 9000 (row teams, ranks as threads of one process)"; tail -1 $O/fuzz_row_team.log; }
   [ -s $O/fuzz_gamma_search.log ] && { echo "## tests/tools/fuzz_gamma_search.py 150 31000 (step-size search of PANOC / ZeroFPR: three candidates per read of A against one product per candidate)"; grep "^FAIL" $O/fuzz_gamma_search.log | cut -c1-400; tail -1 $O/fuzz_gamma_search.log; }
+  [ -s $O/fuzz_final.log ] && { echo "## every randomised tool once more on the round's LAST build (one gpurun call; seeds no earlier campaign used)"; sed 's/^## /### /' $O/fuzz_final.log; }
   [ -n "$HIST" ] && { echo; echo "$HIST"; }
 } > $P/r6_fuzz_campaigns.log.new && mv $P/r6_fuzz_campaigns.log.new $P/r6_fuzz_campaigns.log
 python scripts/r6_counter_table.py > /dev/null && echo "counters: profiles/r6_peer_sweep_counters.md is written by hand around scripts/r6_counter_table.py's table"
