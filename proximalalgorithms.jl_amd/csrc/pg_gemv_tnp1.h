@@ -244,6 +244,25 @@ __global__ __launch_bounds__(PG_TNP1_BLOCK) PG_TNP1_ATTR void gemv_tnp1_kernel(T
     }
     const unsigned long long word = ((unsigned long long)tag_of(i) << 32) | bits;
 #ifdef PG_TNT_EXPERIMENT
+    if constexpr (G == 1 && C == 2 && !PAIR && !DELAY) {
+      if (a.dbg & 65536) {
+        // experiment: the post as SCALAR stores (one s_store_dwordx4 of this device's two granules per inbox, then s_dcache_wb) -- outside the
+        // wave's vector-memory queue; scripts/kernel_lab/scalar_store_probe.hip: such a store reaches uncached memory while the kernel runs
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const unsigned tg = __builtin_amdgcn_readfirstlane(tag_of(i));
+        u4 w;
+        w.x = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, pg_readlane(d[0], 0)));
+        w.y = tg;
+        w.z = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, pg_readlane(d[0], GL)));
+        w.w = tg;
+        for (int q = 0; q < TM; ++q) {
+          unsigned long long* dst = a.peer_ring[q] + ring_off + slot_of(i) + (size_t)member * MS;
+          asm volatile("s_store_dwordx4 %0, %1, 0x0 glc" ::"s"(w), "s"(dst) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+        return;
+      }
+    }
     if (a.dbg & (8 | 256)) return;  // timing experiment: no post
     if (a.dbg & 64) {  // timing experiment (solo): a FULL 64-byte line per post instead of 8 * MS bytes
       if (lane < 8) __hip_atomic_store(a.peer_ring[0] + ring_off + slot_of(i) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

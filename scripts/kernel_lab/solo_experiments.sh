@@ -40,6 +40,24 @@ if [ -n "$LANDING" ]; then
   for nf in 2 8 16; do run landing_${nf}_one_store PG_TNT_DBG=24577 PG_TNT_FAKE=$nf; done
   run landing_base PG_TNT_DBG=1
 fi
+if [ -n "$SPOST" ]; then
+  # the post as scalar stores (bit 65536): parity first, then the rates alone and with two ranks on the device
+  for sh in "4096 3001" "4096 70001"; do set -- $sh
+    $E PG_TNT_DBG=65536 timeout 300 python3 tests/tools/row_team.py --m $1 --n $2 --ranks 2 --steps 12 2>&1 | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+if 'error' in d: print('parity $1 x $2 scalar post: ERROR', str(d)[:400])
+else:
+    st=d['steps'][0]; print('parity $1 x $2 scalar post: ranks bitwise', d['ranks_agree_bitwise'], 'max dz/scale %.3g' % max(x['dz']/x['z_scale'] for x in st), 'flags', sorted(set(x['flags'] for x in st)), 'a_passes', [x['a_passes'] for x in st][:6], d['geometry'][0])" 2>&1 | cut -c1-400
+  done
+  for d in 0 65536 0 65536 257; do run spost_$d PG_TNT_DBG=$d; done
+  RT2="python3 tests/tools/row_team.py --bench --ranks 2 --m 4096 --n 1048576 --steps 20 --max-wgs -2"
+  for d in 0 65536 0 65536; do
+    $E PG_TNT_DBG=$d $RT2 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('two ranks dbg $d', d.get('it_per_s'), [r.get('late_waves') for r in d.get('ranks_out', [])], [r.get('fallbacks') for r in d.get('ranks_out', [])])"
+  done
+fi
 if [ -n "$LINES" ]; then
   # chunks of 16 / 32 / 64 columns: the same bytes stored with twice / once / half the store instructions
   for l in 32 64 16 32 64 16; do run line_cols_$l PG_TNT_LINE_COLS=$l; done
