@@ -237,7 +237,7 @@ pg_status pg_mat_mul(pg_mat* A, const void* x, void* y);
 /* ys[k] = A xs[k] for nv <= 3 vectors on ONE read of A, each ys[k] bit-identical to pg_mat_mul's (the same multiply-adds in the same
  * order): the step-size search of src/utilities/fb_tools.jl:46-55 forms `mul!(Az, A, z)` once per halving of gamma, and its next
  * candidates gamma / 2, gamma / 4, gamma / 8 differ in z only -- their images are taken together, the decisions stay the reference's.
- * PG_ERR_UNSUPPORTED for sharded operators and below 16 row groups (4096 Float32 / 2048 Float64 rows): one product at a time there. */
+ * PG_ERR_UNSUPPORTED for sharded operators and below 13 row groups (3073 Float32 / 1537 Float64 rows): one product at a time there. */
 pg_status pg_mat_mul_multi(pg_mat* A, int32_t nv, const void* const* xs, void* const* ys);
 pg_status pg_mat_mul_adjoint(pg_mat* A, const void* r, void* g);
 /* The single sweep for x -> f(A x) compositions (PANOC: panoc.jl:186, :199-201, and the `mul!(Az, A, z)` of the next line

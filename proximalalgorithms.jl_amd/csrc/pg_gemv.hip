@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const T* __restrict
 
 // Pass N for up to THREE vectors on ONE read of A: y_k = A x_k, k < 3 (pg_mat_mul_multi).  The step-size search of
 // fb_tools.jl:46-55 forms A z once per halving of gamma; its candidates gamma / 2, gamma / 4, gamma / 8 differ in the n-vector z
-// only, so their images can be taken together.  This is gemv_n_partial_kernel<T, 4, 2, 1> (the plan of every matrix of >= 16 row
+// only, so their images can be taken together.  This is gemv_n_partial_kernel<T, 4, 2, 1> (the plan of every matrix of >= 13 row
 // groups) with three x and three accumulator sets: per vector the SAME multiply-adds in the SAME order over the same slots, so each
 // y_k is bit-identical to pg_mat_mul's -- the search takes the decisions it would have taken one product at a time.
 template <typename T>
@@ -423,7 +423,7 @@ pg_status gemv_n_multi(pg_mat* A, int nv, const void* const* xs, void* const* ys
   pg_ctx* c = A->ctx;
   PlanN p = plan_n(A);
   if (pg_row_sharded(c) || pg_col_sharded(c) || A->m <= 0 || A->n <= 0 || !(p.R == 4 && p.U == 2 && p.TW == 1)) {
-    pg_set_error("the multi-vector product needs an unsharded matrix of at least 16 row groups (its pass-N plan is R=%d U=%d TW=%d)", p.R, p.U, p.TW);
+    pg_set_error("the multi-vector product needs an unsharded matrix of at least 13 row groups (its pass-N plan is R=%d U=%d TW=%d)", p.R, p.U, p.TW);
     return PG_ERR_UNSUPPORTED;
   }
   PG_TRY(ensure_partials(A, 3 * p.S_eff));

@@ -449,7 +449,7 @@ class HIPMatrix:
 
     def mul_multi(self, xs, outs):
         """outs[k] = A xs[k] for up to three vectors on ONE read of A, each bit-identical to mul's (pg_mat_mul_multi); ProxGradError
-        with code PG_ERR_UNSUPPORTED where only single products exist (sharded operators, fewer than 16 row groups)"""
+        with code PG_ERR_UNSUPPORTED where only single products exist (sharded operators, fewer than 13 row groups)"""
         nv = len(xs)
         xp = (C.c_void_p * nv)(*[v.vp for v in xs])
         yp = (C.c_void_p * nv)(*[v.vp for v in outs])
