@@ -1012,7 +1012,8 @@ def test_bench_default_line_carries_every_single_gpu_config(pa, bench_default_li
     assert labels == ["headline_adaptive", "config2", "config3", "config4", "config4_zerofpr", "config4_panocplus", "config5_column_block",
                       "headline_row_block_n8", "rows_2proc_two_sweeps", "rows_2proc_row_team"], labels
     ad, c2, c3, c4, zf, pp, c5c, c5r, r2, rt = d["also"]
-    assert zf["config"]["A_passes_per_step"] <= 3.0 and pp["config"]["A_passes_per_step"] <= 1.3, (zf["config"], pp["config"])
+    # (ZeroFPR: 2.09 since the step-size search takes three candidates per read, 2.22 before; a count, the same on every box)
+    assert zf["config"]["A_passes_per_step"] <= 2.2 and pp["config"]["A_passes_per_step"] <= 1.3, (zf["config"], pp["config"])
     # north_star's row layout between two PROCESSES on this device: the row team reads its blocks ONCE per iteration (IPC-mapped
     # inboxes, self-test ok, no fallback) and ends at the two-sweep iterate
     assert r2["config"]["a_passes_per_step"] == 2.0 and not r2["config"]["row_teams"]
