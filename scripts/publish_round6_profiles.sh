@@ -33,6 +33,7 @@ done
 [ -s $O/geometry_parity.log ] && cp $O/geometry_parity.log $P/r6_row_team_geometry_parity.log
 [ -s $O/gpu_suite.log ] && cp $O/gpu_suite.log $P/r6_gpu_suite_final.log
 [ -s gpurun_out/gpu_rates.json ] && cp gpurun_out/gpu_rates.json $P/r6_gpu_rates.json
+[ -s gpurun_out/bench_8rank_dry.json ] && cp gpurun_out/bench_8rank_dry.json $P/r6_bench_8rank_dry.json
 HIST=$(sed -n '/^## history/,$p' $P/r6_fuzz_campaigns.log 2>/dev/null)  # (the hand-written history below the summary lines is kept)
 {
   echo "# Randomised campaigns of round 6 (summary lines; every campaign also lists its failing cases, none below unless said)"

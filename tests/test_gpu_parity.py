@@ -1084,11 +1084,12 @@ def test_four_ranks_one_gpu_column_shards(pa):
         assert led.get(key) is not None and led[key] >= 0, (key, led)
     full, total = bench.extrapolate_ledger(eight, 16384, 1 << 20)
     print("eight-rank dry-run ledger:", led, "extrapolated to 16384 x 2^20:", full)
-    assert total < 900, (led, full)
+    assert total < 0.1 * 900, (led, full)  # (measured: 17 s extrapolated, 8.5 s as run -- a tenth of the limit is five times that)
     import json
 
+    # (the artefact goes where the box's scratch is collected from, not into the source tree: gpurun_out/ is git- and gpurun-ignored)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(root, "gpurun_out", "r5_bench_8rank_dry.json"), "w") as fh:  # (copied to profiles/ by the round's collection)
+    with open(os.path.join(root, "gpurun_out", "bench_8rank_dry.json"), "w") as fh:
         json.dump({"line": eight, "ledger": led, "extrapolated_to_16384x2^20": full, "extrapolated_total_s": total}, fh)
 
 
@@ -1657,7 +1658,9 @@ def test_panoc_at_config4_column_length_against_oracle(pa):
 def test_zerofpr_panocplus_at_config4_column_length_against_oracle(pa, alg):
     """SURVEY 8(f) row 4 at the headline column length (16384 x 32768, logistic + L1, L-BFGS(5), adaptive): the same
     criteria as PANOC above."""
-    _panoc_logistic_vs_oracle(pa, 16384, 32768, 8, alg=alg, passes_per_it=2.6)
+    # (ZeroFPR: two sweeps per iteration plus its start-up; PANOCplus: ONE since its second pass rides in the next first sweep -- a run that
+    # silently lost the speculation would read A twice per iteration and fail here)
+    _panoc_logistic_vs_oracle(pa, 16384, 32768, 8, alg=alg, passes_per_it=2.6 if alg == "ZeroFPRIteration" else 1.5)
 
 
 @pytest.mark.parametrize("alg", ["PANOC", "ZeroFPR", "PANOCplus"])
