@@ -1037,7 +1037,9 @@ def test_bench_default_line_carries_every_single_gpu_config(pa, bench_default_li
     if not d["roofline"]["frac"] > 0.6:
         d = bench_default_line(fresh=True)
     assert d["roofline"]["frac"] > 0.6, d["roofline"]
-    assert -0.10 < d["value"] / d["sustained"]["value"] - 1.0 < 0.05, (d["value"], d["sustained"])  # (measured spread over five rounds: -2 % .. +0.3 %)
+    # (measured over six rounds: -2 % .. +0.3 %.  The bound here says "not a burst figure" and leaves room for a box that throttles during the five
+    # sustained seconds; the tight comparison is REPORTED by tests/test_gpu_rates.py, like every other rate)
+    assert -0.15 < d["value"] / d["sustained"]["value"] - 1.0 < 0.10, (d["value"], d["sustained"])
 
 
 def test_four_ranks_one_gpu_column_shards(pa):

@@ -50,7 +50,8 @@ def test_default_line_rates_reported_and_above_hard_floors(bench_default_line):
         "ZeroFPR / PANOC": (zf["value"] / c4["value"], 0.40, 0.15),
         "PANOCplus / PANOC": (pp["value"] / c4["value"], 0.85, 0.40),
         "row team / two sweeps (two processes)": (rt["value"] / r2["value"], 1.8, 1.0),
-        "K steps / sustained": (d["value"] / d["sustained"]["value"], 0.90, 0.50),
+        "K steps / sustained": (d["value"] / d["sustained"]["value"], 0.97, 0.50),
+        "sustained / K steps (the K-step figure is no burst)": (d["sustained"]["value"] / d["value"], 0.97, 0.85),
     }
     for name, (v, soft, hard) in ratios.items():
         report[name] = {"value": v, "soft": soft, "hard_floor": hard}
