@@ -58,6 +58,12 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('two ranks dbg $d', d.get('it_per_s'), [r.get('late_waves') for r in d.get('ranks_out', [])], [r.get('fallbacks') for r in d.get('ranks_out', [])])"
   done
 fi
+if [ -n "$BOXID" ]; then
+  # which box is this?  clocks / power next to the sweep's rate with and without its post (boxes of the pool differ by up to 9 % on this kernel)
+  /opt/rocm/bin/rocm-smi --showclocks --showpower --showperflevel --showmemvendor 2>&1 | grep -v "^=\|^$" | cut -c1-160 | head -30
+  for d in 0 257 0 257; do run box_$d PG_TNT_DBG=$d; done
+  /opt/rocm/bin/rocm-smi --showclocks 2>&1 | grep -i "mclk\|sclk\|fclk" | cut -c1-160
+fi
 if [ -n "$LINES" ]; then
   # chunks of 16 / 32 / 64 columns: the same bytes stored with twice / once / half the store instructions
   for l in 32 64 16 32 64 16; do run line_cols_$l PG_TNT_LINE_COLS=$l; done
